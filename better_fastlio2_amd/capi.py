@@ -1,0 +1,327 @@
+"""ctypes binding of liblio_hip.so (include/lio_hip.h) plus thin Python mirrors of the reference's
+host-side objects for the LIO measurement path:
+
+    MapIndex      <-> KD_TREE<PointType> ikdtree        (include/ikd-Tree/ikd_Tree.h:225-249)
+    LioContext.measure(...)  <-> h_share_model(s, ekfom_data)   (src/laserMapping.cpp:1876-2004)
+    Esekf         <-> esekfom::esekf<state_ikfom, 12, input_ikfom>  (esekfom.hpp)
+
+There is NO CPU fallback: importing works anywhere (so that the CPU test-suite can check the ABI),
+but creating a LioContext needs a gfx950 GPU and raises LioError otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+LIO_OK = 0
+ERRORS = {-1: "LIO_ERR_INVALID_ARG", -2: "LIO_ERR_NO_DEVICE", -3: "LIO_ERR_HIP", -4: "LIO_ERR_CAPACITY",
+          -5: "LIO_ERR_NO_SCAN", -6: "LIO_ERR_NO_MAP"}
+PROF_KNN, PROF_FALLBACK, PROF_RESIDUAL, PROF_REDUCE = 0, 1, 2, 3
+PROF_NAMES = {PROF_KNN: "knn27", PROF_FALLBACK: "knn_tree", PROF_RESIDUAL: "residual", PROF_REDUCE: "reduce_final"}
+
+
+class LioError(RuntimeError):
+    pass
+
+
+class lio_config(C.Structure):
+    _fields_ = [("device", C.c_int), ("filter_size_map_min", C.c_float), ("cell_size", C.c_float),
+                ("max_scan_points", C.c_int), ("max_map_points", C.c_longlong), ("lanes_per_query", C.c_int)]
+
+
+class lio_out(C.Structure):
+    _fields_ = [("m", C.c_int), ("valid", C.c_int), ("n_unresolved", C.c_int), ("reserved", C.c_int),
+                ("res_mean", C.c_double), ("HTH", C.c_double * 144), ("HTh", C.c_double * 12),
+                ("n_candidates", C.c_ulonglong)]
+
+
+class lio_map_info(C.Structure):
+    _fields_ = [("n_points", C.c_longlong), ("n_live", C.c_longlong), ("n_cells", C.c_longlong),
+                ("table_slots", C.c_longlong), ("cell_size", C.c_float), ("downsample_size", C.c_float),
+                ("bytes_resident", C.c_longlong)]
+
+
+class lio_update_log(C.Structure):
+    _fields_ = [("n_calls", C.c_int), ("n_search", C.c_int), ("converged", C.c_int), ("last_m", C.c_int),
+                ("last_res_mean", C.c_double), ("solve_seconds", C.c_double), ("measure_seconds", C.c_double)]
+
+
+# every symbol include/lio_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_stream", "lio_synchronize",
+    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_delete_boxes", "lio_map_reconstruct",
+    "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_get_info", "lio_map_nearest_search",
+    "lio_scan_set", "lio_scan_set_device", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
+    "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_profile_reset", "lio_profile_get",
+    "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
+    "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_state_boxplus",
+    "lio_state_boxminus",
+]
+
+_lib = None
+_vp = C.c_void_p
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """Load liblio_hip.so (building it with hipcc when it is missing).  Fails loudly otherwise."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise LioError(f"{path} is missing: run `python -m better_fastlio2_amd.build` (no CPU fallback exists)")
+        _build.build()
+    L = C.CDLL(path)
+    L.lio_version.restype = C.c_char_p
+    L.lio_last_error.restype = C.c_char_p
+    L.lio_last_error.argtypes = [_vp]
+    L.lio_create.argtypes = [C.POINTER(lio_config), C.POINTER(_vp)]
+    L.lio_destroy.argtypes = [_vp]
+    L.lio_destroy.restype = None
+    L.lio_stream.argtypes = [_vp]
+    L.lio_stream.restype = _vp
+    L.lio_synchronize.argtypes = [_vp]
+    L.lio_map_build.argtypes = [_vp, _vp, C.c_longlong, C.c_int]
+    L.lio_map_build_device.argtypes = [_vp, _vp, C.c_longlong]
+    L.lio_map_add.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.lio_map_delete_boxes.argtypes = [_vp, _vp, C.c_int, C.POINTER(C.c_int)]
+    L.lio_map_reconstruct.argtypes = [_vp, _vp, C.c_longlong, C.c_int]
+    L.lio_map_size.argtypes = [_vp]
+    L.lio_map_size.restype = C.c_longlong
+    L.lio_map_validnum.argtypes = [_vp]
+    L.lio_map_validnum.restype = C.c_longlong
+    L.lio_map_flatten.argtypes = [_vp, _vp, C.c_longlong, C.POINTER(C.c_longlong)]
+    L.lio_map_get_info.argtypes = [_vp, C.POINTER(lio_map_info)]
+    L.lio_map_nearest_search.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
+    L.lio_scan_set.argtypes = [_vp, _vp, C.c_int, C.c_int]
+    L.lio_scan_set_device.argtypes = [_vp, _vp, C.c_int]
+    L.lio_measure.argtypes = [_vp, _vp, C.c_int, C.c_int, C.POINTER(lio_out)]
+    L.lio_measure_rows.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int]
+    L.lio_get_neighbors.argtypes = [_vp, _vp, _vp, _vp]
+    L.lio_get_scan_state.argtypes = [_vp, _vp, _vp, _vp]
+    L.lio_scan_size.argtypes = [_vp]
+    L.lio_profile_enable.argtypes = [_vp, C.c_int]
+    L.lio_profile_reset.argtypes = [_vp]
+    L.lio_profile_get.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    L.lio_eskf_create.restype = _vp
+    L.lio_eskf_destroy.argtypes = [_vp]
+    L.lio_eskf_destroy.restype = None
+    L.lio_eskf_init_dyn_share.argtypes = [_vp, C.c_int, _vp]
+    L.lio_eskf_change_x.argtypes = [_vp, _vp]
+    L.lio_eskf_change_P.argtypes = [_vp, _vp]
+    L.lio_eskf_get_x.argtypes = [_vp, _vp]
+    L.lio_eskf_get_P.argtypes = [_vp, _vp]
+    L.lio_eskf_update_iterated_dyn_share_modified.argtypes = [_vp, _vp, C.c_double, C.c_int, C.POINTER(lio_update_log)]
+    L.lio_state_boxplus.argtypes = [_vp, _vp]
+    L.lio_state_boxminus.argtypes = [_vp, _vp, _vp]
+    _lib = L
+    return L
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(_vp)
+
+
+def _points(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("points must be [n, >=3] float32")
+    return a
+
+
+class LioContext:
+    """One GPU-resident map + scan + measurement-model context (lio_ctx)."""
+
+    def __init__(self, filter_size_map_min: float = 0.2, max_scan_points: int = 100000,
+                 max_map_points: int = 6_000_000, device: int = 0, cell_size: float = 0.0,
+                 lanes_per_query: int = 0):
+        self.L = load()
+        cfg = lio_config(device, filter_size_map_min, cell_size, max_scan_points, max_map_points, lanes_per_query)
+        h = _vp()
+        rc = self.L.lio_create(C.byref(cfg), C.byref(h))
+        if rc != LIO_OK:
+            raise LioError(f"lio_create failed: {ERRORS.get(rc, rc)} (a gfx950 GPU is required; there is no CPU path)")
+        self.h = h
+        self.max_scan_points = max_scan_points
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lio_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int, what: str):
+        if rc != LIO_OK:
+            raise LioError(f"{what}: {ERRORS.get(rc, rc)}: {self.L.lio_last_error(self.h).decode()}")
+
+    # ---- map (KD_TREE facade) --------------------------------------------------------------------
+    def map_build(self, pts):
+        p = _points(pts)
+        self._chk(self.L.lio_map_build(self.h, _ptr(p), len(p), p.strides[0]), "lio_map_build")
+
+    def map_build_device(self, d_ptr: int, n: int):
+        self._chk(self.L.lio_map_build_device(self.h, _vp(d_ptr), n), "lio_map_build_device")
+
+    def map_add(self, pts, downsample_on: bool) -> int:
+        p = _points(pts)
+        n_added = C.c_int(0)
+        self._chk(self.L.lio_map_add(self.h, _ptr(p), len(p), p.strides[0], int(downsample_on), C.byref(n_added)),
+                  "lio_map_add")
+        return n_added.value
+
+    def map_delete_boxes(self, boxes) -> int:
+        b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+        n = C.c_int(0)
+        self._chk(self.L.lio_map_delete_boxes(self.h, _ptr(b), len(b), C.byref(n)), "lio_map_delete_boxes")
+        return n.value
+
+    def map_size(self) -> int:
+        return self.L.lio_map_size(self.h)
+
+    def map_validnum(self) -> int:
+        return self.L.lio_map_validnum(self.h)
+
+    def map_flatten(self) -> np.ndarray:
+        n = self.map_validnum()
+        out = np.zeros((max(n, 1), 3), np.float32)
+        got = C.c_longlong(0)
+        self._chk(self.L.lio_map_flatten(self.h, _ptr(out), n, C.byref(got)), "lio_map_flatten")
+        return out[:min(n, got.value)]
+
+    def map_info(self) -> dict:
+        info = lio_map_info()
+        self._chk(self.L.lio_map_get_info(self.h, C.byref(info)), "lio_map_get_info")
+        return {k: getattr(info, k) for k, _ in lio_map_info._fields_}
+
+    def nearest_search(self, queries):
+        q = _points(queries)
+        n = len(q)
+        xyz = np.full((n, 5, 3), np.nan, np.float32)
+        d = np.full((n, 5), np.inf, np.float32)
+        cnt = np.zeros(n, np.int32)
+        self._chk(self.L.lio_map_nearest_search(self.h, _ptr(q), n, q.strides[0], _ptr(xyz), _ptr(d), _ptr(cnt)),
+                  "lio_map_nearest_search")
+        return xyz, d, cnt
+
+    # ---- scan + measurement model ------------------------------------------------------------------
+    def scan_set(self, body):
+        b = _points(body)
+        self._chk(self.L.lio_scan_set(self.h, _ptr(b), len(b), b.strides[0]), "lio_scan_set")
+
+    def scan_set_device(self, d_ptr: int, n: int):
+        self._chk(self.L.lio_scan_set_device(self.h, _vp(d_ptr), n), "lio_scan_set_device")
+
+    def measure(self, state14, do_search: bool, extrinsic_est_en: bool) -> dict:
+        s = np.ascontiguousarray(state14, dtype=np.float64)
+        assert s.shape == (14,)
+        o = lio_out()
+        self._chk(self.L.lio_measure(self.h, _ptr(s), int(do_search), int(extrinsic_est_en), C.byref(o)), "lio_measure")
+        return {"m": o.m, "valid": bool(o.valid), "n_unresolved": o.n_unresolved, "res_mean": o.res_mean,
+                "HTH": np.array(o.HTH, dtype=np.float64).reshape(12, 12), "HTh": np.array(o.HTh, dtype=np.float64),
+                "n_candidates": int(o.n_candidates)}
+
+    def measure_rows(self, m: int):
+        h_x = np.zeros((max(m, 1), 12), np.float64)
+        h = np.zeros(max(m, 1), np.float64)
+        self._chk(self.L.lio_measure_rows(self.h, _ptr(h_x), _ptr(h), m, 0), "lio_measure_rows")
+        return h_x[:m], h[:m]
+
+    def neighbors(self):
+        n = self.L.lio_scan_size(self.h)
+        xyz = np.full((n, 5, 3), np.nan, np.float32)
+        d = np.full((n, 5), np.inf, np.float32)
+        cnt = np.zeros(n, np.int32)
+        self._chk(self.L.lio_get_neighbors(self.h, _ptr(xyz), _ptr(d), _ptr(cnt)), "lio_get_neighbors")
+        return xyz, d, cnt
+
+    def scan_state(self):
+        n = self.L.lio_scan_size(self.h)
+        world = np.zeros((n, 3), np.float32)
+        sel = np.zeros(n, np.uint8)
+        nv = np.zeros((n, 4), np.float32)
+        self._chk(self.L.lio_get_scan_state(self.h, _ptr(world), _ptr(sel), _ptr(nv)), "lio_get_scan_state")
+        return world, sel, nv
+
+    # ---- timing ------------------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self.L.lio_profile_enable(self.h, int(on))
+
+    def profile_reset(self):
+        self.L.lio_profile_reset(self.h)
+
+    def profile(self) -> dict:
+        out = {}
+        for w, name in PROF_NAMES.items():
+            ms, n = C.c_double(0), C.c_longlong(0)
+            self.L.lio_profile_get(self.h, w, C.byref(ms), C.byref(n))
+            out[name] = {"total_ms": ms.value, "launches": n.value}
+        return out
+
+    def synchronize(self):
+        self._chk(self.L.lio_synchronize(self.h), "lio_synchronize")
+
+
+class Esekf:
+    """Host-side iterated ESKF (lio_eskf_*): mirror of esekfom::esekf around the GPU path."""
+
+    def __init__(self, maximum_iter: int = 3, limit=None):
+        self.L = load()
+        self.h = _vp(self.L.lio_eskf_create())
+        lim = np.full(23, 0.001) if limit is None else np.ascontiguousarray(limit, np.float64)   # laserMapping.cpp:2148
+        rc = self.L.lio_eskf_init_dyn_share(self.h, maximum_iter, _ptr(lim))
+        if rc != LIO_OK:
+            raise LioError("lio_eskf_init_dyn_share failed")
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.lio_eskf_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def change_x(self, x26):
+        x = np.ascontiguousarray(x26, np.float64)
+        assert x.shape == (26,)
+        self.L.lio_eskf_change_x(self.h, _ptr(x))
+
+    def change_P(self, P):
+        p = np.ascontiguousarray(P, np.float64)
+        assert p.shape == (23, 23)
+        self.L.lio_eskf_change_P(self.h, _ptr(p))
+
+    def get_x(self) -> np.ndarray:
+        x = np.zeros(26)
+        self.L.lio_eskf_get_x(self.h, _ptr(x))
+        return x
+
+    def get_P(self) -> np.ndarray:
+        p = np.zeros((23, 23))
+        self.L.lio_eskf_get_P(self.h, _ptr(p))
+        return p
+
+    def update_iterated_dyn_share_modified(self, ctx: LioContext, R: float = 0.001, extrinsic_est_en: bool = False) -> dict:
+        log = lio_update_log()
+        rc = self.L.lio_eskf_update_iterated_dyn_share_modified(self.h, ctx.h, R, int(extrinsic_est_en), C.byref(log))
+        if rc != LIO_OK:
+            raise LioError(f"update_iterated_dyn_share_modified: {ERRORS.get(rc, rc)}: {ctx.L.lio_last_error(ctx.h).decode()}")
+        return {k: getattr(log, k) for k, _ in lio_update_log._fields_}
+
+
+def make_state26(pos, rot, off_R, off_T, vel=(0, 0, 0), bg=(0, 0, 0), ba=(0, 0, 0), grav=(0, 0, -9.809)) -> np.ndarray:
+    """x26 = pos3, rot xyzw, offR xyzw, offT3, vel3, bg3, ba3, grav3 (use-ikfom.hpp:21-30)."""
+    return np.concatenate([pos, rot, off_R, off_T, vel, bg, ba, grav]).astype(np.float64)

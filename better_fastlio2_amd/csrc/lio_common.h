@@ -1,0 +1,116 @@
+// lio_common.h -- data layout shared by the host side of liblio_hip.so and its gfx950 kernels.
+//
+// Map index ("hashed voxel grid over a Morton-sorted point array"; replaces the pointer-chased
+// KD_TREE_NODE of include/ikd-Tree/ikd_Tree.h:64-86):
+//   pts   float4[N_m]   x, y, z, w   (w != 0 marks a tomb-stoned point, cf. point_deleted ikd_Tree.h:70)
+//                       sorted by the Morton code of the point's neighbour-grid cell, so every
+//                       octree node (2^L cells per edge) is one contiguous range of the array
+//   mkeys u64[N_m]      that Morton code, per point (binary-searched by the exact tree walk)
+//   table HashEntry[T]  open addressing, linear probing, packed cell key -> {start, count}
+// The cell edge `cell` is a power of two, so floor(p * inv_cell) and the cell -> world box
+// conversion are exact in fp32; this is what makes the "proven inside the searched block" test
+// of the k-NN kernel sound.
+#pragma once
+#include <stdint.h>
+
+#ifndef __HIPCC__            // host-only build of the shared math (tests/csrc/host_harness.cpp)
+#ifndef __host__
+#define __host__
+#endif
+#ifndef __device__
+#define __device__
+#endif
+#ifndef __forceinline__
+#define __forceinline__ inline __attribute__((always_inline))
+#endif
+#endif
+
+#define LIO_HD __host__ __device__ __forceinline__
+
+namespace lio {
+
+constexpr int K = 5;                          // NUM_MATCH_POINTS, include/common_lib.h:149
+constexpr int CELL_BITS = 21;                 // cell coordinate bits per axis
+constexpr int CELL_OFF = 1 << 20;             // coordinate bias: cells are stored non-negative
+constexpr uint32_t CELL_MAX = (1u << CELL_BITS) - 1u;
+constexpr uint64_t KEY_EMPTY = ~0ull;
+constexpr uint64_t KEY64_MAX = ~0ull;         // "no candidate" in the (sqdist bits, index) ordering
+constexpr uint32_t INF_BITS = 0x7f800000u;    // +inf as fp32 bits
+
+struct HashEntry {                            // 16 bytes: one global_load_dwordx4
+    uint32_t key_lo, key_hi;                  // packed cell key (x << 42 | y << 21 | z), KEY_EMPTY = free
+    uint32_t start, count;                    // range of the cell in the sorted point array
+};
+
+struct Grid {
+    float    cell;                            // power of two
+    float    inv_cell;
+    uint32_t table_mask;                      // table slots - 1 (slots is a power of two)
+    uint32_t n_points;                        // stored points (live + tomb-stoned)
+};
+
+// pos3, rot xyzw, offR xyzw, offT3 -- passed to kernels by value (112 bytes of kernarg)
+struct Pose14 { double v[14]; };
+
+// per-block partial of the measurement reduction: 78 + 12 unique sums, residual sum, count
+constexpr int RED_NE_EXT = 78 + 12;           // extrinsic_est_en: 12 columns
+constexpr int RED_NE_NOEXT = 21 + 6;          // otherwise columns 6..11 are zero (laserMapping.cpp:1997)
+constexpr int RED_STRIDE = 96;                // doubles per block partial (>= 90 + 2)
+
+struct DeviceOut {                            // written by the final reduction kernel
+    double   HTH[144];
+    double   HTh[12];
+    double   res_sum;
+    unsigned long long n_candidates;
+    int      m;
+    int      n_unresolved;
+};
+
+// ---- cell / key arithmetic (host + device) ----------------------------------------------------
+LIO_HD int cell_coord(float v, float inv_cell) {
+    // exact: inv_cell is a power of two.  Bias into [0, 2^21) and clamp (|p| beyond 2^20 cells is
+    // outside the supported range: 524 km at a 0.5 m cell).
+    float f = __builtin_floorf(v * inv_cell);
+    f = f < -1048576.0f ? -1048576.0f : (f > 1048575.0f ? 1048575.0f : f);
+    if (!(f == f)) f = 0.0f;
+    return (int)f + CELL_OFF;
+}
+LIO_HD uint64_t pack_key(uint32_t cx, uint32_t cy, uint32_t cz) {
+    return ((uint64_t)cx << 42) | ((uint64_t)cy << 21) | (uint64_t)cz;
+}
+LIO_HD uint64_t spread21(uint32_t v) {       // bit i -> bit 3i
+    uint64_t x = v & 0x1fffffu;
+    x = (x | (x << 32)) & 0x001f00000000ffffull;
+    x = (x | (x << 16)) & 0x001f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+LIO_HD uint32_t compact21(uint64_t x) {      // inverse of spread21
+    x &= 0x1249249249249249ull;
+    x = (x | (x >> 2)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x >> 4)) & 0x100f00f00f00f00full;
+    x = (x | (x >> 8)) & 0x001f0000ff0000ffull;
+    x = (x | (x >> 16)) & 0x001f00000000ffffull;
+    x = (x | (x >> 32)) & 0x1fffffull;
+    return (uint32_t)x;
+}
+LIO_HD uint64_t morton3(uint32_t cx, uint32_t cy, uint32_t cz) {
+    return (spread21(cx) << 2) | (spread21(cy) << 1) | spread21(cz);
+}
+LIO_HD uint32_t hash_key(uint64_t k) {       // 64 -> 32 bit finaliser
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+// squared distance exactly as KD_TREE::calc_dist (include/ikd-Tree/ikd_Tree.cpp:1374-1378):
+// fp32, (dx*dx + dy*dy) + dz*dz, no contraction (translation units are built -ffp-contract=off).
+LIO_HD float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+}  // namespace lio

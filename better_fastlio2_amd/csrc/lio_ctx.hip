@@ -1,0 +1,790 @@
+// lio_ctx.hip -- host side of liblio_hip.so: the context object and the C ABI of include/lio_hip.h.
+// One context = one GPU = one HIP stream; every device buffer is allocated once at lio_create
+// (capacities from lio_config) so that a scan step performs no allocation.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lio_hip.h"
+#include "lio_esekf.hpp"
+#include "lio_kernels.h"
+#include "lio_mapadd.h"
+
+using namespace lio;
+
+struct lio_ctx {
+    lio_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string arch;
+
+    // ---- map --------------------------------------------------------------------------------
+    Grid grid{};
+    size_t cap_map = 0;
+    float4 *d_pts = nullptr, *d_pts_tmp = nullptr;
+    uint64_t *d_mkeys = nullptr, *d_mkeys_tmp = nullptr;
+    uint32_t *d_vals = nullptr, *d_vals_tmp = nullptr;
+    uint64_t* d_cell_keys = nullptr;
+    uint32_t *d_cell_counts = nullptr, *d_cell_starts = nullptr;
+    HashEntry* d_table = nullptr;
+    size_t table_slots = 0;
+    void* d_temp = nullptr;
+    size_t temp_bytes = 0;
+    uint32_t* d_counters = nullptr;            // [0] n_unresolved, [1] n_runs / misc, [2..3] spare
+    unsigned long long* d_cand = nullptr;
+    float* d_boxes = nullptr;                  // up to 64 boxes
+    uint32_t n_points = 0, n_live = 0, n_cells = 0;
+    bool have_map = false;
+
+    // ---- scan -------------------------------------------------------------------------------
+    int cap_q = 0, nq = 0;
+    float4 *d_body = nullptr, *d_world = nullptr, *d_nbr = nullptr, *d_normvec = nullptr;
+    uint8_t *d_cnt = nullptr, *d_sel = nullptr;
+    uint32_t* d_unres = nullptr;
+    double *d_rows = nullptr, *d_partials = nullptr;
+    DeviceOut* d_out = nullptr;
+    DeviceOut* h_out = nullptr;                // pinned
+    bool have_scan = false, have_search = false, have_pass = false;
+    Pose14 last_pose{};
+    bool last_ext = false;
+    int last_m = 0;
+
+    // ---- staging / scratch --------------------------------------------------------------------
+    float4* h_stage = nullptr;                 // pinned upload staging
+    size_t h_stage_cap = 0;
+    void* d_scratch = nullptr;                 // download staging (device side)
+    size_t d_scratch_bytes = 0;
+    void* h_scratch = nullptr;                 // pinned download staging
+    size_t h_scratch_bytes = 0;
+    // query buffers of lio_map_nearest_search
+    int cap_qs = 0;
+    float4 *d_qs_world = nullptr, *d_qs_nbr = nullptr;
+    uint8_t* d_qs_cnt = nullptr;
+    uint32_t* d_qs_unres = nullptr;
+
+    // batch buffers of lio_map_add
+    size_t cap_add = 0;
+    float4 *d_add_pts = nullptr, *d_add_out = nullptr;
+    uint64_t *d_add_keys = nullptr, *d_add_keys2 = nullptr, *d_add_ukeys = nullptr;
+    uint32_t *d_add_order = nullptr, *d_add_order2 = nullptr, *d_add_gcount = nullptr, *d_add_gstart = nullptr;
+
+    // ---- profiling ----------------------------------------------------------------------------
+    bool prof = false;
+    hipEvent_t ev[LIO_PROF_COUNT][2]{};
+    bool ev_used[LIO_PROF_COUNT]{};
+    double prof_ms[LIO_PROF_COUNT]{};
+    long long prof_n[LIO_PROF_COUNT]{};
+
+    int fail(int code, const char* what, const char* detail) {
+        err = std::string(what) + ": " + (detail ? detail : "");
+        return code;
+    }
+};
+
+#define HIPCHK(ctx, expr)                                                                     \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return (ctx)->fail(LIO_ERR_HIP, #expr, hipGetErrorString(_e));  \
+    } while (0)
+
+namespace {
+
+float auto_cell_size(float ds) {
+    // largest power of two <= 2.5 * ds
+    const float target = 2.5f * ds;
+    float c = 1.0f;
+    while (c > target) c *= 0.5f;
+    while (c * 2.0f <= target) c *= 2.0f;
+    return c;
+}
+bool is_pow2f(float v) {
+    int e;
+    return v > 0.0f && std::frexp(v, &e) == 0.5f;
+}
+int auto_lanes(int nq) {
+    if (nq >= 60000) return 8;
+    if (nq >= 20000) return 16;
+    return 32;
+}
+
+int ensure_stage(lio_ctx* c, size_t n) {
+    if (n <= c->h_stage_cap) return LIO_OK;
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->h_stage_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, n * sizeof(float4), hipHostMallocDefault));
+    c->h_stage_cap = n;
+    return LIO_OK;
+}
+int ensure_scratch(lio_ctx* c, size_t bytes) {
+    if (bytes > c->d_scratch_bytes) {
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        c->d_scratch = nullptr; c->d_scratch_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->d_scratch, bytes));
+        c->d_scratch_bytes = bytes;
+    }
+    if (bytes > c->h_scratch_bytes) {
+        if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+        c->h_scratch = nullptr; c->h_scratch_bytes = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_scratch, bytes, hipHostMallocDefault));
+        c->h_scratch_bytes = bytes;
+    }
+    return LIO_OK;
+}
+// host records (x,y,z first, stride bytes) -> pinned float4 staging -> device
+int upload_points(lio_ctx* c, const float* pts, size_t n, int stride_bytes, float4* d_dst) {
+    if (n == 0) return LIO_OK;
+    int rc = ensure_stage(c, n);
+    if (rc != LIO_OK) return rc;
+    const char* src = reinterpret_cast<const char*>(pts);
+    for (size_t i = 0; i < n; ++i) {
+        const float* p = reinterpret_cast<const float*>(src + i * (size_t)stride_bytes);
+        c->h_stage[i] = make_float4(p[0], p[1], p[2], 0.0f);
+    }
+    HIPCHK(c, hipMemcpyAsync(d_dst, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // staging is reused by the next call
+    return LIO_OK;
+}
+
+// (re)build the index from n points at src (device, float4, must not alias c->d_pts)
+int build_index(lio_ctx* c, const float4* src, uint32_t n) {
+    hipStream_t s = c->stream;
+    c->have_map = false;
+    c->n_points = n; c->n_live = n; c->n_cells = 0;
+    c->grid.n_points = n;
+    if (n == 0) {
+        // empty map: a one-slot-masked empty table keeps the kernels well defined
+        HIPCHK(c, hipMemsetAsync(c->d_table, 0xFF, c->table_slots * sizeof(HashEntry), s));
+        c->grid.table_mask = (uint32_t)(c->table_slots - 1);
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->have_map = true;
+        return LIO_OK;
+    }
+    HIPCHK(c, launch_point_keys(src, n, c->grid, c->d_mkeys_tmp, c->d_vals_tmp, s));
+    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_mkeys_tmp, c->d_mkeys, c->d_vals_tmp, c->d_vals, n, s));
+    HIPCHK(c, launch_gather_points(src, c->d_vals, n, c->d_pts, s));
+    HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_mkeys, n, c->d_cell_keys, c->d_cell_counts,
+                                    c->d_counters + 1, s));
+    uint32_t n_cells = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_cells, c->d_counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_cell_counts, c->d_cell_starts, n_cells, s));
+    // table: power of two >= 4 x cells (load factor <= 0.25 keeps unsuccessful probes short)
+    size_t slots = 1024;
+    while (slots < (size_t)n_cells * 4) slots <<= 1;
+    if (slots > c->table_slots) {
+        if (c->d_table) (void)hipFree(c->d_table);
+        c->d_table = nullptr; c->table_slots = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_table, slots * sizeof(HashEntry)));
+        c->table_slots = slots;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_table, 0xFF, slots * sizeof(HashEntry), s));
+    HIPCHK(c, launch_table_insert(c->d_cell_keys, c->d_cell_starts, c->d_cell_counts, n_cells, c->d_table,
+                                  (uint32_t)(slots - 1), s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->grid.table_mask = (uint32_t)(slots - 1);
+    c->n_cells = n_cells;
+    c->have_map = true;
+    return LIO_OK;
+}
+
+void prof_begin(lio_ctx* c, int which) {
+    if (c->prof) { (void)hipEventRecord(c->ev[which][0], c->stream); }
+}
+void prof_end(lio_ctx* c, int which) {
+    if (c->prof) { (void)hipEventRecord(c->ev[which][1], c->stream); c->ev_used[which] = true; }
+}
+void prof_collect(lio_ctx* c) {
+    if (!c->prof) return;
+    for (int w = 0; w < LIO_PROF_COUNT; ++w) {
+        if (!c->ev_used[w]) continue;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev[w][0], c->ev[w][1]) == hipSuccess) {
+            c->prof_ms[w] += ms;
+            c->prof_n[w] += 1;
+        }
+        c->ev_used[w] = false;
+    }
+}
+
+// k-NN of nq world/body queries into (nbr, cnt); queries_world must hold the world points when
+// body == nullptr, and receives them otherwise.
+int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14& pose, int nq, int stride,
+            float4* nbr, uint8_t* cnt, uint32_t* unres) {
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(uint32_t), s));
+    HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), s));
+    KnnArgs ka{};
+    ka.map_pts = c->d_pts; ka.table = c->d_table; ka.grid = c->grid;
+    ka.body = body; ka.world_in = body ? nullptr : queries_world; ka.pose = pose;
+    ka.nq = nq; ka.nq_stride = stride;
+    ka.world_out = body ? queries_world : nullptr;
+    ka.nbr = nbr; ka.cnt = cnt; ka.unresolved = unres; ka.n_unresolved = c->d_counters; ka.cand_total = c->d_cand;
+    const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
+    prof_begin(c, LIO_PROF_KNN);
+    HIPCHK(c, launch_knn27(ka, lanes, s));
+    prof_end(c, LIO_PROF_KNN);
+    TreeArgs ta{};
+    ta.map_pts = c->d_pts; ta.mkeys = c->d_mkeys; ta.grid = c->grid; ta.queries = queries_world;
+    ta.list = unres; ta.n_list = c->d_counters; ta.nq = nq; ta.nq_stride = stride; ta.nbr = nbr; ta.cnt = cnt;
+    prof_begin(c, LIO_PROF_FALLBACK);
+    HIPCHK(c, launch_knn_tree(ta, s));
+    prof_end(c, LIO_PROF_FALLBACK);
+    return LIO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lio_version(void) { return "lio_hip 0.1 (gfx950)"; }
+
+int lio_create(const lio_config* cfg, lio_ctx** out) {
+    if (!cfg || !out) return LIO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LIO_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return LIO_ERR_INVALID_ARG;
+    if (!(cfg->filter_size_map_min > 0.0f) || cfg->max_scan_points <= 0 || cfg->max_map_points <= 0 ||
+        cfg->max_map_points > 0x7fffff00ll)
+        return LIO_ERR_INVALID_ARG;
+    if (cfg->lanes_per_query != 0 && cfg->lanes_per_query != 8 && cfg->lanes_per_query != 16 &&
+        cfg->lanes_per_query != 32 && cfg->lanes_per_query != 64)
+        return LIO_ERR_INVALID_ARG;
+    if (cfg->cell_size != 0.0f && !is_pow2f(cfg->cell_size)) return LIO_ERR_INVALID_ARG;
+
+    lio_ctx* c = new lio_ctx();
+    c->cfg = *cfg;
+    c->device = cfg->device;
+#define CREATE_CHK(expr)                                                         \
+    do {                                                                         \
+        hipError_t _e = (expr);                                                  \
+        if (_e != hipSuccess) {                                                  \
+            fprintf(stderr, "lio_create: %s failed: %s\n", #expr, hipGetErrorString(_e)); \
+            lio_destroy(c);                                                      \
+            return LIO_ERR_HIP;                                                  \
+        }                                                                        \
+    } while (0)
+    CREATE_CHK(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    CREATE_CHK(hipGetDeviceProperties(&prop, c->device));
+    c->arch = prop.gcnArchName;
+    CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+    c->grid.cell = cfg->cell_size != 0.0f ? cfg->cell_size : auto_cell_size(cfg->filter_size_map_min);
+    c->grid.inv_cell = 1.0f / c->grid.cell;
+    c->grid.table_mask = 0; c->grid.n_points = 0;
+
+    const size_t nm = (size_t)cfg->max_map_points;
+    c->cap_map = nm;
+    CREATE_CHK(hipMalloc((void**)&c->d_pts, nm * sizeof(float4)));
+    CREATE_CHK(hipMalloc((void**)&c->d_pts_tmp, nm * sizeof(float4)));
+    CREATE_CHK(hipMalloc((void**)&c->d_mkeys, nm * sizeof(uint64_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_mkeys_tmp, nm * sizeof(uint64_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_vals, nm * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_vals_tmp, nm * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_cell_keys, nm * sizeof(uint64_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_cell_counts, nm * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_cell_starts, nm * sizeof(uint32_t)));
+    size_t tb = sort_pairs_temp_bytes(nm);
+    size_t t2 = rle_temp_bytes(nm); if (t2 > tb) tb = t2;
+    t2 = scan_temp_bytes(nm); if (t2 > tb) tb = t2;
+    t2 = select_temp_bytes(nm); if (t2 > tb) tb = t2;
+    c->temp_bytes = tb + 256;
+    CREATE_CHK(hipMalloc(&c->d_temp, c->temp_bytes));
+    c->table_slots = 1024;
+    CREATE_CHK(hipMalloc((void**)&c->d_table, c->table_slots * sizeof(HashEntry)));
+    CREATE_CHK(hipMemset(c->d_table, 0xFF, c->table_slots * sizeof(HashEntry)));
+    CREATE_CHK(hipMalloc((void**)&c->d_counters, 4 * sizeof(uint32_t)));
+    CREATE_CHK(hipMemset(c->d_counters, 0, 4 * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_cand, sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc((void**)&c->d_boxes, 64 * 6 * sizeof(float)));
+
+    const size_t nq = (size_t)cfg->max_scan_points;
+    c->cap_q = cfg->max_scan_points;
+    CREATE_CHK(hipMalloc((void**)&c->d_body, nq * sizeof(float4)));
+    CREATE_CHK(hipMalloc((void**)&c->d_world, nq * sizeof(float4)));
+    CREATE_CHK(hipMalloc((void**)&c->d_nbr, nq * K * sizeof(float4)));
+    CREATE_CHK(hipMalloc((void**)&c->d_normvec, nq * sizeof(float4)));
+    CREATE_CHK(hipMalloc((void**)&c->d_cnt, nq));
+    CREATE_CHK(hipMalloc((void**)&c->d_sel, nq));
+    CREATE_CHK(hipMalloc((void**)&c->d_unres, nq * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_partials, (size_t)residual_blocks((int)nq) * RED_STRIDE * sizeof(double)));
+    CREATE_CHK(hipMalloc((void**)&c->d_out, sizeof(DeviceOut)));
+    CREATE_CHK(hipHostMalloc((void**)&c->h_out, sizeof(DeviceOut), hipHostMallocDefault));
+    for (int w = 0; w < LIO_PROF_COUNT; ++w) {
+        CREATE_CHK(hipEventCreate(&c->ev[w][0]));
+        CREATE_CHK(hipEventCreate(&c->ev[w][1]));
+    }
+#undef CREATE_CHK
+    c->have_map = true;                         // an empty map is a valid map (Build not yet called)
+    *out = c;
+    return LIO_OK;
+}
+
+void lio_destroy(lio_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
+                   c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
+                   c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
+                   c->d_partials, c->d_out, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
+                   c->d_add_pts, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys, c->d_add_order,
+                   c->d_add_order2, c->d_add_gcount, c->d_add_gstart};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_scratch) (void)hipHostFree(c->h_scratch);
+    for (int w = 0; w < LIO_PROF_COUNT; ++w) {
+        if (c->ev[w][0]) (void)hipEventDestroy(c->ev[w][0]);
+        if (c->ev[w][1]) (void)hipEventDestroy(c->ev[w][1]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* lio_last_error(lio_ctx* c) { return c ? c->err.c_str() : "null context"; }
+void* lio_stream(lio_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int lio_synchronize(lio_ctx* c) {
+    if (!c) return LIO_ERR_INVALID_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LIO_OK;
+}
+
+// ---- map ---------------------------------------------------------------------------------------
+int lio_map_build(lio_ctx* c, const float* pts, long long n, int stride_bytes) {
+    if (!c || n < 0 || (n > 0 && !pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
+    if ((size_t)n > c->cap_map) return c->fail(LIO_ERR_CAPACITY, "lio_map_build", "n exceeds max_map_points");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = upload_points(c, pts, (size_t)n, stride_bytes, c->d_pts_tmp);
+    if (rc != LIO_OK) return rc;
+    return build_index(c, c->d_pts_tmp, (uint32_t)n);
+}
+int lio_map_build_device(lio_ctx* c, const void* d_pts_f4, long long n) {
+    if (!c || n < 0 || (n > 0 && !d_pts_f4)) return LIO_ERR_INVALID_ARG;
+    if ((size_t)n > c->cap_map) return c->fail(LIO_ERR_CAPACITY, "lio_map_build_device", "n exceeds max_map_points");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > 0)
+        HIPCHK(c, hipMemcpyAsync(c->d_pts_tmp, d_pts_f4, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    return build_index(c, c->d_pts_tmp, (uint32_t)n);
+}
+int lio_map_reconstruct(lio_ctx* c, const float* pts, long long n, int stride_bytes) {
+    return lio_map_build(c, pts, n, stride_bytes);       // ikd_Tree.cpp:1394-1405: delete all, Build
+}
+
+// Add_Points (ikd_Tree.cpp:414-489).  Returns through *n_added what the reference returns: the number
+// of down-sampled inserts that changed the tree (tmp_counter), 0 when downsample_on is false.
+int lio_map_add(lio_ctx* c, const float* pts, int n, int stride_bytes, int downsample_on, int* n_added) {
+    if (!c || n < 0 || (n > 0 && !pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
+    if (n_added) *n_added = 0;
+    if (n == 0) return LIO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if ((size_t)c->n_points + (size_t)n > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "lio_map_add", "stored points + batch exceed max_map_points");
+    if ((size_t)n > c->cap_add) {
+        void* old[] = {c->d_add_pts, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys, c->d_add_order,
+                       c->d_add_order2, c->d_add_gcount, c->d_add_gstart};
+        for (void* p : old) if (p) (void)hipFree(p);
+        c->d_add_pts = c->d_add_out = nullptr; c->d_add_keys = c->d_add_keys2 = c->d_add_ukeys = nullptr;
+        c->d_add_order = c->d_add_order2 = c->d_add_gcount = c->d_add_gstart = nullptr; c->cap_add = 0;
+        const size_t m = (size_t)n;
+        HIPCHK(c, hipMalloc((void**)&c->d_add_pts, m * sizeof(float4)));
+        HIPCHK(c, hipMalloc((void**)&c->d_add_out, m * sizeof(float4)));
+        HIPCHK(c, hipMalloc((void**)&c->d_add_keys, m * sizeof(uint64_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_add_keys2, m * sizeof(uint64_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_add_ukeys, m * sizeof(uint64_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_add_order, m * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_add_order2, m * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_add_gcount, m * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_add_gstart, m * sizeof(uint32_t)));
+        c->cap_add = m;
+    }
+    int rc = upload_points(c, pts, (size_t)n, stride_bytes, c->d_add_pts);
+    if (rc != LIO_OK) return rc;
+    uint32_t n_append = 0;
+    const float4* append_src = nullptr;
+    if (downsample_on) {
+        const float ds = c->cfg.filter_size_map_min;
+        HIPCHK(c, launch_voxel_keys(c->d_add_pts, (uint32_t)n, ds, c->d_add_keys, c->d_add_order, s));
+        HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_add_keys, c->d_add_keys2, c->d_add_order,
+                                     c->d_add_order2, (size_t)n, s));
+        HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_add_keys2, (size_t)n, c->d_add_ukeys,
+                                        c->d_add_gcount, c->d_counters + 1, s));
+        uint32_t n_groups = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_groups, c->d_counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, n_groups, s));
+        HIPCHK(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(uint32_t), s));
+        FoldArgs fa{};
+        fa.map_pts = c->d_pts; fa.table = c->d_table; fa.grid = c->grid; fa.ds = ds; fa.new_pts = c->d_add_pts;
+        fa.order = c->d_add_order2; fa.group_start = c->d_add_gstart; fa.group_count = c->d_add_gcount;
+        fa.n_groups = n_groups; fa.out_pts = c->d_add_out; fa.n_added = c->d_counters + 2;
+        HIPCHK(c, launch_fold_groups(fa, s));
+        // survivors (w == 0) -> front of d_add_pts (the batch itself is no longer needed)
+        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, c->d_add_pts, c->d_counters + 3, n_groups, s));
+        uint32_t host_cnt[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(host_cnt, c->d_counters + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (n_added) *n_added = (int)host_cnt[0];
+        n_append = host_cnt[1];
+        append_src = c->d_add_pts;
+    } else {
+        n_append = (uint32_t)n;
+        append_src = c->d_add_pts;
+    }
+    // append, drop tomb-stones, rebuild the index
+    if (n_append > 0)
+        HIPCHK(c, hipMemcpyAsync(c->d_pts + c->n_points, append_src, (size_t)n_append * sizeof(float4),
+                                 hipMemcpyDeviceToDevice, s));
+    const uint32_t total = c->n_points + n_append;
+    HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_pts_tmp, c->d_counters + 3, total, s));
+    uint32_t live = 0;
+    HIPCHK(c, hipMemcpyAsync(&live, c->d_counters + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return build_index(c, c->d_pts_tmp, live);
+}
+
+long long lio_map_size(lio_ctx* c) { return c ? (long long)c->n_points : 0; }
+long long lio_map_validnum(lio_ctx* c) { return c ? (long long)c->n_live : 0; }
+
+int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_deleted) {
+    if (!c || nb < 0 || (nb > 0 && !minmax6)) return LIO_ERR_INVALID_ARG;
+    if (n_deleted) *n_deleted = 0;
+    if (nb == 0 || c->n_points == 0) return LIO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int total = 0;
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+        const int nbb = nb - b0 < 64 ? nb - b0 : 64;
+        HIPCHK(c, hipMemcpyAsync(c->d_boxes, minmax6 + 6 * (size_t)b0, (size_t)nbb * 6 * sizeof(float),
+                                 hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(uint32_t), c->stream));
+        HIPCHK(c, launch_delete_boxes(c->d_pts, c->n_points, c->d_boxes, nbb, c->d_counters + 2, c->stream));
+        uint32_t cnt = 0;
+        HIPCHK(c, hipMemcpyAsync(&cnt, c->d_counters + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        total += (int)cnt;
+    }
+    c->n_live -= (uint32_t)total;
+    if (n_deleted) *n_deleted = total;
+    return LIO_OK;
+}
+
+int lio_map_flatten(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
+    if (!c || cap < 0 || (cap > 0 && !out_xyz)) return LIO_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n) *n = (long long)c->n_live;
+    if (c->n_points == 0 || cap == 0) return LIO_OK;
+    // compact the live points (order-preserving), pack xyz, download
+    HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_pts_tmp, c->d_counters + 3, c->n_points, c->stream));
+    uint32_t live = 0;
+    HIPCHK(c, hipMemcpyAsync(&live, c->d_counters + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t m = (size_t)live < (size_t)cap ? (size_t)live : (size_t)cap;
+    if (m == 0) return LIO_OK;
+    int rc = ensure_scratch(c, m * 3 * sizeof(float));
+    if (rc != LIO_OK) return rc;
+    HIPCHK(c, launch_pack_xyz(c->d_pts_tmp, (uint32_t)m, (float*)c->d_scratch, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, m * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(out_xyz, c->h_scratch, m * 3 * sizeof(float));
+    return LIO_OK;
+}
+
+int lio_map_get_info(lio_ctx* c, lio_map_info* info) {
+    if (!c || !info) return LIO_ERR_INVALID_ARG;
+    info->n_points = c->n_points; info->n_live = c->n_live; info->n_cells = c->n_cells;
+    info->table_slots = (long long)c->grid.table_mask + 1;
+    info->cell_size = c->grid.cell; info->downsample_size = c->cfg.filter_size_map_min;
+    info->bytes_resident = (long long)c->n_points * (long long)(sizeof(float4) + sizeof(uint64_t)) +
+                           (long long)(c->grid.table_mask + 1ll) * (long long)sizeof(HashEntry);
+    return LIO_OK;
+}
+
+int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_bytes, float* out_xyz,
+                           float* out_sqdist, int* out_count) {
+    if (!c || n < 0 || (n > 0 && !q_xyz) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
+    if (n == 0) return LIO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > c->cap_qs) {
+        void* old[] = {c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres};
+        for (void* p : old) if (p) (void)hipFree(p);
+        c->d_qs_world = nullptr; c->d_qs_nbr = nullptr; c->d_qs_cnt = nullptr; c->d_qs_unres = nullptr; c->cap_qs = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_qs_world, (size_t)n * sizeof(float4)));
+        HIPCHK(c, hipMalloc((void**)&c->d_qs_nbr, (size_t)n * K * sizeof(float4)));
+        HIPCHK(c, hipMalloc((void**)&c->d_qs_cnt, (size_t)n));
+        HIPCHK(c, hipMalloc((void**)&c->d_qs_unres, (size_t)n * sizeof(uint32_t)));
+        c->cap_qs = n;
+    }
+    int rc = upload_points(c, q_xyz, (size_t)n, stride_bytes, c->d_qs_world);
+    if (rc != LIO_OK) return rc;
+    Pose14 ident{};
+    rc = run_knn(c, nullptr, c->d_qs_world, ident, n, n, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres);
+    if (rc != LIO_OK) return rc;
+    const size_t b_xyz = (size_t)n * K * 3 * sizeof(float), b_d = (size_t)n * K * sizeof(float), b_c = (size_t)n * sizeof(int);
+    rc = ensure_scratch(c, b_xyz + b_d + b_c);
+    if (rc != LIO_OK) return rc;
+    float* dx = (float*)c->d_scratch;
+    float* dd = (float*)((char*)c->d_scratch + b_xyz);
+    int* dc = (int*)((char*)c->d_scratch + b_xyz + b_d);
+    HIPCHK(c, launch_unpack_neighbors(c->d_qs_nbr, c->d_qs_cnt, n, n, dx, dd, dc, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, b_xyz + b_d + b_c, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    if (out_xyz) std::memcpy(out_xyz, c->h_scratch, b_xyz);
+    if (out_sqdist) std::memcpy(out_sqdist, (char*)c->h_scratch + b_xyz, b_d);
+    if (out_count) std::memcpy(out_count, (char*)c->h_scratch + b_xyz + b_d, b_c);
+    return LIO_OK;
+}
+
+// ---- scan + measurement ----------------------------------------------------------------------
+static int scan_reset(lio_ctx* c, int n) {
+    c->nq = n;
+    c->have_scan = true; c->have_search = false; c->have_pass = false; c->last_m = 0;
+    if (n > 0) HIPCHK(c, hipMemsetAsync(c->d_sel, 1, (size_t)n, c->stream));     // laserMapping.cpp:2131
+    return LIO_OK;
+}
+int lio_scan_set(lio_ctx* c, const float* body_pts, int n, int stride_bytes) {
+    if (!c || n < 0 || (n > 0 && !body_pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
+    if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_set", "n exceeds max_scan_points");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = upload_points(c, body_pts, (size_t)n, stride_bytes, c->d_body);
+    if (rc != LIO_OK) return rc;
+    return scan_reset(c, n);
+}
+int lio_scan_set_device(lio_ctx* c, const void* d_body_f4, int n) {
+    if (!c || n < 0 || (n > 0 && !d_body_f4)) return LIO_ERR_INVALID_ARG;
+    if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_set_device", "n exceeds max_scan_points");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > 0) HIPCHK(c, hipMemcpyAsync(c->d_body, d_body_f4, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    return scan_reset(c, n);
+}
+int lio_scan_size(lio_ctx* c) { return c ? c->nq : 0; }
+
+int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrinsic_est_en, lio_out* out) {
+    if (!c || !state14 || !out) return LIO_ERR_INVALID_ARG;
+    if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "no scan set");
+    if (!do_search && !c->have_search) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "first pass of a scan must search");
+    std::memset(out, 0, sizeof(*out));
+    const int nq = c->nq;
+    if (nq == 0) { out->valid = 0; return LIO_OK; }       // "No Effective Points" laserMapping.cpp:1956
+    hipStream_t s = c->stream;
+    Pose14 pose;
+    for (int i = 0; i < 14; ++i) pose.v[i] = state14[i];
+    const bool ext = extrinsic_est_en != 0;
+
+    if (do_search) {
+        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_unres);
+        if (rc != LIO_OK) return rc;
+        c->have_search = true;
+    }
+    ResidualArgs ra{};
+    ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
+    ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.rows = nullptr; ra.partials = c->d_partials;
+    prof_begin(c, LIO_PROF_RESIDUAL);
+    HIPCHK(c, launch_residual(ra, do_search != 0, ext, s));
+    prof_end(c, LIO_PROF_RESIDUAL);
+    prof_begin(c, LIO_PROF_REDUCE);
+    HIPCHK(c, launch_reduce_final(c->d_partials, residual_blocks(nq), ext, do_search ? c->d_counters : nullptr,
+                                  do_search ? c->d_cand : nullptr, c->d_out, s));
+    prof_end(c, LIO_PROF_REDUCE);
+    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(DeviceOut), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    prof_collect(c);
+
+    const DeviceOut& d = *c->h_out;
+    out->m = d.m;
+    out->valid = d.m >= 1 ? 1 : 0;                        // laserMapping.cpp:1956-1961
+    out->n_unresolved = d.n_unresolved;
+    out->res_mean = d.m >= 1 ? d.res_sum / (double)d.m : 0.0;   // :1963
+    std::memcpy(out->HTH, d.HTH, sizeof(out->HTH));
+    std::memcpy(out->HTh, d.HTh, sizeof(out->HTh));
+    out->n_candidates = d.n_candidates;
+    c->last_pose = pose; c->last_ext = ext; c->last_m = d.m; c->have_pass = true;
+    return LIO_OK;
+}
+
+int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_major) {
+    if (!c || !h_x || !h) return LIO_ERR_INVALID_ARG;
+    if (!c->have_pass) return c->fail(LIO_ERR_NO_SCAN, "lio_measure_rows", "no measurement pass yet");
+    const int nq = c->nq, m = c->last_m;
+    if (cap_rows < m) return c->fail(LIO_ERR_CAPACITY, "lio_measure_rows", "cap_rows < m");
+    if (m == 0) return LIO_OK;
+    hipStream_t s = c->stream;
+    if (!c->d_rows) HIPCHK(c, hipMalloc((void**)&c->d_rows, (size_t)c->cap_q * 13 * sizeof(double)));
+    // Re-evaluate the rows of the selected points with the pose of the last pass: selection flags
+    // are a fixed point of the no-search pass (same neighbours, same pose -> same decisions).
+    ResidualArgs ra{};
+    ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = c->last_pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
+    ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.rows = c->d_rows; ra.partials = c->d_partials;
+    HIPCHK(c, launch_residual(ra, false, c->last_ext, s));
+    const size_t b_rows = (size_t)nq * 13 * sizeof(double);
+    int rc = ensure_scratch(c, b_rows + (size_t)nq);
+    if (rc != LIO_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_rows, b_rows, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync((char*)c->h_scratch + b_rows, c->d_sel, (size_t)nq, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const double* rows = (const double*)c->h_scratch;
+    const uint8_t* sel = (const uint8_t*)c->h_scratch + b_rows;
+    int r = 0;
+    for (int i = 0; i < nq && r < m; ++i) {               // stable compaction, laserMapping.cpp:1944-1954
+        if (!sel[i]) continue;
+        const double* src = rows + (size_t)i * 13;
+        for (int cidx = 0; cidx < 12; ++cidx) {
+            if (col_major) h_x[(size_t)cidx * m + r] = src[cidx];
+            else h_x[(size_t)r * 12 + cidx] = src[cidx];
+        }
+        h[r] = src[12];
+        ++r;
+    }
+    if (r != m) return c->fail(LIO_ERR_HIP, "lio_measure_rows", "row count changed between passes");
+    return LIO_OK;
+}
+
+int lio_get_neighbors(lio_ctx* c, float* out_xyz, float* out_sqdist, int* out_count) {
+    if (!c) return LIO_ERR_INVALID_ARG;
+    if (!c->have_search) return c->fail(LIO_ERR_NO_SCAN, "lio_get_neighbors", "no search pass yet");
+    const int n = c->nq;
+    if (n == 0) return LIO_OK;
+    const size_t b_xyz = (size_t)n * K * 3 * sizeof(float), b_d = (size_t)n * K * sizeof(float), b_c = (size_t)n * sizeof(int);
+    int rc = ensure_scratch(c, b_xyz + b_d + b_c);
+    if (rc != LIO_OK) return rc;
+    float* dx = (float*)c->d_scratch;
+    float* dd = (float*)((char*)c->d_scratch + b_xyz);
+    int* dc = (int*)((char*)c->d_scratch + b_xyz + b_d);
+    HIPCHK(c, launch_unpack_neighbors(c->d_nbr, c->d_cnt, n, c->cap_q, dx, dd, dc, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, b_xyz + b_d + b_c, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out_xyz) std::memcpy(out_xyz, c->h_scratch, b_xyz);
+    if (out_sqdist) std::memcpy(out_sqdist, (char*)c->h_scratch + b_xyz, b_d);
+    if (out_count) std::memcpy(out_count, (char*)c->h_scratch + b_xyz + b_d, b_c);
+    return LIO_OK;
+}
+
+int lio_get_scan_state(lio_ctx* c, float* world_xyz, uint8_t* selected, float* normvec) {
+    if (!c) return LIO_ERR_INVALID_ARG;
+    if (!c->have_pass) return c->fail(LIO_ERR_NO_SCAN, "lio_get_scan_state", "no measurement pass yet");
+    const int n = c->nq;
+    if (n == 0) return LIO_OK;
+    const size_t b4 = (size_t)n * sizeof(float4);
+    int rc = ensure_scratch(c, 2 * b4 + (size_t)n);
+    if (rc != LIO_OK) return rc;
+    char* hs = (char*)c->h_scratch;
+    HIPCHK(c, hipMemcpyAsync(hs, c->d_world, b4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs + b4, c->d_normvec, b4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs + 2 * b4, c->d_sel, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const float4* w = (const float4*)hs;
+    const float4* nv = (const float4*)(hs + b4);
+    const uint8_t* sl = (const uint8_t*)(hs + 2 * b4);
+    for (int i = 0; i < n; ++i) {
+        if (world_xyz) { world_xyz[3 * i] = w[i].x; world_xyz[3 * i + 1] = w[i].y; world_xyz[3 * i + 2] = w[i].z; }
+        if (normvec) {
+            // normvec is only written for selected points (laserMapping.cpp:1932-1936)
+            if (sl[i]) { normvec[4 * i] = nv[i].x; normvec[4 * i + 1] = nv[i].y; normvec[4 * i + 2] = nv[i].z; normvec[4 * i + 3] = nv[i].w; }
+            else { normvec[4 * i] = normvec[4 * i + 1] = normvec[4 * i + 2] = normvec[4 * i + 3] = 0.0f; }
+        }
+        if (selected) selected[i] = sl[i];
+    }
+    return LIO_OK;
+}
+
+// ---- profiling -----------------------------------------------------------------------------------
+int lio_profile_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; c->prof = on != 0; return LIO_OK; }
+int lio_profile_reset(lio_ctx* c) {
+    if (!c) return LIO_ERR_INVALID_ARG;
+    for (int w = 0; w < LIO_PROF_COUNT; ++w) { c->prof_ms[w] = 0.0; c->prof_n[w] = 0; c->ev_used[w] = false; }
+    return LIO_OK;
+}
+int lio_profile_get(lio_ctx* c, int which, double* total_ms, long long* launches) {
+    if (!c || which < 0 || which >= LIO_PROF_COUNT) return LIO_ERR_INVALID_ARG;
+    if (total_ms) *total_ms = c->prof_ms[which];
+    if (launches) *launches = c->prof_n[which];
+    return LIO_OK;
+}
+
+// ---- host-side ESKF -----------------------------------------------------------------------------
+struct lio_eskf {
+    lio::esekf kf;
+};
+
+lio_eskf* lio_eskf_create(void) { return new lio_eskf(); }
+void lio_eskf_destroy(lio_eskf* kf) { delete kf; }
+int lio_eskf_init_dyn_share(lio_eskf* kf, int maximum_iter, const double limit23[23]) {
+    if (!kf || maximum_iter < 0 || !limit23) return LIO_ERR_INVALID_ARG;
+    kf->kf.init_dyn_share(nullptr, maximum_iter, limit23);
+    return LIO_OK;
+}
+int lio_eskf_change_x(lio_eskf* kf, const double x26[26]) {
+    if (!kf || !x26) return LIO_ERR_INVALID_ARG;
+    kf->kf.change_x(lio::state_ikfom::from_array(x26));
+    return LIO_OK;
+}
+int lio_eskf_change_P(lio_eskf* kf, const double P[23 * 23]) {
+    if (!kf || !P) return LIO_ERR_INVALID_ARG;
+    kf->kf.change_P(P);
+    return LIO_OK;
+}
+int lio_eskf_get_x(lio_eskf* kf, double x26[26]) {
+    if (!kf || !x26) return LIO_ERR_INVALID_ARG;
+    kf->kf.get_x().to_array(x26);
+    return LIO_OK;
+}
+int lio_eskf_get_P(lio_eskf* kf, double P[23 * 23]) {
+    if (!kf || !P) return LIO_ERR_INVALID_ARG;
+    std::memcpy(P, kf->kf.get_P(), sizeof(double) * 23 * 23);
+    return LIO_OK;
+}
+int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, double R, int extrinsic_est_en,
+                                                lio_update_log* log) {
+    if (!kf || !ctx || !(R > 0.0)) return LIO_ERR_INVALID_ARG;
+    int status = LIO_OK;
+    // the reference's h_share_model, bound to the GPU path (laserMapping.cpp:1876 <-> lio_measure)
+    kf->kf.set_measurement_model([&](lio::state_ikfom& s, lio::dyn_share_datastruct& d) {
+        double pose[14];
+        s.pose14(pose);
+        lio_out o;
+        const int rc = lio_measure(ctx, pose, d.converge ? 1 : 0, extrinsic_est_en, &o);
+        if (rc != LIO_OK) { status = rc; d.valid = false; d.m = 0; return; }
+        d.valid = o.valid != 0;
+        d.m = o.m;
+        d.res_mean = o.res_mean;
+        std::memcpy(d.HTH, o.HTH, sizeof(d.HTH));
+        std::memcpy(d.HTh, o.HTh, sizeof(d.HTh));
+        if (d.valid && o.m < lio::DOF) {                    // dense-gain branch needs the rows
+            d.h_x.assign((size_t)o.m * 12, 0.0);
+            d.h.assign((size_t)o.m, 0.0);
+            const int rc2 = lio_measure_rows(ctx, d.h_x.data(), d.h.data(), o.m, 0);
+            if (rc2 != LIO_OK) { status = rc2; d.valid = false; }
+        }
+    });
+    double solve_time = 0.0;
+    kf->kf.update_iterated_dyn_share_modified(R, solve_time);
+    if (log) {
+        const lio::update_stats& st = kf->kf.stats();
+        log->n_calls = st.n_calls; log->n_search = st.n_search; log->converged = st.converged ? 1 : 0;
+        log->last_m = st.last_m; log->last_res_mean = st.last_res_mean;
+        log->solve_seconds = st.solve_seconds; log->measure_seconds = st.measure_seconds;
+    }
+    return status;
+}
+int lio_state_boxplus(double x26[26], const double dx23[23]) {
+    if (!x26 || !dx23) return LIO_ERR_INVALID_ARG;
+    lio::state_ikfom s = lio::state_ikfom::from_array(x26);
+    s.boxplus(dx23);
+    s.to_array(x26);
+    return LIO_OK;
+}
+int lio_state_boxminus(const double x26[26], const double y26[26], double dx23[23]) {
+    if (!x26 || !y26 || !dx23) return LIO_ERR_INVALID_ARG;
+    lio::state_ikfom::from_array(x26).boxminus(dx23, lio::state_ikfom::from_array(y26));
+    return LIO_OK;
+}
+
+}  // extern "C"

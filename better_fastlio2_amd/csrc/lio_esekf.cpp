@@ -1,0 +1,512 @@
+// lio_esekf.cpp -- host-side iterated ESKF around the GPU measurement path (see lio_esekf.hpp).
+// Plain C++17, fp64.  Each block cites the lines of the reference it mirrors (paths relative to the
+// reference repository; "esekfom.hpp" = include/IKFoM_toolkit/esekfom/esekfom.hpp, "mtk/" =
+// include/IKFoM_toolkit/mtk/).
+#include "lio_esekf.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace lio {
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// tiny fixed-size dense algebra (row-major)
+// ------------------------------------------------------------------------------------------
+template <int R, int C>
+struct Mat {
+    double a[R * C];
+    double& operator()(int r, int c) { return a[r * C + c]; }
+    double operator()(int r, int c) const { return a[r * C + c]; }
+    static Mat zero() { Mat m; for (double& v : m.a) v = 0.0; return m; }
+    static Mat identity() { Mat m = zero(); for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = 1.0; return m; }
+};
+template <int R, int K, int C>
+Mat<R, C> operator*(const Mat<R, K>& x, const Mat<K, C>& y) {
+    Mat<R, C> z;
+    for (int r = 0; r < R; ++r)
+        for (int c = 0; c < C; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < K; ++k) s += x(r, k) * y(k, c);
+            z(r, c) = s;
+        }
+    return z;
+}
+template <int R, int C>
+Mat<C, R> transpose(const Mat<R, C>& x) {
+    Mat<C, R> t;
+    for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) t(c, r) = x(r, c);
+    return t;
+}
+typedef Mat<3, 3> M3;
+typedef Mat<3, 1> V3;
+
+V3 v3(double x, double y, double z) { V3 v; v.a[0] = x; v.a[1] = y; v.a[2] = z; return v; }
+V3 v3(const Vec3& p) { return v3(p.x, p.y, p.z); }
+M3 hat(const V3& v) {                                        // mtk/src/mtkmath.hpp:176-183
+    M3 h = M3::zero();
+    h(0, 1) = -v.a[2]; h(0, 2) = v.a[1];
+    h(1, 0) = v.a[2];  h(1, 2) = -v.a[0];
+    h(2, 0) = -v.a[1]; h(2, 1) = v.a[0];
+    return h;
+}
+double dot3(const V3& x, const V3& y) { return x.a[0] * y.a[0] + x.a[1] * y.a[1] + x.a[2] * y.a[2]; }
+double norm3(const V3& x) { return std::sqrt(dot3(x, x)); }
+
+// general inverse by LU with partial pivoting (what Eigen's inverse() does for sizes > 4)
+bool invert(const double* A, double* Ainv, int n) {
+    std::vector<double> lu(A, A + (size_t)n * n);
+    std::vector<int> perm(n);
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    for (int k = 0; k < n; ++k) {
+        int piv = k;
+        double big = std::fabs(lu[(size_t)k * n + k]);
+        for (int r = k + 1; r < n; ++r) {
+            const double v = std::fabs(lu[(size_t)r * n + k]);
+            if (v > big) { big = v; piv = r; }
+        }
+        if (big == 0.0) return false;
+        if (piv != k) {
+            for (int c = 0; c < n; ++c) std::swap(lu[(size_t)k * n + c], lu[(size_t)piv * n + c]);
+            std::swap(perm[k], perm[piv]);
+        }
+        const double d = lu[(size_t)k * n + k];
+        for (int r = k + 1; r < n; ++r) {
+            const double f = lu[(size_t)r * n + k] / d;
+            lu[(size_t)r * n + k] = f;
+            for (int c = k + 1; c < n; ++c) lu[(size_t)r * n + c] -= f * lu[(size_t)k * n + c];
+        }
+    }
+    std::vector<double> col(n);
+    for (int j = 0; j < n; ++j) {
+        for (int r = 0; r < n; ++r) {                         // forward: L y = P e_j
+            double s = perm[r] == j ? 1.0 : 0.0;
+            for (int c = 0; c < r; ++c) s -= lu[(size_t)r * n + c] * col[c];
+            col[r] = s;
+        }
+        for (int r = n - 1; r >= 0; --r) {                    // backward: U x = y
+            double s = col[r];
+            for (int c = r + 1; c < n; ++c) s -= lu[(size_t)r * n + c] * Ainv[(size_t)c * n + j];
+            Ainv[(size_t)r * n + j] = s / lu[(size_t)r * n + r];
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// MTK pieces
+// ------------------------------------------------------------------------------------------
+const double kTol = 1e-11;                                   // MTK::tolerance<double>, mtkmath.hpp:122
+const double kGravLen = 98090.0 / 10000.0;                   // S2<double, 98090, 10000, 1>, use-ikfom.hpp:8
+
+// cos(sqrt(x2)) and sin(sqrt(x2))/sqrt(x2)                   mtk/src/mtkmath.hpp:142-174
+void cos_sinc_sqrt(double x2, double& c, double& sc) {
+    static const double b0 = std::numeric_limits<double>::epsilon();
+    static const double b2 = std::sqrt(b0);
+    static const double bn = std::sqrt(b2);
+    if (x2 >= bn) {
+        const double x = std::sqrt(x2);
+        c = std::cos(x);
+        sc = std::sin(x) / x;
+        return;
+    }
+    static const double inv[] = {1 / 3., 1 / 4., 1 / 5., 1 / 6., 1 / 7., 1 / 8., 1 / 9.};
+    double cosi = 1., sinc = 1.;
+    double term = -1 / 2. * x2;
+    for (int i = 0; i < 3; ++i) {
+        cosi += term;
+        term *= inv[2 * i];
+        sinc += term;
+        term *= -inv[2 * i + 1] * x2;
+    }
+    c = cosi; sc = sinc;
+}
+// MTK::exp (mtkmath.hpp:250-256) into a quaternion: vec = sinc * scale * v, w = cos
+Quat exp_quat(const V3& v, double scale) {
+    double c, sc;
+    cos_sinc_sqrt(scale * scale * dot3(v, v), c, sc);
+    const double mult = sc * scale;
+    Quat q;
+    q.x = mult * v.a[0]; q.y = mult * v.a[1]; q.z = mult * v.a[2]; q.w = c;
+    return q;
+}
+Quat qmul(const Quat& a, const Quat& b) {                    // Eigen quaternion product
+    Quat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+    r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+    return r;
+}
+Quat qconj(const Quat& q) { Quat r; r.x = -q.x; r.y = -q.y; r.z = -q.z; r.w = q.w; return r; }
+M3 qmatrix(const Quat& q) {                                  // Eigen toRotationMatrix
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    M3 r;
+    r(0, 0) = 1 - (tyy + tzz); r(0, 1) = txy - twz;       r(0, 2) = txz + twy;
+    r(1, 0) = txy + twz;       r(1, 1) = 1 - (txx + tzz); r(1, 2) = tyz - twx;
+    r(2, 0) = txz - twy;       r(2, 1) = tyz + twx;       r(2, 2) = 1 - (txx + tyy);
+    return r;
+}
+// SO3::log (mtk/types/SOn.hpp:293-297 -> mtkmath.hpp:268-288, scale 2, plus_minus_periodicity)
+V3 so3_log(const Quat& q) {
+    V3 v = v3(q.x, q.y, q.z);
+    double nv = norm3(v);
+    if (nv < kTol) nv = kTol;
+    const double s = 2.0 / nv * std::atan(nv / q.w);
+    return v3(s * v.a[0], s * v.a[1], s * v.a[2]);
+}
+// A_matrix (mtkmath.hpp:236-247)
+M3 A_matrix(const V3& v) {
+    const double sq = v.a[0] * v.a[0] + v.a[1] * v.a[1] + v.a[2] * v.a[2];
+    const double n = std::sqrt(sq);
+    M3 res = M3::identity();
+    if (n < kTol) return res;
+    const M3 h = hat(v);
+    const M3 hh = h * h;
+    const double ca = (1 - std::cos(n)) / sq, cb = (1 - std::sin(n) / n) / sq;
+    for (int i = 0; i < 9; ++i) res.a[i] += ca * h.a[i] + cb * hh.a[i];
+    return res;
+}
+
+// S2 with S2_typ == 1 (mtk/types/S2.hpp:213-231)
+Mat<3, 2> S2_Bx(const V3& vec) {
+    Mat<3, 2> B = Mat<3, 2>::zero();
+    const double L = kGravLen;
+    if (vec.a[0] + L > kTol) {
+        const double den = L + vec.a[0];
+        B(0, 0) = -vec.a[1];                       B(0, 1) = -vec.a[2];
+        B(1, 0) = L - vec.a[1] * vec.a[1] / den;   B(1, 1) = -vec.a[2] * vec.a[1] / den;
+        B(2, 0) = -vec.a[2] * vec.a[1] / den;      B(2, 1) = L - vec.a[2] * vec.a[2] / den;
+        for (double& v : B.a) v /= L;
+    } else {
+        B(1, 1) = -1;
+        B(2, 0) = 1;
+    }
+    return B;
+}
+// S2::boxplus (S2.hpp:136-142)
+V3 S2_boxplus(const V3& vec, double d0, double d1) {
+    Mat<2, 1> d; d.a[0] = d0; d.a[1] = d1;
+    const V3 Bu = S2_Bx(vec) * d;
+    return qmatrix(exp_quat(Bu, 0.5)) * vec;                 // scalar(scale/2), scale = 1
+}
+// S2::boxminus (S2.hpp:144-167): res = vec [-] other
+void S2_boxminus(const V3& vec, const V3& other, double res[2]) {
+    const double v_sin = norm3(hat(vec) * other);
+    const double v_cos = dot3(vec, other);
+    const double theta = std::atan2(v_sin, v_cos);
+    if (v_sin < kTol) {
+        if (std::fabs(theta) > kTol) { res[0] = 3.1415926; res[1] = 0; }
+        else { res[0] = 0; res[1] = 0; }
+        return;
+    }
+    const Mat<2, 1> r = transpose(S2_Bx(other)) * (hat(other) * vec);
+    res[0] = theta / v_sin * r.a[0];
+    res[1] = theta / v_sin * r.a[1];
+}
+// S2_Nx_yy (S2.hpp:259-264)
+Mat<2, 3> S2_Nx_yy(const V3& vec) {
+    Mat<2, 3> N = transpose(S2_Bx(vec)) * hat(vec);
+    for (double& v : N.a) v = 1 / kGravLen / kGravLen * v;
+    return N;
+}
+// S2_Mx (S2.hpp:266-280); scalar(1/2) there is an integer division, i.e. exp(Bu, 0) = identity
+Mat<3, 2> S2_Mx(const V3& vec, double d0, double d1) {
+    const Mat<3, 2> Bx = S2_Bx(vec);
+    Mat<3, 2> res;
+    if (std::sqrt(d0 * d0 + d1 * d1) < kTol) {
+        res = hat(vec) * Bx;
+    } else {
+        Mat<2, 1> d; d.a[0] = d0; d.a[1] = d1;
+        const V3 Bu = Bx * d;
+        const M3 Rexp = qmatrix(exp_quat(Bu, 0.0));
+        res = Rexp * hat(vec) * transpose(A_matrix(Bu)) * Bx;
+    }
+    for (double& v : res.a) v = -v;
+    return res;
+}
+
+// P rows [idx, idx+k) <- J * rows ; then P cols [idx, idx+k) <- cols * J^T   (esekfom.hpp:1672-1678)
+template <int k>
+void rows_times(double* P, int idx, const Mat<k, k>& J) {
+    for (int c = 0; c < DOF; ++c) {
+        double t[k];
+        for (int i = 0; i < k; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < k; ++j) s += J(i, j) * P[(idx + j) * DOF + c];
+            t[i] = s;
+        }
+        for (int i = 0; i < k; ++i) P[(idx + i) * DOF + c] = t[i];
+    }
+}
+template <int k>
+void cols_times_T(double* P, int idx, const Mat<k, k>& J) {
+    for (int r = 0; r < DOF; ++r) {
+        double t[k];
+        for (int i = 0; i < k; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < k; ++j) s += P[r * DOF + idx + j] * J(i, j);
+            t[i] = s;
+        }
+        for (int i = 0; i < k; ++i) P[r * DOF + idx + i] = t[i];
+    }
+}
+
+const int kSO3Index[2] = {3, 6};                             // x_.SO3_state (build_manifold.hpp:204-212)
+const int kS2Index = 21;                                     // x_.S2_state
+
+double now_seconds() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// state_ikfom
+// ------------------------------------------------------------------------------------------
+void state_ikfom::boxplus(const double d[DOF]) {
+    // vect: += (mtk/types/vect.hpp:117-119); SO3: q <- q * exp(d) (SOn.hpp:233-236); S2 (S2.hpp:136)
+    pos.x += d[0]; pos.y += d[1]; pos.z += d[2];
+    rot = qmul(rot, exp_quat(v3(d[3], d[4], d[5]), 0.5));
+    offset_R_L_I = qmul(offset_R_L_I, exp_quat(v3(d[6], d[7], d[8]), 0.5));
+    offset_T_L_I.x += d[9]; offset_T_L_I.y += d[10]; offset_T_L_I.z += d[11];
+    vel.x += d[12]; vel.y += d[13]; vel.z += d[14];
+    bg.x += d[15]; bg.y += d[16]; bg.z += d[17];
+    ba.x += d[18]; ba.y += d[19]; ba.z += d[20];
+    const V3 g = S2_boxplus(v3(grav), d[21], d[22]);
+    grav.x = g.a[0]; grav.y = g.a[1]; grav.z = g.a[2];
+}
+void state_ikfom::boxminus(double r[DOF], const state_ikfom& o) const {
+    r[0] = pos.x - o.pos.x; r[1] = pos.y - o.pos.y; r[2] = pos.z - o.pos.z;
+    V3 t = so3_log(qmul(qconj(o.rot), rot));                 // SOn.hpp:237-239
+    r[3] = t.a[0]; r[4] = t.a[1]; r[5] = t.a[2];
+    t = so3_log(qmul(qconj(o.offset_R_L_I), offset_R_L_I));
+    r[6] = t.a[0]; r[7] = t.a[1]; r[8] = t.a[2];
+    r[9] = offset_T_L_I.x - o.offset_T_L_I.x; r[10] = offset_T_L_I.y - o.offset_T_L_I.y; r[11] = offset_T_L_I.z - o.offset_T_L_I.z;
+    r[12] = vel.x - o.vel.x; r[13] = vel.y - o.vel.y; r[14] = vel.z - o.vel.z;
+    r[15] = bg.x - o.bg.x; r[16] = bg.y - o.bg.y; r[17] = bg.z - o.bg.z;
+    r[18] = ba.x - o.ba.x; r[19] = ba.y - o.ba.y; r[20] = ba.z - o.ba.z;
+    S2_boxminus(v3(grav), v3(o.grav), r + 21);
+}
+void state_ikfom::to_array(double x[26]) const {
+    x[0] = pos.x; x[1] = pos.y; x[2] = pos.z;
+    x[3] = rot.x; x[4] = rot.y; x[5] = rot.z; x[6] = rot.w;
+    x[7] = offset_R_L_I.x; x[8] = offset_R_L_I.y; x[9] = offset_R_L_I.z; x[10] = offset_R_L_I.w;
+    x[11] = offset_T_L_I.x; x[12] = offset_T_L_I.y; x[13] = offset_T_L_I.z;
+    x[14] = vel.x; x[15] = vel.y; x[16] = vel.z;
+    x[17] = bg.x; x[18] = bg.y; x[19] = bg.z;
+    x[20] = ba.x; x[21] = ba.y; x[22] = ba.z;
+    x[23] = grav.x; x[24] = grav.y; x[25] = grav.z;
+}
+state_ikfom state_ikfom::from_array(const double x[26]) {
+    state_ikfom s;
+    s.pos = {x[0], x[1], x[2]};
+    s.rot.x = x[3]; s.rot.y = x[4]; s.rot.z = x[5]; s.rot.w = x[6];
+    s.offset_R_L_I.x = x[7]; s.offset_R_L_I.y = x[8]; s.offset_R_L_I.z = x[9]; s.offset_R_L_I.w = x[10];
+    s.offset_T_L_I = {x[11], x[12], x[13]};
+    s.vel = {x[14], x[15], x[16]};
+    s.bg = {x[17], x[18], x[19]};
+    s.ba = {x[20], x[21], x[22]};
+    s.grav = {x[23], x[24], x[25]};
+    return s;
+}
+void state_ikfom::pose14(double p[14]) const {
+    p[0] = pos.x; p[1] = pos.y; p[2] = pos.z;
+    p[3] = rot.x; p[4] = rot.y; p[5] = rot.z; p[6] = rot.w;
+    p[7] = offset_R_L_I.x; p[8] = offset_R_L_I.y; p[9] = offset_R_L_I.z; p[10] = offset_R_L_I.w;
+    p[11] = offset_T_L_I.x; p[12] = offset_T_L_I.y; p[13] = offset_T_L_I.z;
+}
+
+// ------------------------------------------------------------------------------------------
+// esekf
+// ------------------------------------------------------------------------------------------
+esekf::esekf() {
+    for (int i = 0; i < DOF * DOF; ++i) P_[i] = 0.0;
+    for (int i = 0; i < DOF; ++i) { P_[i * DOF + i] = 1.0; limit_[i] = 0.001; }
+}
+void esekf::init_dyn_share(measurementModel_dyn_share h, int maximum_iteration, const double limit_vector[DOF]) {
+    h_dyn_share_ = std::move(h);                             // esekfom.hpp:244
+    maximum_iter_ = maximum_iteration;                       // esekfom.hpp:246
+    for (int i = 0; i < DOF; ++i) limit_[i] = limit_vector[i];
+}
+void esekf::change_P(const double* P) { std::memcpy(P_, P, sizeof(P_)); }
+
+void esekf::update_iterated_dyn_share_modified(double R, double& solve_time) {
+    stats_ = update_stats();
+    dyn_share_datastruct dyn_share;
+    dyn_share.valid = true;
+    dyn_share.converge = true;                               // esekfom.hpp:1623-1624
+    int t = 0;
+    const state_ikfom x_propagated = x_;                     // :1628
+    double P_propagated[DOF * DOF];
+    std::memcpy(P_propagated, P_, sizeof(P_));               // :1629
+
+    double K_h[DOF];
+    double K_x[DOF * DOF];
+    double dx_new[DOF];
+    for (double& v : dx_new) v = 0.0;                        // :1635
+
+    for (int i = -1; i < maximum_iter_; ++i) {               // :1636
+        dyn_share.valid = true;
+        const double t_meas = now_seconds();
+        if (dyn_share.converge) ++stats_.n_search;
+        h_dyn_share_(x_, dyn_share);                         // :1639
+        stats_.measure_seconds += now_seconds() - t_meas;
+        ++stats_.n_calls;
+        stats_.last_m = dyn_share.m;
+        stats_.last_res_mean = dyn_share.res_mean;
+        if (!dyn_share.valid) continue;                      // :1641-1644
+
+        const double solve_start = now_seconds();
+        const int dof_Measurement = dyn_share.m;             // :1653
+        double dx[DOF];
+        x_.boxminus(dx, x_propagated);                       // :1655
+        for (int k = 0; k < DOF; ++k) dx_new[k] = dx[k];
+        std::memcpy(P_, P_propagated, sizeof(P_));           // :1660
+
+        for (int idx : kSO3Index) {                          // :1665-1680
+            const M3 J = transpose(A_matrix(v3(dx[idx], dx[idx + 1], dx[idx + 2])));
+            const V3 seg = J * v3(dx_new[idx], dx_new[idx + 1], dx_new[idx + 2]);
+            dx_new[idx] = seg.a[0]; dx_new[idx + 1] = seg.a[1]; dx_new[idx + 2] = seg.a[2];
+            rows_times<3>(P_, idx, J);
+            cols_times_T<3>(P_, idx, J);
+        }
+        {                                                    // :1684-1703
+            const int idx = kS2Index;
+            const Mat<2, 2> J = S2_Nx_yy(v3(x_.grav)) * S2_Mx(v3(x_propagated.grav), dx[idx], dx[idx + 1]);
+            const double d0 = J(0, 0) * dx_new[idx] + J(0, 1) * dx_new[idx + 1];
+            const double d1 = J(1, 0) * dx_new[idx] + J(1, 1) * dx_new[idx + 1];
+            dx_new[idx] = d0; dx_new[idx + 1] = d1;
+            rows_times<2>(P_, idx, J);
+            cols_times_T<2>(P_, idx, J);
+        }
+
+        if (DOF > dof_Measurement) {
+            // fewer rows than states: K = P H^T (H P H^T / R + I)^-1 / R, H zero-padded   :1720-1750
+            const int m = dof_Measurement;
+            std::vector<double> H((size_t)m * DOF, 0.0);
+            for (int r = 0; r < m; ++r)
+                for (int c = 0; c < 12; ++c) H[(size_t)r * DOF + c] = dyn_share.h_x[(size_t)r * 12 + c];
+            std::vector<double> PHt((size_t)DOF * m), S((size_t)m * m), Sinv((size_t)m * m), Kg((size_t)DOF * m);
+            for (int a = 0; a < DOF; ++a)
+                for (int r = 0; r < m; ++r) {
+                    double s = 0.0;
+                    for (int c = 0; c < DOF; ++c) s += P_[a * DOF + c] * H[(size_t)r * DOF + c];
+                    PHt[(size_t)a * m + r] = s;
+                }
+            for (int r = 0; r < m; ++r)
+                for (int q = 0; q < m; ++q) {
+                    double s = 0.0;
+                    for (int c = 0; c < DOF; ++c) s += H[(size_t)r * DOF + c] * PHt[(size_t)c * m + q];
+                    S[(size_t)r * m + q] = s / R + (r == q ? 1.0 : 0.0);
+                }
+            invert(S.data(), Sinv.data(), m);
+            for (int a = 0; a < DOF; ++a)
+                for (int q = 0; q < m; ++q) {
+                    double s = 0.0;
+                    for (int r = 0; r < m; ++r) s += PHt[(size_t)a * m + r] * Sinv[(size_t)r * m + q];
+                    Kg[(size_t)a * m + q] = s / R;
+                }
+            for (int a = 0; a < DOF; ++a) {
+                double s = 0.0;
+                for (int r = 0; r < m; ++r) s += Kg[(size_t)a * m + r] * dyn_share.h[r];
+                K_h[a] = s;
+                for (int c = 0; c < DOF; ++c) {
+                    double v = 0.0;
+                    for (int r = 0; r < m; ++r) v += Kg[(size_t)a * m + r] * H[(size_t)r * DOF + c];
+                    K_x[a * DOF + c] = v;
+                }
+            }
+        } else {
+            // information form                                                      :1788-1815
+            double PR[DOF * DOF], P_temp[DOF * DOF], P_inv[DOF * DOF];
+            for (int k = 0; k < DOF * DOF; ++k) PR[k] = P_[k] / R;
+            invert(PR, P_temp, DOF);                         // (P_/R).inverse()
+            for (int a = 0; a < 12; ++a)
+                for (int b = 0; b < 12; ++b) P_temp[a * DOF + b] += dyn_share.HTH[a * 12 + b];   // :1791
+            invert(P_temp, P_inv, DOF);                      // :1808
+            for (int a = 0; a < DOF; ++a) {                  // K_h = P_inv[:, 0:12] H^T h          :1810
+                double s = 0.0;
+                for (int c = 0; c < 12; ++c) s += P_inv[a * DOF + c] * dyn_share.HTh[c];
+                K_h[a] = s;
+            }
+            for (double& v : K_x) v = 0.0;                   // :1814
+            for (int a = 0; a < DOF; ++a)                    // K_x[:, 0:12] = P_inv[:, 0:12] HTH   :1815
+                for (int b = 0; b < 12; ++b) {
+                    double s = 0.0;
+                    for (int c = 0; c < 12; ++c) s += P_inv[a * DOF + c] * dyn_share.HTH[c * 12 + b];
+                    K_x[a * DOF + b] = s;
+                }
+        }
+
+        double dx_[DOF];                                     // dx_ = K_h + (K_x - I) dx_new      :1821
+        for (int a = 0; a < DOF; ++a) {
+            double s = 0.0;
+            for (int c = 0; c < DOF; ++c) s += (K_x[a * DOF + c] - (a == c ? 1.0 : 0.0)) * dx_new[c];
+            dx_[a] = K_h[a] + s;
+        }
+        x_.boxplus(dx_);                                     // :1823
+        dyn_share.converge = true;                           // :1824-1832
+        for (int k = 0; k < DOF; ++k) {
+            if (std::fabs(dx_[k]) > limit_[k]) { dyn_share.converge = false; break; }
+        }
+        if (dyn_share.converge) ++t;
+        if (!t && i == maximum_iter_ - 2) dyn_share.converge = true;   // :1835-1838
+
+        if (t > 1 || i == maximum_iter_ - 1) {               // covariance update           :1841-1935
+            double L_[DOF * DOF];
+            std::memcpy(L_, P_, sizeof(P_));                 // :1843
+            for (int idx : kSO3Index) {                      // :1847-1872
+                const M3 J = transpose(A_matrix(v3(dx_[idx], dx_[idx + 1], dx_[idx + 2])));
+                for (int c = 0; c < DOF; ++c) {              // L rows <- J * P rows
+                    const V3 col = J * v3(P_[idx * DOF + c], P_[(idx + 1) * DOF + c], P_[(idx + 2) * DOF + c]);
+                    L_[idx * DOF + c] = col.a[0]; L_[(idx + 1) * DOF + c] = col.a[1]; L_[(idx + 2) * DOF + c] = col.a[2];
+                }
+                for (int c = 0; c < 12; ++c) {               // K_x rows (first 12 columns)
+                    const V3 col = J * v3(K_x[idx * DOF + c], K_x[(idx + 1) * DOF + c], K_x[(idx + 2) * DOF + c]);
+                    K_x[idx * DOF + c] = col.a[0]; K_x[(idx + 1) * DOF + c] = col.a[1]; K_x[(idx + 2) * DOF + c] = col.a[2];
+                }
+                cols_times_T<3>(L_, idx, J);
+                cols_times_T<3>(P_, idx, J);
+            }
+            {                                                // :1874-1907
+                const int idx = kS2Index;
+                const Mat<2, 2> J = S2_Nx_yy(v3(x_.grav)) * S2_Mx(v3(x_propagated.grav), dx_[idx], dx_[idx + 1]);
+                for (int c = 0; c < DOF; ++c) {
+                    const double a0 = P_[idx * DOF + c], a1 = P_[(idx + 1) * DOF + c];
+                    L_[idx * DOF + c] = J(0, 0) * a0 + J(0, 1) * a1;
+                    L_[(idx + 1) * DOF + c] = J(1, 0) * a0 + J(1, 1) * a1;
+                }
+                for (int c = 0; c < 12; ++c) {
+                    const double a0 = K_x[idx * DOF + c], a1 = K_x[(idx + 1) * DOF + c];
+                    K_x[idx * DOF + c] = J(0, 0) * a0 + J(0, 1) * a1;
+                    K_x[(idx + 1) * DOF + c] = J(1, 0) * a0 + J(1, 1) * a1;
+                }
+                cols_times_T<2>(L_, idx, J);
+                cols_times_T<2>(P_, idx, J);
+            }
+            // P_ = L_ - K_x[:, 0:12] * P_[0:12, :]                                       :1931
+            double Pn[DOF * DOF];
+            for (int a = 0; a < DOF; ++a)
+                for (int c = 0; c < DOF; ++c) {
+                    double s = 0.0;
+                    for (int b = 0; b < 12; ++b) s += K_x[a * DOF + b] * P_[b * DOF + c];
+                    Pn[a * DOF + c] = L_[a * DOF + c] - s;
+                }
+            std::memcpy(P_, Pn, sizeof(P_));
+            stats_.converged = t > 1;
+            const double dt = now_seconds() - solve_start;
+            solve_time += dt; stats_.solve_seconds += dt;
+            return;
+        }
+        const double dt = now_seconds() - solve_start;
+        solve_time += dt; stats_.solve_seconds += dt;
+    }
+}
+
+}  // namespace lio

@@ -1,0 +1,89 @@
+// lio_esekf.hpp -- host-side iterated error-state Kalman filter on the 23-DOF LIO manifold.
+//
+// Mirrors the pieces of the reference's IKFoM instantiation that surround the measurement path,
+// with the same names and call shapes, so that host code written against the reference reads the
+// same (paths relative to the reference repository):
+//   state_ikfom                          include/use-ikfom.hpp:21-30 (MTK_BUILD_MANIFOLD)
+//   esekfom::dyn_share_datastruct        include/IKFoM_toolkit/esekfom/esekfom.hpp:79-89
+//   esekfom::esekf::init_dyn_share       esekfom.hpp:239-258
+//   esekf::update_iterated_dyn_share_modified   esekfom.hpp:1620-1938
+//   get_x / get_P / change_x / change_P  esekfom.hpp:1940-1961
+// The reference builds these from Eigen + Boost.PP (neither ships with it nor with this image);
+// here they are plain C++17 with fixed-size arrays.  IMU propagation (predict, esekfom.hpp:280)
+// stays with the caller and is out of scope.
+//
+// The measurement callback has the reference's shape
+//     void h(state_ikfom& s, dyn_share_datastruct& d)          (esekfom.hpp:130)
+// and, being the consumer of the GPU path, receives the reduced information form
+// (d.HTH = h_x^T h_x, d.HTh = h_x^T h, d.m rows) instead of the m x 12 matrix; d.h_x / d.h are
+// filled only when m < 23, where the reference switches to the dense gain (esekfom.hpp:1720-1750).
+#pragma once
+#include <functional>
+#include <vector>
+
+namespace lio {
+
+constexpr int DOF = 23;                       // state_ikfom::DOF
+constexpr int DIM = 24;                       // state_ikfom::DIM (two quaternions, S2 stored as 3-vector)
+
+struct Vec3 { double x = 0, y = 0, z = 0; };
+struct Quat { double x = 0, y = 0, z = 0, w = 1; };   // Eigen coefficient order
+
+// DOF layout: pos 0, rot 3, offset_R_L_I 6, offset_T_L_I 9, vel 12, bg 15, ba 18, grav 21 (S2)
+struct state_ikfom {
+    Vec3 pos;
+    Quat rot;
+    Quat offset_R_L_I;
+    Vec3 offset_T_L_I;
+    Vec3 vel, bg, ba;
+    Vec3 grav{0.0, 0.0, -9.809};               // S2 of length 98090/10000 (use-ikfom.hpp:8)
+
+    void boxplus(const double dx[DOF]);                         // x <- x [+] dx
+    void boxminus(double res[DOF], const state_ikfom& other) const;   // res = x [-] other
+    void to_array(double x26[26]) const;
+    static state_ikfom from_array(const double x26[26]);
+    void pose14(double p[14]) const;           // the block handed to lio_measure
+};
+
+struct dyn_share_datastruct {
+    bool valid = true;
+    bool converge = true;
+    int m = 0;                                 // rows of h_x
+    double HTH[144];                           // h_x^T h_x, row-major 12x12
+    double HTh[12];                            // h_x^T h
+    std::vector<double> h_x;                   // m x 12 row-major, only when m < DOF
+    std::vector<double> h;                     // m
+    double res_mean = 0.0;
+};
+
+typedef std::function<void(state_ikfom&, dyn_share_datastruct&)> measurementModel_dyn_share;
+
+struct update_stats {
+    int n_calls = 0, n_search = 0, last_m = 0;
+    bool converged = false;
+    double last_res_mean = 0.0, solve_seconds = 0.0, measure_seconds = 0.0;
+};
+
+class esekf {
+public:
+    esekf();
+    void init_dyn_share(measurementModel_dyn_share h, int maximum_iteration, const double limit_vector[DOF]);
+    void set_measurement_model(measurementModel_dyn_share h) { h_dyn_share_ = std::move(h); }
+    // R = LASER_POINT_COV (laserMapping.cpp:14, :2380)
+    void update_iterated_dyn_share_modified(double R, double& solve_time);
+    const state_ikfom& get_x() const { return x_; }
+    const double* get_P() const { return P_; }             // 23 x 23 row-major
+    void change_x(const state_ikfom& s) { x_ = s; }
+    void change_P(const double* P);
+    const update_stats& stats() const { return stats_; }
+
+private:
+    state_ikfom x_;
+    double P_[DOF * DOF];
+    double limit_[DOF];
+    int maximum_iter_ = 0;
+    measurementModel_dyn_share h_dyn_share_;
+    update_stats stats_;
+};
+
+}  // namespace lio

@@ -1,0 +1,96 @@
+// lio_kernels.h -- launch interface between the host side of liblio_hip.so (lio_ctx.hip) and the
+// gfx950 kernels (lio_knn.hip, lio_measure.hip, lio_map.hip).  Internal; the public boundary is
+// include/lio_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "lio_common.h"
+
+namespace lio {
+
+// ---- k-NN (replaces KD_TREE::Nearest_Search / Search, ikd_Tree.cpp:367-397, 869-1013) ---------
+struct KnnArgs {
+    const float4*    map_pts;       // Morton-sorted map
+    const HashEntry* table;
+    Grid             grid;
+    const float4*    body;          // != nullptr: queries = pose (x) body points (laserMapping.cpp:1895)
+    const float4*    world_in;      // else: queries given in the world frame
+    Pose14           pose;
+    int              nq;
+    int              nq_stride;     // leading dimension of nbr
+    float4*          world_out;     // feats_down_world (may be nullptr)
+    float4*          nbr;           // [5][nq_stride]: x, y, z, sqdist of the k-th neighbour
+    uint8_t*         cnt;           // [nq] neighbours found (0..5)
+    uint32_t*        unresolved;    // [nq] list of queries whose result is not proven by the 27-cell search
+    uint32_t*        n_unresolved;  // device counter
+    unsigned long long* cand_total; // device counter: sum of C(q)
+};
+// lanes_per_query in {8, 16, 32, 64}
+hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s);
+
+struct TreeArgs {
+    const float4*    map_pts;
+    const uint64_t*  mkeys;         // Morton key per map point (sorted)
+    Grid             grid;
+    const float4*    queries;       // world-frame queries, indexed by the entries of `list`
+    const uint32_t*  list;
+    const uint32_t*  n_list;        // device counter
+    int              nq;
+    int              nq_stride;
+    float4*          nbr;
+    uint8_t*         cnt;
+};
+hipError_t launch_knn_tree(const TreeArgs& a, hipStream_t s);
+
+// ---- measurement model (replaces h_share_model's per-point body, laserMapping.cpp:1888-2002) --
+struct ResidualArgs {
+    const float4*  body;            // feats_down_body
+    int            nq;
+    int            nq_stride;
+    Pose14         pose;
+    const float4*  nbr;             // Nearest_Points
+    const uint8_t* cnt;
+    uint8_t*       sel;             // point_selected_surf (in: previous pass, out: this pass)
+    float4*        world;           // feats_down_world
+    float4*        normvec;         // normvec (n^, pd2)
+    double*        rows;            // optional [nq][13]: h_x row (12) + h, valid where sel
+    double*        partials;        // [nblocks][RED_STRIDE]
+};
+int residual_blocks(int nq);
+hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s);
+hipError_t launch_reduce_final(const double* partials, int nblocks, bool extrinsic_est_en,
+                               const uint32_t* n_unresolved, const unsigned long long* cand_total,
+                               DeviceOut* out, hipStream_t s);
+
+// ---- map construction / mutation ----------------------------------------------------------------
+hipError_t launch_point_keys(const float4* pts, uint32_t n, Grid grid, uint64_t* mkeys, uint32_t* vals,
+                             hipStream_t s);
+hipError_t launch_gather_points(const float4* src, const uint32_t* vals, uint32_t n, float4* dst,
+                                hipStream_t s);
+hipError_t launch_table_insert(const uint64_t* cell_mkeys, const uint32_t* cell_start,
+                               const uint32_t* cell_count, uint32_t n_cells, HashEntry* table,
+                               uint32_t table_mask, hipStream_t s);
+// w != 0 for every live point inside any of the nb half-open boxes; *counter += points tomb-stoned
+hipError_t launch_delete_boxes(float4* pts, uint32_t n, const float* boxes6, int nb, uint32_t* counter,
+                               hipStream_t s);
+// stream compaction of live points (w == 0) into dst; *n_out = count.  Order-preserving.
+hipError_t launch_pack_xyz(const float4* src, uint32_t n, float* dst_xyz, hipStream_t s);
+hipError_t launch_unpack_neighbors(const float4* nbr, const uint8_t* cnt, int nq, int nq_stride,
+                                   float* out_xyz, float* out_d, int* out_cnt, hipStream_t s);
+
+// ---- rocPRIM-backed helpers (lio_sort.hip) ------------------------------------------------------
+size_t sort_pairs_temp_bytes(size_t n);
+hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
+                              const uint32_t* vals_in, uint32_t* vals_out, size_t n, hipStream_t s);
+size_t rle_temp_bytes(size_t n);
+hipError_t run_length_encode_u64(void* temp, size_t temp_bytes, const uint64_t* keys, size_t n,
+                                 uint64_t* unique_out, uint32_t* counts_out, uint32_t* n_runs_out,
+                                 hipStream_t s);
+size_t scan_temp_bytes(size_t n);
+hipError_t exclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, size_t n,
+                              hipStream_t s);
+size_t select_temp_bytes(size_t n);
+// order-preserving compaction of the live (w == 0) points of src into dst; *n_out = live count
+hipError_t select_live_points(void* temp, size_t temp_bytes, const float4* src, float4* dst,
+                              uint32_t* n_out, size_t n, hipStream_t s);
+
+}  // namespace lio

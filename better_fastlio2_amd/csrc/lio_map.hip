@@ -1,0 +1,137 @@
+// lio_map.hip -- construction and mutation kernels of the GPU-resident map index, gfx950 only.
+//
+// Replaces the structural side of KD_TREE<PointType> (include/ikd-Tree/ikd_Tree.cpp): Build (:353),
+// Delete_Point_Boxes (:536) / Delete_by_range (:648-710), flatten (:1326).  The index is rebuilt
+// by sorting (no pointer tree, no re-balancing thread): Morton key per point -> radix sort
+// (rocPRIM, lio_sort.hip) -> gather -> run-length encode cells -> hash-table insert.
+#include "lio_kernels.h"
+#include "lio_math.h"
+
+namespace lio {
+
+__global__ __launch_bounds__(256) void point_keys_kernel(const float4* pts, uint32_t n, Grid grid,
+                                                         uint64_t* mkeys, uint32_t* vals) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = pts[i];
+        const uint32_t cx = (uint32_t)cell_coord(p.x, grid.inv_cell);
+        const uint32_t cy = (uint32_t)cell_coord(p.y, grid.inv_cell);
+        const uint32_t cz = (uint32_t)cell_coord(p.z, grid.inv_cell);
+        mkeys[i] = morton3(cx, cy, cz);
+        vals[i] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_points_kernel(const float4* src, const uint32_t* vals, uint32_t n,
+                                                            float4* dst) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[i] = src[vals[i]];
+}
+
+// one lane per occupied cell: claim a slot by CAS on the 64-bit key, then publish {start, count}
+__global__ __launch_bounds__(256) void table_insert_kernel(const uint64_t* cell_mkeys, const uint32_t* cell_start,
+                                                           const uint32_t* cell_count, uint32_t n_cells,
+                                                           HashEntry* table, uint32_t mask) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cells; c += gridDim.x * blockDim.x) {
+        const uint64_t mk = cell_mkeys[c];
+        const uint64_t key = pack_key(compact21(mk >> 2), compact21(mk >> 1), compact21(mk));
+        uint32_t slot = hash_key(key) & mask;
+        for (;;) {
+            unsigned long long* kp = reinterpret_cast<unsigned long long*>(&table[slot]);
+            const unsigned long long prev = atomicCAS(kp, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+            if (prev == KEY_EMPTY || prev == key) {
+                table[slot].start = cell_start[c];
+                table[slot].count = cell_count[c];
+                break;
+            }
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+
+// Delete_by_range (ikd_Tree.cpp:648-710): a live point is removed when
+// min <= p < max on every axis for any of the boxes.
+__global__ __launch_bounds__(256) void delete_boxes_kernel(float4* pts, uint32_t n, const float* boxes6, int nb,
+                                                           uint32_t* counter) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 p = pts[i];
+        if (p.w != 0.0f) continue;
+        bool hit = false;
+        for (int b = 0; b < nb; ++b) {
+            const float* bx = boxes6 + 6 * b;
+            if (bx[0] <= p.x && bx[3] > p.x && bx[1] <= p.y && bx[4] > p.y && bx[2] <= p.z && bx[5] > p.z) hit = true;
+        }
+        if (hit) {
+            p.w = 1.0f;
+            pts[i] = p;
+            atomicAdd(counter, 1u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_xyz_kernel(const float4* src, uint32_t n, float* dst) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = src[i];
+        dst[3 * (size_t)i + 0] = p.x; dst[3 * (size_t)i + 1] = p.y; dst[3 * (size_t)i + 2] = p.z;
+    }
+}
+
+// [5][stride] float4 -> the caller-facing layout of Nearest_Points: xyz [n][5][3], sqdist [n][5]
+__global__ __launch_bounds__(256) void unpack_neighbors_kernel(const float4* nbr, const uint8_t* cnt, int nq,
+                                                               int stride, float* out_xyz, float* out_d, int* out_cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float4 p = nbr[(size_t)k * stride + i];
+        if (out_xyz != nullptr) {
+            float* o = out_xyz + ((size_t)i * K + k) * 3;
+            o[0] = p.x; o[1] = p.y; o[2] = p.z;
+        }
+        if (out_d != nullptr) out_d[(size_t)i * K + k] = p.w;
+    }
+    if (out_cnt != nullptr) out_cnt[i] = (int)cnt[i];
+}
+
+static inline dim3 grid_for(uint32_t n) {
+    uint32_t b = (n + 255u) / 256u;
+    if (b > 4096u) b = 4096u;
+    if (b == 0u) b = 1u;
+    return dim3(b);
+}
+
+hipError_t launch_point_keys(const float4* pts, uint32_t n, Grid grid, uint64_t* mkeys, uint32_t* vals, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(point_keys_kernel, grid_for(n), dim3(256), 0, s, pts, n, grid, mkeys, vals);
+    return hipGetLastError();
+}
+hipError_t launch_gather_points(const float4* src, const uint32_t* vals, uint32_t n, float4* dst, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_points_kernel, grid_for(n), dim3(256), 0, s, src, vals, n, dst);
+    return hipGetLastError();
+}
+hipError_t launch_table_insert(const uint64_t* cell_mkeys, const uint32_t* cell_start, const uint32_t* cell_count,
+                               uint32_t n_cells, HashEntry* table, uint32_t table_mask, hipStream_t s) {
+    if (n_cells == 0) return hipSuccess;
+    hipLaunchKernelGGL(table_insert_kernel, grid_for(n_cells), dim3(256), 0, s, cell_mkeys, cell_start, cell_count,
+                       n_cells, table, table_mask);
+    return hipGetLastError();
+}
+hipError_t launch_delete_boxes(float4* pts, uint32_t n, const float* boxes6, int nb, uint32_t* counter, hipStream_t s) {
+    if (n == 0 || nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(delete_boxes_kernel, grid_for(n), dim3(256), 0, s, pts, n, boxes6, nb, counter);
+    return hipGetLastError();
+}
+hipError_t launch_pack_xyz(const float4* src, uint32_t n, float* dst_xyz, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_xyz_kernel, grid_for(n), dim3(256), 0, s, src, n, dst_xyz);
+    return hipGetLastError();
+}
+hipError_t launch_unpack_neighbors(const float4* nbr, const uint8_t* cnt, int nq, int nq_stride, float* out_xyz,
+                                   float* out_d, int* out_cnt, hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_neighbors_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, nbr, cnt, nq, nq_stride,
+                       out_xyz, out_d, out_cnt);
+    return hipGetLastError();
+}
+
+}  // namespace lio

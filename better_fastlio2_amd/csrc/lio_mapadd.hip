@@ -1,0 +1,135 @@
+// lio_mapadd.hip -- KD_TREE::Add_Points (include/ikd-Tree/ikd_Tree.cpp:414-489) on the GPU index.
+//
+// The reference inserts the points of a batch one after another; with down-sampling on, every
+// insert (a) box-searches the down-sample voxel of the point, (b) picks, among the point itself
+// and the points found, the one nearest the voxel centre (the new point wins ties, strict `<`
+// :440), and (c) if the voxel held more than one point or the winner is the new point, deletes
+// the voxel's points and adds the winner (:445-448).  Inserts interact only through their voxel,
+// so the batch is grouped by voxel (stable radix sort keeps the batch order inside a group) and
+// one lane folds each group sequentially -- the result equals the sequential one.
+//   voxel_keys_kernel     voxel key of each new point
+//   fold_groups_kernel    per voxel: existing points in the box (hash probes of the <= 8 grid
+//                         cells the box touches), sequential fold, tomb-stone + emit the survivor
+// The caller then appends the survivors and rebuilds the index (sort + hash), see lio_ctx.hip.
+#include "lio_device.h"
+#include "lio_kernels.h"
+#include "lio_mapadd.h"
+
+namespace lio {
+
+__device__ __forceinline__ float voxel_floor(float v, float ds) { return floorf(v / ds); }   // :424
+
+__global__ __launch_bounds__(256) void voxel_keys_kernel(const float4* pts, uint32_t n, float ds, uint64_t* vkeys,
+                                                         uint32_t* order) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = pts[i];
+        float kx = voxel_floor(p.x, ds), ky = voxel_floor(p.y, ds), kz = voxel_floor(p.z, ds);
+        kx = fminf(fmaxf(kx, -1048576.0f), 1048575.0f);
+        ky = fminf(fmaxf(ky, -1048576.0f), 1048575.0f);
+        kz = fminf(fmaxf(kz, -1048576.0f), 1048575.0f);
+        vkeys[i] = pack_key((uint32_t)((int)kx + CELL_OFF), (uint32_t)((int)ky + CELL_OFF), (uint32_t)((int)kz + CELL_OFF));
+        order[i] = i;
+    }
+}
+
+__device__ __forceinline__ bool same_point(float4 a, float4 b) {         // ikd_Tree.cpp:1365-1367, EPSS 1e-6
+    return (double)fabsf(a.x - b.x) < 1e-6 && (double)fabsf(a.y - b.y) < 1e-6 && (double)fabsf(a.z - b.z) < 1e-6;
+}
+
+__global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < a.n_groups; g += gridDim.x * blockDim.x) {
+        const uint32_t gs = a.group_start[g], gc = a.group_count[g];
+        const float ds = a.ds;
+        const float4 p0 = a.new_pts[a.order[gs]];
+        // Box_of_Point and mid_point (:424-432): fp32 box, centre through double
+        float bmin[3], bmax[3], mid[3];
+        const float pc[3] = {p0.x, p0.y, p0.z};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            bmin[ax] = voxel_floor(pc[ax], ds) * ds;
+            bmax[ax] = bmin[ax] + ds;
+            mid[ax] = (float)((double)bmin[ax] + (double)(bmax[ax] - bmin[ax]) / 2.0);
+        }
+        int c0[3], c1[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            c0[ax] = cell_coord(bmin[ax], a.grid.inv_cell);
+            c1[ax] = cell_coord(bmax[ax], a.grid.inv_cell);
+        }
+        // ---- pass 1: existing live points inside the box (Search_by_range :1015-1045) -------------
+        uint32_t n_e = 0;
+        float d_e = __uint_as_float(INF_BITS);
+        float4 e_best = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int cx = c0[0]; cx <= c1[0]; ++cx)
+            for (int cy = c0[1]; cy <= c1[1]; ++cy)
+                for (int cz = c0[2]; cz <= c1[2]; ++cz) {
+                    uint32_t st, ct;
+                    table_find(a.table, a.grid.table_mask, pack_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz), st, ct);
+                    for (uint32_t i = st; i < st + ct; ++i) {
+                        const float4 s = a.map_pts[i];
+                        if (s.w != 0.0f) continue;
+                        if (bmin[0] <= s.x && bmax[0] > s.x && bmin[1] <= s.y && bmax[1] > s.y && bmin[2] <= s.z && bmax[2] > s.z) {
+                            ++n_e;
+                            const float d = sqdist3(s.x, s.y, s.z, mid[0], mid[1], mid[2]);
+                            if (d < d_e) { d_e = d; e_best = s; }
+                        }
+                    }
+                }
+        // ---- sequential fold over the group's new points (:433-449) -------------------------------
+        bool touched = false;
+        float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
+        float d_cur = 0.0f;
+        uint32_t counter = 0;
+        for (uint32_t j = 0; j < gc; ++j) {
+            const float4 p = a.new_pts[a.order[gs + j]];
+            const float d_p = sqdist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
+            if (!touched) {
+                const bool best_is_p = !(n_e > 0 && d_e < d_p);
+                const float4 best = best_is_p ? p : e_best;
+                if (n_e > 1 || same_point(p, best)) {
+                    touched = true; cur = best; d_cur = best_is_p ? d_p : d_e; ++counter;
+                }
+            } else {
+                const bool best_is_p = !(d_cur < d_p);
+                const float4 best = best_is_p ? p : cur;
+                if (same_point(p, best)) { cur = best; d_cur = best_is_p ? d_p : d_cur; ++counter; }
+            }
+        }
+        // ---- pass 2: Delete_by_range of the box + Add_by_point of the survivor --------------------
+        float4 outp = make_float4(0.f, 0.f, 0.f, 1.0f);      // w = 1: nothing to append
+        if (touched) {
+            for (int cx = c0[0]; cx <= c1[0]; ++cx)
+                for (int cy = c0[1]; cy <= c1[1]; ++cy)
+                    for (int cz = c0[2]; cz <= c1[2]; ++cz) {
+                        uint32_t st, ct;
+                        table_find(a.table, a.grid.table_mask, pack_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz), st, ct);
+                        for (uint32_t i = st; i < st + ct; ++i) {
+                            float4 s = a.map_pts[i];
+                            if (s.w != 0.0f) continue;
+                            if (bmin[0] <= s.x && bmax[0] > s.x && bmin[1] <= s.y && bmax[1] > s.y && bmin[2] <= s.z && bmax[2] > s.z) {
+                                s.w = 1.0f;
+                                a.map_pts[i] = s;
+                            }
+                        }
+                    }
+            outp = make_float4(cur.x, cur.y, cur.z, 0.0f);
+        }
+        a.out_pts[g] = outp;
+        if (counter != 0) atomicAdd(a.n_added, counter);
+    }
+}
+
+hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint32_t b = (n + 255u) / 256u; if (b > 4096u) b = 4096u;
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3(b), dim3(256), 0, s, pts, n, ds, vkeys, order);
+    return hipGetLastError();
+}
+hipError_t launch_fold_groups(const FoldArgs& a, hipStream_t s) {
+    if (a.n_groups == 0) return hipSuccess;
+    uint32_t b = (a.n_groups + 63u) / 64u; if (b > 8192u) b = 8192u;
+    hipLaunchKernelGGL(fold_groups_kernel, dim3(b), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace lio

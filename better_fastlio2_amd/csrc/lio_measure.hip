@@ -1,0 +1,186 @@
+// lio_measure.hip -- fused plane fit + residual + Jacobian + reduction, gfx950 only.
+//
+// Replaces the per-point body and the two serial loops of h_share_model
+// (src/laserMapping.cpp:1888-1940 OMP loop, :1942-1954 compaction, :1967-2002 Jacobian rows) and
+// the h_x^T h_x / h_x^T h products of its consumer (esekfom.hpp:1790,1810): the filter needs only
+// those 12x12 + 12 numbers, so the m x 12 matrix never leaves the GPU unless asked for.
+//
+//   residual_kernel<EXT, SEARCH>  one lane per scan point: world transform (fp64 -> fp32),
+//       neighbour gate (:1911), esti_plane (fp32 Householder QR, lio_math.h), pd2 and the
+//       s > 0.9 test (:1925-1930), the fp64 Jacobian row (:1976-2001); the rows of a 256-point
+//       workgroup are staged in LDS and reduced to the unique entries of H^T H, H^T h, the
+//       residual sum and the row count in a FIXED order (run-to-run bit-stable, no atomics).
+//   reduce_final_kernel<EXT>      one workgroup: sums the per-workgroup partials in block order,
+//       expands the symmetric matrix and fills the DeviceOut record that is copied to the host.
+#include "lio_kernels.h"
+#include "lio_math.h"
+
+namespace lio {
+
+template <bool EXT> struct RedShape {
+    static constexpr int NC = EXT ? 12 : 6;            // non-zero columns of h_x
+    static constexpr int NP = NC * (NC + 1) / 2;       // unique entries of H^T H
+    static constexpr int COL_H = NC;                   // staged columns: J[0..NC), h, |pd2|, 1
+    static constexpr int COL_RES = NC + 1;
+    static constexpr int COL_ONE = NC + 2;
+    static constexpr int NCOLS = NC + 3;
+    static constexpr int NE = NP + NC + 2;             // + H^T h, residual sum, count
+    static constexpr int NEP = EXT ? 128 : 32;         // lanes per row segment (>= NE)
+    static constexpr int SEG = 256 / NEP;              // row segments per workgroup
+    static constexpr int RS = 256 / SEG;               // rows per segment
+};
+
+// entry e -> the two staged columns whose product is summed
+template <bool EXT>
+__device__ __forceinline__ void entry_columns(int e, int& ca, int& cb) {
+    typedef RedShape<EXT> S;
+    if (e < S::NP) {
+        // row-major upper triangle: (0,0),(0,1)...(0,NC-1),(1,1)...
+        int a = 0, rem = e, len = S::NC;
+        while (rem >= len) { rem -= len; --len; ++a; }
+        ca = a; cb = a + rem;
+    } else if (e < S::NP + S::NC) {
+        ca = e - S::NP; cb = S::COL_H;
+    } else if (e == S::NP + S::NC) {
+        ca = S::COL_RES; cb = S::COL_ONE;
+    } else {
+        ca = S::COL_ONE; cb = S::COL_ONE;
+    }
+}
+
+template <bool EXT, bool SEARCH>
+__global__ __launch_bounds__(256) void residual_kernel(ResidualArgs a) {
+    typedef RedShape<EXT> S;
+    __shared__ double s_rows[256][S::NCOLS];
+    __shared__ double s_part[S::SEG][S::NEP];
+
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * 256 + tid;
+    bool sel = false;
+    double row[12];
+    double h = 0.0;
+    float pd2 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) row[c] = 0.0;
+
+    if (i < a.nq) {
+        const float4 b = a.body[i];
+        const PoseQ s = pose_unpack(a.pose);
+        float wx, wy, wz;
+        body_to_world(s, b.x, b.y, b.z, wx, wy, wz);                       // :1894-1899
+        a.world[i] = make_float4(wx, wy, wz, b.w);
+        bool cand;
+        if (SEARCH) {
+            // points_near.size() < 5 ? false : sqdis[4] > 5 ? false : true          :1911
+            const float d5 = a.nbr[(size_t)4 * a.nq_stride + i].w;
+            cand = (a.cnt[i] >= K) && !(d5 > 5.0f);
+        } else {
+            cand = a.sel[i] != 0;                                          // :1916 (previous flag)
+        }
+        if (cand) {
+            float px[5], py[5], pz[5];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float4 p = a.nbr[(size_t)k * a.nq_stride + i];
+                px[k] = p.x; py[k] = p.y; pz[k] = p.z;
+            }
+            float nx, ny, nz;
+            sel = point_residual(px, py, pz, wx, wy, wz, b.x, b.y, b.z, nx, ny, nz, pd2);
+            if (sel) {
+                a.normvec[i] = make_float4(nx, ny, nz, pd2);               // :1933-1936
+                jacobian_row<EXT>(s, b.x, b.y, b.z, nx, ny, nz, pd2, row, h);
+            }
+        }
+        a.sel[i] = sel ? 1 : 0;
+        if (a.rows != nullptr && sel) {
+            double* dst = a.rows + (size_t)i * 13;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) dst[c] = row[c];
+            dst[12] = h;
+        }
+    }
+
+    // ---- stage the row (zeros when not selected) ---------------------------------------------
+#pragma unroll
+    for (int c = 0; c < S::NC; ++c) s_rows[tid][c] = row[c];
+    s_rows[tid][S::COL_H] = h;
+    s_rows[tid][S::COL_RES] = sel ? (double)__builtin_fabsf(pd2) : 0.0;     // res_last[i] :1937
+    s_rows[tid][S::COL_ONE] = sel ? 1.0 : 0.0;
+    __syncthreads();
+
+    // ---- workgroup reduction: lane (seg, e) sums rows [seg*RS, (seg+1)*RS) of entry e ---------
+    const int e = tid % S::NEP, seg = tid / S::NEP;
+    double acc = 0.0;
+    if (e < S::NE) {
+        int ca, cb;
+        entry_columns<EXT>(e, ca, cb);
+        const int r0 = seg * S::RS;
+        for (int r = 0; r < S::RS; ++r) acc += s_rows[r0 + r][ca] * s_rows[r0 + r][cb];
+    }
+    s_part[seg][e] = acc;
+    __syncthreads();
+    if (tid < S::NE) {
+        double t = 0.0;
+#pragma unroll
+        for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
+        a.partials[(size_t)blockIdx.x * RED_STRIDE + tid] = t;
+    }
+}
+
+int residual_blocks(int nq) { return (nq + 255) / 256; }
+
+hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool ext, hipStream_t s) {
+    if (a.nq <= 0) return hipSuccess;
+    const dim3 grid(residual_blocks(a.nq)), block(256);
+    if (ext) {
+        if (do_search) hipLaunchKernelGGL((residual_kernel<true, true>), grid, block, 0, s, a);
+        else           hipLaunchKernelGGL((residual_kernel<true, false>), grid, block, 0, s, a);
+    } else {
+        if (do_search) hipLaunchKernelGGL((residual_kernel<false, true>), grid, block, 0, s, a);
+        else           hipLaunchKernelGGL((residual_kernel<false, false>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+template <bool EXT>
+__global__ __launch_bounds__(256) void reduce_final_kernel(const double* partials, int nblocks,
+                                                           const uint32_t* n_unresolved,
+                                                           const unsigned long long* cand_total,
+                                                           DeviceOut* out) {
+    typedef RedShape<EXT> S;
+    __shared__ double s_fin[S::NE];
+    const int tid = threadIdx.x;
+    if (tid < S::NE) {
+        double t = 0.0;
+        for (int b = 0; b < nblocks; ++b) t += partials[(size_t)b * RED_STRIDE + tid];   // fixed order
+        s_fin[tid] = t;
+    }
+    __syncthreads();
+    if (tid < 144) {
+        const int r = tid / 12, c = tid % 12;
+        double v = 0.0;
+        if (r < S::NC && c < S::NC) {
+            const int lo = r < c ? r : c, hi = r < c ? c : r;
+            // index of (lo, hi) in the row-major upper triangle
+            const int idx = lo * S::NC - (lo * (lo - 1)) / 2 + (hi - lo);
+            v = s_fin[idx];
+        }
+        out->HTH[tid] = v;
+    }
+    if (tid < 12) out->HTh[tid] = tid < S::NC ? s_fin[S::NP + tid] : 0.0;
+    if (tid == 0) {
+        out->res_sum = s_fin[S::NP + S::NC];
+        out->m = (int)(s_fin[S::NP + S::NC + 1] + 0.5);
+        out->n_unresolved = n_unresolved != nullptr ? (int)*n_unresolved : 0;
+        out->n_candidates = cand_total != nullptr ? *cand_total : 0ull;
+    }
+}
+
+hipError_t launch_reduce_final(const double* partials, int nblocks, bool ext, const uint32_t* n_unresolved,
+                               const unsigned long long* cand_total, DeviceOut* out, hipStream_t s) {
+    if (ext) hipLaunchKernelGGL(reduce_final_kernel<true>, dim3(1), dim3(256), 0, s, partials, nblocks, n_unresolved, cand_total, out);
+    else     hipLaunchKernelGGL(reduce_final_kernel<false>, dim3(1), dim3(256), 0, s, partials, nblocks, n_unresolved, cand_total, out);
+    return hipGetLastError();
+}
+
+}  // namespace lio

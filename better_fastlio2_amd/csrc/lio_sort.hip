@@ -1,0 +1,57 @@
+// lio_sort.hip -- the library primitives of the map (re)build: radix sort, run-length encode,
+// exclusive scan, stream compaction.  These are plain device-wide primitives (rocPRIM, shipped
+// with ROCm); the hot path of a scan step never calls them.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include "lio_kernels.h"
+
+namespace lio {
+
+size_t sort_pairs_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                    (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 63, (hipStream_t)0);
+    return bytes;
+}
+hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
+                              const uint32_t* vals_in, uint32_t* vals_out, size_t n, hipStream_t s) {
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 63, s);
+}
+
+size_t rle_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    (void)rocprim::run_length_encode(nullptr, bytes, (const uint64_t*)nullptr, n, (uint64_t*)nullptr,
+                                     (uint32_t*)nullptr, (uint32_t*)nullptr, (hipStream_t)0);
+    return bytes;
+}
+hipError_t run_length_encode_u64(void* temp, size_t temp_bytes, const uint64_t* keys, size_t n,
+                                 uint64_t* unique_out, uint32_t* counts_out, uint32_t* n_runs_out, hipStream_t s) {
+    return rocprim::run_length_encode(temp, temp_bytes, keys, n, unique_out, counts_out, n_runs_out, s);
+}
+
+size_t scan_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n,
+                                  rocprim::plus<uint32_t>(), (hipStream_t)0);
+    return bytes;
+}
+hipError_t exclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s) {
+    return rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s);
+}
+
+struct LivePoint {
+    __host__ __device__ bool operator()(const float4& p) const { return p.w == 0.0f; }
+};
+size_t select_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    (void)rocprim::select(nullptr, bytes, (const float4*)nullptr, (float4*)nullptr, (uint32_t*)nullptr, n,
+                          LivePoint(), (hipStream_t)0);
+    return bytes;
+}
+hipError_t select_live_points(void* temp, size_t temp_bytes, const float4* src, float4* dst, uint32_t* n_out,
+                              size_t n, hipStream_t s) {
+    return rocprim::select(temp, temp_bytes, src, dst, n_out, n, LivePoint(), s);
+}
+
+}  // namespace lio

@@ -1,0 +1,181 @@
+/* lio_hip.h -- C ABI of liblio_hip.so: the MI355X-native (gfx950, hand-written HIP) replacement for
+ * the per-scan LIO measurement path of Yixin-F/better_fastlio2.
+ *
+ * What it replaces (paths relative to the reference repository):
+ *   - KD_TREE<PointType> ikdtree            include/ikd-Tree/ikd_Tree.h:225-249   -> lio_map_*
+ *   - h_share_model(state_ikfom&, dyn_share_datastruct<double>&)
+ *                                           src/laserMapping.cpp:1876-2004        -> lio_scan_set + lio_measure
+ *   - esti_plane<float>                     include/common_lib.h:506-536          -> inside lio_measure
+ *   - the consumer side, update_iterated_dyn_share_modified
+ *                                           include/IKFoM_toolkit/esekfom/esekfom.hpp:1620-1938
+ *     stays on the host; this library ships a host C++ mirror of it (lio_eskf_*) so that a
+ *     scan step can be run, tested and timed without Eigen/IKFoM.
+ *
+ * Conventions: plain C, int status returns (LIO_OK == 0, negative = error), caller-owned host
+ * buffers, one context per GPU, a context is not re-entrant.  No torch / Eigen / PCL types cross
+ * this boundary.  There is NO CPU fallback: every entry point that computes needs a gfx950 device
+ * and fails with LIO_ERR_NO_DEVICE / LIO_ERR_HIP otherwise.
+ *
+ * Point input: `const float* pts` + `stride_bytes` addresses x,y,z as the first three floats of
+ * each record, so the reference's pcl::PointXYZINormal (48-byte records, include/common_lib.h:161)
+ * can be passed without repacking (stride 48) as well as packed xyz (stride 12) or float4 (16).
+ *
+ * Pose block `state14`: pos(3), rot quaternion x,y,z,w (4), offset_R_L_I quaternion x,y,z,w (4),
+ * offset_T_L_I (3) -- the members of state_ikfom read by h_share_model
+ * (include/use-ikfom.hpp:21-30; Eigen::Quaternion coefficient order).
+ */
+#ifndef LIO_HIP_H
+#define LIO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIO_OK                 0
+#define LIO_ERR_INVALID_ARG   (-1)
+#define LIO_ERR_NO_DEVICE     (-2)
+#define LIO_ERR_HIP           (-3)
+#define LIO_ERR_CAPACITY      (-4)
+#define LIO_ERR_NO_SCAN       (-5)
+#define LIO_ERR_NO_MAP        (-6)
+
+#define LIO_NUM_MATCH_POINTS   5      /* NUM_MATCH_POINTS, include/common_lib.h:149 */
+
+typedef struct lio_ctx lio_ctx;
+
+typedef struct lio_config {
+    int       device;               /* HIP device ordinal                                               */
+    float     filter_size_map_min;  /* map down-sample box (ikdtree.set_downsample_param,
+                                       src/laserMapping.cpp:2332; default 0.2 laserMapping.cpp:2067)      */
+    float     cell_size;            /* neighbour-grid cell edge; 0 = auto = largest power of two that is
+                                       <= 2.5 * filter_size_map_min (0.5 m for 0.2, 0.25 m for 0.1)       */
+    int       max_scan_points;      /* N_q capacity (the node's static cap is 100000,
+                                       src/laserMapping.cpp:52,65)                                        */
+    long long max_map_points;       /* N_m capacity of the resident map                                   */
+    int       lanes_per_query;      /* kNN sub-group width: 4, 8, 16, 32 or 64 lanes; 0 = auto           */
+} lio_config;
+
+/* Result of one pass of the measurement model (what update_iterated_dyn_share_modified consumes,
+ * esekfom.hpp:1790,1810: h_x^T h_x and h_x^T h; h_x has 12 non-zero columns, laserMapping.cpp:1967). */
+typedef struct lio_out {
+    int      m;                 /* effct_feat_num (laserMapping.cpp:1942-1954)                            */
+    int      valid;             /* ekfom_data.valid (laserMapping.cpp:1956-1961): 0 when m < 1            */
+    int      n_unresolved;      /* queries of this pass that left the 27-cell search unproven and were
+                                   answered by the exact tree walk (0 when do_search == 0)                */
+    int      reserved;
+    double   res_mean;          /* res_mean_last (laserMapping.cpp:1963)                                  */
+    double   HTH[144];          /* h_x^T h_x, 12x12 row-major (symmetric)                                 */
+    double   HTh[12];           /* h_x^T h                                                                */
+    unsigned long long n_candidates; /* sum over queries of C(q) = live map points in the 27 cells
+                                   searched (SURVEY.md section 8(d) byte model); 0 when do_search == 0    */
+} lio_out;
+
+typedef struct lio_map_info {
+    long long n_points;         /* stored points (live + tomb-stoned)                                     */
+    long long n_live;           /* validnum()                                                             */
+    long long n_cells;          /* occupied neighbour-grid cells                                          */
+    long long table_slots;      /* hash-table capacity                                                    */
+    float     cell_size;
+    float     downsample_size;
+    long long bytes_resident;   /* device bytes held by the map index                                     */
+} lio_map_info;
+
+/* ---- context -------------------------------------------------------------------------------- */
+int  lio_create(const lio_config* cfg, lio_ctx** out);
+void lio_destroy(lio_ctx* ctx);
+const char* lio_last_error(lio_ctx* ctx);           /* text of the last failure on this context        */
+const char* lio_version(void);
+void* lio_stream(lio_ctx* ctx);                     /* the hipStream_t every kernel of ctx runs on     */
+int  lio_synchronize(lio_ctx* ctx);
+
+/* ---- map: replaces KD_TREE<PointType> (ikd_Tree.h:225-249) ----------------------------------- */
+/* KD_TREE::Build (ikd_Tree.cpp:353-364): the map becomes exactly these points, no down-sampling.  */
+int  lio_map_build(lio_ctx* ctx, const float* pts, long long n, int stride_bytes);
+/* same, points already resident in device memory (float4 records x,y,z,_)                          */
+int  lio_map_build_device(lio_ctx* ctx, const void* d_pts_f4, long long n);
+/* KD_TREE::Add_Points (ikd_Tree.cpp:414-489); *n_added = its return value: the number of
+ * down-sampled inserts that changed the tree (tmp_counter), 0 when downsample_on == 0.             */
+int  lio_map_add(lio_ctx* ctx, const float* pts, int n, int stride_bytes, int downsample_on, int* n_added);
+/* KD_TREE::Delete_Point_Boxes (ikd_Tree.cpp:536-556): boxes = nb x {min xyz, max xyz}, half-open.  */
+int  lio_map_delete_boxes(lio_ctx* ctx, const float* minmax6, int nb, int* n_deleted);
+/* KD_TREE::reconstruct (ikd_Tree.cpp:1394-1405) == Build on a new cloud.                           */
+int  lio_map_reconstruct(lio_ctx* ctx, const float* pts, long long n, int stride_bytes);
+long long lio_map_size(lio_ctx* ctx);               /* KD_TREE::size()     (ikd_Tree.cpp:79)           */
+long long lio_map_validnum(lio_ctx* ctx);           /* KD_TREE::validnum() (ikd_Tree.cpp:129)          */
+/* KD_TREE::flatten (ikd_Tree.cpp:1326-1352): live points, xyz packed; *n = live count (may exceed
+ * cap, in which case only cap points were written).                                                */
+int  lio_map_flatten(lio_ctx* ctx, float* out_xyz, long long cap, long long* n);
+int  lio_map_get_info(lio_ctx* ctx, lio_map_info* info);
+/* KD_TREE::Nearest_Search (ikd_Tree.cpp:367-397) for a batch of world-frame queries: out_xyz
+ * [n*5*3], out_sqdist [n*5] ascending, out_count [n].  Unfilled slots: NaN / +inf.               */
+int  lio_map_nearest_search(lio_ctx* ctx, const float* q_xyz, int n, int stride_bytes,
+                            float* out_xyz, float* out_sqdist, int* out_count);
+
+/* ---- scan + measurement model: replaces h_share_model (laserMapping.cpp:1876-2004) ----------- */
+/* feats_down_body (laserMapping.cpp:2322-2325): uploads the body-frame scan and resets
+ * point_selected_surf to all-true (laserMapping.cpp:2131).                                         */
+int  lio_scan_set(lio_ctx* ctx, const float* body_pts, int n, int stride_bytes);
+int  lio_scan_set_device(lio_ctx* ctx, const void* d_body_f4, int n);
+/* One pass.  do_search = ekfom_data.converge (laserMapping.cpp:1906); out->valid = ekfom_data.valid.*/
+int  lio_measure(lio_ctx* ctx, const double state14[14], int do_search, int extrinsic_est_en,
+                 lio_out* out);
+/* h_x (m x 12) and h (m) of the LAST lio_measure, compacted in scan order exactly like
+ * laserCloudOri / corr_normvect (laserMapping.cpp:1942-2002).  col_major != 0 writes h_x in
+ * Eigen's default (column-major, leading dimension m).  cap_rows >= m required.                    */
+int  lio_measure_rows(lio_ctx* ctx, double* h_x, double* h, int cap_rows, int col_major);
+/* Nearest_Points of the last search pass (consumed by map_incremental, laserMapping.cpp:1453-1481):
+ * xyz [n*5*3], sqdist [n*5], count [n] (any of them may be NULL).                                  */
+int  lio_get_neighbors(lio_ctx* ctx, float* out_xyz, float* out_sqdist, int* out_count);
+/* feats_down_world (xyz [n*3]), point_selected_surf ([n]), normvec ([n*4] = n^ xyz, pd2) after the
+ * last pass (any may be NULL).                                                                     */
+int  lio_get_scan_state(lio_ctx* ctx, float* world_xyz, uint8_t* selected, float* normvec);
+int  lio_scan_size(lio_ctx* ctx);
+
+/* ---- timing hooks (HIP events on lio_stream around each kernel family) ------------------------ */
+#define LIO_PROF_KNN       0    /* 27-cell k-NN kernel                                              */
+#define LIO_PROF_FALLBACK  1    /* exact tree walk for unresolved queries                           */
+#define LIO_PROF_RESIDUAL  2    /* plane fit + residual + Jacobian + block reduction                */
+#define LIO_PROF_REDUCE    3    /* final HTH/HTh reduction                                          */
+#define LIO_PROF_COUNT     4
+int  lio_profile_enable(lio_ctx* ctx, int on);
+int  lio_profile_reset(lio_ctx* ctx);
+/* accumulated milliseconds and launch count of one kernel family since the last reset             */
+int  lio_profile_get(lio_ctx* ctx, int which, double* total_ms, long long* launches);
+
+/* ---- host-side iterated ESKF (mirror of esekfom::esekf, esekfom.hpp:106-2011) ----------------- */
+/* State x26 = pos3, rot xyzw, offset_R_L_I xyzw, offset_T_L_I 3, vel3, bg3, ba3, grav3 (S2, |g| =
+ * 9.809, use-ikfom.hpp:8,21-30).  P is 23x23 row-major in DOF order pos,rot,offR,offT,vel,bg,ba,grav.*/
+typedef struct lio_eskf lio_eskf;
+typedef struct lio_update_log {
+    int    n_calls;             /* calls of the measurement model (<= maximum_iter + 1)             */
+    int    n_search;            /* of which with do_search = 1                                      */
+    int    converged;           /* t > 1 reached before the last iteration                          */
+    int    last_m;
+    double last_res_mean;
+    double solve_seconds;       /* host time in the 23x23 algebra                                   */
+    double measure_seconds;     /* host wall time inside lio_measure                                */
+} lio_update_log;
+
+lio_eskf* lio_eskf_create(void);
+void lio_eskf_destroy(lio_eskf* kf);
+/* init_dyn_share (esekfom.hpp:239-258): maximum_iter and the 23 convergence limits.               */
+int  lio_eskf_init_dyn_share(lio_eskf* kf, int maximum_iter, const double limit23[23]);
+int  lio_eskf_change_x(lio_eskf* kf, const double x26[26]);       /* esekfom.hpp:1948             */
+int  lio_eskf_change_P(lio_eskf* kf, const double P[23 * 23]);    /* esekfom.hpp:1953             */
+int  lio_eskf_get_x(lio_eskf* kf, double x26[26]);                /* esekfom.hpp:1940             */
+int  lio_eskf_get_P(lio_eskf* kf, double P[23 * 23]);             /* esekfom.hpp:1944             */
+/* update_iterated_dyn_share_modified(R, solve_time) (esekfom.hpp:1620-1938) with the measurement
+ * model bound to lio_measure on ctx (the scan must have been set with lio_scan_set).             */
+int  lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, double R,
+                                                 int extrinsic_est_en, lio_update_log* log);
+/* manifold helpers exposed for tests: x [+] dx and x [-] y on the 23-DOF compound manifold        */
+int  lio_state_boxplus(double x26[26], const double dx23[23]);
+int  lio_state_boxminus(const double x26[26], const double y26[26], double dx23[23]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIO_HIP_H */
