@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- scans/sec (+ mean kNN us/point) of the LIO measurement path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU)
+
+A "step" is one scan step of the reference (everything inside kf.update_iterated_dyn_share_modified,
+src/laserMapping.cpp:2380): up to NUM_MAX_ITERATIONS+1 passes of the measurement model (k-NN +
+plane fit + residual + Jacobian + H^T H reduction on the GPU, 23x23 algebra on the host), on a
+synthetic KITTI-64-like 100 k-point scan against a 5 M-point map (BASELINE.json configs[1];
+SURVEY.md section 8d generators, seed 20240926).  Scan and map are resident in HBM before the timed
+region.  N > 1: every rank owns one GPU, one replica of the map and its own scan stream (weak
+scaling, no data-path collective inside a scan step -- SURVEY.md section 8e).
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (N_m, N_q, voxel, scan kind, NUM_MAX_ITERATIONS)
+    "c2": (5_000_000, 100_000, 0.2, "kitti64", 3),
+    "c3": (2_000_000, 24_000, 0.2, "hap", 3),
+    "c5": (50_000_000, 1_000_000, 0.1, "wide", 3),
+}
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def knn_algorithmic_bytes(nq: int, cand_sum: int) -> float:
+    """per query 16 (query in) + 216 (27 cell headers x 8 B) + 16 C(q)
+    (candidate float4 gathers) + 40 (5 x (idx + sqdist) out)."""
+    return nq * (16.0 + 216.0 + 40.0) + 16.0 * cand_sum
+
+
+def dist_setup(n_gpus: int):
+    """(rank, world, local_rank, dist or None).  Re-launches itself under torchrun when asked for
+    N > 1 from a plain `python bench.py --gpus N`."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if n_gpus > 1 and world == 1:
+        port = 29500 + (os.getpid() % 2000)
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                   f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+                                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    if world == 1:
+        return 0, 1, 0, None
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    return dist.get_rank(), dist.get_world_size(), local, dist
+
+
+def timed_steps(step_fn, steps: int, warmup: int, dist, device):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
+    import torch
+    for _ in range(warmup):
+        step_fn()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def cpu_baseline(world_pts, scan, x0, P0, max_iter: int, ext: bool, sample_every: int):
+    """The reference CPU path timed on this host: the reference's own ikd-Tree (oracle/_ref, compiled
+    verbatim) for Nearest_Search + the oracle restatement of h_share_model / IKFoM update, one thread,
+    on every `sample_every`-th point of the scan against the full map."""
+    from oracle import pyoracle as po
+    body = np.ascontiguousarray(scan.body[::sample_every])
+    om = po.OracleMap(0.2)
+    use_ref = po.ref_available()
+    t_build0 = time.perf_counter()
+    if use_ref:
+        tree = po.RefIkdTree(0.2)
+        tree.build(world_pts)
+        po.use_reference_knn(tree)
+        method = 2
+    else:
+        om.build(world_pts)
+        method = 1
+    t_build = time.perf_counter() - t_build0
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        xo, Po, arrs, log = po.update_iterated(om, x0, P0, body, 0.001, max_iter, None, ext, knn_method=method)
+        ts.append(time.perf_counter() - t0)
+    # mean kNN cost per point on the same sample
+    st = np.concatenate([x0[0:14]])
+    wq = po.body_to_world(st, body)
+    if use_ref:
+        _, _, _, secs = tree.knn(wq)
+        po.use_reference_knn(None)
+    else:
+        _, _, _, secs = om.knn(wq, 5, 1)
+    t_step = float(np.median(ts)) * sample_every
+    return {"value": 1.0 / t_step, "unit": "scans/s", "cores": 1, "kind": "port",
+            "knn": "reference ikd-Tree (oracle/_ref, verbatim)" if use_ref else "oracle kd-tree restatement",
+            "knn_us_per_point": secs / len(wq) * 1e6,
+            "sample": f"every {sample_every}th point of the scan ({len(body)} of {len(scan.body)}) vs the full "
+                      f"{len(world_pts)}-point map, {len(log)} passes, median of 3, scaled x{sample_every}; "
+                      f"tree build {t_build:.1f}s untimed",
+            "passes": int(len(log)), "posterior": xo}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--lanes", type=int, default=0, help="kNN lanes per query (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank, world_size, local, dist = dist_setup(a.gpus)
+    import torch
+    from better_fastlio2_amd import capi, synth
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the measurement path has no CPU fallback")
+    device = torch.device("cuda", local)
+
+    nm, nq, voxel, kind, max_iter = CONFIGS[a.config]
+    world = synth.make_world(nm, voxel)                        # identical replica on every rank
+    # independent scan streams: every rank looks at the world from its own pose
+    rng = np.random.default_rng(1000 + rank)
+    px, py = (3.1, -2.2) if rank == 0 else tuple(rng.uniform(-0.3, 0.3, 2) * world.ground_half)
+    yaw = 0.52 if rank == 0 else float(rng.uniform(-3.1, 3.1))
+    scan = synth.make_scan(world, nq, kind=kind, seed=synth.SEED + 1 + rank, pos=(px, py, 0.0), rpy=(0.004, -0.006, yaw))
+    pos, rot = synth.perturb_state(scan, seed=synth.SEED + 2 + rank)
+    x0 = capi.make_state26(pos, rot, scan.off_R, scan.off_T)
+    P0 = synth.init_cov()
+    ext = scan.extrinsic_est_en
+
+    ctx = capi.LioContext(voxel, max_scan_points=nq, max_map_points=nm + 1024, device=local, lanes_per_query=a.lanes)
+    ctx.map_build(world.points)
+    body4 = np.zeros((nq, 4), np.float32)
+    body4[:, :3] = scan.body
+    d_body = torch.from_numpy(body4).to(device)                # scan resident in HBM
+    kf = capi.Esekf(max_iter)
+
+    def step():
+        kf.change_x(x0)
+        kf.change_P(P0)
+        ctx.scan_set_device(d_body.data_ptr(), nq)
+        return kf.update_iterated_dyn_share_modified(ctx, 0.001, ext)
+
+    # untimed: candidate census for the byte model, parity of the posterior with the truth
+    ctx.census_enable(True)
+    ctx.scan_set_device(d_body.data_ptr(), nq)
+    g = ctx.measure(x0[:14], True, ext)
+    ctx.census_enable(False)
+    cand_sum, unresolved = g["n_candidates"], g["n_unresolved"]
+    log = step()
+    pos_err = float(np.linalg.norm(kf.get_x()[:3] - scan.pos))
+
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    elapsed = timed_steps(step, a.steps, a.warmup, dist, device)
+    prof = ctx.profile()
+    ctx.profile_enable(False)
+    # the warm-up launches are in the accumulators too; averages are per launch either way
+    knn_ms = prof["knn27"]["total_ms"] / max(prof["knn27"]["launches"], 1)
+    kernels_us = {k: (v["total_ms"] / max(v["launches"], 1)) * 1e3 for k, v in prof.items()}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    total_scans = world_size * a.steps
+    bytes_knn = knn_algorithmic_bytes(nq, cand_sum)
+    achieved = bytes_knn / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(a.config, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "scans/sec + mean kNN us/point, KITTI-64 100k-pt scan vs 5M-pt map",
+        "value": total_scans / elapsed, "unit": "scans/s", "n_gpus": world_size, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.config}: {kind} scan N_q={nq} vs map N_m={nm} (voxel {voxel} m), k=5, "
+                               f"NUM_MAX_ITERATIONS={max_iter}, extrinsic_est_en={ext}",
+                   "passes_per_step": log["n_calls"], "search_passes_per_step": log["n_search"],
+                   "parallelism": f"{world_size} independent scan stream(s), replicated map",
+                   "lanes_per_query": a.lanes or "auto", "C_mean": cand_sum / nq, "unresolved_queries": unresolved,
+                   "pos_err_to_truth_m": pos_err},
+        "knn_us_per_point": knn_ms * 1e3 / nq,
+        "kernels_us": kernels_us,
+        "roofline": {"bound": "hbm", "kernel": "knn27_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": bytes_knn, "avg_launch_us": knn_ms * 1e3},
+    }
+    if world_size == 1 and not a.no_cpu_baseline:
+        cb = cpu_baseline(world.points, scan, x0, P0, max_iter, ext, sample_every=4)
+        cb.pop("posterior")
+        out["cpu_baseline"] = cb
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,7 +56,7 @@ EXPORTS = [
     "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_delete_boxes", "lio_map_reconstruct",
     "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_get_info", "lio_map_nearest_search",
     "lio_scan_set", "lio_scan_set_device", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
-    "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_profile_reset", "lio_profile_get",
+    "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
     "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_state_boxplus",
     "lio_state_boxminus",
@@ -111,6 +111,7 @@ def load(build_if_missing: bool = True):
     L.lio_scan_size.argtypes = [_vp]
     L.lio_profile_enable.argtypes = [_vp, C.c_int]
     L.lio_profile_reset.argtypes = [_vp]
+    L.lio_census_enable.argtypes = [_vp, C.c_int]
     L.lio_profile_get.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.lio_eskf_create.restype = _vp
     L.lio_eskf_destroy.argtypes = [_vp]
@@ -259,6 +260,10 @@ class LioContext:
     # ---- timing ------------------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         self.L.lio_profile_enable(self.h, int(on))
+
+    def census_enable(self, on: bool = True):
+        """Make search passes report n_candidates (sum of C(q)); off in timed runs."""
+        self.L.lio_census_enable(self.h, int(on))
 
     def profile_reset(self):
         self.L.lio_profile_reset(self.h)

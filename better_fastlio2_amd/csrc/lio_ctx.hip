@@ -76,6 +76,7 @@ struct lio_ctx {
 
     // ---- profiling ----------------------------------------------------------------------------
     bool prof = false;
+    bool census = false;                       // count C(q) in the k-NN kernel (one atomic per wavefront)
     hipEvent_t ev[LIO_PROF_COUNT][2]{};
     bool ev_used[LIO_PROF_COUNT]{};
     double prof_ms[LIO_PROF_COUNT]{};
@@ -224,7 +225,7 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.body = body; ka.world_in = body ? nullptr : queries_world; ka.pose = pose;
     ka.nq = nq; ka.nq_stride = stride;
     ka.world_out = body ? queries_world : nullptr;
-    ka.nbr = nbr; ka.cnt = cnt; ka.unresolved = unres; ka.n_unresolved = c->d_counters; ka.cand_total = c->d_cand;
+    ka.nbr = nbr; ka.cnt = cnt; ka.unresolved = unres; ka.n_unresolved = c->d_counters; ka.cand_total = c->census ? c->d_cand : nullptr;
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
     prof_begin(c, LIO_PROF_KNN);
     HIPCHK(c, launch_knn27(ka, lanes, s));
@@ -697,6 +698,7 @@ int lio_get_scan_state(lio_ctx* c, float* world_xyz, uint8_t* selected, float* n
 
 // ---- profiling -----------------------------------------------------------------------------------
 int lio_profile_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; c->prof = on != 0; return LIO_OK; }
+int lio_census_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; c->census = on != 0; return LIO_OK; }
 int lio_profile_reset(lio_ctx* c) {
     if (!c) return LIO_ERR_INVALID_ARG;
     for (int w = 0; w < LIO_PROF_COUNT; ++w) { c->prof_ms[w] = 0.0; c->prof_n[w] = 0; c->ev_used[w] = false; }

@@ -142,18 +142,31 @@ hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool ext, hipS
     return hipGetLastError();
 }
 
+// 1024 lanes: lane (part, e) sums the partials of blocks part, part + PARTS, ... for entry e (loads
+// are independent, so they pipeline); the PARTS sub-sums are then combined in a fixed order.
 template <bool EXT>
-__global__ __launch_bounds__(256) void reduce_final_kernel(const double* partials, int nblocks,
-                                                           const uint32_t* n_unresolved,
-                                                           const unsigned long long* cand_total,
-                                                           DeviceOut* out) {
+__global__ __launch_bounds__(1024) void reduce_final_kernel(const double* partials, int nblocks,
+                                                            const uint32_t* n_unresolved,
+                                                            const unsigned long long* cand_total,
+                                                            DeviceOut* out) {
     typedef RedShape<EXT> S;
-    __shared__ double s_fin[S::NE];
+    constexpr int PARTS = 1024 / S::NEP;
+    __shared__ double s_sub[PARTS][S::NEP];
+    __shared__ double s_fin[S::NEP];
     const int tid = threadIdx.x;
+    const int e = tid % S::NEP, part = tid / S::NEP;
+    double t = 0.0;
+    if (e < S::NE) {
+#pragma unroll 8
+        for (int b = part; b < nblocks; b += PARTS) t += partials[(size_t)b * RED_STRIDE + e];
+    }
+    s_sub[part][e] = t;
+    __syncthreads();
     if (tid < S::NE) {
-        double t = 0.0;
-        for (int b = 0; b < nblocks; ++b) t += partials[(size_t)b * RED_STRIDE + tid];   // fixed order
-        s_fin[tid] = t;
+        double f = 0.0;
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p) f += s_sub[p][tid];
+        s_fin[tid] = f;
     }
     __syncthreads();
     if (tid < 144) {
@@ -178,8 +191,8 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double* partial
 
 hipError_t launch_reduce_final(const double* partials, int nblocks, bool ext, const uint32_t* n_unresolved,
                                const unsigned long long* cand_total, DeviceOut* out, hipStream_t s) {
-    if (ext) hipLaunchKernelGGL(reduce_final_kernel<true>, dim3(1), dim3(256), 0, s, partials, nblocks, n_unresolved, cand_total, out);
-    else     hipLaunchKernelGGL(reduce_final_kernel<false>, dim3(1), dim3(256), 0, s, partials, nblocks, n_unresolved, cand_total, out);
+    if (ext) hipLaunchKernelGGL(reduce_final_kernel<true>, dim3(1), dim3(1024), 0, s, partials, nblocks, n_unresolved, cand_total, out);
+    else     hipLaunchKernelGGL(reduce_final_kernel<false>, dim3(1), dim3(1024), 0, s, partials, nblocks, n_unresolved, cand_total, out);
     return hipGetLastError();
 }
 

@@ -70,7 +70,7 @@ typedef struct lio_out {
     double   HTH[144];          /* h_x^T h_x, 12x12 row-major (symmetric)                                 */
     double   HTh[12];           /* h_x^T h                                                                */
     unsigned long long n_candidates; /* sum over queries of C(q) = live map points in the 27 cells
-                                   searched (SURVEY.md section 8(d) byte model); 0 when do_search == 0    */
+                                   searched (SURVEY.md section 8(d) byte model); 0 unless lio_census_enable  */
 } lio_out;
 
 typedef struct lio_map_info {
@@ -141,6 +141,9 @@ int  lio_scan_size(lio_ctx* ctx);
 #define LIO_PROF_REDUCE    3    /* final HTH/HTh reduction                                          */
 #define LIO_PROF_COUNT     4
 int  lio_profile_enable(lio_ctx* ctx, int on);
+/* candidate census: when on, search passes also report lio_out.n_candidates (costs one device
+ * atomic per wavefront of the k-NN kernel, so it is off by default and never on in timed runs)    */
+int  lio_census_enable(lio_ctx* ctx, int on);
 int  lio_profile_reset(lio_ctx* ctx);
 /* accumulated milliseconds and launch count of one kernel family since the last reset             */
 int  lio_profile_get(lio_ctx* ctx, int which, double* total_ms, long long* launches);

@@ -254,6 +254,13 @@ struct OMap {
     }
 };
 
+// Optional external k-NN provider (knn_method == 2): lets the harness run the restated measurement
+// model on top of the REFERENCE's own ikd-Tree (oracle/_ref/libikd_ref.so, ref_ikd_nearest), which
+// is what bench.py's cpu_baseline times.
+typedef double (*ext_knn_fn)(void* h, const float* q_xyz, int nq, int k, float* out_xyz, float* out_d, int* out_cnt);
+ext_knn_fn g_ext_knn = nullptr;
+void* g_ext_handle = nullptr;
+
 inline bool same_point(P3 a, P3 b) {                       // ikd_Tree.cpp:1365-1367 (EPSS 1e-6)
     return std::fabs(a.x - b.x) < 1e-6 && std::fabs(a.y - b.y) < 1e-6 && std::fabs(a.z - b.z) < 1e-6;
 }
@@ -604,6 +611,8 @@ bool inverse_n(const double* Ain, double* inv, int n) {
 // =====================================================================================
 extern "C" {
 
+void orc_set_external_knn(void* fn, void* handle) { g_ext_knn = (ext_knn_fn)fn; g_ext_handle = handle; }
+
 void* orc_map_create(float downsample_size) { OMap* m = new OMap; m->ds = downsample_size; return m; }
 void orc_map_destroy(void* m) { delete static_cast<OMap*>(m); }
 
@@ -733,13 +742,17 @@ int orc_h_share_model(void* map, const double* s14, const float* body, int n, in
     OMap* m = static_cast<OMap*>(map);
     Pose s = pose_from(s14);
     const int K = 5;                                       // NUM_MATCH_POINTS common_lib.h:149
-    if (converge && knn_method != 0) m->ensure_tree();
+    if (converge && knn_method == 1) m->ensure_tree();
     for (int i = 0; i < n; ++i) {                          // :1888-1940
         V3 pb{body[3 * i], body[3 * i + 1], body[3 * i + 2]};
         V3 pg = qrot(s.rot, qrot(s.offR, pb) + s.offT) + s.pos;     // :1895
         P3 pw{(float)pg.x, (float)pg.y, (float)pg.z};
         world[3 * i] = pw.x; world[3 * i + 1] = pw.y; world[3 * i + 2] = pw.z;
-        if (converge) {                                    // :1906-1912
+        if (converge && knn_method == 2 && g_ext_knn) {    // the reference's own Nearest_Search
+            const float qq[3] = {pw.x, pw.y, pw.z};
+            g_ext_knn(g_ext_handle, qq, 1, K, nbr_xyz + (size_t)i * K * 3, nbr_d + (size_t)i * K, nbr_cnt + i);
+            selected[i] = nbr_cnt[i] < K ? 0 : (nbr_d[i * K + K - 1] > 5 ? 0 : 1);
+        } else if (converge) {                             // :1906-1912
             TopK hp(K);
             m->knn(pw, K, hp, knn_method);
             nbr_cnt[i] = hp.n;

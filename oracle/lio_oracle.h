@@ -37,6 +37,11 @@ int    orc_map_flatten(void* m, float* out_xyz, int cap);           /* ikd_Tree.
 double orc_map_knn(void* m, const float* q_xyz, int nq, int k, float* out_xyz, float* out_d,
                    int* out_cnt, int method);
 
+/* knn_method == 2 routes the k-NN of orc_h_share_model / orc_update_iterated through an external
+ * provider with the signature of ref_ikd_nearest (oracle/ref_ikd_capi.cpp), i.e. the reference's
+ * own ikd-Tree; `map` may then be any (even empty) oracle map. */
+void   orc_set_external_knn(void* fn, void* handle);
+
 /* ---- measurement model ------------------------------------------------------------------------ */
 /* esti_plane<float> (include/common_lib.h:506-536); pts = 5 x (x,y,z); returns 1 if plane ok. */
 int    orc_esti_plane(const float* pts5x3, float threshold, float* pabcd);

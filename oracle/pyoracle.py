@@ -68,6 +68,7 @@ def lib():
                                           C.POINTER(C.c_int)]
         L.orc_hth.argtypes = [_f64p, _f64p, C.c_int, _f64p, _f64p]
         L.orc_map_incremental_classify.argtypes = [_f32p, C.c_int, _f32p, _i32p, C.c_double, C.c_int, _u8p]
+        L.orc_set_external_knn.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -299,3 +300,12 @@ class RefIkdTree:
 
     def quiesce(self, ms: int = 200):
         self.L.ref_ikd_quiesce(ms)
+
+
+def use_reference_knn(tree: "RefIkdTree | None"):
+    """knn_method=2 of h_share_model / update_iterated then calls the reference's Nearest_Search."""
+    if tree is None:
+        lib().orc_set_external_knn(None, None)
+    else:
+        fn = C.cast(ref_lib().ref_ikd_nearest, C.c_void_p)
+        lib().orc_set_external_knn(fn, tree.h)

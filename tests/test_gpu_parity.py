@@ -1,0 +1,253 @@
+"""Parity of the HIP path (through the C ABI) with the oracle on identical seeded inputs, the edge
+cases of the domain, and size-independent properties at the benchmark's full size."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _hard_queries(case, oracle, n_scan=4000, seed=5):
+    rng = np.random.default_rng(seed)
+    wq = oracle.body_to_world(case["state14"], case["scan"].body)[:n_scan]
+    half = case["world"].ground_half
+    return np.ascontiguousarray(np.concatenate([
+        wq,
+        (rng.uniform(-1.3 * half, 1.3 * half, (2000, 3)) * [1, 1, 0.03]).astype(np.float32),   # map edge and beyond
+        (rng.uniform(-half, half, (500, 3)) * [1, 1, 0.1] + [0, 0, 6]).astype(np.float32),      # above everything
+        rng.uniform(-300, 300, (300, 3)).astype(np.float32),                                    # far away
+        np.array([[1e4, -2e4, 50.0], [0, 0, 900.0], [-3e5, 1e5, 0]], np.float32)]))
+
+
+@pytest.fixture(scope="module")
+def ctx_small(gpu_capi, small_case):
+    c = gpu_capi.LioContext(0.2, max_scan_points=32768, max_map_points=400_000)
+    c.map_build(small_case["world"].points)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("lanes", [8, 16, 32, 64])
+def test_nearest_search_bit_exact(gpu_capi, oracle, small_case, lanes):
+    """Neighbour points, squared distances and counts identical to the (reference-pinned) oracle,
+    for in-map queries (27-cell kernel) and edge/far queries (exact tree walk)."""
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=1024, max_map_points=400_000, lanes_per_query=lanes)
+    ctx.map_build(small_case["world"].points)
+    q = _hard_queries(small_case, oracle)
+    om = oracle.OracleMap(0.2); om.build(small_case["world"].points)
+    ox, od, oc, _ = om.knn(q)
+    gx, gd, gc = ctx.nearest_search(q)
+    assert np.array_equal(gc, oc)
+    assert bits_equal(gd, od)
+    assert bits_equal(gx, ox)
+    # stride-48 input (pcl::PointXYZINormal records, common_lib.h:161) gives the same answer
+    rec = np.zeros((len(q), 12), np.float32); rec[:, :3] = q; rec[:, 3] = 1.0; rec[:, 8] = 7.0
+    gx2, gd2, gc2 = ctx.nearest_search(rec)
+    assert bits_equal(gx2, gx) and bits_equal(gd2, gd)
+    ctx.close()
+
+
+@pytest.mark.parametrize("case_name,ext", [("small_case", False), ("small_case", True), ("hap_case", True)])
+def test_measurement_pass_parity(gpu_capi, oracle, request, case_name, ext):
+    """h_share_model: search pass, then a no-search pass at a moved pose (reuses neighbours and the
+    previous accept flags, laserMapping.cpp:1906-1917)."""
+    case = request.getfixturevalue(case_name)
+    w, sc, st = case["world"], case["scan"], case["state14"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+    ctx.map_build(w.points)
+    ctx.scan_set(sc.body)
+    om = oracle.OracleMap(0.2); om.build(w.points)
+    arr = oracle.ScanArrays(len(sc.body))
+    st2 = st.copy(); st2[:3] += [0.012, -0.02, 0.006]
+    for search, pose in ((True, st), (False, st2), (True, st2)):
+        valid, hx, h, m, rm = oracle.h_share_model(om, pose, sc.body, arr, search, ext)
+        g = ctx.measure(pose, search, ext)
+        assert g["m"] == m and g["valid"] == valid and m > 1000
+        world, sel, nv = ctx.scan_state()
+        assert bits_equal(world, arr.world)
+        assert np.array_equal(sel, arr.selected)                 # validity mask identical
+        s = sel.astype(bool)
+        assert bits_equal(nv[s], arr.normvec[s])
+        HTH, HTh = oracle.hth(hx, h)
+        assert np.abs(g["HTH"] - HTH).max() <= 1e-9 * np.abs(HTH).max()
+        assert np.abs(g["HTh"] - HTh).max() <= 1e-9 * np.abs(HTh).max()
+        assert np.allclose(g["HTH"], g["HTH"].T, rtol=0, atol=0)
+        assert abs(g["res_mean"] - rm) <= 1e-12
+        ghx, gh = ctx.measure_rows(m)
+        assert np.array_equal(ghx, hx) and np.array_equal(gh, h)  # rows bit-equal, scan order
+        if search:
+            nx, nd, nc = ctx.neighbors()
+            assert np.array_equal(nc, arr.nbr_cnt) and bits_equal(nd, arr.nbr_d) and bits_equal(nx, arr.nbr_xyz)
+    ctx.close()
+
+
+@pytest.mark.parametrize("case_name,ext", [("small_case", False), ("hap_case", True)])
+def test_iterated_update_pose_parity(gpu_capi, oracle, synth, request, case_name, ext):
+    """update_iterated_dyn_share_modified on the GPU path vs the CPU path: pose within
+    1e-4 m / 1e-5 rad (north_star), same number of passes, same final neighbours."""
+    case = request.getfixturevalue(case_name)
+    w, sc = case["world"], case["scan"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+    ctx.map_build(w.points)
+    om = oracle.OracleMap(0.2); om.build(w.points)
+    x0 = gpu_capi.make_state26(case["pos"], case["rot"], sc.off_R, sc.off_T)
+    P0 = synth.init_cov()
+    xo, Po, arrs, log = oracle.update_iterated(om, x0, P0, sc.body, 0.001, 3, None, ext)
+    kf = gpu_capi.Esekf(3)
+    kf.change_x(x0); kf.change_P(P0)
+    ctx.scan_set(sc.body)
+    lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, ext)
+    xg, Pg = kf.get_x(), kf.get_P()
+    assert lg["n_calls"] == len(log)
+    assert np.abs(xg[:3] - xo[:3]).max() < 1e-4
+    assert 2 * np.abs(xg[3:7] - xo[3:7]).max() < 1e-5 and 2 * np.abs(xg[7:11] - xo[7:11]).max() < 1e-5
+    assert np.abs(xg - xo).max() < 1e-8                          # in practice ~1e-12
+    assert np.abs(Pg - Po).max() <= 1e-6 * np.abs(Po).max()
+    assert np.linalg.norm(xg[:3] - sc.pos) < 0.02 < np.linalg.norm(x0[:3] - sc.pos)
+    nx, nd, nc = ctx.neighbors()
+    assert bits_equal(nx, arrs.nbr_xyz) and np.array_equal(nc, arrs.nbr_cnt)
+    ctx.close()
+
+
+def test_dense_gain_branch_small_scan(gpu_capi, oracle, synth, small_case):
+    """m < 23 rows: the reference switches to the dense Kalman gain (esekfom.hpp:1720-1750) and needs
+    h_x itself -> lio_measure_rows path."""
+    w, sc = small_case["world"], small_case["scan"]
+    body = np.ascontiguousarray(sc.body[:15])
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=64, max_map_points=400_000)
+    ctx.map_build(w.points)
+    om = oracle.OracleMap(0.2); om.build(w.points)
+    x0 = gpu_capi.make_state26(small_case["pos"], small_case["rot"], sc.off_R, sc.off_T)
+    xo, Po, arrs, log = oracle.update_iterated(om, x0, synth.init_cov(), body)
+    kf = gpu_capi.Esekf(3); kf.change_x(x0); kf.change_P(synth.init_cov())
+    ctx.scan_set(body)
+    lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+    assert 0 < lg["last_m"] < 23
+    assert np.abs(kf.get_x() - xo).max() < 1e-9 and np.abs(kf.get_P() - Po).max() < 1e-9
+    ctx.close()
+
+
+def test_map_mutation_parity(gpu_capi, oracle, small_case):
+    """Add_Points (down-sampled: one point per voxel, nearest the centre; plain), Delete_Point_Boxes,
+    validnum/size/flatten: same return values and live set as the oracle, k-NN parity afterwards."""
+    w, sc = small_case["world"], small_case["scan"]
+    rng = np.random.default_rng(21)
+    base = w.points[:80000]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=1024, max_map_points=400_000)
+    ctx.map_build(base)
+    om = oracle.OracleMap(0.2); om.build(base)
+    wq = oracle.body_to_world(small_case["state14"], sc.body)
+    key = lambda p: p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+    for rnd in range(3):
+        new = np.ascontiguousarray(wq[rnd * 5000:(rnd + 1) * 5000] + rng.normal(0, 0.04, (5000, 3)).astype(np.float32))
+        # repeated points and several points per voxel inside one batch (order dependence)
+        new[100:200] = new[0:100]
+        new[200:300] = new[0:100] + np.float32(0.01)
+        assert ctx.map_add(new, True) == om.add(new, True)
+        plain = np.ascontiguousarray(rng.uniform(-35, 35, (300, 3)).astype(np.float32))
+        assert ctx.map_add(plain, False) == om.add(plain, False) == 0
+        boxes = np.array([[-12 + 3 * rnd, -10, -1, 4, 2 + rnd, 3], [3, 3, -1, 9, 9 + rnd, 2.5]], np.float32)
+        assert ctx.map_delete_boxes(boxes) == om.delete_boxes(boxes)
+        assert ctx.map_validnum() == om.validnum()
+        assert bits_equal(key(ctx.map_flatten()), key(om.flatten()))
+        q = np.ascontiguousarray(wq[15000 + rnd * 1000: 16000 + rnd * 1000])
+        gx, gd, gc = ctx.nearest_search(q)
+        ox, od, oc, _ = om.knn(q)
+        assert np.array_equal(gc, oc) and bits_equal(gd, od) and bits_equal(gx, ox)
+    assert ctx.map_size() >= ctx.map_validnum()
+    ctx.close()
+
+
+def test_edge_cases(gpu_capi, oracle, small_case):
+    sc, st = small_case["scan"], small_case["state14"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=1000, max_map_points=10_000)
+    # empty map: no neighbours, measurement invalid ("No Effective Points", laserMapping.cpp:1956)
+    q = np.ascontiguousarray(sc.body[:10])
+    x, d, c = ctx.nearest_search(q)
+    assert (c == 0).all() and np.isinf(d).all() and np.isnan(x).all()
+    ctx.scan_set(sc.body[:100])
+    g = ctx.measure(st, True, False)
+    assert g["m"] == 0 and not g["valid"]
+    # fewer than 5 map points
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], np.float32)
+    ctx.map_build(pts)
+    om = oracle.OracleMap(0.2); om.build(pts)
+    qq = np.array([[0.1, 0.1, 0.1], [10, 10, 10]], np.float32)
+    x, d, c = ctx.nearest_search(qq)
+    ox, od, oc, _ = om.knn(qq)
+    assert np.array_equal(c, oc) and bits_equal(d, od) and bits_equal(x[:, :3], ox[:, :3])
+    g = ctx.measure(st, True, False)
+    assert g["m"] == 0 and not g["valid"]
+    # empty scan
+    ctx.scan_set(np.zeros((0, 3), np.float32))
+    assert not ctx.measure(st, True, False)["valid"]
+    # a pass without a preceding search of the same scan is refused, as is over-capacity input
+    ctx.scan_set(sc.body[:100])
+    with pytest.raises(gpu_capi.LioError, match="LIO_ERR_NO_SCAN"):
+        ctx.measure(st, False, False)
+    with pytest.raises(gpu_capi.LioError, match="LIO_ERR_CAPACITY"):
+        ctx.scan_set(sc.body[:2000])
+    with pytest.raises(gpu_capi.LioError, match="LIO_ERR_CAPACITY"):
+        ctx.map_build(np.zeros((20_000, 3), np.float32))
+    # ragged size (not a multiple of the 256-point workgroup) and duplicate map points
+    dup = np.repeat(np.array([[1, 1, 1], [1.05, 1, 1], [1, 1.05, 1]], np.float32), 3, 0)
+    ctx.map_build(dup)
+    om = oracle.OracleMap(0.2); om.build(dup)
+    x, d, c = ctx.nearest_search(np.array([[1.01, 1.0, 1.02]], np.float32))
+    ox, od, oc, _ = om.knn(np.array([[1.01, 1.0, 1.02]], np.float32))
+    assert np.array_equal(c, oc) and bits_equal(d, od)       # ties in distance: same multiset of distances
+    ctx.close()
+
+
+def test_run_to_run_determinism(gpu_capi, ctx_small, small_case):
+    sc, st = small_case["scan"], small_case["state14"]
+    ctx_small.scan_set(sc.body)
+    a = ctx_small.measure(st, True, True)
+    b = ctx_small.measure(st, True, True)
+    assert np.array_equal(a["HTH"], b["HTH"]) and np.array_equal(a["HTh"], b["HTh"]) and a["res_mean"] == b["res_mean"]
+
+
+def test_full_size_properties(gpu_capi, synth):
+    """BASELINE config 2 (100 k-point scan vs 5 M-point map): properties that need no oracle run.
+    - every reported sqdist is the fp32 distance of the reported point, ascending, and the gate,
+    - a brute-force check of 200 random queries against all 5 M points,
+    - the candidate census C_mean of the byte model is in the surveyed range,
+    - two runs give identical bits, and the update converges to the true pose."""
+    nm, nq = 5_000_000, 100_000
+    world = synth.make_world(nm, 0.2)
+    scan = synth.make_scan(world, nq)
+    pos, rot = synth.perturb_state(scan)
+    st = synth.state_vector(pos, rot, scan.off_R, scan.off_T)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=nq, max_map_points=nm + 1000)
+    ctx.map_build(world.points)
+    assert ctx.map_validnum() == nm
+    ctx.census_enable(True)
+    ctx.scan_set(scan.body)
+    g = ctx.measure(st, True, False)
+    ctx.census_enable(False)
+    assert 40 < g["n_candidates"] / nq < 80
+    assert g["m"] > 0.8 * nq
+    world_pts, sel, nv = ctx.scan_state()
+    nx, nd, nc = ctx.neighbors()
+    assert (nc == 5).all()
+    diff = nx.astype(np.float32) - world_pts[:, None, :]
+    d = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    assert bits_equal(d.astype(np.float32), nd)
+    assert (np.diff(nd, axis=1) >= 0).all()
+    rng = np.random.default_rng(0)
+    mp = world.points
+    for i in rng.choice(nq, 200, replace=False):
+        dd = mp - world_pts[i]
+        dist = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
+        best = np.sort(dist)[:5]
+        assert bits_equal(best.astype(np.float32), nd[i])
+    g2 = ctx.measure(st, True, False)
+    assert np.array_equal(g["HTH"], g2["HTH"]) and g["m"] == g2["m"]
+    kf = gpu_capi.Esekf(3)
+    kf.change_x(gpu_capi.make_state26(pos, rot, scan.off_R, scan.off_T)); kf.change_P(synth.init_cov())
+    ctx.scan_set(scan.body)
+    lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+    assert lg["n_calls"] <= 4
+    assert np.linalg.norm(kf.get_x()[:3] - scan.pos) < 0.02
+    ctx.close()

@@ -1,0 +1,112 @@
+"""Second opinions for the parts of the oracle that cannot be pinned on the reference (they need
+Eigen, which is neither vendored nor installed -- SURVEY.md section 8c): scipy / numpy in higher
+precision as the independent check, with explicit tolerances."""
+import numpy as np
+import scipy.linalg as sl
+
+from conftest import bits_equal
+
+
+def _planar_sets(n, seed=1):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+        base = rng.uniform(-60, 60, 3)
+        u = np.cross(nrm, [1, 0, 0.3]); u /= np.linalg.norm(u)
+        v = np.cross(nrm, u)
+        pts = base + rng.uniform(-0.3, 0.3, (5, 1)) * u + rng.uniform(-0.3, 0.3, (5, 1)) * v \
+            + rng.normal(0, rng.choice([0.004, 0.02, 0.06]), (5, 1)) * nrm
+        out.append(pts.astype(np.float32))
+    return out
+
+
+def test_esti_plane_against_scipy_qr(oracle):
+    """common_lib.h:506-536: least-squares plane through 5 points, fp32 column-pivoted QR.  The fp64
+    least-squares solution is the truth; LAPACK's own fp32 pivoted QR (sgeqp3 via scipy) sets the
+    error scale an fp32 Householder QR is allowed on these ill-conditioned systems (|p| ~ 60 m,
+    spread ~ 0.3 m)."""
+    err_o, err_l = [], []
+    for pts in _planar_sets(3000):
+        ok, p = oracle.esti_plane(pts, 0.1)
+        A = pts.astype(np.float64)
+        sol, *_ = sl.lstsq(A, -np.ones(5), lapack_driver="gelsy")
+        n = np.linalg.norm(sol)
+        ref = np.concatenate([sol / n, [1 / n]])
+        Q, R, P = sl.qr(pts, mode="economic", pivoting=True)                 # float32 throughout
+        y = sl.solve_triangular(R, Q.T @ (-np.ones(5, np.float32)))
+        s32 = np.zeros(3, np.float32); s32[P] = y
+        n32 = np.linalg.norm(s32)
+        lap = np.concatenate([s32 / n32, [1 / n32]]).astype(np.float64)
+        scale = max(1.0, abs(ref[3]))
+        err_o.append(np.abs(p.astype(np.float64) - ref).max() / scale)
+        err_l.append(np.abs(lap - ref).max() / scale)
+        resid = np.abs(A @ ref[:3] + ref[3])
+        if np.abs(resid - 0.1).min() > 1e-3:          # away from the inlier threshold
+            assert ok == bool((resid <= 0.1).all())
+    err_o, err_l = np.array(err_o), np.array(err_l)
+    assert np.median(err_o) < 2e-4
+    assert err_o.max() < 4 * err_l.max() + 1e-5
+    assert np.mean(err_o) < 3 * np.mean(err_l) + 1e-6
+
+
+def test_world_transform(oracle, small_case):
+    from better_fastlio2_amd import synth
+    sc = small_case["scan"]
+    st = small_case["state14"]
+    w = oracle.body_to_world(st, sc.body[:2000])
+    R_wi = synth.quat_to_rot(st[3:7]); R_il = synth.quat_to_rot(st[7:11])
+    ref = (R_wi @ (R_il @ sc.body[:2000].astype(np.float64).T + st[11:14, None]) + st[0:3, None]).T
+    assert np.abs(w - ref).max() < 2e-5               # fp32 storage of ~60 m coordinates
+
+
+def test_manifold_boxplus_boxminus_roundtrip(oracle):
+    rng = np.random.default_rng(2)
+    from better_fastlio2_amd import capi
+    for _ in range(200):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        q2 = rng.normal(size=4); q2 /= np.linalg.norm(q2)
+        x = capi.make_state26(rng.normal(size=3), q, q2, rng.normal(size=3), rng.normal(size=3),
+                              rng.normal(size=3) * 0.01, rng.normal(size=3) * 0.01, (0.3, 0.2, -9.8009))
+        x[23:26] *= 9.809 / np.linalg.norm(x[23:26])
+        dx = rng.normal(size=23) * 0.05
+        y = oracle.state_boxplus(x, dx)
+        back = oracle.state_boxminus(y, x)
+        assert np.abs(back - dx).max() < 1e-9
+        assert abs(np.linalg.norm(y[23:26]) - 9.809) < 1e-9
+        assert abs(np.linalg.norm(y[3:7]) - 1) < 1e-12
+
+
+def test_iterated_update_reduces_pose_error(oracle, small_case):
+    """End-to-end sanity of the restated filter: three iterations pull a 10 cm / 0.5 deg perturbation
+    back to the centimetre level, and the information-form gain equals the textbook one."""
+    from better_fastlio2_amd import capi, synth
+    w, sc = small_case["world"], small_case["scan"]
+    om = oracle.OracleMap(0.2); om.build(w.points)
+    x0 = capi.make_state26(small_case["pos"], small_case["rot"], sc.off_R, sc.off_T)
+    x1, P1, arr, log = oracle.update_iterated(om, x0, synth.init_cov(), sc.body)
+    assert np.linalg.norm(x0[:3] - sc.pos) > 0.09
+    assert np.linalg.norm(x1[:3] - sc.pos) < 0.02
+    assert len(log) == 4 and log[0][0] == 1          # first pass always searches (esekfom.hpp:1624)
+    assert np.allclose(P1, P1.T, atol=1e-12)
+    assert np.linalg.eigvalsh(0.5 * (P1 + P1.T)).min() > -1e-12
+    assert P1[0, 0] < 1e-4                            # position covariance collapsed from 1.0
+
+
+def test_hth_matches_numpy(oracle):
+    rng = np.random.default_rng(3)
+    hx = rng.normal(size=(500, 12)); h = rng.normal(size=500)
+    HTH, HTh = oracle.hth(hx, h)
+    assert np.allclose(HTH, hx.T @ hx, rtol=1e-12, atol=1e-12)
+    assert np.allclose(HTh, hx.T @ h, rtol=1e-12, atol=1e-12)
+
+
+def test_map_incremental_classification_is_total(oracle, small_case):
+    """map_incremental (laserMapping.cpp:1440-1496): every point is skip / add / add-no-downsample."""
+    w, sc = small_case["world"], small_case["scan"]
+    om = oracle.OracleMap(0.2); om.build(w.points)
+    wq = oracle.body_to_world(small_case["state14"], sc.body[:3000])
+    x, d, c, _ = om.knn(wq)
+    cls = oracle.map_incremental_classify(wq, x, c, 0.2)
+    assert set(np.unique(cls)) <= {0, 1, 2}
+    assert (cls == 0).sum() > 0 and (cls == 1).sum() > 0
