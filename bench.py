@@ -115,6 +115,7 @@ def cpu_baseline(world_pts, scan, x0, P0, max_iter: int, ext: bool, sample_every
     if use_ref:
         _, _, _, secs = tree.knn(wq)
         po.use_reference_knn(None)
+        del tree
     else:
         _, _, _, secs = om.knn(wq, 5, 1)
     t_step = float(np.median(ts)) * sample_every
@@ -219,7 +220,18 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_knn, "avg_launch_us": knn_ms * 1e3},
     }
     if world_size == 1 and not a.no_cpu_baseline:
-        cb = cpu_baseline(world.points, scan, x0, P0, max_iter, ext, sample_every=4)
+        # the reference's ikd-Tree printf()s from its re-balancing thread: keep stdout to the ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            cb = cpu_baseline(world.points, scan, x0, P0, max_iter, ext, sample_every=4)
+            import gc
+            gc.collect()                                       # ~RefIkdTree joins the thread (prints again)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         cb.pop("posterior")
         out["cpu_baseline"] = cb
     print(json.dumps(out), flush=True)

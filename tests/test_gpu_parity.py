@@ -39,8 +39,21 @@ def test_nearest_search_bit_exact(gpu_capi, oracle, small_case, lanes):
     ox, od, oc, _ = om.knn(q)
     gx, gd, gc = ctx.nearest_search(q)
     assert np.array_equal(gc, oc)
-    assert bits_equal(gd, od)
-    assert bits_equal(gx, ox)
+    assert bits_equal(gd, od)                                   # every squared distance, every query
+    # Which of several EXACTLY equidistant points the reference returns depends on its traversal
+    # order (strict `<` at ikd_Tree.cpp:887), so points are compared where ranks 1..6 are tie-free
+    # (all in-map queries; far queries collide in fp32: ulp(d^2) ~ 8 at 10 km) ...
+    x6, d6, c6, _ = om.knn(q, 6, 1)
+    tie_free = (np.diff(d6, axis=1) > 0).all(1)
+    assert tie_free[:4000].all() and tie_free.mean() > 0.95
+    assert bits_equal(gx[tie_free], ox[tie_free])
+    # ... and on tied rows every returned point must be a map point at exactly the reported distance
+    mp = {p.tobytes() for p in small_case["world"].points}
+    for i in np.where(~tie_free)[0]:
+        for k in range(5):
+            assert gx[i, k].tobytes() in mp
+            dd = q[i] - gx[i, k]
+            assert np.float32(np.float32(dd[0] * dd[0] + dd[1] * dd[1]) + dd[2] * dd[2]) == gd[i, k]
     # stride-48 input (pcl::PointXYZINormal records, common_lib.h:161) gives the same answer
     rec = np.zeros((len(q), 12), np.float32); rec[:, :3] = q; rec[:, 3] = 1.0; rec[:, 8] = 7.0
     gx2, gd2, gc2 = ctx.nearest_search(rec)
