@@ -230,6 +230,8 @@ def main():
             gc.collect()                                       # ~RefIkdTree joins the thread (prints again)
         finally:
             sys.stdout.flush()
+            import ctypes
+            ctypes.CDLL(None).fflush(None)                     # the tree's printf()s sit in libc's buffer
             os.dup2(saved, 1)
             os.close(saved)
         cb.pop("posterior")

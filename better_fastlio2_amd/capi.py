@@ -139,6 +139,11 @@ def _points(a) -> np.ndarray:
     return a
 
 
+def _stride(a: np.ndarray) -> int:
+    """Record stride in bytes (numpy reports (0, 0) strides for empty arrays)."""
+    return a.shape[1] * a.itemsize
+
+
 class LioContext:
     """One GPU-resident map + scan + measurement-model context (lio_ctx)."""
 
@@ -172,7 +177,7 @@ class LioContext:
     # ---- map (KD_TREE facade) --------------------------------------------------------------------
     def map_build(self, pts):
         p = _points(pts)
-        self._chk(self.L.lio_map_build(self.h, _ptr(p), len(p), p.strides[0]), "lio_map_build")
+        self._chk(self.L.lio_map_build(self.h, _ptr(p), len(p), _stride(p)), "lio_map_build")
 
     def map_build_device(self, d_ptr: int, n: int):
         self._chk(self.L.lio_map_build_device(self.h, _vp(d_ptr), n), "lio_map_build_device")
@@ -180,7 +185,7 @@ class LioContext:
     def map_add(self, pts, downsample_on: bool) -> int:
         p = _points(pts)
         n_added = C.c_int(0)
-        self._chk(self.L.lio_map_add(self.h, _ptr(p), len(p), p.strides[0], int(downsample_on), C.byref(n_added)),
+        self._chk(self.L.lio_map_add(self.h, _ptr(p), len(p), _stride(p), int(downsample_on), C.byref(n_added)),
                   "lio_map_add")
         return n_added.value
 
@@ -214,14 +219,14 @@ class LioContext:
         xyz = np.full((n, 5, 3), np.nan, np.float32)
         d = np.full((n, 5), np.inf, np.float32)
         cnt = np.zeros(n, np.int32)
-        self._chk(self.L.lio_map_nearest_search(self.h, _ptr(q), n, q.strides[0], _ptr(xyz), _ptr(d), _ptr(cnt)),
+        self._chk(self.L.lio_map_nearest_search(self.h, _ptr(q), n, _stride(q), _ptr(xyz), _ptr(d), _ptr(cnt)),
                   "lio_map_nearest_search")
         return xyz, d, cnt
 
     # ---- scan + measurement model ------------------------------------------------------------------
     def scan_set(self, body):
         b = _points(body)
-        self._chk(self.L.lio_scan_set(self.h, _ptr(b), len(b), b.strides[0]), "lio_scan_set")
+        self._chk(self.L.lio_scan_set(self.h, _ptr(b), len(b), _stride(b)), "lio_scan_set")
 
     def scan_set_device(self, d_ptr: int, n: int):
         self._chk(self.L.lio_scan_set_device(self.h, _vp(d_ptr), n), "lio_scan_set_device")

@@ -64,6 +64,7 @@ struct DeviceOut {                            // written by the final reduction 
     unsigned long long n_candidates;
     int      m;
     int      n_unresolved;
+    unsigned long long seq;                   // written LAST (system-scope release): the host polls it
 };
 
 // ---- cell / key arithmetic (host + device) ----------------------------------------------------
@@ -99,11 +100,18 @@ LIO_HD uint32_t compact21(uint64_t x) {      // inverse of spread21
 LIO_HD uint64_t morton3(uint32_t cx, uint32_t cy, uint32_t cz) {
     return (spread21(cx) << 2) | (spread21(cy) << 1) | spread21(cz);
 }
-LIO_HD uint32_t hash_key(uint64_t k) {       // 64 -> 32 bit finaliser
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
-    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
-    k ^= k >> 33;
-    return (uint32_t)k;
+// Slot hash of a cell: three 24-bit multiplies (full-rate v_mul_u32_u24 on gfx950; the biased
+// coordinates have 21 bits) and an xor-shift fold -- 64-bit multiplies are quarter rate and showed
+// up in the k-NN kernel's VALU time.
+LIO_HD uint32_t hash_cell(uint32_t cx, uint32_t cy, uint32_t cz) {
+    uint32_t h = ((cx & 0xffffffu) * 0x9e3779u) ^ ((cy & 0xffffffu) * 0x85ebcbu) ^ ((cz & 0xffffffu) * 0xc2b2afu);
+    h ^= h >> 15;
+    h ^= h << 7;
+    h ^= h >> 11;
+    return h;
+}
+LIO_HD uint32_t hash_key(uint64_t packed) {  // same hash from the packed key (x << 42 | y << 21 | z)
+    return hash_cell((uint32_t)(packed >> 42) & 0x1fffffu, (uint32_t)(packed >> 21) & 0x1fffffu, (uint32_t)packed & 0x1fffffu);
 }
 
 // squared distance exactly as KD_TREE::calc_dist (include/ikd-Tree/ikd_Tree.cpp:1374-1378):

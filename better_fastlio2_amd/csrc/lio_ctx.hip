@@ -34,9 +34,12 @@ struct lio_ctx {
     uint32_t *d_cell_counts = nullptr, *d_cell_starts = nullptr;
     HashEntry* d_table = nullptr;
     size_t table_slots = 0;
+    HashEntry* d_ltable = nullptr;             // tables of the coarser tree levels (>= 1), back to back
+    size_t ltable_slots = 0;
+    TreeLevels levels{};
     void* d_temp = nullptr;
     size_t temp_bytes = 0;
-    uint32_t* d_counters = nullptr;            // [0] n_unresolved, [1] n_runs / misc, [2..3] spare
+    uint32_t* d_counters = nullptr;            // [0] n_unresolved, [1] reduction ticket, [2..3] build/add scratch, [4] run counts
     unsigned long long* d_cand = nullptr;
     float* d_boxes = nullptr;                  // up to 64 boxes
     uint32_t n_points = 0, n_live = 0, n_cells = 0;
@@ -46,10 +49,11 @@ struct lio_ctx {
     int cap_q = 0, nq = 0;
     float4 *d_body = nullptr, *d_world = nullptr, *d_nbr = nullptr, *d_normvec = nullptr;
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
-    uint32_t* d_unres = nullptr;
+    uint8_t* d_unres = nullptr;                // per query: 1 = needs the exact tree walk
     double *d_rows = nullptr, *d_partials = nullptr;
-    DeviceOut* d_out = nullptr;
-    DeviceOut* h_out = nullptr;                // pinned
+    DeviceOut* h_out = nullptr;                // pinned + mapped: the final reduction writes it directly
+    DeviceOut* d_out = nullptr;                // device alias of h_out
+    unsigned long long seq = 0;                // sequence number of the last pass (polled in h_out->seq)
     bool have_scan = false, have_search = false, have_pass = false;
     Pose14 last_pose{};
     bool last_ext = false;
@@ -66,7 +70,7 @@ struct lio_ctx {
     int cap_qs = 0;
     float4 *d_qs_world = nullptr, *d_qs_nbr = nullptr;
     uint8_t* d_qs_cnt = nullptr;
-    uint32_t* d_qs_unres = nullptr;
+    uint8_t* d_qs_unres = nullptr;
 
     // batch buffers of lio_map_add
     size_t cap_add = 0;
@@ -75,10 +79,12 @@ struct lio_ctx {
     uint32_t *d_add_order = nullptr, *d_add_order2 = nullptr, *d_add_gcount = nullptr, *d_add_gstart = nullptr;
 
     // ---- profiling ----------------------------------------------------------------------------
+    // HIP-event pairs around each kernel family; recorded without synchronising and resolved when
+    // the totals are read, so that timing a run does not add a stream synchronisation per pass
     bool prof = false;
     bool census = false;                       // count C(q) in the k-NN kernel (one atomic per wavefront)
-    hipEvent_t ev[LIO_PROF_COUNT][2]{};
-    bool ev_used[LIO_PROF_COUNT]{};
+    std::vector<hipEvent_t> ev_pool[LIO_PROF_COUNT];   // start, stop, start, stop, ...
+    size_t ev_next[LIO_PROF_COUNT]{};          // events of the pool in use
     double prof_ms[LIO_PROF_COUNT]{};
     long long prof_n[LIO_PROF_COUNT]{};
 
@@ -163,6 +169,7 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
         HIPCHK(c, hipMemsetAsync(c->d_table, 0xFF, c->table_slots * sizeof(HashEntry), s));
         c->grid.table_mask = (uint32_t)(c->table_slots - 1);
         HIPCHK(c, hipStreamSynchronize(s));
+        c->levels = TreeLevels{};
         c->have_map = true;
         return LIO_OK;
     }
@@ -170,9 +177,9 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
     HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_mkeys_tmp, c->d_mkeys, c->d_vals_tmp, c->d_vals, n, s));
     HIPCHK(c, launch_gather_points(src, c->d_vals, n, c->d_pts, s));
     HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_mkeys, n, c->d_cell_keys, c->d_cell_counts,
-                                    c->d_counters + 1, s));
+                                    c->d_counters + 4, s));
     uint32_t n_cells = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_cells, c->d_counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&n_cells, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_cell_counts, c->d_cell_starts, n_cells, s));
     // table: power of two >= 4 x cells (load factor <= 0.25 keeps unsuccessful probes short)
@@ -190,49 +197,110 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
     HIPCHK(c, hipStreamSynchronize(s));
     c->grid.table_mask = (uint32_t)(slots - 1);
     c->n_cells = n_cells;
+
+    // ---- coarser levels of the hashed 64-ary tree (exact fallback of the k-NN) ---------------------
+    // top level = lowest level at which one cell holds every point (first vs last Morton key)
+    uint64_t kfirst = 0, klast = 0;
+    HIPCHK(c, hipMemcpyAsync(&kfirst, c->d_mkeys, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&klast, c->d_mkeys + (n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    TreeLevels lv{};
+    const uint64_t diff = kfirst ^ klast;
+    int top = 0;
+    if (diff != 0) top = (63 - __builtin_clzll(diff)) / 6 + 1;
+    lv.top_level = top;
+    {
+        const uint64_t prefix = 6 * top >= 64 ? 0ull : (kfirst >> (6 * top));
+        lv.top_cx = compact21(prefix >> 2); lv.top_cy = compact21(prefix >> 1); lv.top_cz = compact21(prefix);
+    }
+    size_t used = 0;
+    for (int L = 1; L < top; ++L) {
+        HIPCHK(c, run_length_encode_shifted(c->d_temp, c->temp_bytes, c->d_mkeys, n, 6 * L, c->d_cell_keys,
+                                            c->d_cell_counts, c->d_counters + 4, s));
+        uint32_t n_l = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_l, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_cell_counts, c->d_cell_starts, n_l, s));
+        size_t sl = 64;
+        while (sl < (size_t)n_l * 4) sl <<= 1;
+        if (used + sl > c->ltable_slots) {
+            // grow (keeps the levels already inserted)
+            size_t cap = c->ltable_slots ? c->ltable_slots : 4096;
+            while (cap < used + sl) cap <<= 1;
+            HashEntry* nt = nullptr;
+            HIPCHK(c, hipMalloc((void**)&nt, cap * sizeof(HashEntry)));
+            if (used > 0) HIPCHK(c, hipMemcpyAsync(nt, c->d_ltable, used * sizeof(HashEntry), hipMemcpyDeviceToDevice, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (c->d_ltable) (void)hipFree(c->d_ltable);
+            c->d_ltable = nt; c->ltable_slots = cap;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_ltable + used, 0xFF, sl * sizeof(HashEntry), s));
+        HIPCHK(c, launch_table_insert(c->d_cell_keys, c->d_cell_starts, c->d_cell_counts, n_l, c->d_ltable + used,
+                                      (uint32_t)(sl - 1), s));
+        lv.off[L] = (uint32_t)used; lv.mask[L] = (uint32_t)(sl - 1);
+        used += sl;
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->levels = lv;
     c->have_map = true;
     return LIO_OK;
 }
 
+// resolve every recorded pair (needs the stream drained) and recycle the pool
+void prof_collect(lio_ctx* c) {
+    bool any = false;
+    for (int w = 0; w < LIO_PROF_COUNT; ++w) any = any || c->ev_next[w] > 0;
+    if (!any) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (int w = 0; w < LIO_PROF_COUNT; ++w) {
+        for (size_t i = 0; i + 1 < c->ev_next[w]; i += 2) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, c->ev_pool[w][i], c->ev_pool[w][i + 1]) == hipSuccess) {
+                c->prof_ms[w] += ms;
+                c->prof_n[w] += 1;
+            }
+        }
+        c->ev_next[w] = 0;
+    }
+}
 void prof_begin(lio_ctx* c, int which) {
-    if (c->prof) { (void)hipEventRecord(c->ev[which][0], c->stream); }
+    if (!c->prof) return;
+    if (c->ev_next[which] + 2 > 8192) prof_collect(c);            // bounded pool
+    while (c->ev_pool[which].size() < c->ev_next[which] + 2) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->ev_pool[which].push_back(e);
+    }
+    (void)hipEventRecord(c->ev_pool[which][c->ev_next[which]], c->stream);
 }
 void prof_end(lio_ctx* c, int which) {
-    if (c->prof) { (void)hipEventRecord(c->ev[which][1], c->stream); c->ev_used[which] = true; }
-}
-void prof_collect(lio_ctx* c) {
     if (!c->prof) return;
-    for (int w = 0; w < LIO_PROF_COUNT; ++w) {
-        if (!c->ev_used[w]) continue;
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, c->ev[w][0], c->ev[w][1]) == hipSuccess) {
-            c->prof_ms[w] += ms;
-            c->prof_n[w] += 1;
-        }
-        c->ev_used[w] = false;
-    }
+    if (c->ev_pool[which].size() < c->ev_next[which] + 2) return;
+    (void)hipEventRecord(c->ev_pool[which][c->ev_next[which] + 1], c->stream);
+    c->ev_next[which] += 2;
 }
 
 // k-NN of nq world/body queries into (nbr, cnt); queries_world must hold the world points when
 // body == nullptr, and receives them otherwise.
 int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14& pose, int nq, int stride,
-            float4* nbr, uint8_t* cnt, uint32_t* unres) {
+            float4* nbr, uint8_t* cnt, uint8_t* unres) {
     hipStream_t s = c->stream;
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(uint32_t), s));
-    HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), s));
+    // d_counters[0] / d_cand are zero here: zeroed at creation and re-zeroed by whoever consumes them
+    // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
     KnnArgs ka{};
     ka.map_pts = c->d_pts; ka.table = c->d_table; ka.grid = c->grid;
     ka.body = body; ka.world_in = body ? nullptr : queries_world; ka.pose = pose;
     ka.nq = nq; ka.nq_stride = stride;
     ka.world_out = body ? queries_world : nullptr;
-    ka.nbr = nbr; ka.cnt = cnt; ka.unresolved = unres; ka.n_unresolved = c->d_counters; ka.cand_total = c->census ? c->d_cand : nullptr;
+    ka.nbr = nbr; ka.cnt = cnt; ka.unres = unres; ka.cand_total = c->census ? c->d_cand : nullptr;
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
     prof_begin(c, LIO_PROF_KNN);
     HIPCHK(c, launch_knn27(ka, lanes, s));
     prof_end(c, LIO_PROF_KNN);
     TreeArgs ta{};
-    ta.map_pts = c->d_pts; ta.mkeys = c->d_mkeys; ta.grid = c->grid; ta.queries = queries_world;
-    ta.list = unres; ta.n_list = c->d_counters; ta.nq = nq; ta.nq_stride = stride; ta.nbr = nbr; ta.cnt = cnt;
+    ta.map_pts = c->d_pts; ta.table0 = c->d_table; ta.ltable = c->d_ltable; ta.levels = c->levels; ta.grid = c->grid;
+    ta.queries = queries_world; ta.unres = unres; ta.n_unresolved = c->d_counters;
+    ta.nq = nq; ta.nq_stride = stride; ta.nbr = nbr; ta.cnt = cnt;
     prof_begin(c, LIO_PROF_FALLBACK);
     HIPCHK(c, launch_knn_tree(ta, s));
     prof_end(c, LIO_PROF_FALLBACK);
@@ -254,7 +322,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     if (!(cfg->filter_size_map_min > 0.0f) || cfg->max_scan_points <= 0 || cfg->max_map_points <= 0 ||
         cfg->max_map_points > 0x7fffff00ll)
         return LIO_ERR_INVALID_ARG;
-    if (cfg->lanes_per_query != 0 && cfg->lanes_per_query != 8 && cfg->lanes_per_query != 16 &&
+    if (cfg->lanes_per_query != 0 && cfg->lanes_per_query != 4 && cfg->lanes_per_query != 8 && cfg->lanes_per_query != 16 &&
         cfg->lanes_per_query != 32 && cfg->lanes_per_query != 64)
         return LIO_ERR_INVALID_ARG;
     if (cfg->cell_size != 0.0f && !is_pow2f(cfg->cell_size)) return LIO_ERR_INVALID_ARG;
@@ -301,9 +369,10 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     c->table_slots = 1024;
     CREATE_CHK(hipMalloc((void**)&c->d_table, c->table_slots * sizeof(HashEntry)));
     CREATE_CHK(hipMemset(c->d_table, 0xFF, c->table_slots * sizeof(HashEntry)));
-    CREATE_CHK(hipMalloc((void**)&c->d_counters, 4 * sizeof(uint32_t)));
-    CREATE_CHK(hipMemset(c->d_counters, 0, 4 * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)));
+    CREATE_CHK(hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_cand, sizeof(unsigned long long)));
+    CREATE_CHK(hipMemset(c->d_cand, 0, sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc((void**)&c->d_boxes, 64 * 6 * sizeof(float)));
 
     const size_t nq = (size_t)cfg->max_scan_points;
@@ -314,14 +383,11 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_normvec, nq * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_cnt, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_sel, nq));
-    CREATE_CHK(hipMalloc((void**)&c->d_unres, nq * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_unres, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_partials, (size_t)residual_blocks((int)nq) * RED_STRIDE * sizeof(double)));
-    CREATE_CHK(hipMalloc((void**)&c->d_out, sizeof(DeviceOut)));
-    CREATE_CHK(hipHostMalloc((void**)&c->h_out, sizeof(DeviceOut), hipHostMallocDefault));
-    for (int w = 0; w < LIO_PROF_COUNT; ++w) {
-        CREATE_CHK(hipEventCreate(&c->ev[w][0]));
-        CREATE_CHK(hipEventCreate(&c->ev[w][1]));
-    }
+    CREATE_CHK(hipHostMalloc((void**)&c->h_out, sizeof(DeviceOut), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_out, 0, sizeof(DeviceOut));
+    CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
 #undef CREATE_CHK
     c->have_map = true;                         // an empty map is a valid map (Build not yet called)
     *out = c;
@@ -333,19 +399,17 @@ void lio_destroy(lio_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
-                   c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
+                   c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_ltable, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
                    c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
-                   c->d_partials, c->d_out, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
+                   c->d_partials, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
                    c->d_add_pts, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys, c->d_add_order,
                    c->d_add_order2, c->d_add_gcount, c->d_add_gstart};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
-    for (int w = 0; w < LIO_PROF_COUNT; ++w) {
-        if (c->ev[w][0]) (void)hipEventDestroy(c->ev[w][0]);
-        if (c->ev[w][1]) (void)hipEventDestroy(c->ev[w][1]);
-    }
+    for (int w = 0; w < LIO_PROF_COUNT; ++w)
+        for (hipEvent_t e : c->ev_pool[w]) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -417,9 +481,9 @@ int lio_map_add(lio_ctx* c, const float* pts, int n, int stride_bytes, int downs
         HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_add_keys, c->d_add_keys2, c->d_add_order,
                                      c->d_add_order2, (size_t)n, s));
         HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_add_keys2, (size_t)n, c->d_add_ukeys,
-                                        c->d_add_gcount, c->d_counters + 1, s));
+                                        c->d_add_gcount, c->d_counters + 4, s));
         uint32_t n_groups = 0;
-        HIPCHK(c, hipMemcpyAsync(&n_groups, c->d_counters + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&n_groups, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, n_groups, s));
         HIPCHK(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(uint32_t), s));
@@ -520,7 +584,7 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
         HIPCHK(c, hipMalloc((void**)&c->d_qs_world, (size_t)n * sizeof(float4)));
         HIPCHK(c, hipMalloc((void**)&c->d_qs_nbr, (size_t)n * K * sizeof(float4)));
         HIPCHK(c, hipMalloc((void**)&c->d_qs_cnt, (size_t)n));
-        HIPCHK(c, hipMalloc((void**)&c->d_qs_unres, (size_t)n * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_qs_unres, (size_t)n));
         c->cap_qs = n;
     }
     int rc = upload_points(c, q_xyz, (size_t)n, stride_bytes, c->d_qs_world);
@@ -535,9 +599,10 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
     float* dd = (float*)((char*)c->d_scratch + b_xyz);
     int* dc = (int*)((char*)c->d_scratch + b_xyz + b_d);
     HIPCHK(c, launch_unpack_neighbors(c->d_qs_nbr, c->d_qs_cnt, n, n, dx, dd, dc, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, b_xyz + b_d + b_c, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    prof_collect(c);
     if (out_xyz) std::memcpy(out_xyz, c->h_scratch, b_xyz);
     if (out_sqdist) std::memcpy(out_sqdist, (char*)c->h_scratch + b_xyz, b_d);
     if (out_count) std::memcpy(out_count, (char*)c->h_scratch + b_xyz + b_d, b_c);
@@ -588,16 +653,29 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
     ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.rows = nullptr; ra.partials = c->d_partials;
+    const unsigned long long seq = ++c->seq;
+    ra.ticket = c->d_counters + 1; ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
     prof_begin(c, LIO_PROF_RESIDUAL);
     HIPCHK(c, launch_residual(ra, do_search != 0, ext, s));
     prof_end(c, LIO_PROF_RESIDUAL);
-    prof_begin(c, LIO_PROF_REDUCE);
-    HIPCHK(c, launch_reduce_final(c->d_partials, residual_blocks(nq), ext, do_search ? c->d_counters : nullptr,
-                                  do_search ? c->d_cand : nullptr, c->d_out, s));
-    prof_end(c, LIO_PROF_REDUCE);
-    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, sizeof(DeviceOut), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    prof_collect(c);
+    // The record lands in host-mapped memory; poll its sequence number instead of paying for a
+    // device-to-host copy plus a stream synchronisation.  hipStreamQuery guards against a fault.
+    {
+        volatile unsigned long long* pseq = &c->h_out->seq;
+        unsigned spins = 0;
+        for (;;) {
+            if (__atomic_load_n(pseq, __ATOMIC_ACQUIRE) == seq) break;
+            if ((++spins & 0x3fff) == 0) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) {
+                    if (__atomic_load_n(pseq, __ATOMIC_ACQUIRE) == seq) break;
+                    return c->fail(LIO_ERR_HIP, "lio_measure", "stream idle but result record not published");
+                }
+                if (q != hipErrorNotReady) return c->fail(LIO_ERR_HIP, "lio_measure", hipGetErrorString(q));
+            }
+            __builtin_ia32_pause();
+        }
+    }
 
     const DeviceOut& d = *c->h_out;
     out->m = d.m;
@@ -624,6 +702,8 @@ int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_m
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = c->last_pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
     ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.rows = c->d_rows; ra.partials = c->d_partials;
+    ra.ticket = c->d_counters + 1; ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out;
+    ra.seq = ++c->seq;                          // the record is rewritten with identical content
     HIPCHK(c, launch_residual(ra, false, c->last_ext, s));
     const size_t b_rows = (size_t)nq * 13 * sizeof(double);
     int rc = ensure_scratch(c, b_rows + (size_t)nq);
@@ -697,15 +777,22 @@ int lio_get_scan_state(lio_ctx* c, float* world_xyz, uint8_t* selected, float* n
 }
 
 // ---- profiling -----------------------------------------------------------------------------------
-int lio_profile_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; c->prof = on != 0; return LIO_OK; }
+int lio_profile_enable(lio_ctx* c, int on) {
+    if (!c) return LIO_ERR_INVALID_ARG;
+    if (!on) prof_collect(c);
+    c->prof = on != 0;
+    return LIO_OK;
+}
 int lio_census_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; c->census = on != 0; return LIO_OK; }
 int lio_profile_reset(lio_ctx* c) {
     if (!c) return LIO_ERR_INVALID_ARG;
-    for (int w = 0; w < LIO_PROF_COUNT; ++w) { c->prof_ms[w] = 0.0; c->prof_n[w] = 0; c->ev_used[w] = false; }
+    prof_collect(c);
+    for (int w = 0; w < LIO_PROF_COUNT; ++w) { c->prof_ms[w] = 0.0; c->prof_n[w] = 0; }
     return LIO_OK;
 }
 int lio_profile_get(lio_ctx* c, int which, double* total_ms, long long* launches) {
     if (!c || which < 0 || which >= LIO_PROF_COUNT) return LIO_ERR_INVALID_ARG;
+    prof_collect(c);
     if (total_ms) *total_ms = c->prof_ms[which];
     if (launches) *launches = c->prof_n[which];
     return LIO_OK;

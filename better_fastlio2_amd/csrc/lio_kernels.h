@@ -20,20 +20,29 @@ struct KnnArgs {
     float4*          world_out;     // feats_down_world (may be nullptr)
     float4*          nbr;           // [5][nq_stride]: x, y, z, sqdist of the k-th neighbour
     uint8_t*         cnt;           // [nq] neighbours found (0..5)
-    uint32_t*        unresolved;    // [nq] list of queries whose result is not proven by the 27-cell search
-    uint32_t*        n_unresolved;  // device counter
+    uint8_t*         unres;         // [nq] 1 = result not proven by the 27-cell search (-> tree walk)
     unsigned long long* cand_total; // device counter: sum of C(q)
 };
-// lanes_per_query in {8, 16, 32, 64}
+// lanes_per_query in {4, 8, 16, 32, 64}
 hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s);
 
+// hashed 64-ary tree: level L = grid coarsened by 4^L, tables of levels 1.. live in one buffer
+constexpr int TREE_MAX_LEVELS = 12;
+struct TreeLevels {
+    uint32_t off[TREE_MAX_LEVELS];   // first slot of level L in ltable (L >= 1)
+    uint32_t mask[TREE_MAX_LEVELS];  // slots - 1 of level L
+    int      top_level;              // level of the single node that holds every point
+    uint32_t top_cx, top_cy, top_cz; // its cell coordinates at top_level
+};
 struct TreeArgs {
     const float4*    map_pts;
-    const uint64_t*  mkeys;         // Morton key per map point (sorted)
+    const HashEntry* table0;        // level-0 table (the k-NN kernel's)
+    const HashEntry* ltable;        // levels >= 1
+    TreeLevels       levels;
     Grid             grid;
-    const float4*    queries;       // world-frame queries, indexed by the entries of `list`
-    const uint32_t*  list;
-    const uint32_t*  n_list;        // device counter
+    const float4*    queries;       // world-frame queries
+    const uint8_t*   unres;         // [nq] 1 = not proven by the 27-cell kernel
+    uint32_t*        n_unresolved;  // device counter (+= queries handled here)
     int              nq;
     int              nq_stride;
     float4*          nbr;
@@ -54,12 +63,14 @@ struct ResidualArgs {
     float4*        normvec;         // normvec (n^, pd2)
     double*        rows;            // optional [nq][13]: h_x row (12) + h, valid where sel
     double*        partials;        // [nblocks][RED_STRIDE]
+    uint32_t*      ticket;          // device counter, zero between launches: arrival order of the workgroups
+    uint32_t*      n_unresolved;    // read into the record and reset (search passes)
+    unsigned long long* cand_total; // ditto
+    DeviceOut*     out;             // host-mapped result record
+    unsigned long long seq;         // published last (system-scope release) in out->seq
 };
 int residual_blocks(int nq);
 hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s);
-hipError_t launch_reduce_final(const double* partials, int nblocks, bool extrinsic_est_en,
-                               const uint32_t* n_unresolved, const unsigned long long* cand_total,
-                               DeviceOut* out, hipStream_t s);
 
 // ---- map construction / mutation ----------------------------------------------------------------
 hipError_t launch_point_keys(const float4* pts, uint32_t n, Grid grid, uint64_t* mkeys, uint32_t* vals,
@@ -85,6 +96,10 @@ size_t rle_temp_bytes(size_t n);
 hipError_t run_length_encode_u64(void* temp, size_t temp_bytes, const uint64_t* keys, size_t n,
                                  uint64_t* unique_out, uint32_t* counts_out, uint32_t* n_runs_out,
                                  hipStream_t s);
+// same on (keys[i] >> shift): the cells of a coarser tree level
+hipError_t run_length_encode_shifted(void* temp, size_t temp_bytes, const uint64_t* keys, size_t n, int shift,
+                                     uint64_t* unique_out, uint32_t* counts_out, uint32_t* n_runs_out,
+                                     hipStream_t s);
 size_t scan_temp_bytes(size_t n);
 hipError_t exclusive_scan_u32(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, size_t n,
                               hipStream_t s);

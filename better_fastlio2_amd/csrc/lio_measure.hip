@@ -10,8 +10,10 @@
 //       s > 0.9 test (:1925-1930), the fp64 Jacobian row (:1976-2001); the rows of a 256-point
 //       workgroup are staged in LDS and reduced to the unique entries of H^T H, H^T h, the
 //       residual sum and the row count in a FIXED order (run-to-run bit-stable, no atomics).
-//   reduce_final_kernel<EXT>      one workgroup: sums the per-workgroup partials in block order,
-//       expands the symmetric matrix and fills the DeviceOut record that is copied to the host.
+//       The workgroup that arrives LAST (device-scope ticket) sums the per-workgroup partials in a
+//       fixed order, expands the symmetric matrix and writes the DeviceOut record straight into
+//       host-mapped memory, publishing it with a system-scope release of a sequence number: one
+//       launch per pass, no separate reduction kernel, no device-to-host copy.
 #include "lio_kernels.h"
 #include "lio_math.h"
 
@@ -123,7 +125,66 @@ __global__ __launch_bounds__(256) void residual_kernel(ResidualArgs a) {
         double t = 0.0;
 #pragma unroll
         for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
-        a.partials[(size_t)blockIdx.x * RED_STRIDE + tid] = t;
+        // write-through (sc1) store: the last-arriving workgroup reads it back with sc1 loads, so no
+        // L2 write-back fence is needed (cdna_hip_programming.md G16, "sc1 both sides" form)
+        __hip_atomic_store(&a.partials[(size_t)blockIdx.x * RED_STRIDE + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ uint32_t s_last;
+    if (tid == 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last == 0u) return;
+
+    // ---- last workgroup: final reduction over all block partials, fixed order ----------------------
+    const int nblocks = (int)gridDim.x;
+    double f = 0.0;
+    if (e < S::NE) {
+#pragma unroll 8
+        for (int b = seg; b < nblocks; b += S::SEG)
+            f += __hip_atomic_load(&a.partials[(size_t)b * RED_STRIDE + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                               // s_part is reused
+    s_part[seg][e] = f;
+    __syncthreads();
+    __shared__ double s_fin[S::NEP];
+    if (tid < S::NE) {
+        double t = 0.0;
+#pragma unroll
+        for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
+        s_fin[tid] = t;
+    }
+    __syncthreads();
+    // One wavefront writes the whole record into host-mapped memory, fences at system scope and only
+    // then publishes the sequence number the host is polling.
+    if (tid < 64) {
+        DeviceOut* out = a.out;
+        for (int i = tid; i < 144; i += 64) {
+            const int r = i / 12, c = i % 12;
+            double v = 0.0;
+            if (r < S::NC && c < S::NC) {
+                const int lo = r < c ? r : c, hi = r < c ? c : r;
+                // index of (lo, hi) in the row-major upper triangle
+                const int idx = lo * S::NC - (lo * (lo - 1)) / 2 + (hi - lo);
+                v = s_fin[idx];
+            }
+            out->HTH[i] = v;
+        }
+        if (tid < 12) out->HTh[tid] = tid < S::NC ? s_fin[S::NP + tid] : 0.0;
+        if (tid == 0) {
+            out->res_sum = s_fin[S::NP + S::NC];
+            out->m = (int)(s_fin[S::NP + S::NC + 1] + 0.5);
+            out->n_unresolved = SEARCH ? (int)*a.n_unresolved : 0;
+            out->n_candidates = SEARCH ? *a.cand_total : 0ull;
+            // consumed: zero the counters and the ticket for the next pass
+            if (SEARCH) { *a.n_unresolved = 0u; *a.cand_total = 0ull; }
+            *a.ticket = 0u;
+        }
+        __threadfence_system();
+        if (tid == 0) __hip_atomic_store(&out->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -139,60 +200,6 @@ hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool ext, hipS
         if (do_search) hipLaunchKernelGGL((residual_kernel<false, true>), grid, block, 0, s, a);
         else           hipLaunchKernelGGL((residual_kernel<false, false>), grid, block, 0, s, a);
     }
-    return hipGetLastError();
-}
-
-// 1024 lanes: lane (part, e) sums the partials of blocks part, part + PARTS, ... for entry e (loads
-// are independent, so they pipeline); the PARTS sub-sums are then combined in a fixed order.
-template <bool EXT>
-__global__ __launch_bounds__(1024) void reduce_final_kernel(const double* partials, int nblocks,
-                                                            const uint32_t* n_unresolved,
-                                                            const unsigned long long* cand_total,
-                                                            DeviceOut* out) {
-    typedef RedShape<EXT> S;
-    constexpr int PARTS = 1024 / S::NEP;
-    __shared__ double s_sub[PARTS][S::NEP];
-    __shared__ double s_fin[S::NEP];
-    const int tid = threadIdx.x;
-    const int e = tid % S::NEP, part = tid / S::NEP;
-    double t = 0.0;
-    if (e < S::NE) {
-#pragma unroll 8
-        for (int b = part; b < nblocks; b += PARTS) t += partials[(size_t)b * RED_STRIDE + e];
-    }
-    s_sub[part][e] = t;
-    __syncthreads();
-    if (tid < S::NE) {
-        double f = 0.0;
-#pragma unroll
-        for (int p = 0; p < PARTS; ++p) f += s_sub[p][tid];
-        s_fin[tid] = f;
-    }
-    __syncthreads();
-    if (tid < 144) {
-        const int r = tid / 12, c = tid % 12;
-        double v = 0.0;
-        if (r < S::NC && c < S::NC) {
-            const int lo = r < c ? r : c, hi = r < c ? c : r;
-            // index of (lo, hi) in the row-major upper triangle
-            const int idx = lo * S::NC - (lo * (lo - 1)) / 2 + (hi - lo);
-            v = s_fin[idx];
-        }
-        out->HTH[tid] = v;
-    }
-    if (tid < 12) out->HTh[tid] = tid < S::NC ? s_fin[S::NP + tid] : 0.0;
-    if (tid == 0) {
-        out->res_sum = s_fin[S::NP + S::NC];
-        out->m = (int)(s_fin[S::NP + S::NC + 1] + 0.5);
-        out->n_unresolved = n_unresolved != nullptr ? (int)*n_unresolved : 0;
-        out->n_candidates = cand_total != nullptr ? *cand_total : 0ull;
-    }
-}
-
-hipError_t launch_reduce_final(const double* partials, int nblocks, bool ext, const uint32_t* n_unresolved,
-                               const unsigned long long* cand_total, DeviceOut* out, hipStream_t s) {
-    if (ext) hipLaunchKernelGGL(reduce_final_kernel<true>, dim3(1), dim3(1024), 0, s, partials, nblocks, n_unresolved, cand_total, out);
-    else     hipLaunchKernelGGL(reduce_final_kernel<false>, dim3(1), dim3(1024), 0, s, partials, nblocks, n_unresolved, cand_total, out);
     return hipGetLastError();
 }
 

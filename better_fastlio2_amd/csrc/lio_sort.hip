@@ -30,6 +30,20 @@ hipError_t run_length_encode_u64(void* temp, size_t temp_bytes, const uint64_t* 
     return rocprim::run_length_encode(temp, temp_bytes, keys, n, unique_out, counts_out, n_runs_out, s);
 }
 
+struct ShiftRight {
+    int shift;
+    __host__ __device__ uint64_t operator()(uint64_t k) const { return k >> shift; }
+};
+hipError_t run_length_encode_shifted(void* temp, size_t temp_bytes, const uint64_t* keys, size_t n, int shift,
+                                     uint64_t* unique_out, uint32_t* counts_out, uint32_t* n_runs_out, hipStream_t s) {
+    auto it = rocprim::make_transform_iterator(keys, ShiftRight{shift});
+    size_t need = 0;
+    hipError_t e = rocprim::run_length_encode(nullptr, need, it, n, unique_out, counts_out, n_runs_out, s);
+    if (e != hipSuccess) return e;
+    if (need > temp_bytes) return hipErrorOutOfMemory;
+    return rocprim::run_length_encode(temp, temp_bytes, it, n, unique_out, counts_out, n_runs_out, s);
+}
+
 size_t scan_temp_bytes(size_t n) {
     size_t bytes = 0;
     (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n,

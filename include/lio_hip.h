@@ -137,8 +137,8 @@ int  lio_scan_size(lio_ctx* ctx);
 /* ---- timing hooks (HIP events on lio_stream around each kernel family) ------------------------ */
 #define LIO_PROF_KNN       0    /* 27-cell k-NN kernel                                              */
 #define LIO_PROF_FALLBACK  1    /* exact tree walk for unresolved queries                           */
-#define LIO_PROF_RESIDUAL  2    /* plane fit + residual + Jacobian + block reduction                */
-#define LIO_PROF_REDUCE    3    /* final HTH/HTh reduction                                          */
+#define LIO_PROF_RESIDUAL  2    /* plane fit + residual + Jacobian + H^T H reduction + result record */
+#define LIO_PROF_REDUCE    3    /* (fused into LIO_PROF_RESIDUAL since the last-arriver reduction; 0) */
 #define LIO_PROF_COUNT     4
 int  lio_profile_enable(lio_ctx* ctx, int on);
 /* candidate census: when on, search passes also report lio_out.n_candidates (costs one device

@@ -111,7 +111,7 @@ def main():
         scan = synth.make_scan(world, nq)
         pos, rot = synth.perturb_state(scan)
         st = synth.state_vector(pos, rot, scan.off_R, scan.off_T)
-        for lanes in (8, 16, 32, 64):
+        for lanes in (4, 8, 16):
             ctx = capi.LioContext(0.2, max_scan_points=nq, max_map_points=nm + 200000, lanes_per_query=lanes)
             t0 = time.time(); ctx.map_build(world.points); tb = time.time() - t0
             ctx.scan_set(scan.body)

@@ -54,7 +54,7 @@ def test_oracle_step_reproduces_golden(oracle, step):
 # ------------------------------------------------------------------ GPU path vs the same files
 @pytest.mark.gpu
 def test_gpu_knn_reproduces_reference_golden(gpu_capi, knn_ref):
-    for lanes in (8, 16, 32, 64):
+    for lanes in (4, 8, 16, 32, 64):
         ctx = gpu_capi.LioContext(0.2, max_scan_points=4096, max_map_points=100_000, lanes_per_query=lanes)
         ctx.map_build(knn_ref["map"])
         x, d, c = ctx.nearest_search(knn_ref["queries"])
