@@ -1,0 +1,68 @@
+"""Keeping map replicas identical across GPUs.
+
+Every rank owns one GPU, one scan stream and one full replica of the map.  After a scan step a rank
+holds the points it wants inserted (`PointToAdd` / `PointNoNeedDownsample`, src/laserMapping.cpp
+:1442-1493) and at most a few delete boxes (`cub_needrm`, :1183-1198).  One all-gather of
+fixed-capacity buffers moves everybody's list to everybody (backend "nccl" = RCCL over xGMI on
+MI355X; "gloo" in the CPU tests); every replica then applies the lists in RANK ORDER through the same
+sequential-equivalent `Add_Points` rule, so the replicas stay bit-identical.  Messages are small
+(<= N_q float4 = 1.6 MB per rank), i.e. latency-bound: no ring all-reduce, no bucketing.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def exchange_inserts(points: np.ndarray, capacity: int, device: "torch.device | str" = "cpu", group=None):
+    """All-gather variable-length insert lists.  points: [n, 3] float32 with n <= capacity.
+    Returns a list (one entry per rank, rank order) of [n_r, 3] float32 arrays."""
+    if not dist.is_initialized():
+        return [np.ascontiguousarray(points, np.float32)]
+    world = dist.get_world_size(group)
+    n = len(points)
+    if n > capacity:
+        raise ValueError(f"{n} points exceed the exchange capacity {capacity}")
+    # one buffer per rank: row 0 = [count, 0, 0, 0], rows 1.. = x, y, z, 0  (float4 records)
+    buf = torch.zeros((capacity + 1, 4), dtype=torch.float32)
+    buf[0, 0] = float(n)
+    if n:
+        buf[1:n + 1, :3] = torch.from_numpy(np.ascontiguousarray(points, np.float32))
+    buf = buf.to(device)
+    out = torch.empty((world * (capacity + 1), 4), dtype=torch.float32, device=device)   # concatenated along dim 0
+    dist.all_gather_into_tensor(out, buf, group=group)
+    out = out.cpu().numpy().reshape(world, capacity + 1, 4)
+    res = []
+    for r in range(world):
+        k = int(out[r, 0, 0])
+        res.append(np.ascontiguousarray(out[r, 1:k + 1, :3]))
+    return res
+
+
+def exchange_boxes(boxes: np.ndarray, max_boxes: int = 4, device: "torch.device | str" = "cpu", group=None):
+    """All-gather delete boxes ([nb, 6] float32, nb <= max_boxes); returns them concatenated in rank order."""
+    boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+    if not dist.is_initialized():
+        return boxes
+    world = dist.get_world_size(group)
+    buf = torch.zeros((max_boxes + 1, 6), dtype=torch.float32)
+    buf[0, 0] = float(len(boxes))
+    if len(boxes):
+        buf[1:len(boxes) + 1] = torch.from_numpy(boxes)
+    buf = buf.to(device)
+    out = torch.empty((world * (max_boxes + 1), 6), dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    out = out.cpu().numpy().reshape(world, max_boxes + 1, 6)
+    parts = [out[r, 1:int(out[r, 0, 0]) + 1] for r in range(world)]
+    return np.ascontiguousarray(np.concatenate(parts, 0)) if parts else boxes
+
+
+def apply_in_rank_order(map_like, insert_lists, downsample_on: bool = True) -> int:
+    """Apply every rank's insert list, rank 0 first (map_like: LioContext or anything with
+    map_add(points, downsample_on)).  Returns the summed Add_Points counters."""
+    total = 0
+    for pts in insert_lists:
+        if len(pts):
+            total += map_like.map_add(pts, downsample_on)
+    return total
