@@ -47,7 +47,11 @@ def _compile(src: str, force: bool, verbose: bool) -> str:
     path = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _newest_header()):
         return obj
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-x", "hip", "-c", path, "-o", obj] + COMMON
+    if src.endswith(".cpp"):
+        # host-only translation unit (the ESKF mirror): plain C++ through the same clang
+        cmd = [hipcc(), "-x", "c++", "-c", path, "-o", obj] + COMMON
+    else:
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-x", "hip", "-c", path, "-o", obj] + COMMON
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

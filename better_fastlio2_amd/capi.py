@@ -11,7 +11,9 @@ but creating a LioContext needs a gfx950 GPU and raises LioError otherwise.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -75,6 +77,18 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's); two HIP runtimes
+    # in one process fight over the device ("No HIP GPUs are available" for whichever initialises
+    # second).  Map torch's copy first -- without importing torch, which can take minutes on a cold
+    # box -- so that liblio_hip.so and a later `import torch` share one runtime whatever the import order.
+    if "torch" not in sys.modules:
+        try:
+            spec = importlib.util.find_spec("torch")
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so") if spec else None
+            if cand and os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except Exception:
+            pass
     path = library_path()
     if not os.path.exists(path):
         if not build_if_missing:

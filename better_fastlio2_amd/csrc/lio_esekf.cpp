@@ -55,43 +55,80 @@ M3 hat(const V3& v) {                                        // mtk/src/mtkmath.
 double dot3(const V3& x, const V3& y) { return x.a[0] * y.a[0] + x.a[1] * y.a[1] + x.a[2] * y.a[2]; }
 double norm3(const V3& x) { return std::sqrt(dot3(x, x)); }
 
-// general inverse by LU with partial pivoting (what Eigen's inverse() does for sizes > 4)
-bool invert(const double* A, double* Ainv, int n) {
-    std::vector<double> lu(A, A + (size_t)n * n);
-    std::vector<int> perm(n);
-    for (int i = 0; i < n; ++i) perm[i] = i;
-    for (int k = 0; k < n; ++k) {
+// Solve A X = [e_0 .. e_{NRHS-1}] (the first NRHS columns of A^-1) for a fixed-size N x N matrix by
+// Gauss-Jordan elimination with partial (row) pivoting on a stack-resident augmented matrix.  The
+// reference calls Eigen's inverse() (PartialPivLU for sizes > 4); same pivoting rule, same result
+// up to rounding.  Fixed trip counts let the compiler vectorise the row updates; the 23 x 23 case
+// is what every pass of the iterated update pays twice.
+template <int N, int NRHS>
+static inline __attribute__((always_inline)) bool solve_identity_cols_impl(const double* A, double* X /* N x NRHS, row-major */) {
+    constexpr int W = N + NRHS;
+    double m[N][W];
+    for (int r = 0; r < N; ++r) {
+        for (int c = 0; c < N; ++c) m[r][c] = A[r * N + c];
+        for (int c = 0; c < NRHS; ++c) m[r][N + c] = r == c ? 1.0 : 0.0;
+    }
+    for (int k = 0; k < N; ++k) {
         int piv = k;
-        double big = std::fabs(lu[(size_t)k * n + k]);
-        for (int r = k + 1; r < n; ++r) {
-            const double v = std::fabs(lu[(size_t)r * n + k]);
+        double big = std::fabs(m[k][k]);
+        for (int r = k + 1; r < N; ++r) {
+            const double v = std::fabs(m[r][k]);
             if (v > big) { big = v; piv = r; }
         }
         if (big == 0.0) return false;
-        if (piv != k) {
-            for (int c = 0; c < n; ++c) std::swap(lu[(size_t)k * n + c], lu[(size_t)piv * n + c]);
-            std::swap(perm[k], perm[piv]);
+        if (piv != k)
+            for (int c = 0; c < W; ++c) { const double t = m[k][c]; m[k][c] = m[piv][c]; m[piv][c] = t; }
+        const double inv = 1.0 / m[k][k];
+        for (int c = 0; c < W; ++c) m[k][c] *= inv;
+        for (int r = 0; r < N; ++r) {
+            if (r == k) continue;
+            const double f = m[r][k];
+            if (f == 0.0) continue;
+            for (int c = 0; c < W; ++c) m[r][c] -= f * m[k][c];
         }
-        const double d = lu[(size_t)k * n + k];
+    }
+    for (int r = 0; r < N; ++r)
+        for (int c = 0; c < NRHS; ++c) X[r * NRHS + c] = m[r][N + c];
+    return true;
+}
+
+// the two instances a pass needs, multi-versioned so that an AVX2 host runs the wide row updates
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define LIO_HOST_CLONES __attribute__((target_clones("avx2", "default")))
+#else
+#define LIO_HOST_CLONES
+#endif
+LIO_HOST_CLONES bool invert23(const double* A, double* Ainv) { return solve_identity_cols_impl<DOF, DOF>(A, Ainv); }
+LIO_HOST_CLONES bool invert23_first12(const double* A, double* X) { return solve_identity_cols_impl<DOF, 12>(A, X); }
+
+// general (run-time size) inverse, same method: only the m < 23 dense-gain branch uses it
+bool invert(const double* A, double* Ainv, int n) {
+    const int w = 2 * n;
+    std::vector<double> m((size_t)n * w, 0.0);
+    for (int r = 0; r < n; ++r) {
+        for (int c = 0; c < n; ++c) m[(size_t)r * w + c] = A[(size_t)r * n + c];
+        m[(size_t)r * w + n + r] = 1.0;
+    }
+    for (int k = 0; k < n; ++k) {
+        int piv = k;
+        double big = std::fabs(m[(size_t)k * w + k]);
         for (int r = k + 1; r < n; ++r) {
-            const double f = lu[(size_t)r * n + k] / d;
-            lu[(size_t)r * n + k] = f;
-            for (int c = k + 1; c < n; ++c) lu[(size_t)r * n + c] -= f * lu[(size_t)k * n + c];
+            const double v = std::fabs(m[(size_t)r * w + k]);
+            if (v > big) { big = v; piv = r; }
+        }
+        if (big == 0.0) return false;
+        if (piv != k) for (int c = 0; c < w; ++c) std::swap(m[(size_t)k * w + c], m[(size_t)piv * w + c]);
+        const double inv = 1.0 / m[(size_t)k * w + k];
+        for (int c = 0; c < w; ++c) m[(size_t)k * w + c] *= inv;
+        for (int r = 0; r < n; ++r) {
+            if (r == k) continue;
+            const double f = m[(size_t)r * w + k];
+            if (f == 0.0) continue;
+            for (int c = 0; c < w; ++c) m[(size_t)r * w + c] -= f * m[(size_t)k * w + c];
         }
     }
-    std::vector<double> col(n);
-    for (int j = 0; j < n; ++j) {
-        for (int r = 0; r < n; ++r) {                         // forward: L y = P e_j
-            double s = perm[r] == j ? 1.0 : 0.0;
-            for (int c = 0; c < r; ++c) s -= lu[(size_t)r * n + c] * col[c];
-            col[r] = s;
-        }
-        for (int r = n - 1; r >= 0; --r) {                    // backward: U x = y
-            double s = col[r];
-            for (int c = r + 1; c < n; ++c) s -= lu[(size_t)r * n + c] * Ainv[(size_t)c * n + j];
-            Ainv[(size_t)r * n + j] = s / lu[(size_t)r * n + r];
-        }
-    }
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) Ainv[(size_t)r * n + c] = m[(size_t)r * w + n + c];
     return true;
 }
 
@@ -424,22 +461,23 @@ void esekf::update_iterated_dyn_share_modified(double R, double& solve_time) {
             }
         } else {
             // information form                                                      :1788-1815
-            double PR[DOF * DOF], P_temp[DOF * DOF], P_inv[DOF * DOF];
+            double PR[DOF * DOF], P_temp[DOF * DOF], P_inv12[DOF * 12];
             for (int k = 0; k < DOF * DOF; ++k) PR[k] = P_[k] / R;
-            invert(PR, P_temp, DOF);                         // (P_/R).inverse()
+            invert23(PR, P_temp);              // (P_/R).inverse()
             for (int a = 0; a < 12; ++a)
                 for (int b = 0; b < 12; ++b) P_temp[a * DOF + b] += dyn_share.HTH[a * 12 + b];   // :1791
-            invert(P_temp, P_inv, DOF);                      // :1808
+            // :1808 P_inv = P_temp.inverse(); only its first 12 columns are used (:1810, :1815)
+            invert23_first12(P_temp, P_inv12);
             for (int a = 0; a < DOF; ++a) {                  // K_h = P_inv[:, 0:12] H^T h          :1810
                 double s = 0.0;
-                for (int c = 0; c < 12; ++c) s += P_inv[a * DOF + c] * dyn_share.HTh[c];
+                for (int c = 0; c < 12; ++c) s += P_inv12[a * 12 + c] * dyn_share.HTh[c];
                 K_h[a] = s;
             }
             for (double& v : K_x) v = 0.0;                   // :1814
             for (int a = 0; a < DOF; ++a)                    // K_x[:, 0:12] = P_inv[:, 0:12] HTH   :1815
                 for (int b = 0; b < 12; ++b) {
                     double s = 0.0;
-                    for (int c = 0; c < 12; ++c) s += P_inv[a * DOF + c] * dyn_share.HTH[c * 12 + b];
+                    for (int c = 0; c < 12; ++c) s += P_inv12[a * 12 + c] * dyn_share.HTH[c * 12 + b];
                     K_x[a * DOF + b] = s;
                 }
         }

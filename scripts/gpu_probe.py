@@ -106,12 +106,14 @@ def main():
 
     if a.big:
         del ctx
+        import torch
+        torch.cuda.init()
         nm, nq = 5_000_000, 100_000
         t0 = time.time(); world = synth.make_world(nm, 0.2); print("world gen s", time.time() - t0)
         scan = synth.make_scan(world, nq)
         pos, rot = synth.perturb_state(scan)
         st = synth.state_vector(pos, rot, scan.off_R, scan.off_T)
-        for lanes in (4, 8, 16):
+        for lanes in (8,):
             ctx = capi.LioContext(0.2, max_scan_points=nq, max_map_points=nm + 200000, lanes_per_query=lanes)
             t0 = time.time(); ctx.map_build(world.points); tb = time.time() - t0
             ctx.scan_set(scan.body)
@@ -135,12 +137,22 @@ def main():
             print(f"           measure(no search) wall {tw * 1e6:.1f} us, " + ", ".join(f"{k} {v['total_ms'] / max(v['launches'], 1) * 1e3:.1f}us" for k, v in pr.items()))
             kf = capi.Esekf(3)
             x0 = capi.make_state26(pos, rot, scan.off_R, scan.off_T)
-            ts = []
-            for _ in range(10):
-                kf.change_x(x0); kf.change_P(synth.init_cov()); ctx.scan_set_device(0, 0) if False else None
-                ctx.scan_set(scan.body)
-                t0 = time.time(); lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, False); ts.append(time.time() - t0)
-            print(f"           scan step {np.median(ts) * 1e6:.1f} us ({lg['n_calls']} passes, {lg['n_search']} searches) -> {1 / np.median(ts):.1f} scans/s; final pos err {np.linalg.norm(kf.get_x()[:3] - scan.pos):.4f}")
+            ctx.profile_enable(False)
+            body4 = np.zeros((nq, 4), np.float32); body4[:, :3] = scan.body
+            d_body = torch.from_numpy(body4).cuda()
+            for mode in ("host scan_set", "device-resident scan"):
+                ts, sol, mea = [], [], []
+                for _ in range(30):
+                    kf.change_x(x0); kf.change_P(synth.init_cov())
+                    t0 = time.perf_counter()
+                    if mode.startswith("host"):
+                        ctx.scan_set(scan.body)
+                    else:
+                        ctx.scan_set_device(d_body.data_ptr(), nq)
+                    lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+                    ts.append(time.perf_counter() - t0); sol.append(lg["solve_seconds"]); mea.append(lg["measure_seconds"])
+                print(f"           scan step [{mode}] {np.median(ts) * 1e6:.1f} us ({lg['n_calls']} passes, {lg['n_search']} searches) -> {1 / np.median(ts):.1f} scans/s; "
+                      f"host solve {np.median(sol) * 1e6:.1f} us, inside lio_measure {np.median(mea) * 1e6:.1f} us; final pos err {np.linalg.norm(kf.get_x()[:3] - scan.pos):.4f}")
             del ctx
     print("FAILS", fails)
     return 1 if fails else 0

@@ -106,3 +106,31 @@ void hh_boxminus(const double* x26, const double* y26, double* dx23) {
 }
 
 }  // extern "C"
+
+// micro-benchmark of the host-side algebra of one scan step (no GPU, synthetic H^T H): seconds per update
+extern "C" double hh_eskf_bench(int iters, int max_iter) {
+    using namespace lio;
+    double HTH[144], HTh[12];
+    for (int i = 0; i < 12; ++i) {
+        for (int j = 0; j < 12; ++j) HTH[i * 12 + j] = (i == j ? 5000.0 + 100.0 * i : 10.0 / (1 + i + j));
+        HTh[i] = 1e-3 * (i - 6);
+    }
+    esekf kf;
+    double lim[DOF];
+    for (double& v : lim) v = 0.001;
+    kf.init_dyn_share([&](state_ikfom&, dyn_share_datastruct& d) {
+        d.valid = true; d.m = 5000; d.res_mean = 0.01;
+        std::memcpy(d.HTH, HTH, sizeof(HTH)); std::memcpy(d.HTh, HTh, sizeof(HTh));
+    }, max_iter, lim);
+    double P0[DOF * DOF] = {0};
+    for (int i = 0; i < DOF; ++i) P0[i * DOF + i] = i < 6 ? 1.0 : 1e-4;
+    double st = 0.0, total = 0.0;
+    for (int it = 0; it < iters; ++it) {
+        kf.change_x(state_ikfom());
+        kf.change_P(P0);
+        st = 0.0;
+        kf.update_iterated_dyn_share_modified(0.001, st);
+        total += st;
+    }
+    return total / iters;
+}

@@ -48,8 +48,7 @@ def test_invalid_arguments_are_rejected(gpu_capi):
 
 def test_no_cpu_fallback(gpu_capi):
     """Without a GPU the product refuses to run (LIO_ERR_NO_DEVICE); it never computes on the host."""
-    import torch
-    if torch.cuda.is_available():
+    if os.path.exists("/dev/kfd"):
         pytest.skip("GPU present: the refusal path is exercised on CPU-only hosts")
     with pytest.raises(gpu_capi.LioError, match="LIO_ERR_NO_DEVICE"):
         gpu_capi.LioContext()
