@@ -349,3 +349,38 @@ class Esekf:
 def make_state26(pos, rot, off_R, off_T, vel=(0, 0, 0), bg=(0, 0, 0), ba=(0, 0, 0), grav=(0, 0, -9.809)) -> np.ndarray:
     """x26 = pos3, rot xyzw, offR xyzw, offT3, vel3, bg3, ba3, grav3 (use-ikfom.hpp:21-30)."""
     return np.concatenate([pos, rot, off_R, off_T, vel, bg, ba, grav]).astype(np.float64)
+
+
+class DeviceBuffer:
+    """A plain hipMalloc'ed buffer filled from a numpy array (torch-free way to keep a scan resident
+    in HBM for lio_scan_set_device / lio_map_build_device)."""
+
+    def __init__(self, host: np.ndarray):
+        load()
+        self.hip = C.CDLL("libamdhip64.so.7")          # SONAME of the runtime that is already mapped
+        self.hip.hipMalloc.argtypes = [C.POINTER(_vp), C.c_size_t]
+        self.hip.hipMemcpy.argtypes = [_vp, _vp, C.c_size_t, C.c_int]
+        self.hip.hipFree.argtypes = [_vp]
+        host = np.ascontiguousarray(host)
+        self.nbytes = host.nbytes
+        p = _vp()
+        if self.hip.hipMalloc(C.byref(p), max(self.nbytes, 16)) != 0:
+            raise LioError("hipMalloc failed")
+        self.ptr = p.value
+        if self.nbytes and self.hip.hipMemcpy(_vp(self.ptr), host.ctypes.data_as(_vp), self.nbytes, 1) != 0:   # H2D
+            raise LioError("hipMemcpy failed")
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                self.hip.hipFree(_vp(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def scan_to_device(body_xyz: np.ndarray) -> "DeviceBuffer":
+    """float4 records (x, y, z, 0) of a body-frame scan, resident in HBM."""
+    b4 = np.zeros((len(body_xyz), 4), np.float32)
+    b4[:, :3] = body_xyz
+    return DeviceBuffer(b4)

@@ -289,9 +289,9 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
     KnnArgs ka{};
     ka.map_pts = c->d_pts; ka.table = c->d_table; ka.grid = c->grid;
-    ka.body = body; ka.world_in = body ? nullptr : queries_world; ka.pose = pose;
+    if (body != nullptr) HIPCHK(c, launch_transform(body, nq, pose, queries_world, s));
+    ka.world_in = queries_world;
     ka.nq = nq; ka.nq_stride = stride;
-    ka.world_out = body ? queries_world : nullptr;
     ka.nbr = nbr; ka.cnt = cnt; ka.unres = unres; ka.cand_total = c->census ? c->d_cand : nullptr;
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
     prof_begin(c, LIO_PROF_KNN);

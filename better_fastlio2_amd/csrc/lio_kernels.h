@@ -12,17 +12,16 @@ struct KnnArgs {
     const float4*    map_pts;       // Morton-sorted map
     const HashEntry* table;
     Grid             grid;
-    const float4*    body;          // != nullptr: queries = pose (x) body points (laserMapping.cpp:1895)
-    const float4*    world_in;      // else: queries given in the world frame
-    Pose14           pose;
+    const float4*    world_in;      // queries in the world frame
     int              nq;
     int              nq_stride;     // leading dimension of nbr
-    float4*          world_out;     // feats_down_world (may be nullptr)
     float4*          nbr;           // [5][nq_stride]: x, y, z, sqdist of the k-th neighbour
     uint8_t*         cnt;           // [nq] neighbours found (0..5)
     uint8_t*         unres;         // [nq] 1 = result not proven by the 27-cell search (-> tree walk)
     unsigned long long* cand_total; // device counter: sum of C(q)
 };
+// feats_down_world = pose (x) feats_down_body, fp64 -> fp32 (laserMapping.cpp:1894-1899)
+hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float4* world, hipStream_t s);
 // lanes_per_query in {4, 8, 16, 32, 64}
 hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s);
 

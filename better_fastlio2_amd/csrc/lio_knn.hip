@@ -71,35 +71,29 @@ struct Top5 {
 
 __device__ __forceinline__ u64 candidate_key(float qx, float qy, float qz, float4 p, uint32_t idx) {
     const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
-    uint32_t db = __float_as_uint(d);
-    // tomb-stoned or non-comparable (NaN) candidates sort after every real one and are dropped
-    if (p.w != 0.0f || !(d == d)) db = INF_BITS;
+    // tomb-stoned candidates (w != 0) sort after every real one and are dropped; a NaN distance
+    // (non-finite query) has bits above +inf and is dropped by the same `< INF_BITS` tests
+    const uint32_t db = p.w != 0.0f ? INF_BITS : __float_as_uint(d);
     return ((u64)db << 32) | (u64)idx;
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int G>
+template <int G, bool CENSUS>
 __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
+    constexpr int WPB = 4;
     constexpr int GPW = 64 / G;                    // queries per wavefront
     constexpr int SLOTS = (27 + G - 1) / G;        // hash probes per lane
-    __shared__ uint2 s_bucket[4][GPW][28];         // LDS-staged non-empty buckets {start, count}
+    __shared__ uint2 s_bucket[WPB][GPW][28];       // LDS-staged non-empty buckets {start, count}
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / G, r = lane % G;
-    const int q = (blockIdx.x * 4 + wave) * GPW + g;
+    const int q = (blockIdx.x * WPB + wave) * GPW + g;
     const bool active = q < a.nq;
 
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
     if (active) {
-        if (a.body != nullptr) {
-            const float4 b = a.body[q];
-            const PoseQ s = pose_unpack(a.pose);
-            body_to_world(s, b.x, b.y, b.z, qx, qy, qz);
-            if (r == 0 && a.world_out != nullptr) a.world_out[q] = make_float4(qx, qy, qz, b.w);
-        } else {
-            const float4 w = a.world_in[q];
-            qx = w.x; qy = w.y; qz = w.z;
-        }
+        const float4 w = a.world_in[q];            // world-frame query (transform_kernel / caller)
+        qx = w.x; qy = w.y; qz = w.z;
     }
     const float inv_cell = a.grid.inv_cell;
     const int cx = cell_coord(qx, inv_cell), cy = cell_coord(qy, inv_cell), cz = cell_coord(qz, inv_cell);
@@ -159,10 +153,16 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     uint32_t csum = 0;
     for (int i = 0; i < n_ne; ++i) {
         const uint2 bk = s_bucket[wave][g][i];
-        csum += bk.y;
-        for (uint32_t t = (uint32_t)r; t < bk.y; t += G) {
-            const uint32_t idx = bk.x + t;
+        if (CENSUS) csum += bk.y;
+        if ((uint32_t)r < bk.y) {
+            const uint32_t idx = bk.x + (uint32_t)r;
             top.offer(candidate_key(qx, qy, qz, a.map_pts[idx], idx));
+        }
+        if (bk.y > (uint32_t)G) {                  // rare at one point per down-sample voxel
+            for (uint32_t t = (uint32_t)(r + G); t < bk.y; t += G) {
+                const uint32_t idx = bk.x + t;
+                top.offer(candidate_key(qx, qy, qz, a.map_pts[idx], idx));
+            }
         }
     }
 
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         a.unres[q] = proven ? 0 : 1;               // unproven queries are redone by knn_tree_kernel
     }
     // candidate census for the byte model (opt-in: one atomic per wavefront)
-    if (a.cand_total != nullptr) {
+    if (CENSUS) {
         uint32_t c = (active && r == 0) ? csum : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
@@ -225,16 +225,37 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     }
 }
 
+template <int G>
+static void launch_knn27_g(const KnnArgs& a, hipStream_t s) {
+    const int qpb = 4 * (64 / G);                  // queries per 256-thread workgroup
+    const dim3 grid((a.nq + qpb - 1) / qpb), block(256);
+    if (a.cand_total != nullptr) hipLaunchKernelGGL((knn27_kernel<G, true>), grid, block, 0, s, a);
+    else                         hipLaunchKernelGGL((knn27_kernel<G, false>), grid, block, 0, s, a);
+}
+// feats_down_world = pose (x) feats_down_body (laserMapping.cpp:1894-1899), one lane per point
+__global__ __launch_bounds__(256) void transform_kernel(const float4* body, int n, Pose14 pose, float4* world) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 b = body[i];
+    const PoseQ s = pose_unpack(pose);
+    float wx, wy, wz;
+    body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
+    world[i] = make_float4(wx, wy, wz, b.w);
+}
+hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float4* world, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(transform_kernel, dim3((n + 255) / 256), dim3(256), 0, s, body, n, pose, world);
+    return hipGetLastError();
+}
+
 hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s) {
     if (a.nq <= 0) return hipSuccess;
-    const int qpb = 256 / lanes_per_query;         // queries per 256-thread workgroup
-    const dim3 grid((a.nq + qpb - 1) / qpb), block(256);
     switch (lanes_per_query) {
-        case 4:  hipLaunchKernelGGL(knn27_kernel<4>, grid, block, 0, s, a); break;
-        case 8:  hipLaunchKernelGGL(knn27_kernel<8>, grid, block, 0, s, a); break;
-        case 16: hipLaunchKernelGGL(knn27_kernel<16>, grid, block, 0, s, a); break;
-        case 32: hipLaunchKernelGGL(knn27_kernel<32>, grid, block, 0, s, a); break;
-        case 64: hipLaunchKernelGGL(knn27_kernel<64>, grid, block, 0, s, a); break;
+        case 4:  launch_knn27_g<4>(a, s); break;
+        case 8:  launch_knn27_g<8>(a, s); break;
+        case 16: launch_knn27_g<16>(a, s); break;
+        case 32: launch_knn27_g<32>(a, s); break;
+        case 64: launch_knn27_g<64>(a, s); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

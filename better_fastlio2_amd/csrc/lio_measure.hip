@@ -69,8 +69,14 @@ __global__ __launch_bounds__(256) void residual_kernel(ResidualArgs a) {
         const float4 b = a.body[i];
         const PoseQ s = pose_unpack(a.pose);
         float wx, wy, wz;
-        body_to_world(s, b.x, b.y, b.z, wx, wy, wz);                       // :1894-1899
-        a.world[i] = make_float4(wx, wy, wz, b.w);
+        if (SEARCH) {
+            // a search pass already holds feats_down_world (transform_kernel, same pose)
+            const float4 w = a.world[i];
+            wx = w.x; wy = w.y; wz = w.z;
+        } else {
+            body_to_world(s, b.x, b.y, b.z, wx, wy, wz);                   // :1894-1899
+            a.world[i] = make_float4(wx, wy, wz, b.w);
+        }
         bool cand;
         if (SEARCH) {
             // points_near.size() < 5 ? false : sqdis[4] > 5 ? false : true          :1911

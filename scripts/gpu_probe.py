@@ -106,8 +106,6 @@ def main():
 
     if a.big:
         del ctx
-        import torch
-        torch.cuda.init()
         nm, nq = 5_000_000, 100_000
         t0 = time.time(); world = synth.make_world(nm, 0.2); print("world gen s", time.time() - t0)
         scan = synth.make_scan(world, nq)
@@ -138,8 +136,7 @@ def main():
             kf = capi.Esekf(3)
             x0 = capi.make_state26(pos, rot, scan.off_R, scan.off_T)
             ctx.profile_enable(False)
-            body4 = np.zeros((nq, 4), np.float32); body4[:, :3] = scan.body
-            d_body = torch.from_numpy(body4).cuda()
+            d_body = capi.scan_to_device(scan.body)
             for mode in ("host scan_set", "device-resident scan"):
                 ts, sol, mea = [], [], []
                 for _ in range(30):
@@ -148,7 +145,7 @@ def main():
                     if mode.startswith("host"):
                         ctx.scan_set(scan.body)
                     else:
-                        ctx.scan_set_device(d_body.data_ptr(), nq)
+                        ctx.scan_set_device(d_body.ptr, nq)
                     lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
                     ts.append(time.perf_counter() - t0); sol.append(lg["solve_seconds"]); mea.append(lg["measure_seconds"])
                 print(f"           scan step [{mode}] {np.median(ts) * 1e6:.1f} us ({lg['n_calls']} passes, {lg['n_search']} searches) -> {1 / np.median(ts):.1f} scans/s; "
