@@ -55,7 +55,7 @@ class lio_update_log(C.Structure):
 # every symbol include/lio_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_stream", "lio_synchronize",
-    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_delete_boxes", "lio_map_reconstruct",
+    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_incremental", "lio_map_delete_boxes", "lio_map_reconstruct",
     "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_get_info", "lio_map_nearest_search",
     "lio_scan_set", "lio_scan_set_device", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get",
@@ -108,6 +108,7 @@ def load(build_if_missing: bool = True):
     L.lio_map_build_device.argtypes = [_vp, _vp, C.c_longlong]
     L.lio_map_add.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.lio_map_delete_boxes.argtypes = [_vp, _vp, C.c_int, C.POINTER(C.c_int)]
+    L.lio_map_incremental.argtypes = [_vp, _vp, C.c_double, C.c_int, C.c_int, _vp, C.POINTER(C.c_int), _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lio_map_reconstruct.argtypes = [_vp, _vp, C.c_longlong, C.c_int]
     L.lio_map_size.argtypes = [_vp]
     L.lio_map_size.restype = C.c_longlong
@@ -203,6 +204,23 @@ class LioContext:
                   "lio_map_add")
         return n_added.value
 
+    def map_incremental(self, state14, filter_size_map_min: float = 0.2, flg_EKF_inited: bool = True,
+                        apply: bool = True, want_lists: bool = False) -> dict:
+        """map_incremental (laserMapping.cpp:1440-1496) on the current scan and its last neighbours."""
+        s = np.ascontiguousarray(state14, dtype=np.float64)
+        n = self.L.lio_scan_size(self.h)
+        a = np.zeros((max(n, 1), 3), np.float32) if want_lists else None
+        b = np.zeros((max(n, 1), 3), np.float32) if want_lists else None
+        na, nb, cnt = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self.L.lio_map_incremental(self.h, _ptr(s), float(filter_size_map_min), int(flg_EKF_inited), int(apply),
+                                             _ptr(a) if want_lists else None, C.byref(na), _ptr(b) if want_lists else None,
+                                             C.byref(nb), C.byref(cnt)), "lio_map_incremental")
+        out = {"n_add": na.value, "n_nodown": nb.value, "add_counter": cnt.value}
+        if want_lists:
+            out["add"] = a[:na.value].copy()
+            out["nodown"] = b[:nb.value].copy()
+        return out
+
     def map_delete_boxes(self, boxes) -> int:
         b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
         n = C.c_int(0)
@@ -277,8 +295,15 @@ class LioContext:
         return world, sel, nv
 
     # ---- timing ------------------------------------------------------------------------------------
-    def profile_enable(self, on: bool = True):
-        self.L.lio_profile_enable(self.h, int(on))
+    def profile_enable(self, on=True, only=None):
+        """Time kernel families with HIP events.  only=[PROF_KNN, ...] restricts it to those families."""
+        if only is not None:
+            mask = 0x100
+            for w in only:
+                mask |= 1 << w
+            self.L.lio_profile_enable(self.h, mask)
+        else:
+            self.L.lio_profile_enable(self.h, int(bool(on)))
 
     def census_enable(self, on: bool = True):
         """Make search passes report n_candidates (sum of C(q)); off in timed runs."""

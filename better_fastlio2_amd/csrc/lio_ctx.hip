@@ -74,14 +74,15 @@ struct lio_ctx {
 
     // batch buffers of lio_map_add
     size_t cap_add = 0;
-    float4 *d_add_pts = nullptr, *d_add_out = nullptr;
+    float4 *d_add_pts = nullptr, *d_add_pts2 = nullptr, *d_add_out = nullptr;
+    uint8_t* d_add_cls = nullptr;
     uint64_t *d_add_keys = nullptr, *d_add_keys2 = nullptr, *d_add_ukeys = nullptr;
     uint32_t *d_add_order = nullptr, *d_add_order2 = nullptr, *d_add_gcount = nullptr, *d_add_gstart = nullptr;
 
     // ---- profiling ----------------------------------------------------------------------------
     // HIP-event pairs around each kernel family; recorded without synchronising and resolved when
     // the totals are read, so that timing a run does not add a stream synchronisation per pass
-    bool prof = false;
+    unsigned prof = 0;                         // bit w set: time kernel family w
     bool census = false;                       // count C(q) in the k-NN kernel (one atomic per wavefront)
     std::vector<hipEvent_t> ev_pool[LIO_PROF_COUNT];   // start, stop, start, stop, ...
     size_t ev_next[LIO_PROF_COUNT]{};          // events of the pool in use
@@ -264,7 +265,7 @@ void prof_collect(lio_ctx* c) {
     }
 }
 void prof_begin(lio_ctx* c, int which) {
-    if (!c->prof) return;
+    if (!(c->prof & (1u << which))) return;
     if (c->ev_next[which] + 2 > 8192) prof_collect(c);            // bounded pool
     while (c->ev_pool[which].size() < c->ev_next[which] + 2) {
         hipEvent_t e = nullptr;
@@ -274,7 +275,7 @@ void prof_begin(lio_ctx* c, int which) {
     (void)hipEventRecord(c->ev_pool[which][c->ev_next[which]], c->stream);
 }
 void prof_end(lio_ctx* c, int which) {
-    if (!c->prof) return;
+    if (!(c->prof & (1u << which))) return;
     if (c->ev_pool[which].size() < c->ev_next[which] + 2) return;
     (void)hipEventRecord(c->ev_pool[which][c->ev_next[which] + 1], c->stream);
     c->ev_next[which] += 2;
@@ -402,8 +403,8 @@ void lio_destroy(lio_ctx* c) {
                    c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_ltable, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
                    c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
                    c->d_partials, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
-                   c->d_add_pts, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys, c->d_add_order,
-                   c->d_add_order2, c->d_add_gcount, c->d_add_gstart};
+                   c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
+                   c->d_add_order, c->d_add_order2, c->d_add_gcount, c->d_add_gstart};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -443,41 +444,44 @@ int lio_map_reconstruct(lio_ctx* c, const float* pts, long long n, int stride_by
     return lio_map_build(c, pts, n, stride_bytes);       // ikd_Tree.cpp:1394-1405: delete all, Build
 }
 
-// Add_Points (ikd_Tree.cpp:414-489).  Returns through *n_added what the reference returns: the number
-// of down-sampled inserts that changed the tree (tmp_counter), 0 when downsample_on is false.
-int lio_map_add(lio_ctx* c, const float* pts, int n, int stride_bytes, int downsample_on, int* n_added) {
-    if (!c || n < 0 || (n > 0 && !pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
+// ---- Add_Points machinery (ikd_Tree.cpp:414-489) --------------------------------------------------
+static int ensure_add_buffers(lio_ctx* c, size_t n) {
+    if (n <= c->cap_add) return LIO_OK;
+    void* old[] = {c->d_add_pts, c->d_add_pts2, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys, c->d_add_order,
+                   c->d_add_order2, c->d_add_gcount, c->d_add_gstart, c->d_add_cls};
+    for (void* p : old) if (p) (void)hipFree(p);
+    c->d_add_pts = c->d_add_pts2 = c->d_add_out = nullptr; c->d_add_keys = c->d_add_keys2 = c->d_add_ukeys = nullptr;
+    c->d_add_order = c->d_add_order2 = c->d_add_gcount = c->d_add_gstart = nullptr; c->d_add_cls = nullptr; c->cap_add = 0;
+    HIPCHK(c, hipMalloc((void**)&c->d_add_pts, n * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_pts2, n * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_out, n * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_keys, n * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_keys2, n * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_ukeys, n * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_order, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_order2, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_gcount, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_gstart, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_cls, n));
+    c->cap_add = n;
+    return LIO_OK;
+}
+
+// One Add_Points call on a device-resident batch (float4, batch order = insertion order), WITHOUT
+// rebuilding the index: down-sampled inserts fold per voxel against the indexed points (tomb-stoning
+// what they replace) and append the survivors; plain inserts are appended as they are.  `batch` is
+// clobbered when downsample_on.  At most one down-sampled call per rebuild (appended points are not
+// in the index yet).
+static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsample_on, int* n_added) {
+    hipStream_t s = c->stream;
     if (n_added) *n_added = 0;
     if (n == 0) return LIO_OK;
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
     if ((size_t)c->n_points + (size_t)n > c->cap_map)
-        return c->fail(LIO_ERR_CAPACITY, "lio_map_add", "stored points + batch exceed max_map_points");
-    if ((size_t)n > c->cap_add) {
-        void* old[] = {c->d_add_pts, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys, c->d_add_order,
-                       c->d_add_order2, c->d_add_gcount, c->d_add_gstart};
-        for (void* p : old) if (p) (void)hipFree(p);
-        c->d_add_pts = c->d_add_out = nullptr; c->d_add_keys = c->d_add_keys2 = c->d_add_ukeys = nullptr;
-        c->d_add_order = c->d_add_order2 = c->d_add_gcount = c->d_add_gstart = nullptr; c->cap_add = 0;
-        const size_t m = (size_t)n;
-        HIPCHK(c, hipMalloc((void**)&c->d_add_pts, m * sizeof(float4)));
-        HIPCHK(c, hipMalloc((void**)&c->d_add_out, m * sizeof(float4)));
-        HIPCHK(c, hipMalloc((void**)&c->d_add_keys, m * sizeof(uint64_t)));
-        HIPCHK(c, hipMalloc((void**)&c->d_add_keys2, m * sizeof(uint64_t)));
-        HIPCHK(c, hipMalloc((void**)&c->d_add_ukeys, m * sizeof(uint64_t)));
-        HIPCHK(c, hipMalloc((void**)&c->d_add_order, m * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc((void**)&c->d_add_order2, m * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc((void**)&c->d_add_gcount, m * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc((void**)&c->d_add_gstart, m * sizeof(uint32_t)));
-        c->cap_add = m;
-    }
-    int rc = upload_points(c, pts, (size_t)n, stride_bytes, c->d_add_pts);
-    if (rc != LIO_OK) return rc;
-    uint32_t n_append = 0;
-    const float4* append_src = nullptr;
+        return c->fail(LIO_ERR_CAPACITY, "Add_Points", "stored points + batch exceed max_map_points");
+    uint32_t n_append = n;
     if (downsample_on) {
         const float ds = c->cfg.filter_size_map_min;
-        HIPCHK(c, launch_voxel_keys(c->d_add_pts, (uint32_t)n, ds, c->d_add_keys, c->d_add_order, s));
+        HIPCHK(c, launch_voxel_keys(batch, n, ds, c->d_add_keys, c->d_add_order, s));
         HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_add_keys, c->d_add_keys2, c->d_add_order,
                                      c->d_add_order2, (size_t)n, s));
         HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_add_keys2, (size_t)n, c->d_add_ukeys,
@@ -488,32 +492,103 @@ int lio_map_add(lio_ctx* c, const float* pts, int n, int stride_bytes, int downs
         HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, n_groups, s));
         HIPCHK(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(uint32_t), s));
         FoldArgs fa{};
-        fa.map_pts = c->d_pts; fa.table = c->d_table; fa.grid = c->grid; fa.ds = ds; fa.new_pts = c->d_add_pts;
+        fa.map_pts = c->d_pts; fa.table = c->d_table; fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch;
         fa.order = c->d_add_order2; fa.group_start = c->d_add_gstart; fa.group_count = c->d_add_gcount;
         fa.n_groups = n_groups; fa.out_pts = c->d_add_out; fa.n_added = c->d_counters + 2;
         HIPCHK(c, launch_fold_groups(fa, s));
-        // survivors (w == 0) -> front of d_add_pts (the batch itself is no longer needed)
-        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, c->d_add_pts, c->d_counters + 3, n_groups, s));
+        // survivors (w == 0) -> front of `batch` (the batch itself is no longer needed)
+        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_counters + 3, n_groups, s));
         uint32_t host_cnt[2] = {0, 0};
         HIPCHK(c, hipMemcpyAsync(host_cnt, c->d_counters + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         if (n_added) *n_added = (int)host_cnt[0];
         n_append = host_cnt[1];
-        append_src = c->d_add_pts;
-    } else {
-        n_append = (uint32_t)n;
-        append_src = c->d_add_pts;
     }
-    // append, drop tomb-stones, rebuild the index
     if (n_append > 0)
-        HIPCHK(c, hipMemcpyAsync(c->d_pts + c->n_points, append_src, (size_t)n_append * sizeof(float4),
-                                 hipMemcpyDeviceToDevice, s));
-    const uint32_t total = c->n_points + n_append;
-    HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_pts_tmp, c->d_counters + 3, total, s));
+        HIPCHK(c, hipMemcpyAsync(c->d_pts + c->n_points, batch, (size_t)n_append * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    c->n_points += n_append;
+    return LIO_OK;
+}
+
+// drop tomb-stones, re-sort, re-hash
+static int rebuild_from_stored(lio_ctx* c) {
+    hipStream_t s = c->stream;
+    HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_pts_tmp, c->d_counters + 3, c->n_points, s));
     uint32_t live = 0;
     HIPCHK(c, hipMemcpyAsync(&live, c->d_counters + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     return build_index(c, c->d_pts_tmp, live);
+}
+
+// Add_Points (ikd_Tree.cpp:414-489).  Returns through *n_added what the reference returns: the number
+// of down-sampled inserts that changed the tree (tmp_counter), 0 when downsample_on is false.
+int lio_map_add(lio_ctx* c, const float* pts, int n, int stride_bytes, int downsample_on, int* n_added) {
+    if (!c || n < 0 || (n > 0 && !pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
+    if (n_added) *n_added = 0;
+    if (n == 0) return LIO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((size_t)c->n_points + (size_t)n > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "lio_map_add", "stored points + batch exceed max_map_points");
+    int rc = ensure_add_buffers(c, (size_t)n);
+    if (rc != LIO_OK) return rc;
+    rc = upload_points(c, pts, (size_t)n, stride_bytes, c->d_add_pts);
+    if (rc != LIO_OK) return rc;
+    rc = add_batch_device(c, c->d_add_pts, (uint32_t)n, downsample_on != 0, n_added);
+    if (rc != LIO_OK) return rc;
+    return rebuild_from_stored(c);
+}
+
+// map_incremental (src/laserMapping.cpp:1440-1496) on the scan of the last measurement passes.
+int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
+                        int apply, float* out_add_xyz, int* n_add, float* out_nodown_xyz, int* n_nodown,
+                        int* add_counter) {
+    if (!c || !state14 || !(filter_size_map_min > 0.0)) return LIO_ERR_INVALID_ARG;
+    if (n_add) *n_add = 0;
+    if (n_nodown) *n_nodown = 0;
+    if (add_counter) *add_counter = 0;
+    if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_map_incremental", "no scan set");
+    const int nq = c->nq;
+    if (nq == 0) return LIO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc = ensure_add_buffers(c, (size_t)nq);
+    if (rc != LIO_OK) return rc;
+    if (!c->have_search) {
+        // no neighbour lists at all (first scans): every point is a PointToAdd (:1487)
+        HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, (size_t)nq, s));
+    }
+    IncrArgs ia{};
+    ia.body = c->d_body; ia.nq = nq; ia.nq_stride = c->cap_q;
+    for (int i = 0; i < 14; ++i) ia.pose.v[i] = state14[i];
+    ia.nbr = c->d_nbr; ia.cnt = c->d_cnt; ia.filter_size_map_min = filter_size_map_min;
+    ia.flg_EKF_inited = flg_EKF_inited; ia.world = c->d_world; ia.cls = c->d_add_cls;
+    HIPCHK(c, launch_map_incremental(ia, s));
+    HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 1, c->d_add_pts, c->d_counters + 5, (size_t)nq, s));
+    HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 2, c->d_add_pts2, c->d_counters + 6, (size_t)nq, s));
+    uint32_t cnts[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(cnts, c->d_counters + 5, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (n_add) *n_add = (int)cnts[0];
+    if (n_nodown) *n_nodown = (int)cnts[1];
+    // the lists, for the caller that replicates them to other GPUs
+    for (int which = 0; which < 2; ++which) {
+        float* dst = which == 0 ? out_add_xyz : out_nodown_xyz;
+        const uint32_t m = cnts[which];
+        if (!dst || m == 0) continue;
+        rc = ensure_scratch(c, (size_t)m * 3 * sizeof(float));
+        if (rc != LIO_OK) return rc;
+        HIPCHK(c, launch_pack_xyz(which == 0 ? c->d_add_pts : c->d_add_pts2, m, (float*)c->d_scratch, s));
+        HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        std::memcpy(dst, c->h_scratch, (size_t)m * 3 * sizeof(float));
+    }
+    if (!apply) return LIO_OK;
+    // ikdtree.Add_Points(PointToAdd, true); ikdtree.Add_Points(PointNoNeedDownsample, false);   :1492-1493
+    rc = add_batch_device(c, c->d_add_pts, cnts[0], true, add_counter);
+    if (rc != LIO_OK) return rc;
+    rc = add_batch_device(c, c->d_add_pts2, cnts[1], false, nullptr);
+    if (rc != LIO_OK) return rc;
+    return rebuild_from_stored(c);
 }
 
 long long lio_map_size(lio_ctx* c) { return c ? (long long)c->n_points : 0; }
@@ -779,8 +854,9 @@ int lio_get_scan_state(lio_ctx* c, float* world_xyz, uint8_t* selected, float* n
 // ---- profiling -----------------------------------------------------------------------------------
 int lio_profile_enable(lio_ctx* c, int on) {
     if (!c) return LIO_ERR_INVALID_ARG;
-    if (!on) prof_collect(c);
-    c->prof = on != 0;
+    prof_collect(c);
+    // on == 1: every family; otherwise a bit mask (1 << LIO_PROF_x) | ... ; 0 = off
+    c->prof = on == 1 ? 0xffu : ((unsigned)on & 0xffu);
     return LIO_OK;
 }
 int lio_census_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; c->census = on != 0; return LIO_OK; }

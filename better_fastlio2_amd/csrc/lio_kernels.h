@@ -107,4 +107,7 @@ size_t select_temp_bytes(size_t n);
 hipError_t select_live_points(void* temp, size_t temp_bytes, const float4* src, float4* dst,
                               uint32_t* n_out, size_t n, hipStream_t s);
 
+hipError_t select_points_by_class(void* temp, size_t temp_bytes, const float4* src, const uint8_t* cls, uint8_t want,
+                                  float4* dst, uint32_t* n_out, size_t n, hipStream_t s);
+
 }  // namespace lio

@@ -404,19 +404,35 @@ __global__ __launch_bounds__(64) void knn_tree_kernel(TreeArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (uint32_t base = 0; base < total; base += 64) {
-                const uint32_t f = base + (uint32_t)lane;
-                u64 key = KEY64_MAX;
-                if (f < total) {
-                    int lo = 0, hi = n_ne - 1;               // largest b with s_pre[b] <= f
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (s_pre[mid] <= f) lo = mid; else hi = mid - 1;
+            // four 64-candidate chunks per round: their index searches and 16-byte gathers are all in
+            // flight before the first merge (one memory round trip instead of four)
+            for (uint32_t base = 0; base < total; base += 256) {
+                u64 key[4];
+                uint32_t idx[4];
+                float4 pt[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t f = base + 64u * c + (uint32_t)lane;
+                    idx[c] = 0xffffffffu;
+                    if (f < total) {
+                        int lo = 0, hi = n_ne - 1;               // largest b with s_pre[b] <= f
+                        while (lo < hi) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (s_pre[mid] <= f) lo = mid; else hi = mid - 1;
+                        }
+                        idx[c] = s_bk[lo].x + (f - s_pre[lo]);
                     }
-                    const uint32_t idx = s_bk[lo].x + (f - s_pre[lo]);
-                    key = candidate_key(qx, qy, qz, a.map_pts[idx], idx);
                 }
-                top.merge(key);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    pt[c] = make_float4(0.f, 0.f, 0.f, 1.f);
+                    if (idx[c] != 0xffffffffu) pt[c] = a.map_pts[idx[c]];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    key[c] = idx[c] != 0xffffffffu ? candidate_key(qx, qy, qz, pt[c], idx[c]) : KEY64_MAX;
+                    if (base + 64u * c < total) top.merge(key[c]);
+                }
             }
             bool proven = false;
             if (inrange && (uint32_t)(top.g4 >> 32) < INF_BITS) {

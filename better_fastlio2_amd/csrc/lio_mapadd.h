@@ -18,6 +18,18 @@ struct FoldArgs {
     float4*          out_pts;       // per group: survivor to append (w == 0) or nothing (w == 1)
     uint32_t*        n_added;       // += tmp_counter of ikd_Tree.cpp:448
 };
+struct IncrArgs {
+    const float4*  body;            // feats_down_body
+    int            nq, nq_stride;
+    Pose14         pose;            // posterior state (state_point, laserMapping.cpp:2381)
+    const float4*  nbr;             // Nearest_Points of the last search pass
+    const uint8_t* cnt;
+    double         filter_size_map_min;
+    int            flg_EKF_inited;
+    float4*        world;           // feats_down_world at the posterior pose
+    uint8_t*       cls;             // 0 skip, 1 PointToAdd, 2 PointNoNeedDownsample
+};
+hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s);
 hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, hipStream_t s);
 hipError_t launch_fold_groups(const FoldArgs& a, hipStream_t s);
 

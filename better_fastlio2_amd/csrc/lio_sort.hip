@@ -68,4 +68,19 @@ hipError_t select_live_points(void* temp, size_t temp_bytes, const float4* src, 
     return rocprim::select(temp, temp_bytes, src, dst, n_out, n, LivePoint(), s);
 }
 
+struct ClassIs {
+    uint8_t want;
+    __host__ __device__ bool operator()(uint8_t c) const { return c == want; }
+};
+// order-preserving compaction of the points whose class byte equals `want`
+hipError_t select_points_by_class(void* temp, size_t temp_bytes, const float4* src, const uint8_t* cls, uint8_t want,
+                                  float4* dst, uint32_t* n_out, size_t n, hipStream_t s) {
+    auto flags = rocprim::make_transform_iterator(cls, ClassIs{want});
+    size_t need = 0;
+    hipError_t e = rocprim::select(nullptr, need, src, flags, dst, n_out, n, s);
+    if (e != hipSuccess) return e;
+    if (need > temp_bytes) return hipErrorOutOfMemory;
+    return rocprim::select(temp, temp_bytes, src, flags, dst, n_out, n, s);
+}
+
 }  // namespace lio

@@ -99,6 +99,16 @@ int  lio_map_build_device(lio_ctx* ctx, const void* d_pts_f4, long long n);
 /* KD_TREE::Add_Points (ikd_Tree.cpp:414-489); *n_added = its return value: the number of
  * down-sampled inserts that changed the tree (tmp_counter), 0 when downsample_on == 0.             */
 int  lio_map_add(lio_ctx* ctx, const float* pts, int n, int stride_bytes, int downsample_on, int* n_added);
+/* map_incremental (src/laserMapping.cpp:1440-1496) for the scan of the last measurement passes:
+ * world points at the posterior pose `state14` (pointBodyToWorld, :1451), per-point decision from the
+ * neighbours of the last search pass (skip / PointToAdd / PointNoNeedDownsample, :1453-1488), then --
+ * if apply != 0 -- Add_Points(PointToAdd, true) and Add_Points(PointNoNeedDownsample, false)
+ * (:1492-1493) on this replica.  filter_size_map_min is the reference's double (:56, :2067).
+ * out_add_xyz / out_nodown_xyz (may be NULL, capacity lio_scan_size * 3 floats) receive the two lists in
+ * scan order, e.g. to replicate them to other GPUs; *add_counter = Add_Points' return value.           */
+int  lio_map_incremental(lio_ctx* ctx, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
+                         int apply, float* out_add_xyz, int* n_add, float* out_nodown_xyz, int* n_nodown,
+                         int* add_counter);
 /* KD_TREE::Delete_Point_Boxes (ikd_Tree.cpp:536-556): boxes = nb x {min xyz, max xyz}, half-open.  */
 int  lio_map_delete_boxes(lio_ctx* ctx, const float* minmax6, int nb, int* n_deleted);
 /* KD_TREE::reconstruct (ikd_Tree.cpp:1394-1405) == Build on a new cloud.                           */
@@ -140,6 +150,8 @@ int  lio_scan_size(lio_ctx* ctx);
 #define LIO_PROF_RESIDUAL  2    /* plane fit + residual + Jacobian + H^T H reduction + result record */
 #define LIO_PROF_REDUCE    3    /* (fused into LIO_PROF_RESIDUAL since the last-arriver reduction; 0) */
 #define LIO_PROF_COUNT     4
+/* on = 0: off; 1: every family; otherwise a bit mask of (1 << LIO_PROF_x) | 0x100 (0x100 marks a mask,
+ * e.g. 0x100 | 1 << LIO_PROF_KNN times only the k-NN kernel: 2 event records per search pass)        */
 int  lio_profile_enable(lio_ctx* ctx, int on);
 /* candidate census: when on, search passes also report lio_out.n_candidates (costs one device
  * atomic per wavefront of the k-NN kernel, so it is off by default and never on in timed runs)    */

@@ -266,3 +266,53 @@ def test_full_size_properties(gpu_capi, synth):
     assert lg["n_calls"] <= 4
     assert np.linalg.norm(kf.get_x()[:3] - scan.pos) < 0.02
     ctx.close()
+
+
+def test_map_incremental_sequence(gpu_capi, oracle, synth, small_case):
+    """Three consecutive scans through the reference's loop body: iterated update, then
+    map_incremental (laserMapping.cpp:1440-1496) with Add_Points(down-sampled) + Add_Points(plain).
+    Lists, counters and the live set must equal the CPU path after every scan; the map starts from a
+    THINNED world so that the scans really add points."""
+    w = small_case["world"]
+    base = np.ascontiguousarray(w.points[::3])                     # a sparser initial map
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=20_000, max_map_points=400_000)
+    ctx.map_build(base)
+    om = oracle.OracleMap(0.2); om.build(base)
+    key = lambda p: p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+    for k, (px, py, yaw) in enumerate([(3.1, -2.2, 0.52), (4.0, -1.6, 0.60), (5.2, -1.1, 0.71)]):
+        sc = synth.make_scan(w, 12_000, seed=synth.SEED + 40 + k, pos=(px, py, 0.0), rpy=(0.003, -0.004, yaw))
+        pos, rot = synth.perturb_state(sc, dpos=0.05, drot_deg=0.3, seed=synth.SEED + 50 + k)
+        x0 = gpu_capi.make_state26(pos, rot, sc.off_R, sc.off_T)
+        # CPU path
+        xo, Po, arrs, log = oracle.update_iterated(om, x0, synth.init_cov(), sc.body)
+        world_post = oracle.body_to_world(xo[:14], sc.body)
+        cls = oracle.map_incremental_classify(world_post, arrs.nbr_xyz, arrs.nbr_cnt, 0.2, True)
+        to_add, nodown = world_post[cls == 1], world_post[cls == 2]
+        # GPU path
+        kf = gpu_capi.Esekf(3); kf.change_x(x0); kf.change_P(synth.init_cov())
+        ctx.scan_set(sc.body)
+        kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+        xg = kf.get_x()
+        assert np.abs(xg - xo).max() < 1e-8
+        # same posterior bits are needed for bit-equal world points: feed the oracle's (the two agree to ~1e-12)
+        r = ctx.map_incremental(xo[:14], 0.2, True, apply=True, want_lists=True)
+        assert r["n_add"] == len(to_add) and r["n_nodown"] == len(nodown)
+        assert bits_equal(r["add"], to_add) and bits_equal(r["nodown"], nodown)
+        c1 = om.add(np.ascontiguousarray(to_add), True)
+        om.add(np.ascontiguousarray(nodown), False)
+        assert r["add_counter"] == c1
+        assert ctx.map_validnum() == om.validnum()
+        assert bits_equal(key(ctx.map_flatten()), key(om.flatten()))
+        assert r["n_add"] > 500                                  # the thinned map does get filled in
+    ctx.close()
+
+
+def test_map_incremental_before_first_search(gpu_capi, small_case):
+    """No neighbour lists yet (EKF not initialised / first scans): every point is a PointToAdd (:1487)."""
+    sc, st = small_case["scan"], small_case["state14"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=4096, max_map_points=50_000)
+    ctx.scan_set(sc.body[:3000])
+    r = ctx.map_incremental(st, 0.2, False, apply=True)
+    assert r["n_add"] == 3000 and r["n_nodown"] == 0
+    assert 0 < ctx.map_validnum() <= 3000
+    ctx.close()
