@@ -272,7 +272,7 @@ hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s) {
 // LDS stack nearest-on-top, and scan leaf ranges 64 points at a time; the running top-5 is
 // wave-uniform and candidates are merged with DPP min reductions.
 // ---------------------------------------------------------------------------------------------
-constexpr int TREE_STACK = 640;
+constexpr int TREE_STACK = 384;
 constexpr uint32_t TREE_LEAF_POINTS = 128;       // ranges this small are scanned, not descended
 
 // squared distance from q to the box of cell (cx,cy,cz) at `level` (edge = cell * 4^level); same
@@ -535,7 +535,10 @@ __global__ __launch_bounds__(64) void knn_tree_kernel(TreeArgs a) {
 
 hipError_t launch_knn_tree(const TreeArgs& a, hipStream_t s) {
     if (a.nq <= 0) return hipSuccess;
-    int blocks = a.nq < 8192 ? a.nq : 8192;       // one wavefront per unresolved query, strided over the scan
+    // one wavefront per workgroup; every lane checks one flag per round, so nq / 64 wavefronts cover the
+    // scan in a single round trip (capped: large scans loop)
+    int blocks = (a.nq + 63) / 64;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(knn_tree_kernel, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }

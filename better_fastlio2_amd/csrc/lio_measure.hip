@@ -66,13 +66,20 @@ __global__ __launch_bounds__(256) void residual_kernel(ResidualArgs a) {
     for (int c = 0; c < 12; ++c) row[c] = 0.0;
 
     if (i < a.nq) {
+        // every load of this point is issued up front (body, flags, the five neighbours): one memory
+        // round trip instead of a dependent chain -- the kernel is latency-bound at ~1.5 waves per SIMD
         const float4 b = a.body[i];
+        float4 nb[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) nb[k] = a.nbr[(size_t)k * a.nq_stride + i];
+        const uint8_t cnt_i = SEARCH ? a.cnt[i] : (uint8_t)K;
+        const uint8_t sel_prev = SEARCH ? (uint8_t)1 : a.sel[i];
+        float4 wpt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (SEARCH) wpt = a.world[i];             // a search pass already holds feats_down_world (transform_kernel)
         const PoseQ s = pose_unpack(a.pose);
         float wx, wy, wz;
         if (SEARCH) {
-            // a search pass already holds feats_down_world (transform_kernel, same pose)
-            const float4 w = a.world[i];
-            wx = w.x; wy = w.y; wz = w.z;
+            wx = wpt.x; wy = wpt.y; wz = wpt.z;
         } else {
             body_to_world(s, b.x, b.y, b.z, wx, wy, wz);                   // :1894-1899
             a.world[i] = make_float4(wx, wy, wz, b.w);
@@ -80,18 +87,14 @@ __global__ __launch_bounds__(256) void residual_kernel(ResidualArgs a) {
         bool cand;
         if (SEARCH) {
             // points_near.size() < 5 ? false : sqdis[4] > 5 ? false : true          :1911
-            const float d5 = a.nbr[(size_t)4 * a.nq_stride + i].w;
-            cand = (a.cnt[i] >= K) && !(d5 > 5.0f);
+            cand = (cnt_i >= K) && !(nb[4].w > 5.0f);
         } else {
-            cand = a.sel[i] != 0;                                          // :1916 (previous flag)
+            cand = sel_prev != 0;                                          // :1916 (previous flag)
         }
         if (cand) {
             float px[5], py[5], pz[5];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const float4 p = a.nbr[(size_t)k * a.nq_stride + i];
-                px[k] = p.x; py[k] = p.y; pz[k] = p.z;
-            }
+            for (int k = 0; k < K; ++k) { px[k] = nb[k].x; py[k] = nb[k].y; pz[k] = nb[k].z; }
             float nx, ny, nz;
             sel = point_residual(px, py, pz, wx, wy, wz, b.x, b.y, b.z, nx, ny, nz, pd2);
             if (sel) {
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void residual_kernel(ResidualArgs a) {
     const int nblocks = (int)gridDim.x;
     double f = 0.0;
     if (e < S::NE) {
-#pragma unroll 8
+#pragma unroll 16
         for (int b = seg; b < nblocks; b += S::SEG)
             f += __hip_atomic_load(&a.partials[(size_t)b * RED_STRIDE + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
