@@ -56,6 +56,7 @@ struct Pose14 { double v[14]; };
 constexpr int RED_NE_EXT = 78 + 12;           // extrinsic_est_en: 12 columns
 constexpr int RED_NE_NOEXT = 21 + 6;          // otherwise columns 6..11 are zero (laserMapping.cpp:1997)
 constexpr int RED_STRIDE = 96;                // doubles per block partial (>= 90 + 2)
+constexpr int RED_GROUP = 16;                 // workgroups per first-level arrival group
 
 struct DeviceOut {                            // written by the final reduction kernel
     double   HTH[144];

@@ -50,7 +50,8 @@ struct lio_ctx {
     float4 *d_body = nullptr, *d_world = nullptr, *d_nbr = nullptr, *d_normvec = nullptr;
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
     uint8_t* d_unres = nullptr;                // per query: 1 = needs the exact tree walk
-    double *d_rows = nullptr, *d_partials = nullptr;
+    double *d_rows = nullptr, *d_partials = nullptr, *d_gpartials = nullptr;
+    uint32_t* d_tickets = nullptr;             // [1 + groups] arrival counters of the residual kernel's reduction
     DeviceOut* h_out = nullptr;                // pinned + mapped: the final reduction writes it directly
     DeviceOut* d_out = nullptr;                // device alias of h_out
     unsigned long long seq = 0;                // sequence number of the last pass (polled in h_out->seq)
@@ -116,8 +117,10 @@ bool is_pow2f(float v) {
     return v > 0.0f && std::frexp(v, &e) == 0.5f;
 }
 int auto_lanes(int nq) {
-    if (nq >= 60000) return 8;
-    if (nq >= 20000) return 16;
+    // measured on MI355X: 8 lanes per query wins from 24 k to 1 M queries (C2/C3/C5); very small
+    // scans have too few wavefronts to fill the chip and prefer wider groups
+    if (nq >= 8000) return 8;
+    if (nq >= 2000) return 16;
     return 32;
 }
 
@@ -386,6 +389,12 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_sel, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_unres, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_partials, (size_t)residual_blocks((int)nq) * RED_STRIDE * sizeof(double)));
+    {
+        const size_t groups = ((size_t)residual_blocks((int)nq) + RED_GROUP - 1) / RED_GROUP;
+        CREATE_CHK(hipMalloc((void**)&c->d_gpartials, groups * RED_STRIDE * sizeof(double)));
+        CREATE_CHK(hipMalloc((void**)&c->d_tickets, (1 + groups) * sizeof(uint32_t)));
+        CREATE_CHK(hipMemset(c->d_tickets, 0, (1 + groups) * sizeof(uint32_t)));
+    }
     CREATE_CHK(hipHostMalloc((void**)&c->h_out, sizeof(DeviceOut), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->h_out, 0, sizeof(DeviceOut));
     CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_out, c->h_out, 0));
@@ -402,7 +411,7 @@ void lio_destroy(lio_ctx* c) {
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_ltable, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
                    c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
-                   c->d_partials, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
+                   c->d_partials, c->d_gpartials, c->d_tickets, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
                    c->d_add_order, c->d_add_order2, c->d_add_gcount, c->d_add_gstart};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -729,7 +738,7 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
     ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.rows = nullptr; ra.partials = c->d_partials;
     const unsigned long long seq = ++c->seq;
-    ra.ticket = c->d_counters + 1; ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
+    ra.gpartials = c->d_gpartials; ra.ticket = c->d_tickets; ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
     prof_begin(c, LIO_PROF_RESIDUAL);
     HIPCHK(c, launch_residual(ra, do_search != 0, ext, s));
     prof_end(c, LIO_PROF_RESIDUAL);
@@ -777,7 +786,7 @@ int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_m
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = c->last_pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
     ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.rows = c->d_rows; ra.partials = c->d_partials;
-    ra.ticket = c->d_counters + 1; ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out;
+    ra.gpartials = c->d_gpartials; ra.ticket = c->d_tickets; ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out;
     ra.seq = ++c->seq;                          // the record is rewritten with identical content
     HIPCHK(c, launch_residual(ra, false, c->last_ext, s));
     const size_t b_rows = (size_t)nq * 13 * sizeof(double);

@@ -62,7 +62,8 @@ struct ResidualArgs {
     float4*        normvec;         // normvec (n^, pd2)
     double*        rows;            // optional [nq][13]: h_x row (12) + h, valid where sel
     double*        partials;        // [nblocks][RED_STRIDE]
-    uint32_t*      ticket;          // device counter, zero between launches: arrival order of the workgroups
+    double*        gpartials;       // [groups][RED_STRIDE] partial of each arrival group
+    uint32_t*      ticket;          // [1 + groups] arrival counters (top, then one per group), zero between launches
     uint32_t*      n_unresolved;    // read into the record and reset (search passes)
     unsigned long long* cand_total; // ditto
     DeviceOut*     out;             // host-mapped result record

@@ -140,23 +140,59 @@ __global__ __launch_bounds__(256) void residual_kernel(ResidualArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+
+    // ---- two-level last-arriver reduction ------------------------------------------------------------
+    // A single arrival counter would serialise ~400 device-scope atomics at the tail of the launch
+    // (~13 ns each).  Workgroups arrive per GROUP of RED_GROUP; the last arriver of a group folds the
+    // group's partials into one group partial and arrives at the top counter; the last group arriver
+    // folds the group partials.  Every sum has a fixed order, whoever arrives last.
     __shared__ uint32_t s_last;
+    const int nblocks = (int)gridDim.x;
+    const int grp = (int)blockIdx.x / RED_GROUP;
+    const int ngroups = (nblocks + RED_GROUP - 1) / RED_GROUP;
+    const int grp_first = grp * RED_GROUP;
+    const int grp_size = (grp_first + RED_GROUP <= nblocks) ? RED_GROUP : nblocks - grp_first;
+    if (tid == 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(a.ticket + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == (uint32_t)(grp_size - 1) ? 1u : 0u;
+        if (s_last) a.ticket[1 + grp] = 0u;                        // consumed: ready for the next launch
+    }
+    __syncthreads();
+    if (s_last == 0u) return;
+    double f = 0.0;
+    if (e < S::NE) {
+#pragma unroll
+        for (int j = seg; j < RED_GROUP; j += S::SEG)
+            if (j < grp_size)
+                f += __hip_atomic_load(&a.partials[(size_t)(grp_first + j) * RED_STRIDE + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                               // s_part is reused
+    s_part[seg][e] = f;
+    __syncthreads();
+    if (tid < S::NE) {
+        double t = 0.0;
+#pragma unroll
+        for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
+        __hip_atomic_store(&a.gpartials[(size_t)grp * RED_STRIDE + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (tid == 0) {
         const uint32_t prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev == gridDim.x - 1 ? 1u : 0u;
+        s_last = prev == (uint32_t)(ngroups - 1) ? 1u : 0u;
+        if (s_last) a.ticket[0] = 0u;
     }
     __syncthreads();
     if (s_last == 0u) return;
 
-    // ---- last workgroup: final reduction over all block partials, fixed order ----------------------
-    const int nblocks = (int)gridDim.x;
-    double f = 0.0;
+    // ---- the very last workgroup: sum of the group partials, fixed order -------------------------------
+    f = 0.0;
     if (e < S::NE) {
-#pragma unroll 16
-        for (int b = seg; b < nblocks; b += S::SEG)
-            f += __hip_atomic_load(&a.partials[(size_t)b * RED_STRIDE + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 8
+        for (int gidx = seg; gidx < ngroups; gidx += S::SEG)
+            f += __hip_atomic_load(&a.gpartials[(size_t)gidx * RED_STRIDE + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();                               // s_part is reused
+    __syncthreads();
     s_part[seg][e] = f;
     __syncthreads();
     __shared__ double s_fin[S::NEP];
@@ -190,7 +226,6 @@ __global__ __launch_bounds__(256) void residual_kernel(ResidualArgs a) {
             out->n_candidates = SEARCH ? *a.cand_total : 0ull;
             // consumed: zero the counters and the ticket for the next pass
             if (SEARCH) { *a.n_unresolved = 0u; *a.cand_total = 0ull; }
-            *a.ticket = 0u;
         }
         __threadfence_system();
         if (tid == 0) __hip_atomic_store(&out->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
