@@ -287,7 +287,7 @@ void prof_end(lio_ctx* c, int which) {
 // k-NN of nq world/body queries into (nbr, cnt); queries_world must hold the world points when
 // body == nullptr, and receives them otherwise.
 int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14& pose, int nq, int stride,
-            float4* nbr, uint8_t* cnt, uint8_t* unres) {
+            float4* nbr, uint8_t* cnt, uint8_t* unres, bool use_hint) {
     hipStream_t s = c->stream;
     // d_counters[0] / d_cand are zero here: zeroed at creation and re-zeroed by whoever consumes them
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
@@ -297,6 +297,7 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.world_in = queries_world;
     ka.nq = nq; ka.nq_stride = stride;
     ka.nbr = nbr; ka.cnt = cnt; ka.unres = unres; ka.cand_total = c->census ? c->d_cand : nullptr;
+    ka.use_hint = use_hint ? 1 : 0;
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
     prof_begin(c, LIO_PROF_KNN);
     HIPCHK(c, launch_knn27(ka, lanes, s));
@@ -674,7 +675,7 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
     int rc = upload_points(c, q_xyz, (size_t)n, stride_bytes, c->d_qs_world);
     if (rc != LIO_OK) return rc;
     Pose14 ident{};
-    rc = run_knn(c, nullptr, c->d_qs_world, ident, n, n, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres);
+    rc = run_knn(c, nullptr, c->d_qs_world, ident, n, n, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres, false);
     if (rc != LIO_OK) return rc;
     const size_t b_xyz = (size_t)n * K * 3 * sizeof(float), b_d = (size_t)n * K * sizeof(float), b_c = (size_t)n * sizeof(int);
     rc = ensure_scratch(c, b_xyz + b_d + b_c);
@@ -730,7 +731,8 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     const bool ext = extrinsic_est_en != 0;
 
     if (do_search) {
-        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_unres);
+        // a later search of the same scan re-uses the neighbours of the previous one as a bound
+        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_unres, c->have_search);
         if (rc != LIO_OK) return rc;
         c->have_search = true;
     }

@@ -19,6 +19,7 @@ struct KnnArgs {
     uint8_t*         cnt;           // [nq] neighbours found (0..5)
     uint8_t*         unres;         // [nq] 1 = result not proven by the 27-cell search (-> tree walk)
     unsigned long long* cand_total; // device counter: sum of C(q)
+    int              use_hint;      // nbr/cnt hold this scan's previous neighbours: bound the search with them
 };
 // feats_down_world = pose (x) feats_down_body, fp64 -> fp32 (laserMapping.cpp:1894-1899)
 hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float4* world, hipStream_t s);

@@ -51,6 +51,23 @@ __device__ __forceinline__ u64 group_min_u64(u64 v) {
     return v;
 }
 
+// maximum of a 32-bit value over each aligned group of G lanes, result in every lane of the group
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_move_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+template <int G>
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
+    if (G >= 2) v = max_u32(v, dpp_move_u32<0xB1>(v));
+    if (G >= 4) v = max_u32(v, dpp_move_u32<0x4E>(v));
+    if (G >= 8) v = max_u32(v, dpp_move_u32<0x141>(v));
+    if (G >= 16) v = max_u32(v, dpp_move_u32<0x140>(v));
+    if (G >= 32) v = max_u32(v, (uint32_t)__shfl_xor((int)v, 16, 64));
+    if (G >= 64) v = max_u32(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+    return v;
+}
+
 // sorted (ascending) list of five keys in registers
 struct Top5 {
     u64 k0, k1, k2, k3, k4;
@@ -78,7 +95,7 @@ __device__ __forceinline__ u64 candidate_key(float qx, float qy, float qz, float
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int G, bool CENSUS>
+template <int G, bool CENSUS, bool HINT>
 __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     constexpr int WPB = 4;
     constexpr int GPW = 64 / G;                    // queries per wavefront
@@ -98,6 +115,33 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     const float inv_cell = a.grid.inv_cell;
     const int cx = cell_coord(qx, inv_cell), cy = cell_coord(qy, inv_cell), cz = cell_coord(qz, inv_cell);
 
+    // ---- HINT (second and later searches of a scan): the previous neighbours of this scan point,
+    // re-measured from the new query, bound the new 5th distance from above: tau = max_k d(q, nbr_k).
+    // Every point that can enter the result then lies in a cell whose box distance is <= tau, so the
+    // other cells are neither probed nor streamed (exactness: see DESIGN.md section 3.1).
+    uint32_t tau_bits = INF_BITS;
+    float glo[3] = {0.f, 0.f, 0.f}, ghi[3] = {0.f, 0.f, 0.f};
+    if (HINT) {
+        uint32_t db = 0u;
+        bool have = false;
+        if (active) {
+            have = a.cnt[q] >= K;
+            if (r < K) {
+                const float4 p = a.nbr[(size_t)r * a.nq_stride + q];
+                const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
+                db = d == d ? __float_as_uint(d) : INF_BITS;
+            }
+        }
+        db = group_max_u32<G>(db);
+        tau_bits = have ? (db < INF_BITS ? db : INF_BITS) : INF_BITS;
+        // distances from the query to the faces of its own cell (exact differences of exact numbers)
+        const float cell = a.grid.cell;
+        const float lox = (float)(cx - CELL_OFF) * cell, loy = (float)(cy - CELL_OFF) * cell, loz = (float)(cz - CELL_OFF) * cell;
+        glo[0] = qx - lox; glo[1] = qy - loy; glo[2] = qz - loz;
+        ghi[0] = (lox + cell) - qx; ghi[1] = (loy + cell) - qy; ghi[2] = (loz + cell) - qz;
+    }
+    const float tau = __uint_as_float(tau_bits);
+
     // ---- 27 hash probes, SLOTS per lane: the first probe of every slot is issued before any is
     // consumed; collisions continue in a rarely taken serial loop
     uint32_t st[SLOTS], ct[SLOTS];
@@ -111,7 +155,16 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         for (int s = 0; s < SLOTS; ++s) {
             const int j = r + s * G;
             const int nx = cx + (j / 9) - 1, ny = cy + ((j / 3) % 3) - 1, nz = cz + (j % 3) - 1;
-            const bool live = active && j < 27 && (uint32_t)nx <= CELL_MAX && (uint32_t)ny <= CELL_MAX && (uint32_t)nz <= CELL_MAX;
+            bool live = active && j < 27 && (uint32_t)nx <= CELL_MAX && (uint32_t)ny <= CELL_MAX && (uint32_t)nz <= CELL_MAX;
+            if (HINT) {
+                // box distance of the neighbour cell, same fp32 form as sqdist3 (a lower bound of every
+                // computed point distance inside it)
+                const int ox = (j / 9) - 1, oy = ((j / 3) % 3) - 1, oz = (j % 3) - 1;
+                const float bx = ox < 0 ? glo[0] : (ox > 0 ? ghi[0] : 0.0f);
+                const float by = oy < 0 ? glo[1] : (oy > 0 ? ghi[1] : 0.0f);
+                const float bz = oz < 0 ? glo[2] : (oz > 0 ? ghi[2] : 0.0f);
+                live = live && ((bx * bx + by * by) + bz * bz <= tau);
+            }
             key[s] = pack_key((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
             slot[s] = hash_cell((uint32_t)nx, (uint32_t)ny, (uint32_t)nz) & mask;
             e[s] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);      // reads as "empty slot"
@@ -156,7 +209,8 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         if (CENSUS) csum += bk.y;
         if ((uint32_t)r < bk.y) {
             const uint32_t idx = bk.x + (uint32_t)r;
-            top.offer(candidate_key(qx, qy, qz, a.map_pts[idx], idx));
+            const u64 key = candidate_key(qx, qy, qz, a.map_pts[idx], idx);
+            if (!HINT || (uint32_t)(key >> 32) <= tau_bits) top.offer(key);
         }
         if (bk.y > (uint32_t)G) {                  // rare at one point per down-sample voxel
             for (uint32_t t = (uint32_t)(r + G); t < bk.y; t += G) {
@@ -229,8 +283,9 @@ template <int G>
 static void launch_knn27_g(const KnnArgs& a, hipStream_t s) {
     const int qpb = 4 * (64 / G);                  // queries per 256-thread workgroup
     const dim3 grid((a.nq + qpb - 1) / qpb), block(256);
-    if (a.cand_total != nullptr) hipLaunchKernelGGL((knn27_kernel<G, true>), grid, block, 0, s, a);
-    else                         hipLaunchKernelGGL((knn27_kernel<G, false>), grid, block, 0, s, a);
+    if (a.cand_total != nullptr) hipLaunchKernelGGL((knn27_kernel<G, true, false>), grid, block, 0, s, a);
+    else if (a.use_hint)         hipLaunchKernelGGL((knn27_kernel<G, false, true>), grid, block, 0, s, a);
+    else                         hipLaunchKernelGGL((knn27_kernel<G, false, false>), grid, block, 0, s, a);
 }
 // feats_down_world = pose (x) feats_down_body (laserMapping.cpp:1894-1899), one lane per point
 __global__ __launch_bounds__(256) void transform_kernel(const float4* body, int n, Pose14 pose, float4* world) {
