@@ -52,7 +52,7 @@ def dist_setup(n_gpus: int):
         os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                                    f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
                                    "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
-    if world == 1:
+    if world == 1 and "RANK" not in os.environ:
         return 0, 1, 0, None
     import torch
     import torch.distributed as dist
@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--lanes", type=int, default=0, help="kNN lanes per query (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--map-update", action="store_true",
+                    help="also time map maintenance per step: map_incremental on every rank, all-gather of the insert "
+                         "lists (RCCL over xGMI) and their application on every replica (BASELINE.json configs[3])")
     a = ap.parse_args()
 
     rank, world_size, local, dist = dist_setup(a.gpus)
@@ -157,18 +160,52 @@ def main():
     P0 = synth.init_cov()
     ext = scan.extrinsic_est_en
 
-    ctx = capi.LioContext(voxel, max_scan_points=nq, max_map_points=nm + 1024, device=local, lanes_per_query=a.lanes)
+    ctx = capi.LioContext(voxel, max_scan_points=nq, max_map_points=nm + (8 * nq * max(world_size, 1) * 32 if a.map_update else 1024),
+                          device=local, lanes_per_query=a.lanes)
     ctx.map_build(world.points)
     body4 = np.zeros((nq, 4), np.float32)
     body4[:, :3] = scan.body
     d_body = torch.from_numpy(body4).to(device)                # scan resident in HBM
     kf = capi.Esekf(max_iter)
 
+    # map-maintenance mode: a short drive (4 poses per rank) so that successive steps really add points
+    drive = []
+    if a.map_update:
+        for k in range(4):
+            sc = synth.make_scan(world, nq, kind=kind, seed=synth.SEED + 101 + 17 * rank + k,
+                                 pos=(px + 0.9 * k, py + 0.4 * k, 0.0), rpy=(0.004, -0.006, yaw + 0.05 * k))
+            ps, rt = synth.perturb_state(sc, dpos=0.05, drot_deg=0.3, seed=synth.SEED + 7 + k)
+            b4 = np.zeros((nq, 4), np.float32)
+            b4[:, :3] = sc.body
+            drive.append((torch.from_numpy(b4).to(device), capi.make_state26(ps, rt, sc.off_R, sc.off_T)))
+    step_no = [0]
+    maint = {"n_add": 0, "n_nodown": 0, "seconds": 0.0}
+
     def step():
-        kf.change_x(x0)
+        if a.map_update:
+            d_b, xs = drive[step_no[0] % len(drive)]
+            step_no[0] += 1
+        else:
+            d_b, xs = d_body, x0
+        kf.change_x(xs)
         kf.change_P(P0)
-        ctx.scan_set_device(d_body.data_ptr(), nq)
-        return kf.update_iterated_dyn_share_modified(ctx, 0.001, ext)
+        ctx.scan_set_device(d_b.data_ptr(), nq)
+        lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, ext)
+        if a.map_update:
+            t0 = time.perf_counter()
+            post = kf.get_x()[:14]
+            if dist is None:
+                r = ctx.map_incremental(post, voxel, True, apply=True)
+            else:
+                # every rank contributes its lists; every replica applies all of them, rank 0 first
+                from better_fastlio2_amd import replicate
+                r = ctx.map_incremental(post, voxel, True, apply=False, want_lists=True)
+                adds = replicate.exchange_inserts(r["add"], capacity=nq, device=device)
+                nods = replicate.exchange_inserts(r["nodown"], capacity=nq, device=device)
+                ctx.map_add_pair(np.concatenate(adds, 0), np.concatenate(nods, 0))
+            maint["n_add"] += r["n_add"]; maint["n_nodown"] += r["n_nodown"]
+            maint["seconds"] += time.perf_counter() - t0
+        return lg
 
     # untimed: candidate census for the byte model, parity of the posterior with the truth
     ctx.census_enable(True)
@@ -218,7 +255,11 @@ def main():
                    "passes_per_step": log["n_calls"], "search_passes_per_step": log["n_search"],
                    "parallelism": f"{world_size} independent scan stream(s), replicated map",
                    "lanes_per_query": a.lanes or "auto", "C_mean": cand_sum / nq, "unresolved_queries": unresolved,
-                   "pos_err_to_truth_m": pos_err},
+                   "pos_err_to_truth_m": pos_err,
+                   "map_update": ({"per_step_ms": maint["seconds"] / max(step_no[0], 1) * 1e3,
+                                   "inserted_per_step": (maint["n_add"] + maint["n_nodown"]) / max(step_no[0], 1),
+                                   "exchange": "all_gather_into_tensor (RCCL)" if dist is not None else "none (1 rank)"}
+                                  if a.map_update else None)},
         "knn_us_per_point": knn_ms * 1e3 / nq,
         "kernels_us": kernels_us,
         "roofline": {"bound": "hbm", "kernel": "knn27_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -55,7 +55,7 @@ class lio_update_log(C.Structure):
 # every symbol include/lio_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_stream", "lio_synchronize",
-    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_incremental", "lio_map_delete_boxes", "lio_map_reconstruct",
+    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_incremental", "lio_map_delete_boxes", "lio_map_reconstruct",
     "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_get_info", "lio_map_nearest_search",
     "lio_scan_set", "lio_scan_set_device", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get",
@@ -108,6 +108,7 @@ def load(build_if_missing: bool = True):
     L.lio_map_build_device.argtypes = [_vp, _vp, C.c_longlong]
     L.lio_map_add.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.lio_map_delete_boxes.argtypes = [_vp, _vp, C.c_int, C.POINTER(C.c_int)]
+    L.lio_map_add_pair.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.lio_map_incremental.argtypes = [_vp, _vp, C.c_double, C.c_int, C.c_int, _vp, C.POINTER(C.c_int), _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lio_map_reconstruct.argtypes = [_vp, _vp, C.c_longlong, C.c_int]
     L.lio_map_size.argtypes = [_vp]
@@ -203,6 +204,15 @@ class LioContext:
         self._chk(self.L.lio_map_add(self.h, _ptr(p), len(p), _stride(p), int(downsample_on), C.byref(n_added)),
                   "lio_map_add")
         return n_added.value
+
+    def map_add_pair(self, add, nodown) -> int:
+        """Add_Points(add, True); Add_Points(nodown, False) with one index rebuild."""
+        a = np.ascontiguousarray(add, np.float32).reshape(-1, 3)
+        b = np.ascontiguousarray(nodown, np.float32).reshape(-1, 3)
+        cnt = C.c_int(0)
+        self._chk(self.L.lio_map_add_pair(self.h, _ptr(a) if len(a) else None, len(a), _ptr(b) if len(b) else None, len(b),
+                                          12, C.byref(cnt)), "lio_map_add_pair")
+        return cnt.value
 
     def map_incremental(self, state14, filter_size_map_min: float = 0.2, flg_EKF_inited: bool = True,
                         apply: bool = True, want_lists: bool = False) -> dict:

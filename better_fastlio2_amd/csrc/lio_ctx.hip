@@ -548,6 +548,34 @@ int lio_map_add(lio_ctx* c, const float* pts, int n, int stride_bytes, int downs
     return rebuild_from_stored(c);
 }
 
+// Add_Points(add, true) followed by Add_Points(nodown, false) -- the pair map_incremental issues
+// (laserMapping.cpp:1492-1493) -- with ONE index rebuild.  Used to apply replicated insert lists.
+int lio_map_add_pair(lio_ctx* c, const float* add_pts, int n_add, const float* nodown_pts, int n_nodown,
+                     int stride_bytes, int* add_counter) {
+    if (!c || n_add < 0 || n_nodown < 0 || (n_add > 0 && !add_pts) || (n_nodown > 0 && !nodown_pts) || stride_bytes < 12)
+        return LIO_ERR_INVALID_ARG;
+    if (add_counter) *add_counter = 0;
+    if (n_add + n_nodown == 0) return LIO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((size_t)c->n_points + (size_t)n_add + (size_t)n_nodown > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "lio_map_add_pair", "stored points + batches exceed max_map_points");
+    int rc = ensure_add_buffers(c, (size_t)(n_add > n_nodown ? n_add : n_nodown));
+    if (rc != LIO_OK) return rc;
+    if (n_add > 0) {
+        rc = upload_points(c, add_pts, (size_t)n_add, stride_bytes, c->d_add_pts);
+        if (rc != LIO_OK) return rc;
+        rc = add_batch_device(c, c->d_add_pts, (uint32_t)n_add, true, add_counter);
+        if (rc != LIO_OK) return rc;
+    }
+    if (n_nodown > 0) {
+        rc = upload_points(c, nodown_pts, (size_t)n_nodown, stride_bytes, c->d_add_pts2);
+        if (rc != LIO_OK) return rc;
+        rc = add_batch_device(c, c->d_add_pts2, (uint32_t)n_nodown, false, nullptr);
+        if (rc != LIO_OK) return rc;
+    }
+    return rebuild_from_stored(c);
+}
+
 // map_incremental (src/laserMapping.cpp:1440-1496) on the scan of the last measurement passes.
 int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
                         int apply, float* out_add_xyz, int* n_add, float* out_nodown_xyz, int* n_nodown,

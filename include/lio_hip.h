@@ -109,6 +109,10 @@ int  lio_map_add(lio_ctx* ctx, const float* pts, int n, int stride_bytes, int do
 int  lio_map_incremental(lio_ctx* ctx, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
                          int apply, float* out_add_xyz, int* n_add, float* out_nodown_xyz, int* n_nodown,
                          int* add_counter);
+/* Add_Points(add, true) then Add_Points(nodown, false) (the pair of laserMapping.cpp:1492-1493) with a
+ * single index rebuild; *add_counter = return value of the first call.  Applies replicated insert lists. */
+int  lio_map_add_pair(lio_ctx* ctx, const float* add_pts, int n_add, const float* nodown_pts, int n_nodown,
+                      int stride_bytes, int* add_counter);
 /* KD_TREE::Delete_Point_Boxes (ikd_Tree.cpp:536-556): boxes = nb x {min xyz, max xyz}, half-open.  */
 int  lio_map_delete_boxes(lio_ctx* ctx, const float* minmax6, int nb, int* n_deleted);
 /* KD_TREE::reconstruct (ikd_Tree.cpp:1394-1405) == Build on a new cloud.                           */
