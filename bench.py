@@ -58,7 +58,21 @@ def dist_setup(n_gpus: int):
     import torch.distributed as dist
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    # RCCL prints a version banner on stdout when the communicator is created; create it now, with
+    # stdout pointed at stderr, so that rank 0's stdout carries nothing but the JSON line
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        warm = torch.zeros(1, device=torch.device("cuda", local))
+        dist.all_reduce(warm)
+        torch.cuda.synchronize(local)
+    finally:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
     return dist.get_rank(), dist.get_world_size(), local, dist
 
 
