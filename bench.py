@@ -211,12 +211,15 @@ def main():
             if dist is None:
                 r = ctx.map_incremental(post, voxel, True, apply=True)
             else:
-                # every rank contributes its lists; every replica applies all of them, rank 0 first
+                # every rank contributes its lists; every replica applies all of them, rank 0 first.
+                # The lists never leave HBM: device pointers -> RCCL all-gather -> device pointers.
                 from better_fastlio2_amd import replicate
-                r = ctx.map_incremental(post, voxel, True, apply=False, want_lists=True)
-                adds = replicate.exchange_inserts(r["add"], capacity=nq, device=device)
-                nods = replicate.exchange_inserts(r["nodown"], capacity=nq, device=device)
-                ctx.map_add_pair(np.concatenate(adds, 0), np.concatenate(nods, 0))
+                pa, na, pb, nb = ctx.map_incremental_device(post, voxel, True)
+                A, _ = replicate.exchange_inserts_device(pa, na, nq, device)
+                B, _ = replicate.exchange_inserts_device(pb, nb, nq, device)
+                torch.cuda.synchronize(device)                 # torch's stream -> the library's stream
+                ctx.map_add_pair_device(A.data_ptr(), A.shape[0], B.data_ptr(), B.shape[0])
+                r = {"n_add": na, "n_nodown": nb}
             maint["n_add"] += r["n_add"]; maint["n_nodown"] += r["n_nodown"]
             maint["seconds"] += time.perf_counter() - t0
         return lg

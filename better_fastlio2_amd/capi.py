@@ -55,7 +55,7 @@ class lio_update_log(C.Structure):
 # every symbol include/lio_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_stream", "lio_synchronize",
-    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_incremental", "lio_map_delete_boxes", "lio_map_reconstruct",
+    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_map_reconstruct",
     "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_get_info", "lio_map_nearest_search",
     "lio_scan_set", "lio_scan_set_device", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get",
@@ -109,6 +109,8 @@ def load(build_if_missing: bool = True):
     L.lio_map_add.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.lio_map_delete_boxes.argtypes = [_vp, _vp, C.c_int, C.POINTER(C.c_int)]
     L.lio_map_add_pair.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.lio_map_incremental_device.argtypes = [_vp, _vp, C.c_double, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.POINTER(_vp), C.POINTER(C.c_int)]
+    L.lio_map_add_pair_device.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.POINTER(C.c_int)]
     L.lio_map_incremental.argtypes = [_vp, _vp, C.c_double, C.c_int, C.c_int, _vp, C.POINTER(C.c_int), _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lio_map_reconstruct.argtypes = [_vp, _vp, C.c_longlong, C.c_int]
     L.lio_map_size.argtypes = [_vp]
@@ -212,6 +214,20 @@ class LioContext:
         cnt = C.c_int(0)
         self._chk(self.L.lio_map_add_pair(self.h, _ptr(a) if len(a) else None, len(a), _ptr(b) if len(b) else None, len(b),
                                           12, C.byref(cnt)), "lio_map_add_pair")
+        return cnt.value
+
+    def map_incremental_device(self, state14, filter_size_map_min: float = 0.2, flg_EKF_inited: bool = True):
+        """map_incremental's two lists left in HBM: (ptr_add, n_add, ptr_nodown, n_nodown), float4 records."""
+        s = np.ascontiguousarray(state14, dtype=np.float64)
+        pa, pb, na, nb = _vp(), _vp(), C.c_int(0), C.c_int(0)
+        self._chk(self.L.lio_map_incremental_device(self.h, _ptr(s), float(filter_size_map_min), int(flg_EKF_inited),
+                                                    C.byref(pa), C.byref(na), C.byref(pb), C.byref(nb)), "lio_map_incremental_device")
+        return pa.value or 0, na.value, pb.value or 0, nb.value
+
+    def map_add_pair_device(self, ptr_add: int, n_add: int, ptr_nodown: int, n_nodown: int) -> int:
+        cnt = C.c_int(0)
+        self._chk(self.L.lio_map_add_pair_device(self.h, _vp(ptr_add), n_add, _vp(ptr_nodown), n_nodown, C.byref(cnt)),
+                  "lio_map_add_pair_device")
         return cnt.value
 
     def map_incremental(self, state14, filter_size_map_min: float = 0.2, flg_EKF_inited: bool = True,

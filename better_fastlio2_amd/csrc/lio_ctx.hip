@@ -576,14 +576,11 @@ int lio_map_add_pair(lio_ctx* c, const float* add_pts, int n_add, const float* n
     return rebuild_from_stored(c);
 }
 
-// map_incremental (src/laserMapping.cpp:1440-1496) on the scan of the last measurement passes.
-int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
-                        int apply, float* out_add_xyz, int* n_add, float* out_nodown_xyz, int* n_nodown,
-                        int* add_counter) {
-    if (!c || !state14 || !(filter_size_map_min > 0.0)) return LIO_ERR_INVALID_ARG;
-    if (n_add) *n_add = 0;
-    if (n_nodown) *n_nodown = 0;
-    if (add_counter) *add_counter = 0;
+// map_incremental's classification + the two order-preserving lists, left on the device
+// (c->d_add_pts = PointToAdd, c->d_add_pts2 = PointNoNeedDownsample).
+static int map_incremental_lists(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
+                                 uint32_t cnts[2]) {
+    cnts[0] = cnts[1] = 0;
     if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_map_incremental", "no scan set");
     const int nq = c->nq;
     if (nq == 0) return LIO_OK;
@@ -603,9 +600,23 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
     HIPCHK(c, launch_map_incremental(ia, s));
     HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 1, c->d_add_pts, c->d_counters + 5, (size_t)nq, s));
     HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 2, c->d_add_pts2, c->d_counters + 6, (size_t)nq, s));
-    uint32_t cnts[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(cnts, c->d_counters + 5, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    return LIO_OK;
+}
+
+// map_incremental (src/laserMapping.cpp:1440-1496) on the scan of the last measurement passes.
+int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
+                        int apply, float* out_add_xyz, int* n_add, float* out_nodown_xyz, int* n_nodown,
+                        int* add_counter) {
+    if (!c || !state14 || !(filter_size_map_min > 0.0)) return LIO_ERR_INVALID_ARG;
+    if (n_add) *n_add = 0;
+    if (n_nodown) *n_nodown = 0;
+    if (add_counter) *add_counter = 0;
+    uint32_t cnts[2];
+    int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, cnts);
+    if (rc != LIO_OK) return rc;
+    hipStream_t s = c->stream;
     if (n_add) *n_add = (int)cnts[0];
     if (n_nodown) *n_nodown = (int)cnts[1];
     // the lists, for the caller that replicates them to other GPUs
@@ -625,6 +636,54 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
     rc = add_batch_device(c, c->d_add_pts, cnts[0], true, add_counter);
     if (rc != LIO_OK) return rc;
     rc = add_batch_device(c, c->d_add_pts2, cnts[1], false, nullptr);
+    if (rc != LIO_OK) return rc;
+    return rebuild_from_stored(c);
+}
+
+// Device-resident variants for replicated maps: the lists stay in HBM (float4 records), are exchanged
+// by the caller (RCCL all-gather over xGMI) and applied from device memory.
+int lio_map_incremental_device(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
+                               void** d_add_f4, int* n_add, void** d_nodown_f4, int* n_nodown) {
+    if (!c || !state14 || !(filter_size_map_min > 0.0) || !d_add_f4 || !n_add || !d_nodown_f4 || !n_nodown)
+        return LIO_ERR_INVALID_ARG;
+    uint32_t cnts[2];
+    int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, cnts);
+    if (rc != LIO_OK) return rc;
+    *d_add_f4 = c->d_add_pts; *n_add = (int)cnts[0];
+    *d_nodown_f4 = c->d_add_pts2; *n_nodown = (int)cnts[1];
+    return LIO_OK;
+}
+int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const void* d_nodown_f4, int n_nodown,
+                            int* add_counter) {
+    if (!c || n_add < 0 || n_nodown < 0 || (n_add > 0 && !d_add_f4) || (n_nodown > 0 && !d_nodown_f4)) return LIO_ERR_INVALID_ARG;
+    if (add_counter) *add_counter = 0;
+    if (n_add + n_nodown == 0) return LIO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((size_t)c->n_points + (size_t)n_add + (size_t)n_nodown > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "lio_map_add_pair_device", "stored points + batches exceed max_map_points");
+    // stage into the context's own batch buffers (the fold clobbers its input; the caller's may be ours)
+    const size_t need = (size_t)(n_add > n_nodown ? n_add : n_nodown);
+    if (need > c->cap_add) {
+        // growing would free buffers the caller may be pointing into: copy out first
+        float4 *ta = nullptr, *tb = nullptr;
+        if (n_add) { HIPCHK(c, hipMalloc((void**)&ta, (size_t)n_add * sizeof(float4))); HIPCHK(c, hipMemcpy(ta, d_add_f4, (size_t)n_add * sizeof(float4), hipMemcpyDeviceToDevice)); }
+        if (n_nodown) { HIPCHK(c, hipMalloc((void**)&tb, (size_t)n_nodown * sizeof(float4))); HIPCHK(c, hipMemcpy(tb, d_nodown_f4, (size_t)n_nodown * sizeof(float4), hipMemcpyDeviceToDevice)); }
+        int rc0 = ensure_add_buffers(c, need);
+        if (rc0 == LIO_OK && n_add) HIPCHK(c, hipMemcpy(c->d_add_pts, ta, (size_t)n_add * sizeof(float4), hipMemcpyDeviceToDevice));
+        if (rc0 == LIO_OK && n_nodown) HIPCHK(c, hipMemcpy(c->d_add_pts2, tb, (size_t)n_nodown * sizeof(float4), hipMemcpyDeviceToDevice));
+        if (ta) (void)hipFree(ta);
+        if (tb) (void)hipFree(tb);
+        if (rc0 != LIO_OK) return rc0;
+    } else {
+        hipStream_t s = c->stream;
+        if (n_add && d_add_f4 != c->d_add_pts)
+            HIPCHK(c, hipMemcpyAsync(c->d_add_pts, d_add_f4, (size_t)n_add * sizeof(float4), hipMemcpyDeviceToDevice, s));
+        if (n_nodown && d_nodown_f4 != c->d_add_pts2)
+            HIPCHK(c, hipMemcpyAsync(c->d_add_pts2, d_nodown_f4, (size_t)n_nodown * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    }
+    int rc = add_batch_device(c, c->d_add_pts, (uint32_t)n_add, true, add_counter);
+    if (rc != LIO_OK) return rc;
+    rc = add_batch_device(c, c->d_add_pts2, (uint32_t)n_nodown, false, nullptr);
     if (rc != LIO_OK) return rc;
     return rebuild_from_stored(c);
 }

@@ -40,6 +40,37 @@ def exchange_inserts(points: np.ndarray, capacity: int, device: "torch.device | 
     return res
 
 
+class _DeviceView:
+    """Wraps a raw device pointer so that torch can alias it (``__cuda_array_interface__``, read-only use)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def exchange_inserts_device(ptr: int, n: int, capacity: int, device, group=None):
+    """Device-resident form: this rank's list is n float4 records at device pointer `ptr`
+    (lio_map_incremental_device).  Returns (tensor [total, 4] float32 on `device`, rank order; counts).
+    One all-gather of the counts and one of fixed-capacity buffers -- xGMI moves <= capacity*16 B per
+    rank, nothing goes through the host."""
+    if n > capacity:
+        raise ValueError(f"{n} points exceed the exchange capacity {capacity}")
+    mine = torch.as_tensor(_DeviceView(ptr, n), device=device) if n else torch.empty((0, 4), dtype=torch.float32, device=device)
+    if not dist.is_initialized():
+        return mine.clone(), [n]
+    world = dist.get_world_size(group)
+    buf = torch.zeros((capacity, 4), dtype=torch.float32, device=device)
+    if n:
+        buf[:n] = mine
+    cnt = torch.tensor([n], dtype=torch.int32, device=device)
+    counts = torch.empty(world, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(counts, cnt, group=group)
+    out = torch.empty((world * capacity, 4), dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    cs = [int(v) for v in counts.cpu().tolist()]
+    parts = [out[r * capacity: r * capacity + cs[r]] for r in range(world)]
+    return torch.cat(parts, 0).contiguous(), cs
+
+
 def exchange_boxes(boxes: np.ndarray, max_boxes: int = 4, device: "torch.device | str" = "cpu", group=None):
     """All-gather delete boxes ([nb, 6] float32, nb <= max_boxes); returns them concatenated in rank order."""
     boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)

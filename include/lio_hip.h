@@ -109,6 +109,13 @@ int  lio_map_add(lio_ctx* ctx, const float* pts, int n, int stride_bytes, int do
 int  lio_map_incremental(lio_ctx* ctx, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
                          int apply, float* out_add_xyz, int* n_add, float* out_nodown_xyz, int* n_nodown,
                          int* add_counter);
+/* Device-resident forms for replicated maps (one rank per GPU): the two lists of map_incremental stay in
+ * HBM as float4 records (pointers valid until the next lio_map_* call on ctx), are exchanged by the caller
+ * (RCCL all-gather) and applied from device memory.                                                      */
+int  lio_map_incremental_device(lio_ctx* ctx, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
+                                void** d_add_f4, int* n_add, void** d_nodown_f4, int* n_nodown);
+int  lio_map_add_pair_device(lio_ctx* ctx, const void* d_add_f4, int n_add, const void* d_nodown_f4, int n_nodown,
+                             int* add_counter);
 /* Add_Points(add, true) then Add_Points(nodown, false) (the pair of laserMapping.cpp:1492-1493) with a
  * single index rebuild; *add_counter = return value of the first call.  Applies replicated insert lists. */
 int  lio_map_add_pair(lio_ctx* ctx, const float* add_pts, int n_add, const float* nodown_pts, int n_nodown,

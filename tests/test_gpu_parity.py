@@ -316,3 +316,38 @@ def test_map_incremental_before_first_search(gpu_capi, small_case):
     assert r["n_add"] == 3000 and r["n_nodown"] == 0
     assert 0 < ctx.map_validnum() <= 3000
     ctx.close()
+
+
+def test_replicated_apply_from_device_lists(gpu_capi, oracle, synth, small_case):
+    """The multi-GPU map-maintenance path on one GPU: map_incremental's lists stay in HBM, pass through
+    replicate.exchange_inserts_device (identity without a process group; RCCL all-gather with one) and
+    are applied with lio_map_add_pair_device -- same live set as applying map_incremental directly."""
+    import torch
+    from better_fastlio2_amd import replicate
+    w, sc = small_case["world"], small_case["scan"]
+    base = np.ascontiguousarray(w.points[::3])
+    key = lambda p: p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+    ctxs = [gpu_capi.LioContext(0.2, max_scan_points=20_000, max_map_points=400_000) for _ in range(2)]
+    x0 = gpu_capi.make_state26(small_case["pos"], small_case["rot"], sc.off_R, sc.off_T)
+    posts = []
+    for c in ctxs:
+        c.map_build(base)
+        kf = gpu_capi.Esekf(3); kf.change_x(x0); kf.change_P(synth.init_cov())
+        c.scan_set(sc.body)
+        kf.update_iterated_dyn_share_modified(c, 0.001, False)
+        posts.append(kf.get_x()[:14])
+    assert np.array_equal(posts[0], posts[1])                     # same inputs -> same bits on both replicas
+    r = ctxs[0].map_incremental(posts[0], 0.2, True, apply=True)
+    pa, na, pb, nb = ctxs[1].map_incremental_device(posts[1], 0.2, True)
+    assert (na, nb) == (r["n_add"], r["n_nodown"])
+    dev = torch.device("cuda", 0)
+    A, ca = replicate.exchange_inserts_device(pa, na, 20_000, dev)
+    B, cb = replicate.exchange_inserts_device(pb, nb, 20_000, dev)
+    torch.cuda.synchronize()
+    assert ca == [na] and cb == [nb] and A.shape == (na, 4)
+    cnt = ctxs[1].map_add_pair_device(A.data_ptr(), na, B.data_ptr(), nb)
+    assert cnt == r["add_counter"]
+    assert ctxs[0].map_validnum() == ctxs[1].map_validnum()
+    assert bits_equal(key(ctxs[0].map_flatten()), key(ctxs[1].map_flatten()))
+    for c in ctxs:
+        c.close()
