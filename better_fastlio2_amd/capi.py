@@ -55,7 +55,7 @@ class lio_update_log(C.Structure):
 # every symbol include/lio_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_stream", "lio_synchronize",
-    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_map_reconstruct",
+    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_fov_segment", "lio_map_reconstruct",
     "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_get_info", "lio_map_nearest_search",
     "lio_scan_set", "lio_scan_set_device", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get",
@@ -112,6 +112,7 @@ def load(build_if_missing: bool = True):
     L.lio_map_incremental_device.argtypes = [_vp, _vp, C.c_double, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.POINTER(_vp), C.POINTER(C.c_int)]
     L.lio_map_add_pair_device.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.POINTER(C.c_int)]
     L.lio_map_incremental.argtypes = [_vp, _vp, C.c_double, C.c_int, C.c_int, _vp, C.POINTER(C.c_int), _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.lio_fov_segment.argtypes = [_vp, _vp, C.c_double, C.c_float, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lio_map_reconstruct.argtypes = [_vp, _vp, C.c_longlong, C.c_int]
     L.lio_map_size.argtypes = [_vp]
     L.lio_map_size.restype = C.c_longlong
@@ -252,6 +253,15 @@ class LioContext:
         n = C.c_int(0)
         self._chk(self.L.lio_map_delete_boxes(self.h, _ptr(b), len(b), C.byref(n)), "lio_map_delete_boxes")
         return n.value
+
+    def fov_segment(self, pos_lid, cube_len: float, det_range: float):
+        """lasermap_fov_segment (laserMapping.cpp:1136-1200): returns (boxes [nb, 6], n_deleted)."""
+        p = np.ascontiguousarray(pos_lid, np.float64)
+        boxes = np.zeros((3, 6), np.float32)
+        nb, nd = C.c_int(0), C.c_int(0)
+        self._chk(self.L.lio_fov_segment(self.h, _ptr(p), float(cube_len), float(det_range), _ptr(boxes), C.byref(nb), C.byref(nd)),
+                  "lio_fov_segment")
+        return boxes[:nb.value].copy(), nd.value
 
     def map_size(self) -> int:
         return self.L.lio_map_size(self.h)

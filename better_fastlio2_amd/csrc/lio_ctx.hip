@@ -45,6 +45,10 @@ struct lio_ctx {
     uint32_t n_points = 0, n_live = 0, n_cells = 0;
     bool have_map = false;
 
+    // local-map cube of lasermap_fov_segment (laserMapping.cpp:1132-1133)
+    float localmap_min[3] = {0.f, 0.f, 0.f}, localmap_max[3] = {0.f, 0.f, 0.f};
+    bool localmap_initialized = false;
+
     // ---- scan -------------------------------------------------------------------------------
     int cap_q = 0, nq = 0;
     float4 *d_body = nullptr, *d_world = nullptr, *d_nbr = nullptr, *d_normvec = nullptr;
@@ -710,6 +714,62 @@ int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_delete
     }
     c->n_live -= (uint32_t)total;
     if (n_deleted) *n_deleted = total;
+    return LIO_OK;
+}
+
+// lasermap_fov_segment (src/laserMapping.cpp:1136-1200): keep the map inside a cube of edge cube_len that
+// follows the LiDAR; when the LiDAR comes within MOV_THRESHOLD * DET_RANGE of a face the cube moves by
+// mov_dist and the slab left behind is deleted (Delete_Point_Boxes).  Types follow the reference: the
+// cube corners are float (BoxPointType), pos_LiD / cube_len double, DET_RANGE / MOV_THRESHOLD float.
+int lio_fov_segment(lio_ctx* c, const double pos_lid[3], double cube_len, float det_range, float* boxes_out,
+                    int* n_boxes, int* n_deleted) {
+    if (!c || !pos_lid) return LIO_ERR_INVALID_ARG;
+    if (n_boxes) *n_boxes = 0;
+    if (n_deleted) *n_deleted = 0;
+    const float MOV_THRESHOLD = 1.5f;                                        // :53
+    if (!c->localmap_initialized) {                                           // :1144-1153
+        for (int i = 0; i < 3; ++i) {
+            c->localmap_min[i] = (float)(pos_lid[i] - cube_len / 2.0);
+            c->localmap_max[i] = (float)(pos_lid[i] + cube_len / 2.0);
+        }
+        c->localmap_initialized = true;
+        return LIO_OK;
+    }
+    float dist_to_map_edge[3][2];
+    bool need_move = false;
+    const float thr = MOV_THRESHOLD * det_range;
+    for (int i = 0; i < 3; ++i) {                                             // :1158-1166
+        dist_to_map_edge[i][0] = (float)std::fabs(pos_lid[i] - (double)c->localmap_min[i]);
+        dist_to_map_edge[i][1] = (float)std::fabs(pos_lid[i] - (double)c->localmap_max[i]);
+        if (dist_to_map_edge[i][0] <= thr || dist_to_map_edge[i][1] <= thr) need_move = true;
+    }
+    if (!need_move) return LIO_OK;
+    float new_min[3], new_max[3];
+    for (int i = 0; i < 3; ++i) { new_min[i] = c->localmap_min[i]; new_max[i] = c->localmap_max[i]; }
+    const double m1 = (cube_len - 2.0 * (double)MOV_THRESHOLD * (double)det_range) * 0.5 * 0.9;
+    const double m2 = (double)(det_range * (MOV_THRESHOLD - 1));
+    const float mov_dist = (float)(m1 > m2 ? m1 : m2);                        // :1173
+    float boxes[3 * 6];
+    int nb = 0;
+    for (int i = 0; i < 3; ++i) {                                             // :1174-1192
+        float tmin[3], tmax[3];
+        for (int k = 0; k < 3; ++k) { tmin[k] = c->localmap_min[k]; tmax[k] = c->localmap_max[k]; }
+        if (dist_to_map_edge[i][0] <= thr) {
+            new_max[i] -= mov_dist; new_min[i] -= mov_dist;
+            tmin[i] = c->localmap_max[i] - mov_dist;
+        } else if (dist_to_map_edge[i][1] <= thr) {
+            new_max[i] += mov_dist; new_min[i] += mov_dist;
+            tmax[i] = c->localmap_min[i] + mov_dist;
+        } else {
+            continue;
+        }
+        for (int k = 0; k < 3; ++k) { boxes[6 * nb + k] = tmin[k]; boxes[6 * nb + 3 + k] = tmax[k]; }
+        ++nb;
+    }
+    for (int i = 0; i < 3; ++i) { c->localmap_min[i] = new_min[i]; c->localmap_max[i] = new_max[i]; }
+    if (boxes_out) std::memcpy(boxes_out, boxes, sizeof(float) * 6 * (size_t)nb);
+    if (n_boxes) *n_boxes = nb;
+    if (nb > 0) return lio_map_delete_boxes(c, boxes, nb, n_deleted);         // :1196-1198
     return LIO_OK;
 }
 

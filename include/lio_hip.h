@@ -122,6 +122,11 @@ int  lio_map_add_pair(lio_ctx* ctx, const float* add_pts, int n_add, const float
                       int stride_bytes, int* add_counter);
 /* KD_TREE::Delete_Point_Boxes (ikd_Tree.cpp:536-556): boxes = nb x {min xyz, max xyz}, half-open.  */
 int  lio_map_delete_boxes(lio_ctx* ctx, const float* minmax6, int nb, int* n_deleted);
+/* lasermap_fov_segment (src/laserMapping.cpp:1136-1200): the local-map cube (edge cube_len) follows the
+ * LiDAR position pos_lid; when it moves, the slabs left behind (<= 3 boxes, written to boxes_out[18] if
+ * not NULL) are removed with Delete_Point_Boxes.  The cube state (LocalMap_Points) lives in ctx.        */
+int  lio_fov_segment(lio_ctx* ctx, const double pos_lid[3], double cube_len, float det_range, float* boxes_out,
+                     int* n_boxes, int* n_deleted);
 /* KD_TREE::reconstruct (ikd_Tree.cpp:1394-1405) == Build on a new cloud.                           */
 int  lio_map_reconstruct(lio_ctx* ctx, const float* pts, long long n, int stride_bytes);
 long long lio_map_size(lio_ctx* ctx);               /* KD_TREE::size()     (ikd_Tree.cpp:79)           */

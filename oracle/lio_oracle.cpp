@@ -1045,4 +1045,45 @@ void orc_map_incremental_classify(const float* world, int n, const float* nbr_xy
     }
 }
 
+// lasermap_fov_segment (src/laserMapping.cpp:1136-1200).  state7 = LocalMap_Points min xyz, max xyz,
+// Localmap_Initialized (as float 0/1).  Writes up to 3 boxes (cub_needrm) and returns their number; the
+// caller applies them with orc_map_delete_boxes.
+int orc_fov_segment(float* state7, const double* pos_lid, double cube_len, float DET_RANGE, float* boxes18) {
+    const float MOV_THRESHOLD = 1.5f;
+    float* vmin = state7; float* vmax = state7 + 3;
+    if (state7[6] == 0.0f) {
+        for (int i = 0; i < 3; i++) {
+            vmin[i] = pos_lid[i] - cube_len / 2.0;
+            vmax[i] = pos_lid[i] + cube_len / 2.0;
+        }
+        state7[6] = 1.0f;
+        return 0;
+    }
+    float dist_to_map_edge[3][2];
+    bool need_move = false;
+    for (int i = 0; i < 3; i++) {
+        dist_to_map_edge[i][0] = std::fabs(pos_lid[i] - vmin[i]);
+        dist_to_map_edge[i][1] = std::fabs(pos_lid[i] - vmax[i]);
+        if (dist_to_map_edge[i][0] <= MOV_THRESHOLD * DET_RANGE || dist_to_map_edge[i][1] <= MOV_THRESHOLD * DET_RANGE) need_move = true;
+    }
+    if (!need_move) return 0;
+    float nmin[3] = {vmin[0], vmin[1], vmin[2]}, nmax[3] = {vmax[0], vmax[1], vmax[2]};
+    float mov_dist = std::max((cube_len - 2.0 * MOV_THRESHOLD * DET_RANGE) * 0.5 * 0.9, double(DET_RANGE * (MOV_THRESHOLD - 1)));
+    int nb = 0;
+    for (int i = 0; i < 3; i++) {
+        float tmin[3] = {vmin[0], vmin[1], vmin[2]}, tmax[3] = {vmax[0], vmax[1], vmax[2]};
+        if (dist_to_map_edge[i][0] <= MOV_THRESHOLD * DET_RANGE) {
+            nmax[i] -= mov_dist; nmin[i] -= mov_dist;
+            tmin[i] = vmax[i] - mov_dist;
+        } else if (dist_to_map_edge[i][1] <= MOV_THRESHOLD * DET_RANGE) {
+            nmax[i] += mov_dist; nmin[i] += mov_dist;
+            tmax[i] = vmin[i] + mov_dist;
+        } else continue;
+        for (int k = 0; k < 3; k++) { boxes18[6 * nb + k] = tmin[k]; boxes18[6 * nb + 3 + k] = tmax[k]; }
+        ++nb;
+    }
+    for (int i = 0; i < 3; i++) { vmin[i] = nmin[i]; vmax[i] = nmax[i]; }
+    return nb;
+}
+
 }  // extern "C"

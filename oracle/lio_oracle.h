@@ -83,6 +83,9 @@ void   orc_map_incremental_classify(const float* world_xyz, int n, const float* 
                                     const int* nbr_cnt, double filter_size_map_min,
                                     int flg_EKF_inited, uint8_t* cls);
 
+/* lasermap_fov_segment (src/laserMapping.cpp:1136-1200); state7 = LocalMap_Points min, max, initialised flag */
+int    orc_fov_segment(float* state7, const double* pos_lid, double cube_len, float det_range, float* boxes18);
+
 #ifdef __cplusplus
 }
 #endif

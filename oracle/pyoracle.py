@@ -69,6 +69,8 @@ def lib():
         L.orc_hth.argtypes = [_f64p, _f64p, C.c_int, _f64p, _f64p]
         L.orc_map_incremental_classify.argtypes = [_f32p, C.c_int, _f32p, _i32p, C.c_double, C.c_int, _u8p]
         L.orc_set_external_knn.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_fov_segment.restype = C.c_int
+        L.orc_fov_segment.argtypes = [_f32p, _f64p, C.c_double, C.c_float, _f32p]
         _lib = L
     return _lib
 
@@ -300,6 +302,18 @@ class RefIkdTree:
 
     def quiesce(self, ms: int = 200):
         self.L.ref_ikd_quiesce(ms)
+
+
+class FovSegment:
+    """lasermap_fov_segment state machine (LocalMap_Points / Localmap_Initialized)."""
+
+    def __init__(self):
+        self.state = np.zeros(7, np.float32)
+
+    def step(self, pos_lid, cube_len: float, det_range: float):
+        boxes = np.zeros((3, 6), np.float32)
+        nb = lib().orc_fov_segment(self.state, np.ascontiguousarray(pos_lid, np.float64), cube_len, det_range, boxes)
+        return boxes[:nb].copy()
 
 
 def use_reference_knn(tree: "RefIkdTree | None"):

@@ -351,3 +351,28 @@ def test_replicated_apply_from_device_lists(gpu_capi, oracle, synth, small_case)
     assert bits_equal(key(ctxs[0].map_flatten()), key(ctxs[1].map_flatten()))
     for c in ctxs:
         c.close()
+
+
+def test_fov_segment_sliding_cube(gpu_capi, oracle, small_case):
+    """lasermap_fov_segment (laserMapping.cpp:1136-1200): the local-map cube follows the LiDAR and the
+    slabs left behind are deleted -- same boxes, same delete counts, same live set as the CPU path."""
+    w = small_case["world"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=1024, max_map_points=400_000)
+    ctx.map_build(w.points)
+    om = oracle.OracleMap(0.2); om.build(w.points)
+    fov = oracle.FovSegment()
+    key = lambda p: p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+    cube_len, det_range = 60.0, 15.0               # 1.5 * 15 = 22.5 m from a face triggers a move of 6.75 m
+    moved = 0
+    for k in range(12):
+        pos = np.array([-20.0 + 5.5 * k, 3.0 - 2.0 * k, 1.7])
+        boxes_o = fov.step(pos, cube_len, det_range)
+        boxes_g, nd_g = ctx.fov_segment(pos, cube_len, det_range)
+        assert boxes_g.shape == boxes_o.shape and bits_equal(boxes_g, boxes_o)
+        nd_o = om.delete_boxes(boxes_o) if len(boxes_o) else 0
+        assert nd_g == nd_o
+        moved += len(boxes_o)
+        assert ctx.map_validnum() == om.validnum()
+    assert moved >= 3
+    assert bits_equal(key(ctx.map_flatten()), key(om.flatten()))
+    ctx.close()
