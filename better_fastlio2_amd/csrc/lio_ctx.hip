@@ -60,6 +60,7 @@ struct lio_ctx {
     DeviceOut* d_out = nullptr;                // device alias of h_out
     unsigned long long seq = 0;                // sequence number of the last pass (polled in h_out->seq)
     bool have_scan = false, have_search = false, have_pass = false;
+    bool hint_valid = false;                   // d_nbr holds live map points of THIS map state for THIS scan
     Pose14 last_pose{};
     bool last_ext = false;
     int last_m = 0;
@@ -170,6 +171,7 @@ int upload_points(lio_ctx* c, const float* pts, size_t n, int stride_bytes, floa
 int build_index(lio_ctx* c, const float4* src, uint32_t n) {
     hipStream_t s = c->stream;
     c->have_map = false;
+    c->hint_valid = false;                     // neighbours of an older map state no longer bound a search
     c->n_points = n; c->n_live = n; c->n_cells = 0;
     c->grid.n_points = n;
     if (n == 0) {
@@ -700,6 +702,7 @@ int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_delete
     if (n_deleted) *n_deleted = 0;
     if (nb == 0 || c->n_points == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    c->hint_valid = false;
     int total = 0;
     for (int b0 = 0; b0 < nb; b0 += 64) {
         const int nbb = nb - b0 < 64 ? nb - b0 : 64;
@@ -844,7 +847,7 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
 // ---- scan + measurement ----------------------------------------------------------------------
 static int scan_reset(lio_ctx* c, int n) {
     c->nq = n;
-    c->have_scan = true; c->have_search = false; c->have_pass = false; c->last_m = 0;
+    c->have_scan = true; c->have_search = false; c->have_pass = false; c->last_m = 0; c->hint_valid = false;
     if (n > 0) HIPCHK(c, hipMemsetAsync(c->d_sel, 1, (size_t)n, c->stream));     // laserMapping.cpp:2131
     return LIO_OK;
 }
@@ -879,9 +882,9 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
 
     if (do_search) {
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
-        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_unres, c->have_search);
+        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_unres, c->hint_valid);
         if (rc != LIO_OK) return rc;
-        c->have_search = true;
+        c->have_search = true; c->hint_valid = true;
     }
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;

@@ -376,3 +376,30 @@ def test_fov_segment_sliding_cube(gpu_capi, oracle, small_case):
     assert moved >= 3
     assert bits_equal(key(ctx.map_flatten()), key(om.flatten()))
     ctx.close()
+
+
+def test_search_after_map_mutation_ignores_stale_bound(gpu_capi, oracle, small_case):
+    """The repeated-search bound (previous neighbours) must be dropped when the map changes between two
+    searches of the same scan: delete a slab that holds many of the previous neighbours, search again."""
+    w, sc, st = small_case["world"], small_case["scan"], small_case["state14"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=20_000, max_map_points=400_000)
+    ctx.map_build(w.points)
+    om = oracle.OracleMap(0.2); om.build(w.points)
+    ctx.scan_set(sc.body)
+    arr = oracle.ScanArrays(len(sc.body))
+    oracle.h_share_model(om, st, sc.body, arr, True, False)
+    ctx.measure(st, True, False)
+    box = np.array([[-6.0, -8.0, -1.0, 9.0, 4.0, 3.0]], np.float32)       # around the sensor: most neighbours live here
+    assert ctx.map_delete_boxes(box) == om.delete_boxes(box) > 1000
+    valid, hx, h, m, rm = oracle.h_share_model(om, st, sc.body, arr, True, False)
+    g = ctx.measure(st, True, False)
+    assert g["m"] == m
+    nx, nd, nc = ctx.neighbors()
+    assert np.array_equal(nc, arr.nbr_cnt) and bits_equal(nd, arr.nbr_d) and bits_equal(nx, arr.nbr_xyz)
+    # ... and with an unchanged map the bounded search gives the same bits as the unbounded one
+    st2 = st.copy(); st2[:3] += [0.02, -0.015, 0.004]
+    oracle.h_share_model(om, st2, sc.body, arr, True, False)
+    ctx.measure(st2, True, False)
+    nx, nd, nc = ctx.neighbors()
+    assert np.array_equal(nc, arr.nbr_cnt) and bits_equal(nd, arr.nbr_d) and bits_equal(nx, arr.nbr_xyz)
+    ctx.close()
