@@ -43,6 +43,10 @@ struct lio_ctx {
     unsigned long long* d_cand = nullptr;
     float* d_boxes = nullptr;                  // up to 64 boxes
     uint32_t n_points = 0, n_live = 0, n_cells = 0;
+    uint32_t n_sorted = 0;                     // d_pts[0..n_sorted) is the Morton-sorted, indexed prefix
+    uint64_t* d_new_keys = nullptr;            // sorted keys / indices of the appended points (merge_rebuild)
+    uint32_t* d_new_vals = nullptr;
+    size_t cap_new = 0;
     bool have_map = false;
 
     // local-map cube of lasermap_fov_segment (laserMapping.cpp:1132-1133)
@@ -167,29 +171,20 @@ int upload_points(lio_ctx* c, const float* pts, size_t n, int stride_bytes, floa
     return LIO_OK;
 }
 
-// (re)build the index from n points at src (device, float4, must not alias c->d_pts)
-int build_index(lio_ctx* c, const float4* src, uint32_t n) {
+// Second half of every (re)build: c->d_pts[0..n) is Morton-sorted and live, c->d_mkeys[0..n) holds the
+// keys.  Run-length encode the cells, fill the level-0 hash table, derive the coarser tree levels.
+int finish_index(lio_ctx* c, uint32_t n) {
     hipStream_t s = c->stream;
-    c->have_map = false;
-    c->hint_valid = false;                     // neighbours of an older map state no longer bound a search
-    c->n_points = n; c->n_live = n; c->n_cells = 0;
+    c->n_points = n; c->n_live = n; c->n_sorted = n; c->n_cells = 0;
     c->grid.n_points = n;
-    if (n == 0) {
-        // empty map: a one-slot-masked empty table keeps the kernels well defined
-        HIPCHK(c, hipMemsetAsync(c->d_table, 0xFF, c->table_slots * sizeof(HashEntry), s));
-        c->grid.table_mask = (uint32_t)(c->table_slots - 1);
-        HIPCHK(c, hipStreamSynchronize(s));
-        c->levels = TreeLevels{};
-        c->have_map = true;
-        return LIO_OK;
-    }
-    HIPCHK(c, launch_point_keys(src, n, c->grid, c->d_mkeys_tmp, c->d_vals_tmp, s));
-    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_mkeys_tmp, c->d_mkeys, c->d_vals_tmp, c->d_vals, n, s));
-    HIPCHK(c, launch_gather_points(src, c->d_vals, n, c->d_pts, s));
     HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_mkeys, n, c->d_cell_keys, c->d_cell_counts,
                                     c->d_counters + 4, s));
+    // first / last Morton key: the top level is the lowest one at which a single cell holds every point
+    uint64_t kfirst = 0, klast = 0;
     uint32_t n_cells = 0;
     HIPCHK(c, hipMemcpyAsync(&n_cells, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&kfirst, c->d_mkeys, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&klast, c->d_mkeys + (n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_cell_counts, c->d_cell_starts, n_cells, s));
     // table: power of two >= 4 x cells (load factor <= 0.25 keeps unsuccessful probes short)
@@ -204,16 +199,11 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
     HIPCHK(c, hipMemsetAsync(c->d_table, 0xFF, slots * sizeof(HashEntry), s));
     HIPCHK(c, launch_table_insert(c->d_cell_keys, c->d_cell_starts, c->d_cell_counts, n_cells, c->d_table,
                                   (uint32_t)(slots - 1), s));
-    HIPCHK(c, hipStreamSynchronize(s));
     c->grid.table_mask = (uint32_t)(slots - 1);
     c->n_cells = n_cells;
 
-    // ---- coarser levels of the hashed 64-ary tree (exact fallback of the k-NN) ---------------------
-    // top level = lowest level at which one cell holds every point (first vs last Morton key)
-    uint64_t kfirst = 0, klast = 0;
-    HIPCHK(c, hipMemcpyAsync(&kfirst, c->d_mkeys, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&klast, c->d_mkeys + (n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    // ---- coarser levels of the hashed 64-ary tree (exact fallback of the k-NN): level L+1 is a
+    // reduce-by-key of level L (keys >> 6, counts summed) -- the point array is not touched again
     TreeLevels lv{};
     const uint64_t diff = kfirst ^ klast;
     int top = 0;
@@ -224,13 +214,16 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
         lv.top_cx = compact21(prefix >> 2); lv.top_cy = compact21(prefix >> 1); lv.top_cz = compact21(prefix);
     }
     size_t used = 0;
+    uint32_t n_prev = n_cells;
+    // ping-pong between the cell arrays and the (now free) build scratch
+    uint64_t* kin = c->d_cell_keys; uint32_t* cin = c->d_cell_counts;
+    uint64_t* kout = c->d_mkeys_tmp; uint32_t* cout = c->d_vals_tmp;
     for (int L = 1; L < top; ++L) {
-        HIPCHK(c, run_length_encode_shifted(c->d_temp, c->temp_bytes, c->d_mkeys, n, 6 * L, c->d_cell_keys,
-                                            c->d_cell_counts, c->d_counters + 4, s));
+        HIPCHK(c, coarsen_level(c->d_temp, c->temp_bytes, kin, cin, n_prev, kout, cout, c->d_counters + 4, s));
         uint32_t n_l = 0;
         HIPCHK(c, hipMemcpyAsync(&n_l, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
-        HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_cell_counts, c->d_cell_starts, n_l, s));
+        HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, cout, c->d_cell_starts, n_l, s));
         size_t sl = 64;
         while (sl < (size_t)n_l * 4) sl <<= 1;
         if (used + sl > c->ltable_slots) {
@@ -245,15 +238,79 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
             c->d_ltable = nt; c->ltable_slots = cap;
         }
         HIPCHK(c, hipMemsetAsync(c->d_ltable + used, 0xFF, sl * sizeof(HashEntry), s));
-        HIPCHK(c, launch_table_insert(c->d_cell_keys, c->d_cell_starts, c->d_cell_counts, n_l, c->d_ltable + used,
-                                      (uint32_t)(sl - 1), s));
+        HIPCHK(c, launch_table_insert(kout, c->d_cell_starts, cout, n_l, c->d_ltable + used, (uint32_t)(sl - 1), s));
         lv.off[L] = (uint32_t)used; lv.mask[L] = (uint32_t)(sl - 1);
         used += sl;
+        n_prev = n_l;
+        // next level reads what this one wrote; alternate between two scratch pairs
+        if (kout == c->d_mkeys_tmp) { kin = c->d_mkeys_tmp; cin = c->d_vals_tmp; kout = c->d_cell_keys; cout = c->d_cell_counts; }
+        else { kin = c->d_cell_keys; cin = c->d_cell_counts; kout = c->d_mkeys_tmp; cout = c->d_vals_tmp; }
     }
     HIPCHK(c, hipStreamSynchronize(s));
     c->levels = lv;
     c->have_map = true;
     return LIO_OK;
+}
+
+// (re)build the index from n points at src (device, float4, must not alias c->d_pts): full sort
+int build_index(lio_ctx* c, const float4* src, uint32_t n) {
+    hipStream_t s = c->stream;
+    c->have_map = false;
+    c->hint_valid = false;                     // neighbours of an older map state no longer bound a search
+    if (n == 0) {
+        c->n_points = 0; c->n_live = 0; c->n_sorted = 0; c->n_cells = 0;
+        c->grid.n_points = 0;
+        // empty map: an all-empty table keeps the kernels well defined
+        HIPCHK(c, hipMemsetAsync(c->d_table, 0xFF, c->table_slots * sizeof(HashEntry), s));
+        c->grid.table_mask = (uint32_t)(c->table_slots - 1);
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->levels = TreeLevels{};
+        c->have_map = true;
+        return LIO_OK;
+    }
+    HIPCHK(c, launch_point_keys(src, n, c->grid, c->d_mkeys_tmp, c->d_vals_tmp, s));
+    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_mkeys_tmp, c->d_mkeys, c->d_vals_tmp, c->d_vals, n, s));
+    HIPCHK(c, launch_gather_points(src, c->d_vals, n, c->d_pts, s));
+    return finish_index(c, n);
+}
+
+// Rebuild after Add_Points / tomb-stoning: c->d_pts = [sorted prefix of n_sorted points, possibly with
+// tomb-stones | appended points in insertion order].  Only the appended points are sorted; they are
+// MERGED into the sorted prefix (stable: old before new inside a cell, exactly what a full stable
+// sort would give), tomb-stones are dropped on the way, then the tables are rebuilt.
+int merge_rebuild(lio_ctx* c) {
+    hipStream_t s = c->stream;
+    c->have_map = false;
+    c->hint_valid = false;
+    const uint32_t n_old = c->n_sorted, n_all = c->n_points, n_new = n_all - n_old;
+    if (n_all == 0) return build_index(c, c->d_pts_tmp, 0);
+    if (n_new > 0) {
+        if ((size_t)n_new > c->cap_new) {
+            if (c->d_new_keys) (void)hipFree(c->d_new_keys);
+            if (c->d_new_vals) (void)hipFree(c->d_new_vals);
+            c->d_new_keys = nullptr; c->d_new_vals = nullptr; c->cap_new = 0;
+            size_t cap = 65536;
+            while (cap < n_new) cap <<= 1;
+            HIPCHK(c, hipMalloc((void**)&c->d_new_keys, cap * sizeof(uint64_t)));
+            HIPCHK(c, hipMalloc((void**)&c->d_new_vals, cap * sizeof(uint32_t)));
+            c->cap_new = cap;
+        }
+        HIPCHK(c, launch_point_keys(c->d_pts + n_old, n_new, c->grid, c->d_mkeys_tmp, c->d_vals_tmp, s, n_old));
+        HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_mkeys_tmp, c->d_new_keys, c->d_vals_tmp, c->d_new_vals, n_new, s));
+    }
+    // merged (key, index) sequence over [old | new]
+    HIPCHK(c, merge_pairs_identity(c->d_temp, c->temp_bytes, c->d_mkeys, c->d_new_keys, c->d_mkeys_tmp, c->d_new_vals,
+                                   c->d_vals_tmp, n_old, n_new, s));
+    // drop tomb-stones: final keys -> d_mkeys, gather indices -> d_vals
+    HIPCHK(c, select_live_pairs(c->d_temp, c->temp_bytes, c->d_mkeys_tmp, c->d_vals_tmp, c->d_pts, c->d_mkeys, c->d_vals,
+                                c->d_counters + 3, n_all, s));
+    uint32_t live = 0;
+    HIPCHK(c, hipMemcpyAsync(&live, c->d_counters + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (live == 0) return build_index(c, c->d_pts_tmp, 0);
+    HIPCHK(c, launch_gather_points(c->d_pts, c->d_vals, live, c->d_pts_tmp, s));
+    std::swap(c->d_pts, c->d_pts_tmp);             // the gathered array becomes the map
+    return finish_index(c, live);
 }
 
 // resolve every recorded pair (needs the stream drained) and recycle the pool
@@ -375,6 +432,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     size_t t2 = rle_temp_bytes(nm); if (t2 > tb) tb = t2;
     t2 = scan_temp_bytes(nm); if (t2 > tb) tb = t2;
     t2 = select_temp_bytes(nm); if (t2 > tb) tb = t2;
+    t2 = merge_temp_bytes(nm, nm); if (t2 > tb) tb = t2;
     c->temp_bytes = tb + 256;
     CREATE_CHK(hipMalloc(&c->d_temp, c->temp_bytes));
     c->table_slots = 1024;
@@ -385,6 +443,9 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_cand, sizeof(unsigned long long)));
     CREATE_CHK(hipMemset(c->d_cand, 0, sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc((void**)&c->d_boxes, 64 * 6 * sizeof(float)));
+    c->cap_new = 65536;
+    CREATE_CHK(hipMalloc((void**)&c->d_new_keys, c->cap_new * sizeof(uint64_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_new_vals, c->cap_new * sizeof(uint32_t)));
 
     const size_t nq = (size_t)cfg->max_scan_points;
     c->cap_q = cfg->max_scan_points;
@@ -416,7 +477,7 @@ void lio_destroy(lio_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
-                   c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_ltable, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
+                   c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_ltable, c->d_new_keys, c->d_new_vals, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
                    c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
                    c->d_partials, c->d_gpartials, c->d_tickets, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
@@ -526,15 +587,8 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
     return LIO_OK;
 }
 
-// drop tomb-stones, re-sort, re-hash
-static int rebuild_from_stored(lio_ctx* c) {
-    hipStream_t s = c->stream;
-    HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_pts_tmp, c->d_counters + 3, c->n_points, s));
-    uint32_t live = 0;
-    HIPCHK(c, hipMemcpyAsync(&live, c->d_counters + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    return build_index(c, c->d_pts_tmp, live);
-}
+// drop tomb-stones, merge the appended points into the sorted prefix, re-hash
+static int rebuild_from_stored(lio_ctx* c) { return merge_rebuild(c); }
 
 // Add_Points (ikd_Tree.cpp:414-489).  Returns through *n_added what the reference returns: the number
 // of down-sampled inserts that changed the tree (tmp_counter), 0 when downsample_on is false.

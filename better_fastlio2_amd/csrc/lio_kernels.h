@@ -74,8 +74,9 @@ int residual_blocks(int nq);
 hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s);
 
 // ---- map construction / mutation ----------------------------------------------------------------
+// mkeys[i] = Morton key of pts[i], vals[i] = base_index + i
 hipError_t launch_point_keys(const float4* pts, uint32_t n, Grid grid, uint64_t* mkeys, uint32_t* vals,
-                             hipStream_t s);
+                             hipStream_t s, uint32_t base_index = 0);
 hipError_t launch_gather_points(const float4* src, const uint32_t* vals, uint32_t n, float4* dst,
                                 hipStream_t s);
 hipError_t launch_table_insert(const uint64_t* cell_mkeys, const uint32_t* cell_start,
@@ -109,6 +110,16 @@ size_t select_temp_bytes(size_t n);
 hipError_t select_live_points(void* temp, size_t temp_bytes, const float4* src, float4* dst,
                               uint32_t* n_out, size_t n, hipStream_t s);
 
+hipError_t coarsen_level(void* temp, size_t temp_bytes, const uint64_t* keys_in, const uint32_t* counts_in, size_t n,
+                         uint64_t* keys_out, uint32_t* counts_out, uint32_t* n_out, hipStream_t s);
+size_t merge_temp_bytes(size_t n1, size_t n2);
+hipError_t merge_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* k1, const uint64_t* k2, uint64_t* kout,
+                               const uint32_t* v1, const uint32_t* v2, uint32_t* vout, size_t n1, size_t n2, hipStream_t s);
+hipError_t select_live_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, const uint32_t* vals_in,
+                             const float4* pts, uint64_t* keys_out, uint32_t* vals_out, uint32_t* n_out, size_t n,
+                             hipStream_t s);
+hipError_t merge_pairs_identity(void* temp, size_t temp_bytes, const uint64_t* k1, const uint64_t* k2, uint64_t* kout,
+                                const uint32_t* v2, uint32_t* vout, size_t n1, size_t n2, hipStream_t s);
 hipError_t select_points_by_class(void* temp, size_t temp_bytes, const float4* src, const uint8_t* cls, uint8_t want,
                                   float4* dst, uint32_t* n_out, size_t n, hipStream_t s);
 

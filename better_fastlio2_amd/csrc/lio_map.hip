@@ -10,14 +10,14 @@
 namespace lio {
 
 __global__ __launch_bounds__(256) void point_keys_kernel(const float4* pts, uint32_t n, Grid grid,
-                                                         uint64_t* mkeys, uint32_t* vals) {
+                                                         uint64_t* mkeys, uint32_t* vals, uint32_t base_index) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = pts[i];
         const uint32_t cx = (uint32_t)cell_coord(p.x, grid.inv_cell);
         const uint32_t cy = (uint32_t)cell_coord(p.y, grid.inv_cell);
         const uint32_t cz = (uint32_t)cell_coord(p.z, grid.inv_cell);
         mkeys[i] = morton3(cx, cy, cz);
-        vals[i] = i;
+        vals[i] = base_index + i;
     }
 }
 
@@ -99,9 +99,10 @@ static inline dim3 grid_for(uint32_t n) {
     return dim3(b);
 }
 
-hipError_t launch_point_keys(const float4* pts, uint32_t n, Grid grid, uint64_t* mkeys, uint32_t* vals, hipStream_t s) {
+hipError_t launch_point_keys(const float4* pts, uint32_t n, Grid grid, uint64_t* mkeys, uint32_t* vals, hipStream_t s,
+                             uint32_t base_index) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(point_keys_kernel, grid_for(n), dim3(256), 0, s, pts, n, grid, mkeys, vals);
+    hipLaunchKernelGGL(point_keys_kernel, grid_for(n), dim3(256), 0, s, pts, n, grid, mkeys, vals, base_index);
     return hipGetLastError();
 }
 hipError_t launch_gather_points(const float4* src, const uint32_t* vals, uint32_t n, float4* dst, hipStream_t s) {

@@ -68,6 +68,66 @@ hipError_t select_live_points(void* temp, size_t temp_bytes, const float4* src, 
     return rocprim::select(temp, temp_bytes, src, dst, n_out, n, LivePoint(), s);
 }
 
+// next coarser tree level from the current one: keys >> 6, counts summed per run
+hipError_t coarsen_level(void* temp, size_t temp_bytes, const uint64_t* keys_in, const uint32_t* counts_in, size_t n,
+                         uint64_t* keys_out, uint32_t* counts_out, uint32_t* n_out, hipStream_t s) {
+    auto kin = rocprim::make_transform_iterator(keys_in, ShiftRight{6});
+    size_t need = 0;
+    hipError_t e = rocprim::reduce_by_key(nullptr, need, kin, counts_in, n, keys_out, counts_out, n_out,
+                                          rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), s);
+    if (e != hipSuccess) return e;
+    if (need > temp_bytes) return hipErrorOutOfMemory;
+    return rocprim::reduce_by_key(temp, temp_bytes, kin, counts_in, n, keys_out, counts_out, n_out,
+                                  rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), s);
+}
+
+// merge of two key-sorted (key, value) sequences (stable: ties take the first sequence first)
+size_t merge_temp_bytes(size_t n1, size_t n2) {
+    size_t bytes = 0;
+    (void)rocprim::merge(nullptr, bytes, (const uint64_t*)nullptr, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n1, n2,
+                         rocprim::less<uint64_t>(), (hipStream_t)0);
+    return bytes;
+}
+hipError_t merge_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* k1, const uint64_t* k2, uint64_t* kout,
+                               const uint32_t* v1, const uint32_t* v2, uint32_t* vout, size_t n1, size_t n2, hipStream_t s) {
+    size_t need = 0;
+    hipError_t e = rocprim::merge(nullptr, need, k1, k2, kout, v1, v2, vout, n1, n2, rocprim::less<uint64_t>(), s);
+    if (e != hipSuccess) return e;
+    if (need > temp_bytes) return hipErrorOutOfMemory;
+    return rocprim::merge(temp, temp_bytes, k1, k2, kout, v1, v2, vout, n1, n2, rocprim::less<uint64_t>(), s);
+}
+
+// (key, index) pairs whose point is live (pts[index].w == 0), order-preserving
+struct LiveIndex {
+    const float4* pts;
+    __host__ __device__ bool operator()(uint32_t i) const { return pts[i].w == 0.0f; }
+};
+hipError_t select_live_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, const uint32_t* vals_in,
+                             const float4* pts, uint64_t* keys_out, uint32_t* vals_out, uint32_t* n_out, size_t n,
+                             hipStream_t s) {
+    auto flags = rocprim::make_transform_iterator(vals_in, LiveIndex{pts});
+    size_t need = 0, need2 = 0;
+    hipError_t e = rocprim::select(nullptr, need, keys_in, flags, keys_out, n_out, n, s);
+    if (e != hipSuccess) return e;
+    e = rocprim::select(nullptr, need2, vals_in, flags, vals_out, n_out, n, s);
+    if (e != hipSuccess) return e;
+    if (need > temp_bytes || need2 > temp_bytes) return hipErrorOutOfMemory;
+    e = rocprim::select(temp, temp_bytes, keys_in, flags, keys_out, n_out, n, s);
+    if (e != hipSuccess) return e;
+    return rocprim::select(temp, temp_bytes, vals_in, flags, vals_out, n_out, n, s);
+}
+// merge with an implicit identity value sequence 0..n1-1 for the first input
+hipError_t merge_pairs_identity(void* temp, size_t temp_bytes, const uint64_t* k1, const uint64_t* k2, uint64_t* kout,
+                                const uint32_t* v2, uint32_t* vout, size_t n1, size_t n2, hipStream_t s) {
+    rocprim::counting_iterator<uint32_t> v1(0u);
+    size_t need = 0;
+    hipError_t e = rocprim::merge(nullptr, need, k1, k2, kout, v1, v2, vout, n1, n2, rocprim::less<uint64_t>(), s);
+    if (e != hipSuccess) return e;
+    if (need > temp_bytes) return hipErrorOutOfMemory;
+    return rocprim::merge(temp, temp_bytes, k1, k2, kout, v1, v2, vout, n1, n2, rocprim::less<uint64_t>(), s);
+}
+
 struct ClassIs {
     uint8_t want;
     __host__ __device__ bool operator()(uint8_t c) const { return c == want; }
