@@ -57,7 +57,7 @@ EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_stream", "lio_synchronize",
     "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_fov_segment", "lio_map_reconstruct",
     "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_get_info", "lio_map_nearest_search",
-    "lio_scan_set", "lio_scan_set_device", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
+    "lio_scan_set", "lio_scan_set_device", "lio_scan_undistort", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
     "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_state_boxplus",
@@ -123,6 +123,9 @@ def load(build_if_missing: bool = True):
     L.lio_map_nearest_search.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
     L.lio_scan_set.argtypes = [_vp, _vp, C.c_int, C.c_int]
     L.lio_scan_set_device.argtypes = [_vp, _vp, C.c_int]
+    L.lio_scan_undistort.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]
+    L.lio_scan_voxel_filter.argtypes = [_vp, C.c_float, C.POINTER(C.c_int)]
+    L.lio_scan_get_cloud.argtypes = [_vp, C.c_int, _vp, C.c_int, C.POINTER(C.c_int)]
     L.lio_measure.argtypes = [_vp, _vp, C.c_int, C.c_int, C.POINTER(lio_out)]
     L.lio_measure_rows.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int]
     L.lio_get_neighbors.argtypes = [_vp, _vp, _vp, _vp]
@@ -295,6 +298,30 @@ class LioContext:
     def scan_set(self, body):
         b = _points(body)
         self._chk(self.L.lio_scan_set(self.h, _ptr(b), len(b), _stride(b)), "lio_scan_set")
+
+    def scan_undistort(self, raw_xyzt, imu_poses=None, end_state14=None):
+        """UndistortPcl's point side: raw_xyzt [n, 4] = x, y, z, time offset in ms; imu_poses [K, 22]
+        (offset_time, acc3, gyr3, vel3, pos3, rot9); end_state14 = propagated state at scan end."""
+        r = np.ascontiguousarray(raw_xyzt, np.float32)
+        assert r.ndim == 2 and r.shape[1] == 4
+        if imu_poses is None:
+            self._chk(self.L.lio_scan_undistort(self.h, _ptr(r), len(r), 16, 12, None, 0, None), "lio_scan_undistort")
+            return
+        p = np.ascontiguousarray(imu_poses, np.float64).reshape(-1, 22)
+        e = np.ascontiguousarray(end_state14, np.float64)
+        self._chk(self.L.lio_scan_undistort(self.h, _ptr(r), len(r), 16, 12, _ptr(p), len(p), _ptr(e)), "lio_scan_undistort")
+
+    def scan_voxel_filter(self, leaf_size: float) -> int:
+        n = C.c_int(0)
+        self._chk(self.L.lio_scan_voxel_filter(self.h, float(leaf_size), C.byref(n)), "lio_scan_voxel_filter")
+        return n.value
+
+    def scan_cloud(self, which: int) -> np.ndarray:
+        n = C.c_int(0)
+        self._chk(self.L.lio_scan_get_cloud(self.h, which, None, 0, C.byref(n)), "lio_scan_get_cloud")
+        out = np.zeros((max(n.value, 1), 3), np.float32)
+        self._chk(self.L.lio_scan_get_cloud(self.h, which, _ptr(out), n.value, C.byref(n)), "lio_scan_get_cloud")
+        return out[:n.value]
 
     def scan_set_device(self, d_ptr: int, n: int):
         self._chk(self.L.lio_scan_set_device(self.h, _vp(d_ptr), n), "lio_scan_set_device")

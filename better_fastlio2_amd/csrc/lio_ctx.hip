@@ -14,6 +14,7 @@
 #include "lio_esekf.hpp"
 #include "lio_kernels.h"
 #include "lio_mapadd.h"
+#include "lio_scanprep.h"
 
 using namespace lio;
 
@@ -81,6 +82,16 @@ struct lio_ctx {
     float4 *d_qs_world = nullptr, *d_qs_nbr = nullptr;
     uint8_t* d_qs_cnt = nullptr;
     uint8_t* d_qs_unres = nullptr;
+
+    // raw-scan preparation (lio_scan_undistort / lio_scan_voxel_filter)
+    size_t cap_raw = 0;
+    int n_raw = 0;
+    bool have_raw = false;
+    float4 *d_raw = nullptr, *d_undist = nullptr, *d_leafpts = nullptr;
+    uint64_t *d_raw_keys = nullptr, *d_raw_keys2 = nullptr, *d_leaf_keys = nullptr;
+    uint32_t *d_raw_order = nullptr, *d_raw_order2 = nullptr, *d_leaf_count = nullptr, *d_leaf_start = nullptr;
+    double* d_imu_poses = nullptr;             // up to 512 Pose6D records (22 doubles each)
+    int* d_minmax = nullptr;
 
     // batch buffers of lio_map_add
     size_t cap_add = 0;
@@ -480,6 +491,8 @@ void lio_destroy(lio_ctx* c) {
                    c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_ltable, c->d_new_keys, c->d_new_vals, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
                    c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
                    c->d_partials, c->d_gpartials, c->d_tickets, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
+                   c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
+                   c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_minmax,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
                    c->d_add_order, c->d_add_order2, c->d_add_gcount, c->d_add_gstart};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -921,6 +934,138 @@ int lio_scan_set_device(lio_ctx* c, const void* d_body_f4, int n) {
     return scan_reset(c, n);
 }
 int lio_scan_size(lio_ctx* c) { return c ? c->nq : 0; }
+
+// ---- raw-scan preparation: UndistortPcl's compensation + pcl::VoxelGrid ----
+static int ensure_raw_buffers(lio_ctx* c, size_t n) {
+    if (!c->d_imu_poses) HIPCHK(c, hipMalloc((void**)&c->d_imu_poses, 512 * 22 * sizeof(double)));
+    if (!c->d_minmax) HIPCHK(c, hipMalloc((void**)&c->d_minmax, 6 * sizeof(int)));
+    if (n <= c->cap_raw) return LIO_OK;
+    void* old[] = {c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
+                   c->d_raw_order2, c->d_leaf_count, c->d_leaf_start};
+    for (void* p : old) if (p) (void)hipFree(p);
+    c->d_raw = c->d_undist = c->d_leafpts = nullptr; c->d_raw_keys = c->d_raw_keys2 = c->d_leaf_keys = nullptr;
+    c->d_raw_order = c->d_raw_order2 = c->d_leaf_count = c->d_leaf_start = nullptr; c->cap_raw = 0;
+    HIPCHK(c, hipMalloc((void**)&c->d_raw, n * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_undist, n * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_leafpts, n * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_raw_keys, n * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_raw_keys2, n * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_leaf_keys, n * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_raw_order, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_raw_order2, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_leaf_count, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_leaf_start, n * sizeof(uint32_t)));
+    c->cap_raw = n;
+    return LIO_OK;
+}
+
+// ImuProcess::UndistortPcl, point side (src/IMU_Processing.hpp:250-251, 334-386): sort the raw scan by its
+// per-point time offset, then compensate every point to the scan-end LiDAR frame from the forward-propagated
+// IMU poses (IMUpose, :258/:322) and the propagated end state.  n_poses == 0: upload only (no sort, no motion).
+int lio_scan_undistort(lio_ctx* c, const float* raw_pts, int n, int stride_bytes, int time_offset_bytes,
+                       const lio_pose6d* imu_poses, int n_poses, const double end_state14[14]) {
+    if (!c || n < 0 || (n > 0 && !raw_pts) || stride_bytes < 12 || n_poses < 0 || n_poses > 512 ||
+        (n_poses > 0 && (!imu_poses || !end_state14 || time_offset_bytes < 12 || time_offset_bytes + 4 > stride_bytes)))
+        return LIO_ERR_INVALID_ARG;
+    if ((size_t)n > c->temp_bytes / 16) return c->fail(LIO_ERR_CAPACITY, "lio_scan_undistort", "raw scan larger than the sort workspace");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc = ensure_raw_buffers(c, (size_t)(n > 0 ? n : 1));
+    if (rc != LIO_OK) return rc;
+    c->n_raw = n; c->have_raw = true;
+    if (n == 0) return LIO_OK;
+    rc = ensure_stage(c, (size_t)n);
+    if (rc != LIO_OK) return rc;
+    const char* src = reinterpret_cast<const char*>(raw_pts);
+    for (int i = 0; i < n; ++i) {
+        const char* rec = src + (size_t)i * (size_t)stride_bytes;
+        const float* p = reinterpret_cast<const float*>(rec);
+        const float t = n_poses > 0 ? *reinterpret_cast<const float*>(rec + time_offset_bytes) : 0.0f;
+        c->h_stage[i] = make_float4(p[0], p[1], p[2], t);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_raw, c->h_stage, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s));
+    if (n_poses == 0) {
+        HIPCHK(c, hipMemcpyAsync(c->d_undist, c->d_raw, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        return LIO_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_imu_poses, imu_poses, (size_t)n_poses * sizeof(lio_pose6d), hipMemcpyHostToDevice, s));
+    // sort(pcl_out.points.begin(), pcl_out.points.end(), time_list)   (:251; stable here)
+    HIPCHK(c, launch_time_keys(c->d_raw, n, c->d_raw_keys, c->d_raw_order, s));
+    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s));
+    HIPCHK(c, launch_gather_points(c->d_raw, c->d_raw_order2, (uint32_t)n, c->d_leafpts, s));
+    Pose14 end;
+    for (int i = 0; i < 14; ++i) end.v[i] = end_state14[i];
+    HIPCHK(c, launch_undistort(c->d_leafpts, n, c->d_imu_poses, n_poses, end, c->d_undist, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return LIO_OK;
+}
+
+// downSizeFilterSurf.setInputCloud(feats_undistort); downSizeFilterSurf.filter(*feats_down_body)
+// (src/laserMapping.cpp:2322-2323): pcl::VoxelGrid on the cloud left by lio_scan_undistort; the centroids
+// become the current scan (as lio_scan_set would).
+int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
+    if (!c || !(leaf_size > 0.0f)) return LIO_ERR_INVALID_ARG;
+    if (n_out) *n_out = 0;
+    if (!c->have_raw) return c->fail(LIO_ERR_NO_SCAN, "lio_scan_voxel_filter", "no raw scan (lio_scan_undistort first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int n = c->n_raw;
+    if (n == 0) return scan_reset(c, 0);
+    // getMinMax3D
+    const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    int mm[6];
+    HIPCHK(c, hipMemcpyAsync(c->d_minmax, init, sizeof(init), hipMemcpyHostToDevice, s));
+    HIPCHK(c, launch_minmax(c->d_undist, n, c->d_minmax, s));
+    HIPCHK(c, hipMemcpyAsync(mm, c->d_minmax, sizeof(mm), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (mm[0] == 0x7fffffff) return scan_reset(c, 0);                 // no finite point
+    VoxelGridParams g{};
+    g.inv_leaf = 1.0f / leaf_size;                                    // inverse_leaf_size_ = 1 / leaf_size_
+    long long div[3];
+    for (int a = 0; a < 3; ++a) {
+        const float lo = minmax_decode(mm[a]), hi = minmax_decode(mm[3 + a]);
+        g.min_b[a] = (int)std::floor(lo * g.inv_leaf);
+        const int max_b = (int)std::floor(hi * g.inv_leaf);
+        div[a] = (long long)max_b - g.min_b[a] + 1;
+    }
+    if (div[0] * div[1] * div[2] > (long long)0x7fffffff)
+        return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "leaf size too small for the extent of the scan (index overflow, as in PCL)");
+    g.divb_mul[0] = 1; g.divb_mul[1] = (int)div[0]; g.divb_mul[2] = (int)(div[0] * div[1]);
+    HIPCHK(c, launch_voxel_index(c->d_undist, n, g, c->d_raw_keys, c->d_raw_order, s));
+    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s));
+    HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_raw_keys2, (size_t)n, c->d_leaf_keys, c->d_leaf_count, c->d_counters + 4, s));
+    uint32_t n_leaves = 0;
+    uint64_t last_key = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_leaves, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&last_key, c->d_raw_keys2 + (n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_leaf_count, c->d_leaf_start, n_leaves, s));
+    const uint32_t n_real = last_key == ~0ull ? n_leaves - 1 : n_leaves;     // the run of dropped (non-finite) points is last
+    if ((int)n_real > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "down-sampled scan exceeds max_scan_points");
+    HIPCHK(c, launch_centroids(c->d_undist, c->d_raw_order2, c->d_leaf_keys, c->d_leaf_start, c->d_leaf_count, n_leaves, c->d_leafpts, s));
+    if (n_real > 0) HIPCHK(c, hipMemcpyAsync(c->d_body, c->d_leafpts, (size_t)n_real * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    if (n_out) *n_out = (int)n_real;
+    return scan_reset(c, (int)n_real);
+}
+
+// which = 0: feats_undistort (time-sorted, compensated); 1: the current scan (feats_down_body)
+int lio_scan_get_cloud(lio_ctx* c, int which, float* out_xyz, int cap, int* n) {
+    if (!c || (which != 0 && which != 1) || cap < 0 || (cap > 0 && !out_xyz)) return LIO_ERR_INVALID_ARG;
+    const float4* src = which == 0 ? c->d_undist : c->d_body;
+    const int cnt = which == 0 ? (c->have_raw ? c->n_raw : 0) : (c->have_scan ? c->nq : 0);
+    if (n) *n = cnt;
+    const int m = cnt < cap ? cnt : cap;
+    if (m <= 0) return LIO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, (size_t)m * 3 * sizeof(float));
+    if (rc != LIO_OK) return rc;
+    HIPCHK(c, launch_pack_xyz(src, (uint32_t)m, (float*)c->d_scratch, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(out_xyz, c->h_scratch, (size_t)m * 3 * sizeof(float));
+    return LIO_OK;
+}
 
 int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrinsic_est_en, lio_out* out) {
     if (!c || !state14 || !out) return LIO_ERR_INVALID_ARG;

@@ -145,6 +145,28 @@ int  lio_map_nearest_search(lio_ctx* ctx, const float* q_xyz, int n, int stride_
  * point_selected_surf to all-true (laserMapping.cpp:2131).                                         */
 int  lio_scan_set(lio_ctx* ctx, const float* body_pts, int n, int stride_bytes);
 int  lio_scan_set_device(lio_ctx* ctx, const void* d_body_f4, int n);
+/* ---- raw-scan preparation (the step before the path) ---------------------- */
+/* Pose6D (msg/Pose6D.msg, include/common_lib.h:446-460): one forward-propagated IMU pose of IMUpose.      */
+typedef struct lio_pose6d {
+    double offset_time;      /* seconds after the first LiDAR point                                          */
+    double acc[3], gyr[3];   /* world-frame acceleration, unbiased body angular rate                          */
+    double vel[3], pos[3];   /* world-frame velocity / position                                              */
+    double rot[9];           /* world rotation, row-major                                                    */
+} lio_pose6d;
+/* ImuProcess::UndistortPcl, point side (src/IMU_Processing.hpp:250-251, 334-386): time-sorts the raw scan
+ * (the per-point offset in MILLISECONDS is the float at time_offset_bytes inside each record -- `curvature`
+ * of pcl::PointXYZINormal, byte 36) and compensates every point to the scan-end LiDAR frame from the IMU
+ * poses and the propagated end state (pos, rot, offset_R_L_I, offset_T_L_I as in state14).  The result
+ * (feats_undistort) stays in device memory.  n_poses == 0: upload only, no sort, no compensation.          */
+int  lio_scan_undistort(lio_ctx* ctx, const float* raw_pts, int n, int stride_bytes, int time_offset_bytes,
+                        const lio_pose6d* imu_poses, int n_poses, const double end_state14[14]);
+/* pcl::VoxelGrid (downSizeFilterSurf, src/laserMapping.cpp:2135, 2322-2323) on feats_undistort: centroid
+ * of every occupied leaf, ascending leaf index; the result becomes the current scan (feats_down_body),
+ * exactly as if it had been passed to lio_scan_set.  *n_out = feats_down_size.                             */
+int  lio_scan_voxel_filter(lio_ctx* ctx, float leaf_size, int* n_out);
+/* which = 0: feats_undistort, 1: the current scan; xyz packed, *n = number of points available.            */
+int  lio_scan_get_cloud(lio_ctx* ctx, int which, float* out_xyz, int cap, int* n);
+
 /* One pass.  do_search = ekfom_data.converge (laserMapping.cpp:1906); out->valid = ekfom_data.valid.*/
 int  lio_measure(lio_ctx* ctx, const double state14[14], int do_search, int extrinsic_est_en,
                  lio_out* out);

@@ -7,6 +7,7 @@
 #include "lio_oracle.h"
 
 #include <algorithm>
+#include <cfloat>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1043,6 +1044,110 @@ void orc_map_incremental_classify(const float* world, int n, const float* nbr_xy
             cls[i] = 1;                                    // :1487
         }
     }
+}
+
+// ImuProcess::UndistortPcl, point side (src/IMU_Processing.hpp:250-251 sort by time, :334-386 backward
+// compensation).  xyzt = n x (x, y, z, curvature = time offset in ms); poses = K x Pose6D (22 doubles:
+// offset_time, acc, gyr, vel, pos, rot row-major; msg/Pose6D.msg); end14 = imu_state after propagation.
+// Output: the time-sorted (stable), compensated cloud.  The inner loop assigns a point to the interval
+// [head, tail] with the largest head.offset_time < t (the reference walks points and poses backwards);
+// the reference's re-processing of the very first point when it lies beyond the second pose (the
+// `break` at :384 leaves it_pcl at begin) is not reproduced.
+void orc_undistort(const float* xyzt, int n, const double* poses, int K, const double* end14, float* out_xyz,
+                   float* out_t) {
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return xyzt[4 * a + 3] < xyzt[4 * b + 3]; });
+    Pose s = pose_from(end14);
+    for (int o = 0; o < n; ++o) {
+        const float* p = xyzt + 4 * order[o];
+        float rx = p[0], ry = p[1], rz = p[2];
+        const double t = p[3] / double(1000);
+        int k = -1;
+        for (int j = 0; j + 1 < K; ++j) if (poses[22 * j] < t) k = j;
+        if (k >= 0) {
+            const double* head = poses + 22 * k; const double* tail = head + 22;
+            const double dt = t - head[0];
+            V3 acc{tail[1], tail[2], tail[3]}, gyr{tail[4], tail[5], tail[6]};
+            V3 vel{head[7], head[8], head[9]}, pos{head[10], head[11], head[12]};
+            M3 Rm; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rm.m[i][j] = head[13 + 3 * i + j];
+            // Exp(ang_vel, dt)  include/math_tools.h:39-61
+            M3 E = {{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}};
+            const double nrm = norm(gyr);
+            if (nrm > 0.0000001) {
+                V3 ax{gyr.x / nrm, gyr.y / nrm, gyr.z / nrm};
+                M3 Kx = hat(ax), KK = mmul(Kx, Kx);
+                const double ang = nrm * dt;
+                const double sn = std::sin(ang), cs = 1.0 - std::cos(ang);
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E.m[i][j] = (E.m[i][j] + sn * Kx.m[i][j]) + cs * KK.m[i][j];
+            }
+            M3 Ri = mmul(Rm, E);                                                           // :355
+            V3 Pi{p[0], p[1], p[2]};
+            V3 Tei{((pos.x + vel.x * dt) + ((0.5 * acc.x) * dt) * dt) - s.pos.x,              // :359
+                   ((pos.y + vel.y * dt) + ((0.5 * acc.y) * dt) * dt) - s.pos.y,
+                   ((pos.z + vel.z * dt) + ((0.5 * acc.z) * dt) * dt) - s.pos.z};
+            V3 in = mvec(Ri, qrot(s.offR, Pi) + s.offT) + Tei;
+            V3 b = qrot(conj(s.rot), in) - s.offT;
+            V3 c = qrot(conj(s.offR), b);                                                  // :372-374
+            rx = (float)c.x; ry = (float)c.y; rz = (float)c.z;
+        }
+        out_xyz[3 * o] = rx; out_xyz[3 * o + 1] = ry; out_xyz[3 * o + 2] = rz;
+        if (out_t) out_t[o] = p[3];
+    }
+}
+
+// pcl::VoxelGrid<PointType>::applyFilter (PCL 1.10 filters/impl/voxel_grid.hpp; PCL is a third-party,
+// un-vendored dependency of the reference: laserMapping.cpp:112, 2135, 2322-2323), xyz only:
+// getMinMax3D -> min_b/div_b -> leaf index per point -> sort by leaf (PCL: std::sort on the index, i.e.
+// unspecified order among equal leaves; here stable = input order) -> centroid (CentroidPoint: fp32 sums
+// in that order, divided by the count) -> output in ascending leaf order.  Returns the number of leaves
+// (or -1 for the "leaf size too small" overflow, where PCL returns the input unfiltered).
+int orc_voxel_grid(const float* xyz, int n, float leaf, float* out_xyz, int cap) {
+    const float inv = 1.0f / leaf;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    int finite = 0;
+    for (int i = 0; i < n; ++i) {
+        const float* p = xyz + 3 * i;
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); }
+        ++finite;
+    }
+    if (!finite) return 0;
+    int min_b[3], max_b[3]; long long div[3];
+    for (int a = 0; a < 3; ++a) {
+        min_b[a] = static_cast<int>(std::floor(mn[a] * inv));
+        max_b[a] = static_cast<int>(std::floor(mx[a] * inv));
+        div[a] = (long long)max_b[a] - min_b[a] + 1;
+    }
+    if (div[0] * div[1] * div[2] > (long long)std::numeric_limits<int>::max()) return -1;
+    const int mul[3] = {1, (int)div[0], (int)(div[0] * div[1])};
+    std::vector<std::pair<unsigned, int>> iv;
+    iv.reserve(n);
+    for (int i = 0; i < n; ++i) {
+        const float* p = xyz + 3 * i;
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+        const int i0 = static_cast<int>(std::floor(p[0] * inv) - static_cast<float>(min_b[0]));
+        const int i1 = static_cast<int>(std::floor(p[1] * inv) - static_cast<float>(min_b[1]));
+        const int i2 = static_cast<int>(std::floor(p[2] * inv) - static_cast<float>(min_b[2]));
+        iv.emplace_back(static_cast<unsigned>(i0 * mul[0] + i1 * mul[1] + i2 * mul[2]), i);
+    }
+    std::stable_sort(iv.begin(), iv.end(), [](const std::pair<unsigned, int>& a, const std::pair<unsigned, int>& b) { return a.first < b.first; });
+    int nout = 0;
+    size_t i = 0;
+    while (i < iv.size()) {
+        size_t j = i;
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        while (j < iv.size() && iv[j].first == iv[i].first) {
+            const float* p = xyz + 3 * iv[j].second;
+            sx += p[0]; sy += p[1]; sz += p[2];
+            ++j;
+        }
+        const float fn = static_cast<float>(j - i);
+        if (nout < cap) { out_xyz[3 * nout] = sx / fn; out_xyz[3 * nout + 1] = sy / fn; out_xyz[3 * nout + 2] = sz / fn; }
+        ++nout;
+        i = j;
+    }
+    return nout;
 }
 
 // lasermap_fov_segment (src/laserMapping.cpp:1136-1200).  state7 = LocalMap_Points min xyz, max xyz,

@@ -83,6 +83,10 @@ void   orc_map_incremental_classify(const float* world_xyz, int n, const float* 
                                     const int* nbr_cnt, double filter_size_map_min,
                                     int flg_EKF_inited, uint8_t* cls);
 
+/* UndistortPcl point side (src/IMU_Processing.hpp:250-251, 334-386) and pcl::VoxelGrid (PCL 1.10, xyz only):
+ * both "parity unpinned" (Eigen / PCL are un-vendored third-party code). */
+void   orc_undistort(const float* xyzt, int n, const double* poses22, int K, const double* end14, float* out_xyz, float* out_t);
+int    orc_voxel_grid(const float* xyz, int n, float leaf, float* out_xyz, int cap);
 /* lasermap_fov_segment (src/laserMapping.cpp:1136-1200); state7 = LocalMap_Points min, max, initialised flag */
 int    orc_fov_segment(float* state7, const double* pos_lid, double cube_len, float det_range, float* boxes18);
 

@@ -69,6 +69,9 @@ def lib():
         L.orc_hth.argtypes = [_f64p, _f64p, C.c_int, _f64p, _f64p]
         L.orc_map_incremental_classify.argtypes = [_f32p, C.c_int, _f32p, _i32p, C.c_double, C.c_int, _u8p]
         L.orc_set_external_knn.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_undistort.argtypes = [_f32p, C.c_int, _f64p, C.c_int, _f64p, _f32p, _f32p]
+        L.orc_voxel_grid.restype = C.c_int
+        L.orc_voxel_grid.argtypes = [_f32p, C.c_int, C.c_float, _f32p, C.c_int]
         L.orc_fov_segment.restype = C.c_int
         L.orc_fov_segment.argtypes = [_f32p, _f64p, C.c_double, C.c_float, _f32p]
         _lib = L
@@ -302,6 +305,26 @@ class RefIkdTree:
 
     def quiesce(self, ms: int = 200):
         self.L.ref_ikd_quiesce(ms)
+
+
+def undistort(xyzt, poses22, end14):
+    """UndistortPcl's point side: returns (time-sorted compensated xyz [n,3], sorted times [n])."""
+    xyzt = _c32(xyzt).reshape(-1, 4)
+    p = np.ascontiguousarray(poses22, np.float64).reshape(-1, 22)
+    out = np.zeros((len(xyzt), 3), np.float32)
+    tt = np.zeros(len(xyzt), np.float32)
+    lib().orc_undistort(xyzt, len(xyzt), p, len(p), np.ascontiguousarray(end14, np.float64), out, tt)
+    return out, tt
+
+
+def voxel_grid(xyz, leaf: float):
+    """pcl::VoxelGrid centroid filter (xyz only)."""
+    xyz = _c32(xyz).reshape(-1, 3)
+    out = np.zeros((max(len(xyz), 1), 3), np.float32)
+    n = lib().orc_voxel_grid(xyz, len(xyz), leaf, out, len(xyz))
+    if n < 0:
+        raise OverflowError("leaf size too small for the extent of the cloud")
+    return out[:n].copy()
 
 
 class FovSegment:

@@ -403,3 +403,66 @@ def test_search_after_map_mutation_ignores_stale_bound(gpu_capi, oracle, small_c
     nx, nd, nc = ctx.neighbors()
     assert np.array_equal(nc, arr.nbr_cnt) and bits_equal(nd, arr.nbr_d) and bits_equal(nx, arr.nbr_xyz)
     ctx.close()
+
+
+def _imu_poses(n_poses=14, dt=0.0085):
+    """A smooth IMUpose list (Pose6D records) for the undistortion tests: gentle turn + acceleration."""
+    poses = np.zeros((n_poses, 22))
+    w = np.array([0.02, -0.015, 0.35]); acc = np.array([0.4, 0.1, 0.05]); v0 = np.array([2.0, 0.3, 0.0])
+    for k in range(n_poses):
+        t = k * dt
+        ang = np.linalg.norm(w) * t
+        ax = w / np.linalg.norm(w)
+        Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+        poses[k, 0] = t
+        poses[k, 1:4] = acc + [0, 0, 0.01 * k]; poses[k, 4:7] = w + [0.001 * k, 0, 0]
+        poses[k, 7:10] = v0 + acc * t; poses[k, 10:13] = v0 * t + 0.5 * acc * t * t
+        poses[k, 13:22] = R.ravel()
+    return poses
+
+
+def test_scan_undistort_and_voxel_filter(gpu_capi, oracle, synth, small_case):
+    """The step before the path (SURVEY.md 8f rank 3): UndistortPcl's point side and pcl::VoxelGrid on the
+    device vs the oracle restatement (both "parity unpinned": Eigen / PCL are un-vendored).  Then the
+    down-sampled scan drives a scan step exactly like a scan handed over with lio_scan_set."""
+    w, sc = small_case["world"], small_case["scan"]
+    rng = np.random.default_rng(12)
+    n = len(sc.body)
+    t_ms = rng.uniform(0, 100.0, n).astype(np.float32)
+    t_ms[:5] = 0.0                                              # points at the scan start are left untouched (:351)
+    t_ms[5:9] = t_ms[9]                                         # equal time stamps: stable order
+    raw = np.concatenate([sc.body, t_ms[:, None]], 1).astype(np.float32)
+    poses = _imu_poses()
+    end = synth.state_vector(poses[-1, 10:13] + [0.01, 0, 0], synth._quat_from_rot(poses[-1, 13:22].reshape(3, 3)), sc.off_R, sc.off_T)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=20_000, max_map_points=400_000)
+    ctx.map_build(w.points)
+    ctx.scan_undistort(raw, poses, end)
+    und_g = ctx.scan_cloud(0)
+    und_o, ts = oracle.undistort(raw, poses, end)
+    assert und_g.shape == und_o.shape == (n, 3)
+    # fp64 arithmetic with device sin/cos vs glibc: sub-ulp differences may flip an fp32 rounding
+    assert np.abs(und_g - und_o).max() < 1e-5
+    assert (und_g.view(np.uint32) == und_o.view(np.uint32)).mean() > 0.999
+    assert np.abs(und_g - sc.body[np.argsort(t_ms, kind="stable")]).max() > 0.05      # it did move points
+    # voxel grid: bit-exact given the same input cloud
+    for leaf in (0.5, 0.2):
+        ctx.scan_undistort(np.concatenate([und_o, ts[:, None]], 1).astype(np.float32))   # upload only
+        m = ctx.scan_voxel_filter(leaf)
+        down_o = oracle.voxel_grid(und_o, leaf)
+        down_g = ctx.scan_cloud(1)
+        assert m == len(down_o) == len(down_g) and m < n
+        assert bits_equal(down_g, down_o)
+    # the filtered cloud is the scan: a measurement pass on it equals lio_scan_set of the same points
+    st = small_case["state14"]
+    g1 = ctx.measure(st, True, False)
+    ctx.scan_set(down_o)
+    g2 = ctx.measure(st, True, False)
+    assert g1["m"] == g2["m"] > 100 and np.array_equal(g1["HTH"], g2["HTH"])
+    # non-finite points are dropped, an absurd leaf size is refused like PCL's overflow check
+    bad = np.concatenate([und_o[:100], [[np.nan, 0, 0], [np.inf, 1, 1]]]).astype(np.float32)
+    ctx.scan_undistort(np.concatenate([bad, np.zeros((len(bad), 1), np.float32)], 1))
+    assert ctx.scan_voxel_filter(0.5) == len(oracle.voxel_grid(bad, 0.5))
+    with pytest.raises(gpu_capi.LioError, match="LIO_ERR_CAPACITY"):
+        ctx.scan_voxel_filter(1e-4)
+    ctx.close()
