@@ -466,3 +466,62 @@ def test_scan_undistort_and_voxel_filter(gpu_capi, oracle, synth, small_case):
     with pytest.raises(gpu_capi.LioError, match="LIO_ERR_CAPACITY"):
         ctx.scan_voxel_filter(1e-4)
     ctx.close()
+
+
+def test_node_loop_composition(gpu_capi, oracle, synth, small_case):
+    """The reference's main loop body (laserMapping.cpp:2320-2401), five scans of a short drive:
+    lasermap_fov_segment -> VoxelGrid down-sampling -> iterated update -> map_incremental, every stage on the
+    GPU path vs the CPU path, state carried from scan to scan (posterior -> next prior, map -> next map)."""
+    w = small_case["world"]
+    base = np.ascontiguousarray(w.points[::2])
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=20_000, max_map_points=400_000)
+    ctx.map_build(base)
+    om = oracle.OracleMap(0.2); om.build(base)
+    fov = oracle.FovSegment()
+    key = lambda p: p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+    x_g = x_o = None
+    P_g = P_o = synth.init_cov()
+    for k in range(5):
+        sc = synth.make_scan(w, 15_000, seed=synth.SEED + 70 + k, pos=(2.0 + 1.1 * k, -2.0 + 0.3 * k, 0.0), rpy=(0.002, -0.003, 0.5 + 0.04 * k))
+        if x_g is None:
+            pos, rot = synth.perturb_state(sc, dpos=0.04, drot_deg=0.2, seed=synth.SEED + 80)
+            x_g = x_o = gpu_capi.make_state26(pos, rot, sc.off_R, sc.off_T)
+        else:
+            # constant-position "prediction": the previous posterior is the prior (the drive moves ~1.1 m per
+            # scan, so put the truth's translation in -- IMU propagation is the host's job and not under test)
+            step = np.zeros(26); step[:3] = sc.pos - prev_true
+            x_g = x_g + step; x_o = x_o + step
+        prev_true = sc.pos.copy()
+        pos_lid = x_o[:3]
+        # lasermap_fov_segment
+        bo = fov.step(pos_lid, 70.0, 20.0)
+        bg, nd = ctx.fov_segment(pos_lid, 70.0, 20.0)
+        assert bits_equal(bg, bo) and nd == (om.delete_boxes(bo) if len(bo) else 0)
+        # VoxelGrid down-sampling of the (already compensated) scan
+        raw = np.concatenate([sc.body, np.zeros((len(sc.body), 1), np.float32)], 1)
+        ctx.scan_undistort(raw)
+        m = ctx.scan_voxel_filter(0.3)
+        down = oracle.voxel_grid(sc.body, 0.3)
+        assert m == len(down) and bits_equal(ctx.scan_cloud(1), down)
+        # iterated update
+        xo, Po, arrs, log = oracle.update_iterated(om, x_o, P_o, down)
+        kf = gpu_capi.Esekf(3); kf.change_x(x_g); kf.change_P(P_g)
+        lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+        xg, Pg = kf.get_x(), kf.get_P()
+        assert lg["n_calls"] == len(log)
+        assert np.abs(xg[:3] - xo[:3]).max() < 1e-4 and 2 * np.abs(xg[3:7] - xo[3:7]).max() < 1e-5
+        assert np.abs(xg - xo).max() < 1e-6                      # rounding-level (different 23x23 elimination orders)
+        assert np.abs(Pg - Po).max() <= 1e-6 * np.abs(Po).max()
+        assert np.linalg.norm(xg[:3] - sc.pos) < 0.1             # the prior ignores the 0.04 rad yaw step; parity is the point
+        # map_incremental at the CPU path's posterior (bit-equal world points need identical pose bits)
+        wp = oracle.body_to_world(xo[:14], down)
+        cls = oracle.map_incremental_classify(wp, arrs.nbr_xyz, arrs.nbr_cnt, 0.2, True)
+        r = ctx.map_incremental(xo[:14], 0.2, True, apply=True)
+        c1 = om.add(np.ascontiguousarray(wp[cls == 1]), True)
+        om.add(np.ascontiguousarray(wp[cls == 2]), False)
+        assert (r["n_add"], r["n_nodown"], r["add_counter"]) == (int((cls == 1).sum()), int((cls == 2).sum()), c1)
+        assert ctx.map_validnum() == om.validnum()
+        # both paths continue from the same prior, so that every scan is an independent bit-level comparison
+        x_g, P_g, x_o, P_o = xo, Po, xo, Po
+    assert bits_equal(key(ctx.map_flatten()), key(om.flatten()))
+    ctx.close()
