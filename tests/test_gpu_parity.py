@@ -479,19 +479,13 @@ def test_node_loop_composition(gpu_capi, oracle, synth, small_case):
     om = oracle.OracleMap(0.2); om.build(base)
     fov = oracle.FovSegment()
     key = lambda p: p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
-    x_g = x_o = None
     P_g = P_o = synth.init_cov()
     for k in range(5):
         sc = synth.make_scan(w, 15_000, seed=synth.SEED + 70 + k, pos=(2.0 + 1.1 * k, -2.0 + 0.3 * k, 0.0), rpy=(0.002, -0.003, 0.5 + 0.04 * k))
-        if x_g is None:
-            pos, rot = synth.perturb_state(sc, dpos=0.04, drot_deg=0.2, seed=synth.SEED + 80)
-            x_g = x_o = gpu_capi.make_state26(pos, rot, sc.off_R, sc.off_T)
-        else:
-            # constant-position "prediction": the previous posterior is the prior (the drive moves ~1.1 m per
-            # scan, so put the truth's translation in -- IMU propagation is the host's job and not under test)
-            step = np.zeros(26); step[:3] = sc.pos - prev_true
-            x_g = x_g + step; x_o = x_o + step
-        prev_true = sc.pos.copy()
+        # the prior of every scan = truth (+) a small error, as a good IMU prediction would give (IMU
+        # propagation is the host's job and not under test); covariance and map are carried over
+        pos, rot = synth.perturb_state(sc, dpos=0.04, drot_deg=0.2, seed=synth.SEED + 80 + k)
+        x_g = x_o = gpu_capi.make_state26(pos, rot, sc.off_R, sc.off_T)
         pos_lid = x_o[:3]
         # lasermap_fov_segment
         bo = fov.step(pos_lid, 70.0, 20.0)
@@ -512,7 +506,7 @@ def test_node_loop_composition(gpu_capi, oracle, synth, small_case):
         assert np.abs(xg[:3] - xo[:3]).max() < 1e-4 and 2 * np.abs(xg[3:7] - xo[3:7]).max() < 1e-5
         assert np.abs(xg - xo).max() < 1e-6                      # rounding-level (different 23x23 elimination orders)
         assert np.abs(Pg - Po).max() <= 1e-6 * np.abs(Po).max()
-        assert np.linalg.norm(xg[:3] - sc.pos) < 0.1             # the prior ignores the 0.04 rad yaw step; parity is the point
+        assert np.linalg.norm(xg[:3] - sc.pos) < 0.06            # sanity only (tight carried-over covariance)
         # map_incremental at the CPU path's posterior (bit-equal world points need identical pose bits)
         wp = oracle.body_to_world(xo[:14], down)
         cls = oracle.map_incremental_classify(wp, arrs.nbr_xyz, arrs.nbr_cnt, 0.2, True)
@@ -522,6 +516,6 @@ def test_node_loop_composition(gpu_capi, oracle, synth, small_case):
         assert (r["n_add"], r["n_nodown"], r["add_counter"]) == (int((cls == 1).sum()), int((cls == 2).sum()), c1)
         assert ctx.map_validnum() == om.validnum()
         # both paths continue from the same prior, so that every scan is an independent bit-level comparison
-        x_g, P_g, x_o, P_o = xo, Po, xo, Po
+        P_g, P_o = Po, Po
     assert bits_equal(key(ctx.map_flatten()), key(om.flatten()))
     ctx.close()
