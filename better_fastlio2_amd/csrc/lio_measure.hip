@@ -19,7 +19,7 @@
 
 namespace lio {
 
-template <bool EXT> struct RedShape {
+template <bool EXT, int BS = 256> struct RedShape {
     static constexpr int NC = EXT ? 12 : 6;            // non-zero columns of h_x
     static constexpr int NP = NC * (NC + 1) / 2;       // unique entries of H^T H
     static constexpr int COL_H = NC;                   // staged columns: J[0..NC), h, |pd2|, 1
@@ -28,8 +28,8 @@ template <bool EXT> struct RedShape {
     static constexpr int NCOLS = NC + 3;
     static constexpr int NE = NP + NC + 2;             // + H^T h, residual sum, count
     static constexpr int NEP = EXT ? 128 : 32;         // lanes per row segment (>= NE)
-    static constexpr int SEG = 256 / NEP;              // row segments per workgroup
-    static constexpr int RS = 256 / SEG;               // rows per segment
+    static constexpr int SEG = BS / NEP;               // row segments per workgroup
+    static constexpr int RS = BS / SEG;                // rows per segment
 };
 
 // entry e -> the two staged columns whose product is summed
@@ -50,14 +50,14 @@ __device__ __forceinline__ void entry_columns(int e, int& ca, int& cb) {
     }
 }
 
-template <bool EXT, bool SEARCH>
-__global__ __launch_bounds__(256) void residual_kernel(ResidualArgs a) {
-    typedef RedShape<EXT> S;
-    __shared__ double s_rows[256][S::NCOLS];
+template <bool EXT, bool SEARCH, int BS>
+__global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
+    typedef RedShape<EXT, BS> S;
+    __shared__ double s_rows[BS][S::NCOLS];
     __shared__ double s_part[S::SEG][S::NEP];
 
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * 256 + tid;
+    const int i = blockIdx.x * BS + tid;
     bool sel = false;
     double row[12];
     double h = 0.0;
@@ -234,15 +234,17 @@ __global__ __launch_bounds__(256) void residual_kernel(ResidualArgs a) {
 
 int residual_blocks(int nq) { return (nq + 255) / 256; }
 
+// 256 lanes per workgroup: 512 measured the same and 1024 slower on MI355X (the kernel is a chain of
+// dependent round trips, not throughput-bound)
 hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool ext, hipStream_t s) {
     if (a.nq <= 0) return hipSuccess;
     const dim3 grid(residual_blocks(a.nq)), block(256);
     if (ext) {
-        if (do_search) hipLaunchKernelGGL((residual_kernel<true, true>), grid, block, 0, s, a);
-        else           hipLaunchKernelGGL((residual_kernel<true, false>), grid, block, 0, s, a);
+        if (do_search) hipLaunchKernelGGL((residual_kernel<true, true, 256>), grid, block, 0, s, a);
+        else           hipLaunchKernelGGL((residual_kernel<true, false, 256>), grid, block, 0, s, a);
     } else {
-        if (do_search) hipLaunchKernelGGL((residual_kernel<false, true>), grid, block, 0, s, a);
-        else           hipLaunchKernelGGL((residual_kernel<false, false>), grid, block, 0, s, a);
+        if (do_search) hipLaunchKernelGGL((residual_kernel<false, true, 256>), grid, block, 0, s, a);
+        else           hipLaunchKernelGGL((residual_kernel<false, false, 256>), grid, block, 0, s, a);
     }
     return hipGetLastError();
 }

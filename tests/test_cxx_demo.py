@@ -1,0 +1,38 @@
+"""The C ABI used the way the reference node would use it: from C++, no Python in the loop.
+examples/lio_demo.cpp is compiled with plain g++ against include/lio_hip.h and liblio_hip.so."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "examples", "lio_demo")
+
+
+def _compile_demo():
+    from better_fastlio2_amd import build
+    lib = build.build()
+    cmd = ["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "lio_demo.cpp"),
+           "-o", DEMO, "-L", os.path.dirname(lib), "-llio_hip", "-Wl,-rpath," + os.path.dirname(lib)]
+    subprocess.run(cmd, check=True, cwd=ROOT)
+
+
+def test_header_is_plain_c():
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "lio_hip.h")],
+                   check=True)
+
+
+def test_demo_links_and_fails_loudly_without_gpu():
+    _compile_demo()
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([DEMO], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "lio_create failed: -2" in r.stdout      # LIO_ERR_NO_DEVICE, no CPU fallback
+
+
+@pytest.mark.gpu
+def test_demo_runs_on_gpu():
+    _compile_demo()
+    r = subprocess.run([DEMO], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "DEMO OK" in r.stdout
