@@ -68,23 +68,68 @@ __device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
     return v;
 }
 
-// sorted (ascending) list of five keys in registers
+// The (sqdist bits << 32 | map index) key of a candidate, carried as an IEEE double: for sign-clear,
+// non-NaN bit patterns the double order IS the unsigned 64-bit order, and gfx950 has full-rate
+// v_min_f64 / v_max_f64 where a 64-bit integer min costs a compare and two selects.  The high word is
+// clamped to +inf's fp32 pattern (0x7f800000), which as a double exponent is finite, so no key is a NaN;
+// distances below 2^-126 make denormal doubles, which the f64 denorm mode of HIP kernels preserves.
+__device__ __forceinline__ double key_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double key_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double key_make(uint32_t dist_bits, uint32_t idx) { return __hiloint2double((int)dist_bits, (int)idx); }
+__device__ __forceinline__ uint32_t key_dist_bits(double k) { return (uint32_t)__double2hiint(k); }
+__device__ __forceinline__ uint32_t key_index(double k) { return (uint32_t)__double2loint(k); }
+__device__ __forceinline__ bool key_same(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
+// sorted (ascending) list of five keys in registers; insertion = a 9-instruction min/max ladder
 struct Top5 {
-    u64 k0, k1, k2, k3, k4;
-    __device__ __forceinline__ void init() { k0 = k1 = k2 = k3 = k4 = KEY64_MAX; }
-    __device__ __forceinline__ void offer(u64 key) {
-        if (key < k4) {
-            // position by four more compares, then shift the tail down by one (selects only)
-            const bool c0 = key < k0, c1 = key < k1, c2 = key < k2, c3 = key < k3;
-            k4 = c3 ? k3 : key;
-            k3 = c2 ? k2 : (c3 ? key : k3);
-            k2 = c1 ? k1 : (c2 ? key : k2);
-            k1 = c0 ? k0 : (c1 ? key : k1);
-            k0 = c0 ? key : k0;
-        }
+    double k0, k1, k2, k3, k4;
+    __device__ __forceinline__ static double none() { return key_make(INF_BITS, 0xffffffffu); }
+    __device__ __forceinline__ void init() { k0 = k1 = k2 = k3 = k4 = none(); }
+    __device__ __forceinline__ void offer(double x) {
+        double t;
+        t = key_max(k0, x); k0 = key_min(k0, x); x = t;
+        t = key_max(k1, x); k1 = key_min(k1, x); x = t;
+        t = key_max(k2, x); k2 = key_min(k2, x); x = t;
+        t = key_max(k3, x); k3 = key_min(k3, x); x = t;
+        k4 = key_min(k4, x);
     }
-    __device__ __forceinline__ void pop() { k0 = k1; k1 = k2; k2 = k3; k3 = k4; k4 = KEY64_MAX; }
+    __device__ __forceinline__ void pop() { k0 = k1; k1 = k2; k2 = k3; k3 = k4; k4 = none(); }
 };
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int G>
+__device__ __forceinline__ double group_min_key(double v) {
+    if (G >= 2) v = key_min(v, dpp_move_f64<0xB1>(v));       // quad_perm [1,0,3,2]
+    if (G >= 4) v = key_min(v, dpp_move_f64<0x4E>(v));       // quad_perm [2,3,0,1]
+    if (G >= 8) v = key_min(v, dpp_move_f64<0x141>(v));      // row_half_mirror
+    if (G >= 16) v = key_min(v, dpp_move_f64<0x140>(v));     // row_mirror
+    if (G >= 32) v = key_min(v, __shfl_xor(v, 16, 64));
+    if (G >= 64) v = key_min(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+// candidate of the 3x3x3 search: tomb-stoned points (w != 0) and NaN distances (non-finite query) take
+// the +inf pattern, sort after every real candidate and are dropped by the `< INF_BITS` tests
+__device__ __forceinline__ double candidate_key_f(float qx, float qy, float qz, float4 p, uint32_t idx) {
+    const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
+    const uint32_t bits = __float_as_uint(d);
+    const uint32_t db = p.w != 0.0f ? INF_BITS : (bits < INF_BITS ? bits : INF_BITS);
+    return key_make(db, idx);
+}
 
 __device__ __forceinline__ u64 candidate_key(float qx, float qy, float qz, float4 p, uint32_t idx) {
     const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
@@ -209,29 +254,29 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         if (CENSUS) csum += bk.y;
         if ((uint32_t)r < bk.y) {
             const uint32_t idx = bk.x + (uint32_t)r;
-            const u64 key = candidate_key(qx, qy, qz, a.map_pts[idx], idx);
-            if (!HINT || (uint32_t)(key >> 32) <= tau_bits) top.offer(key);
+            top.offer(candidate_key_f(qx, qy, qz, a.map_pts[idx], idx));
         }
         if (bk.y > (uint32_t)G) {                  // rare at one point per down-sample voxel
             for (uint32_t t = (uint32_t)(r + G); t < bk.y; t += G) {
                 const uint32_t idx = bk.x + t;
-                top.offer(candidate_key(qx, qy, qz, a.map_pts[idx], idx));
+                top.offer(candidate_key_f(qx, qy, qz, a.map_pts[idx], idx));
             }
         }
     }
 
     // ---- merge the G sorted lists: five rounds of group-min + pop ------------------------------
     // lane r keeps result r (and result r + G when G < 5)
-    u64 mine0 = KEY64_MAX, mine1 = KEY64_MAX;
+    double mine0 = Top5::none(), mine1 = Top5::none();
     int nvalid = 0;
     uint32_t d5bits = INF_BITS;
 #pragma unroll
     for (int rd = 0; rd < K; ++rd) {
-        const u64 m = group_min_u64<G>(top.k0);
-        if (top.k0 == m && m != KEY64_MAX) top.pop();      // keys are unique (distinct map indices)
+        const double m = group_min_key<G>(top.k0);
+        if (key_same(top.k0, m)) top.pop();                // real keys are unique (distinct map indices);
+                                                           // popping the "none" key leaves "none"
         if (r == rd % G) { if (rd < G) mine0 = m; else mine1 = m; }
-        nvalid += ((uint32_t)(m >> 32) < INF_BITS) ? 1 : 0;
-        if (rd == K - 1) d5bits = (uint32_t)(m >> 32);
+        nvalid += (key_dist_bits(m) < INF_BITS) ? 1 : 0;
+        if (rd == K - 1) d5bits = key_dist_bits(m);
     }
 
     // ---- write Nearest_Points[q] ---------------------------------------------------------------
@@ -239,11 +284,11 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     for (int half = 0; half < (G < K ? 2 : 1); ++half) {
         const int slot = r + half * G;
         if (active && slot < K) {
-            const u64 mine = half == 0 ? mine0 : mine1;
-            const uint32_t db = (uint32_t)(mine >> 32);
+            const double mine = half == 0 ? mine0 : mine1;
+            const uint32_t db = key_dist_bits(mine);
             float4 o;
             if (db < INF_BITS) {
-                const float4 p = a.map_pts[(uint32_t)mine];
+                const float4 p = a.map_pts[key_index(mine)];
                 o = make_float4(p.x, p.y, p.z, __uint_as_float(db));
             } else {
                 const float nanv = __uint_as_float(0x7fc00000u);
