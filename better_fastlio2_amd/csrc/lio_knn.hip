@@ -241,26 +241,28 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         if (ne) s_bucket[wave][g][pos] = make_uint2(st[s], ct[s]);
         n_ne += __popcll(gb);
     }
+    // a sentinel bucket that no candidate number reaches ends the walk below
+    if (r == 0) s_bucket[wave][g][n_ne] = make_uint2(0u, 0xffffffffu);
     // LDS is in-order per wavefront; the fence keeps the compiler from moving the reads up
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- stream the candidates: lane r takes points r, r+G, ... of every bucket ---------------
+    // ---- stream the candidates: the buckets of a query are walked as ONE concatenated list and lane r
+    // takes its candidates r, r+G, r+2G, ... -- every iteration keeps all G lanes busy whatever the
+    // bucket sizes are (points of a bucket are contiguous: consecutive lanes, consecutive addresses)
     Top5 top; top.init();
     uint32_t csum = 0;
-    for (int i = 0; i < n_ne; ++i) {
-        const uint2 bk = s_bucket[wave][g][i];
-        if (CENSUS) csum += bk.y;
-        if ((uint32_t)r < bk.y) {
-            const uint32_t idx = bk.x + (uint32_t)r;
+    if (CENSUS) for (int i = 0; i < n_ne; ++i) csum += s_bucket[wave][g][i].y;
+    {
+        uint32_t b = 0, base = 0, t = (uint32_t)r;
+        uint2 bk = s_bucket[wave][g][0];
+        for (;;) {
+            while (t - base >= bk.y) { base += bk.y; ++b; bk = s_bucket[wave][g][b]; }
+            if ((int)b >= n_ne) break;
+            const uint32_t idx = bk.x + (t - base);
             top.offer(candidate_key_f(qx, qy, qz, a.map_pts[idx], idx));
-        }
-        if (bk.y > (uint32_t)G) {                  // rare at one point per down-sample voxel
-            for (uint32_t t = (uint32_t)(r + G); t < bk.y; t += G) {
-                const uint32_t idx = bk.x + t;
-                top.offer(candidate_key_f(qx, qy, qz, a.map_pts[idx], idx));
-            }
+            t += (uint32_t)G;
         }
     }
 
