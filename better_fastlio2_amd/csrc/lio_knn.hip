@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         u64 key[SLOTS];
         uint32_t slot[SLOTS];
         uint4 e[SLOTS];
+        bool live_s[SLOTS];
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int j = r + s * G;
@@ -212,9 +213,14 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             }
             key[s] = pack_key((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
             slot[s] = hash_cell((uint32_t)nx, (uint32_t)ny, (uint32_t)nz) & mask;
-            e[s] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);      // reads as "empty slot"
-            if (live) e[s] = table[slot[s]];
+            // unconditional load (dead lanes read slot 0 and discard it): no branch, so the SLOTS loads
+            // of a lane are in flight together
+            live_s[s] = live;
+            e[s] = table[live ? slot[s] : 0u];
         }
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (!live_s[s]) e[s] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);      // reads as "empty slot"
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             st[s] = 0; ct[s] = 0;
@@ -257,12 +263,20 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     {
         uint32_t b = 0, base = 0, t = (uint32_t)r;
         uint2 bk = s_bucket[wave][g][0];
-        for (;;) {
-            while (t - base >= bk.y) { base += bk.y; ++b; bk = s_bucket[wave][g][b]; }
-            if ((int)b >= n_ne) break;
-            const uint32_t idx = bk.x + (t - base);
-            top.offer(candidate_key_f(qx, qy, qz, a.map_pts[idx], idx));
+        while (t - base >= bk.y) { base += bk.y; ++b; bk = s_bucket[wave][g][b]; }
+        // the load of candidate i+1 is in flight while candidate i goes through the ladder
+        bool have = (int)b < n_ne;
+        uint32_t idx_next = 0;
+        float4 p_next = make_float4(0.f, 0.f, 0.f, 1.f);
+        if (have) { idx_next = bk.x + (t - base); p_next = a.map_pts[idx_next]; }
+        while (have) {
+            const float4 p = p_next;
+            const uint32_t idx = idx_next;
             t += (uint32_t)G;
+            while (t - base >= bk.y) { base += bk.y; ++b; bk = s_bucket[wave][g][b]; }
+            have = (int)b < n_ne;
+            if (have) { idx_next = bk.x + (t - base); p_next = a.map_pts[idx_next]; }
+            top.offer(candidate_key_f(qx, qy, qz, p, idx));
         }
     }
 
