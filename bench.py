@@ -233,13 +233,13 @@ def main():
     log = step()
     pos_err = float(np.linalg.norm(kf.get_x()[:3] - scan.pos))
 
-    # untimed: per-family kernel times (HIP events around every launch)
+    # untimed: per-family kernel times (a HIP event pair on every launch)
     ctx.profile_enable(True)
     ctx.profile_reset()
     for _ in range(10):
         step()
     kernels_us = {k: (v["total_ms"] / max(v["launches"], 1)) * 1e3 for k, v in ctx.profile().items() if v["launches"]}
-    # timed region: HIP events only around the dominant kernel (knn27) on the library's stream
+    # timed region: HIP events only on the dominant kernel (knn27), on the library's stream
     ctx.profile_enable(only=[capi.PROF_KNN])
     ctx.profile_reset()
     elapsed = timed_steps(step, a.steps, a.warmup, dist, device)

@@ -101,7 +101,7 @@ struct lio_ctx {
     uint32_t *d_add_order = nullptr, *d_add_order2 = nullptr, *d_add_gcount = nullptr, *d_add_gstart = nullptr;
 
     // ---- profiling ----------------------------------------------------------------------------
-    // HIP-event pairs around each kernel family; recorded without synchronising and resolved when
+    // one HIP-event pair per timed launch, stamped by the dispatch (hipExtLaunchKernelGGL); resolved when
     // the totals are read, so that timing a run does not add a stream synchronisation per pass
     unsigned prof = 0;                         // bit w set: time kernel family w
     bool census = false;                       // count C(q) in the k-NN kernel (one atomic per wavefront)
@@ -341,21 +341,20 @@ void prof_collect(lio_ctx* c) {
         c->ev_next[w] = 0;
     }
 }
-void prof_begin(lio_ctx* c, int which) {
-    if (!(c->prof & (1u << which))) return;
+// the next event pair of a family (empty timer when the family is not being timed)
+KernelTimer prof_timer(lio_ctx* c, int which) {
+    KernelTimer t;
+    if (!(c->prof & (1u << which))) return t;
     if (c->ev_next[which] + 2 > 8192) prof_collect(c);            // bounded pool
     while (c->ev_pool[which].size() < c->ev_next[which] + 2) {
         hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess) return;
+        if (hipEventCreate(&e) != hipSuccess) return t;
         c->ev_pool[which].push_back(e);
     }
-    (void)hipEventRecord(c->ev_pool[which][c->ev_next[which]], c->stream);
-}
-void prof_end(lio_ctx* c, int which) {
-    if (!(c->prof & (1u << which))) return;
-    if (c->ev_pool[which].size() < c->ev_next[which] + 2) return;
-    (void)hipEventRecord(c->ev_pool[which][c->ev_next[which] + 1], c->stream);
+    t.start = c->ev_pool[which][c->ev_next[which]];
+    t.stop = c->ev_pool[which][c->ev_next[which] + 1];
     c->ev_next[which] += 2;
+    return t;
 }
 
 // k-NN of nq world/body queries into (nbr, cnt); queries_world must hold the world points when
@@ -373,16 +372,12 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.nbr = nbr; ka.cnt = cnt; ka.unres = unres; ka.cand_total = c->census ? c->d_cand : nullptr;
     ka.use_hint = use_hint ? 1 : 0;
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
-    prof_begin(c, LIO_PROF_KNN);
-    HIPCHK(c, launch_knn27(ka, lanes, s));
-    prof_end(c, LIO_PROF_KNN);
+    HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, LIO_PROF_KNN)));
     TreeArgs ta{};
     ta.map_pts = c->d_pts; ta.table0 = c->d_table; ta.ltable = c->d_ltable; ta.levels = c->levels; ta.grid = c->grid;
     ta.queries = queries_world; ta.unres = unres; ta.n_unresolved = c->d_counters;
     ta.nq = nq; ta.nq_stride = stride; ta.nbr = nbr; ta.cnt = cnt;
-    prof_begin(c, LIO_PROF_FALLBACK);
-    HIPCHK(c, launch_knn_tree(ta, s));
-    prof_end(c, LIO_PROF_FALLBACK);
+    HIPCHK(c, launch_knn_tree(ta, s, prof_timer(c, LIO_PROF_FALLBACK)));
     return LIO_OK;
 }
 
@@ -1090,9 +1085,7 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.rows = nullptr; ra.partials = c->d_partials;
     const unsigned long long seq = ++c->seq;
     ra.gpartials = c->d_gpartials; ra.ticket = c->d_tickets; ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
-    prof_begin(c, LIO_PROF_RESIDUAL);
-    HIPCHK(c, launch_residual(ra, do_search != 0, ext, s));
-    prof_end(c, LIO_PROF_RESIDUAL);
+    HIPCHK(c, launch_residual(ra, do_search != 0, ext, s, prof_timer(c, LIO_PROF_RESIDUAL)));
     // The record lands in host-mapped memory; poll its sequence number instead of paying for a
     // device-to-host copy plus a stream synchronisation.  hipStreamQuery guards against a fault.
     {

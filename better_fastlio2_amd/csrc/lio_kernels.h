@@ -3,6 +3,7 @@
 // include/lio_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "lio_common.h"
 
 namespace lio {
@@ -24,7 +25,10 @@ struct KnnArgs {
 // feats_down_world = pose (x) feats_down_body, fp64 -> fp32 (laserMapping.cpp:1894-1899)
 hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float4* world, hipStream_t s);
 // lanes_per_query in {4, 8, 16, 32, 64}
-hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s);
+// optional per-launch timing: when `start` is set the kernel is dispatched through hipExtLaunchKernelGGL,
+// which stamps the two events with the dispatch's own begin/end (no marker packets around the kernel)
+struct KernelTimer { hipEvent_t start = nullptr, stop = nullptr; };
+hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s, KernelTimer t = KernelTimer());
 
 // hashed 64-ary tree: level L = grid coarsened by 4^L, tables of levels 1.. live in one buffer
 constexpr int TREE_MAX_LEVELS = 12;
@@ -48,7 +52,7 @@ struct TreeArgs {
     float4*          nbr;
     uint8_t*         cnt;
 };
-hipError_t launch_knn_tree(const TreeArgs& a, hipStream_t s);
+hipError_t launch_knn_tree(const TreeArgs& a, hipStream_t s, KernelTimer t = KernelTimer());
 
 // ---- measurement model (replaces h_share_model's per-point body, laserMapping.cpp:1888-2002) --
 struct ResidualArgs {
@@ -71,7 +75,7 @@ struct ResidualArgs {
     unsigned long long seq;         // published last (system-scope release) in out->seq
 };
 int residual_blocks(int nq);
-hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s);
+hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s, KernelTimer t = KernelTimer());
 
 // ---- map construction / mutation ----------------------------------------------------------------
 // mkeys[i] = Morton key of pts[i], vals[i] = base_index + i

@@ -341,9 +341,15 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
 }
 
 template <int G>
-static void launch_knn27_g(const KnnArgs& a, hipStream_t s) {
+static void launch_knn27_g(const KnnArgs& a, hipStream_t s, KernelTimer t) {
     const int qpb = 4 * (64 / G);                  // queries per 256-thread workgroup
     const dim3 grid((a.nq + qpb - 1) / qpb), block(256);
+    if (t.start != nullptr) {
+        if (a.cand_total != nullptr) hipExtLaunchKernelGGL((knn27_kernel<G, true, false>), grid, block, 0, s, t.start, t.stop, 0, a);
+        else if (a.use_hint)         hipExtLaunchKernelGGL((knn27_kernel<G, false, true>), grid, block, 0, s, t.start, t.stop, 0, a);
+        else                         hipExtLaunchKernelGGL((knn27_kernel<G, false, false>), grid, block, 0, s, t.start, t.stop, 0, a);
+        return;
+    }
     if (a.cand_total != nullptr) hipLaunchKernelGGL((knn27_kernel<G, true, false>), grid, block, 0, s, a);
     else if (a.use_hint)         hipLaunchKernelGGL((knn27_kernel<G, false, true>), grid, block, 0, s, a);
     else                         hipLaunchKernelGGL((knn27_kernel<G, false, false>), grid, block, 0, s, a);
@@ -364,14 +370,14 @@ hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float
     return hipGetLastError();
 }
 
-hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s) {
+hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s, KernelTimer t) {
     if (a.nq <= 0) return hipSuccess;
     switch (lanes_per_query) {
-        case 4:  launch_knn27_g<4>(a, s); break;
-        case 8:  launch_knn27_g<8>(a, s); break;
-        case 16: launch_knn27_g<16>(a, s); break;
-        case 32: launch_knn27_g<32>(a, s); break;
-        case 64: launch_knn27_g<64>(a, s); break;
+        case 4:  launch_knn27_g<4>(a, s, t); break;
+        case 8:  launch_knn27_g<8>(a, s, t); break;
+        case 16: launch_knn27_g<16>(a, s, t); break;
+        case 32: launch_knn27_g<32>(a, s, t); break;
+        case 64: launch_knn27_g<64>(a, s, t); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -649,13 +655,14 @@ __global__ __launch_bounds__(64) void knn_tree_kernel(TreeArgs a) {
     if (lane == 0 && handled != 0) atomicAdd(a.n_unresolved, handled);
 }
 
-hipError_t launch_knn_tree(const TreeArgs& a, hipStream_t s) {
+hipError_t launch_knn_tree(const TreeArgs& a, hipStream_t s, KernelTimer t) {
     if (a.nq <= 0) return hipSuccess;
     // one wavefront per workgroup; every lane checks one flag per round, so nq / 64 wavefronts cover the
     // scan in a single round trip (capped: large scans loop)
     int blocks = (a.nq + 63) / 64;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(knn_tree_kernel, dim3(blocks), dim3(64), 0, s, a);
+    if (t.start != nullptr) hipExtLaunchKernelGGL(knn_tree_kernel, dim3(blocks), dim3(64), 0, s, t.start, t.stop, 0, a);
+    else hipLaunchKernelGGL(knn_tree_kernel, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -236,15 +236,20 @@ int residual_blocks(int nq) { return (nq + 255) / 256; }
 
 // 256 lanes per workgroup: 512 measured the same and 1024 slower on MI355X (the kernel is a chain of
 // dependent round trips, not throughput-bound)
-hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool ext, hipStream_t s) {
-    if (a.nq <= 0) return hipSuccess;
+template <bool EXT, bool SEARCH>
+static void launch_residual_v(const ResidualArgs& a, hipStream_t s, KernelTimer t) {
     const dim3 grid(residual_blocks(a.nq)), block(256);
+    if (t.start != nullptr) hipExtLaunchKernelGGL((residual_kernel<EXT, SEARCH, 256>), grid, block, 0, s, t.start, t.stop, 0, a);
+    else hipLaunchKernelGGL((residual_kernel<EXT, SEARCH, 256>), grid, block, 0, s, a);
+}
+hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool ext, hipStream_t s, KernelTimer t) {
+    if (a.nq <= 0) return hipSuccess;
     if (ext) {
-        if (do_search) hipLaunchKernelGGL((residual_kernel<true, true, 256>), grid, block, 0, s, a);
-        else           hipLaunchKernelGGL((residual_kernel<true, false, 256>), grid, block, 0, s, a);
+        if (do_search) launch_residual_v<true, true>(a, s, t);
+        else           launch_residual_v<true, false>(a, s, t);
     } else {
-        if (do_search) hipLaunchKernelGGL((residual_kernel<false, true, 256>), grid, block, 0, s, a);
-        else           hipLaunchKernelGGL((residual_kernel<false, false, 256>), grid, block, 0, s, a);
+        if (do_search) launch_residual_v<false, true>(a, s, t);
+        else           launch_residual_v<false, false>(a, s, t);
     }
     return hipGetLastError();
 }

@@ -182,14 +182,14 @@ int  lio_get_neighbors(lio_ctx* ctx, float* out_xyz, float* out_sqdist, int* out
 int  lio_get_scan_state(lio_ctx* ctx, float* world_xyz, uint8_t* selected, float* normvec);
 int  lio_scan_size(lio_ctx* ctx);
 
-/* ---- timing hooks (HIP events on lio_stream around each kernel family) ------------------------ */
+/* ---- timing hooks (a HIP event pair per launch, stamped by the dispatch itself on lio_stream) -------- */
 #define LIO_PROF_KNN       0    /* 27-cell k-NN kernel                                              */
 #define LIO_PROF_FALLBACK  1    /* exact tree walk for unresolved queries                           */
 #define LIO_PROF_RESIDUAL  2    /* plane fit + residual + Jacobian + H^T H reduction + result record */
 #define LIO_PROF_REDUCE    3    /* (fused into LIO_PROF_RESIDUAL since the last-arriver reduction; 0) */
 #define LIO_PROF_COUNT     4
 /* on = 0: off; 1: every family; otherwise a bit mask of (1 << LIO_PROF_x) | 0x100 (0x100 marks a mask,
- * e.g. 0x100 | 1 << LIO_PROF_KNN times only the k-NN kernel: 2 event records per search pass)        */
+ * e.g. 0x100 | 1 << LIO_PROF_KNN times only the k-NN kernel: one event pair per search pass)              */
 int  lio_profile_enable(lio_ctx* ctx, int on);
 /* candidate census: when on, search passes also report lio_out.n_candidates (costs one device
  * atomic per wavefront of the k-NN kernel, so it is off by default and never on in timed runs)    */
