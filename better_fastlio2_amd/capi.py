@@ -56,7 +56,7 @@ class lio_update_log(C.Structure):
 EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_stream", "lio_synchronize",
     "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_fov_segment", "lio_map_reconstruct",
-    "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_get_info", "lio_map_nearest_search",
+    "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_acquire_removed_points", "lio_map_get_info", "lio_map_nearest_search",
     "lio_scan_set", "lio_scan_set_device", "lio_scan_undistort", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
@@ -119,6 +119,7 @@ def load(build_if_missing: bool = True):
     L.lio_map_validnum.argtypes = [_vp]
     L.lio_map_validnum.restype = C.c_longlong
     L.lio_map_flatten.argtypes = [_vp, _vp, C.c_longlong, C.POINTER(C.c_longlong)]
+    L.lio_map_acquire_removed_points.argtypes = [_vp, _vp, C.c_longlong, C.POINTER(C.c_longlong)]
     L.lio_map_get_info.argtypes = [_vp, C.POINTER(lio_map_info)]
     L.lio_map_nearest_search.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
     L.lio_scan_set.argtypes = [_vp, _vp, C.c_int, C.c_int]
@@ -278,6 +279,14 @@ class LioContext:
         got = C.c_longlong(0)
         self._chk(self.L.lio_map_flatten(self.h, _ptr(out), n, C.byref(got)), "lio_map_flatten")
         return out[:min(n, got.value)]
+
+    def acquire_removed_points(self) -> np.ndarray:
+        """KD_TREE::acquire_removed_points (ikd_Tree.cpp:559-571): box-deleted points reclaimed since the last call."""
+        got = C.c_longlong(0)
+        self._chk(self.L.lio_map_acquire_removed_points(self.h, None, 0, C.byref(got)), "lio_map_acquire_removed_points")
+        out = np.zeros((max(got.value, 1), 3), np.float32)
+        self._chk(self.L.lio_map_acquire_removed_points(self.h, _ptr(out), got.value, C.byref(got)), "lio_map_acquire_removed_points")
+        return out[:got.value]
 
     def map_info(self) -> dict:
         info = lio_map_info()

@@ -49,6 +49,11 @@ struct lio_ctx {
     uint32_t* d_new_vals = nullptr;
     size_t cap_new = 0;
     bool have_map = false;
+    // acquire_removed_points: box-deleted points whose storage was reclaimed by a rebuild, not yet handed out
+    float4* d_removed = nullptr;
+    size_t cap_removed = 0;
+    uint32_t n_removed = 0;
+    uint32_t box_deleted_pending = 0;          // box tomb-stones still inside d_pts
 
     // local-map cube of lasermap_fov_segment (laserMapping.cpp:1132-1133)
     float localmap_min[3] = {0.f, 0.f, 0.f}, localmap_max[3] = {0.f, 0.f, 0.f};
@@ -312,6 +317,27 @@ int merge_rebuild(lio_ctx* c) {
     // merged (key, index) sequence over [old | new]
     HIPCHK(c, merge_pairs_identity(c->d_temp, c->temp_bytes, c->d_mkeys, c->d_new_keys, c->d_mkeys_tmp, c->d_new_vals,
                                    c->d_vals_tmp, n_old, n_new, s));
+    // Points_deleted (ikd_Tree.cpp:1338-1341): box-deleted points leave the storage in this rebuild
+    if (c->box_deleted_pending > 0) {
+        const size_t need = (size_t)c->n_removed + (size_t)c->box_deleted_pending;
+        if (need > c->cap_removed) {
+            size_t cap = c->cap_removed ? c->cap_removed : 65536;
+            while (cap < need) cap <<= 1;
+            float4* nb = nullptr;
+            HIPCHK(c, hipMalloc((void**)&nb, cap * sizeof(float4)));
+            if (c->n_removed > 0)
+                HIPCHK(c, hipMemcpyAsync(nb, c->d_removed, (size_t)c->n_removed * sizeof(float4), hipMemcpyDeviceToDevice, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (c->d_removed) (void)hipFree(c->d_removed);
+            c->d_removed = nb; c->cap_removed = cap;
+        }
+        HIPCHK(c, select_box_deleted_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_removed + c->n_removed, c->d_counters + 7, n_all, s));
+        uint32_t got = 0;
+        HIPCHK(c, hipMemcpyAsync(&got, c->d_counters + 7, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->n_removed += got;
+        c->box_deleted_pending = 0;
+    }
     // drop tomb-stones: final keys -> d_mkeys, gather indices -> d_vals
     HIPCHK(c, select_live_pairs(c->d_temp, c->temp_bytes, c->d_mkeys_tmp, c->d_vals_tmp, c->d_pts, c->d_mkeys, c->d_vals,
                                 c->d_counters + 3, n_all, s));
@@ -485,7 +511,7 @@ void lio_destroy(lio_ctx* c) {
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_ltable, c->d_new_keys, c->d_new_vals, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
                    c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
-                   c->d_partials, c->d_gpartials, c->d_tickets, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
+                   c->d_partials, c->d_gpartials, c->d_tickets, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_minmax,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
@@ -515,6 +541,7 @@ int lio_map_build(lio_ctx* c, const float* pts, long long n, int stride_bytes) {
     HIPCHK(c, hipSetDevice(c->device));
     int rc = upload_points(c, pts, (size_t)n, stride_bytes, c->d_pts_tmp);
     if (rc != LIO_OK) return rc;
+    c->box_deleted_pending = 0;                // Build drops the old nodes without recording them (ikd_Tree.cpp:353-358)
     return build_index(c, c->d_pts_tmp, (uint32_t)n);
 }
 int lio_map_build_device(lio_ctx* c, const void* d_pts_f4, long long n) {
@@ -523,6 +550,7 @@ int lio_map_build_device(lio_ctx* c, const void* d_pts_f4, long long n) {
     HIPCHK(c, hipSetDevice(c->device));
     if (n > 0)
         HIPCHK(c, hipMemcpyAsync(c->d_pts_tmp, d_pts_f4, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    c->box_deleted_pending = 0;
     return build_index(c, c->d_pts_tmp, (uint32_t)n);
 }
 int lio_map_reconstruct(lio_ctx* c, const float* pts, long long n, int stride_bytes) {
@@ -778,6 +806,7 @@ int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_delete
         total += (int)cnt;
     }
     c->n_live -= (uint32_t)total;
+    c->box_deleted_pending += (uint32_t)total;
     if (n_deleted) *n_deleted = total;
     return LIO_OK;
 }
@@ -856,6 +885,24 @@ int lio_map_flatten(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
     HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, m * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::memcpy(out_xyz, c->h_scratch, m * 3 * sizeof(float));
+    return LIO_OK;
+}
+
+int lio_map_acquire_removed_points(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
+    if (!c || !n || cap < 0) return LIO_ERR_INVALID_ARG;
+    *n = (long long)c->n_removed;
+    if (!out_xyz) return LIO_OK;                              // count only
+    if (cap < (long long)c->n_removed) return c->fail(LIO_ERR_CAPACITY, "lio_map_acquire_removed_points", "cap < removed points");
+    const size_t m = c->n_removed;
+    if (m == 0) return LIO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, m * 3 * sizeof(float));
+    if (rc != LIO_OK) return rc;
+    HIPCHK(c, launch_pack_xyz(c->d_removed, (uint32_t)m, (float*)c->d_scratch, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, m * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(out_xyz, c->h_scratch, m * 3 * sizeof(float));
+    c->n_removed = 0;                                         // Points_deleted.clear()  (ikd_Tree.cpp:567)
     return LIO_OK;
 }
 

@@ -113,6 +113,8 @@ size_t select_temp_bytes(size_t n);
 // order-preserving compaction of the live (w == 0) points of src into dst; *n_out = live count
 hipError_t select_live_points(void* temp, size_t temp_bytes, const float4* src, float4* dst,
                               uint32_t* n_out, size_t n, hipStream_t s);
+hipError_t select_box_deleted_points(void* temp, size_t temp_bytes, const float4* src, float4* dst, uint32_t* n_out,
+                                     size_t n, hipStream_t s);
 
 hipError_t coarsen_level(void* temp, size_t temp_bytes, const uint64_t* keys_in, const uint32_t* counts_in, size_t n,
                          uint64_t* keys_out, uint32_t* counts_out, uint32_t* n_out, hipStream_t s);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void delete_boxes_kernel(float4* pts, uint32_t
             if (bx[0] <= p.x && bx[3] > p.x && bx[1] <= p.y && bx[4] > p.y && bx[2] <= p.z && bx[5] > p.z) hit = true;
         }
         if (hit) {
-            p.w = 1.0f;
+            p.w = TOMB_BOX;
             pts[i] = p;
             atomicAdd(counter, 1u);
         }

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
                             float4 s = a.map_pts[i];
                             if (s.w != 0.0f) continue;
                             if (bmin[0] <= s.x && bmax[0] > s.x && bmin[1] <= s.y && bmax[1] > s.y && bmin[2] <= s.z && bmax[2] > s.z) {
-                                s.w = 1.0f;
+                                s.w = TOMB_DOWNSAMPLE;
                                 a.map_pts[i] = s;
                             }
                         }

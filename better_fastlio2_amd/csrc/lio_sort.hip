@@ -68,6 +68,14 @@ hipError_t select_live_points(void* temp, size_t temp_bytes, const float4* src, 
     return rocprim::select(temp, temp_bytes, src, dst, n_out, n, LivePoint(), s);
 }
 
+struct BoxDeletedPoint {
+    __device__ bool operator()(const float4& p) const { return p.w == TOMB_BOX; }
+};
+hipError_t select_box_deleted_points(void* temp, size_t temp_bytes, const float4* src, float4* dst, uint32_t* n_out,
+                                     size_t n, hipStream_t s) {
+    return rocprim::select(temp, temp_bytes, src, dst, n_out, n, BoxDeletedPoint(), s);
+}
+
 // next coarser tree level from the current one: keys >> 6, counts summed per run
 hipError_t coarsen_level(void* temp, size_t temp_bytes, const uint64_t* keys_in, const uint32_t* counts_in, size_t n,
                          uint64_t* keys_out, uint32_t* counts_out, uint32_t* n_out, hipStream_t s) {

@@ -134,6 +134,13 @@ long long lio_map_validnum(lio_ctx* ctx);           /* KD_TREE::validnum() (ikd_
 /* KD_TREE::flatten (ikd_Tree.cpp:1326-1352): live points, xyz packed; *n = live count (may exceed
  * cap, in which case only cap points were written).                                                */
 int  lio_map_flatten(lio_ctx* ctx, float* out_xyz, long long cap, long long* n);
+/* KD_TREE::acquire_removed_points (ikd_Tree.cpp:559-571, caller laserMapping.cpp:1127): the points removed
+ * by Delete_Point_Boxes (down-sample replacements are not reported, ikd_Tree.cpp:1339) whose storage has
+ * been reclaimed since the last call.  The reference reports a point when the rebuild thread happens to
+ * flatten its sub-tree; here every box-deleted point is reported exactly once, after the next index
+ * rebuild (any lio_map_add* / lio_map_incremental).  out_xyz == NULL: only *n (nothing is consumed);
+ * cap < *n: LIO_ERR_CAPACITY (nothing is consumed).                                                     */
+int  lio_map_acquire_removed_points(lio_ctx* ctx, float* out_xyz, long long cap, long long* n);
 int  lio_map_get_info(lio_ctx* ctx, lio_map_info* info);
 /* KD_TREE::Nearest_Search (ikd_Tree.cpp:367-397) for a batch of world-frame queries: out_xyz
  * [n*5*3], out_sqdist [n*5] ascending, out_count [n].  Unfilled slots: NaN / +inf.               */

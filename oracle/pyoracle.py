@@ -251,6 +251,8 @@ def ref_lib():
         L.ref_ikd_delete_boxes.argtypes = [C.c_void_p, _f32p, C.c_int]
         L.ref_ikd_flatten.restype = C.c_int
         L.ref_ikd_flatten.argtypes = [C.c_void_p, _f32p, C.c_int]
+        L.ref_ikd_acquire_removed.restype = C.c_int
+        L.ref_ikd_acquire_removed.argtypes = [C.c_void_p, _f32p, C.c_int]
         L.ref_ikd_quiesce.argtypes = [C.c_int]
         _ref = L
     return _ref
@@ -293,6 +295,11 @@ class RefIkdTree:
         out = np.zeros((n, 3), np.float32)
         c = self.L.ref_ikd_flatten(self.h, out, n)
         return out[:c]
+
+    def acquire_removed(self, cap: int = 1 << 22):
+        out = np.zeros((cap, 3), np.float32)
+        c = self.L.ref_ikd_acquire_removed(self.h, out, cap)
+        return out[:min(c, cap)]
 
     def knn(self, q, k: int = 5):
         q = _c32(q)

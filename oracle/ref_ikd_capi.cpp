@@ -90,6 +90,16 @@ int ref_ikd_flatten(void* h, float* out_xyz, int cap) {
     }
     return n;
 }
+// acquire_removed_points (ikd_Tree.cpp:559-571): box-deleted points recorded by the rebuilds so far.
+int ref_ikd_acquire_removed(void* h, float* out_xyz, int cap) {
+    PointVector st;
+    static_cast<Tree*>(h)->acquire_removed_points(st);
+    int n = (int)st.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        out_xyz[3 * i] = st[i].x; out_xyz[3 * i + 1] = st[i].y; out_xyz[3 * i + 2] = st[i].z;
+    }
+    return n;
+}
 // The rebuild pthread (ikd_Tree.cpp:201) may still be re-balancing a sub-tree after a mutation;
 // give it time to go idle so timing and visibility are stable.
 void ref_ikd_quiesce(int ms) { std::this_thread::sleep_for(std::chrono::milliseconds(ms)); }

@@ -378,6 +378,44 @@ def test_fov_segment_sliding_cube(gpu_capi, oracle, small_case):
     ctx.close()
 
 
+def test_acquire_removed_points(gpu_capi, oracle, small_case):
+    """KD_TREE::acquire_removed_points (ikd_Tree.cpp:559-571): box-deleted points are handed out exactly once,
+    after their storage is reclaimed; points replaced inside a down-sample voxel are not reported
+    (ikd_Tree.cpp:1339).  The reference reports a point only when a rebuild happens to flatten its sub-tree,
+    so its list must be a subset of ours; ours is the full set of box-deleted points."""
+    w = small_case["world"]
+    rng = np.random.default_rng(77)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=1024, max_map_points=400_000)
+    ctx.map_build(w.points)
+    key = lambda p: p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+    assert len(ctx.acquire_removed_points()) == 0
+    boxes = np.array([[-12.0, -9.0, -1.0, -4.0, 2.0, 2.5], [5.0, 1.0, -0.5, 9.5, 6.0, 4.0]], np.float32)
+    inside = np.zeros(len(w.points), bool)
+    for b in boxes:
+        inside |= np.all((w.points >= b[:3]) & (w.points < b[3:]), axis=1)
+    assert inside.sum() > 500
+    assert ctx.map_delete_boxes(boxes) == int(inside.sum())
+    assert len(ctx.acquire_removed_points()) == 0              # tomb-stones only: nothing reclaimed yet
+    # an insert batch with down-sampling: replaces points inside voxels (not reported) and triggers the rebuild
+    batch = (w.points[~inside][rng.choice((~inside).sum(), 3000, replace=False)] +
+             rng.uniform(-0.03, 0.03, (3000, 3))).astype(np.float32)
+    ctx.map_add(batch, True)
+    got = ctx.acquire_removed_points()
+    assert bits_equal(key(got), key(w.points[inside]))
+    assert len(ctx.acquire_removed_points()) == 0              # handed out once
+    if oracle.ref_available():
+        ref = oracle.RefIkdTree(0.2)
+        ref.build(w.points)
+        assert ref.delete_boxes(boxes) == int(inside.sum())
+        ref.add(batch, True)
+        ref.quiesce(300)
+        rr = ref.acquire_removed()
+        ours = {tuple(p) for p in got.tolist()}
+        assert all(tuple(p) in ours for p in rr.tolist())
+        assert ref.validnum() == ctx.map_validnum()
+    ctx.close()
+
+
 def test_search_after_map_mutation_ignores_stale_bound(gpu_capi, oracle, small_case):
     """The repeated-search bound (previous neighbours) must be dropped when the map changes between two
     searches of the same scan: delete a slab that holds many of the previous neighbours, search again."""
