@@ -142,9 +142,10 @@ bool is_pow2f(float v) {
     return v > 0.0f && std::frexp(v, &e) == 0.5f;
 }
 int auto_lanes(int nq) {
-    // measured on MI355X: 8 lanes per query wins from 24 k to 1 M queries (C2/C3/C5); very small
-    // scans have too few wavefronts to fill the chip and prefer wider groups
-    if (nq >= 8000) return 8;
+    // measured on MI355X: 8 lanes per query wins at 100 k and 1 M queries (C2/C5: the kernel is VALU-bound and
+    // 8 lanes waste the fewest instructions); at 24 k (C3) there are too few wavefronts to fill 256 CUs and
+    // 16 lanes are 5 % faster; very small scans prefer wider groups still
+    if (nq >= 40000) return 8;
     if (nq >= 2000) return 16;
     return 32;
 }
