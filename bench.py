@@ -57,6 +57,15 @@ def dist_setup(n_gpus: int):
     import torch
     import torch.distributed as dist
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # every rank drives its GPU from one polling host thread: give the ranks disjoint core sets so that two
+    # of them never share a core
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+        if per >= 1:
+            os.sched_setaffinity(0, set(cores[local * per:(local + 1) * per]))
+    except (AttributeError, OSError):
+        pass
     torch.cuda.set_device(local)
     # RCCL prints a version banner on stdout when the communicator is created; create it now, with
     # stdout pointed at stderr, so that rank 0's stdout carries nothing but the JSON line
