@@ -44,7 +44,8 @@ class lio_out(C.Structure):
 class lio_map_info(C.Structure):
     _fields_ = [("n_points", C.c_longlong), ("n_live", C.c_longlong), ("n_cells", C.c_longlong),
                 ("table_slots", C.c_longlong), ("cell_size", C.c_float), ("downsample_size", C.c_float),
-                ("bytes_resident", C.c_longlong)]
+                ("bytes_resident", C.c_longlong), ("n_retired", C.c_longlong), ("n_incremental_updates", C.c_longlong),
+                ("n_full_rebuilds", C.c_longlong)]
 
 
 class lio_update_log(C.Structure):

@@ -37,9 +37,12 @@ constexpr uint64_t KEY_EMPTY = ~0ull;
 constexpr uint64_t KEY64_MAX = ~0ull;         // "no candidate" in the (sqdist bits, index) ordering
 constexpr uint32_t INF_BITS = 0x7f800000u;    // +inf as fp32 bits
 // tomb-stones live in the w lane of a map point: 0 = live, TOMB_BOX = removed by Delete_Point_Boxes,
-// TOMB_DOWNSAMPLE = replaced inside its down-sample voxel (point_downsample_deleted, ikd_Tree.cpp:662-700)
+// TOMB_DOWNSAMPLE = replaced inside its down-sample voxel (point_downsample_deleted, ikd_Tree.cpp:662-700),
+// TOMB_MOVED = not a deletion at all: the slot of a bucket that has been re-written elsewhere
 constexpr float TOMB_BOX = 1.0f;
 constexpr float TOMB_DOWNSAMPLE = 2.0f;
+constexpr float TOMB_BOX_REPORTED = 4.0f;    // box-deleted and already handed out by acquire_removed_points
+constexpr float TOMB_MOVED = 3.0f;           // the live copy is in the bucket re-written at the tail (lio_mapadd.hip)
 
 struct HashEntry {                            // 16 bytes: one global_load_dwordx4
     uint32_t key_lo, key_hi;                  // packed cell key (x << 42 | y << 21 | z), KEY_EMPTY = free

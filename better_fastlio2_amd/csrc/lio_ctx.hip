@@ -43,11 +43,20 @@ struct lio_ctx {
     uint32_t* d_counters = nullptr;            // [0] n_unresolved, [1] reduction ticket, [2..3] build/add scratch, [4] run counts
     unsigned long long* d_cand = nullptr;
     float* d_boxes = nullptr;                  // up to 64 boxes
-    uint32_t n_points = 0, n_live = 0, n_cells = 0;
-    uint32_t n_sorted = 0;                     // d_pts[0..n_sorted) is the Morton-sorted, indexed prefix
-    uint64_t* d_new_keys = nullptr;            // sorted keys / indices of the appended points (merge_rebuild)
-    uint32_t* d_new_vals = nullptr;
-    size_t cap_new = 0;
+    uint32_t n_points = 0, n_live = 0, n_cells = 0;   // slots in use (live + tomb-stones + retired copies), live points, cells
+    size_t slots_cap = 0;                      // physical slots of d_pts / d_pts_tmp (cap_map + room for re-written buckets)
+    uint32_t n_retired = 0;                    // TOMB_MOVED slots since the last full rebuild
+    long long n_incremental_updates = 0, n_full_rebuilds = 0;
+    uint32_t n_new_cells = 0, n_cells_built = 0;   // cells inserted since / present at the last full rebuild
+    // points appended by Add_Points, waiting for apply_pending (batch order)
+    float4* d_pend = nullptr;
+    size_t cap_pend = 0;
+    uint32_t n_pend = 0;
+    uint64_t *d_pkeys = nullptr, *d_pkeys2 = nullptr, *d_pcell = nullptr;
+    uint32_t *d_porder = nullptr, *d_porder2 = nullptr, *d_pgcount = nullptr, *d_pgstart = nullptr, *d_pnewsize = nullptr,
+             *d_pnewoff = nullptr;
+    CellPlan* d_plan = nullptr;
+    uint32_t* d_apply = nullptr;               // [0..2] apply stats, [3] touched cells, [4] fold: replaced points
     bool have_map = false;
     // acquire_removed_points: box-deleted points whose storage was reclaimed by a rebuild, not yet handed out
     float4* d_removed = nullptr;
@@ -192,7 +201,8 @@ int upload_points(lio_ctx* c, const float* pts, size_t n, int stride_bytes, floa
 // keys.  Run-length encode the cells, fill the level-0 hash table, derive the coarser tree levels.
 int finish_index(lio_ctx* c, uint32_t n) {
     hipStream_t s = c->stream;
-    c->n_points = n; c->n_live = n; c->n_sorted = n; c->n_cells = 0;
+    c->n_points = n; c->n_live = n; c->n_cells = 0;
+    c->n_retired = 0; c->n_new_cells = 0; c->n_cells_built = 0;
     c->grid.n_points = n;
     HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_mkeys, n, c->d_cell_keys, c->d_cell_counts,
                                     c->d_counters + 4, s));
@@ -217,13 +227,13 @@ int finish_index(lio_ctx* c, uint32_t n) {
     HIPCHK(c, launch_table_insert(c->d_cell_keys, c->d_cell_starts, c->d_cell_counts, n_cells, c->d_table,
                                   (uint32_t)(slots - 1), s));
     c->grid.table_mask = (uint32_t)(slots - 1);
-    c->n_cells = n_cells;
+    c->n_cells = n_cells; c->n_cells_built = n_cells;
 
     // ---- coarser levels of the hashed 64-ary tree (exact fallback of the k-NN): level L+1 is a
     // reduce-by-key of level L (keys >> 6, counts summed) -- the point array is not touched again
     TreeLevels lv{};
     const uint64_t diff = kfirst ^ klast;
-    int top = 0;
+    int top = 1;                               // the root is always an internal node: its children are level-0 cells at least
     if (diff != 0) top = (63 - __builtin_clzll(diff)) / 6 + 1;
     lv.top_level = top;
     {
@@ -266,6 +276,7 @@ int finish_index(lio_ctx* c, uint32_t n) {
     HIPCHK(c, hipStreamSynchronize(s));
     c->levels = lv;
     c->have_map = true;
+    ++c->n_full_rebuilds;
     return LIO_OK;
 }
 
@@ -275,7 +286,8 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
     c->have_map = false;
     c->hint_valid = false;                     // neighbours of an older map state no longer bound a search
     if (n == 0) {
-        c->n_points = 0; c->n_live = 0; c->n_sorted = 0; c->n_cells = 0;
+        c->n_points = 0; c->n_live = 0; c->n_cells = 0;
+        c->n_retired = 0; c->n_new_cells = 0; c->n_cells_built = 0;
         c->grid.n_points = 0;
         // empty map: an all-empty table keeps the kernels well defined
         HIPCHK(c, hipMemsetAsync(c->d_table, 0xFF, c->table_slots * sizeof(HashEntry), s));
@@ -291,64 +303,101 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
     return finish_index(c, n);
 }
 
-// Rebuild after Add_Points / tomb-stoning: c->d_pts = [sorted prefix of n_sorted points, possibly with
-// tomb-stones | appended points in insertion order].  Only the appended points are sorted; they are
-// MERGED into the sorted prefix (stable: old before new inside a cell, exactly what a full stable
-// sort would give), tomb-stones are dropped on the way, then the tables are rebuilt.
-int merge_rebuild(lio_ctx* c) {
+// box-deleted points not handed out yet -> the tail of d_removed (they stay tomb-stones in d_pts, re-marked)
+int collect_box_deleted(lio_ctx* c) {
+    hipStream_t s = c->stream;
+    if (c->box_deleted_pending == 0 || c->n_points == 0) { c->box_deleted_pending = 0; return LIO_OK; }
+    const size_t need = (size_t)c->n_removed + (size_t)c->box_deleted_pending;
+    if (need > c->cap_removed) {
+        size_t cap = c->cap_removed ? c->cap_removed : 65536;
+        while (cap < need) cap <<= 1;
+        float4* nb = nullptr;
+        HIPCHK(c, hipMalloc((void**)&nb, cap * sizeof(float4)));
+        if (c->n_removed > 0)
+            HIPCHK(c, hipMemcpyAsync(nb, c->d_removed, (size_t)c->n_removed * sizeof(float4), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->d_removed) (void)hipFree(c->d_removed);
+        c->d_removed = nb; c->cap_removed = cap;
+    }
+    HIPCHK(c, select_box_deleted_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_removed + c->n_removed, c->d_counters + 7, c->n_points, s));
+    HIPCHK(c, launch_mark_reported(c->d_pts, c->n_points, s));
+    uint32_t got = 0;
+    HIPCHK(c, hipMemcpyAsync(&got, c->d_counters + 7, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->n_removed += got;
+    c->box_deleted_pending = 0;
+    return LIO_OK;
+}
+
+// Full rebuild: the live points in array order (a bucket is contiguous, so the order inside a cell is kept),
+// then the pending points, re-sorted and re-hashed.  Run when the tail is full, when the retired slots or
+// the new cells have grown past their budget, or when a new cell lies outside the root of the tree.
+int rebuild_full(lio_ctx* c) {
     hipStream_t s = c->stream;
     c->have_map = false;
     c->hint_valid = false;
-    const uint32_t n_old = c->n_sorted, n_all = c->n_points, n_new = n_all - n_old;
-    if (n_all == 0) return build_index(c, c->d_pts_tmp, 0);
-    if (n_new > 0) {
-        if ((size_t)n_new > c->cap_new) {
-            if (c->d_new_keys) (void)hipFree(c->d_new_keys);
-            if (c->d_new_vals) (void)hipFree(c->d_new_vals);
-            c->d_new_keys = nullptr; c->d_new_vals = nullptr; c->cap_new = 0;
-            size_t cap = 65536;
-            while (cap < n_new) cap <<= 1;
-            HIPCHK(c, hipMalloc((void**)&c->d_new_keys, cap * sizeof(uint64_t)));
-            HIPCHK(c, hipMalloc((void**)&c->d_new_vals, cap * sizeof(uint32_t)));
-            c->cap_new = cap;
-        }
-        HIPCHK(c, launch_point_keys(c->d_pts + n_old, n_new, c->grid, c->d_mkeys_tmp, c->d_vals_tmp, s, n_old));
-        HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_mkeys_tmp, c->d_new_keys, c->d_vals_tmp, c->d_new_vals, n_new, s));
-    }
-    // merged (key, index) sequence over [old | new]
-    HIPCHK(c, merge_pairs_identity(c->d_temp, c->temp_bytes, c->d_mkeys, c->d_new_keys, c->d_mkeys_tmp, c->d_new_vals,
-                                   c->d_vals_tmp, n_old, n_new, s));
+    const uint32_t n_all = c->n_points;
     // Points_deleted (ikd_Tree.cpp:1338-1341): box-deleted points leave the storage in this rebuild
-    if (c->box_deleted_pending > 0) {
-        const size_t need = (size_t)c->n_removed + (size_t)c->box_deleted_pending;
-        if (need > c->cap_removed) {
-            size_t cap = c->cap_removed ? c->cap_removed : 65536;
-            while (cap < need) cap <<= 1;
-            float4* nb = nullptr;
-            HIPCHK(c, hipMalloc((void**)&nb, cap * sizeof(float4)));
-            if (c->n_removed > 0)
-                HIPCHK(c, hipMemcpyAsync(nb, c->d_removed, (size_t)c->n_removed * sizeof(float4), hipMemcpyDeviceToDevice, s));
-            HIPCHK(c, hipStreamSynchronize(s));
-            if (c->d_removed) (void)hipFree(c->d_removed);
-            c->d_removed = nb; c->cap_removed = cap;
-        }
-        HIPCHK(c, select_box_deleted_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_removed + c->n_removed, c->d_counters + 7, n_all, s));
-        uint32_t got = 0;
-        HIPCHK(c, hipMemcpyAsync(&got, c->d_counters + 7, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        c->n_removed += got;
-        c->box_deleted_pending = 0;
+    {
+        const int rc = collect_box_deleted(c);
+        if (rc != LIO_OK) return rc;
     }
-    // drop tomb-stones: final keys -> d_mkeys, gather indices -> d_vals
-    HIPCHK(c, select_live_pairs(c->d_temp, c->temp_bytes, c->d_mkeys_tmp, c->d_vals_tmp, c->d_pts, c->d_mkeys, c->d_vals,
-                                c->d_counters + 3, n_all, s));
     uint32_t live = 0;
-    HIPCHK(c, hipMemcpyAsync(&live, c->d_counters + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (n_all > 0) {
+        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_pts_tmp, c->d_counters + 3, n_all, s));
+        HIPCHK(c, hipMemcpyAsync(&live, c->d_counters + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    if ((size_t)live + (size_t)c->n_pend > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
+    if (c->n_pend > 0)
+        HIPCHK(c, hipMemcpyAsync(c->d_pts_tmp + live, c->d_pend, (size_t)c->n_pend * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    const uint32_t n = live + c->n_pend;
+    c->n_pend = 0;
+    return build_index(c, c->d_pts_tmp, n);
+}
+
+// The pending points enter the index: O(batch), the rest of the map is not touched (lio_mapadd.hip).
+int apply_pending(lio_ctx* c) {
+    hipStream_t s = c->stream;
+    c->hint_valid = false;
+    if (c->n_pend == 0) return LIO_OK;
+    if (!c->have_map || c->n_live == 0 || c->n_points == 0) return rebuild_full(c);
+    const uint32_t n = c->n_pend;
+    HIPCHK(c, launch_pend_keys(c->d_pend, n, c->grid, c->d_pkeys, c->d_porder, s));
+    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_pkeys, c->d_pkeys2, c->d_porder, c->d_porder2, (size_t)n, s));
+    HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_pkeys2, (size_t)n, c->d_pcell, c->d_pgcount, c->d_apply + 3, s));
+    HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pgcount, c->d_pgstart, (size_t)n, s));
+    HIPCHK(c, hipMemsetAsync(c->d_apply, 0, 3 * sizeof(uint32_t), s));
+    HIPCHK(c, hipMemsetAsync(c->d_pnewsize, 0, ((size_t)n + 1) * sizeof(uint32_t), s));
+    ApplyArgs a{};
+    a.map_pts = c->d_pts; a.table = c->d_table; a.grid = c->grid; a.ltable = c->d_ltable;
+    for (int L = 0; L < 12; ++L) { a.loff[L] = c->levels.off[L]; a.lmask[L] = c->levels.mask[L]; }
+    a.top_level = c->levels.top_level; a.top_cx = c->levels.top_cx; a.top_cy = c->levels.top_cy; a.top_cz = c->levels.top_cz;
+    a.pend = c->d_pend; a.order = c->d_porder2; a.cell_key = c->d_pcell; a.group_start = c->d_pgstart;
+    a.group_count = c->d_pgcount; a.n_groups = c->d_apply + 3; a.plan = c->d_plan; a.new_size = c->d_pnewsize;
+    a.new_off = c->d_pnewoff; a.tail = c->n_points; a.stats = c->d_apply;
+    HIPCHK(c, launch_cell_plan(a, n, s));
+    // entries past the touched cells are zero, so element n of the scan is the total
+    HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pnewsize, c->d_pnewoff, (size_t)n + 1, s));
+    uint32_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, c->d_pnewoff + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (live == 0) return build_index(c, c->d_pts_tmp, 0);
-    HIPCHK(c, launch_gather_points(c->d_pts, c->d_vals, live, c->d_pts_tmp, s));
-    std::swap(c->d_pts, c->d_pts_tmp);             // the gathered array becomes the map
-    return finish_index(c, live);
+    if ((size_t)c->n_points + (size_t)total > c->slots_cap) return rebuild_full(c);
+    HIPCHK(c, launch_cell_apply(a, n, s));
+    uint32_t st[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(st, c->d_apply, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->n_points += total;
+    c->grid.n_points = c->n_points;
+    c->n_live += n;
+    c->n_pend = 0;
+    c->n_cells += st[0]; c->n_new_cells += st[0]; c->n_retired += st[1];
+    ++c->n_incremental_updates;
+    const uint32_t retired_budget = c->n_live / 8 > 65536u ? c->n_live / 8 : 65536u;
+    if (st[2] != 0 || c->n_retired > retired_budget || (size_t)c->n_new_cells * 4 > (size_t)c->n_cells_built + 1024)
+        return rebuild_full(c);
+    return LIO_OK;
 }
 
 // resolve every recorded pair (needs the stream drained) and recycle the pool
@@ -452,8 +501,14 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
 
     const size_t nm = (size_t)cfg->max_map_points;
     c->cap_map = nm;
-    CREATE_CHK(hipMalloc((void**)&c->d_pts, nm * sizeof(float4)));
-    CREATE_CHK(hipMalloc((void**)&c->d_pts_tmp, nm * sizeof(float4)));
+    // buckets that receive points are re-written at the tail of the array; the room for that is ours, not the
+    // caller's (max_map_points bounds the live points)
+    c->slots_cap = nm + nm / 4 + 262144;
+    if (c->slots_cap > 0xfffffff0ull) c->slots_cap = 0xfffffff0ull;
+    CREATE_CHK(hipMalloc((void**)&c->d_pts, c->slots_cap * sizeof(float4)));
+    CREATE_CHK(hipMalloc((void**)&c->d_pts_tmp, c->slots_cap * sizeof(float4)));
+    CREATE_CHK(hipMalloc((void**)&c->d_apply, 8 * sizeof(uint32_t)));
+    CREATE_CHK(hipMemset(c->d_apply, 0, 8 * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_mkeys, nm * sizeof(uint64_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_mkeys_tmp, nm * sizeof(uint64_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_vals, nm * sizeof(uint32_t)));
@@ -464,8 +519,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     size_t tb = sort_pairs_temp_bytes(nm);
     size_t t2 = rle_temp_bytes(nm); if (t2 > tb) tb = t2;
     t2 = scan_temp_bytes(nm); if (t2 > tb) tb = t2;
-    t2 = select_temp_bytes(nm); if (t2 > tb) tb = t2;
-    t2 = merge_temp_bytes(nm, nm); if (t2 > tb) tb = t2;
+    t2 = select_temp_bytes(c->slots_cap); if (t2 > tb) tb = t2;
     c->temp_bytes = tb + 256;
     CREATE_CHK(hipMalloc(&c->d_temp, c->temp_bytes));
     c->table_slots = 1024;
@@ -476,9 +530,6 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_cand, sizeof(unsigned long long)));
     CREATE_CHK(hipMemset(c->d_cand, 0, sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc((void**)&c->d_boxes, 64 * 6 * sizeof(float)));
-    c->cap_new = 65536;
-    CREATE_CHK(hipMalloc((void**)&c->d_new_keys, c->cap_new * sizeof(uint64_t)));
-    CREATE_CHK(hipMalloc((void**)&c->d_new_vals, c->cap_new * sizeof(uint32_t)));
 
     const size_t nq = (size_t)cfg->max_scan_points;
     c->cap_q = cfg->max_scan_points;
@@ -510,7 +561,7 @@ void lio_destroy(lio_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
-                   c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_ltable, c->d_new_keys, c->d_new_vals, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
+                   c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
                    c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
                    c->d_partials, c->d_gpartials, c->d_tickets, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
@@ -561,11 +612,20 @@ int lio_map_reconstruct(lio_ctx* c, const float* pts, long long n, int stride_by
 // ---- Add_Points machinery (ikd_Tree.cpp:414-489) --------------------------------------------------
 static int ensure_add_buffers(lio_ctx* c, size_t n) {
     if (n <= c->cap_add) return LIO_OK;
+    if (c->n_pend != 0) {                      // left behind by a call that failed half-way: index them first
+        const int rc = apply_pending(c);
+        if (rc != LIO_OK) return rc;
+    }
     void* old[] = {c->d_add_pts, c->d_add_pts2, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys, c->d_add_order,
-                   c->d_add_order2, c->d_add_gcount, c->d_add_gstart, c->d_add_cls};
+                   c->d_add_order2, c->d_add_gcount, c->d_add_gstart, c->d_add_cls,
+                   c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart,
+                   c->d_pnewsize, c->d_pnewoff, c->d_plan};
     for (void* p : old) if (p) (void)hipFree(p);
     c->d_add_pts = c->d_add_pts2 = c->d_add_out = nullptr; c->d_add_keys = c->d_add_keys2 = c->d_add_ukeys = nullptr;
     c->d_add_order = c->d_add_order2 = c->d_add_gcount = c->d_add_gstart = nullptr; c->d_add_cls = nullptr; c->cap_add = 0;
+    c->d_pend = nullptr; c->d_pkeys = c->d_pkeys2 = c->d_pcell = nullptr;
+    c->d_porder = c->d_porder2 = c->d_pgcount = c->d_pgstart = c->d_pnewsize = c->d_pnewoff = nullptr; c->d_plan = nullptr;
+    c->cap_pend = 0;
     HIPCHK(c, hipMalloc((void**)&c->d_add_pts, n * sizeof(float4)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_pts2, n * sizeof(float4)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_out, n * sizeof(float4)));
@@ -578,20 +638,36 @@ static int ensure_add_buffers(lio_ctx* c, size_t n) {
     HIPCHK(c, hipMalloc((void**)&c->d_add_gstart, n * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_cls, n));
     c->cap_add = n;
+    // the pair Add_Points(add, true) + Add_Points(nodown, false) is applied together: two batches pending
+    const size_t np = 2 * n + 2;
+    HIPCHK(c, hipMalloc((void**)&c->d_pend, np * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_pkeys, np * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_pkeys2, np * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_pcell, np * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_porder, np * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_porder2, np * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_pgcount, np * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_pgstart, np * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_pnewsize, np * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_pnewoff, np * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_plan, np * sizeof(CellPlan)));
+    c->cap_pend = np;
     return LIO_OK;
 }
 
 // One Add_Points call on a device-resident batch (float4, batch order = insertion order), WITHOUT
-// rebuilding the index: down-sampled inserts fold per voxel against the indexed points (tomb-stoning
-// what they replace) and append the survivors; plain inserts are appended as they are.  `batch` is
-// clobbered when downsample_on.  At most one down-sampled call per rebuild (appended points are not
-// in the index yet).
+// touching the index: down-sampled inserts fold per voxel against the indexed points (tomb-stoning
+// what they replace) and leave the survivors pending; plain inserts are left pending as they are.  `batch`
+// is clobbered when downsample_on.  At most one down-sampled call per apply_pending (pending points are
+// not in the index yet).
 static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsample_on, int* n_added) {
     hipStream_t s = c->stream;
     if (n_added) *n_added = 0;
     if (n == 0) return LIO_OK;
-    if ((size_t)c->n_points + (size_t)n > c->cap_map)
-        return c->fail(LIO_ERR_CAPACITY, "Add_Points", "stored points + batch exceed max_map_points");
+    if ((size_t)c->n_live + (size_t)c->n_pend + (size_t)n > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
+    if ((size_t)c->n_pend + (size_t)n > c->cap_pend)
+        return c->fail(LIO_ERR_CAPACITY, "Add_Points", "pending buffer too small");
     uint32_t n_append = n;
     if (downsample_on) {
         const float ds = c->cfg.filter_size_map_min;
@@ -605,27 +681,30 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
         HIPCHK(c, hipStreamSynchronize(s));
         HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, n_groups, s));
         HIPCHK(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(uint32_t), s));
+        HIPCHK(c, hipMemsetAsync(c->d_apply + 4, 0, sizeof(uint32_t), s));
         FoldArgs fa{};
         fa.map_pts = c->d_pts; fa.table = c->d_table; fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch;
         fa.order = c->d_add_order2; fa.group_start = c->d_add_gstart; fa.group_count = c->d_add_gcount;
-        fa.n_groups = n_groups; fa.out_pts = c->d_add_out; fa.n_added = c->d_counters + 2;
+        fa.n_groups = n_groups; fa.out_pts = c->d_add_out; fa.n_added = c->d_counters + 2; fa.n_replaced = c->d_apply + 4;
         HIPCHK(c, launch_fold_groups(fa, s));
         // survivors (w == 0) -> front of `batch` (the batch itself is no longer needed)
         HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_counters + 3, n_groups, s));
-        uint32_t host_cnt[2] = {0, 0};
+        uint32_t host_cnt[2] = {0, 0}, replaced = 0;
         HIPCHK(c, hipMemcpyAsync(host_cnt, c->d_counters + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&replaced, c->d_apply + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         if (n_added) *n_added = (int)host_cnt[0];
         n_append = host_cnt[1];
+        c->n_live -= replaced;                     // points of the map replaced inside their down-sample voxel
     }
     if (n_append > 0)
-        HIPCHK(c, hipMemcpyAsync(c->d_pts + c->n_points, batch, (size_t)n_append * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    c->n_points += n_append;
+        HIPCHK(c, hipMemcpyAsync(c->d_pend + c->n_pend, batch, (size_t)n_append * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    c->n_pend += n_append;
     return LIO_OK;
 }
 
-// drop tomb-stones, merge the appended points into the sorted prefix, re-hash
-static int rebuild_from_stored(lio_ctx* c) { return merge_rebuild(c); }
+// the appended points enter the index (incrementally, or through a full rebuild when budgets are exceeded)
+static int rebuild_from_stored(lio_ctx* c) { return apply_pending(c); }
 
 // Add_Points (ikd_Tree.cpp:414-489).  Returns through *n_added what the reference returns: the number
 // of down-sampled inserts that changed the tree (tmp_counter), 0 when downsample_on is false.
@@ -634,8 +713,8 @@ int lio_map_add(lio_ctx* c, const float* pts, int n, int stride_bytes, int downs
     if (n_added) *n_added = 0;
     if (n == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    if ((size_t)c->n_points + (size_t)n > c->cap_map)
-        return c->fail(LIO_ERR_CAPACITY, "lio_map_add", "stored points + batch exceed max_map_points");
+    if ((size_t)c->n_live + (size_t)n > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "lio_map_add", "live points + batch exceed max_map_points");
     int rc = ensure_add_buffers(c, (size_t)n);
     if (rc != LIO_OK) return rc;
     rc = upload_points(c, pts, (size_t)n, stride_bytes, c->d_add_pts);
@@ -654,8 +733,8 @@ int lio_map_add_pair(lio_ctx* c, const float* add_pts, int n_add, const float* n
     if (add_counter) *add_counter = 0;
     if (n_add + n_nodown == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    if ((size_t)c->n_points + (size_t)n_add + (size_t)n_nodown > c->cap_map)
-        return c->fail(LIO_ERR_CAPACITY, "lio_map_add_pair", "stored points + batches exceed max_map_points");
+    if ((size_t)c->n_live + (size_t)n_add + (size_t)n_nodown > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "lio_map_add_pair", "live points + batches exceed max_map_points");
     int rc = ensure_add_buffers(c, (size_t)(n_add > n_nodown ? n_add : n_nodown));
     if (rc != LIO_OK) return rc;
     if (n_add > 0) {
@@ -756,8 +835,8 @@ int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const v
     if (add_counter) *add_counter = 0;
     if (n_add + n_nodown == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    if ((size_t)c->n_points + (size_t)n_add + (size_t)n_nodown > c->cap_map)
-        return c->fail(LIO_ERR_CAPACITY, "lio_map_add_pair_device", "stored points + batches exceed max_map_points");
+    if ((size_t)c->n_live + (size_t)n_add + (size_t)n_nodown > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "lio_map_add_pair_device", "live points + batches exceed max_map_points");
     // stage into the context's own batch buffers (the fold clobbers its input; the caller's may be ours)
     const size_t need = (size_t)(n_add > n_nodown ? n_add : n_nodown);
     if (need > c->cap_add) {
@@ -785,7 +864,7 @@ int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const v
     return rebuild_from_stored(c);
 }
 
-long long lio_map_size(lio_ctx* c) { return c ? (long long)c->n_points : 0; }
+long long lio_map_size(lio_ctx* c) { return c ? (long long)c->n_points - (long long)c->n_retired : 0; }
 long long lio_map_validnum(lio_ctx* c) { return c ? (long long)c->n_live : 0; }
 
 int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_deleted) {
@@ -891,6 +970,11 @@ int lio_map_flatten(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
 
 int lio_map_acquire_removed_points(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
     if (!c || !n || cap < 0) return LIO_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    {
+        const int rc0 = collect_box_deleted(c);
+        if (rc0 != LIO_OK) return rc0;
+    }
     *n = (long long)c->n_removed;
     if (!out_xyz) return LIO_OK;                              // count only
     if (cap < (long long)c->n_removed) return c->fail(LIO_ERR_CAPACITY, "lio_map_acquire_removed_points", "cap < removed points");
@@ -912,6 +996,7 @@ int lio_map_get_info(lio_ctx* c, lio_map_info* info) {
     info->n_points = c->n_points; info->n_live = c->n_live; info->n_cells = c->n_cells;
     info->table_slots = (long long)c->grid.table_mask + 1;
     info->cell_size = c->grid.cell; info->downsample_size = c->cfg.filter_size_map_min;
+    info->n_retired = c->n_retired; info->n_incremental_updates = c->n_incremental_updates; info->n_full_rebuilds = c->n_full_rebuilds;
     info->bytes_resident = (long long)c->n_points * (long long)(sizeof(float4) + sizeof(uint64_t)) +
                            (long long)(c->grid.table_mask + 1ll) * (long long)sizeof(HashEntry);
     return LIO_OK;
@@ -944,10 +1029,13 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
     float* dd = (float*)((char*)c->d_scratch + b_xyz);
     int* dc = (int*)((char*)c->d_scratch + b_xyz + b_d);
     HIPCHK(c, launch_unpack_neighbors(c->d_qs_nbr, c->d_qs_cnt, n, n, dx, dd, dc, c->stream));
+    uint32_t walked = 0;
+    HIPCHK(c, hipMemcpyAsync(&walked, c->d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, b_xyz + b_d + b_c, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (walked & 0x80000000u) return c->fail(LIO_ERR_HIP, "lio_map_nearest_search", "tree walk exceeded its stack bound");
     if (out_xyz) std::memcpy(out_xyz, c->h_scratch, b_xyz);
     if (out_sqdist) std::memcpy(out_sqdist, (char*)c->h_scratch + b_xyz, b_d);
     if (out_count) std::memcpy(out_count, (char*)c->h_scratch + b_xyz + b_d, b_c);
@@ -1154,6 +1242,7 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     }
 
     const DeviceOut& d = *c->h_out;
+    if (d.n_unresolved < 0) return c->fail(LIO_ERR_HIP, "lio_measure", "tree walk exceeded its stack bound");
     out->m = d.m;
     out->valid = d.m >= 1 ? 1 : 0;                        // laserMapping.cpp:1956-1961
     out->n_unresolved = d.n_unresolved;

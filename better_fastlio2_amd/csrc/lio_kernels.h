@@ -91,6 +91,7 @@ hipError_t launch_delete_boxes(float4* pts, uint32_t n, const float* boxes6, int
                                hipStream_t s);
 // stream compaction of live points (w == 0) into dst; *n_out = count.  Order-preserving.
 hipError_t launch_pack_xyz(const float4* src, uint32_t n, float* dst_xyz, hipStream_t s);
+hipError_t launch_mark_reported(float4* pts, uint32_t n, hipStream_t s);
 hipError_t launch_unpack_neighbors(const float4* nbr, const uint8_t* cnt, int nq, int nq_stride,
                                    float* out_xyz, float* out_d, int* out_cnt, hipStream_t s);
 

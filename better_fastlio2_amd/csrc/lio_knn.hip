@@ -394,8 +394,11 @@ hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s, Ke
 // LDS stack nearest-on-top, and scan leaf ranges 64 points at a time; the running top-5 is
 // wave-uniform and candidates are merged with DPP min reductions.
 // ---------------------------------------------------------------------------------------------
-constexpr int TREE_STACK = 384;
-constexpr uint32_t TREE_LEAF_POINTS = 128;       // ranges this small are scanned, not descended
+// Only level-0 cells are leaves: their buckets are the one thing that is contiguous in the point array
+// (a bucket moves to the tail of the array when points are added to its cell, lio_mapadd.hip).  A pop
+// pushes at most 63 net entries and the tree is at most 11 levels deep (21-bit cell coordinates).
+constexpr int TREE_STACK = 704;
+constexpr uint32_t TREE_OVERFLOW = 0x80000000u;  // or-ed into n_unresolved if the stack bound were ever violated
 
 // squared distance from q to the box of cell (cx,cy,cz) at `level` (edge = cell * 4^level); same
 // fp32 expression form as sqdist3, so it never exceeds the computed distance of a point inside.
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(64) void knn_tree_kernel(TreeArgs a) {
         // ---- phase B: best-first walk of the whole tree, pruned by what phase A already holds
         int sp = 0;
         if (a.grid.n_points > 0) {
-            if (lane == 0) {
+            if (lane == 0) {                              // the root is always an internal node (top_level >= 1)
                 s_node[0] = make_uint4(0u, a.grid.n_points, (uint32_t)a.levels.top_level, 0u);
                 s_cell[0] = make_uint4(a.levels.top_cx, a.levels.top_cy, a.levels.top_cz, 0u);
             }
@@ -588,8 +591,8 @@ __global__ __launch_bounds__(64) void knn_tree_kernel(TreeArgs a) {
             __builtin_amdgcn_wave_barrier();
             if (__uint_as_float(nd.w) > top.tau()) continue;
             const int level = (int)nd.z;
-            if (level == 0 || nd.y <= TREE_LEAF_POINTS) {
-                // leaf: stream the contiguous range, 64 points per round
+            if (level == 0) {
+                // leaf: stream the bucket, 64 points per round
                 for (uint32_t base = 0; base < nd.y; base += 64) {
                     const uint32_t i = base + (uint32_t)lane;
                     u64 key = KEY64_MAX;
@@ -624,19 +627,8 @@ __global__ __launch_bounds__(64) void knn_tree_kernel(TreeArgs a) {
                 const float bj = __shfl(bd, j, 64);
                 rank += (bj > bd || (bj == bd && j < lane)) ? 1 : 0;
             }
-            if (sp + nw > TREE_STACK) {
-                // cannot happen for depth <= 10 with 64-way fan-out pruned by tau; keep exactness anyway:
-                // scan the children in place instead of pushing them
-                for (u64 mm = wm; mm != 0; mm &= mm - 1) {
-                    const int j = __ffsll((long long)mm) - 1;
-                    const uint32_t cst = __shfl(st, j, 64), cct = __shfl(ct, j, 64);
-                    for (uint32_t base = 0; base < cct; base += 64) {
-                        const uint32_t i = base + (uint32_t)lane;
-                        u64 key = KEY64_MAX;
-                        if (i < cct) key = candidate_key(qx, qy, qz, a.map_pts[cst + i], cst + i);
-                        top.merge(key);
-                    }
-                }
+            if (sp + nw > TREE_STACK) {                    // unreachable (see TREE_STACK); reported, never silent
+                if (lane == 0) atomicOr(a.n_unresolved, TREE_OVERFLOW);
                 continue;
             }
             if (want) {

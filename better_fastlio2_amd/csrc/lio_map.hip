@@ -68,6 +68,12 @@ __global__ __launch_bounds__(256) void delete_boxes_kernel(float4* pts, uint32_t
     }
 }
 
+// box-deleted points that have just been copied out for acquire_removed_points are not reported again
+__global__ __launch_bounds__(256) void mark_reported_kernel(float4* pts, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (pts[i].w == TOMB_BOX) pts[i].w = TOMB_BOX_REPORTED;
+}
+
 __global__ __launch_bounds__(256) void pack_xyz_kernel(const float4* src, uint32_t n, float* dst) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = src[i];
@@ -120,6 +126,11 @@ hipError_t launch_table_insert(const uint64_t* cell_mkeys, const uint32_t* cell_
 hipError_t launch_delete_boxes(float4* pts, uint32_t n, const float* boxes6, int nb, uint32_t* counter, hipStream_t s) {
     if (n == 0 || nb <= 0) return hipSuccess;
     hipLaunchKernelGGL(delete_boxes_kernel, grid_for(n), dim3(256), 0, s, pts, n, boxes6, nb, counter);
+    return hipGetLastError();
+}
+hipError_t launch_mark_reported(float4* pts, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(mark_reported_kernel, grid_for(n), dim3(256), 0, s, pts, n);
     return hipGetLastError();
 }
 hipError_t launch_pack_xyz(const float4* src, uint32_t n, float* dst_xyz, hipStream_t s) {

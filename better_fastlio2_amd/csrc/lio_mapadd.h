@@ -17,6 +17,7 @@ struct FoldArgs {
     uint32_t         n_groups;
     float4*          out_pts;       // per group: survivor to append (w == 0) or nothing (w == 1)
     uint32_t*        n_added;       // += tmp_counter of ikd_Tree.cpp:448
+    uint32_t*        n_replaced;    // += points of the map tomb-stoned by the fold (validnum bookkeeping)
 };
 struct IncrArgs {
     const float4*  body;            // feats_down_body
@@ -29,6 +30,37 @@ struct IncrArgs {
     float4*        world;           // feats_down_world at the posterior pose
     uint8_t*       cls;             // 0 skip, 1 PointToAdd, 2 PointNoNeedDownsample
 };
+// ---- incremental index update: appended points enter the index without re-sorting the map ---------------
+// The batch is grouped by grid cell (stable sort: batch order inside a cell).  A touched cell's bucket is
+// re-written at the tail of the point array -- its live points in their old order, then the new ones --
+// the old slots become TOMB_MOVED, and only that cell's table entry changes.  New cells are inserted into
+// the level-0 table and, as existence marks, into the coarser levels of the tree.
+struct CellPlan { uint32_t old_start, old_count, slot, found; };
+struct ApplyArgs {
+    float4*          map_pts;
+    HashEntry*       table;         // level-0 table
+    Grid             grid;
+    HashEntry*       ltable;        // levels >= 1
+    uint32_t         loff[12], lmask[12];
+    int              top_level;
+    uint32_t         top_cx, top_cy, top_cz;
+    const float4*    pend;          // appended points, batch order
+    const uint32_t*  order;         // pending indices sorted by cell key (stable)
+    const uint64_t*  cell_key;      // per touched cell: packed key
+    const uint32_t*  group_start;   // per touched cell: first position in `order`
+    const uint32_t*  group_count;
+    const uint32_t*  n_groups;      // device-resident count of touched cells
+    CellPlan*        plan;          // [touched cells]
+    uint32_t*        new_size;      // [touched cells] live old points + new points
+    const uint32_t*  new_off;       // exclusive scan of new_size
+    uint32_t         tail;          // first free slot of the point array
+    uint32_t*        stats;         // [0] new cells, [1] old slots retired, [2] flags (APPLY_FLAG_*)
+};
+constexpr uint32_t APPLY_FLAG_OUTSIDE_TOP = 1u;   // a new cell lies outside the root node of the tree
+constexpr uint32_t APPLY_FLAG_TABLE_FULL = 2u;    // an insertion probe wrapped around a table
+hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, hipStream_t s);
+hipError_t launch_cell_plan(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);
+hipError_t launch_cell_apply(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);
 hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s);
 hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, hipStream_t s);
 hipError_t launch_fold_groups(const FoldArgs& a, hipStream_t s);

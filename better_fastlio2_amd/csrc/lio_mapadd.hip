@@ -98,6 +98,7 @@ __global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
         }
         // ---- pass 2: Delete_by_range of the box + Add_by_point of the survivor --------------------
         float4 outp = make_float4(0.f, 0.f, 0.f, 1.0f);      // w = 1: nothing to append
+        uint32_t replaced = 0;
         if (touched) {
             for (int cx = c0[0]; cx <= c1[0]; ++cx)
                 for (int cy = c0[1]; cy <= c1[1]; ++cy)
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
                             if (bmin[0] <= s.x && bmax[0] > s.x && bmin[1] <= s.y && bmax[1] > s.y && bmin[2] <= s.z && bmax[2] > s.z) {
                                 s.w = TOMB_DOWNSAMPLE;
                                 a.map_pts[i] = s;
+                                ++replaced;
                             }
                         }
                     }
@@ -117,6 +119,104 @@ __global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
         }
         a.out_pts[g] = outp;
         if (counter != 0) atomicAdd(a.n_added, counter);
+        if (replaced != 0) atomicAdd(a.n_replaced, replaced);
+    }
+}
+
+// ---- incremental index update -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pend_keys_kernel(const float4* pend, uint32_t n, Grid grid, uint64_t* keys,
+                                                        uint32_t* order) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = pend[i];
+        keys[i] = pack_key((uint32_t)cell_coord(p.x, grid.inv_cell), (uint32_t)cell_coord(p.y, grid.inv_cell),
+                           (uint32_t)cell_coord(p.z, grid.inv_cell));
+        order[i] = i;
+    }
+}
+
+// one lane per touched cell: where the cell is now and how large its re-written bucket will be
+__global__ __launch_bounds__(64) void cell_plan_kernel(ApplyArgs a) {
+    const uint32_t n_groups = *a.n_groups;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
+        const uint64_t key = a.cell_key[g];
+        const uint4* table = reinterpret_cast<const uint4*>(a.table);
+        uint32_t slot = hash_key(key) & a.grid.table_mask;
+        CellPlan pl{0u, 0u, 0u, 0u};
+        for (uint32_t probes = 0; probes <= a.grid.table_mask; ++probes) {
+            const uint4 e = table[slot];
+            const uint64_t ek = ((uint64_t)e.y << 32) | (uint64_t)e.x;
+            if (ek == key) { pl.old_start = e.z; pl.old_count = e.w; pl.slot = slot; pl.found = 1u; break; }
+            if (ek == KEY_EMPTY) break;
+            slot = (slot + 1) & a.grid.table_mask;
+        }
+        uint32_t live = 0;
+        for (uint32_t i = 0; i < pl.old_count; ++i) live += a.map_pts[pl.old_start + i].w == 0.0f ? 1u : 0u;
+        a.plan[g] = pl;
+        a.new_size[g] = live + a.group_count[g];
+    }
+}
+
+// find-or-insert of a cell key; returns the slot, or 0xffffffff when the table is full
+__device__ __forceinline__ uint32_t table_claim(HashEntry* table, uint32_t mask, uint64_t key) {
+    uint32_t slot = hash_key(key) & mask;
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+        unsigned long long* kp = reinterpret_cast<unsigned long long*>(&table[slot]);
+        const unsigned long long prev = atomicCAS(kp, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+        if (prev == KEY_EMPTY || prev == key) return slot;
+        slot = (slot + 1) & mask;
+    }
+    return 0xffffffffu;
+}
+
+__global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
+    const uint32_t n_groups = *a.n_groups;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
+        const CellPlan pl = a.plan[g];
+        const uint32_t dst0 = a.tail + a.new_off[g];
+        uint32_t dst = dst0;
+        uint32_t retired = 0;
+        for (uint32_t i = 0; i < pl.old_count; ++i) {           // live points keep their order
+            float4 p = a.map_pts[pl.old_start + i];
+            if (p.w != 0.0f) continue;
+            a.map_pts[dst++] = p;
+            p.w = TOMB_MOVED;
+            a.map_pts[pl.old_start + i] = p;
+            ++retired;
+        }
+        const uint32_t gs = a.group_start[g], gc = a.group_count[g];
+        for (uint32_t j = 0; j < gc; ++j) {                      // then the new ones, in batch order
+            const float4 p = a.pend[a.order[gs + j]];
+            a.map_pts[dst++] = make_float4(p.x, p.y, p.z, 0.0f);
+        }
+        const uint32_t count = dst - dst0;
+        if (retired != 0) atomicAdd(a.stats + 1, retired);
+        if (pl.found) {
+            a.table[pl.slot].start = dst0;
+            a.table[pl.slot].count = count;
+            continue;
+        }
+        // ---- a cell the map did not have ----------------------------------------------------------
+        const uint64_t key = a.cell_key[g];
+        const uint32_t slot = table_claim(a.table, a.grid.table_mask, key);
+        if (slot == 0xffffffffu) { atomicOr(a.stats + 2, APPLY_FLAG_TABLE_FULL); continue; }
+        a.table[slot].start = dst0;
+        a.table[slot].count = count;
+        atomicAdd(a.stats + 0, 1u);
+        const uint32_t cx = (uint32_t)(key >> 42) & 0x1fffffu, cy = (uint32_t)(key >> 21) & 0x1fffffu, cz = (uint32_t)key & 0x1fffffu;
+        const int sh_top = 2 * a.top_level;
+        if ((cx >> sh_top) != a.top_cx || (cy >> sh_top) != a.top_cy || (cz >> sh_top) != a.top_cz) {
+            atomicOr(a.stats + 2, APPLY_FLAG_OUTSIDE_TOP);
+            continue;
+        }
+        // existence marks on the coarser levels (the tree walk only asks "is this child non-empty")
+        for (int L = 1; L < a.top_level; ++L) {
+            const uint64_t ck = pack_key(cx >> (2 * L), cy >> (2 * L), cz >> (2 * L));
+            HashEntry* lt = a.ltable + a.loff[L];
+            const uint32_t ls = table_claim(lt, a.lmask[L], ck);
+            if (ls == 0xffffffffu) { atomicOr(a.stats + 2, APPLY_FLAG_TABLE_FULL); break; }
+            lt[ls].start = 0u;
+            lt[ls].count = 1u;
+        }
     }
 }
 
@@ -161,6 +261,24 @@ hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint32_t b = (n + 255u) / 256u; if (b > 4096u) b = 4096u;
+    hipLaunchKernelGGL(pend_keys_kernel, dim3(b), dim3(256), 0, s, pend, n, grid, keys, order);
+    return hipGetLastError();
+}
+hipError_t launch_cell_plan(const ApplyArgs& a, uint32_t max_groups, hipStream_t s) {
+    if (max_groups == 0) return hipSuccess;
+    uint32_t b = (max_groups + 63u) / 64u; if (b > 8192u) b = 8192u;
+    hipLaunchKernelGGL(cell_plan_kernel, dim3(b), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_cell_apply(const ApplyArgs& a, uint32_t max_groups, hipStream_t s) {
+    if (max_groups == 0) return hipSuccess;
+    uint32_t b = (max_groups + 63u) / 64u; if (b > 8192u) b = 8192u;
+    hipLaunchKernelGGL(cell_apply_kernel, dim3(b), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
 hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint32_t b = (n + 255u) / 256u; if (b > 4096u) b = 4096u;

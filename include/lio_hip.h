@@ -74,13 +74,16 @@ typedef struct lio_out {
 } lio_out;
 
 typedef struct lio_map_info {
-    long long n_points;         /* stored points (live + tomb-stoned)                                     */
+    long long n_points;         /* slots in use: live + tomb-stoned + retired copies of re-written buckets */
     long long n_live;           /* validnum()                                                             */
     long long n_cells;          /* occupied neighbour-grid cells                                          */
     long long table_slots;      /* hash-table capacity                                                    */
     float     cell_size;
     float     downsample_size;
     long long bytes_resident;   /* device bytes held by the map index                                     */
+    long long n_retired;        /* slots whose bucket has been re-written at the tail since the last full rebuild */
+    long long n_incremental_updates;  /* Add_Points batches indexed in O(batch) since lio_create          */
+    long long n_full_rebuilds;  /* full re-sort + re-hash passes since lio_create (Build included)        */
 } lio_map_info;
 
 /* ---- context -------------------------------------------------------------------------------- */
@@ -135,11 +138,10 @@ long long lio_map_validnum(lio_ctx* ctx);           /* KD_TREE::validnum() (ikd_
  * cap, in which case only cap points were written).                                                */
 int  lio_map_flatten(lio_ctx* ctx, float* out_xyz, long long cap, long long* n);
 /* KD_TREE::acquire_removed_points (ikd_Tree.cpp:559-571, caller laserMapping.cpp:1127): the points removed
- * by Delete_Point_Boxes (down-sample replacements are not reported, ikd_Tree.cpp:1339) whose storage has
- * been reclaimed since the last call.  The reference reports a point when the rebuild thread happens to
- * flatten its sub-tree; here every box-deleted point is reported exactly once, after the next index
- * rebuild (any lio_map_add* / lio_map_incremental).  out_xyz == NULL: only *n (nothing is consumed);
- * cap < *n: LIO_ERR_CAPACITY (nothing is consumed).                                                     */
+ * by Delete_Point_Boxes since the last call (down-sample replacements are not reported, ikd_Tree.cpp:1339).
+ * The reference reports a point when the rebuild thread happens to flatten its sub-tree; here every
+ * box-deleted point is reported exactly once, by the first call after its deletion.  out_xyz == NULL: only
+ * *n (nothing is consumed); cap < *n: LIO_ERR_CAPACITY (nothing is consumed).                          */
 int  lio_map_acquire_removed_points(lio_ctx* ctx, float* out_xyz, long long cap, long long* n);
 int  lio_map_get_info(lio_ctx* ctx, lio_map_info* info);
 /* KD_TREE::Nearest_Search (ikd_Tree.cpp:367-397) for a batch of world-frame queries: out_xyz

@@ -307,6 +307,106 @@ def test_map_incremental_sequence(gpu_capi, oracle, synth, small_case):
     ctx.close()
 
 
+def test_incremental_index_stress(gpu_capi, oracle, small_case):
+    """The O(batch) index update (buckets re-written at the tail, new cells inserted into the table and
+    the tree levels) against the reference ikd-Tree over a long mutation sequence: small batches (incremental
+    path), a large one (retired-slot budget -> full rebuild), box deletes in between, territory the map never
+    had (new cells, then cells outside the root of the tree).  After every step: validnum, the live set, and
+    Nearest_Search for near AND far queries (the far ones take the tree walk through the new cells)."""
+    if not oracle.ref_available():
+        pytest.skip("reference ikd-Tree not built")
+    w = small_case["world"]
+    rng = np.random.default_rng(4242)
+    base = np.ascontiguousarray(w.points[::2])
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=4096, max_map_points=600_000)
+    ctx.map_build(base)
+    ref = oracle.RefIkdTree(0.2); ref.build(base)
+    key = lambda p: p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+    lo, hi = base.min(0), base.max(0)
+
+    def queries(extra):
+        near = base[rng.choice(len(base), 600, replace=False)] + rng.normal(0, 0.05, (600, 3))
+        far = rng.uniform(lo - 40.0, hi + 40.0, (300, 3))
+        far[:, 2] = rng.uniform(-3.0, 25.0, 300)
+        return np.concatenate([near, far, extra]).astype(np.float32)
+
+    def check(extra=np.zeros((0, 3), np.float32)):
+        assert ctx.map_validnum() == ref.validnum()
+        q = queries(extra)
+        gx, gd, gc = ctx.nearest_search(q)
+        rx, rd, rc, _ = ref.knn(q, 5)
+        assert np.array_equal(gc, rc)
+        assert bits_equal(gd, rd)                       # distances always; points where the 5th/6th do not tie
+        rx6, rd6, rc6, _ = ref.knn(q, 6)
+        tie_free = np.array([len(np.unique(rd6[i, :rc6[i]])) == rc6[i] for i in range(len(q))])
+        assert tie_free.mean() > 0.95 and bits_equal(gx[tie_free], rx[tie_free])
+
+    info0 = ctx.map_info()
+    # 1. small down-sampled batches: jittered copies of map points and points in the gaps of the thinned map
+    for k in range(6):
+        src = w.points[1::2][rng.choice(len(w.points) // 2, 2500, replace=False)]
+        batch = (src + rng.uniform(-0.02, 0.02, src.shape)).astype(np.float32)
+        assert ctx.map_add(batch, True) == ref.add(batch, True)
+        if k % 2 == 1:
+            c0 = np.array([rng.uniform(lo[0] + 5, hi[0] - 5), rng.uniform(lo[1] + 5, hi[1] - 5), 1.0])
+            box = np.concatenate([c0 - 2.5, c0 + 2.5]).astype(np.float32)[None]
+            assert ctx.map_delete_boxes(box) == ref.delete_boxes(box)
+        ref.quiesce(100)
+        check()
+    info1 = ctx.map_info()
+    assert info1["n_incremental_updates"] - info0["n_incremental_updates"] == 6
+    assert info1["n_full_rebuilds"] == info0["n_full_rebuilds"] and info1["n_retired"] > 0
+    # 2. plain (no down-sampling) inserts into territory next to the map: new cells, new tree nodes
+    strip = rng.uniform([hi[0] + 1.0, lo[1], 0.0], [hi[0] + 30.0, hi[1], 6.0], (4000, 3)).astype(np.float32)
+    assert ctx.map_add(strip, False) == ref.add(strip, False) == 0
+    ref.quiesce(100)
+    check(strip[:200] + np.float32(0.01))
+    info2 = ctx.map_info()
+    assert info2["n_cells"] > info1["n_cells"]
+    # 3. a batch large enough to exceed the retired-slot budget: full rebuild, same answers
+    big = (w.points[1::2] + rng.uniform(-0.02, 0.02, w.points[1::2].shape)).astype(np.float32)
+    assert ctx.map_add(big, True) == ref.add(big, True)
+    ref.quiesce(300)
+    info3 = ctx.map_info()
+    assert info3["n_full_rebuilds"] == info2["n_full_rebuilds"] + 1 and info3["n_retired"] == 0
+    check()
+    # 4. points kilometres away (this map straddles the origin, so its root node already spans the whole grid)
+    away = (rng.uniform(-3.0, 3.0, (500, 3)) + np.array([4000.0, -2500.0, 10.0])).astype(np.float32)
+    assert ctx.map_add(away, False) == ref.add(away, False) == 0
+    ref.quiesce(100)
+    check(away[:100] + np.float32(0.02))
+    assert bits_equal(key(ctx.map_flatten()), key(ref.flatten()))
+    ctx.close()
+
+
+def test_incremental_insert_outside_tree_root(gpu_capi, oracle, small_case):
+    """A map inside one octant has a small root node; a new cell outside it cannot be hung into the tree
+    levels, so the update falls back to a full rebuild with a higher root -- and far queries (tree walk)
+    still find the new points."""
+    if not oracle.ref_available():
+        pytest.skip("reference ikd-Tree not built")
+    rng = np.random.default_rng(99)
+    base = (small_case["world"].points[::4] + np.array([1500.0, 1200.0, 300.0])).astype(np.float32)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=1024, max_map_points=200_000)
+    ctx.map_build(base)
+    ref = oracle.RefIkdTree(0.2); ref.build(base)
+    near = (base[:2000] + rng.uniform(-0.05, 0.05, (2000, 3))).astype(np.float32)
+    assert ctx.map_add(near, True) == ref.add(near, True)
+    i1 = ctx.map_info()
+    assert i1["n_incremental_updates"] == 1 and i1["n_full_rebuilds"] == 1
+    away = (rng.uniform(-3.0, 3.0, (400, 3)) + np.array([9000.0, 7000.0, 350.0])).astype(np.float32)
+    assert ctx.map_add(away, False) == ref.add(away, False) == 0
+    ref.quiesce(100)
+    assert ctx.map_info()["n_full_rebuilds"] == 2
+    q = np.concatenate([away[:150] + np.float32(0.02), base[:150] + np.float32(0.03),
+                        rng.uniform([1400, 1100, 250], [9100, 7100, 400], (200, 3))]).astype(np.float32)
+    gx, gd, gc = ctx.nearest_search(q)
+    rx, rd, rc, _ = ref.knn(q, 5)
+    assert np.array_equal(gc, rc) and bits_equal(gd, rd)
+    assert ctx.map_validnum() == ref.validnum()
+    ctx.close()
+
+
 def test_map_incremental_before_first_search(gpu_capi, small_case):
     """No neighbour lists yet (EKF not initialised / first scans): every point is a PointToAdd (:1487)."""
     sc, st = small_case["scan"], small_case["state14"]
@@ -380,7 +480,7 @@ def test_fov_segment_sliding_cube(gpu_capi, oracle, small_case):
 
 def test_acquire_removed_points(gpu_capi, oracle, small_case):
     """KD_TREE::acquire_removed_points (ikd_Tree.cpp:559-571): box-deleted points are handed out exactly once,
-    after their storage is reclaimed; points replaced inside a down-sample voxel are not reported
+    by the first call after the deletion; points replaced inside a down-sample voxel are not reported
     (ikd_Tree.cpp:1339).  The reference reports a point only when a rebuild happens to flatten its sub-tree,
     so its list must be a subset of ours; ours is the full set of box-deleted points."""
     w = small_case["world"]
@@ -394,15 +494,22 @@ def test_acquire_removed_points(gpu_capi, oracle, small_case):
     for b in boxes:
         inside |= np.all((w.points >= b[:3]) & (w.points < b[3:]), axis=1)
     assert inside.sum() > 500
-    assert ctx.map_delete_boxes(boxes) == int(inside.sum())
-    assert len(ctx.acquire_removed_points()) == 0              # tomb-stones only: nothing reclaimed yet
-    # an insert batch with down-sampling: replaces points inside voxels (not reported) and triggers the rebuild
+    half = int(inside.sum())
+    assert ctx.map_delete_boxes(boxes[:1]) + ctx.map_delete_boxes(boxes[1:]) == half
+    first = ctx.acquire_removed_points()                       # handed out while still tomb-stones in the array
+    in0 = np.all((w.points >= boxes[0, :3]) & (w.points < boxes[0, 3:]), axis=1)
+    assert 0 < in0.sum() < half and len(first) == half
+    # an insert batch with down-sampling: replaces points inside voxels (never reported)
     batch = (w.points[~inside][rng.choice((~inside).sum(), 3000, replace=False)] +
              rng.uniform(-0.03, 0.03, (3000, 3))).astype(np.float32)
     ctx.map_add(batch, True)
-    got = ctx.acquire_removed_points()
+    got = first
     assert bits_equal(key(got), key(w.points[inside]))
-    assert len(ctx.acquire_removed_points()) == 0              # handed out once
+    assert len(ctx.acquire_removed_points()) == 0              # handed out once, the down-sample replacements never
+    # a later delete is reported by the next call only
+    box3 = np.array([[-3.0, -3.0, -1.0, 3.0, 3.0, 3.0]], np.float32)
+    nd = ctx.map_delete_boxes(box3)
+    assert nd > 100 and len(ctx.acquire_removed_points()) == nd
     if oracle.ref_available():
         ref = oracle.RefIkdTree(0.2)
         ref.build(w.points)
@@ -412,6 +519,7 @@ def test_acquire_removed_points(gpu_capi, oracle, small_case):
         rr = ref.acquire_removed()
         ours = {tuple(p) for p in got.tolist()}
         assert all(tuple(p) in ours for p in rr.tolist())
+        assert ref.delete_boxes(box3) == nd
         assert ref.validnum() == ctx.map_validnum()
     ctx.close()
 
