@@ -380,14 +380,13 @@ int apply_pending(lio_ctx* c) {
     HIPCHK(c, launch_cell_plan(a, n, s));
     // entries past the touched cells are zero, so element n of the scan is the total
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pnewsize, c->d_pnewoff, (size_t)n + 1, s));
-    uint32_t total = 0;
-    HIPCHK(c, hipMemcpyAsync(&total, c->d_pnewoff + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    if ((size_t)c->n_points + (size_t)total > c->slots_cap) return rebuild_full(c);
+    a.slots_cap = (uint32_t)c->slots_cap; a.n_scan = n;
     HIPCHK(c, launch_cell_apply(a, n, s));
-    uint32_t st[3] = {0, 0, 0};
+    uint32_t total = 0, st[3] = {0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(&total, c->d_pnewoff + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(st, c->d_apply, sizeof(st), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    if (st[2] & APPLY_FLAG_NO_ROOM) return rebuild_full(c);    // nothing was changed: the pending points go in there
     c->n_points += total;
     c->grid.n_points = c->n_points;
     c->n_live += n;
@@ -676,19 +675,19 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
                                      c->d_add_order2, (size_t)n, s));
         HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_add_keys2, (size_t)n, c->d_add_ukeys,
                                         c->d_add_gcount, c->d_counters + 4, s));
-        uint32_t n_groups = 0;
-        HIPCHK(c, hipMemcpyAsync(&n_groups, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, n_groups, s));
+        // the number of voxel groups stays on the device: launches are sized for the batch, the kernels read the
+        // real count (entries of the scan past it are never used)
+        HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, (size_t)n, s));
         HIPCHK(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(uint32_t), s));
         HIPCHK(c, hipMemsetAsync(c->d_apply + 4, 0, sizeof(uint32_t), s));
         FoldArgs fa{};
         fa.map_pts = c->d_pts; fa.table = c->d_table; fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch;
         fa.order = c->d_add_order2; fa.group_start = c->d_add_gstart; fa.group_count = c->d_add_gcount;
-        fa.n_groups = n_groups; fa.out_pts = c->d_add_out; fa.n_added = c->d_counters + 2; fa.n_replaced = c->d_apply + 4;
+        fa.n_groups = 0; fa.n_groups_dev = c->d_counters + 4; fa.n_groups_max = n;
+        fa.out_pts = c->d_add_out; fa.n_added = c->d_counters + 2; fa.n_replaced = c->d_apply + 4;
         HIPCHK(c, launch_fold_groups(fa, s));
         // survivors (w == 0) -> front of `batch` (the batch itself is no longer needed)
-        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_counters + 3, n_groups, s));
+        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_counters + 3, (size_t)n, s));
         uint32_t host_cnt[2] = {0, 0}, replaced = 0;
         HIPCHK(c, hipMemcpyAsync(host_cnt, c->d_counters + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(&replaced, c->d_apply + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

@@ -14,7 +14,9 @@ struct FoldArgs {
     const uint32_t*  order;         // batch indices sorted by voxel key (stable)
     const uint32_t*  group_start;   // per voxel group: first position in `order`
     const uint32_t*  group_count;
-    uint32_t         n_groups;
+    uint32_t         n_groups;      // number of voxel groups (used when n_groups_dev is null)
+    const uint32_t*  n_groups_dev;  // device-resident number of voxel groups (no host round trip)
+    uint32_t         n_groups_max;  // launch bound (>= the real number); groups past the real count emit "nothing"
     float4*          out_pts;       // per group: survivor to append (w == 0) or nothing (w == 1)
     uint32_t*        n_added;       // += tmp_counter of ikd_Tree.cpp:448
     uint32_t*        n_replaced;    // += points of the map tomb-stoned by the fold (validnum bookkeeping)
@@ -54,10 +56,13 @@ struct ApplyArgs {
     uint32_t*        new_size;      // [touched cells] live old points + new points
     const uint32_t*  new_off;       // exclusive scan of new_size
     uint32_t         tail;          // first free slot of the point array
+    uint32_t         slots_cap;     // physical slots of the point array
+    uint32_t         n_scan;        // new_off[n_scan] = total number of slots the re-written buckets need
     uint32_t*        stats;         // [0] new cells, [1] old slots retired, [2] flags (APPLY_FLAG_*)
 };
 constexpr uint32_t APPLY_FLAG_OUTSIDE_TOP = 1u;   // a new cell lies outside the root node of the tree
 constexpr uint32_t APPLY_FLAG_TABLE_FULL = 2u;    // an insertion probe wrapped around a table
+constexpr uint32_t APPLY_FLAG_NO_ROOM = 4u;       // the tail cannot hold the re-written buckets: nothing was changed
 hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, hipStream_t s);
 hipError_t launch_cell_plan(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);
 hipError_t launch_cell_apply(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);

@@ -37,8 +37,20 @@ __device__ __forceinline__ bool same_point(float4 a, float4 b) {         // ikd_
     return (double)fabsf(a.x - b.x) < 1e-6 && (double)fabsf(a.y - b.y) < 1e-6 && (double)fabsf(a.z - b.z) < 1e-6;
 }
 
+// Eight lanes per voxel group: the down-sample box (edge ds < cell edge) touches at most 2x2x2 grid cells, lane
+// t = 4 dx + 2 dy + dz takes one of them -- probe, bucket scan and tomb-stoning of the eight cells run side by
+// side instead of one after the other.  The reference visits the cells in (x, y, z) order and keeps the FIRST
+// minimum (strict `<`), which is the minimum over (distance, t) here.
 __global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < a.n_groups; g += gridDim.x * blockDim.x) {
+    const uint32_t n_groups = a.n_groups_dev != nullptr ? *a.n_groups_dev : a.n_groups;
+    const int t = threadIdx.x & 7;
+    const uint32_t gpw = 8u;                                    // groups per wavefront
+    for (uint32_t g0 = blockIdx.x * gpw; g0 < a.n_groups_max; g0 += gridDim.x * gpw) {
+        const uint32_t g = g0 + (threadIdx.x >> 3);
+        if (g >= n_groups) {
+            if (g < a.n_groups_max && t == 0) a.out_pts[g] = make_float4(0.f, 0.f, 0.f, 1.0f);   // nothing to append
+            continue;                                           // whole sub-group leaves together
+        }
         const uint32_t gs = a.group_start[g], gc = a.group_count[g];
         const float ds = a.ds;
         const float4 p0 = a.new_pts[a.order[gs]];
@@ -57,26 +69,35 @@ __global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
             c0[ax] = cell_coord(bmin[ax], a.grid.inv_cell);
             c1[ax] = cell_coord(bmax[ax], a.grid.inv_cell);
         }
+        const int cx = c0[0] + ((t >> 2) & 1), cy = c0[1] + ((t >> 1) & 1), cz = c0[2] + (t & 1);
+        const bool mine = cx <= c1[0] && cy <= c1[1] && cz <= c1[2];
         // ---- pass 1: existing live points inside the box (Search_by_range :1015-1045) -------------
+        uint32_t st = 0, ct = 0;
+        if (mine) table_find(a.table, a.grid.table_mask, pack_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz), st, ct);
         uint32_t n_e = 0;
         float d_e = __uint_as_float(INF_BITS);
         float4 e_best = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int cx = c0[0]; cx <= c1[0]; ++cx)
-            for (int cy = c0[1]; cy <= c1[1]; ++cy)
-                for (int cz = c0[2]; cz <= c1[2]; ++cz) {
-                    uint32_t st, ct;
-                    table_find(a.table, a.grid.table_mask, pack_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz), st, ct);
-                    for (uint32_t i = st; i < st + ct; ++i) {
-                        const float4 s = a.map_pts[i];
-                        if (s.w != 0.0f) continue;
-                        if (bmin[0] <= s.x && bmax[0] > s.x && bmin[1] <= s.y && bmax[1] > s.y && bmin[2] <= s.z && bmax[2] > s.z) {
-                            ++n_e;
-                            const float d = sqdist3(s.x, s.y, s.z, mid[0], mid[1], mid[2]);
-                            if (d < d_e) { d_e = d; e_best = s; }
-                        }
-                    }
-                }
-        // ---- sequential fold over the group's new points (:433-449) -------------------------------
+        for (uint32_t i = st; i < st + ct; ++i) {
+            const float4 sp = a.map_pts[i];
+            if (sp.w != 0.0f) continue;
+            if (bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z) {
+                ++n_e;
+                const float d = sqdist3(sp.x, sp.y, sp.z, mid[0], mid[1], mid[2]);
+                if (d < d_e) { d_e = d; e_best = sp; }
+            }
+        }
+        // combine the eight cells: count, and the first minimum in cell order
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            n_e += __shfl_xor(n_e, o, 64);
+            const float od = __shfl_xor(d_e, o, 64);
+            const float ox = __shfl_xor(e_best.x, o, 64), oy = __shfl_xor(e_best.y, o, 64), oz = __shfl_xor(e_best.z, o, 64);
+            // the partner holds the lower cell numbers iff its lane number is lower
+            const bool partner_first = ((t ^ o) < t);
+            const bool take = partner_first ? (od <= d_e) : (od < d_e);
+            if (take) { d_e = od; e_best = make_float4(ox, oy, oz, 0.0f); }
+        }
+        // ---- sequential fold over the group's new points (:433-449), identical in all eight lanes ------
         bool touched = false;
         float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
         float d_cur = 0.0f;
@@ -97,29 +118,23 @@ __global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
             }
         }
         // ---- pass 2: Delete_by_range of the box + Add_by_point of the survivor --------------------
-        float4 outp = make_float4(0.f, 0.f, 0.f, 1.0f);      // w = 1: nothing to append
         uint32_t replaced = 0;
         if (touched) {
-            for (int cx = c0[0]; cx <= c1[0]; ++cx)
-                for (int cy = c0[1]; cy <= c1[1]; ++cy)
-                    for (int cz = c0[2]; cz <= c1[2]; ++cz) {
-                        uint32_t st, ct;
-                        table_find(a.table, a.grid.table_mask, pack_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz), st, ct);
-                        for (uint32_t i = st; i < st + ct; ++i) {
-                            float4 s = a.map_pts[i];
-                            if (s.w != 0.0f) continue;
-                            if (bmin[0] <= s.x && bmax[0] > s.x && bmin[1] <= s.y && bmax[1] > s.y && bmin[2] <= s.z && bmax[2] > s.z) {
-                                s.w = TOMB_DOWNSAMPLE;
-                                a.map_pts[i] = s;
-                                ++replaced;
-                            }
-                        }
-                    }
-            outp = make_float4(cur.x, cur.y, cur.z, 0.0f);
+            for (uint32_t i = st; i < st + ct; ++i) {
+                float4 sp = a.map_pts[i];
+                if (sp.w != 0.0f) continue;
+                if (bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z) {
+                    sp.w = TOMB_DOWNSAMPLE;
+                    a.map_pts[i] = sp;
+                    ++replaced;
+                }
+            }
         }
-        a.out_pts[g] = outp;
-        if (counter != 0) atomicAdd(a.n_added, counter);
         if (replaced != 0) atomicAdd(a.n_replaced, replaced);
+        if (t == 0) {
+            a.out_pts[g] = touched ? make_float4(cur.x, cur.y, cur.z, 0.0f) : make_float4(0.f, 0.f, 0.f, 1.0f);
+            if (counter != 0) atomicAdd(a.n_added, counter);
+        }
     }
 }
 
@@ -170,6 +185,11 @@ __device__ __forceinline__ uint32_t table_claim(HashEntry* table, uint32_t mask,
 
 __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
     const uint32_t n_groups = *a.n_groups;
+    // room check on the device (every lane sees the same total): either the whole batch is applied or nothing is
+    if ((uint64_t)a.tail + (uint64_t)a.new_off[a.n_scan] > (uint64_t)a.slots_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.stats + 2, APPLY_FLAG_NO_ROOM);
+        return;
+    }
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
         const CellPlan pl = a.plan[g];
         const uint32_t dst0 = a.tail + a.new_off[g];
@@ -286,8 +306,8 @@ hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* 
     return hipGetLastError();
 }
 hipError_t launch_fold_groups(const FoldArgs& a, hipStream_t s) {
-    if (a.n_groups == 0) return hipSuccess;
-    uint32_t b = (a.n_groups + 63u) / 64u; if (b > 8192u) b = 8192u;
+    if (a.n_groups_max == 0) return hipSuccess;
+    uint32_t b = (a.n_groups_max + 7u) / 8u; if (b > 16384u) b = 16384u;
     hipLaunchKernelGGL(fold_groups_kernel, dim3(b), dim3(64), 0, s, a);
     return hipGetLastError();
 }
