@@ -17,6 +17,10 @@ def _hard_queries(case, oracle, n_scan=4000, seed=5):
         (rng.uniform(-1.3 * half, 1.3 * half, (2000, 3)) * [1, 1, 0.03]).astype(np.float32),   # map edge and beyond
         (rng.uniform(-half, half, (500, 3)) * [1, 1, 0.1] + [0, 0, 6]).astype(np.float32),      # above everything
         rng.uniform(-300, 300, (300, 3)).astype(np.float32),                                    # far away
+        # exact hits and near-hits: squared distance 0 / subnormal -- the k-NN kernel carries (distance bits,
+        # index) keys as doubles, and these keys are DENORMAL doubles (a flush would lose the index)
+        case["world"].points[::97][:1500].copy(),
+        (case["world"].points[5::131][:500] + np.float32(3e-23)).astype(np.float32),
         np.array([[1e4, -2e4, 50.0], [0, 0, 900.0], [-3e5, 1e5, 0]], np.float32)]))
 
 
@@ -45,7 +49,7 @@ def test_nearest_search_bit_exact(gpu_capi, oracle, small_case, lanes):
     # (all in-map queries; far queries collide in fp32: ulp(d^2) ~ 8 at 10 km) ...
     x6, d6, c6, _ = om.knn(q, 6, 1)
     tie_free = (np.diff(d6, axis=1) > 0).all(1)
-    assert tie_free[:4000].all() and tie_free.mean() > 0.95
+    assert tie_free[:4000].all() and tie_free.mean() > 0.95 and (od[:, 0] == 0).sum() >= 1500
     assert bits_equal(gx[tie_free], ox[tie_free])
     # ... and on tied rows every returned point must be a map point at exactly the reported distance
     mp = {p.tobytes() for p in small_case["world"].points}
