@@ -56,7 +56,8 @@ struct lio_ctx {
     uint32_t *d_porder = nullptr, *d_porder2 = nullptr, *d_pgcount = nullptr, *d_pgstart = nullptr, *d_pnewsize = nullptr,
              *d_pnewoff = nullptr;
     CellPlan* d_plan = nullptr;
-    uint32_t* d_apply = nullptr;               // [0..2] apply stats, [3] touched cells, [4] fold: replaced points
+    uint32_t* d_apply = nullptr;               // [0..2] apply stats, [3] new slots, [4] fold: replaced, [5] fold: tmp_counter,
+                                               // [6] survivors, [7] voxel groups, [8] touched cells
     bool have_map = false;
     // acquire_removed_points: box-deleted points whose storage was reclaimed by a rebuild, not yet handed out
     float4* d_removed = nullptr;
@@ -366,26 +367,24 @@ int apply_pending(lio_ctx* c) {
     const uint32_t n = c->n_pend;
     HIPCHK(c, launch_pend_keys(c->d_pend, n, c->grid, c->d_pkeys, c->d_porder, s));
     HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_pkeys, c->d_pkeys2, c->d_porder, c->d_porder2, (size_t)n, s));
-    HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_pkeys2, (size_t)n, c->d_pcell, c->d_pgcount, c->d_apply + 3, s));
+    HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_pkeys2, (size_t)n, c->d_pcell, c->d_pgcount, c->d_apply + 8, s));
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pgcount, c->d_pgstart, (size_t)n, s));
-    HIPCHK(c, hipMemsetAsync(c->d_apply, 0, 3 * sizeof(uint32_t), s));
-    HIPCHK(c, hipMemsetAsync(c->d_pnewsize, 0, ((size_t)n + 1) * sizeof(uint32_t), s));
     ApplyArgs a{};
     a.map_pts = c->d_pts; a.table = c->d_table; a.grid = c->grid; a.ltable = c->d_ltable;
     for (int L = 0; L < 12; ++L) { a.loff[L] = c->levels.off[L]; a.lmask[L] = c->levels.mask[L]; }
     a.top_level = c->levels.top_level; a.top_cx = c->levels.top_cx; a.top_cy = c->levels.top_cy; a.top_cz = c->levels.top_cz;
     a.pend = c->d_pend; a.order = c->d_porder2; a.cell_key = c->d_pcell; a.group_start = c->d_pgstart;
-    a.group_count = c->d_pgcount; a.n_groups = c->d_apply + 3; a.plan = c->d_plan; a.new_size = c->d_pnewsize;
+    a.group_count = c->d_pgcount; a.n_groups = c->d_apply + 8; a.plan = c->d_plan; a.new_size = c->d_pnewsize;
     a.new_off = c->d_pnewoff; a.tail = c->n_points; a.stats = c->d_apply;
-    HIPCHK(c, launch_cell_plan(a, n, s));
-    // entries past the touched cells are zero, so element n of the scan is the total
-    HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pnewsize, c->d_pnewoff, (size_t)n + 1, s));
     a.slots_cap = (uint32_t)c->slots_cap; a.n_scan = n;
+    HIPCHK(c, launch_cell_plan(a, n, s));
+    // entries past the touched cells are zero (written by the plan kernel), so element n of the scan is the total
+    HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pnewsize, c->d_pnewoff, (size_t)n + 1, s));
     HIPCHK(c, launch_cell_apply(a, n, s));
-    uint32_t total = 0, st[3] = {0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(&total, c->d_pnewoff + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    uint32_t st[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(st, c->d_apply, sizeof(st), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    const uint32_t total = st[3];
     if (st[2] & APPLY_FLAG_NO_ROOM) return rebuild_full(c);    // nothing was changed: the pending points go in there
     c->n_points += total;
     c->grid.n_points = c->n_points;
@@ -506,8 +505,8 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     if (c->slots_cap > 0xfffffff0ull) c->slots_cap = 0xfffffff0ull;
     CREATE_CHK(hipMalloc((void**)&c->d_pts, c->slots_cap * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_pts_tmp, c->slots_cap * sizeof(float4)));
-    CREATE_CHK(hipMalloc((void**)&c->d_apply, 8 * sizeof(uint32_t)));
-    CREATE_CHK(hipMemset(c->d_apply, 0, 8 * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_apply, 16 * sizeof(uint32_t)));
+    CREATE_CHK(hipMemset(c->d_apply, 0, 16 * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_mkeys, nm * sizeof(uint64_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_mkeys_tmp, nm * sizeof(uint64_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_vals, nm * sizeof(uint32_t)));
@@ -670,31 +669,28 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
     uint32_t n_append = n;
     if (downsample_on) {
         const float ds = c->cfg.filter_size_map_min;
-        HIPCHK(c, launch_voxel_keys(batch, n, ds, c->d_add_keys, c->d_add_order, s));
+        HIPCHK(c, launch_voxel_keys(batch, n, ds, c->d_add_keys, c->d_add_order, c->d_apply + 4, s));
         HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_add_keys, c->d_add_keys2, c->d_add_order,
                                      c->d_add_order2, (size_t)n, s));
         HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_add_keys2, (size_t)n, c->d_add_ukeys,
-                                        c->d_add_gcount, c->d_counters + 4, s));
+                                        c->d_add_gcount, c->d_apply + 7, s));
         // the number of voxel groups stays on the device: launches are sized for the batch, the kernels read the
         // real count (entries of the scan past it are never used)
         HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, (size_t)n, s));
-        HIPCHK(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(uint32_t), s));
-        HIPCHK(c, hipMemsetAsync(c->d_apply + 4, 0, sizeof(uint32_t), s));
         FoldArgs fa{};
         fa.map_pts = c->d_pts; fa.table = c->d_table; fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch;
         fa.order = c->d_add_order2; fa.group_start = c->d_add_gstart; fa.group_count = c->d_add_gcount;
-        fa.n_groups = 0; fa.n_groups_dev = c->d_counters + 4; fa.n_groups_max = n;
-        fa.out_pts = c->d_add_out; fa.n_added = c->d_counters + 2; fa.n_replaced = c->d_apply + 4;
+        fa.n_groups = 0; fa.n_groups_dev = c->d_apply + 7; fa.n_groups_max = n;
+        fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4;
         HIPCHK(c, launch_fold_groups(fa, s));
         // survivors (w == 0) -> front of `batch` (the batch itself is no longer needed)
-        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_counters + 3, (size_t)n, s));
-        uint32_t host_cnt[2] = {0, 0}, replaced = 0;
-        HIPCHK(c, hipMemcpyAsync(host_cnt, c->d_counters + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(&replaced, c->d_apply + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_apply + 6, (size_t)n, s));
+        uint32_t host_cnt[3] = {0, 0, 0};                  // replaced, tmp_counter, survivors
+        HIPCHK(c, hipMemcpyAsync(host_cnt, c->d_apply + 4, sizeof(host_cnt), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
-        if (n_added) *n_added = (int)host_cnt[0];
-        n_append = host_cnt[1];
-        c->n_live -= replaced;                     // points of the map replaced inside their down-sample voxel
+        if (n_added) *n_added = (int)host_cnt[1];
+        n_append = host_cnt[2];
+        c->n_live -= host_cnt[0];                     // points of the map replaced inside their down-sample voxel
     }
     if (n_append > 0)
         HIPCHK(c, hipMemcpyAsync(c->d_pend + c->n_pend, batch, (size_t)n_append * sizeof(float4), hipMemcpyDeviceToDevice, s));

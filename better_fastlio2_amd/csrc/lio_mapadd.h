@@ -58,7 +58,7 @@ struct ApplyArgs {
     uint32_t         tail;          // first free slot of the point array
     uint32_t         slots_cap;     // physical slots of the point array
     uint32_t         n_scan;        // new_off[n_scan] = total number of slots the re-written buckets need
-    uint32_t*        stats;         // [0] new cells, [1] old slots retired, [2] flags (APPLY_FLAG_*)
+    uint32_t*        stats;         // [0] new cells, [1] old slots retired, [2] flags (APPLY_FLAG_*), [3] total new slots
 };
 constexpr uint32_t APPLY_FLAG_OUTSIDE_TOP = 1u;   // a new cell lies outside the root node of the tree
 constexpr uint32_t APPLY_FLAG_TABLE_FULL = 2u;    // an insertion probe wrapped around a table
@@ -67,7 +67,7 @@ hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t*
 hipError_t launch_cell_plan(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);
 hipError_t launch_cell_apply(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);
 hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s);
-hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, hipStream_t s);
+hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, uint32_t* zero2, hipStream_t s);
 hipError_t launch_fold_groups(const FoldArgs& a, hipStream_t s);
 
 }  // namespace lio

@@ -21,7 +21,9 @@ namespace lio {
 __device__ __forceinline__ float voxel_floor(float v, float ds) { return floorf(v / ds); }   // :424
 
 __global__ __launch_bounds__(256) void voxel_keys_kernel(const float4* pts, uint32_t n, float ds, uint64_t* vkeys,
-                                                         uint32_t* order) {
+                                                         uint32_t* order, uint32_t* zero2) {
+    // first kernel of an Add_Points(downsample) batch: it also clears the two counters the fold accumulates into
+    if (zero2 != nullptr && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = pts[i];
         float kx = voxel_floor(p.x, ds), ky = voxel_floor(p.y, ds), kz = voxel_floor(p.z, ds);
@@ -152,7 +154,10 @@ __global__ __launch_bounds__(256) void pend_keys_kernel(const float4* pend, uint
 // one lane per touched cell: where the cell is now and how large its re-written bucket will be
 __global__ __launch_bounds__(64) void cell_plan_kernel(ApplyArgs a) {
     const uint32_t n_groups = *a.n_groups;
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
+    // the statistics the apply kernel accumulates start from zero (nothing reads them before it)
+    if (blockIdx.x == 0 && threadIdx.x < 3) a.stats[threadIdx.x] = 0u;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g <= a.n_scan; g += gridDim.x * blockDim.x) {
+        if (g >= n_groups) { a.new_size[g] = 0u; continue; }      // the scan of new_size runs over n_scan + 1 entries
         const uint64_t key = a.cell_key[g];
         const uint4* table = reinterpret_cast<const uint4*>(a.table);
         uint32_t slot = hash_key(key) & a.grid.table_mask;
@@ -186,7 +191,9 @@ __device__ __forceinline__ uint32_t table_claim(HashEntry* table, uint32_t mask,
 __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
     const uint32_t n_groups = *a.n_groups;
     // room check on the device (every lane sees the same total): either the whole batch is applied or nothing is
-    if ((uint64_t)a.tail + (uint64_t)a.new_off[a.n_scan] > (uint64_t)a.slots_cap) {
+    const uint32_t total = a.new_off[a.n_scan];
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.stats[3] = total;
+    if ((uint64_t)a.tail + (uint64_t)total > (uint64_t)a.slots_cap) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.stats + 2, APPLY_FLAG_NO_ROOM);
         return;
     }
@@ -289,7 +296,7 @@ hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t*
 }
 hipError_t launch_cell_plan(const ApplyArgs& a, uint32_t max_groups, hipStream_t s) {
     if (max_groups == 0) return hipSuccess;
-    uint32_t b = (max_groups + 63u) / 64u; if (b > 8192u) b = 8192u;
+    uint32_t b = (max_groups + 1u + 63u) / 64u; if (b > 8192u) b = 8192u;
     hipLaunchKernelGGL(cell_plan_kernel, dim3(b), dim3(64), 0, s, a);
     return hipGetLastError();
 }
@@ -299,10 +306,10 @@ hipError_t launch_cell_apply(const ApplyArgs& a, uint32_t max_groups, hipStream_
     hipLaunchKernelGGL(cell_apply_kernel, dim3(b), dim3(64), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, hipStream_t s) {
+hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, uint32_t* zero2, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint32_t b = (n + 255u) / 256u; if (b > 4096u) b = 4096u;
-    hipLaunchKernelGGL(voxel_keys_kernel, dim3(b), dim3(256), 0, s, pts, n, ds, vkeys, order);
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3(b), dim3(256), 0, s, pts, n, ds, vkeys, order, zero2);
     return hipGetLastError();
 }
 hipError_t launch_fold_groups(const FoldArgs& a, hipStream_t s) {
