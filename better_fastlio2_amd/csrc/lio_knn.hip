@@ -187,8 +187,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     }
     const float tau = __uint_as_float(tau_bits);
 
-    // ---- 27 hash probes, SLOTS per lane: the first probe of every slot is issued before any is
-    // consumed; collisions continue in a rarely taken serial loop
+    // ---- 27 hash probes, SLOTS per lane: the first probe of every slot is issued before any is consumed
     uint32_t st[SLOTS], ct[SLOTS];
     {
         const uint4* table = reinterpret_cast<const uint4*>(a.table);
@@ -221,17 +220,35 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s)
             if (!live_s[s]) e[s] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);      // reads as "empty slot"
+        // resolve: a slot is settled by a key match or an empty entry.  Collisions (load factor <= 0.25:
+        // some lane of a 64-lane wavefront nearly always has one) go on in ROUNDS that probe the next entry of
+        // every unsettled slot together -- the round trips of the SLOTS chains overlap instead of queueing up
+        bool pend[SLOTS];
+        bool any_pend = false;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            st[s] = 0; ct[s] = 0;
-            uint4 ee = e[s];
-            uint32_t sl = slot[s];
-            for (;;) {
-                const u64 ek = ((u64)ee.y << 32) | (u64)ee.x;
-                if (ek == key[s]) { st[s] = ee.z; ct[s] = ee.w; break; }
-                if (ek == KEY_EMPTY) break;
-                sl = (sl + 1) & mask;
-                ee = table[sl];
+            const u64 ek = ((u64)e[s].y << 32) | (u64)e[s].x;
+            const bool hit = ek == key[s];
+            st[s] = hit ? e[s].z : 0u;
+            ct[s] = hit ? e[s].w : 0u;
+            pend[s] = !hit && ek != KEY_EMPTY;
+            any_pend = any_pend || pend[s];
+        }
+        while (__any(any_pend)) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                slot[s] = (slot[s] + 1u) & mask;
+                if (pend[s]) e[s] = table[slot[s]];
+            }
+            any_pend = false;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const u64 ek = ((u64)e[s].y << 32) | (u64)e[s].x;
+                const bool hit = pend[s] && ek == key[s];
+                st[s] = hit ? e[s].z : st[s];
+                ct[s] = hit ? e[s].w : ct[s];
+                pend[s] = pend[s] && !hit && ek != KEY_EMPTY;
+                any_pend = any_pend || pend[s];
             }
         }
     }
@@ -264,19 +281,11 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         uint32_t b = 0, base = 0, t = (uint32_t)r;
         uint2 bk = s_bucket[wave][g][0];
         while (t - base >= bk.y) { base += bk.y; ++b; bk = s_bucket[wave][g][b]; }
-        // the load of candidate i+1 is in flight while candidate i goes through the ladder
-        bool have = (int)b < n_ne;
-        uint32_t idx_next = 0;
-        float4 p_next = make_float4(0.f, 0.f, 0.f, 1.f);
-        if (have) { idx_next = bk.x + (t - base); p_next = a.map_pts[idx_next]; }
-        while (have) {
-            const float4 p = p_next;
-            const uint32_t idx = idx_next;
+        while ((int)b < n_ne) {
+            const uint32_t idx = bk.x + (t - base);
+            top.offer(candidate_key_f(qx, qy, qz, a.map_pts[idx], idx));
             t += (uint32_t)G;
             while (t - base >= bk.y) { base += bk.y; ++b; bk = s_bucket[wave][g][b]; }
-            have = (int)b < n_ne;
-            if (have) { idx_next = bk.x + (t - base); p_next = a.map_pts[idx_next]; }
-            top.offer(candidate_key_f(qx, qy, qz, p, idx));
         }
     }
 
