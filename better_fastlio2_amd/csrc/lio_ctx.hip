@@ -38,6 +38,11 @@ struct lio_ctx {
     HashEntry* d_ltable = nullptr;             // tables of the coarser tree levels (>= 1), back to back
     size_t ltable_slots = 0;
     TreeLevels levels{};
+    // cell directory of the k-NN kernel: one block of 64 {start, count} per level-1 cell
+    uint2* d_child = nullptr;
+    size_t child_blocks_cap = 0;
+    uint32_t n_child_blocks = 0;               // blocks handed out (host view; the device bump counter is d_apply[9])
+    uint32_t* d_rank = nullptr;                // iota scratch of the index build
     void* d_temp = nullptr;
     size_t temp_bytes = 0;
     uint32_t* d_counters = nullptr;            // [0] n_unresolved, [1] reduction ticket, [2..3] build/add scratch, [4] run counts
@@ -234,8 +239,9 @@ int finish_index(lio_ctx* c, uint32_t n) {
     // reduce-by-key of level L (keys >> 6, counts summed) -- the point array is not touched again
     TreeLevels lv{};
     const uint64_t diff = kfirst ^ klast;
-    int top = 1;                               // the root is always an internal node: its children are level-0 cells at least
+    int top = 2;                               // levels 0 and 1 always have tables: the k-NN kernel's cell directory hangs off level 1
     if (diff != 0) top = (63 - __builtin_clzll(diff)) / 6 + 1;
+    if (top < 2) top = 2;
     lv.top_level = top;
     {
         const uint64_t prefix = 6 * top >= 64 ? 0ull : (kfirst >> (6 * top));
@@ -251,7 +257,6 @@ int finish_index(lio_ctx* c, uint32_t n) {
         uint32_t n_l = 0;
         HIPCHK(c, hipMemcpyAsync(&n_l, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
-        HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, cout, c->d_cell_starts, n_l, s));
         size_t sl = 64;
         while (sl < (size_t)n_l * 4) sl <<= 1;
         if (used + sl > c->ltable_slots) {
@@ -266,8 +271,27 @@ int finish_index(lio_ctx* c, uint32_t n) {
             c->d_ltable = nt; c->ltable_slots = cap;
         }
         HIPCHK(c, hipMemsetAsync(c->d_ltable + used, 0xFF, sl * sizeof(HashEntry), s));
-        HIPCHK(c, launch_table_insert(kout, c->d_cell_starts, cout, n_l, c->d_ltable + used, (uint32_t)(sl - 1), s));
+        // `start` of a coarse entry is its rank among the cells of its level; level 1 uses it as the number of its
+        // child block, the levels above only need to exist
+        HIPCHK(c, launch_iota(c->d_rank, n_l, s));
+        HIPCHK(c, launch_table_insert(kout, c->d_rank, cout, n_l, c->d_ltable + used, (uint32_t)(sl - 1), s));
         lv.off[L] = (uint32_t)used; lv.mask[L] = (uint32_t)(sl - 1);
+        if (L == 1) {
+            // cell directory: one block of 64 {start, count} per level-1 cell, with room for the level-1 cells that
+            // incremental updates will add
+            const size_t need = (size_t)n_l + (size_t)n_l / 4 + 4096;
+            if (need > c->child_blocks_cap) {
+                if (c->d_child) (void)hipFree(c->d_child);
+                c->d_child = nullptr; c->child_blocks_cap = 0;
+                HIPCHK(c, hipMalloc((void**)&c->d_child, need * 64 * sizeof(uint2)));
+                c->child_blocks_cap = need;
+            }
+            HIPCHK(c, hipMemsetAsync(c->d_child, 0, c->child_blocks_cap * 64 * sizeof(uint2), s));
+            HIPCHK(c, launch_fill_child_blocks(c->d_cell_keys, c->d_cell_starts, c->d_cell_counts, n_cells,
+                                               c->d_ltable + used, (uint32_t)(sl - 1), c->d_child, s));
+            c->n_child_blocks = n_l;
+            HIPCHK(c, hipMemcpyAsync(c->d_apply + 9, &c->n_child_blocks, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        }
         used += sl;
         n_prev = n_l;
         // next level reads what this one wrote; alternate between two scratch pairs
@@ -292,9 +316,10 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
         c->grid.n_points = 0;
         // empty map: an all-empty table keeps the kernels well defined
         HIPCHK(c, hipMemsetAsync(c->d_table, 0xFF, c->table_slots * sizeof(HashEntry), s));
+        HIPCHK(c, hipMemsetAsync(c->d_ltable, 0xFF, 64 * sizeof(HashEntry), s));
         c->grid.table_mask = (uint32_t)(c->table_slots - 1);
         HIPCHK(c, hipStreamSynchronize(s));
-        c->levels = TreeLevels{};
+        c->levels = TreeLevels{};                  // level-1 table = slot 0 of d_ltable, empty
         c->have_map = true;
         return LIO_OK;
     }
@@ -371,6 +396,7 @@ int apply_pending(lio_ctx* c) {
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pgcount, c->d_pgstart, (size_t)n, s));
     ApplyArgs a{};
     a.map_pts = c->d_pts; a.table = c->d_table; a.grid = c->grid; a.ltable = c->d_ltable;
+    a.child = c->d_child; a.block_bump = c->d_apply + 9; a.blocks_cap = (uint32_t)c->child_blocks_cap;
     for (int L = 0; L < 12; ++L) { a.loff[L] = c->levels.off[L]; a.lmask[L] = c->levels.mask[L]; }
     a.top_level = c->levels.top_level; a.top_cx = c->levels.top_cx; a.top_cy = c->levels.top_cy; a.top_cz = c->levels.top_cz;
     a.pend = c->d_pend; a.order = c->d_porder2; a.cell_key = c->d_pcell; a.group_start = c->d_pgstart;
@@ -440,6 +466,7 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
     KnnArgs ka{};
     ka.map_pts = c->d_pts; ka.table = c->d_table; ka.grid = c->grid;
+    ka.l1table = c->d_ltable + c->levels.off[1]; ka.l1mask = c->levels.mask[1]; ka.child = c->d_child;
     if (body != nullptr) HIPCHK(c, launch_transform(body, nq, pose, queries_world, s));
     ka.world_in = queries_world;
     ka.nq = nq; ka.nq_stride = stride;
@@ -514,6 +541,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_cell_keys, nm * sizeof(uint64_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_cell_counts, nm * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_cell_starts, nm * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_rank, nm * sizeof(uint32_t)));
     size_t tb = sort_pairs_temp_bytes(nm);
     size_t t2 = rle_temp_bytes(nm); if (t2 > tb) tb = t2;
     t2 = scan_temp_bytes(nm); if (t2 > tb) tb = t2;
@@ -523,6 +551,13 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     c->table_slots = 1024;
     CREATE_CHK(hipMalloc((void**)&c->d_table, c->table_slots * sizeof(HashEntry)));
     CREATE_CHK(hipMemset(c->d_table, 0xFF, c->table_slots * sizeof(HashEntry)));
+    // an empty map still has a (one-slot, empty) level-1 table and one zero child block: look-ups stay defined
+    c->ltable_slots = 4096;
+    CREATE_CHK(hipMalloc((void**)&c->d_ltable, c->ltable_slots * sizeof(HashEntry)));
+    CREATE_CHK(hipMemset(c->d_ltable, 0xFF, c->ltable_slots * sizeof(HashEntry)));
+    c->child_blocks_cap = 4096;
+    CREATE_CHK(hipMalloc((void**)&c->d_child, c->child_blocks_cap * 64 * sizeof(uint2)));
+    CREATE_CHK(hipMemset(c->d_child, 0, c->child_blocks_cap * 64 * sizeof(uint2)));
     CREATE_CHK(hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)));
     CREATE_CHK(hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_cand, sizeof(unsigned long long)));
@@ -559,7 +594,7 @@ void lio_destroy(lio_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
-                   c->d_cell_counts, c->d_cell_starts, c->d_table, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
+                   c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_table, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
                    c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
                    c->d_partials, c->d_gpartials, c->d_tickets, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,

@@ -11,7 +11,10 @@ namespace lio {
 // ---- k-NN (replaces KD_TREE::Nearest_Search / Search, ikd_Tree.cpp:367-397, 869-1013) ---------
 struct KnnArgs {
     const float4*    map_pts;       // Morton-sorted map
-    const HashEntry* table;
+    const HashEntry* table;         // level-0 cell table (tree walk, map mutation)
+    const HashEntry* l1table;       // level-1 table (cells of 4x4x4 level-0 cells): key -> child block number
+    uint32_t         l1mask;
+    const uint2*     child;         // [blocks][64] {start, count} of the level-0 cells of a level-1 cell
     Grid             grid;
     const float4*    world_in;      // queries in the world frame
     int              nq;
@@ -86,6 +89,11 @@ hipError_t launch_gather_points(const float4* src, const uint32_t* vals, uint32_
 hipError_t launch_table_insert(const uint64_t* cell_mkeys, const uint32_t* cell_start,
                                const uint32_t* cell_count, uint32_t n_cells, HashEntry* table,
                                uint32_t table_mask, hipStream_t s);
+// cell directory of the k-NN kernel: level-1 entries carry the number of their child block, the block holds
+// {start, count} of the 64 level-0 cells at a fixed position (no hashing, no collisions on the 27 look-ups)
+hipError_t launch_iota(uint32_t* out, uint32_t n, hipStream_t s);
+hipError_t launch_fill_child_blocks(const uint64_t* cell_mkeys, const uint32_t* cell_start, const uint32_t* cell_count,
+                                    uint32_t n_cells, const HashEntry* l1table, uint32_t l1mask, uint2* child, hipStream_t s);
 // w != 0 for every live point inside any of the nb half-open boxes; *counter += points tomb-stoned
 hipError_t launch_delete_boxes(float4* pts, uint32_t n, const float* boxes6, int nb, uint32_t* counter,
                                hipStream_t s);

@@ -187,69 +187,91 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     }
     const float tau = __uint_as_float(tau_bits);
 
-    // ---- 27 hash probes, SLOTS per lane: the first probe of every slot is issued before any is consumed
+    // ---- cell directory look-up.  The 3x3x3 block touches at most 2x2x2 level-1 cells (a level-1 cell = 4x4x4
+    // grid cells): lanes 0..7 of the group hash-probe those (the only hashing, the only collisions), every level-1
+    // entry names a block of 64 {start, count} records, and the 27 cells are then read at FIXED positions of those
+    // blocks -- one 8-byte load per cell, no key compare, no probe sequence.
+    constexpr int L1SLOTS = (8 + G - 1) / G;
     uint32_t st[SLOTS], ct[SLOTS];
     {
-        const uint4* table = reinterpret_cast<const uint4*>(a.table);
-        const uint32_t mask = a.grid.table_mask;
-        u64 key[SLOTS];
-        uint32_t slot[SLOTS];
-        uint4 e[SLOTS];
-        bool live_s[SLOTS];
+        const uint4* l1 = reinterpret_cast<const uint4*>(a.l1table);
+        const uint32_t l1mask = a.l1mask;
+        const uint32_t ucx = (uint32_t)cx, ucy = (uint32_t)cy, ucz = (uint32_t)cz;     // cell_coord clamps into [0, 2^21)
+        const uint32_t b0x = (ucx > 0u ? ucx - 1u : 0u) >> 2, b0y = (ucy > 0u ? ucy - 1u : 0u) >> 2, b0z = (ucz > 0u ? ucz - 1u : 0u) >> 2;
+        const uint32_t h1x = (ucx < CELL_MAX ? ucx + 1u : CELL_MAX) >> 2, h1y = (ucy < CELL_MAX ? ucy + 1u : CELL_MAX) >> 2,
+                       h1z = (ucz < CELL_MAX ? ucz + 1u : CELL_MAX) >> 2;
+        uint32_t blk[L1SLOTS];
+        {
+            u64 k1[L1SLOTS];
+            uint32_t sl1[L1SLOTS];
+            uint4 e1[L1SLOTS];
+            bool pend[L1SLOTS];
+            bool any_pend = false;
+#pragma unroll
+            for (int s1 = 0; s1 < L1SLOTS; ++s1) {
+                const int li = r + s1 * G;
+                const uint32_t x1 = b0x + (uint32_t)((li >> 2) & 1), y1 = b0y + (uint32_t)((li >> 1) & 1), z1 = b0z + (uint32_t)(li & 1);
+                const bool want = active && li < 8 && x1 <= h1x && y1 <= h1y && z1 <= h1z;
+                k1[s1] = pack_key(x1, y1, z1);
+                sl1[s1] = hash_cell(x1, y1, z1) & l1mask;
+                e1[s1] = l1[want ? sl1[s1] : 0u];                   // unconditional load, discarded when not wanted
+                if (!want) e1[s1] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+            }
+#pragma unroll
+            for (int s1 = 0; s1 < L1SLOTS; ++s1) {
+                const u64 ek = ((u64)e1[s1].y << 32) | (u64)e1[s1].x;
+                const bool hit = ek == k1[s1];
+                blk[s1] = hit ? e1[s1].z : 0xffffffffu;
+                pend[s1] = !hit && ek != KEY_EMPTY;
+                any_pend = any_pend || pend[s1];
+            }
+            while (__any(any_pend)) {                               // collision rounds (load factor <= 0.25)
+                any_pend = false;
+#pragma unroll
+                for (int s1 = 0; s1 < L1SLOTS; ++s1) {
+                    sl1[s1] = (sl1[s1] + 1u) & l1mask;
+                    if (pend[s1]) e1[s1] = l1[sl1[s1]];
+                    const u64 ek = ((u64)e1[s1].y << 32) | (u64)e1[s1].x;
+                    const bool hit = pend[s1] && ek == k1[s1];
+                    blk[s1] = hit ? e1[s1].z : blk[s1];
+                    pend[s1] = pend[s1] && !hit && ek != KEY_EMPTY;
+                    any_pend = any_pend || pend[s1];
+                }
+            }
+        }
+        const int gbase = lane - r;                                  // first lane of this group
+        uint2 ch[SLOTS];
+        bool ok[SLOTS];
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int j = r + s * G;
-            const int nx = cx + (j / 9) - 1, ny = cy + ((j / 3) % 3) - 1, nz = cz + (j % 3) - 1;
+            const int ox = (j / 9) - 1, oy = ((j / 3) % 3) - 1, oz = (j % 3) - 1;
+            const int nx = cx + ox, ny = cy + oy, nz = cz + oz;
             bool live = active && j < 27 && (uint32_t)nx <= CELL_MAX && (uint32_t)ny <= CELL_MAX && (uint32_t)nz <= CELL_MAX;
             if (HINT) {
                 // box distance of the neighbour cell, same fp32 form as sqdist3 (a lower bound of every
                 // computed point distance inside it)
-                const int ox = (j / 9) - 1, oy = ((j / 3) % 3) - 1, oz = (j % 3) - 1;
                 const float bx = ox < 0 ? glo[0] : (ox > 0 ? ghi[0] : 0.0f);
                 const float by = oy < 0 ? glo[1] : (oy > 0 ? ghi[1] : 0.0f);
                 const float bz = oz < 0 ? glo[2] : (oz > 0 ? ghi[2] : 0.0f);
                 live = live && ((bx * bx + by * by) + bz * bz <= tau);
             }
-            key[s] = pack_key((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-            slot[s] = hash_cell((uint32_t)nx, (uint32_t)ny, (uint32_t)nz) & mask;
-            // unconditional load (dead lanes read slot 0 and discard it): no branch, so the SLOTS loads
-            // of a lane are in flight together
-            live_s[s] = live;
-            e[s] = table[live ? slot[s] : 0u];
-        }
+            // which of the (up to) eight level-1 cells, i.e. which lane of the group holds its block number
+            const uint32_t li = live ? (((((uint32_t)nx >> 2) - b0x) << 2) | ((((uint32_t)ny >> 2) - b0y) << 1) | (((uint32_t)nz >> 2) - b0z)) : 0u;
+            uint32_t bv = 0xffffffffu;
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s)
-            if (!live_s[s]) e[s] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);      // reads as "empty slot"
-        // resolve: a slot is settled by a key match or an empty entry.  Collisions (load factor <= 0.25:
-        // some lane of a 64-lane wavefront nearly always has one) go on in ROUNDS that probe the next entry of
-        // every unsettled slot together -- the round trips of the SLOTS chains overlap instead of queueing up
-        bool pend[SLOTS];
-        bool any_pend = false;
+            for (int s1 = 0; s1 < L1SLOTS; ++s1) {
+                const uint32_t v = (uint32_t)__shfl((int)blk[s1], gbase + (int)(li % (uint32_t)G), 64);
+                if ((int)(li / (uint32_t)G) == s1) bv = v;
+            }
+            ok[s] = live && bv != 0xffffffffu;
+            const uint32_t pos = (((uint32_t)nx & 3u) << 4) | (((uint32_t)ny & 3u) << 2) | ((uint32_t)nz & 3u);
+            ch[s] = a.child[ok[s] ? (size_t)bv * 64u + pos : 0u];       // unconditional load: the SLOTS loads overlap
+        }
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const u64 ek = ((u64)e[s].y << 32) | (u64)e[s].x;
-            const bool hit = ek == key[s];
-            st[s] = hit ? e[s].z : 0u;
-            ct[s] = hit ? e[s].w : 0u;
-            pend[s] = !hit && ek != KEY_EMPTY;
-            any_pend = any_pend || pend[s];
-        }
-        while (__any(any_pend)) {
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                slot[s] = (slot[s] + 1u) & mask;
-                if (pend[s]) e[s] = table[slot[s]];
-            }
-            any_pend = false;
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const u64 ek = ((u64)e[s].y << 32) | (u64)e[s].x;
-                const bool hit = pend[s] && ek == key[s];
-                st[s] = hit ? e[s].z : st[s];
-                ct[s] = hit ? e[s].w : ct[s];
-                pend[s] = pend[s] && !hit && ek != KEY_EMPTY;
-                any_pend = any_pend || pend[s];
-            }
+            st[s] = ok[s] ? ch[s].x : 0u;
+            ct[s] = ok[s] ? ch[s].y : 0u;
         }
     }
 

@@ -4,6 +4,7 @@
 // Delete_Point_Boxes (:536) / Delete_by_range (:648-710), flatten (:1326).  The index is rebuilt
 // by sorting (no pointer tree, no re-balancing thread): Morton key per point -> radix sort
 // (rocPRIM, lio_sort.hip) -> gather -> run-length encode cells -> hash-table insert.
+#include "lio_device.h"
 #include "lio_kernels.h"
 #include "lio_math.h"
 
@@ -45,6 +46,25 @@ __global__ __launch_bounds__(256) void table_insert_kernel(const uint64_t* cell_
             }
             slot = (slot + 1) & mask;
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t* out, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = i;
+}
+
+// one lane per occupied level-0 cell: its {start, count} goes to its fixed place in the child block of its
+// level-1 cell (block number = the `start` field of the level-1 entry)
+__global__ __launch_bounds__(256) void fill_child_blocks_kernel(const uint64_t* cell_mkeys, const uint32_t* cell_start,
+                                                                const uint32_t* cell_count, uint32_t n_cells,
+                                                                const HashEntry* l1table, uint32_t l1mask, uint2* child) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cells; c += gridDim.x * blockDim.x) {
+        const uint64_t mk = cell_mkeys[c];
+        const uint32_t cx = compact21(mk >> 2), cy = compact21(mk >> 1), cz = compact21(mk);
+        uint32_t blk, one;
+        table_find(l1table, l1mask, pack_key(cx >> 2, cy >> 2, cz >> 2), blk, one);
+        if (one == 0u) continue;                                   // cannot happen: the level-1 cell was derived from this one
+        child[(size_t)blk * 64u + (((cx & 3u) << 4) | ((cy & 3u) << 2) | (cz & 3u))] = make_uint2(cell_start[c], cell_count[c]);
     }
 }
 
@@ -121,6 +141,18 @@ hipError_t launch_table_insert(const uint64_t* cell_mkeys, const uint32_t* cell_
     if (n_cells == 0) return hipSuccess;
     hipLaunchKernelGGL(table_insert_kernel, grid_for(n_cells), dim3(256), 0, s, cell_mkeys, cell_start, cell_count,
                        n_cells, table, table_mask);
+    return hipGetLastError();
+}
+hipError_t launch_iota(uint32_t* out, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, s, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_fill_child_blocks(const uint64_t* cell_mkeys, const uint32_t* cell_start, const uint32_t* cell_count,
+                                    uint32_t n_cells, const HashEntry* l1table, uint32_t l1mask, uint2* child, hipStream_t s) {
+    if (n_cells == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_child_blocks_kernel, grid_for(n_cells), dim3(256), 0, s, cell_mkeys, cell_start, cell_count,
+                       n_cells, l1table, l1mask, child);
     return hipGetLastError();
 }
 hipError_t launch_delete_boxes(float4* pts, uint32_t n, const float* boxes6, int nb, uint32_t* counter, hipStream_t s) {

@@ -43,6 +43,9 @@ struct ApplyArgs {
     HashEntry*       table;         // level-0 table
     Grid             grid;
     HashEntry*       ltable;        // levels >= 1
+    uint2*           child;         // cell directory: [blocks][64] {start, count}
+    uint32_t*        block_bump;    // next free child block
+    uint32_t         blocks_cap;
     uint32_t         loff[12], lmask[12];
     int              top_level;
     uint32_t         top_cx, top_cy, top_cz;
@@ -62,6 +65,7 @@ struct ApplyArgs {
 };
 constexpr uint32_t APPLY_FLAG_OUTSIDE_TOP = 1u;   // a new cell lies outside the root node of the tree
 constexpr uint32_t APPLY_FLAG_TABLE_FULL = 2u;    // an insertion probe wrapped around a table
+constexpr uint32_t APPLY_FLAG_NO_BLOCKS = 8u;     // the pool of child blocks is exhausted
 constexpr uint32_t APPLY_FLAG_NO_ROOM = 4u;       // the tail cannot hold the re-written buckets: nothing was changed
 hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, hipStream_t s);
 hipError_t launch_cell_plan(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);

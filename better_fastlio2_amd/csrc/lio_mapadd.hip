@@ -217,31 +217,50 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
         }
         const uint32_t count = dst - dst0;
         if (retired != 0) atomicAdd(a.stats + 1, retired);
+        const uint64_t key = a.cell_key[g];
+        const uint32_t cx = (uint32_t)(key >> 42) & 0x1fffffu, cy = (uint32_t)(key >> 21) & 0x1fffffu, cz = (uint32_t)key & 0x1fffffu;
+        const uint32_t pos = ((cx & 3u) << 4) | ((cy & 3u) << 2) | (cz & 3u);        // place inside the child block
+        HashEntry* l1t = a.ltable + a.loff[1];
         if (pl.found) {
             a.table[pl.slot].start = dst0;
             a.table[pl.slot].count = count;
+            uint32_t blk, one;
+            table_find(l1t, a.lmask[1], pack_key(cx >> 2, cy >> 2, cz >> 2), blk, one);
+            if (one != 0u) a.child[(size_t)blk * 64u + pos] = make_uint2(dst0, count);
             continue;
         }
         // ---- a cell the map did not have ----------------------------------------------------------
-        const uint64_t key = a.cell_key[g];
         const uint32_t slot = table_claim(a.table, a.grid.table_mask, key);
         if (slot == 0xffffffffu) { atomicOr(a.stats + 2, APPLY_FLAG_TABLE_FULL); continue; }
         a.table[slot].start = dst0;
         a.table[slot].count = count;
         atomicAdd(a.stats + 0, 1u);
-        const uint32_t cx = (uint32_t)(key >> 42) & 0x1fffffu, cy = (uint32_t)(key >> 21) & 0x1fffffu, cz = (uint32_t)key & 0x1fffffu;
         const int sh_top = 2 * a.top_level;
         if ((cx >> sh_top) != a.top_cx || (cy >> sh_top) != a.top_cy || (cz >> sh_top) != a.top_cz) {
             atomicOr(a.stats + 2, APPLY_FLAG_OUTSIDE_TOP);
             continue;
         }
-        // existence marks on the coarser levels (the tree walk only asks "is this child non-empty")
+        // level 1: the entry names the child block of the cell directory (a new level-1 cell takes a block from the
+        // pool; if two lanes race for the same new cell one block number is simply left unused).  Levels above:
+        // existence marks (the tree walk only asks "is this child non-empty").
         for (int L = 1; L < a.top_level; ++L) {
             const uint64_t ck = pack_key(cx >> (2 * L), cy >> (2 * L), cz >> (2 * L));
             HashEntry* lt = a.ltable + a.loff[L];
             const uint32_t ls = table_claim(lt, a.lmask[L], ck);
             if (ls == 0xffffffffu) { atomicOr(a.stats + 2, APPLY_FLAG_TABLE_FULL); break; }
-            lt[ls].start = 0u;
+            if (L == 1) {
+                uint32_t* sp = &lt[ls].start;
+                uint32_t blk = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (blk == 0xffffffffu) {
+                    const uint32_t nb = atomicAdd(a.block_bump, 1u);
+                    if (nb >= a.blocks_cap) { atomicOr(a.stats + 2, APPLY_FLAG_NO_BLOCKS); break; }
+                    const uint32_t prev = atomicCAS(sp, 0xffffffffu, nb);
+                    blk = prev == 0xffffffffu ? nb : prev;
+                }
+                a.child[(size_t)blk * 64u + pos] = make_uint2(dst0, count);
+            } else {
+                lt[ls].start = 0u;
+            }
             lt[ls].count = 1u;
         }
     }
