@@ -52,7 +52,6 @@ struct HashEntry {                            // 16 bytes: one global_load_dword
 struct Grid {
     float    cell;                            // power of two
     float    inv_cell;
-    uint32_t table_mask;                      // table slots - 1 (slots is a power of two)
     uint32_t n_points;                        // stored points (live + tomb-stoned)
 };
 

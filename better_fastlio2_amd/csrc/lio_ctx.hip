@@ -33,8 +33,6 @@ struct lio_ctx {
     uint32_t *d_vals = nullptr, *d_vals_tmp = nullptr;
     uint64_t* d_cell_keys = nullptr;
     uint32_t *d_cell_counts = nullptr, *d_cell_starts = nullptr;
-    HashEntry* d_table = nullptr;
-    size_t table_slots = 0;
     HashEntry* d_ltable = nullptr;             // tables of the coarser tree levels (>= 1), back to back
     size_t ltable_slots = 0;
     TreeLevels levels{};
@@ -220,19 +218,6 @@ int finish_index(lio_ctx* c, uint32_t n) {
     HIPCHK(c, hipMemcpyAsync(&klast, c->d_mkeys + (n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_cell_counts, c->d_cell_starts, n_cells, s));
-    // table: power of two >= 4 x cells (load factor <= 0.25 keeps unsuccessful probes short)
-    size_t slots = 1024;
-    while (slots < (size_t)n_cells * 4) slots <<= 1;
-    if (slots > c->table_slots) {
-        if (c->d_table) (void)hipFree(c->d_table);
-        c->d_table = nullptr; c->table_slots = 0;
-        HIPCHK(c, hipMalloc((void**)&c->d_table, slots * sizeof(HashEntry)));
-        c->table_slots = slots;
-    }
-    HIPCHK(c, hipMemsetAsync(c->d_table, 0xFF, slots * sizeof(HashEntry), s));
-    HIPCHK(c, launch_table_insert(c->d_cell_keys, c->d_cell_starts, c->d_cell_counts, n_cells, c->d_table,
-                                  (uint32_t)(slots - 1), s));
-    c->grid.table_mask = (uint32_t)(slots - 1);
     c->n_cells = n_cells; c->n_cells_built = n_cells;
 
     // ---- coarser levels of the hashed 64-ary tree (exact fallback of the k-NN): level L+1 is a
@@ -314,10 +299,8 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
         c->n_points = 0; c->n_live = 0; c->n_cells = 0;
         c->n_retired = 0; c->n_new_cells = 0; c->n_cells_built = 0;
         c->grid.n_points = 0;
-        // empty map: an all-empty table keeps the kernels well defined
-        HIPCHK(c, hipMemsetAsync(c->d_table, 0xFF, c->table_slots * sizeof(HashEntry), s));
+        // empty map: an all-empty level-1 table keeps the kernels well defined
         HIPCHK(c, hipMemsetAsync(c->d_ltable, 0xFF, 64 * sizeof(HashEntry), s));
-        c->grid.table_mask = (uint32_t)(c->table_slots - 1);
         HIPCHK(c, hipStreamSynchronize(s));
         c->levels = TreeLevels{};                  // level-1 table = slot 0 of d_ltable, empty
         c->have_map = true;
@@ -395,7 +378,7 @@ int apply_pending(lio_ctx* c) {
     HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_pkeys2, (size_t)n, c->d_pcell, c->d_pgcount, c->d_apply + 8, s));
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pgcount, c->d_pgstart, (size_t)n, s));
     ApplyArgs a{};
-    a.map_pts = c->d_pts; a.table = c->d_table; a.grid = c->grid; a.ltable = c->d_ltable;
+    a.map_pts = c->d_pts; a.grid = c->grid; a.ltable = c->d_ltable;
     a.child = c->d_child; a.block_bump = c->d_apply + 9; a.blocks_cap = (uint32_t)c->child_blocks_cap;
     for (int L = 0; L < 12; ++L) { a.loff[L] = c->levels.off[L]; a.lmask[L] = c->levels.mask[L]; }
     a.top_level = c->levels.top_level; a.top_cx = c->levels.top_cx; a.top_cy = c->levels.top_cy; a.top_cz = c->levels.top_cz;
@@ -465,7 +448,7 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     // d_counters[0] / d_cand are zero here: zeroed at creation and re-zeroed by whoever consumes them
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
     KnnArgs ka{};
-    ka.map_pts = c->d_pts; ka.table = c->d_table; ka.grid = c->grid;
+    ka.map_pts = c->d_pts; ka.grid = c->grid;
     ka.l1table = c->d_ltable + c->levels.off[1]; ka.l1mask = c->levels.mask[1]; ka.child = c->d_child;
     if (body != nullptr) HIPCHK(c, launch_transform(body, nq, pose, queries_world, s));
     ka.world_in = queries_world;
@@ -475,7 +458,7 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, LIO_PROF_KNN)));
     TreeArgs ta{};
-    ta.map_pts = c->d_pts; ta.table0 = c->d_table; ta.ltable = c->d_ltable; ta.levels = c->levels; ta.grid = c->grid;
+    ta.map_pts = c->d_pts; ta.child = c->d_child; ta.ltable = c->d_ltable; ta.levels = c->levels; ta.grid = c->grid;
     ta.queries = queries_world; ta.unres = unres; ta.n_unresolved = c->d_counters;
     ta.nq = nq; ta.nq_stride = stride; ta.nbr = nbr; ta.cnt = cnt;
     HIPCHK(c, launch_knn_tree(ta, s, prof_timer(c, LIO_PROF_FALLBACK)));
@@ -522,7 +505,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
 
     c->grid.cell = cfg->cell_size != 0.0f ? cfg->cell_size : auto_cell_size(cfg->filter_size_map_min);
     c->grid.inv_cell = 1.0f / c->grid.cell;
-    c->grid.table_mask = 0; c->grid.n_points = 0;
+    c->grid.n_points = 0;
 
     const size_t nm = (size_t)cfg->max_map_points;
     c->cap_map = nm;
@@ -548,9 +531,6 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     t2 = select_temp_bytes(c->slots_cap); if (t2 > tb) tb = t2;
     c->temp_bytes = tb + 256;
     CREATE_CHK(hipMalloc(&c->d_temp, c->temp_bytes));
-    c->table_slots = 1024;
-    CREATE_CHK(hipMalloc((void**)&c->d_table, c->table_slots * sizeof(HashEntry)));
-    CREATE_CHK(hipMemset(c->d_table, 0xFF, c->table_slots * sizeof(HashEntry)));
     // an empty map still has a (one-slot, empty) level-1 table and one zero child block: look-ups stay defined
     c->ltable_slots = 4096;
     CREATE_CHK(hipMalloc((void**)&c->d_ltable, c->ltable_slots * sizeof(HashEntry)));
@@ -594,7 +574,7 @@ void lio_destroy(lio_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
-                   c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_table, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
+                   c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
                    c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
                    c->d_partials, c->d_gpartials, c->d_tickets, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
@@ -713,7 +693,8 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
         // real count (entries of the scan past it are never used)
         HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, (size_t)n, s));
         FoldArgs fa{};
-        fa.map_pts = c->d_pts; fa.table = c->d_table; fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch;
+        fa.map_pts = c->d_pts; fa.l1table = c->d_ltable + c->levels.off[1]; fa.l1mask = c->levels.mask[1]; fa.child = c->d_child;
+        fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch;
         fa.order = c->d_add_order2; fa.group_start = c->d_add_gstart; fa.group_count = c->d_add_gcount;
         fa.n_groups = 0; fa.n_groups_dev = c->d_apply + 7; fa.n_groups_max = n;
         fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4;
@@ -1024,11 +1005,11 @@ int lio_map_acquire_removed_points(lio_ctx* c, float* out_xyz, long long cap, lo
 int lio_map_get_info(lio_ctx* c, lio_map_info* info) {
     if (!c || !info) return LIO_ERR_INVALID_ARG;
     info->n_points = c->n_points; info->n_live = c->n_live; info->n_cells = c->n_cells;
-    info->table_slots = (long long)c->grid.table_mask + 1;
+    info->table_slots = (long long)c->levels.mask[1] + 1;
     info->cell_size = c->grid.cell; info->downsample_size = c->cfg.filter_size_map_min;
     info->n_retired = c->n_retired; info->n_incremental_updates = c->n_incremental_updates; info->n_full_rebuilds = c->n_full_rebuilds;
     info->bytes_resident = (long long)c->n_points * (long long)(sizeof(float4) + sizeof(uint64_t)) +
-                           (long long)(c->grid.table_mask + 1ll) * (long long)sizeof(HashEntry);
+                           (long long)c->ltable_slots * (long long)sizeof(HashEntry) + (long long)c->child_blocks_cap * 512ll;
     return LIO_OK;
 }
 

@@ -11,7 +11,6 @@ namespace lio {
 // ---- k-NN (replaces KD_TREE::Nearest_Search / Search, ikd_Tree.cpp:367-397, 869-1013) ---------
 struct KnnArgs {
     const float4*    map_pts;       // Morton-sorted map
-    const HashEntry* table;         // level-0 cell table (tree walk, map mutation)
     const HashEntry* l1table;       // level-1 table (cells of 4x4x4 level-0 cells): key -> child block number
     uint32_t         l1mask;
     const uint2*     child;         // [blocks][64] {start, count} of the level-0 cells of a level-1 cell
@@ -43,7 +42,7 @@ struct TreeLevels {
 };
 struct TreeArgs {
     const float4*    map_pts;
-    const HashEntry* table0;        // level-0 table (the k-NN kernel's)
+    const uint2*     child;         // cell directory blocks (level-0 cells), see lio_device.h
     const HashEntry* ltable;        // levels >= 1
     TreeLevels       levels;
     Grid             grid;

@@ -533,8 +533,8 @@ __global__ __launch_bounds__(64) void knn_tree_kernel(TreeArgs a) {
                     const int j = lane + 64 * sl;
                     uint32_t st = 0, ct = 0;
                     if (j < 125)
-                        table_find(a.table0, a.grid.table_mask,
-                                   pack_key((uint32_t)(cx + j / 25 - 2), (uint32_t)(cy + (j / 5) % 5 - 2), (uint32_t)(cz + j % 5 - 2)), st, ct);
+                        cell_find(a.ltable + a.levels.off[1], a.levels.mask[1], a.child, (uint32_t)(cx + j / 25 - 2),
+                                  (uint32_t)(cy + (j / 5) % 5 - 2), (uint32_t)(cz + j % 5 - 2), st, ct);
                     const bool ne = ct != 0;
                     const u64 b = __ballot(ne);
                     const int pos = n_ne + __popcll(b & ((1ull << lane) - 1ull));
@@ -642,9 +642,13 @@ __global__ __launch_bounds__(64) void knn_tree_kernel(TreeArgs a) {
             uint32_t st = 0, ct = 0;
             const uint32_t lim = CELL_MAX >> (2 * cl);
             if (ccx <= lim && ccy <= lim && ccz <= lim) {
-                const HashEntry* tab = cl == 0 ? a.table0 : a.ltable + a.levels.off[cl];
-                const uint32_t mask = cl == 0 ? a.grid.table_mask : a.levels.mask[cl];
-                table_find(tab, mask, pack_key(ccx, ccy, ccz), st, ct);
+                if (cl == 0) {
+                    // the 64 children of a level-1 node ARE its child block (nd.x = block number), lane <-> position
+                    const uint2 e = a.child[(size_t)nd.x * 64u + (uint32_t)lane];
+                    st = e.x; ct = e.y;
+                } else {
+                    table_find(a.ltable + a.levels.off[cl], a.levels.mask[cl], pack_key(ccx, ccy, ccz), st, ct);
+                }
             }
             const float bd = cell_box_sqdist(qx, qy, qz, ccx, ccy, ccz, cl, cell);
             const bool want = ct != 0 && bd <= top.tau();

@@ -7,7 +7,9 @@ namespace lio {
 
 struct FoldArgs {
     float4*          map_pts;       // tomb-stones are written here
-    const HashEntry* table;
+    const HashEntry* l1table;       // cell directory (lio_device.h)
+    uint32_t         l1mask;
+    const uint2*     child;
     Grid             grid;
     float            ds;            // downsample_size (ikd_Tree.h:197)
     const float4*    new_pts;       // the batch, in the caller's order
@@ -37,10 +39,9 @@ struct IncrArgs {
 // re-written at the tail of the point array -- its live points in their old order, then the new ones --
 // the old slots become TOMB_MOVED, and only that cell's table entry changes.  New cells are inserted into
 // the level-0 table and, as existence marks, into the coarser levels of the tree.
-struct CellPlan { uint32_t old_start, old_count, slot, found; };
+struct CellPlan { uint32_t old_start, old_count, index, found; };   // index = position of the cell's record in the directory
 struct ApplyArgs {
     float4*          map_pts;
-    HashEntry*       table;         // level-0 table
     Grid             grid;
     HashEntry*       ltable;        // levels >= 1
     uint2*           child;         // cell directory: [blocks][64] {start, count}

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
         const bool mine = cx <= c1[0] && cy <= c1[1] && cz <= c1[2];
         // ---- pass 1: existing live points inside the box (Search_by_range :1015-1045) -------------
         uint32_t st = 0, ct = 0;
-        if (mine) table_find(a.table, a.grid.table_mask, pack_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz), st, ct);
+        if (mine) cell_find(a.l1table, a.l1mask, a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, st, ct);
         uint32_t n_e = 0;
         float d_e = __uint_as_float(INF_BITS);
         float4 e_best = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -159,16 +159,10 @@ __global__ __launch_bounds__(64) void cell_plan_kernel(ApplyArgs a) {
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g <= a.n_scan; g += gridDim.x * blockDim.x) {
         if (g >= n_groups) { a.new_size[g] = 0u; continue; }      // the scan of new_size runs over n_scan + 1 entries
         const uint64_t key = a.cell_key[g];
-        const uint4* table = reinterpret_cast<const uint4*>(a.table);
-        uint32_t slot = hash_key(key) & a.grid.table_mask;
-        CellPlan pl{0u, 0u, 0u, 0u};
-        for (uint32_t probes = 0; probes <= a.grid.table_mask; ++probes) {
-            const uint4 e = table[slot];
-            const uint64_t ek = ((uint64_t)e.y << 32) | (uint64_t)e.x;
-            if (ek == key) { pl.old_start = e.z; pl.old_count = e.w; pl.slot = slot; pl.found = 1u; break; }
-            if (ek == KEY_EMPTY) break;
-            slot = (slot + 1) & a.grid.table_mask;
-        }
+        const uint32_t cx = (uint32_t)(key >> 42) & 0x1fffffu, cy = (uint32_t)(key >> 21) & 0x1fffffu, cz = (uint32_t)key & 0x1fffffu;
+        CellPlan pl{0u, 0u, 0xffffffffu, 0u};
+        cell_find(a.ltable + a.loff[1], a.lmask[1], a.child, cx, cy, cz, pl.old_start, pl.old_count, &pl.index);
+        pl.found = pl.old_count != 0u ? 1u : 0u;                  // records are only ever written with count >= 1
         uint32_t live = 0;
         for (uint32_t i = 0; i < pl.old_count; ++i) live += a.map_pts[pl.old_start + i].w == 0.0f ? 1u : 0u;
         a.plan[g] = pl;
@@ -220,20 +214,11 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
         const uint64_t key = a.cell_key[g];
         const uint32_t cx = (uint32_t)(key >> 42) & 0x1fffffu, cy = (uint32_t)(key >> 21) & 0x1fffffu, cz = (uint32_t)key & 0x1fffffu;
         const uint32_t pos = ((cx & 3u) << 4) | ((cy & 3u) << 2) | (cz & 3u);        // place inside the child block
-        HashEntry* l1t = a.ltable + a.loff[1];
         if (pl.found) {
-            a.table[pl.slot].start = dst0;
-            a.table[pl.slot].count = count;
-            uint32_t blk, one;
-            table_find(l1t, a.lmask[1], pack_key(cx >> 2, cy >> 2, cz >> 2), blk, one);
-            if (one != 0u) a.child[(size_t)blk * 64u + pos] = make_uint2(dst0, count);
+            a.child[pl.index] = make_uint2(dst0, count);
             continue;
         }
         // ---- a cell the map did not have ----------------------------------------------------------
-        const uint32_t slot = table_claim(a.table, a.grid.table_mask, key);
-        if (slot == 0xffffffffu) { atomicOr(a.stats + 2, APPLY_FLAG_TABLE_FULL); continue; }
-        a.table[slot].start = dst0;
-        a.table[slot].count = count;
         atomicAdd(a.stats + 0, 1u);
         const int sh_top = 2 * a.top_level;
         if ((cx >> sh_top) != a.top_cx || (cy >> sh_top) != a.top_cy || (cz >> sh_top) != a.top_cz) {
