@@ -74,7 +74,7 @@ struct lio_ctx {
 
     // ---- scan -------------------------------------------------------------------------------
     int cap_q = 0, nq = 0;
-    float4 *d_body = nullptr, *d_world = nullptr, *d_nbr = nullptr, *d_normvec = nullptr;
+    float4 *d_body = nullptr, *d_world = nullptr, *d_nbr = nullptr, *d_normvec = nullptr, *d_plane = nullptr;
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
     uint8_t* d_unres = nullptr;                // per query: 1 = needs the exact tree walk
     double *d_rows = nullptr, *d_partials = nullptr, *d_gpartials = nullptr;
@@ -550,6 +550,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_world, nq * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_nbr, nq * K * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_normvec, nq * sizeof(float4)));
+    CREATE_CHK(hipMalloc((void**)&c->d_plane, nq * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_cnt, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_sel, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_unres, nq));
@@ -575,7 +576,7 @@ void lio_destroy(lio_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
-                   c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
+                   c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
                    c->d_partials, c->d_gpartials, c->d_tickets, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_minmax,
@@ -1229,7 +1230,7 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     }
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
-    ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.rows = nullptr; ra.partials = c->d_partials;
+    ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.rows = nullptr; ra.partials = c->d_partials;
     const unsigned long long seq = ++c->seq;
     ra.gpartials = c->d_gpartials; ra.ticket = c->d_tickets; ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
     HIPCHK(c, launch_residual(ra, do_search != 0, ext, s, prof_timer(c, LIO_PROF_RESIDUAL)));
@@ -1277,7 +1278,7 @@ int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_m
     // are a fixed point of the no-search pass (same neighbours, same pose -> same decisions).
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = c->last_pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
-    ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.rows = c->d_rows; ra.partials = c->d_partials;
+    ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.rows = c->d_rows; ra.partials = c->d_partials;
     ra.gpartials = c->d_gpartials; ra.ticket = c->d_tickets; ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out;
     ra.seq = ++c->seq;                          // the record is rewritten with identical content
     HIPCHK(c, launch_residual(ra, false, c->last_ext, s));

@@ -67,6 +67,7 @@ struct ResidualArgs {
     uint8_t*       sel;             // point_selected_surf (in: previous pass, out: this pass)
     float4*        world;           // feats_down_world
     float4*        normvec;         // normvec (n^, pd2)
+    float4*        plane;           // (n^, d) of the plane fitted in the last search pass, valid where sel
     double*        rows;            // optional [nq][13]: h_x row (12) + h, valid where sel
     double*        partials;        // [nblocks][RED_STRIDE]
     double*        gpartials;       // [groups][RED_STRIDE] partial of each arrival group

@@ -266,18 +266,22 @@ LIO_HD bool plane_fit5(const float (&px)[5], const float (&py)[5], const float (
 
 // neighbour gate, plane test, residual and weight test of one scan point
 // (laserMapping.cpp:1911-1938).  Returns the new point_selected_surf[i].
-LIO_HD bool point_residual(const float (&px)[5], const float (&py)[5], const float (&pz)[5],
-                           float wx, float wy, float wz, float bx, float by, float bz,
-                           float& nx, float& ny, float& nz, float& pd2) {
-    float a, b, c, d;
-    if (!plane_fit5(px, py, pz, 0.1f, a, b, c, d)) return false;           // :1922
+LIO_HD bool residual_from_plane(float a, float b, float c, float d, float wx, float wy, float wz, float bx, float by,
+                                float bz, float& pd2) {
     pd2 = ((a * wx + b * wy) + c * wz) + d;                                 // :1925
     // p_body.norm() is fp64 (V3D), sqrt of it, 0.9 * fabs(pd2) promoted to double, result to float
     const double bn = __builtin_sqrt(((double)bx * (double)bx + (double)by * (double)by) + (double)bz * (double)bz);
     const float s = (float)(1 - 0.9 * __builtin_fabs((double)pd2) / __builtin_sqrt(bn));   // :1927
-    if (!(s > 0.9)) return false;                                           // :1930 (float vs double 0.9)
-    nx = a; ny = b; nz = c;
-    return true;
+    return s > 0.9;                                                         // :1930 (float vs double 0.9)
+}
+LIO_HD bool point_residual(const float (&px)[5], const float (&py)[5], const float (&pz)[5],
+                           float wx, float wy, float wz, float bx, float by, float bz,
+                           float& nx, float& ny, float& nz, float& pd2, float* plane_d = nullptr) {
+    float a, b, c, d;
+    if (!plane_fit5(px, py, pz, 0.1f, a, b, c, d)) return false;           // :1922
+    if (plane_d != nullptr) *plane_d = d;
+    nx = a; ny = b; nz = c;                                                 // (read by the caller only when selected)
+    return residual_from_plane(a, b, c, d, wx, wy, wz, bx, by, bz, pd2);
 }
 
 }  // namespace lio

@@ -66,41 +66,42 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     for (int c = 0; c < 12; ++c) row[c] = 0.0;
 
     if (i < a.nq) {
-        // every load of this point is issued up front (body, flags, the five neighbours): one memory
-        // round trip instead of a dependent chain -- the kernel is latency-bound at ~1.5 waves per SIMD
+        // every load of this point is issued up front (one memory round trip instead of a dependent chain -- the
+        // kernel is latency-bound at ~1.5 waves per SIMD).  A search pass fits the plane through the five neighbours;
+        // the passes after it re-evaluate only the points it accepted (:1916), on the SAME neighbours, so the plane
+        // they would re-fit is the one stored here (16 bytes instead of 80, no QR).
         const float4 b = a.body[i];
-        float4 nb[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) nb[k] = a.nbr[(size_t)k * a.nq_stride + i];
-        const uint8_t cnt_i = SEARCH ? a.cnt[i] : (uint8_t)K;
-        const uint8_t sel_prev = SEARCH ? (uint8_t)1 : a.sel[i];
-        float4 wpt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (SEARCH) wpt = a.world[i];             // a search pass already holds feats_down_world (transform_kernel)
         const PoseQ s = pose_unpack(a.pose);
-        float wx, wy, wz;
+        float wx, wy, wz, nx = 0.f, ny = 0.f, nz = 0.f;
         if (SEARCH) {
+            float4 nb[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) nb[k] = a.nbr[(size_t)k * a.nq_stride + i];
+            const uint8_t cnt_i = a.cnt[i];
+            const float4 wpt = a.world[i];        // a search pass already holds feats_down_world (transform_kernel)
             wx = wpt.x; wy = wpt.y; wz = wpt.z;
+            // points_near.size() < 5 ? false : sqdis[4] > 5 ? false : true          :1911
+            if ((cnt_i >= K) && !(nb[4].w > 5.0f)) {
+                float px[5], py[5], pz[5];
+#pragma unroll
+                for (int k = 0; k < K; ++k) { px[k] = nb[k].x; py[k] = nb[k].y; pz[k] = nb[k].z; }
+                float pd = 0.0f;
+                sel = point_residual(px, py, pz, wx, wy, wz, b.x, b.y, b.z, nx, ny, nz, pd2, &pd);
+                if (sel) a.plane[i] = make_float4(nx, ny, nz, pd);
+            }
         } else {
+            const uint8_t sel_prev = a.sel[i];                             // :1916 (previous flag)
+            const float4 pl = a.plane[i];
             body_to_world(s, b.x, b.y, b.z, wx, wy, wz);                   // :1894-1899
             a.world[i] = make_float4(wx, wy, wz, b.w);
-        }
-        bool cand;
-        if (SEARCH) {
-            // points_near.size() < 5 ? false : sqdis[4] > 5 ? false : true          :1911
-            cand = (cnt_i >= K) && !(nb[4].w > 5.0f);
-        } else {
-            cand = sel_prev != 0;                                          // :1916 (previous flag)
-        }
-        if (cand) {
-            float px[5], py[5], pz[5];
-#pragma unroll
-            for (int k = 0; k < K; ++k) { px[k] = nb[k].x; py[k] = nb[k].y; pz[k] = nb[k].z; }
-            float nx, ny, nz;
-            sel = point_residual(px, py, pz, wx, wy, wz, b.x, b.y, b.z, nx, ny, nz, pd2);
-            if (sel) {
-                a.normvec[i] = make_float4(nx, ny, nz, pd2);               // :1933-1936
-                jacobian_row<EXT>(s, b.x, b.y, b.z, nx, ny, nz, pd2, row, h);
+            if (sel_prev != 0) {
+                nx = pl.x; ny = pl.y; nz = pl.z;
+                sel = residual_from_plane(pl.x, pl.y, pl.z, pl.w, wx, wy, wz, b.x, b.y, b.z, pd2);
             }
+        }
+        if (sel) {
+            a.normvec[i] = make_float4(nx, ny, nz, pd2);                   // :1933-1936
+            jacobian_row<EXT>(s, b.x, b.y, b.z, nx, ny, nz, pd2, row, h);
         }
         a.sel[i] = sel ? 1 : 0;
         if (a.rows != nullptr && sel) {
