@@ -55,6 +55,20 @@ struct Grid {
     uint32_t n_points;                        // stored points (live + tomb-stoned)
 };
 
+// Levels of the hashed 64-ary tree over the grid cells (level L = grid coarsened by 4^L).  Levels 1 .. top-1 have a
+// hash table each (level 1 doubles as the hashed half of the cell directory); the cells of level `top_level` are few
+// (<= TREE_MAX_ROOTS) and are simply listed: the walk starts from all of them, so the depth is set by the extent of
+// the map, not by where the map happens to sit relative to the power-of-two boundaries of the grid.
+constexpr int TREE_MAX_LEVELS = 12;
+constexpr int TREE_MAX_ROOTS = 32;
+struct TreeLevels {
+    uint32_t off[TREE_MAX_LEVELS];   // first slot of level L in ltable (1 <= L < top_level)
+    uint32_t mask[TREE_MAX_LEVELS];  // slots - 1 of level L
+    int      top_level;              // level of the root cells
+    int      n_roots;
+    uint32_t root_x[TREE_MAX_ROOTS], root_y[TREE_MAX_ROOTS], root_z[TREE_MAX_ROOTS];   // their coordinates at top_level
+};
+
 // pos3, rot xyzw, offR xyzw, offT3 -- passed to kernels by value (112 bytes of kernarg)
 struct Pose14 { double v[14]; };
 

@@ -210,12 +210,8 @@ int finish_index(lio_ctx* c, uint32_t n) {
     c->grid.n_points = n;
     HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_mkeys, n, c->d_cell_keys, c->d_cell_counts,
                                     c->d_counters + 4, s));
-    // first / last Morton key: the top level is the lowest one at which a single cell holds every point
-    uint64_t kfirst = 0, klast = 0;
     uint32_t n_cells = 0;
     HIPCHK(c, hipMemcpyAsync(&n_cells, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&kfirst, c->d_mkeys, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&klast, c->d_mkeys + (n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_cell_counts, c->d_cell_starts, n_cells, s));
     c->n_cells = n_cells; c->n_cells_built = n_cells;
@@ -223,25 +219,28 @@ int finish_index(lio_ctx* c, uint32_t n) {
     // ---- coarser levels of the hashed 64-ary tree (exact fallback of the k-NN): level L+1 is a
     // reduce-by-key of level L (keys >> 6, counts summed) -- the point array is not touched again
     TreeLevels lv{};
-    const uint64_t diff = kfirst ^ klast;
-    int top = 2;                               // levels 0 and 1 always have tables: the k-NN kernel's cell directory hangs off level 1
-    if (diff != 0) top = (63 - __builtin_clzll(diff)) / 6 + 1;
-    if (top < 2) top = 2;
-    lv.top_level = top;
-    {
-        const uint64_t prefix = 6 * top >= 64 ? 0ull : (kfirst >> (6 * top));
-        lv.top_cx = compact21(prefix >> 2); lv.top_cy = compact21(prefix >> 1); lv.top_cz = compact21(prefix);
-    }
     size_t used = 0;
     uint32_t n_prev = n_cells;
     // ping-pong between the cell arrays and the (now free) build scratch
     uint64_t* kin = c->d_cell_keys; uint32_t* cin = c->d_cell_counts;
     uint64_t* kout = c->d_mkeys_tmp; uint32_t* cout = c->d_vals_tmp;
-    for (int L = 1; L < top; ++L) {
+    // levels 0 and 1 always exist (the cell directory hangs off level 1); the first level from 2 up with at most
+    // TREE_MAX_ROOTS cells is not hashed but listed: its cells are the roots of the walk
+    for (int L = 1; L < TREE_MAX_LEVELS; ++L) {
         HIPCHK(c, coarsen_level(c->d_temp, c->temp_bytes, kin, cin, n_prev, kout, cout, c->d_counters + 4, s));
         uint32_t n_l = 0;
         HIPCHK(c, hipMemcpyAsync(&n_l, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        if (L >= 2 && n_l <= (uint32_t)TREE_MAX_ROOTS) {
+            uint64_t rk[TREE_MAX_ROOTS];
+            HIPCHK(c, hipMemcpyAsync(rk, kout, (size_t)n_l * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            lv.top_level = L; lv.n_roots = (int)n_l;
+            for (uint32_t i = 0; i < n_l; ++i) {
+                lv.root_x[i] = compact21(rk[i] >> 2); lv.root_y[i] = compact21(rk[i] >> 1); lv.root_z[i] = compact21(rk[i]);
+            }
+            break;
+        }
         size_t sl = 64;
         while (sl < (size_t)n_l * 4) sl <<= 1;
         if (used + sl > c->ltable_slots) {
@@ -380,8 +379,7 @@ int apply_pending(lio_ctx* c) {
     ApplyArgs a{};
     a.map_pts = c->d_pts; a.grid = c->grid; a.ltable = c->d_ltable;
     a.child = c->d_child; a.block_bump = c->d_apply + 9; a.blocks_cap = (uint32_t)c->child_blocks_cap;
-    for (int L = 0; L < 12; ++L) { a.loff[L] = c->levels.off[L]; a.lmask[L] = c->levels.mask[L]; }
-    a.top_level = c->levels.top_level; a.top_cx = c->levels.top_cx; a.top_cy = c->levels.top_cy; a.top_cz = c->levels.top_cz;
+    a.levels = c->levels;
     a.pend = c->d_pend; a.order = c->d_porder2; a.cell_key = c->d_pcell; a.group_start = c->d_pgstart;
     a.group_count = c->d_pgcount; a.n_groups = c->d_apply + 8; a.plan = c->d_plan; a.new_size = c->d_pnewsize;
     a.new_off = c->d_pnewoff; a.tail = c->n_points; a.stats = c->d_apply;

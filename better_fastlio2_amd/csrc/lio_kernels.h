@@ -33,13 +33,6 @@ struct KernelTimer { hipEvent_t start = nullptr, stop = nullptr; };
 hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s, KernelTimer t = KernelTimer());
 
 // hashed 64-ary tree: level L = grid coarsened by 4^L, tables of levels 1.. live in one buffer
-constexpr int TREE_MAX_LEVELS = 12;
-struct TreeLevels {
-    uint32_t off[TREE_MAX_LEVELS];   // first slot of level L in ltable (L >= 1)
-    uint32_t mask[TREE_MAX_LEVELS];  // slots - 1 of level L
-    int      top_level;              // level of the single node that holds every point
-    uint32_t top_cx, top_cy, top_cz; // its cell coordinates at top_level
-};
 struct TreeArgs {
     const float4*    map_pts;
     const uint2*     child;         // cell directory blocks (level-0 cells), see lio_device.h

@@ -426,9 +426,10 @@ hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s, Ke
 // wave-uniform and candidates are merged with DPP min reductions.
 // ---------------------------------------------------------------------------------------------
 // Only level-0 cells are leaves: their buckets are the one thing that is contiguous in the point array
-// (a bucket moves to the tail of the array when points are added to its cell, lio_mapadd.hip).  A pop
-// pushes at most 63 net entries and the tree is at most 11 levels deep (21-bit cell coordinates).
-constexpr int TREE_STACK = 704;
+// (a bucket moves to the tail of the array when points are added to its cell, lio_mapadd.hip).  The walk
+// starts with at most TREE_MAX_ROOTS entries, a pop pushes at most 63 net entries and the tree is at most 11
+// levels deep (21-bit cell coordinates): 32 + 63 * 11 < 736.
+constexpr int TREE_STACK = 736;
 constexpr uint32_t TREE_OVERFLOW = 0x80000000u;  // or-ed into n_unresolved if the stack bound were ever violated
 
 // squared distance from q to the box of cell (cx,cy,cz) at `level` (edge = cell * 4^level); same
@@ -603,13 +604,29 @@ __global__ __launch_bounds__(64) void knn_tree_kernel(TreeArgs a) {
         }
 
         // ---- phase B: best-first walk of the whole tree, pruned by what phase A already holds
+        // the walk starts from every root cell that can still hold a better point, nearest on top of the stack
         int sp = 0;
         if (a.grid.n_points > 0) {
-            if (lane == 0) {                              // the root is always an internal node (top_level >= 1)
-                s_node[0] = make_uint4(0u, a.grid.n_points, (uint32_t)a.levels.top_level, 0u);
-                s_cell[0] = make_uint4(a.levels.top_cx, a.levels.top_cy, a.levels.top_cz, 0u);
+            float bd = 0.0f;
+            bool want = false;
+            uint32_t rx = 0, ry = 0, rz = 0;
+            if (lane < a.levels.n_roots) {
+                rx = a.levels.root_x[lane]; ry = a.levels.root_y[lane]; rz = a.levels.root_z[lane];
+                bd = cell_box_sqdist(qx, qy, qz, rx, ry, rz, a.levels.top_level, cell);
+                want = bd <= top.tau();
             }
-            sp = 1;
+            const u64 wm = __ballot(want);
+            int rank = 0;
+            for (u64 mm = wm; mm != 0; mm &= mm - 1) {
+                const int j = __ffsll((long long)mm) - 1;
+                const float bj = __shfl(bd, j, 64);
+                rank += (bj > bd || (bj == bd && j < lane)) ? 1 : 0;
+            }
+            if (want) {
+                s_node[rank] = make_uint4(0u, 1u, (uint32_t)a.levels.top_level, __float_as_uint(bd));
+                s_cell[rank] = make_uint4(rx, ry, rz, 0u);
+            }
+            sp = __popcll(wm);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

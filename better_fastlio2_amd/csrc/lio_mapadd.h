@@ -47,9 +47,7 @@ struct ApplyArgs {
     uint2*           child;         // cell directory: [blocks][64] {start, count}
     uint32_t*        block_bump;    // next free child block
     uint32_t         blocks_cap;
-    uint32_t         loff[12], lmask[12];
-    int              top_level;
-    uint32_t         top_cx, top_cy, top_cz;
+    TreeLevels       levels;
     const float4*    pend;          // appended points, batch order
     const uint32_t*  order;         // pending indices sorted by cell key (stable)
     const uint64_t*  cell_key;      // per touched cell: packed key

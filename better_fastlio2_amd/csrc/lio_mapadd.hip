@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void cell_plan_kernel(ApplyArgs a) {
         const uint64_t key = a.cell_key[g];
         const uint32_t cx = (uint32_t)(key >> 42) & 0x1fffffu, cy = (uint32_t)(key >> 21) & 0x1fffffu, cz = (uint32_t)key & 0x1fffffu;
         CellPlan pl{0u, 0u, 0xffffffffu, 0u};
-        cell_find(a.ltable + a.loff[1], a.lmask[1], a.child, cx, cy, cz, pl.old_start, pl.old_count, &pl.index);
+        cell_find(a.ltable + a.levels.off[1], a.levels.mask[1], a.child, cx, cy, cz, pl.old_start, pl.old_count, &pl.index);
         pl.found = pl.old_count != 0u ? 1u : 0u;                  // records are only ever written with count >= 1
         uint32_t live = 0;
         for (uint32_t i = 0; i < pl.old_count; ++i) live += a.map_pts[pl.old_start + i].w == 0.0f ? 1u : 0u;
@@ -220,18 +220,22 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
         }
         // ---- a cell the map did not have ----------------------------------------------------------
         atomicAdd(a.stats + 0, 1u);
-        const int sh_top = 2 * a.top_level;
-        if ((cx >> sh_top) != a.top_cx || (cy >> sh_top) != a.top_cy || (cz >> sh_top) != a.top_cz) {
-            atomicOr(a.stats + 2, APPLY_FLAG_OUTSIDE_TOP);
-            continue;
+        // the cell must hang under one of the root cells of the tree
+        {
+            const int sh_top = 2 * a.levels.top_level;
+            const uint32_t ax = cx >> sh_top, ay = cy >> sh_top, az = cz >> sh_top;
+            bool under_root = false;
+            for (int i = 0; i < a.levels.n_roots; ++i)
+                under_root = under_root || (a.levels.root_x[i] == ax && a.levels.root_y[i] == ay && a.levels.root_z[i] == az);
+            if (!under_root) { atomicOr(a.stats + 2, APPLY_FLAG_OUTSIDE_TOP); continue; }
         }
         // level 1: the entry names the child block of the cell directory (a new level-1 cell takes a block from the
         // pool; if two lanes race for the same new cell one block number is simply left unused).  Levels above:
         // existence marks (the tree walk only asks "is this child non-empty").
-        for (int L = 1; L < a.top_level; ++L) {
+        for (int L = 1; L < a.levels.top_level; ++L) {
             const uint64_t ck = pack_key(cx >> (2 * L), cy >> (2 * L), cz >> (2 * L));
-            HashEntry* lt = a.ltable + a.loff[L];
-            const uint32_t ls = table_claim(lt, a.lmask[L], ck);
+            HashEntry* lt = a.ltable + a.levels.off[L];
+            const uint32_t ls = table_claim(lt, a.levels.mask[L], ck);
             if (ls == 0xffffffffu) { atomicOr(a.stats + 2, APPLY_FLAG_TABLE_FULL); break; }
             if (L == 1) {
                 uint32_t* sp = &lt[ls].start;
