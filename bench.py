@@ -128,7 +128,7 @@ def cpu_baseline(world_pts, scan, x0, P0, max_iter: int, ext: bool, sample_every
         method = 1
     t_build = time.perf_counter() - t_build0
     ts = []
-    for _ in range(3):
+    for _ in range(5):
         t0 = time.perf_counter()
         xo, Po, arrs, log = po.update_iterated(om, x0, P0, body, 0.001, max_iter, None, ext, knn_method=method)
         ts.append(time.perf_counter() - t0)
@@ -145,9 +145,9 @@ def cpu_baseline(world_pts, scan, x0, P0, max_iter: int, ext: bool, sample_every
     return {"value": 1.0 / t_step, "unit": "scans/s", "cores": 1, "kind": "port",
             "knn": "reference ikd-Tree (oracle/_ref, verbatim)" if use_ref else "oracle kd-tree restatement",
             "knn_us_per_point": secs / len(wq) * 1e6,
-            "sample": f"every {sample_every}th point of the scan ({len(body)} of {len(scan.body)}) vs the full "
-                      f"{len(world_pts)}-point map, {len(log)} passes, median of 3, scaled x{sample_every}; "
-                      f"tree build {t_build:.1f}s untimed",
+            "sample": (f"the whole scan ({len(body)} points)" if sample_every == 1 else
+                       f"every {sample_every}th point of the scan ({len(body)} of {len(scan.body)}), scaled x{sample_every},")
+                      + f" vs the full {len(world_pts)}-point map, {len(log)} passes, median of 5; tree build {t_build:.1f}s untimed",
             "passes": int(len(log)), "posterior": xo}
 
 
@@ -298,7 +298,8 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            cb = cpu_baseline(world.points, scan, x0, P0, max_iter, ext, sample_every=4)
+            # the whole scan when a CPU scan step stays around a second (C2: 0.4 s), a sample of it otherwise
+            cb = cpu_baseline(world.points, scan, x0, P0, max_iter, ext, sample_every=1 if nq <= 200_000 else 8)
             import gc
             gc.collect()                                       # ~RefIkdTree joins the thread (prints again)
         finally:
