@@ -49,6 +49,7 @@ struct lio_ctx {
     uint32_t n_points = 0, n_live = 0, n_cells = 0;   // slots in use (live + tomb-stones + retired copies), live points, cells
     size_t slots_cap = 0;                      // physical slots of d_pts / d_pts_tmp (cap_map + room for re-written buckets)
     uint32_t n_retired = 0;                    // TOMB_MOVED slots since the last full rebuild
+    uint32_t n_dead = 0;                       // box-deleted slots since the last full rebuild
     long long n_incremental_updates = 0, n_full_rebuilds = 0;
     uint32_t n_new_cells = 0, n_cells_built = 0;   // cells inserted since / present at the last full rebuild
     // points appended by Add_Points, waiting for apply_pending (batch order)
@@ -206,7 +207,7 @@ int upload_points(lio_ctx* c, const float* pts, size_t n, int stride_bytes, floa
 int finish_index(lio_ctx* c, uint32_t n) {
     hipStream_t s = c->stream;
     c->n_points = n; c->n_live = n; c->n_cells = 0;
-    c->n_retired = 0; c->n_new_cells = 0; c->n_cells_built = 0;
+    c->n_retired = 0; c->n_dead = 0; c->n_new_cells = 0; c->n_cells_built = 0;
     c->grid.n_points = n;
     HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_mkeys, n, c->d_cell_keys, c->d_cell_counts,
                                     c->d_counters + 4, s));
@@ -296,7 +297,7 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
     c->hint_valid = false;                     // neighbours of an older map state no longer bound a search
     if (n == 0) {
         c->n_points = 0; c->n_live = 0; c->n_cells = 0;
-        c->n_retired = 0; c->n_new_cells = 0; c->n_cells_built = 0;
+        c->n_retired = 0; c->n_dead = 0; c->n_new_cells = 0; c->n_cells_built = 0;
         c->grid.n_points = 0;
         // empty map: an all-empty level-1 table keeps the kernels well defined
         HIPCHK(c, hipMemsetAsync(c->d_ltable, 0xFF, 64 * sizeof(HashEntry), s));
@@ -400,7 +401,7 @@ int apply_pending(lio_ctx* c) {
     c->n_cells += st[0]; c->n_new_cells += st[0]; c->n_retired += st[1];
     ++c->n_incremental_updates;
     const uint32_t retired_budget = c->n_live / 8 > 65536u ? c->n_live / 8 : 65536u;
-    if (st[2] != 0 || c->n_retired > retired_budget || (size_t)c->n_new_cells * 4 > (size_t)c->n_cells_built + 1024)
+    if (st[2] != 0 || (size_t)c->n_retired + (size_t)c->n_dead > (size_t)retired_budget || (size_t)c->n_new_cells * 4 > (size_t)c->n_cells_built + 1024)
         return rebuild_full(c);
     return LIO_OK;
 }
@@ -897,6 +898,7 @@ int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_delete
     }
     c->n_live -= (uint32_t)total;
     c->box_deleted_pending += (uint32_t)total;
+    c->n_dead += (uint32_t)total;              // dead slots count towards the budget that triggers the next full rebuild
     if (n_deleted) *n_deleted = total;
     return LIO_OK;
 }

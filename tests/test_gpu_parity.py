@@ -528,6 +528,42 @@ def test_acquire_removed_points(gpu_capi, oracle, small_case):
     ctx.close()
 
 
+@pytest.mark.parametrize("shift", [2e-4, 5e-3, 0.03, 0.4])
+def test_repeated_search_stays_exact(gpu_capi, oracle, small_case, shift):
+    """Second and third searches of the same scan (esekfom.hpp:1824-1838) are bounded by the previous neighbours
+    (knn27_kernel<.., HINT>): Nearest_Points must equal a fresh search at the new pose -- for pose changes from the
+    filter's convergence scale (0.2 mm) to far beyond it (0.4 m, where the old neighbours bound almost nothing)."""
+    w, sc, st = small_case["world"], small_case["scan"], small_case["state14"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=20_000, max_map_points=400_000)
+    ctx.map_build(w.points)
+    om = oracle.OracleMap(0.2); om.build(w.points)
+    ctx.scan_set(sc.body)
+    ctx.measure(st, True, False)
+    rng = np.random.default_rng(int(shift * 1e6))
+    for rep in range(2):
+        st2 = np.array(st, dtype=np.float64)
+        st2[0:3] += rng.normal(0, 1, 3) * shift / np.sqrt(3)
+        ang = shift * 0.2
+        dq = np.array([ang / 2 * 0.6, -ang / 2 * 0.3, ang / 2 * 0.74, 1.0]); dq /= np.linalg.norm(dq)
+        x, y, z, wq = st2[3:7]
+        st2[3:7] = [wq * dq[0] + x * dq[3] + y * dq[2] - z * dq[1], wq * dq[1] - x * dq[2] + y * dq[3] + z * dq[0],
+                    wq * dq[2] + x * dq[1] - y * dq[0] + z * dq[3], wq * dq[3] - x * dq[0] - y * dq[1] - z * dq[2]]
+        g = ctx.measure(st2, True, False)
+        gx, gd, gc = ctx.neighbors()
+        wq2 = oracle.body_to_world(st2, sc.body)
+        ox, od, oc, _ = om.knn(wq2)
+        assert np.array_equal(gc, oc)
+        assert bits_equal(gd, od)
+        x6, d6, c6, _ = om.knn(wq2, 6, 1)
+        tie_free = (np.diff(d6, axis=1) > 0).all(1)
+        assert tie_free.mean() > 0.99 and bits_equal(gx[tie_free], ox[tie_free])
+        arr = oracle.ScanArrays(len(sc.body))
+        valid, hx, h, m, rm = oracle.h_share_model(om, st2, sc.body, arr, True, False)
+        assert g["m"] == m
+        st = st2
+    ctx.close()
+
+
 def test_search_after_map_mutation_ignores_stale_bound(gpu_capi, oracle, small_case):
     """The repeated-search bound (previous neighbours) must be dropped when the map changes between two
     searches of the same scan: delete a slab that holds many of the previous neighbours, search again."""
