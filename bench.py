@@ -240,7 +240,8 @@ def main():
     ctx.census_enable(False)
     cand_sum, unresolved = g["n_candidates"], g["n_unresolved"]
     log = step()
-    pos_err = float(np.linalg.norm(kf.get_x()[:3] - scan.pos))
+    x_gpu = kf.get_x().copy()                                  # posterior of the benchmarked step (parity gate below)
+    pos_err = float(np.linalg.norm(x_gpu[:3] - scan.pos))
 
     # untimed: per-family kernel times (a HIP event pair on every launch)
     ctx.profile_enable(True)
@@ -308,7 +309,15 @@ def main():
             ctypes.CDLL(None).fflush(None)                     # the tree's printf()s sit in libc's buffer
             os.dup2(saved, 1)
             os.close(saved)
-        cb.pop("posterior")
+        # parity gate of this very measurement: the CPU path ran the same scan step from the
+        # same prior -- its posterior against the GPU's (bar: 1e-4 m / 1e-5 rad)
+        x_cpu = cb.pop("posterior")
+        if cb["sample"].startswith("the whole scan") and not a.map_update:
+            q1, q2 = x_gpu[3:7], x_cpu[3:7]
+            out["parity"] = {"pos_diff_m": float(np.linalg.norm(x_gpu[:3] - x_cpu[:3])),
+                             "rot_diff_rad": float(2.0 * np.arcsin(min(1.0, 0.5 * min(np.linalg.norm(q1 - q2), np.linalg.norm(q1 + q2))))),
+                             "state_max_abs_diff": float(np.max(np.abs(x_gpu - x_cpu))),
+                             "against": "oracle h_share_model + IKFoM update on the reference ikd-Tree, same prior, same scan"}
         out["cpu_baseline"] = cb
     print(json.dumps(out), flush=True)
     if dist is not None:
