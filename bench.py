@@ -315,7 +315,7 @@ def main():
         if cb["sample"].startswith("the whole scan") and not a.map_update:
             q1, q2 = x_gpu[3:7], x_cpu[3:7]
             out["parity"] = {"pos_diff_m": float(np.linalg.norm(x_gpu[:3] - x_cpu[:3])),
-                             "rot_diff_rad": float(2.0 * np.arcsin(min(1.0, 0.5 * min(np.linalg.norm(q1 - q2), np.linalg.norm(q1 + q2))))),
+                             "rot_diff_rad": float(4.0 * np.arcsin(min(1.0, 0.5 * min(np.linalg.norm(q1 - q2), np.linalg.norm(q1 + q2))))),
                              "state_max_abs_diff": float(np.max(np.abs(x_gpu - x_cpu))),
                              "against": "oracle h_share_model + IKFoM update on the reference ikd-Tree, same prior, same scan"}
         out["cpu_baseline"] = cb
