@@ -1058,7 +1058,9 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
 static int scan_reset(lio_ctx* c, int n) {
     c->nq = n;
     c->have_scan = true; c->have_search = false; c->have_pass = false; c->last_m = 0; c->hint_valid = false;
-    if (n > 0) HIPCHK(c, hipMemsetAsync(c->d_sel, 1, (size_t)n, c->stream));     // laserMapping.cpp:2131
+    // point_selected_surf starts all-true (laserMapping.cpp:2131), but nothing reads it before the first pass of
+    // the scan has written it: that pass must search (lio_measure enforces it) and a search pass decides from the
+    // neighbours alone (:1911) -- so there is no fill launch here
     return LIO_OK;
 }
 int lio_scan_set(lio_ctx* c, const float* body_pts, int n, int stride_bytes) {
