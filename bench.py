@@ -204,16 +204,34 @@ def main():
     step_no = [0]
     maint = {"n_add": 0, "n_nodown": 0, "seconds": 0.0}
 
+    # The reference's host is C++; in the loop below the C entry points are called with arguments converted once
+    # (the numpy -> ctypes conversions of the convenience wrappers cost microseconds per call, a scan step is ~160).
+    import ctypes as C
+    L = ctx.L
+    x0_c = np.ascontiguousarray(x0, np.float64); P0_c = np.ascontiguousarray(P0, np.float64)
+    x0_p, P0_p = x0_c.ctypes.data_as(C.c_void_p), P0_c.ctypes.data_as(C.c_void_p)
+    d_body_p = C.c_void_p(d_body.data_ptr())
+    ulog = capi.lio_update_log()
+    ulog_ref = C.byref(ulog)
+    ext_i = int(ext)
+
     def step():
         if a.map_update:
             d_b, xs = drive[step_no[0] % len(drive)]
             step_no[0] += 1
+            kf.change_x(xs)
+            kf.change_P(P0)
+            ctx.scan_set_device(d_b.data_ptr(), nq)
+            lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, ext)
         else:
-            d_b, xs = d_body, x0
-        kf.change_x(xs)
-        kf.change_P(P0)
-        ctx.scan_set_device(d_b.data_ptr(), nq)
-        lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, ext)
+            L.lio_eskf_change_x(kf.h, x0_p)
+            L.lio_eskf_change_P(kf.h, P0_p)
+            rc = L.lio_scan_set_device(ctx.h, d_body_p, nq)
+            if rc == 0:
+                rc = L.lio_eskf_update_iterated_dyn_share_modified(kf.h, ctx.h, 0.001, ext_i, ulog_ref)
+            if rc != 0:
+                raise capi.LioError(f"scan step failed: {capi.ERRORS.get(rc, rc)}: {L.lio_last_error(ctx.h).decode()}")
+            lg = ulog
         if a.map_update:
             t0 = time.perf_counter()
             post = kf.get_x()[:14]
@@ -240,6 +258,7 @@ def main():
     ctx.census_enable(False)
     cand_sum, unresolved = g["n_candidates"], g["n_unresolved"]
     log = step()
+    log = log if isinstance(log, dict) else {k: getattr(log, k) for k, _ in capi.lio_update_log._fields_}
     x_gpu = kf.get_x().copy()                                  # posterior of the benchmarked step (parity gate below)
     pos_err = float(np.linalg.norm(x_gpu[:3] - scan.pos))
 

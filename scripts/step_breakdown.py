@@ -1,0 +1,25 @@
+"""Host-side breakdown of one scan step: time inside lio_measure (launch + wait), host algebra, the rest."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from better_fastlio2_amd import capi, synth
+nm, nq = 5_000_000, 100_000
+world = synth.make_world(nm, 0.2); scan = synth.make_scan(world, nq, seed=synth.SEED + 1, pos=(3.1, -2.2, 0.0), rpy=(0.004, -0.006, 0.52))
+pos, rot = synth.perturb_state(scan, seed=synth.SEED + 2)
+x0 = capi.make_state26(pos, rot, scan.off_R, scan.off_T); P0 = synth.init_cov()
+ctx = capi.LioContext(0.2, max_scan_points=nq, max_map_points=nm + 1024)
+ctx.map_build(world.points)
+dbuf = capi.scan_to_device(scan.body)
+kf = capi.Esekf(3)
+def step():
+    kf.change_x(x0); kf.change_P(P0); ctx.scan_set_device(dbuf.ptr, nq)
+    return kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+for _ in range(30): step()
+ctx.synchronize()
+N = 300; meas = solve = 0.0
+t0 = time.perf_counter()
+for _ in range(N):
+    lg = step(); meas += lg["measure_seconds"]; solve += lg["solve_seconds"]
+ctx.synchronize()
+wall = (time.perf_counter() - t0) / N * 1e6
+print("step %.1f us: inside lio_measure %.1f us (4 passes), host algebra %.1f us, python+glue %.1f us" % (wall, meas / N * 1e6, solve / N * 1e6, wall - (meas + solve) / N * 1e6))
