@@ -43,7 +43,7 @@ struct lio_ctx {
     uint32_t* d_rank = nullptr;                // iota scratch of the index build
     void* d_temp = nullptr;
     size_t temp_bytes = 0;
-    uint32_t* d_counters = nullptr;            // [0] n_unresolved, [1] reduction ticket, [2..3] build/add scratch, [4] run counts
+    uint32_t* d_counters = nullptr;            // [0] n_unresolved, [2..3] delete / build scratch, [4] run counts, [7] removed points
     unsigned long long* d_cand = nullptr;
     float* d_boxes = nullptr;                  // up to 64 boxes
     uint32_t n_points = 0, n_live = 0, n_cells = 0;   // slots in use (live + tomb-stones + retired copies), live points, cells
@@ -78,8 +78,8 @@ struct lio_ctx {
     float4 *d_body = nullptr, *d_world = nullptr, *d_nbr = nullptr, *d_normvec = nullptr, *d_plane = nullptr;
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
     uint8_t* d_unres = nullptr;                // per query: 1 = needs the exact tree walk
-    double *d_rows = nullptr, *d_partials = nullptr, *d_gpartials = nullptr;
-    uint32_t* d_tickets = nullptr;             // [1 + groups] arrival counters of the residual kernel's reduction
+    double* d_rows = nullptr;
+    unsigned long long *d_units = nullptr, *d_gunits = nullptr;   // stamped partial sums of the residual kernel's reduction
     DeviceOut* h_out = nullptr;                // pinned + mapped: the final reduction writes it directly
     DeviceOut* d_out = nullptr;                // device alias of h_out
     unsigned long long seq = 0;                // sequence number of the last pass (polled in h_out->seq)
@@ -553,12 +553,12 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_cnt, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_sel, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_unres, nq));
-    CREATE_CHK(hipMalloc((void**)&c->d_partials, (size_t)residual_blocks((int)nq) * RED_STRIDE * sizeof(double)));
     {
-        const size_t groups = ((size_t)residual_blocks((int)nq) + RED_GROUP - 1) / RED_GROUP;
-        CREATE_CHK(hipMalloc((void**)&c->d_gpartials, groups * RED_STRIDE * sizeof(double)));
-        CREATE_CHK(hipMalloc((void**)&c->d_tickets, (1 + groups) * sizeof(uint32_t)));
-        CREATE_CHK(hipMemset(c->d_tickets, 0, (1 + groups) * sizeof(uint32_t)));
+        const size_t blocks = (size_t)residual_blocks((int)nq), groups = (blocks + RED_GROUP - 1) / RED_GROUP;
+        CREATE_CHK(hipMalloc((void**)&c->d_units, blocks * RED_STRIDE * 2 * sizeof(unsigned long long)));
+        CREATE_CHK(hipMemset(c->d_units, 0, blocks * RED_STRIDE * 2 * sizeof(unsigned long long)));     // stamp 0: no pass has it
+        CREATE_CHK(hipMalloc((void**)&c->d_gunits, groups * RED_STRIDE * 2 * sizeof(unsigned long long)));
+        CREATE_CHK(hipMemset(c->d_gunits, 0, groups * RED_STRIDE * 2 * sizeof(unsigned long long)));
     }
     CREATE_CHK(hipHostMalloc((void**)&c->h_out, sizeof(DeviceOut), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->h_out, 0, sizeof(DeviceOut));
@@ -576,7 +576,7 @@ void lio_destroy(lio_ctx* c) {
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
                    c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
-                   c->d_partials, c->d_gpartials, c->d_tickets, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
+                   c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_minmax,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
@@ -1232,9 +1232,9 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     }
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
-    ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.rows = nullptr; ra.partials = c->d_partials;
+    ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.rows = nullptr; ra.units = c->d_units; ra.gunits = c->d_gunits;
     const unsigned long long seq = ++c->seq;
-    ra.gpartials = c->d_gpartials; ra.ticket = c->d_tickets; ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
+    ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
     HIPCHK(c, launch_residual(ra, do_search != 0, ext, s, prof_timer(c, LIO_PROF_RESIDUAL)));
     // The record lands in host-mapped memory; poll its sequence number instead of paying for a
     // device-to-host copy plus a stream synchronisation.  hipStreamQuery guards against a fault.
@@ -1280,8 +1280,8 @@ int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_m
     // are a fixed point of the no-search pass (same neighbours, same pose -> same decisions).
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = c->last_pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
-    ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.rows = c->d_rows; ra.partials = c->d_partials;
-    ra.gpartials = c->d_gpartials; ra.ticket = c->d_tickets; ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out;
+    ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.rows = c->d_rows; ra.units = c->d_units; ra.gunits = c->d_gunits;
+    ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out;
     ra.seq = ++c->seq;                          // the record is rewritten with identical content
     HIPCHK(c, launch_residual(ra, false, c->last_ext, s));
     const size_t b_rows = (size_t)nq * 13 * sizeof(double);

@@ -62,9 +62,8 @@ struct ResidualArgs {
     float4*        normvec;         // normvec (n^, pd2)
     float4*        plane;           // (n^, d) of the plane fitted in the last search pass, valid where sel
     double*        rows;            // optional [nq][13]: h_x row (12) + h, valid where sel
-    double*        partials;        // [nblocks][RED_STRIDE]
-    double*        gpartials;       // [groups][RED_STRIDE] partial of each arrival group
-    uint32_t*      ticket;          // [1 + groups] arrival counters (top, then one per group), zero between launches
+    unsigned long long* units;      // [nblocks][RED_STRIDE][2] stamped halves of the workgroup partial sums
+    unsigned long long* gunits;     // [groups][RED_STRIDE][2] the same for the group sums
     uint32_t*      n_unresolved;    // read into the record and reset (search passes)
     unsigned long long* cand_total; // ditto
     DeviceOut*     out;             // host-mapped result record

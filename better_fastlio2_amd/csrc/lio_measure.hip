@@ -10,8 +10,8 @@
 //       s > 0.9 test (:1925-1930), the fp64 Jacobian row (:1976-2001); the rows of a 256-point
 //       workgroup are staged in LDS and reduced to the unique entries of H^T H, H^T h, the
 //       residual sum and the row count in a FIXED order (run-to-run bit-stable, no atomics).
-//       The workgroup that arrives LAST (device-scope ticket) sums the per-workgroup partials in a
-//       fixed order, expands the symmetric matrix and writes the DeviceOut record straight into
+//       Designated workgroups fold the per-workgroup sums in two levels (stamped 8-byte units, the poll is
+//       the read: no arrival counters), the last one expands the symmetric matrix and writes the DeviceOut record straight into
 //       host-mapped memory, publishing it with a system-scope release of a sequence number: one
 //       launch per pass, no separate reduction kernel, no device-to-host copy.
 #include "lio_kernels.h"
@@ -58,6 +58,8 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
 
     const int tid = threadIdx.x;
     const int i = blockIdx.x * BS + tid;
+    __shared__ uint32_t s_failed;                  // a bounded wait of the reduction ran out (reported, never silent)
+    if (tid == 0) s_failed = 0u;
     bool sel = false;
     double row[12];
     double h = 0.0;
@@ -131,42 +133,75 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     }
     s_part[seg][e] = acc;
     __syncthreads();
-    if (tid < S::NE) {
-        double t = 0.0;
-#pragma unroll
-        for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
-        // write-through (sc1) store: the last-arriving workgroup reads it back with sc1 loads, so no
-        // L2 write-back fence is needed (cdna_hip_programming.md G16, "sc1 both sides" form)
-        __hip_atomic_store(&a.partials[(size_t)blockIdx.x * RED_STRIDE + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---- two-level last-arriver reduction ------------------------------------------------------------
-    // A single arrival counter would serialise ~400 device-scope atomics at the tail of the launch
-    // (~13 ns each).  Workgroups arrive per GROUP of RED_GROUP; the last arriver of a group folds the
-    // group's partials into one group partial and arrives at the top counter; the last group arriver
-    // folds the group partials.  Every sum has a fixed order, whoever arrives last.
-    __shared__ uint32_t s_last;
+    // ---- two-level reduction across workgroups, no arrival counters ---------------------------------------
+    // A partial sum is published as two 8-byte units per entry, {low 32 bits | stamp} and {high 32 bits | stamp},
+    // stamp = this pass's sequence number: an 8-byte store is single-copy atomic, so whoever reads both units with
+    // the stamp of THIS pass has the value -- the poll IS the read, there is no ticket, no fence, no second round
+    // trip.  The LAST workgroup (by index) of every group of RED_GROUP folds the group: it spins on the units of
+    // the others; the last workgroup of the grid then folds the group sums the same way and writes the record.
+    // Workgroups are dispatched in index order and a reducer only ever waits for lower indices, so what it
+    // waits for is running or done.  Every sum has a fixed order; the waits are bounded (a timeout is reported).
+    typedef unsigned long long u64;
+    __shared__ double s_own[S::NEP];
     const int nblocks = (int)gridDim.x;
     const int grp = (int)blockIdx.x / RED_GROUP;
     const int ngroups = (nblocks + RED_GROUP - 1) / RED_GROUP;
     const int grp_first = grp * RED_GROUP;
     const int grp_size = (grp_first + RED_GROUP <= nblocks) ? RED_GROUP : nblocks - grp_first;
-    if (tid == 0) {
-        const uint32_t prev = __hip_atomic_fetch_add(a.ticket + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev == (uint32_t)(grp_size - 1) ? 1u : 0u;
-        if (s_last) a.ticket[1 + grp] = 0u;                        // consumed: ready for the next launch
-    }
-    __syncthreads();
-    if (s_last == 0u) return;
-    double f = 0.0;
-    if (e < S::NE) {
+    const bool grp_reducer = (int)blockIdx.x == grp_first + grp_size - 1;
+    const bool final_reducer = (int)blockIdx.x == nblocks - 1;
+    const u64 stamp_hi = (u64)(uint32_t)a.seq << 32;
+    constexpr u64 HI_MASK = 0xffffffff00000000ull;
+    constexpr unsigned SPIN_LIMIT = 1u << 18;
+    if (tid < S::NE) {
+        double t = 0.0;
 #pragma unroll
-        for (int j = seg; j < RED_GROUP; j += S::SEG)
-            if (j < grp_size)
-                f += __hip_atomic_load(&a.partials[(size_t)(grp_first + j) * RED_STRIDE + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
+        if (grp_reducer) {
+            s_own[tid] = t;                                 // its own partial never leaves the workgroup
+        } else {
+            const u64 bits = (u64)__double_as_longlong(t);
+            u64* dst = a.units + ((size_t)blockIdx.x * RED_STRIDE + tid) * 2;
+            __hip_atomic_store(dst + 0, (bits & 0xffffffffull) | stamp_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, (bits >> 32) | stamp_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    if (!grp_reducer) return;
+
+    // poll-and-read `count` stamped partials starting at `src` (stride RED_STRIDE entries), fixed order per lane
+    auto fold = [&](const u64* src, int count) -> double {
+        constexpr int PER = (32 + S::SEG - 1) / S::SEG;                // entries per lane and batch: 32 partials in flight
+        double f = 0.0;
+        if (e < S::NE) {
+            for (int j0 = seg; j0 < count; j0 += S::SEG * PER) {
+                u64 lo[PER], hi[PER];
+                unsigned spins = 0;
+                bool ok;
+                do {
+                    ok = true;
+#pragma unroll
+                    for (int u = 0; u < PER; ++u) {
+                        const int j = j0 + u * S::SEG;
+                        lo[u] = stamp_hi; hi[u] = stamp_hi;
+                        if (j < count) {
+                            const u64* p = src + ((size_t)j * RED_STRIDE + e) * 2;
+                            lo[u] = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            hi[u] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < PER; ++u) ok = ok && (lo[u] & HI_MASK) == stamp_hi && (hi[u] & HI_MASK) == stamp_hi;
+                } while (!ok && ++spins < SPIN_LIMIT);
+                if (!ok) s_failed = 1u;
+#pragma unroll
+                for (int u = 0; u < PER; ++u)
+                    if (j0 + u * S::SEG < count) f += __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xffffffffull)));
+            }
+        }
+        return f;
+    };
+
+    double f = fold(a.units + (size_t)grp_first * RED_STRIDE * 2, grp_size - 1);
     __syncthreads();                               // s_part is reused
     s_part[seg][e] = f;
     __syncthreads();
@@ -174,25 +209,20 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         double t = 0.0;
 #pragma unroll
         for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
-        __hip_atomic_store(&a.gpartials[(size_t)grp * RED_STRIDE + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t += s_own[tid];                                    // workgroups of the group in index order, the reducer's own last
+        if (final_reducer) {
+            s_own[tid] = t;
+        } else {
+            const u64 bits = (u64)__double_as_longlong(t);
+            u64* dst = a.gunits + ((size_t)grp * RED_STRIDE + tid) * 2;
+            __hip_atomic_store(dst + 0, (bits & 0xffffffffull) | stamp_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, (bits >> 32) | stamp_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t prev = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev == (uint32_t)(ngroups - 1) ? 1u : 0u;
-        if (s_last) a.ticket[0] = 0u;
-    }
-    __syncthreads();
-    if (s_last == 0u) return;
+    if (!final_reducer) return;
 
-    // ---- the very last workgroup: sum of the group partials, fixed order -------------------------------
-    f = 0.0;
-    if (e < S::NE) {
-#pragma unroll 8
-        for (int gidx = seg; gidx < ngroups; gidx += S::SEG)
-            f += __hip_atomic_load(&a.gpartials[(size_t)gidx * RED_STRIDE + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // ---- the last workgroup of the grid: the group sums in index order, its own group's last ---------------
+    f = fold(a.gunits, ngroups - 1);
     __syncthreads();
     s_part[seg][e] = f;
     __syncthreads();
@@ -201,9 +231,10 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         double t = 0.0;
 #pragma unroll
         for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
-        s_fin[tid] = t;
+        s_fin[tid] = t + s_own[tid];
     }
     __syncthreads();
+    const bool failed = s_failed != 0u;
     // One wavefront writes the whole record into host-mapped memory, fences at system scope and only
     // then publishes the sequence number the host is polling.
     if (tid < 64) {
@@ -222,10 +253,10 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         if (tid < 12) out->HTh[tid] = tid < S::NC ? s_fin[S::NP + tid] : 0.0;
         if (tid == 0) {
             out->res_sum = s_fin[S::NP + S::NC];
-            out->m = (int)(s_fin[S::NP + S::NC + 1] + 0.5);
+            out->m = failed ? -1 : (int)(s_fin[S::NP + S::NC + 1] + 0.5);
             out->n_unresolved = SEARCH ? (int)*a.n_unresolved : 0;
             out->n_candidates = SEARCH ? *a.cand_total : 0ull;
-            // consumed: zero the counters and the ticket for the next pass
+            // consumed: zero the counters for the next pass
             if (SEARCH) { *a.n_unresolved = 0u; *a.cand_total = 0ull; }
         }
         __threadfence_system();
