@@ -99,6 +99,33 @@ def test_measurement_pass_parity(gpu_capi, oracle, request, case_name, ext):
     ctx.close()
 
 
+@pytest.mark.parametrize("ext", [False, True])
+def test_reduction_across_workgroup_counts(gpu_capi, oracle, small_case, ext):
+    """The cross-workgroup reduction (groups of 16 workgroups folded by designated reducers, then the group sums)
+    for scan sizes that hit its edges: one point, one workgroup, a group of exactly one workgroup behind a full
+    group (4097 points = 17 workgroups), partial groups, and the same context reused across sizes (stale stamps of
+    larger passes must never be read)."""
+    w, sc, st = small_case["world"], small_case["scan"], small_case["state14"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+    ctx.map_build(w.points)
+    om = oracle.OracleMap(0.2); om.build(w.points)
+    for n in (len(sc.body), 1, 7, 255, 256, 257, 4096, 4097, 4352, 8193, 12_345, 3):
+        body = np.ascontiguousarray(sc.body[:n])
+        ctx.scan_set(body)
+        arr = oracle.ScanArrays(n)
+        for search in (True, False):
+            valid, hx, h, m, rm = oracle.h_share_model(om, st, body, arr, search, ext)
+            g = ctx.measure(st, search, ext)
+            assert g["m"] == m and g["valid"] == valid
+            if m == 0:
+                continue
+            HTH, HTh = oracle.hth(hx, h)
+            assert np.abs(g["HTH"] - HTH).max() <= 1e-9 * max(np.abs(HTH).max(), 1e-300)
+            assert np.abs(g["HTh"] - HTh).max() <= 1e-9 * max(np.abs(HTh).max(), 1e-300)
+            assert abs(g["res_mean"] - rm) <= 1e-12
+    ctx.close()
+
+
 @pytest.mark.parametrize("case_name,ext", [("small_case", False), ("hap_case", True)])
 def test_iterated_update_pose_parity(gpu_capi, oracle, synth, request, case_name, ext):
     """update_iterated_dyn_share_modified on the GPU path vs the CPU path: pose within
