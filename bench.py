@@ -224,11 +224,7 @@ def main():
             ctx.scan_set_device(d_b.data_ptr(), nq)
             lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, ext)
         else:
-            L.lio_eskf_change_x(kf.h, x0_p)
-            L.lio_eskf_change_P(kf.h, P0_p)
-            rc = L.lio_scan_set_device(ctx.h, d_body_p, nq)
-            if rc == 0:
-                rc = L.lio_eskf_update_iterated_dyn_share_modified(kf.h, ctx.h, 0.001, ext_i, ulog_ref)
+            rc = L.lio_eskf_scan_step_device(kf.h, ctx.h, x0_p, P0_p, d_body_p, nq, 0.001, ext_i, ulog_ref)
             if rc != 0:
                 raise capi.LioError(f"scan step failed: {capi.ERRORS.get(rc, rc)}: {L.lio_last_error(ctx.h).decode()}")
             lg = ulog

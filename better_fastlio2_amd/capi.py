@@ -61,7 +61,7 @@ EXPORTS = [
     "lio_scan_set", "lio_scan_set_device", "lio_scan_undistort", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
-    "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_state_boxplus",
+    "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_eskf_scan_step_device", "lio_state_boxplus",
     "lio_state_boxminus",
 ]
 
@@ -146,6 +146,7 @@ def load(build_if_missing: bool = True):
     L.lio_eskf_get_x.argtypes = [_vp, _vp]
     L.lio_eskf_get_P.argtypes = [_vp, _vp]
     L.lio_eskf_update_iterated_dyn_share_modified.argtypes = [_vp, _vp, C.c_double, C.c_int, C.POINTER(lio_update_log)]
+    L.lio_eskf_scan_step_device.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int, C.POINTER(lio_update_log)]
     L.lio_state_boxplus.argtypes = [_vp, _vp]
     L.lio_state_boxminus.argtypes = [_vp, _vp, _vp]
     _lib = L
@@ -442,6 +443,19 @@ class Esekf:
         if rc != LIO_OK:
             raise LioError(f"update_iterated_dyn_share_modified: {ERRORS.get(rc, rc)}: {ctx.L.lio_last_error(ctx.h).decode()}")
         return {k: getattr(log, k) for k, _ in lio_update_log._fields_}
+
+
+def scan_step_device(kf: "Esekf", ctx: "LioContext", x26, P, d_body_ptr: int, n: int, R: float = 0.001,
+                     extrinsic_est_en: bool = False) -> dict:
+    """lio_eskf_scan_step_device: prior in, device-resident scan in, iterated update -- one call."""
+    x = None if x26 is None else np.ascontiguousarray(x26, np.float64)
+    p = None if P is None else np.ascontiguousarray(P, np.float64)
+    log = lio_update_log()
+    rc = kf.L.lio_eskf_scan_step_device(kf.h, ctx.h, None if x is None else _ptr(x), None if p is None else _ptr(p),
+                                        _vp(d_body_ptr), n, R, int(extrinsic_est_en), C.byref(log))
+    if rc != LIO_OK:
+        raise LioError(f"lio_eskf_scan_step_device: {ERRORS.get(rc, rc)}: {ctx.L.lio_last_error(ctx.h).decode()}")
+    return {k: getattr(log, k) for k, _ in lio_update_log._fields_}
 
 
 def make_state26(pos, rot, off_R, off_T, vel=(0, 0, 0), bg=(0, 0, 0), ba=(0, 0, 0), grav=(0, 0, -9.809)) -> np.ndarray:

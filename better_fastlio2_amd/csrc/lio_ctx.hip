@@ -1443,6 +1443,16 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
     }
     return status;
 }
+int lio_eskf_scan_step_device(lio_eskf* kf, lio_ctx* ctx, const double x26[26], const double P[23 * 23],
+                              const void* d_body_f4, int n, double R, int extrinsic_est_en, lio_update_log* log) {
+    if (!kf || !ctx) return LIO_ERR_INVALID_ARG;
+    int rc = LIO_OK;
+    if (x26 != nullptr) rc = lio_eskf_change_x(kf, x26);
+    if (rc == LIO_OK && P != nullptr) rc = lio_eskf_change_P(kf, P);
+    if (rc == LIO_OK) rc = lio_scan_set_device(ctx, d_body_f4, n);
+    if (rc == LIO_OK) rc = lio_eskf_update_iterated_dyn_share_modified(kf, ctx, R, extrinsic_est_en, log);
+    return rc;
+}
 int lio_state_boxplus(double x26[26], const double dx23[23]) {
     if (!x26 || !dx23) return LIO_ERR_INVALID_ARG;
     lio::state_ikfom s = lio::state_ikfom::from_array(x26);

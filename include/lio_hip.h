@@ -233,6 +233,11 @@ int  lio_eskf_get_P(lio_eskf* kf, double P[23 * 23]);             /* esekfom.hpp
  * model bound to lio_measure on ctx (the scan must have been set with lio_scan_set).             */
 int  lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, double R,
                                                  int extrinsic_est_en, lio_update_log* log);
+/* One scan of the node's loop body (laserMapping.cpp:2320-2325 + :2380) in one call: the propagated state and
+ * covariance go in (kf.change_x / kf.change_P; NULL = keep the filter's), the down-sampled scan goes in from
+ * device memory (lio_scan_set_device), the iterated update runs.  Equivalent to the four calls it names.   */
+int  lio_eskf_scan_step_device(lio_eskf* kf, lio_ctx* ctx, const double x26[26], const double P[23 * 23],
+                               const void* d_body_f4, int n, double R, int extrinsic_est_en, lio_update_log* log);
 /* manifold helpers exposed for tests: x [+] dx and x [-] y on the 23-DOF compound manifold        */
 int  lio_state_boxplus(double x26[26], const double dx23[23]);
 int  lio_state_boxminus(const double x26[26], const double y26[26], double dx23[23]);

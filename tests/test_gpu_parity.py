@@ -99,6 +99,23 @@ def test_measurement_pass_parity(gpu_capi, oracle, request, case_name, ext):
     ctx.close()
 
 
+def test_scan_step_call_equals_the_four_calls(gpu_capi, synth, small_case):
+    """lio_eskf_scan_step_device == change_x + change_P + lio_scan_set_device + update_iterated_dyn_share_modified."""
+    w, sc = small_case["world"], small_case["scan"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+    ctx.map_build(w.points)
+    x0 = gpu_capi.make_state26(small_case["pos"], small_case["rot"], sc.off_R, sc.off_T)
+    buf = gpu_capi.scan_to_device(sc.body)
+    kf1 = gpu_capi.Esekf(3); kf1.change_x(x0); kf1.change_P(synth.init_cov())
+    ctx.scan_set_device(buf.ptr, len(sc.body))
+    l1 = kf1.update_iterated_dyn_share_modified(ctx, 0.001, False)
+    kf2 = gpu_capi.Esekf(3)
+    l2 = gpu_capi.scan_step_device(kf2, ctx, x0, synth.init_cov(), buf.ptr, len(sc.body), 0.001, False)
+    assert np.array_equal(kf1.get_x(), kf2.get_x()) and np.array_equal(kf1.get_P(), kf2.get_P())
+    assert (l1["n_calls"], l1["n_search"], l1["last_m"]) == (l2["n_calls"], l2["n_search"], l2["last_m"])
+    ctx.close()
+
+
 @pytest.mark.parametrize("ext", [False, True])
 def test_reduction_across_workgroup_counts(gpu_capi, oracle, small_case, ext):
     """The cross-workgroup reduction (groups of 16 workgroups folded by designated reducers, then the group sums)
