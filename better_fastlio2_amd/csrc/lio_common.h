@@ -1,6 +1,6 @@
 // lio_common.h -- data layout shared by the host side of liblio_hip.so and its gfx950 kernels.
 //
-// Map index ("hashed voxel grid over a Morton-sorted point array"; replaces the pointer-chased
+// Map index ("hashed voxel grid over a bucketed point array"; replaces the pointer-chased
 // KD_TREE_NODE of include/ikd-Tree/ikd_Tree.h:64-86):
 //   pts   float4[N_m]   x, y, z, w   (w != 0 marks a tomb-stoned point, cf. point_deleted ikd_Tree.h:70)
 //                       sorted by the Morton code of the point's neighbour-grid cell, so every

@@ -203,7 +203,8 @@ int upload_points(lio_ctx* c, const float* pts, size_t n, int stride_bytes, floa
 }
 
 // Second half of every (re)build: c->d_pts[0..n) is Morton-sorted and live, c->d_mkeys[0..n) holds the
-// keys.  Run-length encode the cells, fill the level-0 hash table, derive the coarser tree levels.
+// keys.  Run-length encode the cells, derive the coarser tree levels (hash tables), fill the child blocks of the
+// cell directory.
 int finish_index(lio_ctx* c, uint32_t n) {
     hipStream_t s = c->stream;
     c->n_points = n; c->n_live = n; c->n_cells = 0;

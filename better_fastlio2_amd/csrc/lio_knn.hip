@@ -7,17 +7,18 @@
 //
 // Two kernels:
 //   knn27_kernel<G>  G lanes (a DPP-addressable sub-group of a 64-lane wavefront) per query.
-//                    The lanes split the 27 hash probes of the 3x3x3 cell block, stage the
-//                    non-empty buckets {start,count} in LDS, stream the candidate points
+//                    The lanes look the 27 cells of the 3x3x3 block up in the cell directory (<= 8
+//                    hashed level-1 probes, then fixed-position 8-byte records), stage the non-empty
+//                    buckets {start,count} in LDS, walk them as one concatenated candidate list
 //                    (16-byte loads, consecutive lanes -> consecutive addresses inside a bucket),
-//                    keep a per-lane sorted top-5 of (sqdist bits << 32 | map index) keys and
-//                    merge the G lists with DPP min all-reduces.  A result is PROVEN when the 5th
+//                    keep a per-lane sorted top-5 of (sqdist bits << 32 | map index) keys (carried as
+//                    doubles: v_min_f64 / v_max_f64 ladder) and merge the G lists with DPP min all-reduces.  A result is PROVEN when the 5th
 //                    distance is below the squared distance from the query to the faces of the
 //                    searched block (exact in fp32 because the cell edge is a power of two);
 //                    everything else is flagged for
-//   knn_tree_kernel  one wavefront per unresolved query: best-first branch-and-bound over the hashed
-//                    64-ary tree (grid coarsened by 4^L; each node one contiguous range of the
-//                    Morton-sorted array), 64 children probed per round trip.
+//   knn_tree_kernel  one wavefront per unresolved query (lio_tree.h): the 5x5x5 block first, then a best-first
+//                    branch-and-bound over the hashed 64-ary tree (grid coarsened by 4^L), 64 children
+//                    probed per round trip, level-0 buckets as leaves.
 //
 // Ordering of equal squared distances: by map index (the reference's choice among exact ties
 // is traversal-order dependent, ikd_Tree.cpp:887).
@@ -110,7 +111,7 @@ template <int G, bool CENSUS, bool HINT>
 __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     constexpr int WPB = 4;
     constexpr int GPW = 64 / G;                    // queries per wavefront
-    constexpr int SLOTS = (27 + G - 1) / G;        // hash probes per lane
+    constexpr int SLOTS = (27 + G - 1) / G;        // cells per lane
     __shared__ uint2 s_bucket[WPB][GPW][28];       // LDS-staged non-empty buckets {start, count}
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

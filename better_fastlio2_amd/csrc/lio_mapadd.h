@@ -38,7 +38,7 @@ struct IncrArgs {
 // The batch is grouped by grid cell (stable sort: batch order inside a cell).  A touched cell's bucket is
 // re-written at the tail of the point array -- its live points in their old order, then the new ones --
 // the old slots become TOMB_MOVED, and only that cell's table entry changes.  New cells are inserted into
-// the level-0 table and, as existence marks, into the coarser levels of the tree.
+// the cell directory and, as existence marks, into the coarser levels of the tree.
 struct CellPlan { uint32_t old_start, old_count, index, found; };   // index = position of the cell's record in the directory
 struct ApplyArgs {
     float4*          map_pts;

@@ -8,7 +8,7 @@
 // so the batch is grouped by voxel (stable radix sort keeps the batch order inside a group) and
 // one lane folds each group sequentially -- the result equals the sequential one.
 //   voxel_keys_kernel     voxel key of each new point
-//   fold_groups_kernel    per voxel: existing points in the box (hash probes of the <= 8 grid
+//   fold_groups_kernel    per voxel: existing points in the box (directory look-ups of the <= 8 grid
 //                         cells the box touches), sequential fold, tomb-stone + emit the survivor
 // The caller then appends the survivors and rebuilds the index (sort + hash), see lio_ctx.hip.
 #include "lio_device.h"

@@ -43,9 +43,10 @@ __device__ __forceinline__ u64 candidate_key(float qx, float qy, float qz, float
 // ---------------------------------------------------------------------------------------------
 // Exact fallback: best-first branch-and-bound over the hashed 64-ary tree of the map.
 //
-// Level L of the tree = the neighbour grid coarsened by 4^L (cell edge = cell * 4^L); because the
-// point array is Morton-sorted, every level-L cell is one contiguous range, found through the
-// level's own hash table (packed coarse cell -> {start, count}, built next to the level-0 table).
+// Level L of the tree = the neighbour grid coarsened by 4^L (cell edge = cell * 4^L).  Levels 1 .. top-1 have a
+// hash table each (packed coarse cell -> existence; level 1 -> number of its child block); the level-0 cells of
+// a level-1 node are the 64 records of its child block, and their buckets -- contiguous runs of the point
+// array -- are the leaves.  The walk starts from the few cells of level `top_level` (TreeLevels).
 // One 64-lane wavefront per query: the 64 lanes probe the 4x4x4 children of a node in ONE
 // round trip, rank the non-empty children by box distance (ballot + readlane), push them on an
 // LDS stack nearest-on-top, and scan leaf ranges 64 points at a time; the running top-5 is
