@@ -2,11 +2,13 @@
 //
 // Map index ("hashed voxel grid over a bucketed point array"; replaces the pointer-chased
 // KD_TREE_NODE of include/ikd-Tree/ikd_Tree.h:64-86):
-//   pts   float4[N_m]   x, y, z, w   (w != 0 marks a tomb-stoned point, cf. point_deleted ikd_Tree.h:70)
-//                       sorted by the Morton code of the point's neighbour-grid cell, so every
-//                       octree node (2^L cells per edge) is one contiguous range of the array
-//   mkeys u64[N_m]      that Morton code, per point (binary-searched by the exact tree walk)
-//   table HashEntry[T]  open addressing, linear probing, packed cell key -> {start, count}
+//   pts    float4[slots] x, y, z, w   (w != 0 marks a dead slot, cf. point_deleted ikd_Tree.h:70; kinds below)
+//                        a (re)build sorts by the Morton code of the point's neighbour-grid cell: every occupied
+//                        cell is one contiguous BUCKET; Add_Points later re-writes touched buckets at the tail
+//   ltable HashEntry[..] one open-addressing table per COARSE level (grid / 4, / 16, ...): packed cell key ->
+//                        existence; level 1 -> the number of the cell's child block
+//   child  uint2[B][64]  {start, count} of the 64 grid cells of a level-1 cell at a fixed position: together with
+//                        level 1 of ltable this is the cell directory every look-up goes through (lio_device.h)
 // The cell edge `cell` is a power of two, so floor(p * inv_cell) and the cell -> world box
 // conversion are exact in fp32; this is what makes the "proven inside the searched block" test
 // of the k-NN kernel sound.
