@@ -77,7 +77,7 @@ struct lio_ctx {
     int cap_q = 0, nq = 0;
     float4 *d_body = nullptr, *d_world = nullptr, *d_nbr = nullptr, *d_normvec = nullptr, *d_plane = nullptr;
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
-    uint8_t* d_unres = nullptr;                // per query: 1 = needs the exact tree walk
+    float4* d_ulist = nullptr;                 // queries the 27-cell kernel could not prove (count: d_counters[0])
     double* d_rows = nullptr;
     unsigned long long *d_units = nullptr, *d_gunits = nullptr;   // stamped partial sums of the residual kernel's reduction
     DeviceOut* h_out = nullptr;                // pinned + mapped: the final reduction writes it directly
@@ -100,7 +100,7 @@ struct lio_ctx {
     int cap_qs = 0;
     float4 *d_qs_world = nullptr, *d_qs_nbr = nullptr;
     uint8_t* d_qs_cnt = nullptr;
-    uint8_t* d_qs_unres = nullptr;
+    float4* d_qs_ulist = nullptr;
 
     // raw-scan preparation (lio_scan_undistort / lio_scan_voxel_filter)
     size_t cap_raw = 0;
@@ -443,7 +443,7 @@ KernelTimer prof_timer(lio_ctx* c, int which) {
 // k-NN of nq world/body queries into (nbr, cnt); queries_world must hold the world points when
 // body == nullptr, and receives them otherwise.
 int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14& pose, int nq, int stride,
-            float4* nbr, uint8_t* cnt, uint8_t* unres, bool use_hint) {
+            float4* nbr, uint8_t* cnt, float4* ulist, bool use_hint) {
     hipStream_t s = c->stream;
     // d_counters[0] / d_cand are zero here: zeroed at creation and re-zeroed by whoever consumes them
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
@@ -453,13 +453,13 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     if (body != nullptr) HIPCHK(c, launch_transform(body, nq, pose, queries_world, s));
     ka.world_in = queries_world;
     ka.nq = nq; ka.nq_stride = stride;
-    ka.nbr = nbr; ka.cnt = cnt; ka.unres = unres; ka.cand_total = c->census ? c->d_cand : nullptr;
+    ka.nbr = nbr; ka.cnt = cnt; ka.ulist = ulist; ka.n_unres = c->d_counters; ka.cand_total = c->census ? c->d_cand : nullptr;
     ka.use_hint = use_hint ? 1 : 0;
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, LIO_PROF_KNN)));
     TreeArgs ta{};
     ta.map_pts = c->d_pts; ta.child = c->d_child; ta.ltable = c->d_ltable; ta.levels = c->levels; ta.grid = c->grid;
-    ta.queries = queries_world; ta.unres = unres; ta.n_unresolved = c->d_counters;
+    ta.ulist = ulist; ta.n_unres = c->d_counters;
     ta.nq = nq; ta.nq_stride = stride; ta.nbr = nbr; ta.cnt = cnt;
     HIPCHK(c, launch_knn_tree(ta, s, prof_timer(c, LIO_PROF_FALLBACK)));
     return LIO_OK;
@@ -553,7 +553,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_plane, nq * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_cnt, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_sel, nq));
-    CREATE_CHK(hipMalloc((void**)&c->d_unres, nq));
+    CREATE_CHK(hipMalloc((void**)&c->d_ulist, nq * sizeof(float4)));
     {
         const size_t blocks = (size_t)residual_blocks((int)nq), groups = (blocks + RED_GROUP - 1) / RED_GROUP;
         CREATE_CHK(hipMalloc((void**)&c->d_units, blocks * RED_STRIDE * 2 * sizeof(unsigned long long)));
@@ -576,8 +576,8 @@ void lio_destroy(lio_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
-                   c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_unres, c->d_rows,
-                   c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres,
+                   c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_rows,
+                   c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_minmax,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
@@ -1021,19 +1021,19 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
     if (n == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
     if (n > c->cap_qs) {
-        void* old[] = {c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres};
+        void* old[] = {c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist};
         for (void* p : old) if (p) (void)hipFree(p);
-        c->d_qs_world = nullptr; c->d_qs_nbr = nullptr; c->d_qs_cnt = nullptr; c->d_qs_unres = nullptr; c->cap_qs = 0;
+        c->d_qs_world = nullptr; c->d_qs_nbr = nullptr; c->d_qs_cnt = nullptr; c->d_qs_ulist = nullptr; c->cap_qs = 0;
         HIPCHK(c, hipMalloc((void**)&c->d_qs_world, (size_t)n * sizeof(float4)));
         HIPCHK(c, hipMalloc((void**)&c->d_qs_nbr, (size_t)n * K * sizeof(float4)));
         HIPCHK(c, hipMalloc((void**)&c->d_qs_cnt, (size_t)n));
-        HIPCHK(c, hipMalloc((void**)&c->d_qs_unres, (size_t)n));
+        HIPCHK(c, hipMalloc((void**)&c->d_qs_ulist, (size_t)n * sizeof(float4)));
         c->cap_qs = n;
     }
     int rc = upload_points(c, q_xyz, (size_t)n, stride_bytes, c->d_qs_world);
     if (rc != LIO_OK) return rc;
     Pose14 ident{};
-    rc = run_knn(c, nullptr, c->d_qs_world, ident, n, n, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_unres, false);
+    rc = run_knn(c, nullptr, c->d_qs_world, ident, n, n, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, false);
     if (rc != LIO_OK) return rc;
     const size_t b_xyz = (size_t)n * K * 3 * sizeof(float), b_d = (size_t)n * K * sizeof(float), b_c = (size_t)n * sizeof(int);
     rc = ensure_scratch(c, b_xyz + b_d + b_c);
@@ -1227,7 +1227,7 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
 
     if (do_search) {
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
-        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_unres, c->hint_valid);
+        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->hint_valid);
         if (rc != LIO_OK) return rc;
         c->have_search = true; c->hint_valid = true;
     }

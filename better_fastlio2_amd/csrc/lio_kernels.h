@@ -20,7 +20,8 @@ struct KnnArgs {
     int              nq_stride;     // leading dimension of nbr
     float4*          nbr;           // [5][nq_stride]: x, y, z, sqdist of the k-th neighbour
     uint8_t*         cnt;           // [nq] neighbours found (0..5)
-    uint8_t*         unres;         // [nq] 1 = result not proven by the 27-cell search (-> tree walk)
+    float4*          ulist;         // queries the 27-cell search could not prove: (x, y, z, query number as bits),
+    uint32_t*        n_unres;       // appended here (one atomic per unproven query: tens per 100 k) for the tree walk
     unsigned long long* cand_total; // device counter: sum of C(q)
     int              use_hint;      // nbr/cnt hold this scan's previous neighbours: bound the search with them
 };
@@ -39,9 +40,9 @@ struct TreeArgs {
     const HashEntry* ltable;        // levels >= 1
     TreeLevels       levels;
     Grid             grid;
-    const float4*    queries;       // world-frame queries
-    const uint8_t*   unres;         // [nq] 1 = not proven by the 27-cell kernel
-    uint32_t*        n_unresolved;  // device counter (+= queries handled here)
+    const float4*    ulist;         // the unproven queries: (x, y, z, query number as bits)
+    uint32_t*        n_unres;       // how many (written by knn27_kernel; consumed and zeroed by whoever reads the result;
+                                    // bit 31 = TREE_OVERFLOW report)
     int              nq;
     int              nq_stride;
     float4*          nbr;

@@ -327,7 +327,10 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             // a point outside has |delta| >= gmin on one axis -> its computed sqdist >= fl(gmin*gmin)
             proven = __uint_as_float(d5bits) < gmin * gmin;
         }
-        a.unres[q] = proven ? 0 : 1;               // unproven queries are redone by knn_tree_kernel
+        if (!proven) {                             // unproven queries are redone by knn_tree_kernel
+            const uint32_t slot = atomicAdd(a.n_unres, 1u);
+            a.ulist[slot] = make_float4(qx, qy, qz, __uint_as_float((uint32_t)q));
+        }
     }
     // candidate census for the byte model (opt-in: one atomic per wavefront)
     if (CENSUS) {
@@ -384,31 +387,24 @@ hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s, Ke
 __global__ __launch_bounds__(64) void knn_tree_kernel(TreeArgs a) {
     __shared__ TreeScratch ts;
     const int lane = threadIdx.x;
-    uint32_t handled = 0;
-
-    // wavefront w owns queries w, w + W, w + 2W, ... (runs of unresolved queries cluster in scan
-    // order; this spreads them over many wavefronts).  Lane i fetches the flag of the i-th of them,
-    // so one round trip covers 64 owned queries.
-    for (uint32_t q0 = blockIdx.x; q0 < (uint32_t)a.nq; q0 += 64u * gridDim.x) {
-      const uint32_t qi = q0 + (uint32_t)lane * gridDim.x;
-      u64 pending = __ballot(qi < (uint32_t)a.nq && a.unres[qi] != 0);
-      for (; pending != 0; pending &= pending - 1) {
-        const uint32_t q = q0 + (uint32_t)(__ffsll((long long)pending) - 1) * gridDim.x;
-        ++handled;
-        const float4 qw = a.queries[q];
-        tree_search_one(a, q, qw.x, qw.y, qw.z, lane, ts);
-      }
+    // wavefront w takes entries w, w + W, ... of the list (unproven queries cluster in scan order; the list order is
+    // arrival order, the stride spreads them over wavefronts).  The first entry is fetched together with the count.
+    float4 e = a.ulist[blockIdx.x];
+    const uint32_t n = __hip_atomic_load(a.n_unres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~TREE_OVERFLOW;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        if (i != blockIdx.x) e = a.ulist[i];
+        tree_search_one(a, __float_as_uint(e.w), e.x, e.y, e.z, lane, ts);
     }
-    if (lane == 0 && handled != 0) atomicAdd(a.n_unresolved, handled);
 }
-
 
 hipError_t launch_knn_tree(const TreeArgs& a, hipStream_t s, KernelTimer t) {
     if (a.nq <= 0) return hipSuccess;
-    // one wavefront per workgroup; every lane checks one flag per round, so nq / 64 wavefronts cover the
-    // scan in a single round trip (capped: large scans loop)
-    int blocks = (a.nq + 63) / 64;
+    // one wavefront per workgroup; the list is short (tens of entries per 100 k queries), a few hundred wavefronts
+    // cover it with one entry each, larger lists are strided
+    int blocks = a.nq / 256;
+    if (blocks < 256) blocks = 256;
     if (blocks > 2048) blocks = 2048;
+    if (blocks > a.nq) blocks = a.nq;                 // the list holds at most nq entries (and a.ulist[blockIdx.x] is read unconditionally)
     if (t.start != nullptr) hipExtLaunchKernelGGL(knn_tree_kernel, dim3(blocks), dim3(64), 0, s, t.start, t.stop, 0, a);
     else hipLaunchKernelGGL(knn_tree_kernel, dim3(blocks), dim3(64), 0, s, a);
     return hipGetLastError();

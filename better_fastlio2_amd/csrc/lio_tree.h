@@ -57,7 +57,7 @@ __device__ __forceinline__ u64 candidate_key(float qx, float qy, float qz, float
 // starts with at most TREE_MAX_ROOTS entries, a pop pushes at most 63 net entries and the tree is at most 11
 // levels deep (21-bit cell coordinates): 32 + 63 * 11 < 736.
 constexpr int TREE_STACK = 736;
-constexpr uint32_t TREE_OVERFLOW = 0x80000000u;  // or-ed into n_unresolved if the stack bound were ever violated
+constexpr uint32_t TREE_OVERFLOW = 0x80000000u;  // or-ed into the unproven-query counter if the stack bound were ever violated
 
 // squared distance from q to the box of cell (cx,cy,cz) at `level` (edge = cell * 4^level); same
 // fp32 expression form as sqdist3, so it never exceeds the computed distance of a point inside.
@@ -303,7 +303,7 @@ __device__ __forceinline__ void tree_search_one(const TreeArgs& a, uint32_t q, f
             rank += (bj > bd || (bj == bd && j < lane)) ? 1 : 0;
         }
         if (sp + nw > TREE_STACK) {                    // unreachable (see TREE_STACK); reported, never silent
-            if (lane == 0) atomicOr(a.n_unresolved, TREE_OVERFLOW);
+            if (lane == 0) atomicOr(a.n_unres, TREE_OVERFLOW);
             continue;
         }
         if (want) {
