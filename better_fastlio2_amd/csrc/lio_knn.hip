@@ -29,7 +29,7 @@ namespace lio {
 // maximum of a 32-bit value over each aligned group of G lanes, result in every lane of the group
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_move_u32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 __device__ __forceinline__ uint32_t max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 template <int G>
@@ -82,8 +82,9 @@ struct Top5 {
 template <int CTRL>
 __device__ __forceinline__ double dpp_move_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    // the controls used here are full permutations of their rows: every lane receives a value, `old` is never kept
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 template <int G>

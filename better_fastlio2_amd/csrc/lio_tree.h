@@ -14,8 +14,9 @@ typedef unsigned long long u64;
 template <int CTRL>
 __device__ __forceinline__ u64 dpp_move_u64(u64 v) {
     int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    // the controls used here are full permutations of their rows: every lane receives a value, `old` is never kept
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return ((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo;
 }
 __device__ __forceinline__ u64 min_u64(u64 a, u64 b) { return a < b ? a : b; }
