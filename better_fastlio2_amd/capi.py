@@ -57,7 +57,7 @@ class lio_update_log(C.Structure):
 EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_stream", "lio_synchronize",
     "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_fov_segment", "lio_map_reconstruct",
-    "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_acquire_removed_points", "lio_map_get_info", "lio_map_nearest_search",
+    "lio_map_set_downsample_param", "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_acquire_removed_points", "lio_map_get_info", "lio_map_nearest_search",
     "lio_scan_set", "lio_scan_set_device", "lio_scan_undistort", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
@@ -120,6 +120,7 @@ def load(build_if_missing: bool = True):
     L.lio_map_validnum.argtypes = [_vp]
     L.lio_map_validnum.restype = C.c_longlong
     L.lio_map_flatten.argtypes = [_vp, _vp, C.c_longlong, C.POINTER(C.c_longlong)]
+    L.lio_map_set_downsample_param.argtypes = [_vp, C.c_float]
     L.lio_map_acquire_removed_points.argtypes = [_vp, _vp, C.c_longlong, C.POINTER(C.c_longlong)]
     L.lio_map_get_info.argtypes = [_vp, C.POINTER(lio_map_info)]
     L.lio_map_nearest_search.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
@@ -268,6 +269,9 @@ class LioContext:
         self._chk(self.L.lio_fov_segment(self.h, _ptr(p), float(cube_len), float(det_range), _ptr(boxes), C.byref(nb), C.byref(nd)),
                   "lio_fov_segment")
         return boxes[:nb.value].copy(), nd.value
+
+    def set_downsample_param(self, downsample_size: float):
+        self._chk(self.L.lio_map_set_downsample_param(self.h, float(downsample_size)), "lio_map_set_downsample_param")
 
     def map_size(self) -> int:
         return self.L.lio_map_size(self.h)

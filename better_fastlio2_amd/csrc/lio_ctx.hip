@@ -483,7 +483,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     if (cfg->lanes_per_query != 0 && cfg->lanes_per_query != 4 && cfg->lanes_per_query != 8 && cfg->lanes_per_query != 16 &&
         cfg->lanes_per_query != 32 && cfg->lanes_per_query != 64)
         return LIO_ERR_INVALID_ARG;
-    if (cfg->cell_size != 0.0f && !is_pow2f(cfg->cell_size)) return LIO_ERR_INVALID_ARG;
+    if (cfg->cell_size != 0.0f && (!is_pow2f(cfg->cell_size) || cfg->cell_size < cfg->filter_size_map_min)) return LIO_ERR_INVALID_ARG;
 
     lio_ctx* c = new lio_ctx();
     c->cfg = *cfg;
@@ -876,6 +876,18 @@ int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const v
     return rebuild_from_stored(c);
 }
 
+int lio_map_set_downsample_param(lio_ctx* c, float downsample_size) {
+    if (!c || !(downsample_size > 0.0f)) return LIO_ERR_INVALID_ARG;
+    if (c->n_points == 0 && c->cfg.cell_size == 0.0f) {       // nothing indexed yet: the grid may still follow
+        c->grid.cell = auto_cell_size(downsample_size);
+        c->grid.inv_cell = 1.0f / c->grid.cell;
+    } else if (downsample_size > c->grid.cell) {
+        // the Add_Points fold looks at the 2x2x2 grid cells a down-sample box can touch: the box must not exceed a cell
+        return c->fail(LIO_ERR_INVALID_ARG, "lio_map_set_downsample_param", "down-sample box larger than the neighbour-grid cell of the built map");
+    }
+    c->cfg.filter_size_map_min = downsample_size;
+    return LIO_OK;
+}
 long long lio_map_size(lio_ctx* c) { return c ? (long long)c->n_points - (long long)c->n_retired : 0; }
 long long lio_map_validnum(lio_ctx* c) { return c ? (long long)c->n_live : 0; }
 

@@ -132,6 +132,10 @@ int  lio_fov_segment(lio_ctx* ctx, const double pos_lid[3], double cube_len, flo
                      int* n_boxes, int* n_deleted);
 /* KD_TREE::reconstruct (ikd_Tree.cpp:1394-1405) == Build on a new cloud.                           */
 int  lio_map_reconstruct(lio_ctx* ctx, const float* pts, long long n, int stride_bytes);
+/* KD_TREE::set_downsample_param (ikd_Tree.cpp:186-189, caller laserMapping.cpp:2332): the box edge of
+ * Add_Points' down-sampling.  lio_config.filter_size_map_min is the same parameter at creation; as long as no
+ * map has been built the neighbour-grid cell follows it (largest power of two <= 2.5 * value).          */
+int  lio_map_set_downsample_param(lio_ctx* ctx, float downsample_size);
 long long lio_map_size(lio_ctx* ctx);               /* KD_TREE::size()     (ikd_Tree.cpp:79)           */
 long long lio_map_validnum(lio_ctx* ctx);           /* KD_TREE::validnum() (ikd_Tree.cpp:129)          */
 /* KD_TREE::flatten (ikd_Tree.cpp:1326-1352): live points, xyz packed; *n = live count (may exceed

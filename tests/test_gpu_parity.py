@@ -191,6 +191,32 @@ def test_dense_gain_branch_small_scan(gpu_capi, oracle, synth, small_case):
     ctx.close()
 
 
+def test_set_downsample_param(gpu_capi, oracle, small_case):
+    """KD_TREE::set_downsample_param (laserMapping.cpp:2332): a context created for 0.5 m and then set to 0.2 m before
+    Build behaves like one created for 0.2 m (grid cell included); changed after Build only the Add_Points box changes."""
+    if not oracle.ref_available():
+        pytest.skip("reference ikd-Tree not built")
+    w = small_case["world"]
+    rng = np.random.default_rng(3)
+    base = np.ascontiguousarray(w.points[::2])
+    ctx = gpu_capi.LioContext(0.5, max_scan_points=1024, max_map_points=400_000)
+    ctx.set_downsample_param(0.2)
+    ctx.map_build(base)
+    assert ctx.map_info()["cell_size"] == 0.5 and abs(ctx.map_info()["downsample_size"] - 0.2) < 1e-7
+    ref = oracle.RefIkdTree(0.2); ref.build(base)
+    batch = (w.points[1::2][:6000] + rng.uniform(-0.02, 0.02, (6000, 3))).astype(np.float32)
+    assert ctx.map_add(batch, True) == ref.add(batch, True)
+    assert ctx.map_validnum() == ref.validnum()
+    ctx.set_downsample_param(0.4)                       # coarser down-sampling from now on, same grid
+    ref2 = oracle.RefIkdTree(0.4); ref2.build(ctx.map_flatten())
+    batch2 = (w.points[1::2][6000:12000] + rng.uniform(-0.02, 0.02, (6000, 3))).astype(np.float32)
+    assert ctx.map_add(batch2, True) == ref2.add(batch2, True)
+    assert ctx.map_validnum() == ref2.validnum() and ctx.map_info()["cell_size"] == 0.5
+    with pytest.raises(gpu_capi.LioError, match="LIO_ERR_INVALID_ARG"):
+        ctx.set_downsample_param(0.8)                   # a box larger than the cell of the built grid is refused
+    ctx.close()
+
+
 def test_map_mutation_parity(gpu_capi, oracle, small_case):
     """Add_Points (down-sampled: one point per voxel, nearest the centre; plain), Delete_Point_Boxes,
     validnum/size/flatten: same return values and live set as the oracle, k-NN parity afterwards."""
