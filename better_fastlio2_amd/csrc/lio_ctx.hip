@@ -116,6 +116,8 @@ struct lio_ctx {
     size_t cap_add = 0;
     float4 *d_add_pts = nullptr, *d_add_pts2 = nullptr, *d_add_out = nullptr;
     uint8_t* d_add_cls = nullptr;
+    uint8_t* d_add_dirty = nullptr;            // boundary points of a down-sampled batch (lio_mapadd.hip)
+    uint32_t *d_add_dlist = nullptr, *d_add_dlist2 = nullptr;
     uint64_t *d_add_keys = nullptr, *d_add_keys2 = nullptr, *d_add_ukeys = nullptr;
     uint32_t *d_add_order = nullptr, *d_add_order2 = nullptr, *d_add_gcount = nullptr, *d_add_gstart = nullptr;
 
@@ -631,18 +633,21 @@ static int ensure_add_buffers(lio_ctx* c, size_t n) {
         if (rc != LIO_OK) return rc;
     }
     void* old[] = {c->d_add_pts, c->d_add_pts2, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys, c->d_add_order,
-                   c->d_add_order2, c->d_add_gcount, c->d_add_gstart, c->d_add_cls,
+                   c->d_add_order2, c->d_add_gcount, c->d_add_gstart, c->d_add_cls, c->d_add_dirty, c->d_add_dlist, c->d_add_dlist2,
                    c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart,
                    c->d_pnewsize, c->d_pnewoff, c->d_plan};
     for (void* p : old) if (p) (void)hipFree(p);
     c->d_add_pts = c->d_add_pts2 = c->d_add_out = nullptr; c->d_add_keys = c->d_add_keys2 = c->d_add_ukeys = nullptr;
-    c->d_add_order = c->d_add_order2 = c->d_add_gcount = c->d_add_gstart = nullptr; c->d_add_cls = nullptr; c->cap_add = 0;
+    c->d_add_order = c->d_add_order2 = c->d_add_gcount = c->d_add_gstart = nullptr; c->d_add_cls = nullptr; c->d_add_dirty = nullptr; c->d_add_dlist = c->d_add_dlist2 = nullptr; c->cap_add = 0;
     c->d_pend = nullptr; c->d_pkeys = c->d_pkeys2 = c->d_pcell = nullptr;
     c->d_porder = c->d_porder2 = c->d_pgcount = c->d_pgstart = c->d_pnewsize = c->d_pnewoff = nullptr; c->d_plan = nullptr;
     c->cap_pend = 0;
     HIPCHK(c, hipMalloc((void**)&c->d_add_pts, n * sizeof(float4)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_pts2, n * sizeof(float4)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_out, n * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_out, 2 * n * sizeof(float4)));      // [group survivors | sequential pass]
+    HIPCHK(c, hipMalloc((void**)&c->d_add_dirty, n));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_dlist, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_dlist2, n * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_keys, n * sizeof(uint64_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_keys2, n * sizeof(uint64_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_ukeys, n * sizeof(uint64_t)));
@@ -685,7 +690,8 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
     uint32_t n_append = n;
     if (downsample_on) {
         const float ds = c->cfg.filter_size_map_min;
-        HIPCHK(c, launch_voxel_keys(batch, n, ds, c->d_add_keys, c->d_add_order, c->d_apply + 4, s));
+        HIPCHK(c, launch_voxel_keys(batch, n, ds, c->d_add_keys, c->d_add_order, c->d_apply + 4, c->d_add_dirty, c->d_add_dlist,
+                                    c->d_add_out, s));
         HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_add_keys, c->d_add_keys2, c->d_add_order,
                                      c->d_add_order2, (size_t)n, s));
         HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_add_keys2, (size_t)n, c->d_add_ukeys,
@@ -693,15 +699,28 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
         // the number of voxel groups stays on the device: launches are sized for the batch, the kernels read the
         // real count (entries of the scan past it are never used)
         HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, (size_t)n, s));
+        // boundary points (outside their own fp32 box / inside a neighbour's): their groups leave the parallel fold
+        // and are replayed point by point
+        BoundaryArgs ba{};
+        ba.map_pts = c->d_pts; ba.l1table = c->d_ltable + c->levels.off[1]; ba.l1mask = c->levels.mask[1]; ba.child = c->d_child;
+        ba.grid = c->grid; ba.ds = ds; ba.new_pts = batch; ba.order = c->d_add_order2; ba.ukeys = c->d_add_ukeys;
+        ba.group_start = c->d_add_gstart; ba.group_count = c->d_add_gcount; ba.n_groups = c->d_apply + 7; ba.n = n;
+        ba.dirty = c->d_add_dirty; ba.dlist = c->d_add_dlist; ba.n_dirty = c->d_apply + 10; ba.seq_out = c->d_add_out + n;
+        ba.n_added = c->d_apply + 5; ba.n_replaced = c->d_apply + 4;
+        HIPCHK(c, launch_classify_boundary(ba, s));
+        HIPCHK(c, launch_detect_shared_points(ba, s));
+        HIPCHK(c, launch_gather_dirty(ba, s));
+        HIPCHK(c, sort_keys_u32(c->d_temp, c->temp_bytes, c->d_add_dlist, c->d_add_dlist2, (size_t)n, s));   // batch order
+        HIPCHK(c, launch_fold_sequential(ba, c->d_add_dlist2, s));
         FoldArgs fa{};
         fa.map_pts = c->d_pts; fa.l1table = c->d_ltable + c->levels.off[1]; fa.l1mask = c->levels.mask[1]; fa.child = c->d_child;
         fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch;
         fa.order = c->d_add_order2; fa.group_start = c->d_add_gstart; fa.group_count = c->d_add_gcount;
         fa.n_groups = 0; fa.n_groups_dev = c->d_apply + 7; fa.n_groups_max = n;
-        fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4;
+        fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
         HIPCHK(c, launch_fold_groups(fa, s));
-        // survivors (w == 0) -> front of `batch` (the batch itself is no longer needed)
-        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_apply + 6, (size_t)n, s));
+        // survivors (w == 0) of both passes -> front of `batch` (the batch itself is no longer needed)
+        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_apply + 6, 2 * (size_t)n, s));
         uint32_t host_cnt[3] = {0, 0, 0};                  // replaced, tmp_counter, survivors
         HIPCHK(c, hipMemcpyAsync(host_cnt, c->d_apply + 4, sizeof(host_cnt), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
@@ -982,6 +1001,7 @@ int lio_map_flatten(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
     uint32_t live = 0;
     HIPCHK(c, hipMemcpyAsync(&live, c->d_counters + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n) *n = (long long)live;
     const size_t m = (size_t)live < (size_t)cap ? (size_t)live : (size_t)cap;
     if (m == 0) return LIO_OK;
     int rc = ensure_scratch(c, m * 3 * sizeof(float));

@@ -100,6 +100,7 @@ hipError_t launch_unpack_neighbors(const float4* nbr, const uint8_t* cnt, int nq
 size_t sort_pairs_temp_bytes(size_t n);
 hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
                               const uint32_t* vals_in, uint32_t* vals_out, size_t n, hipStream_t s);
+hipError_t sort_keys_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, size_t n, hipStream_t s);
 size_t rle_temp_bytes(size_t n);
 hipError_t run_length_encode_u64(void* temp, size_t temp_bytes, const uint64_t* keys, size_t n,
                                  uint64_t* unique_out, uint32_t* counts_out, uint32_t* n_runs_out,

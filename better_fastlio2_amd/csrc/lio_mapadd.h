@@ -22,6 +22,7 @@ struct FoldArgs {
     float4*          out_pts;       // per group: survivor to append (w == 0) or nothing (w == 1)
     uint32_t*        n_added;       // += tmp_counter of ikd_Tree.cpp:448
     uint32_t*        n_replaced;    // += points of the map tomb-stoned by the fold (validnum bookkeeping)
+    const uint8_t*   dirty;         // per group: 1 = left to the sequential pass (lio_mapadd.hip, "boundary points")
 };
 struct IncrArgs {
     const float4*  body;            // feats_down_body
@@ -69,8 +70,39 @@ constexpr uint32_t APPLY_FLAG_NO_ROOM = 4u;       // the tail cannot hold the re
 hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, hipStream_t s);
 hipError_t launch_cell_plan(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);
 hipError_t launch_cell_apply(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);
+// Boundary points of a down-sampled batch.  The reference's down-sample box is computed in fp32
+// (floor(p / ds) * ds, + ds): next to a voxel boundary a point can lie outside its own box, or inside the box of
+// the neighbouring voxel.  Such points make the inserts of neighbouring voxels depend on each other, so their
+// voxel groups (and the neighbours they reach) are taken out of the parallel fold and replayed one point after the
+// other, in batch order, with the reference's rule -- exact, and rare (a fraction ~ulp(p)/ds of the points).
+struct BoundaryArgs {
+    float4*          map_pts;
+    const HashEntry* l1table;
+    uint32_t         l1mask;
+    const uint2*     child;
+    Grid             grid;
+    float            ds;
+    const float4*    new_pts;       // the batch, caller's order
+    const uint32_t*  order;         // batch indices sorted by voxel key
+    const uint64_t*  ukeys;         // sorted voxel keys of the groups
+    const uint32_t*  group_start;
+    const uint32_t*  group_count;
+    const uint32_t*  n_groups;      // device-resident
+    uint32_t         n;             // batch size
+    uint8_t*         dirty;         // [n] per group
+    uint32_t*        dlist;         // [n] batch indices of the points of dirty groups (0xffffffff = unused)
+    uint32_t*        n_dirty;
+    float4*          seq_out;       // [n] points appended by the sequential pass (w == 0 live)
+    uint32_t*        n_added;
+    uint32_t*        n_replaced;
+};
+hipError_t launch_classify_boundary(const BoundaryArgs& a, hipStream_t s);
+hipError_t launch_detect_shared_points(const BoundaryArgs& a, hipStream_t s);
+hipError_t launch_gather_dirty(const BoundaryArgs& a, hipStream_t s);
+hipError_t launch_fold_sequential(const BoundaryArgs& a, const uint32_t* dlist_sorted, hipStream_t s);
 hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s);
-hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, uint32_t* zero2, hipStream_t s);
+hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, uint32_t* zero2,
+                             uint8_t* dirty, uint32_t* dlist, float4* out2n, hipStream_t s);
 hipError_t launch_fold_groups(const FoldArgs& a, hipStream_t s);
 
 }  // namespace lio

@@ -21,10 +21,17 @@ namespace lio {
 __device__ __forceinline__ float voxel_floor(float v, float ds) { return floorf(v / ds); }   // :424
 
 __global__ __launch_bounds__(256) void voxel_keys_kernel(const float4* pts, uint32_t n, float ds, uint64_t* vkeys,
-                                                         uint32_t* order, uint32_t* zero2) {
-    // first kernel of an Add_Points(downsample) batch: it also clears the two counters the fold accumulates into
+                                                         uint32_t* order, uint32_t* zero2, uint8_t* dirty, uint32_t* dlist,
+                                                         float4* out2n) {
+    // first kernel of an Add_Points(downsample) batch: it also clears what the later kernels accumulate into
+    // (zero2[0..1] fold counters, zero2[6] number of boundary points) and marks every output slot "nothing"
     if (zero2 != nullptr && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u;
+    if (zero2 != nullptr && blockIdx.x == 0 && threadIdx.x == 2) zero2[6] = 0u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        dirty[i] = 0;
+        dlist[i] = 0xffffffffu;
+        out2n[i] = make_float4(0.f, 0.f, 0.f, 1.0f);
+        out2n[n + i] = make_float4(0.f, 0.f, 0.f, 1.0f);
         const float4 p = pts[i];
         float kx = voxel_floor(p.x, ds), ky = voxel_floor(p.y, ds), kz = voxel_floor(p.z, ds);
         kx = fminf(fmaxf(kx, -1048576.0f), 1048575.0f);
@@ -53,6 +60,7 @@ __global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
             if (g < a.n_groups_max && t == 0) a.out_pts[g] = make_float4(0.f, 0.f, 0.f, 1.0f);   // nothing to append
             continue;                                           // whole sub-group leaves together
         }
+        if (a.dirty[g] != 0) continue;                         // boundary points around: replayed by fold_sequential_kernel
         const uint32_t gs = a.group_start[g], gc = a.group_count[g];
         const float ds = a.ds;
         const float4 p0 = a.new_pts[a.order[gs]];
@@ -126,9 +134,9 @@ __global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
                 float4 sp = a.map_pts[i];
                 if (sp.w != 0.0f) continue;
                 if (bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z) {
-                    sp.w = TOMB_DOWNSAMPLE;
-                    a.map_pts[i] = sp;
-                    ++replaced;
+                    // exchange, not store: the bookkeeping stays exact even if two boxes ever claimed the same point
+                    const uint32_t was = atomicExch(reinterpret_cast<uint32_t*>(&a.map_pts[i].w), __float_as_uint(TOMB_DOWNSAMPLE));
+                    if (was == 0u) ++replaced;
                 }
             }
         }
@@ -137,6 +145,224 @@ __global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
             a.out_pts[g] = touched ? make_float4(cur.x, cur.y, cur.z, 0.0f) : make_float4(0.f, 0.f, 0.f, 1.0f);
             if (counter != 0) atomicAdd(a.n_added, counter);
         }
+    }
+}
+
+// ---- boundary points -----------------------------------------------------------------------------------
+// index of `key` in the sorted group keys, or 0xffffffff
+__device__ __forceinline__ uint32_t find_group(const uint64_t* ukeys, uint32_t n_groups, uint64_t key) {
+    uint32_t lo = 0, hi = n_groups;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ukeys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n_groups && ukeys[lo] == key) ? lo : 0xffffffffu;
+}
+
+// one lane per batch point: is it outside its own fp32 box, or inside a neighbour's?  Then its group and the groups
+// of the voxels it reaches are dirty.
+__global__ __launch_bounds__(256) void classify_boundary_kernel(BoundaryArgs a) {
+    const uint32_t n_groups = *a.n_groups;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+        const float4 p = a.new_pts[i];
+        const float pc[3] = {p.x, p.y, p.z};
+        int dir[3];
+        float kf[3];
+        bool irregular = false;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const float ds = a.ds;
+            kf[ax] = voxel_floor(pc[ax], ds);
+            const float bmin = kf[ax] * ds, bmax = bmin + ds;
+            const float up_min = (kf[ax] + 1.0f) * ds;              // lower bound of the upper neighbour's box
+            const float dn_max = (kf[ax] - 1.0f) * ds + ds;         // upper bound of the lower neighbour's box
+            const bool up = !(pc[ax] < bmax) || pc[ax] >= up_min;
+            const bool dn = !(bmin <= pc[ax]) || pc[ax] < dn_max;
+            dir[ax] = up ? 1 : (dn ? -1 : 0);
+            irregular = irregular || up || dn;
+        }
+        if (!irregular) continue;
+        for (int m = 0; m < 8; ++m) {                              // own voxel (m = 0) and every combination of the reached sides
+            bool use = true;
+            float k[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const bool bit = (m >> ax) & 1;
+                if (bit && dir[ax] == 0) use = false;
+                k[ax] = fminf(fmaxf(kf[ax] + (bit ? (float)dir[ax] : 0.0f), -1048576.0f), 1048575.0f);
+            }
+            if (!use) continue;
+            const uint64_t key = pack_key((uint32_t)((int)k[0] + CELL_OFF), (uint32_t)((int)k[1] + CELL_OFF), (uint32_t)((int)k[2] + CELL_OFF));
+            const uint32_t g = find_group(a.ukeys, n_groups, key);
+            if (g != 0xffffffffu) a.dirty[g] = 1;
+        }
+    }
+}
+
+// Pre-pass of the fold, same lane layout: a LIVE MAP POINT inside the box of a group that also lies inside the box
+// of a neighbouring voxel (fp32 boxes of neighbours can overlap by an ulp) couples the two groups -- if the
+// neighbour has points in this batch, both go to the sequential pass.
+__global__ __launch_bounds__(64) void detect_shared_points_kernel(BoundaryArgs a) {
+    const uint32_t n_groups = *a.n_groups;
+    const int t = threadIdx.x & 7;
+    for (uint32_t g0 = blockIdx.x * 8u; g0 < a.n; g0 += gridDim.x * 8u) {
+        const uint32_t g = g0 + (threadIdx.x >> 3);
+        if (g >= n_groups) continue;
+        const float ds = a.ds;
+        const float4 p0 = a.new_pts[a.order[a.group_start[g]]];
+        const float pc[3] = {p0.x, p0.y, p0.z};
+        float kf[3], bmin[3], bmax[3], up_min[3], dn_max[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            kf[ax] = voxel_floor(pc[ax], ds);
+            bmin[ax] = kf[ax] * ds; bmax[ax] = bmin[ax] + ds;
+            up_min[ax] = (kf[ax] + 1.0f) * ds; dn_max[ax] = (kf[ax] - 1.0f) * ds + ds;
+        }
+        int c0[3], c1[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { c0[ax] = cell_coord(bmin[ax], a.grid.inv_cell); c1[ax] = cell_coord(bmax[ax], a.grid.inv_cell); }
+        const int cx = c0[0] + ((t >> 2) & 1), cy = c0[1] + ((t >> 1) & 1), cz = c0[2] + (t & 1);
+        uint32_t st = 0, ct = 0;
+        if (cx <= c1[0] && cy <= c1[1] && cz <= c1[2]) cell_find(a.l1table, a.l1mask, a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, st, ct);
+        for (uint32_t i = st; i < st + ct; ++i) {
+            const float4 sp = a.map_pts[i];
+            if (sp.w != 0.0f) continue;
+            const float xc[3] = {sp.x, sp.y, sp.z};
+            if (!(bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z)) continue;
+            int dir[3];
+            bool shared = false;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                dir[ax] = xc[ax] >= up_min[ax] ? 1 : (xc[ax] < dn_max[ax] ? -1 : 0);
+                shared = shared || dir[ax] != 0;
+            }
+            if (!shared) continue;
+            for (int m = 1; m < 8; ++m) {
+                bool use = true;
+                float k[3];
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    const bool bit = (m >> ax) & 1;
+                    if (bit && dir[ax] == 0) use = false;
+                    k[ax] = fminf(fmaxf(kf[ax] + (bit ? (float)dir[ax] : 0.0f), -1048576.0f), 1048575.0f);
+                }
+                if (!use) continue;
+                const uint64_t key = pack_key((uint32_t)((int)k[0] + CELL_OFF), (uint32_t)((int)k[1] + CELL_OFF), (uint32_t)((int)k[2] + CELL_OFF));
+                const uint32_t h = find_group(a.ukeys, n_groups, key);
+                if (h != 0xffffffffu) { a.dirty[h] = 1; a.dirty[g] = 1; }
+            }
+        }
+    }
+}
+
+// one lane per group: the batch indices of the points of dirty groups
+__global__ __launch_bounds__(256) void gather_dirty_kernel(BoundaryArgs a) {
+    const uint32_t n_groups = *a.n_groups;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
+        if (a.dirty[g] == 0) continue;
+        const uint32_t gs = a.group_start[g], gc = a.group_count[g];
+        const uint32_t slot = atomicAdd(a.n_dirty, gc);
+        for (uint32_t j = 0; j < gc; ++j) a.dlist[slot + j] = a.order[gs + j];
+    }
+}
+
+// Add_Points(downsample) for the points of dirty groups, replayed in batch order by ONE wavefront with the
+// reference's rule (ikd_Tree.cpp:422-449): Storage = live points inside the fp32 box (map points through the cell
+// directory, lanes 0..7 one cell each; points added earlier in this pass from a list), nearest to the box centre
+// wins (the new point on ties), delete-and-re-add when Storage held more than one point or the new point wins.
+// Everything that later iterations read back goes through agent-scope atomics (no stale L1 lines).
+__global__ __launch_bounds__(64) void fold_sequential_kernel(BoundaryArgs a, const uint32_t* dlist_sorted) {
+    const int lane = threadIdx.x;
+    const uint32_t n_dirty = *a.n_dirty;
+    uint32_t n_seq = 0, counter = 0, replaced = 0;
+    float* seq = reinterpret_cast<float*>(a.seq_out);
+    float* mp = reinterpret_cast<float*>(a.map_pts);
+    auto ld = [](const float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto st = [](float* q, float v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (uint32_t it = 0; it < n_dirty; ++it) {
+        const float4 p = a.new_pts[dlist_sorted[it]];
+        const float ds = a.ds;
+        float bmin[3], bmax[3], mid[3];
+        const float pc[3] = {p.x, p.y, p.z};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            bmin[ax] = voxel_floor(pc[ax], ds) * ds;
+            bmax[ax] = bmin[ax] + ds;
+            mid[ax] = (float)((double)bmin[ax] + (double)(bmax[ax] - bmin[ax]) / 2.0);
+        }
+        auto inbox = [&](float x, float y, float z) {
+            return bmin[0] <= x && bmax[0] > x && bmin[1] <= y && bmax[1] > y && bmin[2] <= z && bmax[2] > z;
+        };
+        // ---- Storage, part 1: map points (lanes 0..7)
+        int c0[3], c1[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { c0[ax] = cell_coord(bmin[ax], a.grid.inv_cell); c1[ax] = cell_coord(bmax[ax], a.grid.inv_cell); }
+        const int cx = c0[0] + ((lane >> 2) & 1), cy = c0[1] + ((lane >> 1) & 1), cz = c0[2] + (lane & 1);
+        const bool mine = lane < 8 && cx <= c1[0] && cy <= c1[1] && cz <= c1[2];
+        uint32_t bst = 0, bct = 0;
+        if (mine) cell_find(a.l1table, a.l1mask, a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, bst, bct);
+        uint32_t cnt = 0;
+        float dbest = __uint_as_float(INF_BITS), bx = 0.f, by = 0.f, bz = 0.f;
+        for (uint32_t i = bst; i < bst + bct; ++i) {
+            const float* q = mp + 4 * (size_t)i;
+            if (ld(q + 3) != 0.0f) continue;
+            const float x = ld(q), y = ld(q + 1), z = ld(q + 2);
+            if (!inbox(x, y, z)) continue;
+            ++cnt;
+            const float d = sqdist3(x, y, z, mid[0], mid[1], mid[2]);
+            if (d < dbest) { dbest = d; bx = x; by = y; bz = z; }
+        }
+        // ---- Storage, part 2: points added earlier in this pass (all lanes, list order); they rank after the map's
+        uint32_t ord = (uint32_t)lane;                             // tie order: map cells first (lane < 8), then list index + 8
+        for (uint32_t j = (uint32_t)lane; j < n_seq; j += 64) {
+            const float* q = seq + 4 * (size_t)j;
+            if (ld(q + 3) != 0.0f) continue;
+            const float x = ld(q), y = ld(q + 1), z = ld(q + 2);
+            if (!inbox(x, y, z)) continue;
+            ++cnt;
+            const float d = sqdist3(x, y, z, mid[0], mid[1], mid[2]);
+            if (d < dbest) { dbest = d; bx = x; by = y; bz = z; ord = 8u + j; }
+        }
+        // combine: count, and the first minimum in (distance, order)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            cnt += __shfl_xor(cnt, o, 64);
+            const float od = __shfl_xor(dbest, o, 64);
+            const uint32_t oo = __shfl_xor(ord, o, 64);
+            const float ox = __shfl_xor(bx, o, 64), oy = __shfl_xor(by, o, 64), oz = __shfl_xor(bz, o, 64);
+            if (od < dbest || (od == dbest && oo < ord)) { dbest = od; ord = oo; bx = ox; by = oy; bz = oz; }
+        }
+        const float d_p = sqdist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
+        const bool best_is_p = !(cnt > 0 && dbest < d_p);
+        const float4 best = best_is_p ? p : make_float4(bx, by, bz, 0.0f);
+        if (cnt > 1 || same_point(p, best)) {
+            ++counter;
+            if (cnt > 0) {                                          // Delete_by_range of the box
+                for (uint32_t i = bst; i < bst + bct; ++i) {
+                    float* q = mp + 4 * (size_t)i;
+                    if (ld(q + 3) != 0.0f) continue;
+                    if (inbox(ld(q), ld(q + 1), ld(q + 2))) { st(q + 3, TOMB_DOWNSAMPLE); ++replaced; }
+                }
+                for (uint32_t j = (uint32_t)lane; j < n_seq; j += 64) {
+                    float* q = seq + 4 * (size_t)j;
+                    if (ld(q + 3) != 0.0f) continue;
+                    if (inbox(ld(q), ld(q + 1), ld(q + 2))) st(q + 3, 1.0f);
+                }
+            }
+            if (lane == 0) {                                        // Add_by_point of the winner
+                float* q = seq + 4 * (size_t)n_seq;
+                st(q, best.x); st(q + 1, best.y); st(q + 2, best.z); st(q + 3, 0.0f);
+            }
+            ++n_seq;
+        }
+        __builtin_amdgcn_s_waitcnt(0);                             // the appends / tomb-stones are out before the next point reads
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) replaced += __shfl_xor(replaced, o, 64);
+    if (lane == 0) {
+        if (counter != 0) atomicAdd(a.n_added, counter);
+        if (replaced != 0) atomicAdd(a.n_replaced, replaced);
     }
 }
 
@@ -296,6 +522,29 @@ hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+hipError_t launch_classify_boundary(const BoundaryArgs& a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    uint32_t b = (a.n + 255u) / 256u; if (b > 4096u) b = 4096u;
+    hipLaunchKernelGGL(classify_boundary_kernel, dim3(b), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_detect_shared_points(const BoundaryArgs& a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    uint32_t b = (a.n + 7u) / 8u; if (b > 16384u) b = 16384u;
+    hipLaunchKernelGGL(detect_shared_points_kernel, dim3(b), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gather_dirty(const BoundaryArgs& a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    uint32_t b = (a.n + 255u) / 256u; if (b > 4096u) b = 4096u;
+    hipLaunchKernelGGL(gather_dirty_kernel, dim3(b), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_fold_sequential(const BoundaryArgs& a, const uint32_t* dlist_sorted, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fold_sequential_kernel, dim3(1), dim3(64), 0, s, a, dlist_sorted);
+    return hipGetLastError();
+}
 hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint32_t b = (n + 255u) / 256u; if (b > 4096u) b = 4096u;
@@ -314,10 +563,11 @@ hipError_t launch_cell_apply(const ApplyArgs& a, uint32_t max_groups, hipStream_
     hipLaunchKernelGGL(cell_apply_kernel, dim3(b), dim3(64), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, uint32_t* zero2, hipStream_t s) {
+hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, uint32_t* zero2,
+                             uint8_t* dirty, uint32_t* dlist, float4* out2n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint32_t b = (n + 255u) / 256u; if (b > 4096u) b = 4096u;
-    hipLaunchKernelGGL(voxel_keys_kernel, dim3(b), dim3(256), 0, s, pts, n, ds, vkeys, order, zero2);
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3(b), dim3(256), 0, s, pts, n, ds, vkeys, order, zero2, dirty, dlist, out2n);
     return hipGetLastError();
 }
 hipError_t launch_fold_groups(const FoldArgs& a, hipStream_t s) {

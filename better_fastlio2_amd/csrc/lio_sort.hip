@@ -25,6 +25,9 @@ size_t rle_temp_bytes(size_t n) {
                                      (uint32_t*)nullptr, (uint32_t*)nullptr, (hipStream_t)0);
     return bytes;
 }
+hipError_t sort_keys_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, size_t n, hipStream_t s) {
+    return rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, n, 0, 32, s);
+}
 hipError_t run_length_encode_u64(void* temp, size_t temp_bytes, const uint64_t* keys, size_t n,
                                  uint64_t* unique_out, uint32_t* counts_out, uint32_t* n_runs_out, hipStream_t s) {
     return rocprim::run_length_encode(temp, temp_bytes, keys, n, unique_out, counts_out, n_runs_out, s);

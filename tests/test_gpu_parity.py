@@ -217,6 +217,23 @@ def test_set_downsample_param(gpu_capi, oracle, small_case):
     ctx.close()
 
 
+def test_downsample_boundary_points_fuzz_seeds(gpu_capi, oracle):
+    """Add_Points(downsample) next to voxel boundaries, where the reference's fp32 boxes misbehave: a point outside
+    its own box (seed 1000: two identical points both survive), a map point inside the boxes of two neighbouring
+    voxels that both receive points (seed 5025).  Cases of scripts/fuzz_map.py (random worlds at kilometre
+    coordinates, random mutation sequences) replayed against the reference ikd-Tree."""
+    if not oracle.ref_available():
+        pytest.skip("reference ikd-Tree not built")
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_map.py")
+    spec = importlib.util.spec_from_file_location("fuzz_map", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for seed in (1000, 5025, 5000, 5005, 5010, 5015):
+        fz.run_case(seed)
+
+
 def test_map_mutation_parity(gpu_capi, oracle, small_case):
     """Add_Points (down-sampled: one point per voxel, nearest the centre; plain), Delete_Point_Boxes,
     validnum/size/flatten: same return values and live set as the oracle, k-NN parity afterwards."""
