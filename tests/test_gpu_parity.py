@@ -234,6 +234,21 @@ def test_downsample_boundary_points_fuzz_seeds(gpu_capi, oracle):
         fz.run_case(seed)
 
 
+def test_measurement_fuzz_seeds(gpu_capi, oracle):
+    """A few cases of scripts/fuzz_measure.py (random worlds up to kilometre offsets, random scans with outliers, both
+    extrinsic modes, scan sizes on the reduction's edges) against the CPU path on the reference ikd-Tree."""
+    if not oracle.ref_available():
+        pytest.skip("reference ikd-Tree not built")
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_measure.py")
+    spec = importlib.util.spec_from_file_location("fuzz_measure", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for seed in (2000, 2004, 2008, 2013, 2021):
+        fz.run_case(seed)
+
+
 def test_map_mutation_parity(gpu_capi, oracle, small_case):
     """Add_Points (down-sampled: one point per voxel, nearest the centre; plain), Delete_Point_Boxes,
     validnum/size/flatten: same return values and live set as the oracle, k-NN parity afterwards."""
