@@ -96,7 +96,8 @@ def run_case(seed):
         kf = capi.Esekf(3); kf.change_x(x0); kf.change_P(synth.init_cov())
         kf.update_iterated_dyn_share_modified(ctx, 0.001, ext)
         xg = kf.get_x()
-        assert np.abs(xg - xo).max() < 1e-7, (seed, "posterior", float(np.abs(xg - xo).max()))
+        dx = xg - xo                                               # bar: 1e-4 m / 1e-5 rad (see fuzz_loop.py)
+        assert np.abs(dx[:3]).max() < 1e-4 and 2.0 * np.abs(dx[3:7]).max() < 1e-5 and np.abs(dx[7:]).max() < 1e-4, (seed, "posterior", dx)
     finally:
         po.use_reference_knn(None)
         ctx.close()

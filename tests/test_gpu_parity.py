@@ -249,6 +249,21 @@ def test_measurement_fuzz_seeds(gpu_capi, oracle):
         fz.run_case(seed)
 
 
+def test_node_loop_fuzz_seeds(gpu_capi, oracle):
+    """A few cases of scripts/fuzz_loop.py: the per-scan loop (fov segment, iterated update, map_incremental, both
+    Add_Points) at kilometre offsets with the REFERENCE ikd-Tree as the CPU side's map."""
+    if not oracle.ref_available():
+        pytest.skip("reference ikd-Tree not built")
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_loop.py")
+    spec = importlib.util.spec_from_file_location("fuzz_loop", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for seed in (7001, 7002, 7004):
+        fz.run_case(seed)
+
+
 def test_map_mutation_parity(gpu_capi, oracle, small_case):
     """Add_Points (down-sampled: one point per voxel, nearest the centre; plain), Delete_Point_Boxes,
     validnum/size/flatten: same return values and live set as the oracle, k-NN parity afterwards."""
