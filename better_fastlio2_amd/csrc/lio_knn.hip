@@ -139,10 +139,12 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         bool have = false;
         if (active) {
             have = a.cnt[q] >= K;
-            if (r < K) {
-                const float4 p = a.nbr[(size_t)r * a.nq_stride + q];
+#pragma unroll
+            for (int k = r; k < K; k += G) {           // G < K (4 lanes per query): lane 0 measures two
+                const float4 p = a.nbr[(size_t)k * a.nq_stride + q];
                 const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
-                db = d == d ? __float_as_uint(d) : INF_BITS;
+                const uint32_t b = d == d ? __float_as_uint(d) : INF_BITS;
+                db = b > db ? b : db;
             }
         }
         db = group_max_u32<G>(db);

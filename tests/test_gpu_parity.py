@@ -645,13 +645,15 @@ def test_acquire_removed_points(gpu_capi, oracle, small_case):
     ctx.close()
 
 
+@pytest.mark.parametrize("lanes", [0, 4, 8, 16, 32, 64])
 @pytest.mark.parametrize("shift", [2e-4, 5e-3, 0.03, 0.4])
-def test_repeated_search_stays_exact(gpu_capi, oracle, small_case, shift):
+def test_repeated_search_stays_exact(gpu_capi, oracle, small_case, shift, lanes):
     """Second and third searches of the same scan (esekfom.hpp:1824-1838) are bounded by the previous neighbours
     (knn27_kernel<.., HINT>): Nearest_Points must equal a fresh search at the new pose -- for pose changes from the
-    filter's convergence scale (0.2 mm) to far beyond it (0.4 m, where the old neighbours bound almost nothing)."""
+    filter's convergence scale (0.2 mm) to far beyond it (0.4 m, where the old neighbours bound almost nothing), and
+    for every lanes-per-query width (with 4 lanes one lane has to re-measure two of the five old neighbours)."""
     w, sc, st = small_case["world"], small_case["scan"], small_case["state14"]
-    ctx = gpu_capi.LioContext(0.2, max_scan_points=20_000, max_map_points=400_000)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=20_000, max_map_points=400_000, lanes_per_query=lanes)
     ctx.map_build(w.points)
     om = oracle.OracleMap(0.2); om.build(w.points)
     ctx.scan_set(sc.body)
