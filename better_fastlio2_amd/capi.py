@@ -53,6 +53,11 @@ class lio_update_log(C.Structure):
                 ("last_res_mean", C.c_double), ("solve_seconds", C.c_double), ("measure_seconds", C.c_double)]
 
 
+class lio_imu_info(C.Structure):
+    _fields_ = [("need_init", C.c_int), ("init_iter_num", C.c_int), ("mean_acc", C.c_double * 3), ("mean_gyr", C.c_double * 3),
+                ("cov_acc", C.c_double * 3), ("cov_gyr", C.c_double * 3), ("last_lidar_end_time", C.c_double)]
+
+
 # every symbol include/lio_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_stream", "lio_synchronize",
@@ -62,7 +67,9 @@ EXPORTS = [
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
     "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_eskf_scan_step_device", "lio_state_boxplus",
-    "lio_state_boxminus",
+    "lio_state_boxminus", "lio_eskf_predict", "lio_process_noise_cov",
+    "lio_imu_create", "lio_imu_destroy", "lio_imu_reset", "lio_imu_set_extrinsic", "lio_imu_set_cov", "lio_imu_process",
+    "lio_imu_get_poses", "lio_imu_get_info",
 ]
 
 _lib = None
@@ -150,6 +157,18 @@ def load(build_if_missing: bool = True):
     L.lio_eskf_scan_step_device.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int, C.POINTER(lio_update_log)]
     L.lio_state_boxplus.argtypes = [_vp, _vp]
     L.lio_state_boxminus.argtypes = [_vp, _vp, _vp]
+    L.lio_eskf_predict.argtypes = [_vp, C.c_double, _vp, _vp, _vp]
+    L.lio_process_noise_cov.argtypes = [_vp]
+    L.lio_imu_create.restype = _vp
+    L.lio_imu_destroy.argtypes = [_vp]
+    L.lio_imu_destroy.restype = None
+    L.lio_imu_reset.argtypes = [_vp]
+    L.lio_imu_set_extrinsic.argtypes = [_vp, _vp, _vp]
+    L.lio_imu_set_cov.argtypes = [_vp, _vp, _vp, _vp, _vp]
+    L.lio_imu_process.argtypes = [_vp, _vp, _vp, C.c_double, C.c_double, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int,
+                                  C.POINTER(C.c_int)]
+    L.lio_imu_get_poses.argtypes = [_vp, _vp, C.c_int, C.POINTER(C.c_int)]
+    L.lio_imu_get_info.argtypes = [_vp, C.POINTER(lio_imu_info)]
     _lib = L
     return L
 
@@ -441,12 +460,87 @@ class Esekf:
         self.L.lio_eskf_get_P(self.h, _ptr(p))
         return p
 
+    def predict(self, dt: float, Q, acc, gyro):
+        """esekf::predict (esekfom.hpp:280-383): propagate x and P over dt with one IMU input."""
+        q = np.ascontiguousarray(Q, np.float64)
+        a = np.ascontiguousarray(acc, np.float64)
+        g = np.ascontiguousarray(gyro, np.float64)
+        assert q.shape == (12, 12) and a.shape == (3,) and g.shape == (3,)
+        rc = self.L.lio_eskf_predict(self.h, float(dt), _ptr(q), _ptr(a), _ptr(g))
+        if rc != LIO_OK:
+            raise LioError("lio_eskf_predict failed")
+
     def update_iterated_dyn_share_modified(self, ctx: LioContext, R: float = 0.001, extrinsic_est_en: bool = False) -> dict:
         log = lio_update_log()
         rc = self.L.lio_eskf_update_iterated_dyn_share_modified(self.h, ctx.h, R, int(extrinsic_est_en), C.byref(log))
         if rc != LIO_OK:
             raise LioError(f"update_iterated_dyn_share_modified: {ERRORS.get(rc, rc)}: {ctx.L.lio_last_error(ctx.h).decode()}")
         return {k: getattr(log, k) for k, _ in lio_update_log._fields_}
+
+
+class ImuProcess:
+    """Host-side IMU front end (lio_imu_*): mirror of the reference's ImuProcess (src/IMU_Processing.hpp).
+    IMU samples are rows [stamp, ax, ay, az, gx, gy, gz]."""
+
+    def __init__(self):
+        self.L = load()
+        self.h = _vp(self.L.lio_imu_create())
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.lio_imu_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def reset(self):
+        self.L.lio_imu_reset(self.h)
+
+    def set_extrinsic(self, T, R):
+        t = np.ascontiguousarray(T, np.float64).reshape(3)
+        r = np.ascontiguousarray(R, np.float64).reshape(9)
+        self.L.lio_imu_set_extrinsic(self.h, _ptr(t), _ptr(r))
+
+    def set_cov(self, gyr_cov=None, acc_cov=None, b_gyr_cov=None, b_acc_cov=None):
+        a = [None if v is None else np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float64), (3,))) for v in
+             (gyr_cov, acc_cov, b_gyr_cov, b_acc_cov)]
+        self.L.lio_imu_set_cov(self.h, *[None if v is None else _ptr(v) for v in a])
+
+    def process(self, kf: "Esekf", ctx, lidar_beg_time: float, lidar_end_time: float, imu, raw_xyzt=None) -> bool:
+        """ImuProcess::Process.  ctx=None: propagate only.  Returns True when ctx holds feats_undistort."""
+        m = np.ascontiguousarray(imu, np.float64).reshape(-1, 7)
+        r = None if raw_xyzt is None else np.ascontiguousarray(raw_xyzt, np.float32).reshape(-1, 4)
+        und = C.c_int(0)
+        rc = self.L.lio_imu_process(self.h, kf.h, None if ctx is None else ctx.h, lidar_beg_time, lidar_end_time,
+                                    None if r is None else _ptr(r), 0 if r is None else len(r), 16, 12,
+                                    _ptr(m) if len(m) else None, len(m), C.byref(und))
+        if rc != LIO_OK:
+            msg = ctx.L.lio_last_error(ctx.h).decode() if ctx is not None else ""
+            raise LioError(f"lio_imu_process: {ERRORS.get(rc, rc)}: {msg}")
+        return bool(und.value)
+
+    def poses(self) -> np.ndarray:
+        """IMUpose as rows of 22 doubles: offset_time, acc3, gyr3, vel3, pos3, rot9."""
+        n = C.c_int(0)
+        self.L.lio_imu_get_poses(self.h, None, 0, C.byref(n))
+        out = np.zeros((n.value, 22))
+        if n.value:
+            self.L.lio_imu_get_poses(self.h, _ptr(out), n.value, C.byref(n))
+        return out
+
+    def info(self) -> dict:
+        i = lio_imu_info()
+        self.L.lio_imu_get_info(self.h, C.byref(i))
+        return {"need_init": bool(i.need_init), "init_iter_num": i.init_iter_num, "mean_acc": np.array(i.mean_acc[:]),
+                "mean_gyr": np.array(i.mean_gyr[:]), "cov_acc": np.array(i.cov_acc[:]), "cov_gyr": np.array(i.cov_gyr[:]),
+                "last_lidar_end_time": i.last_lidar_end_time}
+
+
+def process_noise_cov() -> np.ndarray:
+    q = np.zeros((12, 12))
+    load().lio_process_noise_cov(_ptr(q))
+    return q
 
 
 def scan_step_device(kf: "Esekf", ctx: "LioContext", x26, P, d_body_ptr: int, n: int, R: float = 0.001,

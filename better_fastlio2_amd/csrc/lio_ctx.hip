@@ -12,6 +12,7 @@
 
 #include "../../include/lio_hip.h"
 #include "lio_esekf.hpp"
+#include "lio_imu.hpp"
 #include "lio_kernels.h"
 #include "lio_mapadd.h"
 #include "lio_scanprep.h"
@@ -1493,6 +1494,85 @@ int lio_state_boxplus(double x26[26], const double dx23[23]) {
     s.to_array(x26);
     return LIO_OK;
 }
+int lio_eskf_predict(lio_eskf* kf, double dt, const double Q[12 * 12], const double acc[3], const double gyro[3]) {
+    if (!kf || !Q || !acc || !gyro) return LIO_ERR_INVALID_ARG;
+    lio::input_ikfom in;
+    for (int i = 0; i < 3; ++i) { in.acc[i] = acc[i]; in.gyro[i] = gyro[i]; }
+    kf->kf.predict(dt, Q, in);
+    return LIO_OK;
+}
+int lio_process_noise_cov(double Q[12 * 12]) {
+    if (!Q) return LIO_ERR_INVALID_ARG;
+    lio::process_noise_cov(Q);
+    return LIO_OK;
+}
+
+// ---- host-side IMU front end ----------------------------------------------------------------------
+struct lio_imu {
+    lio::ImuProcess p;
+};
+lio_imu* lio_imu_create(void) { return new lio_imu(); }
+void lio_imu_destroy(lio_imu* imu) { delete imu; }
+int lio_imu_reset(lio_imu* imu) {
+    if (!imu) return LIO_ERR_INVALID_ARG;
+    imu->p.Reset();
+    return LIO_OK;
+}
+int lio_imu_set_extrinsic(lio_imu* imu, const double T[3], const double R[9]) {
+    if (!imu || !T || !R) return LIO_ERR_INVALID_ARG;
+    imu->p.set_extrinsic(T, R);
+    return LIO_OK;
+}
+int lio_imu_set_cov(lio_imu* imu, const double gyr_cov[3], const double acc_cov[3], const double b_gyr_cov[3],
+                    const double b_acc_cov[3]) {
+    if (!imu) return LIO_ERR_INVALID_ARG;
+    if (gyr_cov) imu->p.set_gyr_cov(gyr_cov);
+    if (acc_cov) imu->p.set_acc_cov(acc_cov);
+    if (b_gyr_cov) imu->p.set_gyr_bias_cov(b_gyr_cov);
+    if (b_acc_cov) imu->p.set_acc_bias_cov(b_acc_cov);
+    return LIO_OK;
+}
+int lio_imu_process(lio_imu* imu, lio_eskf* kf, lio_ctx* ctx, double lidar_beg_time, double lidar_end_time,
+                    const float* raw_pts, int n, int stride_bytes, int time_offset_bytes,
+                    const lio_imu_sample* samples, int n_samples, int* undistorted) {
+    if (!imu || !kf || n_samples < 0 || (n_samples > 0 && !samples)) return LIO_ERR_INVALID_ARG;
+    if (ctx && (n < 0 || (n > 0 && !raw_pts))) return LIO_ERR_INVALID_ARG;
+    lio::MeasureGroup meas;
+    meas.lidar_beg_time = lidar_beg_time;
+    meas.lidar_end_time = lidar_end_time;
+    meas.lidar = raw_pts;
+    meas.n_points = n;
+    meas.stride_bytes = stride_bytes;
+    meas.time_offset_bytes = time_offset_bytes;
+    meas.imu.resize((size_t)n_samples);
+    for (int i = 0; i < n_samples; ++i) {
+        meas.imu[i].stamp = samples[i].stamp;
+        for (int k = 0; k < 3; ++k) { meas.imu[i].acc[k] = samples[i].acc[k]; meas.imu[i].gyr[k] = samples[i].gyr[k]; }
+    }
+    return imu->p.Process(meas, kf->kf, ctx, undistorted);
+}
+int lio_imu_get_poses(lio_imu* imu, lio_pose6d* out, int cap, int* n) {
+    if (!imu || !n) return LIO_ERR_INVALID_ARG;
+    const std::vector<lio_pose6d>& v = imu->p.poses();
+    *n = (int)v.size();
+    if (out) {
+        if (cap < (int)v.size()) return LIO_ERR_CAPACITY;
+        for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    }
+    return LIO_OK;
+}
+int lio_imu_get_info(lio_imu* imu, lio_imu_info* info) {
+    if (!imu || !info) return LIO_ERR_INVALID_ARG;
+    info->need_init = imu->p.need_init() ? 1 : 0;
+    info->init_iter_num = imu->p.init_iter();
+    for (int i = 0; i < 3; ++i) {
+        info->mean_acc[i] = imu->p.mean_acc[i]; info->mean_gyr[i] = imu->p.mean_gyr[i];
+        info->cov_acc[i] = imu->p.cov_acc[i]; info->cov_gyr[i] = imu->p.cov_gyr[i];
+    }
+    info->last_lidar_end_time = imu->p.last_lidar_end_time();
+    return LIO_OK;
+}
+
 int lio_state_boxminus(const double x26[26], const double y26[26], double dx23[23]) {
     if (!x26 || !y26 || !dx23) return LIO_ERR_INVALID_ARG;
     lio::state_ikfom::from_array(x26).boxminus(dx23, lio::state_ikfom::from_array(y26));

@@ -304,6 +304,215 @@ double now_seconds() {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+// quaternion helpers shared with the IMU front end (lio_imu.cpp)
+// ------------------------------------------------------------------------------------------
+Vec3 quat_rotate(const Quat& q, const Vec3& v) {             // Eigen 3.3 QuaternionBase::_transformVector
+    const double ux = 2.0 * (q.y * v.z - q.z * v.y), uy = 2.0 * (q.z * v.x - q.x * v.z), uz = 2.0 * (q.x * v.y - q.y * v.x);
+    Vec3 r;
+    r.x = v.x + q.w * ux + (q.y * uz - q.z * uy);
+    r.y = v.y + q.w * uy + (q.z * ux - q.x * uz);
+    r.z = v.z + q.w * uz + (q.x * uy - q.y * ux);
+    return r;
+}
+void quat_to_matrix(const Quat& q, double R[9]) {
+    const M3 m = qmatrix(q);
+    for (int i = 0; i < 9; ++i) R[i] = m.a[i];
+}
+Quat quat_from_matrix(const double R[9]) {                   // Eigen 3.3 quaternionbase_assign_impl<Matrix3>
+    Quat q;
+    double t = R[0] + R[4] + R[8];
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (R[7] - R[5]) * t;
+        q.y = (R[2] - R[6]) * t;
+        q.z = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 4]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+        double v[3];
+        v[i] = 0.5 * t;
+        t = 0.5 / t;
+        q.w = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        v[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        v[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+        q.x = v[0]; q.y = v[1]; q.z = v[2];
+    }
+    return q;
+}
+Vec3 s2_from_vector(const Vec3& v) {                         // S2(const vect_type&), mtk/types/S2.hpp:124-127
+    const double n = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    Vec3 r{v.x / n, v.y / n, v.z / n};
+    r.x *= kGravLen; r.y *= kGravLen; r.z *= kGravLen;
+    return r;
+}
+
+// process_noise_cov (use-ikfom.hpp:44-52): diag(ng 1e-4, na 1e-4, nbg 1e-5, nba 1e-5), 12 x 12 row-major
+void process_noise_cov(double Q[12 * 12]) {
+    for (int i = 0; i < 144; ++i) Q[i] = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        Q[i * 13] = 0.0001; Q[(3 + i) * 13] = 0.0001; Q[(6 + i) * 13] = 0.00001; Q[(9 + i) * 13] = 0.00001;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// process model (use-ikfom.hpp:56-99) and esekf::predict (esekfom.hpp:280-383)
+// ------------------------------------------------------------------------------------------
+// Flattened-state rows (DIM = 24): pos 0, rot 3, offset_R_L_I 6, offset_T_L_I 9, vel 12, bg 15, ba 18, grav 21.
+void get_f(const state_ikfom& s, const input_ikfom& in, double f[DIM]) {          // use-ikfom.hpp:56-69
+    for (int i = 0; i < DIM; ++i) f[i] = 0.0;
+    const Vec3 omega{in.gyro[0] - s.bg.x, in.gyro[1] - s.bg.y, in.gyro[2] - s.bg.z};
+    const Vec3 a_inertial = quat_rotate(s.rot, Vec3{in.acc[0] - s.ba.x, in.acc[1] - s.ba.y, in.acc[2] - s.ba.z});
+    f[0] = s.vel.x; f[1] = s.vel.y; f[2] = s.vel.z;
+    f[3] = omega.x; f[4] = omega.y; f[5] = omega.z;
+    f[12] = a_inertial.x + s.grav.x; f[13] = a_inertial.y + s.grav.y; f[14] = a_inertial.z + s.grav.z;
+}
+void df_dx(const state_ikfom& s, const input_ikfom& in, double F[DIM * DOF]) {    // use-ikfom.hpp:71-88
+    for (int i = 0; i < DIM * DOF; ++i) F[i] = 0.0;
+    for (int i = 0; i < 3; ++i) F[i * DOF + 12 + i] = 1.0;
+    const V3 acc_ = v3(in.acc[0] - s.ba.x, in.acc[1] - s.ba.y, in.acc[2] - s.ba.z);
+    const M3 R = qmatrix(s.rot);
+    const M3 RA = R * hat(acc_);
+    const Mat<3, 2> G = S2_Mx(v3(s.grav), 0.0, 0.0);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            F[(12 + i) * DOF + 3 + j] = -RA(i, j);
+            F[(12 + i) * DOF + 18 + j] = -R(i, j);
+        }
+        F[(12 + i) * DOF + 21] = G(i, 0);
+        F[(12 + i) * DOF + 22] = G(i, 1);
+        F[(3 + i) * DOF + 15 + i] = -1.0;
+    }
+}
+void df_dw(const state_ikfom& s, const input_ikfom&, double W[DIM * 12]) {        // use-ikfom.hpp:91-99
+    for (int i = 0; i < DIM * 12; ++i) W[i] = 0.0;
+    const M3 R = qmatrix(s.rot);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) W[(12 + i) * 12 + 3 + j] = -R(i, j);
+        W[(3 + i) * 12 + i] = -1.0;
+        W[(15 + i) * 12 + 6 + i] = 1.0;
+        W[(18 + i) * 12 + 9 + i] = 1.0;
+    }
+}
+
+void esekf::predict(double dt, const double Q[12 * 12], const input_ikfom& in) {
+    double f_[DIM], f_x_[DIM * DOF], f_w_[DIM * 12];
+    get_f(x_, in, f_);                                       // esekfom.hpp:281-282, 285
+    df_dx(x_, in, f_x_);
+    df_dw(x_, in, f_w_);
+    const state_ikfom x_before = x_;
+
+    // x_.oplus(f_, dt) (esekfom.hpp:288; vect.hpp:124-126, SOn.hpp:242-245, S2.hpp:129-134)
+    x_.pos.x += dt * f_[0]; x_.pos.y += dt * f_[1]; x_.pos.z += dt * f_[2];
+    x_.rot = qmul(x_.rot, exp_quat(v3(f_[3], f_[4], f_[5]), dt / 2));
+    x_.offset_R_L_I = qmul(x_.offset_R_L_I, exp_quat(v3(f_[6], f_[7], f_[8]), dt / 2));
+    x_.offset_T_L_I.x += dt * f_[9]; x_.offset_T_L_I.y += dt * f_[10]; x_.offset_T_L_I.z += dt * f_[11];
+    x_.vel.x += dt * f_[12]; x_.vel.y += dt * f_[13]; x_.vel.z += dt * f_[14];
+    x_.bg.x += dt * f_[15]; x_.bg.y += dt * f_[16]; x_.bg.z += dt * f_[17];
+    x_.ba.x += dt * f_[18]; x_.ba.y += dt * f_[19]; x_.ba.z += dt * f_[20];
+    {
+        const V3 g = qmatrix(exp_quat(v3(f_[21], f_[22], f_[23]), dt / 2)) * v3(x_.grav);
+        x_.grav = {g.a[0], g.a[1], g.a[2]};
+    }
+
+    double F_x1[DOF * DOF], f_x_final[DOF * DOF], f_w_final[DOF * 12];
+    for (int i = 0; i < DOF * DOF; ++i) F_x1[i] = 0.0;
+    for (int i = 0; i < DOF; ++i) F_x1[i * DOF + i] = 1.0;
+    // vect sub-states: rows copied through (esekfom.hpp:291-303); {idx, dim} pairs, dof 3 each
+    static const int vect_idx[5][2] = {{0, 0}, {9, 9}, {12, 12}, {15, 15}, {18, 18}};
+    for (const auto& v : vect_idx)
+        for (int j = 0; j < 3; ++j) {
+            for (int i = 0; i < DOF; ++i) f_x_final[(v[0] + j) * DOF + i] = f_x_[(v[1] + j) * DOF + i];
+            for (int i = 0; i < 12; ++i) f_w_final[(v[0] + j) * 12 + i] = f_w_[(v[1] + j) * 12 + i];
+        }
+    // SO3 sub-states (esekfom.hpp:304-333).  exp(seg, scalar_type(1/2)): 1/2 is an integer division, the
+    // scale is 0 and the "rotation" is the identity -- F_x1's diagonal blocks stay I.
+    for (int k = 0; k < 2; ++k) {
+        const int idx = kSO3Index[k], dim = kSO3Index[k];
+        const V3 seg = v3(-1 * f_[dim] * dt, -1 * f_[dim + 1] * dt, -1 * f_[dim + 2] * dt);
+        const M3 E = qmatrix(exp_quat(seg, 0.0));
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F_x1[(idx + i) * DOF + idx + j] = E(i, j);
+        const M3 A = A_matrix(seg);
+        for (int c = 0; c < DOF; ++c)
+            for (int i = 0; i < 3; ++i) {
+                double acc = 0.0;
+                for (int j = 0; j < 3; ++j) acc += A(i, j) * f_x_[(dim + j) * DOF + c];
+                f_x_final[(idx + i) * DOF + c] = acc;
+            }
+        for (int c = 0; c < 12; ++c)
+            for (int i = 0; i < 3; ++i) {
+                double acc = 0.0;
+                for (int j = 0; j < 3; ++j) acc += A(i, j) * f_w_[(dim + j) * 12 + c];
+                f_w_final[(idx + i) * 12 + c] = acc;
+            }
+    }
+    // S2 sub-state (esekfom.hpp:336-372)
+    {
+        const int idx = kS2Index, dim = 21;
+        const V3 seg = v3(f_[dim] * dt, f_[dim + 1] * dt, f_[dim + 2] * dt);
+        const M3 E = qmatrix(exp_quat(seg, 0.0));
+        const Mat<2, 3> Nx = S2_Nx_yy(v3(x_.grav));
+        const Mat<3, 2> Mx = S2_Mx(v3(x_before.grav), 0.0, 0.0);
+        const Mat<2, 2> D = Nx * E * Mx;
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) F_x1[(idx + i) * DOF + idx + j] = D(i, j);
+        Mat<2, 3> T = Nx * E * hat(v3(x_before.grav)) * transpose(A_matrix(seg));
+        for (double& v : T.a) v = -v;
+        for (int c = 0; c < DOF; ++c)
+            for (int i = 0; i < 2; ++i) {
+                double acc = 0.0;
+                for (int j = 0; j < 3; ++j) acc += T(i, j) * f_x_[(dim + j) * DOF + c];
+                f_x_final[(idx + i) * DOF + c] = acc;
+            }
+        for (int c = 0; c < 12; ++c)
+            for (int i = 0; i < 2; ++i) {
+                double acc = 0.0;
+                for (int j = 0; j < 3; ++j) acc += T(i, j) * f_w_[(dim + j) * 12 + c];
+                f_w_final[(idx + i) * 12 + c] = acc;
+            }
+    }
+    // F_x1 += f_x_final * dt;  P = F_x1 P F_x1^T + (dt f_w_final) Q (dt f_w_final)^T     (esekfom.hpp:380-381)
+    // F_x1 and f_w_final are mostly zeros (<= 9 / <= 3 entries per row): the products below visit the non-zero
+    // entries only, in ascending index order -- the same sums as the dense loops, the skipped terms being exact zeros.
+    for (int i = 0; i < DOF * DOF; ++i) F_x1[i] += f_x_final[i] * dt;
+    for (int i = 0; i < DOF * 12; ++i) f_w_final[i] = dt * f_w_final[i];
+    int fnz[DOF][DOF], fcnt[DOF], wnz[DOF][12], wcnt[DOF];
+    for (int r = 0; r < DOF; ++r) {
+        fcnt[r] = 0; wcnt[r] = 0;
+        for (int k = 0; k < DOF; ++k) if (F_x1[r * DOF + k] != 0.0) fnz[r][fcnt[r]++] = k;
+        for (int k = 0; k < 12; ++k) if (f_w_final[r * 12 + k] != 0.0) wnz[r][wcnt[r]++] = k;
+    }
+    double FP[DOF * DOF], WQ[DOF * 12];
+    for (int r = 0; r < DOF; ++r) {
+        double* row = FP + r * DOF;
+        for (int c = 0; c < DOF; ++c) row[c] = 0.0;
+        for (int i = 0; i < fcnt[r]; ++i) {
+            const int k = fnz[r][i];
+            const double f = F_x1[r * DOF + k];
+            const double* pk = P_ + k * DOF;
+            for (int c = 0; c < DOF; ++c) row[c] += f * pk[c];
+        }
+        double* wrow = WQ + r * 12;
+        for (int c = 0; c < 12; ++c) wrow[c] = 0.0;
+        for (int i = 0; i < wcnt[r]; ++i) {
+            const int k = wnz[r][i];
+            const double f = f_w_final[r * 12 + k];
+            for (int c = 0; c < 12; ++c) wrow[c] += f * Q[k * 12 + c];
+        }
+    }
+    for (int r = 0; r < DOF; ++r)
+        for (int c = 0; c < DOF; ++c) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int i = 0; i < fcnt[c]; ++i) { const int k = fnz[c][i]; a1 += FP[r * DOF + k] * F_x1[c * DOF + k]; }
+            for (int i = 0; i < wcnt[c]; ++i) { const int k = wnz[c][i]; a2 += WQ[r * 12 + k] * f_w_final[c * 12 + k]; }
+            P_[r * DOF + c] = a1 + a2;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // state_ikfom
 // ------------------------------------------------------------------------------------------
 void state_ikfom::boxplus(const double d[DOF]) {

@@ -8,9 +8,9 @@
 //   esekfom::esekf::init_dyn_share       esekfom.hpp:239-258
 //   esekf::update_iterated_dyn_share_modified   esekfom.hpp:1620-1938
 //   get_x / get_P / change_x / change_P  esekfom.hpp:1940-1961
+//   esekf::predict                       esekfom.hpp:280-383 with the process model of use-ikfom.hpp:44-99
 // The reference builds these from Eigen + Boost.PP (neither ships with it nor with this image);
-// here they are plain C++17 with fixed-size arrays.  IMU propagation (predict, esekfom.hpp:280)
-// stays with the caller and is out of scope.
+// here they are plain C++17 with fixed-size arrays.
 //
 // The measurement callback has the reference's shape
 //     void h(state_ikfom& s, dyn_share_datastruct& d)          (esekfom.hpp:130)
@@ -58,6 +58,21 @@ struct dyn_share_datastruct {
 
 typedef std::function<void(state_ikfom&, dyn_share_datastruct&)> measurementModel_dyn_share;
 
+struct input_ikfom { double acc[3] = {0, 0, 0}, gyro[3] = {0, 0, 0}; };   // use-ikfom.hpp:32-35
+
+// process model, use-ikfom.hpp:44-99 (row-major; flattened-state rows: pos 0, rot 3, offset_R_L_I 6,
+// offset_T_L_I 9, vel 12, bg 15, ba 18, grav 21)
+void process_noise_cov(double Q[12 * 12]);
+void get_f(const state_ikfom& s, const input_ikfom& in, double f[DIM]);
+void df_dx(const state_ikfom& s, const input_ikfom& in, double F[DIM * DOF]);
+void df_dw(const state_ikfom& s, const input_ikfom& in, double W[DIM * 12]);
+
+// Eigen-equivalent quaternion helpers used by the IMU front end
+Vec3 quat_rotate(const Quat& q, const Vec3& v);             // q * v
+void quat_to_matrix(const Quat& q, double R[9]);            // toRotationMatrix, row-major
+Quat quat_from_matrix(const double R[9]);                   // Quaternion(Matrix3)
+Vec3 s2_from_vector(const Vec3& v);                         // S2(vec): direction of v, length 9.809
+
 struct update_stats {
     int n_calls = 0, n_search = 0, last_m = 0;
     bool converged = false;
@@ -71,6 +86,8 @@ public:
     void set_measurement_model(measurementModel_dyn_share h) { h_dyn_share_ = std::move(h); }
     // R = LASER_POINT_COV (laserMapping.cpp:14, :2380)
     void update_iterated_dyn_share_modified(double R, double& solve_time);
+    // IMU propagation over dt with input i_in and process noise Q (12 x 12 row-major), esekfom.hpp:280-383
+    void predict(double dt, const double Q[12 * 12], const input_ikfom& i_in);
     const state_ikfom& get_x() const { return x_; }
     const double* get_P() const { return P_; }             // 23 x 23 row-major
     void change_x(const state_ikfom& s) { x_ = s; }

@@ -242,6 +242,47 @@ int  lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, dou
  * device memory (lio_scan_set_device), the iterated update runs.  Equivalent to the four calls it names.   */
 int  lio_eskf_scan_step_device(lio_eskf* kf, lio_ctx* ctx, const double x26[26], const double P[23 * 23],
                                const void* d_body_f4, int n, double R, int extrinsic_est_en, lio_update_log* log);
+/* esekf::predict(dt, Q, i_in) (esekfom.hpp:280-383) with the process model f / df_dx / df_dw of
+ * use-ikfom.hpp:56-99: propagates x and P over dt with the IMU input (acc, gyro); Q = 12 x 12 process noise
+ * (ng, na, nbg, nba), row-major.                                                                             */
+int  lio_eskf_predict(lio_eskf* kf, double dt, const double Q[12 * 12], const double acc[3], const double gyro[3]);
+/* process_noise_cov() (use-ikfom.hpp:44-52)                                                                  */
+int  lio_process_noise_cov(double Q[12 * 12]);
+
+/* ---- host-side IMU front end (mirror of ImuProcess, src/IMU_Processing.hpp:30-441) ------------------------ */
+typedef struct lio_imu lio_imu;
+typedef struct lio_imu_sample {      /* the fields of sensor_msgs::Imu the reference reads                    */
+    double stamp;                    /* header.stamp.toSec()                                                  */
+    double acc[3];                   /* linear_acceleration                                                   */
+    double gyr[3];                   /* angular_velocity                                                      */
+} lio_imu_sample;
+typedef struct lio_imu_info {
+    int    need_init;                /* imu_need_init_                                                        */
+    int    init_iter_num;
+    double mean_acc[3], mean_gyr[3], cov_acc[3], cov_gyr[3];
+    double last_lidar_end_time;
+} lio_imu_info;
+lio_imu* lio_imu_create(void);
+void lio_imu_destroy(lio_imu* imu);
+int  lio_imu_reset(lio_imu* imu);                                                  /* Reset, :91-103          */
+int  lio_imu_set_extrinsic(lio_imu* imu, const double T[3], const double R[9]);    /* :131-135, R row-major   */
+/* set_gyr_cov / set_acc_cov / set_gyr_bias_cov / set_acc_bias_cov (:141-171; laserMapping.cpp:2143-2146);
+ * NULL leaves a value as it is.                                                                              */
+int  lio_imu_set_cov(lio_imu* imu, const double gyr_cov[3], const double acc_cov[3],
+                     const double b_gyr_cov[3], const double b_acc_cov[3]);
+/* ImuProcess::Process(Measures, kf, feats_undistort) (:392-441; laserMapping.cpp:2256): the first calls
+ * initialise (IMU_init, :174-231: gravity, gyroscope bias, extrinsics, P) until more than MAX_INI_COUNT
+ * samples were seen; later calls run UndistortPcl (:237-386): forward propagation of kf through the IMU
+ * samples on the host (lio_eskf_predict per sample), then the per-point compensation on the GPU
+ * (lio_scan_undistort on ctx with the propagated poses).  *undistorted = 1 when ctx now holds
+ * feats_undistort.  ctx == NULL: propagate only (no device work).  raw_pts as for lio_scan_undistort.         */
+int  lio_imu_process(lio_imu* imu, lio_eskf* kf, lio_ctx* ctx, double lidar_beg_time, double lidar_end_time,
+                     const float* raw_pts, int n, int stride_bytes, int time_offset_bytes,
+                     const lio_imu_sample* samples, int n_samples, int* undistorted);
+/* IMUpose of the last UndistortPcl (*n = number available)                                                   */
+int  lio_imu_get_poses(lio_imu* imu, lio_pose6d* out, int cap, int* n);
+int  lio_imu_get_info(lio_imu* imu, lio_imu_info* info);
+
 /* manifold helpers exposed for tests: x [+] dx and x [-] y on the 23-DOF compound manifold        */
 int  lio_state_boxplus(double x26[26], const double dx23[23]);
 int  lio_state_boxminus(const double x26[26], const double y26[26], double dx23[23]);

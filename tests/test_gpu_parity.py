@@ -727,6 +727,69 @@ def _imu_poses(n_poses=14, dt=0.0085):
     return poses
 
 
+def test_imu_front_end_feeds_the_scan_step(gpu_capi, oracle, synth, small_case):
+    """The whole step before the path, as the node runs it (laserMapping.cpp:2256, 2322-2325, 2380):
+    ImuProcess::Process -- forward propagation on the host, point compensation on the device -- then the voxel
+    filter and the iterated update, against the restatements (oracle/imu_model.py for the IMU side)."""
+    from oracle import imu_model as im
+    w, sc = small_case["world"], small_case["scan"]
+    rng = np.random.default_rng(21)
+    n = len(sc.body)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=20_000, max_map_points=400_000)
+    ctx.map_build(w.points)
+    om = oracle.OracleMap(0.2); om.build(w.points)
+    Rm = im.qmat(np.asarray(sc.off_R, np.float64))
+    p = gpu_capi.ImuProcess(); p.set_extrinsic(sc.off_T, Rm); p.set_cov(0.1, 0.1, 0.0001, 0.0001)
+    o = im.ImuProcess(); o.Lidar_T, o.Lidar_R = np.array(sc.off_T, np.float64), np.array(Rm, np.float64)
+    kf = gpu_capi.Esekf(3)
+    xo, Po = kf.get_x(), kf.get_P()
+
+    def imu_rows(t0, t1, moving):
+        rows = []
+        for t in np.arange(t0, t1, 0.005):
+            acc = np.array([0.0, 0.0, 9.79]) + rng.normal(0, 0.01, 3)
+            gyr = np.array([0.001, -0.002, 0.0005]) + rng.normal(0, 0.001, 3)
+            if moving:
+                acc = acc + [0.8 * np.sin(9 * t), 0.5, 0.1]
+                gyr = gyr + [0.03, -0.02, 0.3]
+            rows.append(np.concatenate([[t], acc, gyr]))
+        return np.array(rows)
+
+    # scan 0: static initialisation (no cloud is produced)
+    t_ms = np.sort(rng.uniform(0, 100.0, n)).astype(np.float32)
+    raw = np.concatenate([sc.body, t_ms[:, None]], 1).astype(np.float32)
+    imu0 = imu_rows(10.0, 10.1, False)
+    assert p.process(kf, ctx, 10.0, 10.1, imu0, raw) is False
+    xo, Po, ready = o.process(imu0, 10.0, 10.1, xo, Po)
+    assert not ready and not p.info()["need_init"]
+    # put the initialised filter at the scan's pose (the node starts at the origin; the map here does not)
+    x = kf.get_x(); x[0:7] = small_case["state14"][0:7]; kf.change_x(x); xo[0:7] = x[0:7]
+    # scan 1: the sensor turns and accelerates while the scan is taken
+    rng.shuffle(raw)                                             # Process must time-sort the points itself
+    imu1 = imu_rows(10.1 - 0.002, 10.2 + 0.003, True)
+    assert p.process(kf, ctx, 10.1, 10.1 + float(raw[:, 3].max()) / 1000.0, imu1, raw) is True
+    xo, Po, ready = o.process(imu1, 10.1, 10.1 + float(raw[:, 3].max()) / 1000.0, xo, Po)
+    assert ready
+    assert np.abs(kf.get_x() - xo).max() < 1e-11 and np.abs(kf.get_P() - Po).max() < 1e-11
+    poses = np.array(o.poses)
+    assert np.abs(p.poses() - poses).max() < 1e-11
+    und_g = ctx.scan_cloud(0)
+    und_o, ts = oracle.undistort(raw, poses, np.concatenate([xo[0:14]]))
+    assert und_g.shape == und_o.shape == (n, 3)
+    assert np.abs(und_g - und_o).max() < 1e-5 and (und_g.view(np.uint32) == und_o.view(np.uint32)).mean() > 0.999
+    assert np.abs(und_g - raw[np.argsort(raw[:, 3], kind="stable"), :3]).max() > 0.02      # the motion was compensated
+    # down-sample and update from the propagated state and covariance
+    m = ctx.scan_voxel_filter(0.5)
+    down_o = oracle.voxel_grid(und_g, 0.5)
+    assert m == len(down_o) and bits_equal(ctx.scan_cloud(1), down_o)
+    log = kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+    xu, Pu, arrs, olog = oracle.update_iterated(om, xo, Po, down_o)
+    assert log["n_calls"] == len(olog) and log["last_m"] > 100
+    assert np.abs(kf.get_x()[0:3] - xu[0:3]).max() < 1e-4 and np.abs(kf.get_x()[3:7] - xu[3:7]).max() < 0.5e-5
+    assert np.abs(kf.get_P() - Pu).max() < 1e-6 * np.abs(Pu).max()
+    ctx.close()
+
+
 def test_scan_undistort_and_voxel_filter(gpu_capi, oracle, synth, small_case):
     """The step before the path (SURVEY.md 8f rank 3): UndistortPcl's point side and pcl::VoxelGrid on the
     device vs the oracle restatement (both "parity unpinned": Eigen / PCL are un-vendored).  Then the
