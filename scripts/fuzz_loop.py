@@ -1,6 +1,6 @@
 """Differential fuzzing of the node's per-scan loop (iterated update -> map_incremental -> Add_Points x2 ->
 lasermap_fov_segment) at kilometre coordinates against the CPU path with the REFERENCE ikd-Tree as the map: random
-offsets, voxel sizes, thinning of the initial map, scan poses along a drive.  After every scan: posterior, the two
+offsets, thinning of the initial map, scan poses along a drive, lanes per query, extrinsic estimation on/off.  After every scan: posterior, the two
 insert lists (bit-equal), Add_Points counter, validnum, fov boxes and delete counts.
 
     python scripts/fuzz_loop.py [n_cases] [first_seed]
@@ -26,7 +26,9 @@ def run_case(seed):
     ds = 0.2
     base = np.ascontiguousarray(pts[:: int(rng.integers(2, 5))])
     nq = int(rng.choice([3000, 8000, 12000]))
-    ctx = capi.LioContext(ds, max_scan_points=nq, max_map_points=600_000)
+    lanes = int(rng.choice([0, 0, 0, 4, 8, 16, 32, 64]))
+    ext = bool(rng.integers(0, 2))
+    ctx = capi.LioContext(ds, max_scan_points=nq, max_map_points=600_000, lanes_per_query=lanes)
     ctx.map_build(base)
     ref = po.RefIkdTree(ds); ref.build(base); po.use_reference_knn(ref)
     om = po.OracleMap(ds)                                        # only carries parameters: k-NN goes to the reference tree
@@ -46,14 +48,14 @@ def run_case(seed):
             nd_o = ref.delete_boxes(boxes_o) if len(boxes_o) else 0
             assert nd_g == nd_o, (seed, k, "fov delete count", nd_g, nd_o)
             # CPU path
-            xo, Po, arrs, log = po.update_iterated(om, x0, synth.init_cov(), sc.body, knn_method=2)
+            xo, Po, arrs, log = po.update_iterated(om, x0, synth.init_cov(), sc.body, extrinsic_est_en=ext, knn_method=2)
             world_post = po.body_to_world(xo[:14], sc.body)
             cls = po.map_incremental_classify(world_post, arrs.nbr_xyz, arrs.nbr_cnt, ds, True)
             to_add, nodown = world_post[cls == 1], world_post[cls == 2]
             # GPU path
             kf = capi.Esekf(3); kf.change_x(x0); kf.change_P(synth.init_cov())
             ctx.scan_set(sc.body)
-            kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+            kf.update_iterated_dyn_share_modified(ctx, 0.001, ext)
             # the bar of the path: 1e-4 m / 1e-5 rad.  Usually the two agree to 1e-12; when a point sits
             # exactly on a decision (s > 0.9, the 0.1 m plane test) the 1e-15 difference of the summed H^T H can flip it
             # in a later pass, which moves the posterior by ~1e-5 m
