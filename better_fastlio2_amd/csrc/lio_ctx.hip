@@ -584,7 +584,7 @@ void lio_destroy(lio_ctx* c) {
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_minmax,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
-                   c->d_add_order, c->d_add_order2, c->d_add_gcount, c->d_add_gstart};
+                   c->d_add_order, c->d_add_order2, c->d_add_gcount, c->d_add_gstart, c->d_add_dirty, c->d_add_dlist, c->d_add_dlist2};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_stage) (void)hipHostFree(c->h_stage);

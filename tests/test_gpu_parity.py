@@ -887,3 +887,42 @@ def test_node_loop_composition(gpu_capi, oracle, synth, small_case):
         P_g, P_o = Po, Po
     assert bits_equal(key(ctx.map_flatten()), key(om.flatten()))
     ctx.close()
+
+
+def test_contexts_release_their_memory(gpu_capi, small_case):
+    """lio_destroy gives back everything a context took, including what grew on demand (map-add staging,
+    removed-point lists, the nearest-search batch buffers, scan preparation): device memory free before
+    == after a dozen create / use / destroy cycles."""
+    import ctypes as C
+    gpu_capi.load()
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    w, sc, st = small_case["world"], small_case["scan"], small_case["state14"]
+
+    def cycle():
+        ctx = gpu_capi.LioContext(0.2, max_scan_points=20_000, max_map_points=400_000)
+        ctx.map_build(w.points[::2])
+        ctx.map_add(w.points[1::2][:30_000], True)
+        ctx.scan_set(sc.body)
+        ctx.measure(st, True, False)
+        ctx.map_incremental(st, 0.2, True, apply=True, want_lists=False)
+        ctx.nearest_search(w.points[:1000])
+        ctx.map_delete_boxes(np.array([[0, 0, -1, 5, 5, 3]], np.float32))
+        ctx.acquire_removed_points()
+        raw = np.concatenate([sc.body, np.zeros((len(sc.body), 1), np.float32)], 1)
+        ctx.scan_undistort(raw)
+        ctx.scan_voxel_filter(0.5)
+        ctx.close()
+
+    cycle()                                   # first use pays for runtime-internal pools (code objects, rocPRIM)
+    before = free_bytes()
+    for _ in range(12):
+        cycle()
+    after = free_bytes()
+    assert before - after < (8 << 20), (before, after)      # nothing of the ~100 MB per context stays behind
