@@ -92,6 +92,10 @@ struct lio_ctx {
 
     // ---- staging / scratch --------------------------------------------------------------------
     float4* h_stage = nullptr;                 // pinned upload staging
+    hipEvent_t ev_stage = nullptr;             // recorded behind an asynchronous copy out of h_stage
+    bool stage_busy = false;
+    bool undist_sorted = true;                 // d_undist is in time order (else: input order, sorted on demand)
+    bool raw_time_keyed = false;               // the raw scan came with per-point times and IMU poses
     size_t h_stage_cap = 0;
     void* d_scratch = nullptr;                 // download staging (device side)
     size_t d_scratch_bytes = 0;
@@ -111,7 +115,7 @@ struct lio_ctx {
     uint64_t *d_raw_keys = nullptr, *d_raw_keys2 = nullptr, *d_leaf_keys = nullptr;
     uint32_t *d_raw_order = nullptr, *d_raw_order2 = nullptr, *d_leaf_count = nullptr, *d_leaf_start = nullptr;
     double* d_imu_poses = nullptr;             // up to 512 Pose6D records (22 doubles each)
-    int* d_minmax = nullptr;
+    VoxelGridDev* d_vox = nullptr;
 
     // batch buffers of lio_map_add
     size_t cap_add = 0;
@@ -168,6 +172,10 @@ int auto_lanes(int nq) {
 }
 
 int ensure_stage(lio_ctx* c, size_t n) {
+    if (c->stage_busy) {                       // an upload that did not wait for its own copy (lio_scan_undistort)
+        HIPCHK(c, hipEventSynchronize(c->ev_stage));
+        c->stage_busy = false;
+    }
     if (n <= c->h_stage_cap) return LIO_OK;
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     c->h_stage = nullptr; c->h_stage_cap = 0;
@@ -505,6 +513,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipGetDeviceProperties(&prop, c->device));
     c->arch = prop.gcnArchName;
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
 
     c->grid.cell = cfg->cell_size != 0.0f ? cfg->cell_size : auto_cell_size(cfg->filter_size_map_min);
     c->grid.inv_cell = 1.0f / c->grid.cell;
@@ -582,7 +591,7 @@ void lio_destroy(lio_ctx* c) {
                    c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_rows,
                    c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
-                   c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_minmax,
+                   c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
                    c->d_add_order, c->d_add_order2, c->d_add_gcount, c->d_add_gstart, c->d_add_dirty, c->d_add_dlist, c->d_add_dlist2};
     for (void* p : dev) if (p) (void)hipFree(p);
@@ -591,6 +600,7 @@ void lio_destroy(lio_ctx* c) {
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     for (int w = 0; w < LIO_PROF_COUNT; ++w)
         for (hipEvent_t e : c->ev_pool[w]) (void)hipEventDestroy(e);
+    if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1117,7 +1127,7 @@ int lio_scan_size(lio_ctx* c) { return c ? c->nq : 0; }
 // ---- raw-scan preparation: UndistortPcl's compensation + pcl::VoxelGrid ----
 static int ensure_raw_buffers(lio_ctx* c, size_t n) {
     if (!c->d_imu_poses) HIPCHK(c, hipMalloc((void**)&c->d_imu_poses, 512 * 22 * sizeof(double)));
-    if (!c->d_minmax) HIPCHK(c, hipMalloc((void**)&c->d_minmax, 6 * sizeof(int)));
+    if (!c->d_vox) HIPCHK(c, hipMalloc((void**)&c->d_vox, sizeof(VoxelGridDev)));
     if (n <= c->cap_raw) return LIO_OK;
     void* old[] = {c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start};
@@ -1156,27 +1166,47 @@ int lio_scan_undistort(lio_ctx* c, const float* raw_pts, int n, int stride_bytes
     rc = ensure_stage(c, (size_t)n);
     if (rc != LIO_OK) return rc;
     const char* src = reinterpret_cast<const char*>(raw_pts);
-    for (int i = 0; i < n; ++i) {
-        const char* rec = src + (size_t)i * (size_t)stride_bytes;
-        const float* p = reinterpret_cast<const float*>(rec);
-        const float t = n_poses > 0 ? *reinterpret_cast<const float*>(rec + time_offset_bytes) : 0.0f;
-        c->h_stage[i] = make_float4(p[0], p[1], p[2], t);
+    if (n_poses > 0 && stride_bytes == 16 && time_offset_bytes == 12) {
+        std::memcpy(c->h_stage, raw_pts, (size_t)n * sizeof(float4));         // the records already are x, y, z, t
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const char* rec = src + (size_t)i * (size_t)stride_bytes;
+            const float* p = reinterpret_cast<const float*>(rec);
+            const float t = n_poses > 0 ? *reinterpret_cast<const float*>(rec + time_offset_bytes) : 0.0f;
+            c->h_stage[i] = make_float4(p[0], p[1], p[2], t);
+        }
     }
     HIPCHK(c, hipMemcpyAsync(c->d_raw, c->h_stage, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipEventRecord(c->ev_stage, s));
+    c->stage_busy = true;                                                      // waited for by the next writer of h_stage
+    c->raw_time_keyed = n_poses > 0;
     if (n_poses == 0) {
         HIPCHK(c, hipMemcpyAsync(c->d_undist, c->d_raw, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        c->undist_sorted = true;                                               // taken as it is: no sort, no compensation
         return LIO_OK;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_imu_poses, imu_poses, (size_t)n_poses * sizeof(lio_pose6d), hipMemcpyHostToDevice, s));
-    // sort(pcl_out.points.begin(), pcl_out.points.end(), time_list)   (:251; stable here)
-    HIPCHK(c, launch_time_keys(c->d_raw, n, c->d_raw_keys, c->d_raw_order, s));
-    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s));
-    HIPCHK(c, launch_gather_points(c->d_raw, c->d_raw_order2, (uint32_t)n, c->d_leafpts, s));
+    // The compensation of a point depends on nothing but the point: it runs in input order.  The order
+    // sort(pcl_out.points.begin(), pcl_out.points.end(), time_list) (:251) establishes is produced where it is
+    // consumed -- as the minor key of the voxel filter's sort, or on demand by lio_scan_get_cloud (stable: ties keep
+    // the input order).
     Pose14 end;
     for (int i = 0; i < 14; ++i) end.v[i] = end_state14[i];
-    HIPCHK(c, launch_undistort(c->d_leafpts, n, c->d_imu_poses, n_poses, end, c->d_undist, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, launch_undistort(c->d_raw, n, c->d_imu_poses, n_poses, end, c->d_undist, s));
+    c->undist_sorted = false;
+    return LIO_OK;
+}
+
+// feats_undistort in time order (on demand: the voxel filter does not need it)
+static int sort_undistorted_by_time(lio_ctx* c) {
+    if (c->undist_sorted || c->n_raw == 0) { c->undist_sorted = true; return LIO_OK; }
+    hipStream_t s = c->stream;
+    const int n = c->n_raw;
+    HIPCHK(c, launch_time_keys(c->d_undist, n, c->d_raw_keys, c->d_raw_order, s));
+    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s));
+    HIPCHK(c, launch_gather_points(c->d_undist, c->d_raw_order2, (uint32_t)n, c->d_leafpts, s));
+    float4* t = c->d_undist; c->d_undist = c->d_leafpts; c->d_leafpts = t;
+    c->undist_sorted = true;
     return LIO_OK;
 }
 
@@ -1191,39 +1221,31 @@ int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
     hipStream_t s = c->stream;
     const int n = c->n_raw;
     if (n == 0) return scan_reset(c, 0);
-    // getMinMax3D
-    const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-    int mm[6];
-    HIPCHK(c, hipMemcpyAsync(c->d_minmax, init, sizeof(init), hipMemcpyHostToDevice, s));
-    HIPCHK(c, launch_minmax(c->d_undist, n, c->d_minmax, s));
-    HIPCHK(c, hipMemcpyAsync(mm, c->d_minmax, sizeof(mm), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (mm[0] == 0x7fffffff) return scan_reset(c, 0);                 // no finite point
-    VoxelGridParams g{};
-    g.inv_leaf = 1.0f / leaf_size;                                    // inverse_leaf_size_ = 1 / leaf_size_
-    long long div[3];
-    for (int a = 0; a < 3; ++a) {
-        const float lo = minmax_decode(mm[a]), hi = minmax_decode(mm[3 + a]);
-        g.min_b[a] = (int)std::floor(lo * g.inv_leaf);
-        const int max_b = (int)std::floor(hi * g.inv_leaf);
-        div[a] = (long long)max_b - g.min_b[a] + 1;
-    }
-    if (div[0] * div[1] * div[2] > (long long)0x7fffffff)
-        return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "leaf size too small for the extent of the scan (index overflow, as in PCL)");
-    g.divb_mul[0] = 1; g.divb_mul[1] = (int)div[0]; g.divb_mul[2] = (int)(div[0] * div[1]);
-    HIPCHK(c, launch_voxel_index(c->d_undist, n, g, c->d_raw_keys, c->d_raw_order, s));
+    // One pass over the stream, one read-back at the end: getMinMax3D, min_b_/divb_mul_, the leaf index of every
+    // point, a stable sort by leaf, the run heads and the centroids all stay on the device (VoxelGridDev).
+    int rc = ensure_scratch(c, 64);
+    if (rc != LIO_OK) return rc;
+    VoxelGridDev* vox = c->d_vox;
+    HIPCHK(c, hipMemsetAsync(vox, 0, sizeof(VoxelGridDev), s));
+    HIPCHK(c, launch_minmax(c->d_undist, n, vox, s));
+    HIPCHK(c, launch_voxel_params(vox, 1.0f / leaf_size, s));           // inverse_leaf_size_ = 1 / leaf_size_
+    HIPCHK(c, launch_voxel_index(c->d_undist, n, vox, c->raw_time_keyed && !c->undist_sorted, c->d_raw_keys, c->d_raw_order, s));
     HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s));
-    HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_raw_keys2, (size_t)n, c->d_leaf_keys, c->d_leaf_count, c->d_counters + 4, s));
-    uint32_t n_leaves = 0;
-    uint64_t last_key = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_leaves, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(&last_key, c->d_raw_keys2 + (n - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, select_run_heads_u64(c->d_temp, c->temp_bytes, c->d_raw_keys2, (size_t)n, c->d_leaf_start, &vox->n_leaves, s));
+    const uint32_t max_leaves = (uint32_t)n < (uint32_t)c->cap_q + 1u ? (uint32_t)n : (uint32_t)c->cap_q + 1u;
+    HIPCHK(c, launch_centroids(c->d_undist, c->d_raw_order2, c->d_raw_keys2, c->d_leaf_start, vox, (uint32_t)n, max_leaves,
+                               (uint32_t)c->cap_q, c->d_body, s));
+    uint32_t* summary = reinterpret_cast<uint32_t*>(c->h_scratch);
+    HIPCHK(c, hipMemcpyAsync(summary, vox->summary, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_leaf_count, c->d_leaf_start, n_leaves, s));
-    const uint32_t n_real = last_key == ~0ull ? n_leaves - 1 : n_leaves;     // the run of dropped (non-finite) points is last
-    if ((int)n_real > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "down-sampled scan exceeds max_scan_points");
-    HIPCHK(c, launch_centroids(c->d_undist, c->d_raw_order2, c->d_leaf_keys, c->d_leaf_start, c->d_leaf_count, n_leaves, c->d_leafpts, s));
-    if (n_real > 0) HIPCHK(c, hipMemcpyAsync(c->d_body, c->d_leafpts, (size_t)n_real * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    if (summary[2] & VOX_OVERFLOW)
+        return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "leaf size too small for the extent of the scan (index overflow, as in PCL)");
+    if (summary[2] & VOX_EMPTY) return scan_reset(c, 0);                // no finite point
+    const uint32_t n_real = summary[0] - summary[1];                     // the run of dropped (non-finite) points is last
+    if ((int)n_real > c->cap_q) {
+        c->have_scan = false;                                            // the scan buffer holds a truncated result
+        return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "down-sampled scan exceeds max_scan_points");
+    }
     if (n_out) *n_out = (int)n_real;
     return scan_reset(c, (int)n_real);
 }
@@ -1231,6 +1253,11 @@ int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
 // which = 0: feats_undistort (time-sorted, compensated); 1: the current scan (feats_down_body)
 int lio_scan_get_cloud(lio_ctx* c, int which, float* out_xyz, int cap, int* n) {
     if (!c || (which != 0 && which != 1) || cap < 0 || (cap > 0 && !out_xyz)) return LIO_ERR_INVALID_ARG;
+    if (which == 0 && c->have_raw) {
+        HIPCHK(c, hipSetDevice(c->device));
+        const int rc0 = sort_undistorted_by_time(c);
+        if (rc0 != LIO_OK) return rc0;
+    }
     const float4* src = which == 0 ? c->d_undist : c->d_body;
     const int cnt = which == 0 ? (c->have_raw ? c->n_raw : 0) : (c->have_scan ? c->nq : 0);
     if (n) *n = cnt;

@@ -118,6 +118,8 @@ hipError_t select_live_points(void* temp, size_t temp_bytes, const float4* src, 
                               uint32_t* n_out, size_t n, hipStream_t s);
 hipError_t select_box_deleted_points(void* temp, size_t temp_bytes, const float4* src, float4* dst, uint32_t* n_out,
                                      size_t n, hipStream_t s);
+hipError_t select_run_heads_u64(void* temp, size_t temp_bytes, const uint64_t* sorted_keys, size_t n, uint32_t* starts_out,
+                                uint32_t* n_runs_out, hipStream_t s);
 
 hipError_t coarsen_level(void* temp, size_t temp_bytes, const uint64_t* keys_in, const uint32_t* counts_in, size_t n,
                          uint64_t* keys_out, uint32_t* counts_out, uint32_t* n_out, hipStream_t s);

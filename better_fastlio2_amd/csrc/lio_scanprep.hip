@@ -81,6 +81,7 @@ __device__ __forceinline__ int float_ordered(float f) {                // monoto
     const int i = __float_as_int(f);
     return i >= 0 ? i : i ^ 0x7fffffff;
 }
+__device__ __forceinline__ uint32_t float_ordered_u(float f) { return (uint32_t)float_ordered(f) ^ 0x80000000u; }
 __host__ __device__ inline float ordered_float(int i) {
     const int j = i >= 0 ? i : i ^ 0x7fffffff;
     union { int i; float f; } u;
@@ -92,38 +93,67 @@ __host__ __device__ inline float ordered_float(int i) {
 __global__ __launch_bounds__(256) void time_keys_kernel(const float4* pts, int n, uint64_t* keys, uint32_t* order) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    keys[i] = (uint64_t)((uint32_t)float_ordered(pts[i].w) ^ 0x80000000u);
+    keys[i] = (uint64_t)float_ordered_u(pts[i].w);
     order[i] = (uint32_t)i;
 }
 
-// getMinMax3D: six atomics per wavefront on order-preserving integer images of the floats
-__global__ __launch_bounds__(256) void minmax_kernel(const float4* pts, int n, int* mm /* min xyz, max xyz */) {
-    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+// getMinMax3D: per-workgroup reduction in LDS, then six atomics per workgroup on unsigned order-preserving images
+// (min as the maximum of the complement, so that a zeroed record is the neutral element of all six)
+__global__ __launch_bounds__(256) void minmax_kernel(const float4* pts, int n, VoxelGridDev* vox) {
+    __shared__ uint32_t s_mm[4][6];
+    uint32_t m[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = pts[i];
         if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) continue;
-        const int v[3] = {float_ordered(p.x), float_ordered(p.y), float_ordered(p.z)};
+        const uint32_t v[3] = {float_ordered_u(p.x), float_ordered_u(p.y), float_ordered_u(p.z)};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], v[a]); hi[a] = max(hi[a], v[a]); }
+        for (int a = 0; a < 3; ++a) { m[a] = max(m[a], ~v[a]); m[3 + a] = max(m[3 + a], v[a]); }
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
+    for (int a = 0; a < 6; ++a) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo[a] = min(lo[a], __shfl_xor(lo[a], o, 64));
-            hi[a] = max(hi[a], __shfl_xor(hi[a], o, 64));
-        }
+        for (int o = 32; o > 0; o >>= 1) m[a] = max(m[a], (uint32_t)__shfl_xor((int)m[a], o, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { atomicMin(mm + a, lo[a]); atomicMax(mm + 3 + a, hi[a]); }
+        for (int a = 0; a < 6; ++a) s_mm[wave][a] = m[a];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const uint32_t v = max(max(s_mm[0][threadIdx.x], s_mm[1][threadIdx.x]), max(s_mm[2][threadIdx.x], s_mm[3][threadIdx.x]));
+        if (v != 0u) atomicMax(&vox->mm[threadIdx.x], v);
     }
 }
 
-__global__ __launch_bounds__(256) void voxel_index_kernel(const float4* pts, int n, VoxelGridParams g, uint64_t* keys,
-                                                          uint32_t* order) {
+// min_b_, div_b_, divb_mul_ from the bounding box (voxel_grid.hpp, first pass), on the device
+__global__ void voxel_params_kernel(VoxelGridDev* vox, float inv_leaf) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    VoxelGridParams g;
+    g.inv_leaf = inv_leaf;
+    uint32_t flags = 0u;
+    if (vox->mm[0] == 0u) flags |= VOX_EMPTY;                           // no finite point
+    long long div[3] = {1, 1, 1};
+    for (int a = 0; a < 3; ++a) {
+        const float lo = ordered_float((int)((~vox->mm[a]) ^ 0x80000000u)), hi = ordered_float((int)(vox->mm[3 + a] ^ 0x80000000u));
+        g.min_b[a] = (int)floorf(lo * inv_leaf);
+        const int max_b = (int)floorf(hi * inv_leaf);
+        div[a] = (long long)max_b - g.min_b[a] + 1;
+    }
+    if (!(flags & VOX_EMPTY) && div[0] * div[1] * div[2] > (long long)0x7fffffff) flags |= VOX_OVERFLOW;
+    g.divb_mul[0] = 1; g.divb_mul[1] = (int)div[0]; g.divb_mul[2] = (int)(div[0] * div[1]);
+    vox->g = g;
+    vox->flags = flags;
+}
+
+// key = leaf index (major) | time offset (minor, when the cloud is not in time order yet): one stable sort yields the
+// leaves in ascending order with their points in time order, ties in input order -- what the stable sort by leaf of
+// a time-sorted cloud yields
+__global__ __launch_bounds__(256) void voxel_index_kernel(const float4* pts, int n, const VoxelGridDev* vox, bool time_minor,
+                                                          uint64_t* keys, uint32_t* order) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const VoxelGridParams g = vox->g;
     const float4 p = pts[i];
     uint64_t key = ~0ull;                                               // non-finite points sort last and are dropped
     if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
@@ -132,27 +162,44 @@ __global__ __launch_bounds__(256) void voxel_index_kernel(const float4* pts, int
         const int i1 = (int)(floorf(p.y * g.inv_leaf) - (float)g.min_b[1]);
         const int i2 = (int)(floorf(p.z * g.inv_leaf) - (float)g.min_b[2]);
         const int idx = i0 * g.divb_mul[0] + i1 * g.divb_mul[1] + i2 * g.divb_mul[2];
-        key = (uint64_t)(uint32_t)idx;
+        key = ((uint64_t)(uint32_t)idx << 32) | (time_minor ? (uint64_t)float_ordered_u(p.w) : 0ull);
     }
     keys[i] = key;
     order[i] = (uint32_t)i;
 }
 
-// one lane per leaf: fp32 sums in sorted (stable = time) order, divided by the count (CentroidPoint)
-__global__ __launch_bounds__(256) void centroid_kernel(const float4* pts, const uint32_t* order, const uint64_t* leaf_key,
-                                                       const uint32_t* leaf_start, const uint32_t* leaf_count, uint32_t n_leaves,
+// Sixteen lanes per leaf: the points of the leaf are fetched sixteen at a time (the two dependent loads of every
+// point -- order, then the point -- are what a single lane would wait for, one after the other), then added in
+// sorted (stable = time) order, one at a time, exactly like CentroidPoint: fp32 sums, divided by the count.
+__global__ __launch_bounds__(256) void centroid_kernel(const float4* pts, const uint32_t* order, const uint64_t* sorted_keys,
+                                                       const uint32_t* leaf_start, VoxelGridDev* vox, uint32_t n, uint32_t cap_out,
                                                        float4* out) {
-    const uint32_t l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= n_leaves) return;
-    if (leaf_key[l] == ~0ull) return;                                   // the run of dropped points (always last)
-    const uint32_t st = leaf_start[l], ct = leaf_count[l];
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    for (uint32_t j = 0; j < ct; ++j) {
-        const float4 p = pts[order[st + j]];
-        sx += p.x; sy += p.y; sz += p.z;
+    const uint32_t l = (blockIdx.x * 256 + threadIdx.x) >> 4, r = threadIdx.x & 15;
+    const uint32_t n_leaves = vox->n_leaves;
+    const uint32_t flags = vox->flags;
+    if (l == 0 && r == 0) {
+        vox->summary[0] = n_leaves;
+        vox->summary[1] = (n_leaves > 0 && (sorted_keys[n - 1] >> 32) == 0xffffffffull) ? 1u : 0u;
+        vox->summary[2] = flags;
+        vox->summary[3] = 0u;
     }
-    const float fn = (float)ct;
-    out[l] = make_float4(sx / fn, sy / fn, sz / fn, 0.0f);
+    if (flags != 0u || l >= n_leaves) return;
+    const uint32_t st = leaf_start[l], en = l + 1 < n_leaves ? leaf_start[l + 1] : n;
+    if ((sorted_keys[st] >> 32) == 0xffffffffull) return;               // the run of dropped points (always last)
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    for (uint32_t j0 = st; j0 < en; j0 += 16) {
+        const uint32_t j = j0 + r;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < en) p = pts[order[j]];
+        const int cnt = (int)min(16u, en - j0);
+        for (int k = 0; k < cnt; ++k) {
+            sx += __shfl(p.x, k, 16);
+            sy += __shfl(p.y, k, 16);
+            sz += __shfl(p.z, k, 16);
+        }
+    }
+    const float fn = (float)(en - st);
+    if (r == 0 && l < cap_out) out[l] = make_float4(sx / fn, sy / fn, sz / fn, 0.0f);
 }
 
 hipError_t launch_time_keys(const float4* pts, int n, uint64_t* keys, uint32_t* order, hipStream_t s) {
@@ -166,25 +213,29 @@ hipError_t launch_undistort(const float4* raw, int n, const double* poses, int n
     hipLaunchKernelGGL(undistort_kernel, dim3((n + 255) / 256), dim3(256), 0, s, raw, n, poses, n_poses, end, out);
     return hipGetLastError();
 }
-hipError_t launch_minmax(const float4* pts, int n, int* mm6, hipStream_t s) {
+hipError_t launch_minmax(const float4* pts, int n, VoxelGridDev* vox, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     int b = (n + 255) / 256;
-    if (b > 1024) b = 1024;
-    hipLaunchKernelGGL(minmax_kernel, dim3(b), dim3(256), 0, s, pts, n, mm6);
+    if (b > 64) b = 64;                        // six atomics per workgroup on one cache line: keep them few
+    hipLaunchKernelGGL(minmax_kernel, dim3(b), dim3(256), 0, s, pts, n, vox);
     return hipGetLastError();
 }
-hipError_t launch_voxel_index(const float4* pts, int n, const VoxelGridParams& g, uint64_t* keys, uint32_t* order, hipStream_t s) {
+hipError_t launch_voxel_params(VoxelGridDev* vox, float inv_leaf, hipStream_t s) {
+    hipLaunchKernelGGL(voxel_params_kernel, dim3(1), dim3(64), 0, s, vox, inv_leaf);
+    return hipGetLastError();
+}
+hipError_t launch_voxel_index(const float4* pts, int n, const VoxelGridDev* vox, bool time_minor, uint64_t* keys, uint32_t* order,
+                              hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(voxel_index_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, g, keys, order);
+    hipLaunchKernelGGL(voxel_index_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, vox, time_minor, keys, order);
     return hipGetLastError();
 }
-hipError_t launch_centroids(const float4* pts, const uint32_t* order, const uint64_t* leaf_key, const uint32_t* leaf_start,
-                            const uint32_t* leaf_count, uint32_t n_leaves, float4* out, hipStream_t s) {
-    if (n_leaves == 0) return hipSuccess;
-    hipLaunchKernelGGL(centroid_kernel, dim3((n_leaves + 255) / 256), dim3(256), 0, s, pts, order, leaf_key, leaf_start,
-                       leaf_count, n_leaves, out);
+hipError_t launch_centroids(const float4* pts, const uint32_t* order, const uint64_t* sorted_keys, const uint32_t* leaf_start,
+                            VoxelGridDev* vox, uint32_t n, uint32_t max_leaves, uint32_t cap_out, float4* out, hipStream_t s) {
+    if (n == 0 || max_leaves == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)(((size_t)max_leaves * 16 + 255) / 256);
+    hipLaunchKernelGGL(centroid_kernel, dim3(blocks), dim3(256), 0, s, pts, order, sorted_keys, leaf_start, vox, n, cap_out, out);
     return hipGetLastError();
 }
-float minmax_decode(int ordered) { return ordered_float(ordered); }
 
 }  // namespace lio

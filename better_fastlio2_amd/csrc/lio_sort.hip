@@ -139,6 +139,21 @@ hipError_t merge_pairs_identity(void* temp, size_t temp_bytes, const uint64_t* k
     return rocprim::merge(temp, temp_bytes, k1, k2, kout, v1, v2, vout, n1, n2, rocprim::less<uint64_t>(), s);
 }
 
+// first positions of the runs of equal MAJOR keys (high 32 bits) in a sorted key array, and their number
+struct RunHead {
+    const uint64_t* keys;
+    __host__ __device__ bool operator()(uint32_t i) const { return i == 0u || (keys[i] >> 32) != (keys[i - 1] >> 32); }
+};
+hipError_t select_run_heads_u64(void* temp, size_t temp_bytes, const uint64_t* sorted_keys, size_t n, uint32_t* starts_out,
+                                uint32_t* n_runs_out, hipStream_t s) {
+    rocprim::counting_iterator<uint32_t> idx(0u);
+    size_t need = 0;
+    hipError_t e = rocprim::select(nullptr, need, idx, starts_out, n_runs_out, n, RunHead{sorted_keys}, s);
+    if (e != hipSuccess) return e;
+    if (need > temp_bytes) return hipErrorOutOfMemory;
+    return rocprim::select(temp, temp_bytes, idx, starts_out, n_runs_out, n, RunHead{sorted_keys}, s);
+}
+
 struct ClassIs {
     uint8_t want;
     __host__ __device__ bool operator()(uint8_t c) const { return c == want; }
