@@ -95,7 +95,8 @@ struct lio_ctx {
     hipEvent_t ev_stage = nullptr;             // recorded behind an asynchronous copy out of h_stage
     bool stage_busy = false;
     bool undist_sorted = true;                 // d_undist is in time order (else: input order, sorted on demand)
-    bool raw_time_keyed = false;               // the raw scan came with per-point times and IMU poses
+    bool raw_time_keyed = false;               // the raw scan came with per-point times
+    bool raw_uploaded = false;                 // lio_scan_upload_raw ran (lio_scan_compensate may follow)
     size_t h_stage_cap = 0;
     void* d_scratch = nullptr;                 // download staging (device side)
     size_t d_scratch_bytes = 0;
@@ -171,6 +172,7 @@ int auto_lanes(int nq) {
     return 32;
 }
 
+constexpr size_t POSE_STAGE_SLOTS = 512 * sizeof(lio_pose6d) / sizeof(float4);   // room for IMUpose behind the points
 int ensure_stage(lio_ctx* c, size_t n) {
     if (c->stage_busy) {                       // an upload that did not wait for its own copy (lio_scan_undistort)
         HIPCHK(c, hipEventSynchronize(c->ev_stage));
@@ -1151,41 +1153,64 @@ static int ensure_raw_buffers(lio_ctx* c, size_t n) {
 // ImuProcess::UndistortPcl, point side (src/IMU_Processing.hpp:250-251, 334-386): sort the raw scan by its
 // per-point time offset, then compensate every point to the scan-end LiDAR frame from the forward-propagated
 // IMU poses (IMUpose, :258/:322) and the propagated end state.  n_poses == 0: upload only (no sort, no motion).
-int lio_scan_undistort(lio_ctx* c, const float* raw_pts, int n, int stride_bytes, int time_offset_bytes,
-                       const lio_pose6d* imu_poses, int n_poses, const double end_state14[14]) {
-    if (!c || n < 0 || (n > 0 && !raw_pts) || stride_bytes < 12 || n_poses < 0 || n_poses > 512 ||
-        (n_poses > 0 && (!imu_poses || !end_state14 || time_offset_bytes < 12 || time_offset_bytes + 4 > stride_bytes)))
+// The two halves of it, so that a caller can put host work (the IMU forward propagation) between them while the
+// copy is in flight.  First half: the raw records -> pinned staging -> device (asynchronous).
+// time_offset_bytes < 0: the scan carries no per-point time (w = 0).
+int lio_scan_upload_raw(lio_ctx* c, const float* raw_pts, int n, int stride_bytes, int time_offset_bytes) {
+    if (!c || n < 0 || (n > 0 && !raw_pts) || stride_bytes < 12 ||
+        (time_offset_bytes >= 0 && (time_offset_bytes < 12 || time_offset_bytes + 4 > stride_bytes)))
         return LIO_ERR_INVALID_ARG;
     if ((size_t)n > c->temp_bytes / 16) return c->fail(LIO_ERR_CAPACITY, "lio_scan_undistort", "raw scan larger than the sort workspace");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     int rc = ensure_raw_buffers(c, (size_t)(n > 0 ? n : 1));
     if (rc != LIO_OK) return rc;
-    c->n_raw = n; c->have_raw = true;
+    c->n_raw = n; c->have_raw = false; c->raw_uploaded = true;
+    c->raw_time_keyed = time_offset_bytes >= 0;
     if (n == 0) return LIO_OK;
-    rc = ensure_stage(c, (size_t)n);
+    rc = ensure_stage(c, (size_t)n + POSE_STAGE_SLOTS);                        // the IMU poses travel behind the points
     if (rc != LIO_OK) return rc;
     const char* src = reinterpret_cast<const char*>(raw_pts);
-    if (n_poses > 0 && stride_bytes == 16 && time_offset_bytes == 12) {
+    if (time_offset_bytes == 12 && stride_bytes == 16) {
         std::memcpy(c->h_stage, raw_pts, (size_t)n * sizeof(float4));         // the records already are x, y, z, t
     } else {
         for (int i = 0; i < n; ++i) {
             const char* rec = src + (size_t)i * (size_t)stride_bytes;
             const float* p = reinterpret_cast<const float*>(rec);
-            const float t = n_poses > 0 ? *reinterpret_cast<const float*>(rec + time_offset_bytes) : 0.0f;
+            const float t = time_offset_bytes >= 0 ? *reinterpret_cast<const float*>(rec + time_offset_bytes) : 0.0f;
             c->h_stage[i] = make_float4(p[0], p[1], p[2], t);
         }
     }
     HIPCHK(c, hipMemcpyAsync(c->d_raw, c->h_stage, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipEventRecord(c->ev_stage, s));
     c->stage_busy = true;                                                      // waited for by the next writer of h_stage
-    c->raw_time_keyed = n_poses > 0;
+    return LIO_OK;
+}
+
+// Second half: compensation of the uploaded scan from the forward-propagated poses.  n_poses == 0: the cloud is
+// taken as it is.
+int lio_scan_compensate(lio_ctx* c, const lio_pose6d* imu_poses, int n_poses, const double end_state14[14]) {
+    if (!c || n_poses < 0 || n_poses > 512 || (n_poses > 0 && (!imu_poses || !end_state14))) return LIO_ERR_INVALID_ARG;
+    if (!c->raw_uploaded) return c->fail(LIO_ERR_NO_SCAN, "lio_scan_compensate", "no raw scan uploaded");
+    if (n_poses > 0 && !c->raw_time_keyed) return LIO_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int n = c->n_raw;
+    c->have_raw = true;
+    if (n == 0) return LIO_OK;
     if (n_poses == 0) {
         HIPCHK(c, hipMemcpyAsync(c->d_undist, c->d_raw, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, s));
-        c->undist_sorted = true;                                               // taken as it is: no sort, no compensation
+        c->undist_sorted = true;                                               // no sort, no compensation
+        c->raw_time_keyed = false;
         return LIO_OK;
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_imu_poses, imu_poses, (size_t)n_poses * sizeof(lio_pose6d), hipMemcpyHostToDevice, s));
+    // the poses go through the tail of the pinned staging buffer (bytes the point copy does not read)
+    static_assert(sizeof(lio_pose6d) == 22 * sizeof(double), "Pose6D layout");
+    lio_pose6d* h_poses = reinterpret_cast<lio_pose6d*>(c->h_stage + (c->h_stage_cap - POSE_STAGE_SLOTS));
+    std::memcpy(h_poses, imu_poses, (size_t)n_poses * sizeof(lio_pose6d));
+    HIPCHK(c, hipMemcpyAsync(c->d_imu_poses, h_poses, (size_t)n_poses * sizeof(lio_pose6d), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipEventRecord(c->ev_stage, s));
+    c->stage_busy = true;
     // The compensation of a point depends on nothing but the point: it runs in input order.  The order
     // sort(pcl_out.points.begin(), pcl_out.points.end(), time_list) (:251) establishes is produced where it is
     // consumed -- as the minor key of the voxel filter's sort, or on demand by lio_scan_get_cloud (stable: ties keep
@@ -1195,6 +1220,16 @@ int lio_scan_undistort(lio_ctx* c, const float* raw_pts, int n, int stride_bytes
     HIPCHK(c, launch_undistort(c->d_raw, n, c->d_imu_poses, n_poses, end, c->d_undist, s));
     c->undist_sorted = false;
     return LIO_OK;
+}
+
+int lio_scan_undistort(lio_ctx* c, const float* raw_pts, int n, int stride_bytes, int time_offset_bytes,
+                       const lio_pose6d* imu_poses, int n_poses, const double end_state14[14]) {
+    if (!c || n_poses < 0 || n_poses > 512 ||
+        (n_poses > 0 && (!imu_poses || !end_state14 || time_offset_bytes < 12 || time_offset_bytes + 4 > stride_bytes)))
+        return LIO_ERR_INVALID_ARG;
+    const int rc = lio_scan_upload_raw(c, raw_pts, n, stride_bytes, n_poses > 0 ? time_offset_bytes : -1);
+    if (rc != LIO_OK) return rc;
+    return lio_scan_compensate(c, imu_poses, n_poses, end_state14);
 }
 
 // feats_undistort in time order (on demand: the voxel filter does not need it)

@@ -100,6 +100,11 @@ void ImuProcess::IMU_init(const MeasureGroup& meas, esekf& kf_state, int& N) {
 
 // Forward propagation through the IMU samples of the scan (:237-332), then the point compensation on the GPU.
 int ImuProcess::UndistortPcl(const MeasureGroup& meas, esekf& kf_state, lio_ctx* ctx) {
+    // the raw scan starts its way to the GPU now; the forward propagation below runs while it travels
+    if (ctx) {
+        const int rc = lio_scan_upload_raw(ctx, meas.lidar, meas.n_points, meas.stride_bytes, meas.time_offset_bytes);
+        if (rc != LIO_OK) return rc;
+    }
     std::vector<ImuSample> v_imu;                            // :240-241
     v_imu.reserve(meas.imu.size() + 1);
     v_imu.push_back(last_imu_);
@@ -158,8 +163,7 @@ int ImuProcess::UndistortPcl(const MeasureGroup& meas, esekf& kf_state, lio_ctx*
     if (!ctx) return LIO_OK;
     double end14[14];                                        // :334-386 on the device
     imu_state.pose14(end14);
-    return lio_scan_undistort(ctx, meas.lidar, meas.n_points, meas.stride_bytes, meas.time_offset_bytes,
-                              IMUpose.data(), (int)IMUpose.size(), end14);
+    return lio_scan_compensate(ctx, IMUpose.data(), (int)IMUpose.size(), end14);
 }
 
 int ImuProcess::Process(const MeasureGroup& meas, esekf& kf_state, lio_ctx* ctx, int* undistorted) {   // :392-441

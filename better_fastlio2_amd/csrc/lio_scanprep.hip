@@ -187,10 +187,12 @@ __global__ __launch_bounds__(256) void centroid_kernel(const float4* pts, const 
     const uint32_t st = leaf_start[l], en = l + 1 < n_leaves ? leaf_start[l + 1] : n;
     if ((sorted_keys[st] >> 32) == 0xffffffffull) return;               // the run of dropped points (always last)
     float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (st + r < en) nxt = pts[order[st + r]];
     for (uint32_t j0 = st; j0 < en; j0 += 16) {
-        const uint32_t j = j0 + r;
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < en) p = pts[order[j]];
+        const float4 p = nxt;
+        const uint32_t jn = j0 + 16 + r;                                // the next sixteen are in flight while these are added
+        if (jn < en) nxt = pts[order[jn]];
         const int cnt = (int)min(16u, en - j0);
         for (int k = 0; k < cnt; ++k) {
             sx += __shfl(p.x, k, 16);

@@ -170,9 +170,16 @@ typedef struct lio_pose6d {
  * (the per-point offset in MILLISECONDS is the float at time_offset_bytes inside each record -- `curvature`
  * of pcl::PointXYZINormal, byte 36) and compensates every point to the scan-end LiDAR frame from the IMU
  * poses and the propagated end state (pos, rot, offset_R_L_I, offset_T_L_I as in state14).  The result
- * (feats_undistort) stays in device memory.  n_poses == 0: upload only, no sort, no compensation.          */
+ * (feats_undistort) stays in device memory; the call returns when the work is enqueued (the time order is
+ * materialised where it is consumed: by the voxel filter's sort, or by lio_scan_get_cloud).  n_poses == 0:
+ * upload only, no sort, no compensation.                                                                   */
 int  lio_scan_undistort(lio_ctx* ctx, const float* raw_pts, int n, int stride_bytes, int time_offset_bytes,
                         const lio_pose6d* imu_poses, int n_poses, const double end_state14[14]);
+/* The two halves of lio_scan_undistort for callers that have host work to do while the copy is in flight
+ * (lio_imu_process runs the IMU forward propagation between them): upload of the raw records (asynchronous;
+ * time_offset_bytes < 0: no per-point time), then the compensation from the propagated poses.               */
+int  lio_scan_upload_raw(lio_ctx* ctx, const float* raw_pts, int n, int stride_bytes, int time_offset_bytes);
+int  lio_scan_compensate(lio_ctx* ctx, const lio_pose6d* imu_poses, int n_poses, const double end_state14[14]);
 /* pcl::VoxelGrid (downSizeFilterSurf, src/laserMapping.cpp:2135, 2322-2323) on feats_undistort: centroid
  * of every occupied leaf, ascending leaf index; the result becomes the current scan (feats_down_body),
  * exactly as if it had been passed to lio_scan_set.  *n_out = feats_down_size.                             */
