@@ -28,7 +28,8 @@ def run_case(seed):
     nq = int(rng.choice([3000, 8000, 12000]))
     lanes = int(rng.choice([0, 0, 0, 4, 8, 16, 32, 64]))
     ext = bool(rng.integers(0, 2))
-    ctx = capi.LioContext(ds, max_scan_points=nq, max_map_points=600_000, lanes_per_query=lanes)
+    cell = float(rng.choice([0.0, 0.0, 0.0, 0.25, 0.5, 1.0, 2.0]))              # 0 = auto (0.5 m for the 0.2 m voxel)
+    ctx = capi.LioContext(ds, max_scan_points=nq, max_map_points=600_000, lanes_per_query=lanes, cell_size=cell)
     ctx.map_build(base)
     ref = po.RefIkdTree(ds); ref.build(base); po.use_reference_knn(ref)
     om = po.OracleMap(ds)                                        # only carries parameters: k-NN goes to the reference tree

@@ -35,7 +35,10 @@ def run_case(seed):
     if seed % 5 == 0:
         centre = centre + [2000.0, 1500.0, 30.0]              # one octant, small tree root
     base = surface(rng, int(rng.integers(5_000, 60_000)), centre, float(rng.uniform(5, 40)))
-    ctx = capi.LioContext(ds, max_scan_points=4096, max_map_points=600_000)
+    cells = [c for c in (0.125, 0.25, 0.5, 1.0, 2.0, 4.0) if c >= ds]          # power of two, not below the voxel
+    cell = float(rng.choice([0.0, 0.0] + cells))                               # 0 = auto
+    ctx = capi.LioContext(ds, max_scan_points=4096, max_map_points=600_000, cell_size=cell,
+                          lanes_per_query=int(rng.choice([0, 0, 4, 8, 16, 32, 64])))
     ref = po.RefIkdTree(ds)
     ctx.map_build(base); ref.build(base)
     removed_g, removed_r = 0, 0

@@ -67,8 +67,11 @@ def run_case(seed):
     conj = lambda q: np.array([-q[0], -q[1], -q[2], q[3]])
     body = rotate(conj(offR), rotate(conj(rot), wsel - pos) - offT).astype(np.float32)
     ext = bool(rng.integers(0, 2))
+    lanes = int(rng.choice([0, 0, 4, 8, 16, 32, 64]))
+    cells = [c for c in (0.125, 0.25, 0.5, 1.0, 2.0, 4.0) if c >= ds]          # power of two, not below the voxel
+    cell = float(rng.choice([0.0, 0.0] + cells))                               # 0 = auto
     ctx = capi.LioContext(ds, max_scan_points=max(nq, 16), max_map_points=len(world) + 1000,
-                          lanes_per_query=int(rng.choice([0, 0, 4, 8, 16, 32, 64])))
+                          lanes_per_query=lanes, cell_size=cell)
     ctx.map_build(world); ctx.scan_set(body)
     om = po.OracleMap(ds); om.build(world)
     ref = po.RefIkdTree(ds); ref.build(world); po.use_reference_knn(ref)
