@@ -264,6 +264,24 @@ def test_node_loop_fuzz_seeds(gpu_capi, oracle):
         fz.run_case(seed)
 
 
+def test_scan_preparation_fuzz_seeds(gpu_capi, oracle):
+    """Forty cases of scripts/fuzz_scanprep.py: raw clouds from 1 to 60 k points with time ties, clumps (leaves with
+    hundreds of points), non-finite points, pose lists of 2..25 entries, leaf sizes from 0.1 to 3 m, the cloud read
+    before or after the filter -- compensation vs the restatement, voxel grid bit-exact, PCL's overflow refusal."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_scanprep.py")
+    spec = importlib.util.spec_from_file_location("fuzz_scanprep", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=fz.ctx_cap, max_map_points=100_000)
+    seen = set()
+    for seed in range(30000, 30040):
+        seen.add(fz.run_case(seed, ctx))
+    assert "ok" in seen
+    ctx.close()
+
+
 def test_map_mutation_parity(gpu_capi, oracle, small_case):
     """Add_Points (down-sampled: one point per voxel, nearest the centre; plain), Delete_Point_Boxes,
     validnum/size/flatten: same return values and live set as the oracle, k-NN parity afterwards."""
