@@ -93,6 +93,7 @@ struct lio_ctx {
     // ---- staging / scratch --------------------------------------------------------------------
     float4* h_stage = nullptr;                 // pinned upload staging
     hipEvent_t ev_stage = nullptr;             // recorded behind an asynchronous copy out of h_stage
+    void* h_small = nullptr;                   // 256 pinned bytes: landing zone of the small counter read-backs
     bool stage_busy = false;
     bool undist_sorted = true;                 // d_undist is in time order (else: input order, sorted on demand)
     bool raw_time_keyed = false;               // the raw scan came with per-point times
@@ -172,6 +173,16 @@ int auto_lanes(int nq) {
     return 32;
 }
 
+// A few counters from the device: through pinned memory (a copy into pageable memory takes the runtime's slow
+// staged path, ~3x the latency), then the one synchronisation the caller needs anyway.
+static hipError_t read_back(lio_ctx* c, void* host_dst, const void* d_src, size_t bytes) {
+    hipError_t e = hipMemcpyAsync(c->h_small, d_src, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return e;
+    std::memcpy(host_dst, c->h_small, bytes);
+    return hipSuccess;
+}
 constexpr size_t POSE_STAGE_SLOTS = 512 * sizeof(lio_pose6d) / sizeof(float4);   // room for IMUpose behind the points
 int ensure_stage(lio_ctx* c, size_t n) {
     if (c->stage_busy) {                       // an upload that did not wait for its own copy (lio_scan_undistort)
@@ -226,8 +237,7 @@ int finish_index(lio_ctx* c, uint32_t n) {
     HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_mkeys, n, c->d_cell_keys, c->d_cell_counts,
                                     c->d_counters + 4, s));
     uint32_t n_cells = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_cells, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, read_back(c, &n_cells, c->d_counters + 4, sizeof(uint32_t)));
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_cell_counts, c->d_cell_starts, n_cells, s));
     c->n_cells = n_cells; c->n_cells_built = n_cells;
 
@@ -244,8 +254,7 @@ int finish_index(lio_ctx* c, uint32_t n) {
     for (int L = 1; L < TREE_MAX_LEVELS; ++L) {
         HIPCHK(c, coarsen_level(c->d_temp, c->temp_bytes, kin, cin, n_prev, kout, cout, c->d_counters + 4, s));
         uint32_t n_l = 0;
-        HIPCHK(c, hipMemcpyAsync(&n_l, c->d_counters + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, read_back(c, &n_l, c->d_counters + 4, sizeof(uint32_t)));
         if (L >= 2 && n_l <= (uint32_t)TREE_MAX_ROOTS) {
             uint64_t rk[TREE_MAX_ROOTS];
             HIPCHK(c, hipMemcpyAsync(rk, kout, (size_t)n_l * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -345,8 +354,7 @@ int collect_box_deleted(lio_ctx* c) {
     HIPCHK(c, select_box_deleted_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_removed + c->n_removed, c->d_counters + 7, c->n_points, s));
     HIPCHK(c, launch_mark_reported(c->d_pts, c->n_points, s));
     uint32_t got = 0;
-    HIPCHK(c, hipMemcpyAsync(&got, c->d_counters + 7, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, read_back(c, &got, c->d_counters + 7, sizeof(uint32_t)));
     c->n_removed += got;
     c->box_deleted_pending = 0;
     return LIO_OK;
@@ -368,8 +376,7 @@ int rebuild_full(lio_ctx* c) {
     uint32_t live = 0;
     if (n_all > 0) {
         HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_pts_tmp, c->d_counters + 3, n_all, s));
-        HIPCHK(c, hipMemcpyAsync(&live, c->d_counters + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, read_back(c, &live, c->d_counters + 3, sizeof(uint32_t)));
     }
     if ((size_t)live + (size_t)c->n_pend > c->cap_map)
         return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
@@ -404,8 +411,7 @@ int apply_pending(lio_ctx* c) {
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pnewsize, c->d_pnewoff, (size_t)n + 1, s));
     HIPCHK(c, launch_cell_apply(a, n, s));
     uint32_t st[4] = {0, 0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(st, c->d_apply, sizeof(st), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, read_back(c, st, c->d_apply, sizeof(st)));
     const uint32_t total = st[3];
     if (st[2] & APPLY_FLAG_NO_ROOM) return rebuild_full(c);    // nothing was changed: the pending points go in there
     c->n_points += total;
@@ -516,6 +522,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     c->arch = prop.gcnArchName;
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
+    CREATE_CHK(hipHostMalloc(&c->h_small, 256, hipHostMallocDefault));
 
     c->grid.cell = cfg->cell_size != 0.0f ? cfg->cell_size : auto_cell_size(cfg->filter_size_map_min);
     c->grid.inv_cell = 1.0f / c->grid.cell;
@@ -603,6 +610,7 @@ void lio_destroy(lio_ctx* c) {
     for (int w = 0; w < LIO_PROF_COUNT; ++w)
         for (hipEvent_t e : c->ev_pool[w]) (void)hipEventDestroy(e);
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
+    if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -735,8 +743,7 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
         // survivors (w == 0) of both passes -> front of `batch` (the batch itself is no longer needed)
         HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_apply + 6, 2 * (size_t)n, s));
         uint32_t host_cnt[3] = {0, 0, 0};                  // replaced, tmp_counter, survivors
-        HIPCHK(c, hipMemcpyAsync(host_cnt, c->d_apply + 4, sizeof(host_cnt), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, read_back(c, host_cnt, c->d_apply + 4, sizeof(host_cnt)));
         if (n_added) *n_added = (int)host_cnt[1];
         n_append = host_cnt[2];
         c->n_live -= host_cnt[0];                     // points of the map replaced inside their down-sample voxel
@@ -820,8 +827,7 @@ static int map_incremental_lists(lio_ctx* c, const double state14[14], double fi
     HIPCHK(c, launch_map_incremental(ia, s));
     HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 1, c->d_add_pts, c->d_counters + 5, (size_t)nq, s));
     HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 2, c->d_add_pts2, c->d_counters + 6, (size_t)nq, s));
-    HIPCHK(c, hipMemcpyAsync(cnts, c->d_counters + 5, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, read_back(c, cnts, c->d_counters + 5, 2 * sizeof(uint32_t)));
     return LIO_OK;
 }
 
@@ -937,8 +943,7 @@ int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_delete
         HIPCHK(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(uint32_t), c->stream));
         HIPCHK(c, launch_delete_boxes(c->d_pts, c->n_points, c->d_boxes, nbb, c->d_counters + 2, c->stream));
         uint32_t cnt = 0;
-        HIPCHK(c, hipMemcpyAsync(&cnt, c->d_counters + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, read_back(c, &cnt, c->d_counters + 2, sizeof(uint32_t)));
         total += (int)cnt;
     }
     c->n_live -= (uint32_t)total;
@@ -1012,8 +1017,7 @@ int lio_map_flatten(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
     // compact the live points (order-preserving), pack xyz, download
     HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_pts_tmp, c->d_counters + 3, c->n_points, c->stream));
     uint32_t live = 0;
-    HIPCHK(c, hipMemcpyAsync(&live, c->d_counters + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, read_back(c, &live, c->d_counters + 3, sizeof(uint32_t)));
     if (n) *n = (long long)live;
     const size_t m = (size_t)live < (size_t)cap ? (size_t)live : (size_t)cap;
     if (m == 0) return LIO_OK;
