@@ -7,7 +7,7 @@
  - two runs give identical bits; the update converges to the true pose."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from better_fastlio2_amd import capi, synth
 
 def bits_equal(a, b):

@@ -3,11 +3,11 @@ lasermap_fov_segment) at kilometre coordinates against the CPU path with the REF
 offsets, thinning of the initial map, scan poses along a drive, lanes per query, extrinsic estimation on/off.  After every scan: posterior, the two
 insert lists (bit-equal), Add_Points counter, validnum, fov boxes and delete counts.
 
-    python scripts/fuzz_loop.py [n_cases] [first_seed]
+    python tests/fuzz/fuzz_loop.py [n_cases] [first_seed]
 """
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from better_fastlio2_amd import capi, synth
 from oracle import pyoracle as po
 

@@ -2,11 +2,11 @@
 random sequences of Add_Points (down-sampled / plain, inside the map, in new territory, far away), Delete_Point_Boxes,
 acquire_removed_points and Nearest_Search (near and far queries).  Needs an MI355X and oracle/_ref.
 
-    python scripts/fuzz_map.py [n_cases] [first_seed]
+    python tests/fuzz/fuzz_map.py [n_cases] [first_seed]
 """
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from better_fastlio2_amd import capi
 from oracle import pyoracle as po
 

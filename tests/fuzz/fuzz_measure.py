@@ -3,11 +3,11 @@ iterated update) against the CPU path: oracle h_share_model / IKFoM update with 
 ikd-Tree.  Random small worlds (planes + clutter, at offsets up to kilometres), random scans (on the surfaces, noisy,
 outliers, far points), random priors, both extrinsic modes, random scan sizes (reduction edges).
 
-    python scripts/fuzz_measure.py [n_cases] [first_seed]
+    python tests/fuzz/fuzz_measure.py [n_cases] [first_seed]
 """
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from better_fastlio2_amd import capi, synth
 from oracle import pyoracle as po
 

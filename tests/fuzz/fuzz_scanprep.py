@@ -2,11 +2,11 @@
 against the oracle restatements: random cloud sizes and extents, leaf sizes, time stamps with ties, non-finite
 points, pose lists of random length, both call orders (cloud read before / after the filter).
 
-    python scripts/fuzz_scanprep.py [n_cases] [first_seed]
+    python tests/fuzz/fuzz_scanprep.py [n_cases] [first_seed]
 """
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from better_fastlio2_amd import capi
 from oracle import pyoracle as po
 

@@ -1,7 +1,7 @@
 """First-contact diagnostics on a real MI355X: parity of every stage against the oracle at a small
 size, then kernel timings at the benchmark size.  Prints; exits non-zero on a parity failure.
 
-    python scripts/gpu_probe.py [--nm 200000 --nq 20000] [--big]
+    python tests/fuzz/gpu_probe.py [--nm 200000 --nq 20000] [--big]
 """
 from __future__ import annotations
 
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 from better_fastlio2_amd import capi, synth  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402

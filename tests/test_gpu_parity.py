@@ -220,13 +220,13 @@ def test_set_downsample_param(gpu_capi, oracle, small_case):
 def test_downsample_boundary_points_fuzz_seeds(gpu_capi, oracle):
     """Add_Points(downsample) next to voxel boundaries, where the reference's fp32 boxes misbehave: a point outside
     its own box (seed 1000: two identical points both survive), a map point inside the boxes of two neighbouring
-    voxels that both receive points (seed 5025).  Cases of scripts/fuzz_map.py (random worlds at kilometre
+    voxels that both receive points (seed 5025).  Cases of tests/fuzz/fuzz_map.py (random worlds at kilometre
     coordinates, random mutation sequences) replayed against the reference ikd-Tree."""
     if not oracle.ref_available():
         pytest.skip("reference ikd-Tree not built")
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_map.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz", "fuzz_map.py")
     spec = importlib.util.spec_from_file_location("fuzz_map", path)
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
@@ -235,13 +235,13 @@ def test_downsample_boundary_points_fuzz_seeds(gpu_capi, oracle):
 
 
 def test_measurement_fuzz_seeds(gpu_capi, oracle):
-    """A few cases of scripts/fuzz_measure.py (random worlds up to kilometre offsets, random scans with outliers, both
+    """A few cases of tests/fuzz/fuzz_measure.py (random worlds up to kilometre offsets, random scans with outliers, both
     extrinsic modes, scan sizes on the reduction's edges) against the CPU path on the reference ikd-Tree."""
     if not oracle.ref_available():
         pytest.skip("reference ikd-Tree not built")
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_measure.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz", "fuzz_measure.py")
     spec = importlib.util.spec_from_file_location("fuzz_measure", path)
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
@@ -250,13 +250,13 @@ def test_measurement_fuzz_seeds(gpu_capi, oracle):
 
 
 def test_node_loop_fuzz_seeds(gpu_capi, oracle):
-    """A few cases of scripts/fuzz_loop.py: the per-scan loop (fov segment, iterated update, map_incremental, both
+    """A few cases of tests/fuzz/fuzz_loop.py: the per-scan loop (fov segment, iterated update, map_incremental, both
     Add_Points) at kilometre offsets with the REFERENCE ikd-Tree as the CPU side's map."""
     if not oracle.ref_available():
         pytest.skip("reference ikd-Tree not built")
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_loop.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz", "fuzz_loop.py")
     spec = importlib.util.spec_from_file_location("fuzz_loop", path)
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
@@ -265,12 +265,12 @@ def test_node_loop_fuzz_seeds(gpu_capi, oracle):
 
 
 def test_scan_preparation_fuzz_seeds(gpu_capi, oracle):
-    """Forty cases of scripts/fuzz_scanprep.py: raw clouds from 1 to 60 k points with time ties, clumps (leaves with
+    """Forty cases of tests/fuzz/fuzz_scanprep.py: raw clouds from 1 to 60 k points with time ties, clumps (leaves with
     hundreds of points), non-finite points, pose lists of 2..25 entries, leaf sizes from 0.1 to 3 m, the cloud read
     before or after the filter -- compensation vs the restatement, voxel grid bit-exact, PCL's overflow refusal."""
     import importlib.util
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_scanprep.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz", "fuzz_scanprep.py")
     spec = importlib.util.spec_from_file_location("fuzz_scanprep", path)
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
