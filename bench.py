@@ -314,7 +314,9 @@ def main():
                    "pos_err_to_truth_m": pos_err,
                    "map_update": ({"per_step_ms": maint["seconds"] / max(step_no[0], 1) * 1e3,
                                    "inserted_per_step": (maint["n_add"] + maint["n_nodown"]) / max(step_no[0], 1),
-                                   "exchange": "all_gather_into_tensor (RCCL)" if dist is not None else "none (1 rank)"}
+                                   "exchange": "all_gather_into_tensor (RCCL)" if dist is not None else "none (1 rank)",
+                                   "incremental_index_updates": ctx.map_info()["n_incremental_updates"],
+                                   "full_index_rebuilds": ctx.map_info()["n_full_rebuilds"]}
                                   if a.map_update else None)},
         "knn_us_per_point": knn_ms * 1e3 / nq,
         "kernels_us": kernels_us,

@@ -93,7 +93,9 @@ struct lio_ctx {
     // ---- staging / scratch --------------------------------------------------------------------
     float4* h_stage = nullptr;                 // pinned upload staging
     hipEvent_t ev_stage = nullptr;             // recorded behind an asynchronous copy out of h_stage
-    void* h_small = nullptr;                   // 256 pinned bytes: landing zone of the small counter read-backs
+    void* h_small = nullptr;                   // 256 host-mapped bytes: 32 words of counters + the sequence word the host polls
+    uint32_t* d_small = nullptr;               // device alias of h_small
+    uint32_t small_seq = 0;
     bool stage_busy = false;
     bool undist_sorted = true;                 // d_undist is in time order (else: input order, sorted on demand)
     bool raw_time_keyed = false;               // the raw scan came with per-point times
@@ -175,10 +177,29 @@ int auto_lanes(int nq) {
 
 // A few counters from the device: through pinned memory (a copy into pageable memory takes the runtime's slow
 // staged path, ~3x the latency), then the one synchronisation the caller needs anyway.
-static hipError_t read_back(lio_ctx* c, void* host_dst, const void* d_src, size_t bytes) {
-    hipError_t e = hipMemcpyAsync(c->h_small, d_src, bytes, hipMemcpyDeviceToHost, c->stream);
+// Waiting for the stream without entering the runtime's wait: a one-wavefront kernel at the end of the stream copies
+// the counters the host wants (if any) into host-mapped memory and publishes a sequence number there; the host polls
+// that word.  hipStreamSynchronize may park the thread on an interrupt (tens of microseconds to wake up) and
+// hipStreamQuery costs a runtime call per poll; the mapped word costs a cache miss.  Bounded: after ~1 s of polling
+// the runtime's wait takes over (and reports what went wrong, if something did).
+static hipError_t publish_and_wait(lio_ctx* c, const uint32_t* d_src, int n_words) {
+    const uint32_t seq = ++c->small_seq;
+    hipError_t e = launch_publish_words(d_src, n_words, c->d_small, seq, c->stream);
     if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(c->stream);
+    volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(c->h_small) + 32;
+    for (uint64_t spins = 0; spins < (1ull << 28); ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return hipSuccess;
+        if ((spins & 0xfffffu) == 0xfffffu) {                                  // every ~1 M polls: is the stream still healthy?
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return q;
+        }
+    }
+    return hipStreamSynchronize(c->stream);
+}
+static hipError_t stream_wait(lio_ctx* c) { return publish_and_wait(c, nullptr, 0); }
+// A few counters from the device (bytes: a multiple of 4, at most 128)
+static hipError_t read_back(lio_ctx* c, void* host_dst, const void* d_src, size_t bytes) {
+    const hipError_t e = publish_and_wait(c, reinterpret_cast<const uint32_t*>(d_src), (int)(bytes / 4));
     if (e != hipSuccess) return e;
     std::memcpy(host_dst, c->h_small, bytes);
     return hipSuccess;
@@ -222,7 +243,7 @@ int upload_points(lio_ctx* c, const float* pts, size_t n, int stride_bytes, floa
         c->h_stage[i] = make_float4(p[0], p[1], p[2], 0.0f);
     }
     HIPCHK(c, hipMemcpyAsync(d_dst, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));          // staging is reused by the next call
+    HIPCHK(c, stream_wait(c));          // staging is reused by the next call
     return LIO_OK;
 }
 
@@ -258,7 +279,7 @@ int finish_index(lio_ctx* c, uint32_t n) {
         if (L >= 2 && n_l <= (uint32_t)TREE_MAX_ROOTS) {
             uint64_t rk[TREE_MAX_ROOTS];
             HIPCHK(c, hipMemcpyAsync(rk, kout, (size_t)n_l * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, stream_wait(c));
             lv.top_level = L; lv.n_roots = (int)n_l;
             for (uint32_t i = 0; i < n_l; ++i) {
                 lv.root_x[i] = compact21(rk[i] >> 2); lv.root_y[i] = compact21(rk[i] >> 1); lv.root_z[i] = compact21(rk[i]);
@@ -274,7 +295,7 @@ int finish_index(lio_ctx* c, uint32_t n) {
             HashEntry* nt = nullptr;
             HIPCHK(c, hipMalloc((void**)&nt, cap * sizeof(HashEntry)));
             if (used > 0) HIPCHK(c, hipMemcpyAsync(nt, c->d_ltable, used * sizeof(HashEntry), hipMemcpyDeviceToDevice, s));
-            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, stream_wait(c));
             if (c->d_ltable) (void)hipFree(c->d_ltable);
             c->d_ltable = nt; c->ltable_slots = cap;
         }
@@ -306,7 +327,7 @@ int finish_index(lio_ctx* c, uint32_t n) {
         if (kout == c->d_mkeys_tmp) { kin = c->d_mkeys_tmp; cin = c->d_vals_tmp; kout = c->d_cell_keys; cout = c->d_cell_counts; }
         else { kin = c->d_cell_keys; cin = c->d_cell_counts; kout = c->d_mkeys_tmp; cout = c->d_vals_tmp; }
     }
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, stream_wait(c));
     c->levels = lv;
     c->have_map = true;
     ++c->n_full_rebuilds;
@@ -324,7 +345,7 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
         c->grid.n_points = 0;
         // empty map: an all-empty level-1 table keeps the kernels well defined
         HIPCHK(c, hipMemsetAsync(c->d_ltable, 0xFF, 64 * sizeof(HashEntry), s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, stream_wait(c));
         c->levels = TreeLevels{};                  // level-1 table = slot 0 of d_ltable, empty
         c->have_map = true;
         return LIO_OK;
@@ -347,7 +368,7 @@ int collect_box_deleted(lio_ctx* c) {
         HIPCHK(c, hipMalloc((void**)&nb, cap * sizeof(float4)));
         if (c->n_removed > 0)
             HIPCHK(c, hipMemcpyAsync(nb, c->d_removed, (size_t)c->n_removed * sizeof(float4), hipMemcpyDeviceToDevice, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, stream_wait(c));
         if (c->d_removed) (void)hipFree(c->d_removed);
         c->d_removed = nb; c->cap_removed = cap;
     }
@@ -522,7 +543,9 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     c->arch = prop.gcnArchName;
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
-    CREATE_CHK(hipHostMalloc(&c->h_small, 256, hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc(&c->h_small, 256, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_small, 0, 256);
+    CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_small, c->h_small, 0));
 
     c->grid.cell = cfg->cell_size != 0.0f ? cfg->cell_size : auto_cell_size(cfg->filter_size_map_min);
     c->grid.inv_cell = 1.0f / c->grid.cell;
@@ -619,7 +642,7 @@ const char* lio_last_error(lio_ctx* c) { return c ? c->err.c_str() : "null conte
 void* lio_stream(lio_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int lio_synchronize(lio_ctx* c) {
     if (!c) return LIO_ERR_INVALID_ARG;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c));
     return LIO_OK;
 }
 
@@ -854,7 +877,7 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
         if (rc != LIO_OK) return rc;
         HIPCHK(c, launch_pack_xyz(which == 0 ? c->d_add_pts : c->d_add_pts2, m, (float*)c->d_scratch, s));
         HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, stream_wait(c));
         std::memcpy(dst, c->h_scratch, (size_t)m * 3 * sizeof(float));
     }
     if (!apply) return LIO_OK;
@@ -1025,7 +1048,7 @@ int lio_map_flatten(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
     if (rc != LIO_OK) return rc;
     HIPCHK(c, launch_pack_xyz(c->d_pts_tmp, (uint32_t)m, (float*)c->d_scratch, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, m * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c));
     std::memcpy(out_xyz, c->h_scratch, m * 3 * sizeof(float));
     return LIO_OK;
 }
@@ -1047,7 +1070,7 @@ int lio_map_acquire_removed_points(lio_ctx* c, float* out_xyz, long long cap, lo
     if (rc != LIO_OK) return rc;
     HIPCHK(c, launch_pack_xyz(c->d_removed, (uint32_t)m, (float*)c->d_scratch, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, m * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c));
     std::memcpy(out_xyz, c->h_scratch, m * 3 * sizeof(float));
     c->n_removed = 0;                                         // Points_deleted.clear()  (ikd_Tree.cpp:567)
     return LIO_OK;
@@ -1096,7 +1119,7 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, b_xyz + b_d + b_c, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c));
     if (walked & 0x80000000u) return c->fail(LIO_ERR_HIP, "lio_map_nearest_search", "tree walk exceeded its stack bound");
     if (out_xyz) std::memcpy(out_xyz, c->h_scratch, b_xyz);
     if (out_sqdist) std::memcpy(out_sqdist, (char*)c->h_scratch + b_xyz, b_d);
@@ -1262,8 +1285,6 @@ int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
     if (n == 0) return scan_reset(c, 0);
     // One pass over the stream, one read-back at the end: getMinMax3D, min_b_/divb_mul_, the leaf index of every
     // point, a stable sort by leaf, the run heads and the centroids all stay on the device (VoxelGridDev).
-    int rc = ensure_scratch(c, 64);
-    if (rc != LIO_OK) return rc;
     VoxelGridDev* vox = c->d_vox;
     HIPCHK(c, hipMemsetAsync(vox, 0, sizeof(VoxelGridDev), s));
     HIPCHK(c, launch_minmax(c->d_undist, n, vox, s));
@@ -1274,9 +1295,8 @@ int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
     const uint32_t max_leaves = (uint32_t)n < (uint32_t)c->cap_q + 1u ? (uint32_t)n : (uint32_t)c->cap_q + 1u;
     HIPCHK(c, launch_centroids(c->d_undist, c->d_raw_order2, c->d_raw_keys2, c->d_leaf_start, vox, (uint32_t)n, max_leaves,
                                (uint32_t)c->cap_q, c->d_body, s));
-    uint32_t* summary = reinterpret_cast<uint32_t*>(c->h_scratch);
-    HIPCHK(c, hipMemcpyAsync(summary, vox->summary, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    uint32_t summary[4] = {0, 0, 0, 0};
+    HIPCHK(c, read_back(c, summary, vox->summary, sizeof(summary)));
     if (summary[2] & VOX_OVERFLOW)
         return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "leaf size too small for the extent of the scan (index overflow, as in PCL)");
     if (summary[2] & VOX_EMPTY) return scan_reset(c, 0);                // no finite point
@@ -1307,7 +1327,7 @@ int lio_scan_get_cloud(lio_ctx* c, int which, float* out_xyz, int cap, int* n) {
     if (rc != LIO_OK) return rc;
     HIPCHK(c, launch_pack_xyz(src, (uint32_t)m, (float*)c->d_scratch, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c));
     std::memcpy(out_xyz, c->h_scratch, (size_t)m * 3 * sizeof(float));
     return LIO_OK;
 }
@@ -1389,7 +1409,7 @@ int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_m
     if (rc != LIO_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_rows, b_rows, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync((char*)c->h_scratch + b_rows, c->d_sel, (size_t)nq, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, stream_wait(c));
     const double* rows = (const double*)c->h_scratch;
     const uint8_t* sel = (const uint8_t*)c->h_scratch + b_rows;
     int r = 0;
@@ -1420,7 +1440,7 @@ int lio_get_neighbors(lio_ctx* c, float* out_xyz, float* out_sqdist, int* out_co
     int* dc = (int*)((char*)c->d_scratch + b_xyz + b_d);
     HIPCHK(c, launch_unpack_neighbors(c->d_nbr, c->d_cnt, n, c->cap_q, dx, dd, dc, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, b_xyz + b_d + b_c, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c));
     if (out_xyz) std::memcpy(out_xyz, c->h_scratch, b_xyz);
     if (out_sqdist) std::memcpy(out_sqdist, (char*)c->h_scratch + b_xyz, b_d);
     if (out_count) std::memcpy(out_count, (char*)c->h_scratch + b_xyz + b_d, b_c);
@@ -1439,7 +1459,7 @@ int lio_get_scan_state(lio_ctx* c, float* world_xyz, uint8_t* selected, float* n
     HIPCHK(c, hipMemcpyAsync(hs, c->d_world, b4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(hs + b4, c->d_normvec, b4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(hs + 2 * b4, c->d_sel, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, stream_wait(c));
     const float4* w = (const float4*)hs;
     const float4* nv = (const float4*)(hs + b4);
     const uint8_t* sl = (const uint8_t*)(hs + 2 * b4);

@@ -85,6 +85,7 @@ hipError_t launch_table_insert(const uint64_t* cell_mkeys, const uint32_t* cell_
 // cell directory of the k-NN kernel: level-1 entries carry the number of their child block, the block holds
 // {start, count} of the 64 level-0 cells at a fixed position (no hashing, no collisions on the 27 look-ups)
 hipError_t launch_iota(uint32_t* out, uint32_t n, hipStream_t s);
+hipError_t launch_publish_words(const uint32_t* src, int n, uint32_t* dst_mapped, uint32_t seq, hipStream_t s);
 hipError_t launch_fill_child_blocks(const uint64_t* cell_mkeys, const uint32_t* cell_start, const uint32_t* cell_count,
                                     uint32_t n_cells, const HashEntry* l1table, uint32_t l1mask, uint2* child, hipStream_t s);
 // w != 0 for every live point inside any of the nb half-open boxes; *counter += points tomb-stoned

@@ -143,6 +143,19 @@ hipError_t launch_table_insert(const uint64_t* cell_mkeys, const uint32_t* cell_
                        n_cells, table, table_mask);
     return hipGetLastError();
 }
+// Copies n (<= 32) words into host-mapped memory and then publishes a sequence number there with a system-scope
+// release: the host polls that word instead of calling into the runtime to wait for the stream.
+__global__ void publish_words_kernel(const uint32_t* src, int n, uint32_t* dst_mapped, uint32_t seq) {
+    const int t = threadIdx.x;
+    if (t < n) dst_mapped[t] = src[t];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(dst_mapped + 32, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_publish_words(const uint32_t* src, int n, uint32_t* dst_mapped, uint32_t seq, hipStream_t s) {
+    hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, s, src, n, dst_mapped, seq);
+    return hipGetLastError();
+}
 hipError_t launch_iota(uint32_t* out, uint32_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, s, out, n);
