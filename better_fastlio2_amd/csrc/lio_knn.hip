@@ -139,7 +139,6 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         bool have = false;
         if (active) {
             have = a.cnt[q] >= K;
-#pragma unroll
             for (int k = r; k < K; k += G) {           // G < K (4 lanes per query): lane 0 measures two
                 const float4 p = a.nbr[(size_t)k * a.nq_stride + q];
                 const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
