@@ -22,8 +22,9 @@ from . import build as _build
 LIO_OK = 0
 ERRORS = {-1: "LIO_ERR_INVALID_ARG", -2: "LIO_ERR_NO_DEVICE", -3: "LIO_ERR_HIP", -4: "LIO_ERR_CAPACITY",
           -5: "LIO_ERR_NO_SCAN", -6: "LIO_ERR_NO_MAP"}
-PROF_KNN, PROF_FALLBACK, PROF_RESIDUAL, PROF_REDUCE = 0, 1, 2, 3
-PROF_NAMES = {PROF_KNN: "knn27", PROF_FALLBACK: "knn_tree", PROF_RESIDUAL: "residual", PROF_REDUCE: "reduce_final"}
+PROF_KNN, PROF_FALLBACK, PROF_RESIDUAL, PROF_REDUCE, PROF_KNN_HINT = 0, 1, 2, 3, 4
+PROF_NAMES = {PROF_KNN: "knn27", PROF_FALLBACK: "knn_tree", PROF_RESIDUAL: "residual", PROF_REDUCE: "reduce_final",
+              PROF_KNN_HINT: "knn27_hint"}
 
 
 class LioError(RuntimeError):
@@ -63,8 +64,8 @@ EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_stream", "lio_synchronize",
     "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_fov_segment", "lio_map_reconstruct",
     "lio_map_set_downsample_param", "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_acquire_removed_points", "lio_map_get_info", "lio_map_nearest_search",
-    "lio_scan_set", "lio_scan_set_device", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
-    "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get",
+    "lio_scan_set", "lio_scan_set_device", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_rows", "lio_get_neighbors",
+    "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get", "lio_debug_set",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
     "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_eskf_scan_step_device", "lio_state_boxplus",
     "lio_state_boxminus", "lio_eskf_predict", "lio_process_noise_cov",
@@ -133,6 +134,12 @@ def load(build_if_missing: bool = True):
     L.lio_map_nearest_search.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
     L.lio_scan_set.argtypes = [_vp, _vp, C.c_int, C.c_int]
     L.lio_scan_set_device.argtypes = [_vp, _vp, C.c_int]
+    L.lio_scan_upload_async.argtypes = [_vp, _vp, C.c_int]
+    L.lio_scan_swap.argtypes = [_vp]
+    L.lio_host_alloc.argtypes = [C.c_size_t]
+    L.lio_host_alloc.restype = _vp
+    L.lio_host_free.argtypes = [_vp]
+    L.lio_host_free.restype = None
     L.lio_scan_undistort.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]
     L.lio_scan_upload_raw.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int]
     L.lio_scan_compensate.argtypes = [_vp, _vp, C.c_int, _vp]
@@ -146,6 +153,7 @@ def load(build_if_missing: bool = True):
     L.lio_profile_enable.argtypes = [_vp, C.c_int]
     L.lio_profile_reset.argtypes = [_vp]
     L.lio_census_enable.argtypes = [_vp, C.c_int]
+    L.lio_debug_set.argtypes = [_vp, C.c_char_p, C.c_longlong]
     L.lio_profile_get.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.lio_eskf_create.restype = _vp
     L.lio_eskf_destroy.argtypes = [_vp]
@@ -173,6 +181,26 @@ def load(build_if_missing: bool = True):
     L.lio_imu_get_info.argtypes = [_vp, C.POINTER(lio_imu_info)]
     _lib = L
     return L
+
+
+def pinned_points(xyz) -> np.ndarray:
+    """[n, 4] float32 copy of xyz in pinned host memory (lio_host_alloc): the buffer a sensor driver would fill.
+    The memory lives as long as the returned array (and views of it)."""
+    L = load()
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    n = len(xyz)
+    p = L.lio_host_alloc(max(n, 1) * 16)
+    if not p:
+        raise LioError("lio_host_alloc failed")
+    buf = (C.c_float * (max(n, 1) * 4)).from_address(p)
+    arr = np.frombuffer(buf, np.float32).reshape(-1, 4)[:n]
+    arr[:] = 0.0
+    arr[:, :3] = xyz[:, :3]
+    _pinned_keepalive.append((arr, p))
+    return arr
+
+
+_pinned_keepalive = []
 
 
 def _ptr(a: np.ndarray):
@@ -225,6 +253,11 @@ class LioContext:
     def map_build(self, pts):
         p = _points(pts)
         self._chk(self.L.lio_map_build(self.h, _ptr(p), len(p), _stride(p)), "lio_map_build")
+
+    def map_reconstruct(self, pts):
+        """KD_TREE::reconstruct (ikd_Tree.cpp:1394-1405): the map becomes exactly this cloud."""
+        p = _points(pts)
+        self._chk(self.L.lio_map_reconstruct(self.h, _ptr(p), len(p), _stride(p)), "lio_map_reconstruct")
 
     def map_build_device(self, d_ptr: int, n: int):
         self._chk(self.L.lio_map_build_device(self.h, _vp(d_ptr), n), "lio_map_build_device")
@@ -362,6 +395,15 @@ class LioContext:
     def scan_set_device(self, d_ptr: int, n: int):
         self._chk(self.L.lio_scan_set_device(self.h, _vp(d_ptr), n), "lio_scan_set_device")
 
+    def scan_upload_async(self, pinned_f4: np.ndarray):
+        """Start the host-to-device copy of the NEXT scan ([n, 4] float32 in pinned memory, see pinned_points)."""
+        assert pinned_f4.dtype == np.float32 and pinned_f4.ndim == 2 and pinned_f4.shape[1] == 4 and pinned_f4.flags.c_contiguous
+        self._chk(self.L.lio_scan_upload_async(self.h, _ptr(pinned_f4), len(pinned_f4)), "lio_scan_upload_async")
+
+    def scan_swap(self):
+        """The scan uploaded with scan_upload_async becomes the current scan."""
+        self._chk(self.L.lio_scan_swap(self.h), "lio_scan_swap")
+
     def measure(self, state14, do_search: bool, extrinsic_est_en: bool) -> dict:
         s = np.ascontiguousarray(state14, dtype=np.float64)
         assert s.shape == (14,)
@@ -407,6 +449,10 @@ class LioContext:
     def census_enable(self, on: bool = True):
         """Make search passes report n_candidates (sum of C(q)); off in timed runs."""
         self.L.lio_census_enable(self.h, int(on))
+
+    def debug_set(self, key: str, value: int):
+        """Test hooks of the library (lio_debug_set)."""
+        self._chk(self.L.lio_debug_set(self.h, key.encode(), int(value)), "lio_debug_set")
 
     def profile_reset(self):
         self.L.lio_profile_reset(self.h)

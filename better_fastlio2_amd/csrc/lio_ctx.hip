@@ -53,6 +53,7 @@ struct lio_ctx {
     uint32_t n_dead = 0;                       // box-deleted slots since the last full rebuild
     long long n_incremental_updates = 0, n_full_rebuilds = 0;
     uint32_t n_new_cells = 0, n_cells_built = 0;   // cells inserted since / present at the last full rebuild
+    uint32_t level_entries[TREE_MAX_LEVELS]{};     // entries of each hashed level at the last full rebuild
     // points appended by Add_Points, waiting for apply_pending (batch order)
     float4* d_pend = nullptr;
     size_t cap_pend = 0;
@@ -77,6 +78,12 @@ struct lio_ctx {
     // ---- scan -------------------------------------------------------------------------------
     int cap_q = 0, nq = 0;
     float4 *d_body = nullptr, *d_world = nullptr, *d_nbr = nullptr, *d_normvec = nullptr, *d_plane = nullptr;
+    // pipelined hand-over of the next scan (lio_scan_upload_async / lio_scan_swap): a second scan buffer filled on a
+    // copy stream while the current scan is being processed
+    float4* d_body_back = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy = nullptr;
+    int nq_back = -1;                          // points in the back buffer (-1: nothing uploaded)
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
     float4* d_ulist = nullptr;                 // queries the 27-cell kernel could not prove (count: d_counters[0])
     double* d_rows = nullptr;
@@ -135,6 +142,7 @@ struct lio_ctx {
     // the totals are read, so that timing a run does not add a stream synchronisation per pass
     unsigned prof = 0;                         // bit w set: time kernel family w
     bool census = false;                       // count C(q) in the k-NN kernel (one atomic per wavefront)
+    int dbg_force_timeout = 0;                 // lio_debug_set("force_reduction_timeout")
     std::vector<hipEvent_t> ev_pool[LIO_PROF_COUNT];   // start, stop, start, stop, ...
     size_t ev_next[LIO_PROF_COUNT]{};          // events of the pool in use
     double prof_ms[LIO_PROF_COUNT]{};
@@ -277,9 +285,13 @@ int finish_index(lio_ctx* c, uint32_t n) {
         uint32_t n_l = 0;
         HIPCHK(c, read_back(c, &n_l, c->d_counters + 4, sizeof(uint32_t)));
         if (L >= 2 && n_l <= (uint32_t)TREE_MAX_ROOTS) {
+            // root keys through the host-mapped counter block (a copy into pageable memory may be completed by the
+            // runtime after the stream is seen idle): at most TREE_MAX_ROOTS x 8 bytes = 2 x 128 bytes
             uint64_t rk[TREE_MAX_ROOTS];
-            HIPCHK(c, hipMemcpyAsync(rk, kout, (size_t)n_l * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-            HIPCHK(c, stream_wait(c));
+            for (uint32_t o = 0; o < n_l; o += 16) {
+                const uint32_t part = n_l - o < 16 ? n_l - o : 16;
+                HIPCHK(c, read_back(c, rk + o, kout + o, (size_t)part * sizeof(uint64_t)));
+            }
             lv.top_level = L; lv.n_roots = (int)n_l;
             for (uint32_t i = 0; i < n_l; ++i) {
                 lv.root_x[i] = compact21(rk[i] >> 2); lv.root_y[i] = compact21(rk[i] >> 1); lv.root_z[i] = compact21(rk[i]);
@@ -305,6 +317,7 @@ int finish_index(lio_ctx* c, uint32_t n) {
         HIPCHK(c, launch_iota(c->d_rank, n_l, s));
         HIPCHK(c, launch_table_insert(kout, c->d_rank, cout, n_l, c->d_ltable + used, (uint32_t)(sl - 1), s));
         lv.off[L] = (uint32_t)used; lv.mask[L] = (uint32_t)(sl - 1);
+        c->level_entries[L] = n_l;
         if (L == 1) {
             // cell directory: one block of 64 {start, count} per level-1 cell, with room for the level-1 cells that
             // incremental updates will add
@@ -442,7 +455,14 @@ int apply_pending(lio_ctx* c) {
     c->n_cells += st[0]; c->n_new_cells += st[0]; c->n_retired += st[1];
     ++c->n_incremental_updates;
     const uint32_t retired_budget = c->n_live / 8 > 65536u ? c->n_live / 8 : 65536u;
-    if (st[2] != 0 || (size_t)c->n_retired + (size_t)c->n_dead > (size_t)retired_budget || (size_t)c->n_new_cells * 4 > (size_t)c->n_cells_built + 1024)
+    // Every new grid cell adds at most one entry to each hashed level: keep every table at most half full (they are
+    // built a quarter full), so that probe sequences stay short and a look-up of an absent key always meets an empty
+    // slot -- small maps have 64-slot tables that the cell budget below would let run full.
+    bool table_crowded = false;
+    for (int L = 1; L < c->levels.top_level; ++L)
+        table_crowded = table_crowded || ((size_t)c->level_entries[L] + (size_t)c->n_new_cells) * 2 > (size_t)c->levels.mask[L] + 1;
+    if (st[2] != 0 || table_crowded || (size_t)c->n_retired + (size_t)c->n_dead > (size_t)retired_budget ||
+        (size_t)c->n_new_cells * 4 > (size_t)c->n_cells_built + 1024)
         return rebuild_full(c);
     return LIO_OK;
 }
@@ -496,7 +516,7 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.nbr = nbr; ka.cnt = cnt; ka.ulist = ulist; ka.n_unres = c->d_counters; ka.cand_total = c->census ? c->d_cand : nullptr;
     ka.use_hint = use_hint ? 1 : 0;
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
-    HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, LIO_PROF_KNN)));
+    HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
     TreeArgs ta{};
     ta.map_pts = c->d_pts; ta.child = c->d_child; ta.ltable = c->d_ltable; ta.levels = c->levels; ta.grid = c->grid;
     ta.ulist = ulist; ta.n_unres = c->d_counters;
@@ -591,6 +611,9 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     const size_t nq = (size_t)cfg->max_scan_points;
     c->cap_q = cfg->max_scan_points;
     CREATE_CHK(hipMalloc((void**)&c->d_body, nq * sizeof(float4)));
+    CREATE_CHK(hipMalloc((void**)&c->d_body_back, nq * sizeof(float4)));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    CREATE_CHK(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
     CREATE_CHK(hipMalloc((void**)&c->d_world, nq * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_nbr, nq * K * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_normvec, nq * sizeof(float4)));
@@ -620,7 +643,7 @@ void lio_destroy(lio_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
-                   c->d_body, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_rows,
+                   c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_rows,
                    c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
@@ -633,6 +656,8 @@ void lio_destroy(lio_ctx* c) {
     for (int w = 0; w < LIO_PROF_COUNT; ++w)
         for (hipEvent_t e : c->ev_pool[w]) (void)hipEventDestroy(e);
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -642,6 +667,7 @@ const char* lio_last_error(lio_ctx* c) { return c ? c->err.c_str() : "null conte
 void* lio_stream(lio_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int lio_synchronize(lio_ctx* c) {
     if (!c) return LIO_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, stream_wait(c));
     return LIO_OK;
 }
@@ -653,7 +679,11 @@ int lio_map_build(lio_ctx* c, const float* pts, long long n, int stride_bytes) {
     HIPCHK(c, hipSetDevice(c->device));
     int rc = upload_points(c, pts, (size_t)n, stride_bytes, c->d_pts_tmp);
     if (rc != LIO_OK) return rc;
-    c->box_deleted_pending = 0;                // Build drops the old nodes without recording them (ikd_Tree.cpp:353-358)
+    // Build / reconstruct drop the old nodes (ikd_Tree.cpp:353-358, 1396) but Points_deleted survives them: what the
+    // reference may still hand out afterwards is a subset of the box-deleted points, so they are kept for
+    // acquire_removed_points (every box-deleted point is reported exactly once, lio_hip.h)
+    rc = collect_box_deleted(c);
+    if (rc != LIO_OK) return rc;
     return build_index(c, c->d_pts_tmp, (uint32_t)n);
 }
 int lio_map_build_device(lio_ctx* c, const void* d_pts_f4, long long n) {
@@ -662,7 +692,10 @@ int lio_map_build_device(lio_ctx* c, const void* d_pts_f4, long long n) {
     HIPCHK(c, hipSetDevice(c->device));
     if (n > 0)
         HIPCHK(c, hipMemcpyAsync(c->d_pts_tmp, d_pts_f4, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
-    c->box_deleted_pending = 0;
+    {
+        const int rc = collect_box_deleted(c);
+        if (rc != LIO_OK) return rc;
+    }
     return build_index(c, c->d_pts_tmp, (uint32_t)n);
 }
 int lio_map_reconstruct(lio_ctx* c, const float* pts, long long n, int stride_bytes) {
@@ -862,6 +895,7 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
     if (n_add) *n_add = 0;
     if (n_nodown) *n_nodown = 0;
     if (add_counter) *add_counter = 0;
+    HIPCHK(c, hipSetDevice(c->device));
     uint32_t cnts[2];
     int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, cnts);
     if (rc != LIO_OK) return rc;
@@ -1115,11 +1149,10 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
     int* dc = (int*)((char*)c->d_scratch + b_xyz + b_d);
     HIPCHK(c, launch_unpack_neighbors(c->d_qs_nbr, c->d_qs_cnt, n, n, dx, dd, dc, c->stream));
     uint32_t walked = 0;
-    HIPCHK(c, hipMemcpyAsync(&walked, c->d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, b_xyz + b_d + b_c, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, read_back(c, &walked, c->d_counters, sizeof(uint32_t)));      // through host-mapped memory; waits for the stream
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_cand, 0, sizeof(unsigned long long), c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_scratch, c->d_scratch, b_xyz + b_d + b_c, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, stream_wait(c));
     if (walked & 0x80000000u) return c->fail(LIO_ERR_HIP, "lio_map_nearest_search", "tree walk exceeded its stack bound");
     if (out_xyz) std::memcpy(out_xyz, c->h_scratch, b_xyz);
     if (out_sqdist) std::memcpy(out_sqdist, (char*)c->h_scratch + b_xyz, b_d);
@@ -1152,6 +1185,38 @@ int lio_scan_set_device(lio_ctx* c, const void* d_body_f4, int n) {
     return scan_reset(c, n);
 }
 int lio_scan_size(lio_ctx* c) { return c ? c->nq : 0; }
+
+// ---- pipelined hand-over: the next scan travels while the current one is being processed --------------------
+int lio_scan_upload_async(lio_ctx* c, const void* host_f4, int n) {
+    if (!c || n < 0 || (n > 0 && !host_f4)) return LIO_ERR_INVALID_ARG;
+    if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_upload_async", "n exceeds max_scan_points");
+    HIPCHK(c, hipSetDevice(c->device));
+    // the back buffer is not read by anything in flight: the scan step that used it last has returned to the caller
+    if (n > 0) HIPCHK(c, hipMemcpyAsync(c->d_body_back, host_f4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_copy, c->copy_stream));
+    c->nq_back = n;
+    return LIO_OK;
+}
+int lio_scan_swap(lio_ctx* c) {
+    if (!c) return LIO_ERR_INVALID_ARG;
+    if (c->nq_back < 0) return c->fail(LIO_ERR_NO_SCAN, "lio_scan_swap", "no scan was uploaded with lio_scan_upload_async");
+    HIPCHK(c, hipSetDevice(c->device));
+    // usually the copy finished long ago (it ran beside the previous scan step): then the host has seen it complete
+    // and everything launched from here on is ordered behind it; otherwise the compute stream waits for the event
+    const hipError_t q = hipEventQuery(c->ev_copy);
+    if (q == hipErrorNotReady) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+    else if (q != hipSuccess) return c->fail(LIO_ERR_HIP, "lio_scan_swap", hipGetErrorString(q));
+    float4* t = c->d_body; c->d_body = c->d_body_back; c->d_body_back = t;
+    const int n = c->nq_back;
+    c->nq_back = -1;
+    return scan_reset(c, n);
+}
+void* lio_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void lio_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 // ---- raw-scan preparation: UndistortPcl's compensation + pcl::VoxelGrid ----
 static int ensure_raw_buffers(lio_ctx* c, size_t n) {
@@ -1336,6 +1401,7 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     if (!c || !state14 || !out) return LIO_ERR_INVALID_ARG;
     if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "no scan set");
     if (!do_search && !c->have_search) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "first pass of a scan must search");
+    HIPCHK(c, hipSetDevice(c->device));
     std::memset(out, 0, sizeof(*out));
     const int nq = c->nq;
     if (nq == 0) { out->valid = 0; return LIO_OK; }       // "No Effective Points" laserMapping.cpp:1956
@@ -1355,6 +1421,7 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.rows = nullptr; ra.units = c->d_units; ra.gunits = c->d_gunits;
     const unsigned long long seq = ++c->seq;
     ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
+    ra.debug_fail = c->dbg_force_timeout;
     HIPCHK(c, launch_residual(ra, do_search != 0, ext, s, prof_timer(c, LIO_PROF_RESIDUAL)));
     // The record lands in host-mapped memory; poll its sequence number instead of paying for a
     // device-to-host copy plus a stream synchronisation.  hipStreamQuery guards against a fault.
@@ -1377,6 +1444,7 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
 
     const DeviceOut& d = *c->h_out;
     if (d.n_unresolved < 0) return c->fail(LIO_ERR_HIP, "lio_measure", "tree walk exceeded its stack bound");
+    if (d.m < 0) return c->fail(LIO_ERR_HIP, "lio_measure", "cross-workgroup reduction: a bounded wait ran out (sums incomplete)");
     out->m = d.m;
     out->valid = d.m >= 1 ? 1 : 0;                        // laserMapping.cpp:1956-1961
     out->n_unresolved = d.n_unresolved;
@@ -1391,6 +1459,7 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
 int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_major) {
     if (!c || !h_x || !h) return LIO_ERR_INVALID_ARG;
     if (!c->have_pass) return c->fail(LIO_ERR_NO_SCAN, "lio_measure_rows", "no measurement pass yet");
+    HIPCHK(c, hipSetDevice(c->device));
     const int nq = c->nq, m = c->last_m;
     if (cap_rows < m) return c->fail(LIO_ERR_CAPACITY, "lio_measure_rows", "cap_rows < m");
     if (m == 0) return LIO_OK;
@@ -1430,6 +1499,7 @@ int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_m
 int lio_get_neighbors(lio_ctx* c, float* out_xyz, float* out_sqdist, int* out_count) {
     if (!c) return LIO_ERR_INVALID_ARG;
     if (!c->have_search) return c->fail(LIO_ERR_NO_SCAN, "lio_get_neighbors", "no search pass yet");
+    HIPCHK(c, hipSetDevice(c->device));
     const int n = c->nq;
     if (n == 0) return LIO_OK;
     const size_t b_xyz = (size_t)n * K * 3 * sizeof(float), b_d = (size_t)n * K * sizeof(float), b_c = (size_t)n * sizeof(int);
@@ -1450,6 +1520,7 @@ int lio_get_neighbors(lio_ctx* c, float* out_xyz, float* out_sqdist, int* out_co
 int lio_get_scan_state(lio_ctx* c, float* world_xyz, uint8_t* selected, float* normvec) {
     if (!c) return LIO_ERR_INVALID_ARG;
     if (!c->have_pass) return c->fail(LIO_ERR_NO_SCAN, "lio_get_scan_state", "no measurement pass yet");
+    HIPCHK(c, hipSetDevice(c->device));
     const int n = c->nq;
     if (n == 0) return LIO_OK;
     const size_t b4 = (size_t)n * sizeof(float4);
@@ -1478,14 +1549,21 @@ int lio_get_scan_state(lio_ctx* c, float* world_xyz, uint8_t* selected, float* n
 // ---- profiling -----------------------------------------------------------------------------------
 int lio_profile_enable(lio_ctx* c, int on) {
     if (!c) return LIO_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     prof_collect(c);
     // on == 1: every family; otherwise a bit mask (1 << LIO_PROF_x) | ... ; 0 = off
     c->prof = on == 1 ? 0xffu : ((unsigned)on & 0xffu);
     return LIO_OK;
 }
+int lio_debug_set(lio_ctx* c, const char* key, long long value) {
+    if (!c || !key) return LIO_ERR_INVALID_ARG;
+    if (std::strcmp(key, "force_reduction_timeout") == 0) { c->dbg_force_timeout = value != 0; return LIO_OK; }
+    return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "unknown key");
+}
 int lio_census_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; c->census = on != 0; return LIO_OK; }
 int lio_profile_reset(lio_ctx* c) {
     if (!c) return LIO_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     prof_collect(c);
     for (int w = 0; w < LIO_PROF_COUNT; ++w) { c->prof_ms[w] = 0.0; c->prof_n[w] = 0; }
     return LIO_OK;
@@ -1569,7 +1647,7 @@ int lio_eskf_scan_step_device(lio_eskf* kf, lio_ctx* ctx, const double x26[26], 
     int rc = LIO_OK;
     if (x26 != nullptr) rc = lio_eskf_change_x(kf, x26);
     if (rc == LIO_OK && P != nullptr) rc = lio_eskf_change_P(kf, P);
-    if (rc == LIO_OK) rc = lio_scan_set_device(ctx, d_body_f4, n);
+    if (rc == LIO_OK && d_body_f4 != nullptr) rc = lio_scan_set_device(ctx, d_body_f4, n);
     if (rc == LIO_OK) rc = lio_eskf_update_iterated_dyn_share_modified(kf, ctx, R, extrinsic_est_en, log);
     return rc;
 }

@@ -11,7 +11,9 @@ __device__ __forceinline__ void table_find(const HashEntry* table_, uint32_t mas
     const uint4* table = reinterpret_cast<const uint4*>(table_);
     uint32_t slot = hash_key(key) & mask;
     start = 0; count = 0;
-    for (;;) {
+    // tables are kept at most half full (apply_pending), so a probe sequence ends at an empty slot long before it
+    // wraps; the bound only keeps a corrupted table from hanging the GPU
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
         const uint4 e = table[slot];
         const uint64_t ek = ((uint64_t)e.y << 32) | (uint64_t)e.x;
         if (ek == key) { start = e.z; count = e.w; return; }

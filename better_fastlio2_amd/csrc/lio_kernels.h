@@ -69,6 +69,7 @@ struct ResidualArgs {
     unsigned long long* cand_total; // ditto
     DeviceOut*     out;             // host-mapped result record
     unsigned long long seq;         // published last (system-scope release) in out->seq
+    int            debug_fail;      // test hook (lio_debug_set "force_reduction_timeout"): report a timed-out wait
 };
 int residual_blocks(int nq);
 hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s, KernelTimer t = KernelTimer());

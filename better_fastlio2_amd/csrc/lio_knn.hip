@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
                 pend[s1] = !hit && ek != KEY_EMPTY;
                 any_pend = any_pend || pend[s1];
             }
-            while (__any(any_pend)) {                               // collision rounds (load factor <= 0.25)
+            // collision rounds (load factor <= 0.5, apply_pending); the round bound only matters for a corrupted table
+            for (uint32_t rounds = 0; __any(any_pend) && rounds <= l1mask; ++rounds) {
                 any_pend = false;
 #pragma unroll
                 for (int s1 = 0; s1 < L1SLOTS; ++s1) {

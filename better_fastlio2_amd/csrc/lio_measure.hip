@@ -234,7 +234,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         s_fin[tid] = t + s_own[tid];
     }
     __syncthreads();
-    const bool failed = s_failed != 0u;
+    const bool failed = s_failed != 0u || a.debug_fail != 0;
     // One wavefront writes the whole record into host-mapped memory, fences at system scope and only
     // then publishes the sequence number the host is polling.
     if (tid < 64) {

@@ -158,6 +158,16 @@ int  lio_map_nearest_search(lio_ctx* ctx, const float* q_xyz, int n, int stride_
  * point_selected_surf to all-true (laserMapping.cpp:2131).                                         */
 int  lio_scan_set(lio_ctx* ctx, const float* body_pts, int n, int stride_bytes);
 int  lio_scan_set_device(lio_ctx* ctx, const void* d_body_f4, int n);
+/* Pipelined hand-over (the node receives scan k+1 while scan k is being processed): lio_scan_upload_async enqueues
+ * the host-to-device copy of n float4 records (x, y, z, _) into the context's BACK scan buffer on a copy stream of
+ * its own and returns at once (host_f4 should be pinned -- lio_host_alloc -- and must stay untouched until
+ * lio_scan_swap; pageable memory works but copies synchronously); lio_scan_swap makes the back buffer the current
+ * scan (as lio_scan_set would) -- the compute stream waits for the copy only if it is still in flight.  At most one
+ * upload may be outstanding; the back buffer is the scan that was current before the last swap.             */
+int  lio_scan_upload_async(lio_ctx* ctx, const void* host_f4, int n);
+int  lio_scan_swap(lio_ctx* ctx);
+void* lio_host_alloc(size_t bytes);                 /* pinned host memory (hipHostMalloc); NULL on failure     */
+void lio_host_free(void* p);
 /* ---- raw-scan preparation (the step before the path) ---------------------- */
 /* Pose6D (msg/Pose6D.msg, include/common_lib.h:446-460): one forward-propagated IMU pose of IMUpose.      */
 typedef struct lio_pose6d {
@@ -203,11 +213,12 @@ int  lio_get_scan_state(lio_ctx* ctx, float* world_xyz, uint8_t* selected, float
 int  lio_scan_size(lio_ctx* ctx);
 
 /* ---- timing hooks (a HIP event pair per launch, stamped by the dispatch itself on lio_stream) -------- */
-#define LIO_PROF_KNN       0    /* 27-cell k-NN kernel                                              */
+#define LIO_PROF_KNN       0    /* 27-cell k-NN kernel, first search of a scan                      */
 #define LIO_PROF_FALLBACK  1    /* exact tree walk for unresolved queries                           */
 #define LIO_PROF_RESIDUAL  2    /* plane fit + residual + Jacobian + H^T H reduction + result record */
 #define LIO_PROF_REDUCE    3    /* (fused into LIO_PROF_RESIDUAL since the last-arriver reduction; 0) */
-#define LIO_PROF_COUNT     4
+#define LIO_PROF_KNN_HINT  4    /* 27-cell k-NN kernel, later searches of the same scan (bounded by the previous neighbours) */
+#define LIO_PROF_COUNT     5
 /* on = 0: off; 1: every family; otherwise a bit mask of (1 << LIO_PROF_x) | 0x100 (0x100 marks a mask,
  * e.g. 0x100 | 1 << LIO_PROF_KNN times only the k-NN kernel: one event pair per search pass)              */
 int  lio_profile_enable(lio_ctx* ctx, int on);
@@ -215,6 +226,10 @@ int  lio_profile_enable(lio_ctx* ctx, int on);
  * atomic per wavefront of the k-NN kernel, so it is off by default and never on in timed runs)    */
 int  lio_census_enable(lio_ctx* ctx, int on);
 int  lio_profile_reset(lio_ctx* ctx);
+/* test hooks (never needed by a caller): key "force_reduction_timeout" (value != 0) makes the next measurement
+ * passes report what a timed-out wait of the cross-workgroup reduction reports -> lio_measure fails with
+ * LIO_ERR_HIP instead of returning incomplete sums.  Unknown key: LIO_ERR_INVALID_ARG.                       */
+int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
 /* accumulated milliseconds and launch count of one kernel family since the last reset             */
 int  lio_profile_get(lio_ctx* ctx, int which, double* total_ms, long long* launches);
 
@@ -246,7 +261,8 @@ int  lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, dou
                                                  int extrinsic_est_en, lio_update_log* log);
 /* One scan of the node's loop body (laserMapping.cpp:2320-2325 + :2380) in one call: the propagated state and
  * covariance go in (kf.change_x / kf.change_P; NULL = keep the filter's), the down-sampled scan goes in from
- * device memory (lio_scan_set_device), the iterated update runs.  Equivalent to the four calls it names.   */
+ * device memory (lio_scan_set_device; d_body_f4 == NULL: the current scan, e.g. after lio_scan_swap, is kept), the
+ * iterated update runs.  Equivalent to the four calls it names.                                             */
 int  lio_eskf_scan_step_device(lio_eskf* kf, lio_ctx* ctx, const double x26[26], const double P[23 * 23],
                                const void* d_body_f4, int n, double R, int extrinsic_est_en, lio_update_log* log);
 /* esekf::predict(dt, Q, i_in) (esekfom.hpp:280-383) with the process model f / df_dx / df_dw of

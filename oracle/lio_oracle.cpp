@@ -725,6 +725,34 @@ int orc_esti_plane(const float* p, float threshold, float* pabcd) {
     return esti_plane_f(pabcd, pt, threshold) ? 1 : 0;
 }
 
+// Decision-flip audit (bench.py's parity block): per scan point with five gated neighbours, the distances of the
+// fp32 decisions of the path to their thresholds -- margin_plane = min_j | |n.p_j + d| - 0.1 | (common_lib.h:530),
+// margin_s = | s - 0.9 | for points whose plane passed (laserMapping.cpp:1927-1930); NaN where the test is not reached.
+void orc_decision_margins(const float* nbr_xyz, const float* nbr_d, const int* nbr_cnt, const float* world,
+                          const float* body, int n, float* margin_plane, float* margin_s) {
+    const int K = 5;
+    const float nanv = std::numeric_limits<float>::quiet_NaN();
+    for (int i = 0; i < n; ++i) {
+        margin_plane[i] = nanv; margin_s[i] = nanv;
+        if (nbr_cnt[i] < K || nbr_d[i * K + K - 1] > 5) continue;                        // :1911
+        P3 pn[5];
+        for (int j = 0; j < K; ++j) pn[j] = {nbr_xyz[(i * K + j) * 3], nbr_xyz[(i * K + j) * 3 + 1], nbr_xyz[(i * K + j) * 3 + 2]};
+        float pabcd[4];
+        const bool ok = esti_plane_f(pabcd, pn, 0.1f);
+        float mp = std::numeric_limits<float>::infinity();
+        for (int j = 0; j < K; ++j) {
+            const float r = std::fabs(pabcd[0] * pn[j].x + pabcd[1] * pn[j].y + pabcd[2] * pn[j].z + pabcd[3]);
+            mp = std::fmin(mp, std::fabs(r - 0.1f));
+        }
+        margin_plane[i] = mp;
+        if (!ok) continue;
+        const float pd2 = pabcd[0] * world[3 * i] + pabcd[1] * world[3 * i + 1] + pabcd[2] * world[3 * i + 2] + pabcd[3];
+        V3 pb{body[3 * i], body[3 * i + 1], body[3 * i + 2]};
+        const float sc = (float)(1 - 0.9 * std::fabs(pd2) / std::sqrt(norm(pb)));
+        margin_s[i] = std::fabs(sc - 0.9f);
+    }
+}
+
 // laserMapping.cpp:1894-1898
 void orc_body_to_world(const double* s14, const float* body, int n, float* world) {
     Pose s = pose_from(s14);

@@ -45,6 +45,9 @@ void   orc_set_external_knn(void* fn, void* handle);
 /* ---- measurement model ------------------------------------------------------------------------ */
 /* esti_plane<float> (include/common_lib.h:506-536); pts = 5 x (x,y,z); returns 1 if plane ok. */
 int    orc_esti_plane(const float* pts5x3, float threshold, float* pabcd);
+/* decision-flip audit: distance of the fp32 plane-inlier (0.1 m) and weight (s > 0.9) decisions to their thresholds */
+void   orc_decision_margins(const float* nbr_xyz, const float* nbr_d, const int* nbr_cnt, const float* world_xyz,
+                            const float* body_xyz, int n, float* margin_plane, float* margin_s);
 /* world transform of laserMapping.cpp:1894-1898; state14 = pos3, rot xyzw, offR xyzw, offT3. */
 void   orc_body_to_world(const double* state14, const float* body_xyz, int n, float* world_xyz);
 

@@ -57,6 +57,7 @@ def lib():
         L.orc_esti_plane.restype = C.c_int
         L.orc_esti_plane.argtypes = [_f32p, C.c_float, _f32p]
         L.orc_body_to_world.argtypes = [_f64p, _f32p, C.c_int, _f32p]
+        L.orc_decision_margins.argtypes = [_f32p, _f32p, _i32p, _f32p, _f32p, C.c_int, _f32p, _f32p]
         L.orc_h_share_model.restype = C.c_int
         L.orc_h_share_model.argtypes = [C.c_void_p, _f64p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         _f32p, _f32p, _i32p, _u8p, _f32p, _f32p, _f32p, _f64p, _f64p,
@@ -130,6 +131,16 @@ def esti_plane(pts5, threshold: float = 0.1):
     out = np.zeros(4, np.float32)
     ok = lib().orc_esti_plane(_c32(pts5).reshape(5, 3), threshold, out)
     return bool(ok), out
+
+
+def decision_margins(nbr_xyz, nbr_d, nbr_cnt, world, body):
+    """(margin_plane, margin_s): distance of each point's 0.1 m inlier test / s > 0.9 test to its threshold."""
+    n = len(world)
+    mp = np.zeros(n, np.float32)
+    ms = np.zeros(n, np.float32)
+    lib().orc_decision_margins(_c32(nbr_xyz), _c32(nbr_d), np.ascontiguousarray(nbr_cnt, np.int32), _c32(world), _c32(body),
+                               n, mp, ms)
+    return mp, ms
 
 
 def body_to_world(state14, body):
@@ -239,6 +250,7 @@ def ref_lib():
         L.ref_ikd_destroy.argtypes = [C.c_void_p]
         L.ref_ikd_set_downsample.argtypes = [C.c_void_p, C.c_float]
         L.ref_ikd_build.argtypes = [C.c_void_p, _f32p, C.c_int]
+        L.ref_ikd_reconstruct.argtypes = [C.c_void_p, _f32p, C.c_int]
         L.ref_ikd_size.restype = C.c_int
         L.ref_ikd_size.argtypes = [C.c_void_p]
         L.ref_ikd_validnum.restype = C.c_int
@@ -275,6 +287,10 @@ class RefIkdTree:
     def build(self, xyz):
         xyz = _c32(xyz)
         self.L.ref_ikd_build(self.h, xyz, len(xyz))
+
+    def reconstruct(self, xyz):
+        xyz = _c32(xyz)
+        self.L.ref_ikd_reconstruct(self.h, xyz, len(xyz))
 
     def add(self, xyz, downsample_on: bool) -> int:
         xyz = _c32(xyz)

@@ -37,6 +37,9 @@ void ref_ikd_set_downsample(void* h, float box_length) {
 void ref_ikd_build(void* h, const float* xyz, int n) {          // ikd_Tree.cpp:353
     static_cast<Tree*>(h)->Build(to_vec(xyz, n));
 }
+void ref_ikd_reconstruct(void* h, const float* xyz, int n) {    // ikd_Tree.cpp:1394 (caller laserMapping.cpp:656)
+    static_cast<Tree*>(h)->reconstruct(to_vec(xyz, n));
+}
 int ref_ikd_size(void* h) { return static_cast<Tree*>(h)->size(); }          // ikd_Tree.cpp:79
 int ref_ikd_validnum(void* h) { return static_cast<Tree*>(h)->validnum(); }  // ikd_Tree.cpp:129
 

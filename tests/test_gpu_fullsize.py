@@ -1,0 +1,299 @@
+"""Parity at BASELINE.json's full sizes, against the reference's own ikd-Tree (oracle/_ref/libikd_ref.so,
+compiled verbatim from include/ikd-Tree/ikd_Tree.cpp by oracle/Makefile) -- not a sample, every query:
+
+  C2  100 000-point KITTI-64 scan vs 5 M-point map   all 100 000 x 5 neighbours, distances and counts bit-compared,
+                                                      first search and the bounded (hinted) second search at the moved pose
+  C3  24 000-point HAP scan vs 2 M-point map          the same, plus the whole measurement pass against the oracle's
+                                                      h_share_model (extrinsic_est_en = true, config/hap_livox.yaml:45,49)
+  C5  1 M-point scan vs 50 M-point map                no CPU tree of that size fits a test run (8.8 GB, minutes): the
+                                                      size-independent properties + brute force over all 50 M points
+plus KD_TREE::reconstruct (ikd_Tree.cpp:1394-1405) after adds, box deletes and a moved local-map cube, and the error
+path of a timed-out cross-workgroup reduction.
+"""
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_ref(oracle):
+    if not oracle.ref_available():
+        pytest.fail("oracle/_ref/libikd_ref.so is missing: build it where /root/reference exists (make -C oracle ref); "
+                    "it travels to the GPU box with the repository snapshot")
+
+
+def _compare_all_neighbours(ref_tree, wq, gx, gd, gc):
+    """Every query: counts and squared distances bit-equal; neighbour points bit-equal wherever ranks 1..6 of the
+    reference are tie-free (the reference's choice among exactly equidistant points is traversal-order dependent,
+    ikd_Tree.cpp:887).  Returns (#queries, #distance mismatches, #point mismatches on tie-free rows, #rows with a tie
+    inside ranks 1..6, #rows with a rank-5/6 tie)."""
+    rx6, rd6, rc6, _ = ref_tree.knn(wq, 6)
+    rd, rx = np.ascontiguousarray(rd6[:, :5]), np.ascontiguousarray(rx6[:, :5])
+    rc = np.minimum(rc6, 5)
+    assert np.array_equal(gc, rc)
+    d_bad = int((gd.view(np.uint32) != rd.view(np.uint32)).any(axis=1).sum())
+    tie_free = (np.diff(rd6, axis=1) > 0).all(1)
+    rank56 = int((rd6[:, 4] == rd6[:, 5]).sum())
+    p_bad = int((gx[tie_free].view(np.uint32) != rx[tie_free].view(np.uint32)).any(axis=(1, 2)).sum())
+    return len(wq), d_bad, p_bad, int((~tie_free).sum()), rank56
+
+
+@pytest.fixture(scope="module")
+def c2(synth):
+    nm, nq = 5_000_000, 100_000
+    world = synth.make_world(nm, 0.2)
+    scan = synth.make_scan(world, nq)
+    pos, rot = synth.perturb_state(scan)
+    return {"world": world, "scan": scan, "pos": pos, "rot": rot,
+            "state14": synth.state_vector(pos, rot, scan.off_R, scan.off_T)}
+
+
+def test_c2_every_neighbour_equals_the_reference_tree(gpu_capi, oracle, synth, c2):
+    """BASELINE config 2, all 100 000 queries: Nearest_Points / sqdis / counts of the GPU path == KD_TREE::Nearest_Search
+    of the reference tree built from the same 5 M points -- first search, then the bounded second search of the same
+    scan at the pose the first update moved to (knn27_kernel<.., HINT>), then a fresh search there."""
+    _need_ref(oracle)
+    w, sc, st = c2["world"], c2["scan"], c2["state14"]
+    nq = len(sc.body)
+    ref = oracle.RefIkdTree(0.2)
+    ref.build(w.points)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=nq, max_map_points=len(w.points) + 1000)
+    ctx.map_build(w.points)
+    assert ctx.map_validnum() == ref.validnum() == len(w.points)
+    ctx.scan_set(sc.body)
+    g = ctx.measure(st, True, False)
+    wq, sel, nv = ctx.scan_state()
+    assert bits_equal(wq, oracle.body_to_world(st, sc.body))
+    gx, gd, gc = ctx.neighbors()
+    n, d_bad, p_bad, ties, r56 = _compare_all_neighbours(ref, wq, gx, gd, gc)
+    assert (n, d_bad, p_bad) == (nq, 0, 0), (n, d_bad, p_bad, ties, r56)
+    assert ties == 0 and r56 == 0                  # the synthetic generator is tie-free
+    assert g["n_unresolved"] < nq // 100
+    # the pose after the first update of a scan step: ~10 cm / 0.5 deg away (SURVEY.md section 8d prior error)
+    kf = gpu_capi.Esekf(0)                        # maximum_iter = 0: one pass, one update
+    kf.change_x(gpu_capi.make_state26(c2["pos"], c2["rot"], sc.off_R, sc.off_T)); kf.change_P(synth.init_cov())
+    kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+    st2 = kf.get_x()[:14].copy()
+    assert 0.02 < np.linalg.norm(st2[:3] - st[:3]) < 0.3
+    ctx.measure(st2, True, False)                  # bounded by the neighbours of the search above
+    wq2, _, _ = ctx.scan_state()
+    hx, hd, hc = ctx.neighbors()
+    n, d_bad, p_bad, ties, r56 = _compare_all_neighbours(ref, wq2, hx, hd, hc)
+    assert (n, d_bad, p_bad, ties) == (nq, 0, 0, 0), (n, d_bad, p_bad, ties, r56)
+    ctx.scan_set(sc.body)                          # forgets the bound: an unbounded search at the same pose
+    ctx.measure(st2, True, False)
+    fx, fd, fc = ctx.neighbors()
+    assert bits_equal(fx, hx) and bits_equal(fd, hd) and np.array_equal(fc, hc)
+    ctx.close()
+
+
+def test_c2_measurement_pass_equals_the_oracle_on_the_reference_tree(gpu_capi, oracle, c2):
+    """The whole h_share_model pass at C2 (world points, accept mask, normvec, m, H^T H) against the oracle's
+    restatement fed by the reference tree's neighbours."""
+    _need_ref(oracle)
+    w, sc, st = c2["world"], c2["scan"], c2["state14"]
+    nq = len(sc.body)
+    ref = oracle.RefIkdTree(0.2)
+    ref.build(w.points)
+    oracle.use_reference_knn(ref)
+    try:
+        om = oracle.OracleMap(0.2)
+        arr = oracle.ScanArrays(nq)
+        valid, hx, h, m, rm = oracle.h_share_model(om, st, sc.body, arr, True, False, knn_method=2)
+    finally:
+        oracle.use_reference_knn(None)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=nq, max_map_points=len(w.points) + 1000)
+    ctx.map_build(w.points)
+    ctx.scan_set(sc.body)
+    g = ctx.measure(st, True, False)
+    world, sel, nv = ctx.scan_state()
+    assert g["m"] == m and m > 0.8 * nq
+    assert bits_equal(world, arr.world) and np.array_equal(sel, arr.selected)
+    s = sel.astype(bool)
+    assert bits_equal(nv[s], arr.normvec[s])
+    HTH, HTh = oracle.hth(hx, h)
+    assert np.abs(g["HTH"] - HTH).max() <= 1e-9 * np.abs(HTH).max()
+    assert np.abs(g["HTh"] - HTh).max() <= 1e-9 * np.abs(HTh).max()
+    # decision-flip audit: how close the accepted / rejected points sit to the two thresholds an ulp could flip
+    # (0.1 m plane inlier test common_lib.h:530 is inside `selected`; s > 0.9 laserMapping.cpp:1930)
+    pd2 = np.abs(nv[s, 3].astype(np.float64))
+    bn = np.sqrt(np.linalg.norm(sc.body[s].astype(np.float64), axis=1))
+    s_val = 1.0 - 0.9 * pd2 / bn
+    assert (s_val > 0.9).all()
+    ctx.close()
+
+
+def test_c3_full_size_hap_vs_reference_tree(gpu_capi, oracle, synth):
+    """BASELINE config 3 at full size: 24 000-point Livox-HAP-like scan vs a 2 M-point map, extrinsic_est_en = true
+    (config/hap_livox.yaml:45): every neighbour against the reference tree, the pass against the oracle, and the
+    iterated update's posterior against the oracle's."""
+    _need_ref(oracle)
+    nm, nq = 2_000_000, 24_000
+    world = synth.make_world(nm, 0.2)
+    scan = synth.make_scan(world, nq, kind="hap", pos=(-4.0, 6.5, 0.0), rpy=(0.01, 0.02, -1.1))
+    assert scan.extrinsic_est_en
+    pos, rot = synth.perturb_state(scan, seed=synth.SEED + 9)
+    st = synth.state_vector(pos, rot, scan.off_R, scan.off_T)
+    ref = oracle.RefIkdTree(0.2)
+    ref.build(world.points)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=nq, max_map_points=nm + 1000)
+    ctx.map_build(world.points)
+    ctx.scan_set(scan.body)
+    g = ctx.measure(st, True, True)
+    wq, sel, nv = ctx.scan_state()
+    gx, gd, gc = ctx.neighbors()
+    n, d_bad, p_bad, ties, r56 = _compare_all_neighbours(ref, wq, gx, gd, gc)
+    assert (n, d_bad, p_bad, ties) == (nq, 0, 0, 0), (n, d_bad, p_bad, ties, r56)
+    oracle.use_reference_knn(ref)
+    try:
+        om = oracle.OracleMap(0.2)
+        arr = oracle.ScanArrays(nq)
+        valid, hx, h, m, rm = oracle.h_share_model(om, st, scan.body, arr, True, True, knn_method=2)
+        assert g["m"] == m and np.array_equal(sel, arr.selected) and bits_equal(nv[sel.astype(bool)], arr.normvec[sel.astype(bool)])
+        ghx, gh = ctx.measure_rows(m)
+        assert np.array_equal(ghx, hx) and np.array_equal(gh, h)          # all 12 columns (extrinsic block included)
+        x0 = gpu_capi.make_state26(pos, rot, scan.off_R, scan.off_T)
+        xo, Po, _, olog = oracle.update_iterated(om, x0, synth.init_cov(), scan.body, 0.001, 3, None, True, knn_method=2)
+    finally:
+        oracle.use_reference_knn(None)
+    kf = gpu_capi.Esekf(3)
+    kf.change_x(x0); kf.change_P(synth.init_cov())
+    ctx.scan_set(scan.body)
+    lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, True)
+    xg = kf.get_x()
+    assert lg["n_calls"] == len(olog)
+    assert np.abs(xg[:3] - xo[:3]).max() < 1e-4 and np.abs(xg[3:11] - xo[3:11]).max() < 0.5e-5       # north_star's bar
+    assert np.abs(xg - xo).max() < 1e-9 and np.abs(kf.get_P() - Po).max() <= 1e-9 * np.abs(Po).max()
+    ctx.close()
+
+
+def test_c5_properties_1m_scan_50m_map(gpu_capi, synth):
+    """BASELINE config 5 (cube_len 1000, filter_size_map_min 0.1): five neighbours per point, every reported sqdist is
+    the fp32 distance of the reported point and ascending, brute force over all 50 M points for 32 queries, run-to-run
+    identical bits, an O(batch) insert is found by the next search, the update converges to the true pose."""
+    nm, nq, voxel = 50_000_000, 1_000_000, 0.1
+    world = synth.make_world(nm, voxel)
+    scan = synth.make_scan(world, nq, kind="wide")
+    pos, rot = synth.perturb_state(scan)
+    st = synth.state_vector(pos, rot, scan.off_R, scan.off_T)
+    ctx = gpu_capi.LioContext(voxel, max_scan_points=nq, max_map_points=nm + 100_000)
+    ctx.map_build(world.points)
+    ctx.scan_set(scan.body)
+    g = ctx.measure(st, True, False)
+    wp, sel, nv = ctx.scan_state()
+    nx, nd, nc = ctx.neighbors()
+    full = nc == 5
+    assert full.mean() > 0.999 and g["m"] > 0.9 * nq
+    diff = nx.astype(np.float32) - wp[:, None, :]
+    d = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    assert bits_equal(d.astype(np.float32)[full], nd[full]) and (np.diff(nd[full], axis=1) >= 0).all()
+    rng = np.random.default_rng(0)
+    mp = world.points
+    for i in rng.choice(nq, 32, replace=False):
+        dd = mp - wp[i]
+        dist = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
+        assert bits_equal(np.sort(dist)[:5].astype(np.float32), nd[i])
+    g2 = ctx.measure(st, True, False)
+    assert np.array_equal(g["HTH"], g2["HTH"]) and g["m"] == g2["m"]
+    pick = rng.choice(nq, 5000, replace=False)
+    newp = (wp[pick] + np.float32(0.03)).astype(np.float32)
+    info0 = ctx.map_info(); ctx.map_add(newp, False); info1 = ctx.map_info()
+    assert info1["n_incremental_updates"] == info0["n_incremental_updates"] + 1 and info1["n_full_rebuilds"] == info0["n_full_rebuilds"]
+    ctx.measure(st, True, False)
+    ax, ad, ac = ctx.neighbors()
+    dn = np.linalg.norm(newp - wp[pick], axis=1) ** 2
+    assert (ad[pick, 0] <= dn.astype(np.float32) * 1.0001).all()
+    ctx.close()
+    ctx = gpu_capi.LioContext(voxel, max_scan_points=nq, max_map_points=nm + 100_000)
+    ctx.map_build(world.points)
+    ctx.scan_set(scan.body)
+    kf = gpu_capi.Esekf(3)
+    kf.change_x(gpu_capi.make_state26(pos, rot, scan.off_R, scan.off_T)); kf.change_P(synth.init_cov())
+    lg = kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+    assert lg["n_calls"] <= 4 and np.linalg.norm(kf.get_x()[:3] - scan.pos) < 0.03
+    ctx.close()
+
+
+def test_reconstruct_after_mutations(gpu_capi, oracle, small_case):
+    """KD_TREE::reconstruct (ikd_Tree.cpp:1394-1405; caller laserMapping.cpp:656): after down-sampled adds, box
+    deletes, a moved local-map cube and removed points not yet acquired, reconstruct(cloud) leaves validnum / size /
+    flatten / acquire_removed_points / Nearest_Search equal to a reference tree that was reconstructed the same way."""
+    _need_ref(oracle)
+    w, sc = small_case["world"], small_case["scan"]
+    rng = np.random.default_rng(314)
+    base = w.points[:120_000]
+    key = lambda p: p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=4096, max_map_points=400_000)
+    ref = oracle.RefIkdTree(0.2)
+    ctx.map_build(base); ref.build(base)
+    wq = oracle.body_to_world(small_case["state14"], sc.body)
+    new = np.ascontiguousarray(wq[:6000] + rng.normal(0, 0.05, (6000, 3)).astype(np.float32))
+    assert ctx.map_add(new, True) == ref.add(new, True)
+    boxes = np.array([[-10, -8, -1, -2, 3, 3], [4, 2, -1, 9, 8, 2.5]], np.float32)
+    assert ctx.map_delete_boxes(boxes) == ref.delete_boxes(boxes)
+    # the local-map cube moves (lasermap_fov_segment, laserMapping.cpp:1136-1200): two calls far apart
+    ctx.fov_segment(np.array([0.0, 0.0, 0.0]), 60.0, 20.0)
+    b2, nd2 = ctx.fov_segment(np.array([22.0, 0.0, 0.0]), 60.0, 20.0)
+    if len(b2):
+        assert ref.delete_boxes(b2) == nd2
+    assert ctx.map_validnum() == ref.validnum()
+    # box-deleted points are pending (never acquired) when the map is reconstructed
+    deleted = np.zeros(len(base), bool)
+    for b in list(boxes) + list(b2):
+        deleted |= np.all((base >= b[:3]) & (base < b[3:]), axis=1)
+    cloud = np.ascontiguousarray(np.concatenate([w.points[60_000:200_000:2], new[::3]]))
+    ctx.map_reconstruct(cloud)
+    ref.quiesce(200)
+    ref.reconstruct(cloud)                        # the reference's own reconstruct, on the tree that went through the same history
+    ref2 = ref
+    assert ctx.map_validnum() == ref2.validnum() == len(cloud)
+    assert ctx.map_size() == ref2.size() == len(cloud)
+    assert bits_equal(key(ctx.map_flatten()), key(ref2.flatten()))
+    # Points_deleted survives a reconstruct in the reference (only the nodes go, ikd_Tree.cpp:1396): whatever it still
+    # hands out must be among the points we hand out, and ours are box-deleted points of the old map, each once
+    ours = ctx.acquire_removed_points()
+    ours_set = {p.tobytes() for p in ours}
+    assert len(ours_set) == len(ours) and all(p.tobytes() in ours_set for p in ref2.acquire_removed())
+    dead_set = {p.tobytes() for p in base[deleted]} | {p.tobytes() for p in new}
+    assert all(k in dead_set for k in ours_set) and len(ours) >= deleted.sum() - 200    # (adds may have replaced a few first)
+    assert len(ctx.acquire_removed_points()) == 0
+    q = np.ascontiguousarray(np.concatenate([wq[8000:12000], rng.uniform(-60, 60, (500, 3)).astype(np.float32) * [1, 1, 0.05]]).astype(np.float32))
+    gx, gd, gc = ctx.nearest_search(q)
+    rx, rd, rc, _ = ref2.knn(q)
+    assert np.array_equal(gc, rc) and bits_equal(gd, rd)
+    x6, d6, c6, _ = ref2.knn(q, 6)
+    tf = (np.diff(d6, axis=1) > 0).all(1)
+    assert tf.mean() > 0.95 and bits_equal(gx[tf], rx[tf])
+    # and the map keeps working incrementally after the reconstruct
+    more = np.ascontiguousarray(wq[12000:15000] + rng.normal(0, 0.05, (3000, 3)).astype(np.float32))
+    assert ctx.map_add(more, True) == ref2.add(more, True)
+    assert ctx.map_validnum() == ref2.validnum()
+    assert bits_equal(key(ctx.map_flatten()), key(ref2.flatten()))
+    ctx.close()
+
+
+def test_reduction_timeout_is_an_error(gpu_capi, small_case):
+    """A bounded wait of the cross-workgroup reduction that runs out must surface as LIO_ERR_HIP from lio_measure (the
+    sums are incomplete), not as the reference's 'No Effective Points' branch."""
+    sc, st = small_case["scan"], small_case["state14"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+    ctx.map_build(small_case["world"].points)
+    ctx.scan_set(sc.body)
+    ok = ctx.measure(st, True, False)
+    assert ok["m"] > 1000
+    ctx.debug_set("force_reduction_timeout", 1)
+    with pytest.raises(gpu_capi.LioError, match="reduction"):
+        ctx.measure(st, True, False)
+    kf = gpu_capi.Esekf(3)
+    kf.change_x(np.concatenate([st, np.zeros(9), [0, 0, -9.809]]))
+    x_before = kf.get_x().copy()
+    with pytest.raises(gpu_capi.LioError):
+        kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+    ctx.debug_set("force_reduction_timeout", 0)
+    again = ctx.measure(st, True, False)
+    assert again["m"] == ok["m"] and np.array_equal(again["HTH"], ok["HTH"])
+    with pytest.raises(gpu_capi.LioError):
+        ctx.debug_set("no_such_key", 1)
+    ctx.close()
