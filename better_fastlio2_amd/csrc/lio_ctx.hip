@@ -44,7 +44,7 @@ struct lio_ctx {
     uint32_t* d_rank = nullptr;                // iota scratch of the index build
     void* d_temp = nullptr;
     size_t temp_bytes = 0;
-    uint32_t* d_counters = nullptr;            // [0] n_unresolved, [2..3] delete / build scratch, [4] run counts, [7] removed points
+    uint32_t* d_counters = nullptr;            // [0] n_unresolved, [2..3] delete / build scratch, [4] run counts, [7] removed points, [16] walked queries of a search pass
     unsigned long long* d_cand = nullptr;
     float* d_boxes = nullptr;                  // up to 64 boxes
     uint32_t n_points = 0, n_live = 0, n_cells = 0;   // slots in use (live + tomb-stones + retired copies), live points, cells
@@ -84,6 +84,10 @@ struct lio_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copy = nullptr;
     int nq_back = -1;                          // points in the back buffer (-1: nothing uploaded)
+    bool upload_pending = false;               // lio_scan_upload_async was called, the copy has not been issued yet
+    const void* upload_src = nullptr;
+    int upload_n = 0;
+    bool pass_in_flight = false, pass_empty = false;   // between lio_measure_begin and lio_measure_end
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
     float4* d_ulist = nullptr;                 // queries the 27-cell kernel could not prove (count: d_counters[0])
     double* d_rows = nullptr;
@@ -143,6 +147,7 @@ struct lio_ctx {
     unsigned prof = 0;                         // bit w set: time kernel family w
     bool census = false;                       // count C(q) in the k-NN kernel (one atomic per wavefront)
     int dbg_force_timeout = 0;                 // lio_debug_set("force_reduction_timeout")
+    int dbg_separate_walk = 0;                 // lio_debug_set("separate_tree_walk"): the stand-alone knn_tree_kernel per search pass
     std::vector<hipEvent_t> ev_pool[LIO_PROF_COUNT];   // start, stop, start, stop, ...
     size_t ev_next[LIO_PROF_COUNT]{};          // events of the pool in use
     double prof_ms[LIO_PROF_COUNT]{};
@@ -500,28 +505,32 @@ KernelTimer prof_timer(lio_ctx* c, int which) {
     return t;
 }
 
-// k-NN of nq world/body queries into (nbr, cnt); queries_world must hold the world points when
-// body == nullptr, and receives them otherwise.
+// k-NN of nq world/body queries into (nbr, cnt); queries_world must hold the world points when body == nullptr, and
+// receives them otherwise (the kernel transforms).  walk_now: settle the unproven queries with the stand-alone tree
+// kernel; otherwise they stay listed (count in d_counters[0], cnt marked CNT_UNPROVEN) for the measurement kernel of
+// the pass, which carries the walk itself.
+TreeArgs tree_args(lio_ctx* c, int nq, int stride, float4* nbr, uint8_t* cnt, float4* ulist) {
+    TreeArgs ta{};
+    ta.map_pts = c->d_pts; ta.child = c->d_child; ta.ltable = c->d_ltable; ta.levels = c->levels; ta.grid = c->grid;
+    ta.ulist = ulist; ta.n_unres = c->d_counters;
+    ta.nq = nq; ta.nq_stride = stride; ta.nbr = nbr; ta.cnt = cnt;
+    return ta;
+}
 int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14& pose, int nq, int stride,
-            float4* nbr, uint8_t* cnt, float4* ulist, bool use_hint) {
+            float4* nbr, uint8_t* cnt, float4* ulist, bool use_hint, bool walk_now) {
     hipStream_t s = c->stream;
     // d_counters[0] / d_cand are zero here: zeroed at creation and re-zeroed by whoever consumes them
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
     KnnArgs ka{};
     ka.map_pts = c->d_pts; ka.grid = c->grid;
     ka.l1table = c->d_ltable + c->levels.off[1]; ka.l1mask = c->levels.mask[1]; ka.child = c->d_child;
-    if (body != nullptr) HIPCHK(c, launch_transform(body, nq, pose, queries_world, s));
-    ka.world_in = queries_world;
+    ka.world_in = queries_world; ka.body = body; ka.world_out = queries_world; ka.pose = pose;
     ka.nq = nq; ka.nq_stride = stride;
     ka.nbr = nbr; ka.cnt = cnt; ka.ulist = ulist; ka.n_unres = c->d_counters; ka.cand_total = c->census ? c->d_cand : nullptr;
     ka.use_hint = use_hint ? 1 : 0;
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
-    TreeArgs ta{};
-    ta.map_pts = c->d_pts; ta.child = c->d_child; ta.ltable = c->d_ltable; ta.levels = c->levels; ta.grid = c->grid;
-    ta.ulist = ulist; ta.n_unres = c->d_counters;
-    ta.nq = nq; ta.nq_stride = stride; ta.nbr = nbr; ta.cnt = cnt;
-    HIPCHK(c, launch_knn_tree(ta, s, prof_timer(c, LIO_PROF_FALLBACK)));
+    if (walk_now) HIPCHK(c, launch_knn_tree(tree_args(c, nq, stride, nbr, cnt, ulist), s, prof_timer(c, LIO_PROF_FALLBACK)));
     return LIO_OK;
 }
 
@@ -602,8 +611,8 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     c->child_blocks_cap = 4096;
     CREATE_CHK(hipMalloc((void**)&c->d_child, c->child_blocks_cap * 64 * sizeof(uint2)));
     CREATE_CHK(hipMemset(c->d_child, 0, c->child_blocks_cap * 64 * sizeof(uint2)));
-    CREATE_CHK(hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)));
-    CREATE_CHK(hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_counters, 32 * sizeof(uint32_t)));
+    CREATE_CHK(hipMemset(c->d_counters, 0, 32 * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_cand, sizeof(unsigned long long)));
     CREATE_CHK(hipMemset(c->d_cand, 0, sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc((void**)&c->d_boxes, 64 * 6 * sizeof(float)));
@@ -1139,7 +1148,7 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
     int rc = upload_points(c, q_xyz, (size_t)n, stride_bytes, c->d_qs_world);
     if (rc != LIO_OK) return rc;
     Pose14 ident{};
-    rc = run_knn(c, nullptr, c->d_qs_world, ident, n, n, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, false);
+    rc = run_knn(c, nullptr, c->d_qs_world, ident, n, n, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, false, true);
     if (rc != LIO_OK) return rc;
     const size_t b_xyz = (size_t)n * K * 3 * sizeof(float), b_d = (size_t)n * K * sizeof(float), b_c = (size_t)n * sizeof(int);
     rc = ensure_scratch(c, b_xyz + b_d + b_c);
@@ -1187,20 +1196,31 @@ int lio_scan_set_device(lio_ctx* c, const void* d_body_f4, int n) {
 int lio_scan_size(lio_ctx* c) { return c ? c->nq : 0; }
 
 // ---- pipelined hand-over: the next scan travels while the current one is being processed --------------------
+static int issue_pending_upload(lio_ctx* c) {
+    c->upload_pending = false;
+    // the back buffer is not read by anything in flight: the scan step that used it last has returned to the caller
+    if (c->upload_n > 0)
+        HIPCHK(c, hipMemcpyAsync(c->d_body_back, c->upload_src, (size_t)c->upload_n * sizeof(float4), hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_copy, c->copy_stream));
+    c->nq_back = c->upload_n;
+    return LIO_OK;
+}
 int lio_scan_upload_async(lio_ctx* c, const void* host_f4, int n) {
     if (!c || n < 0 || (n > 0 && !host_f4)) return LIO_ERR_INVALID_ARG;
     if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_upload_async", "n exceeds max_scan_points");
-    HIPCHK(c, hipSetDevice(c->device));
-    // the back buffer is not read by anything in flight: the scan step that used it last has returned to the caller
-    if (n > 0) HIPCHK(c, hipMemcpyAsync(c->d_body_back, host_f4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->copy_stream));
-    HIPCHK(c, hipEventRecord(c->ev_copy, c->copy_stream));
-    c->nq_back = n;
+    // The copy is issued by the next measurement pass right behind its kernel launches (the runtime calls then run
+    // beside the GPU's work), or by lio_scan_swap if no pass comes first.
+    c->upload_pending = true; c->upload_src = host_f4; c->upload_n = n;
     return LIO_OK;
 }
 int lio_scan_swap(lio_ctx* c) {
     if (!c) return LIO_ERR_INVALID_ARG;
-    if (c->nq_back < 0) return c->fail(LIO_ERR_NO_SCAN, "lio_scan_swap", "no scan was uploaded with lio_scan_upload_async");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->upload_pending) {
+        const int rc = issue_pending_upload(c);
+        if (rc != LIO_OK) return rc;
+    }
+    if (c->nq_back < 0) return c->fail(LIO_ERR_NO_SCAN, "lio_scan_swap", "no scan was uploaded with lio_scan_upload_async");
     // usually the copy finished long ago (it ran beside the previous scan step): then the host has seen it complete
     // and everything launched from here on is ordered behind it; otherwise the compute stream waits for the event
     const hipError_t q = hipEventQuery(c->ev_copy);
@@ -1397,23 +1417,28 @@ int lio_scan_get_cloud(lio_ctx* c, int which, float* out_xyz, int cap, int* n) {
     return LIO_OK;
 }
 
-int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrinsic_est_en, lio_out* out) {
-    if (!c || !state14 || !out) return LIO_ERR_INVALID_ARG;
+// One pass = lio_measure_begin (enqueue the kernels, return at once) + lio_measure_end (wait for the result record).
+// The host work of the caller that does not depend on the result -- in the iterated update: x [-] x_prop, the
+// Jacobian-corrected P and its first inversion (esekfom.hpp:1655-1703, :1788) -- runs between the two, beside the GPU.
+int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int extrinsic_est_en) {
+    if (!c || !state14) return LIO_ERR_INVALID_ARG;
+    if (c->pass_in_flight) return c->fail(LIO_ERR_INVALID_ARG, "lio_measure_begin", "the previous pass has not been collected (lio_measure_end)");
     if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "no scan set");
     if (!do_search && !c->have_search) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "first pass of a scan must search");
     HIPCHK(c, hipSetDevice(c->device));
-    std::memset(out, 0, sizeof(*out));
     const int nq = c->nq;
-    if (nq == 0) { out->valid = 0; return LIO_OK; }       // "No Effective Points" laserMapping.cpp:1956
-    hipStream_t s = c->stream;
     Pose14 pose;
     for (int i = 0; i < 14; ++i) pose.v[i] = state14[i];
     const bool ext = extrinsic_est_en != 0;
+    c->last_pose = pose; c->last_ext = ext;
+    c->pass_in_flight = true; c->pass_empty = nq == 0;
+    if (nq == 0) return LIO_OK;                               // "No Effective Points" laserMapping.cpp:1956
+    hipStream_t s = c->stream;
 
     if (do_search) {
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
-        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->hint_valid);
-        if (rc != LIO_OK) return rc;
+        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->hint_valid, c->dbg_separate_walk != 0);
+        if (rc != LIO_OK) { c->pass_in_flight = false; return rc; }
         c->have_search = true; c->hint_valid = true;
     }
     ResidualArgs ra{};
@@ -1422,7 +1447,34 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     const unsigned long long seq = ++c->seq;
     ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
     ra.debug_fail = c->dbg_force_timeout;
-    HIPCHK(c, launch_residual(ra, do_search != 0, ext, s, prof_timer(c, LIO_PROF_RESIDUAL)));
+    if (do_search && !c->dbg_separate_walk) {
+        ra.n_walkers = residual_walkers(nq); ra.walk_done = c->d_counters + 16;
+        ra.tree = tree_args(c, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist);
+    }
+    const hipError_t le = launch_residual(ra, do_search != 0, ext, s, prof_timer(c, LIO_PROF_RESIDUAL));
+    if (le != hipSuccess) { c->pass_in_flight = false; return c->fail(LIO_ERR_HIP, "launch_residual", hipGetErrorString(le)); }
+    // the next scan's upload, if one was handed over (lio_scan_upload_async): issued here, behind this pass's
+    // launches, so that the runtime calls of the copy run while the GPU is busy with the pass
+    if (c->upload_pending) {
+        const int rc = issue_pending_upload(c);
+        if (rc != LIO_OK) {                                   // the pass itself is fine: collect it, report the copy
+            const std::string why = c->err;
+            lio_out dropped;
+            (void)lio_measure_end(c, &dropped);
+            return c->fail(rc, "lio_scan_upload_async", why.c_str());
+        }
+    }
+    return LIO_OK;
+}
+
+int lio_measure_end(lio_ctx* c, lio_out* out) {
+    if (!c || !out) return LIO_ERR_INVALID_ARG;
+    if (!c->pass_in_flight) return c->fail(LIO_ERR_INVALID_ARG, "lio_measure_end", "no pass in flight (lio_measure_begin)");
+    c->pass_in_flight = false;
+    std::memset(out, 0, sizeof(*out));
+    if (c->pass_empty) { out->valid = 0; return LIO_OK; }
+    hipStream_t s = c->stream;
+    const unsigned long long seq = c->seq;
     // The record lands in host-mapped memory; poll its sequence number instead of paying for a
     // device-to-host copy plus a stream synchronisation.  hipStreamQuery guards against a fault.
     {
@@ -1444,7 +1496,7 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
 
     const DeviceOut& d = *c->h_out;
     if (d.n_unresolved < 0) return c->fail(LIO_ERR_HIP, "lio_measure", "tree walk exceeded its stack bound");
-    if (d.m < 0) return c->fail(LIO_ERR_HIP, "lio_measure", "cross-workgroup reduction: a bounded wait ran out (sums incomplete)");
+    if (d.m < 0) return c->fail(LIO_ERR_HIP, "lio_measure", "a bounded wait inside the measurement kernel ran out (sums incomplete)");
     out->m = d.m;
     out->valid = d.m >= 1 ? 1 : 0;                        // laserMapping.cpp:1956-1961
     out->n_unresolved = d.n_unresolved;
@@ -1452,8 +1504,15 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     std::memcpy(out->HTH, d.HTH, sizeof(out->HTH));
     std::memcpy(out->HTh, d.HTh, sizeof(out->HTh));
     out->n_candidates = d.n_candidates;
-    c->last_pose = pose; c->last_ext = ext; c->last_m = d.m; c->have_pass = true;
+    c->last_m = d.m; c->have_pass = true;
     return LIO_OK;
+}
+
+int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrinsic_est_en, lio_out* out) {
+    if (!c || !state14 || !out) return LIO_ERR_INVALID_ARG;
+    const int rc = lio_measure_begin(c, state14, do_search, extrinsic_est_en);
+    if (rc != LIO_OK) return rc;
+    return lio_measure_end(c, out);
 }
 
 int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_major) {
@@ -1558,6 +1617,7 @@ int lio_profile_enable(lio_ctx* c, int on) {
 int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (!c || !key) return LIO_ERR_INVALID_ARG;
     if (std::strcmp(key, "force_reduction_timeout") == 0) { c->dbg_force_timeout = value != 0; return LIO_OK; }
+    if (std::strcmp(key, "separate_tree_walk") == 0) { c->dbg_separate_walk = value != 0; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "unknown key");
 }
 int lio_census_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; c->census = on != 0; return LIO_OK; }
@@ -1612,25 +1672,33 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
                                                 lio_update_log* log) {
     if (!kf || !ctx || !(R > 0.0)) return LIO_ERR_INVALID_ARG;
     int status = LIO_OK;
-    // the reference's h_share_model, bound to the GPU path (laserMapping.cpp:1876 <-> lio_measure)
-    kf->kf.set_measurement_model([&](lio::state_ikfom& s, lio::dyn_share_datastruct& d) {
-        double pose[14];
-        s.pose14(pose);
-        lio_out o;
-        const int rc = lio_measure(ctx, pose, d.converge ? 1 : 0, extrinsic_est_en, &o);
-        if (rc != LIO_OK) { status = rc; d.valid = false; d.m = 0; return; }
-        d.valid = o.valid != 0;
-        d.m = o.m;
-        d.res_mean = o.res_mean;
-        std::memcpy(d.HTH, o.HTH, sizeof(d.HTH));
-        std::memcpy(d.HTh, o.HTh, sizeof(d.HTh));
-        if (d.valid && o.m < lio::DOF) {                    // dense-gain branch needs the rows
-            d.h_x.assign((size_t)o.m * 12, 0.0);
-            d.h.assign((size_t)o.m, 0.0);
-            const int rc2 = lio_measure_rows(ctx, d.h_x.data(), d.h.data(), o.m, 0);
-            if (rc2 != LIO_OK) { status = rc2; d.valid = false; }
-        }
-    });
+    // the reference's h_share_model, bound to the GPU path (laserMapping.cpp:1876 <-> lio_measure), in two halves so
+    // that the filter's result-independent algebra runs while the GPU works on the pass
+    kf->kf.set_measurement_model_async(
+        [&](lio::state_ikfom& s, const lio::dyn_share_datastruct& d) {
+            if (status != LIO_OK) return;
+            double pose[14];
+            s.pose14(pose);
+            const int rc = lio_measure_begin(ctx, pose, d.converge ? 1 : 0, extrinsic_est_en);
+            if (rc != LIO_OK) status = rc;
+        },
+        [&](lio::dyn_share_datastruct& d) {
+            if (status != LIO_OK) { d.valid = false; d.m = 0; return; }
+            lio_out o;
+            const int rc = lio_measure_end(ctx, &o);
+            if (rc != LIO_OK) { status = rc; d.valid = false; d.m = 0; return; }
+            d.valid = o.valid != 0;
+            d.m = o.m;
+            d.res_mean = o.res_mean;
+            std::memcpy(d.HTH, o.HTH, sizeof(d.HTH));
+            std::memcpy(d.HTh, o.HTh, sizeof(d.HTh));
+            if (d.valid && o.m < lio::DOF) {                    // dense-gain branch needs the rows
+                d.h_x.assign((size_t)o.m * 12, 0.0);
+                d.h.assign((size_t)o.m, 0.0);
+                const int rc2 = lio_measure_rows(ctx, d.h_x.data(), d.h.data(), o.m, 0);
+                if (rc2 != LIO_OK) { status = rc2; d.valid = false; }
+            }
+        });
     double solve_time = 0.0;
     kf->kf.update_iterated_dyn_share_modified(R, solve_time);
     if (log) {

@@ -601,36 +601,50 @@ void esekf::update_iterated_dyn_share_modified(double R, double& solve_time) {
         dyn_share.valid = true;
         const double t_meas = now_seconds();
         if (dyn_share.converge) ++stats_.n_search;
-        h_dyn_share_(x_, dyn_share);                         // :1639
-        stats_.measure_seconds += now_seconds() - t_meas;
-        ++stats_.n_calls;
-        stats_.last_m = dyn_share.m;
-        stats_.last_res_mean = dyn_share.res_mean;
-        if (!dyn_share.valid) continue;                      // :1641-1644
+        // Two-phase measurement model (the GPU path): the pass is enqueued, the part of the update that does not
+        // depend on its result is computed beside it, then the result is collected.  With a plain callback the same
+        // statements simply run after it -- the arithmetic and its order are identical either way.
+        if (h_begin_) h_begin_(x_, dyn_share);               // :1639 (first half)
+        else h_dyn_share_(x_, dyn_share);
 
-        const double solve_start = now_seconds();
-        const int dof_Measurement = dyn_share.m;             // :1653
+        double solve_overlapped = now_seconds();
         double dx[DOF];
         x_.boxminus(dx, x_propagated);                       // :1655
-        for (int k = 0; k < DOF; ++k) dx_new[k] = dx[k];
-        std::memcpy(P_, P_propagated, sizeof(P_));           // :1660
-
+        double dx_new_w[DOF], P_w[DOF * DOF];
+        for (int k = 0; k < DOF; ++k) dx_new_w[k] = dx[k];
+        std::memcpy(P_w, P_propagated, sizeof(P_w));         // :1660
         for (int idx : kSO3Index) {                          // :1665-1680
             const M3 J = transpose(A_matrix(v3(dx[idx], dx[idx + 1], dx[idx + 2])));
-            const V3 seg = J * v3(dx_new[idx], dx_new[idx + 1], dx_new[idx + 2]);
-            dx_new[idx] = seg.a[0]; dx_new[idx + 1] = seg.a[1]; dx_new[idx + 2] = seg.a[2];
-            rows_times<3>(P_, idx, J);
-            cols_times_T<3>(P_, idx, J);
+            const V3 seg = J * v3(dx_new_w[idx], dx_new_w[idx + 1], dx_new_w[idx + 2]);
+            dx_new_w[idx] = seg.a[0]; dx_new_w[idx + 1] = seg.a[1]; dx_new_w[idx + 2] = seg.a[2];
+            rows_times<3>(P_w, idx, J);
+            cols_times_T<3>(P_w, idx, J);
         }
         {                                                    // :1684-1703
             const int idx = kS2Index;
             const Mat<2, 2> J = S2_Nx_yy(v3(x_.grav)) * S2_Mx(v3(x_propagated.grav), dx[idx], dx[idx + 1]);
-            const double d0 = J(0, 0) * dx_new[idx] + J(0, 1) * dx_new[idx + 1];
-            const double d1 = J(1, 0) * dx_new[idx] + J(1, 1) * dx_new[idx + 1];
-            dx_new[idx] = d0; dx_new[idx + 1] = d1;
-            rows_times<2>(P_, idx, J);
-            cols_times_T<2>(P_, idx, J);
+            const double d0 = J(0, 0) * dx_new_w[idx] + J(0, 1) * dx_new_w[idx + 1];
+            const double d1 = J(1, 0) * dx_new_w[idx] + J(1, 1) * dx_new_w[idx + 1];
+            dx_new_w[idx] = d0; dx_new_w[idx + 1] = d1;
+            rows_times<2>(P_w, idx, J);
+            cols_times_T<2>(P_w, idx, J);
         }
+        double PR[DOF * DOF], P_temp[DOF * DOF];             // (P_/R).inverse()                    :1788
+        for (int k = 0; k < DOF * DOF; ++k) PR[k] = P_w[k] / R;
+        invert23(PR, P_temp);
+        solve_overlapped = now_seconds() - solve_overlapped;
+
+        if (h_begin_) h_end_(dyn_share);                     // :1639 (second half: wait for the pass)
+        stats_.measure_seconds += now_seconds() - t_meas - (h_begin_ ? 0.0 : solve_overlapped);
+        ++stats_.n_calls;
+        stats_.last_m = dyn_share.m;
+        stats_.last_res_mean = dyn_share.res_mean;
+        if (!dyn_share.valid) continue;                      // :1641-1644 (nothing of this pass is kept)
+
+        const double solve_start = now_seconds() - solve_overlapped;
+        const int dof_Measurement = dyn_share.m;             // :1653
+        for (int k = 0; k < DOF; ++k) dx_new[k] = dx_new_w[k];
+        std::memcpy(P_, P_w, sizeof(P_));
 
         if (DOF > dof_Measurement) {
             // fewer rows than states: K = P H^T (H P H^T / R + I)^-1 / R, H zero-padded   :1720-1750
@@ -670,9 +684,7 @@ void esekf::update_iterated_dyn_share_modified(double R, double& solve_time) {
             }
         } else {
             // information form                                                      :1788-1815
-            double PR[DOF * DOF], P_temp[DOF * DOF], P_inv12[DOF * 12];
-            for (int k = 0; k < DOF * DOF; ++k) PR[k] = P_[k] / R;
-            invert23(PR, P_temp);              // (P_/R).inverse()
+            double P_inv12[DOF * 12];
             for (int a = 0; a < 12; ++a)
                 for (int b = 0; b < 12; ++b) P_temp[a * DOF + b] += dyn_share.HTH[a * 12 + b];   // :1791
             // :1808 P_inv = P_temp.inverse(); only its first 12 columns are used (:1810, :1815)

@@ -83,7 +83,14 @@ class esekf {
 public:
     esekf();
     void init_dyn_share(measurementModel_dyn_share h, int maximum_iteration, const double limit_vector[DOF]);
-    void set_measurement_model(measurementModel_dyn_share h) { h_dyn_share_ = std::move(h); }
+    void set_measurement_model(measurementModel_dyn_share h) { h_dyn_share_ = std::move(h); h_begin_ = nullptr; h_end_ = nullptr; }
+    // Two-phase form for an asynchronous measurement model: begin(s, d) enqueues the pass for state s (reads
+    // d.converge), end(d) waits for it and fills d.  Between the two the update computes what does not depend on the
+    // result (x [-] x_prop, the Jacobian-corrected P, its first inversion): same arithmetic, overlapped with the pass.
+    void set_measurement_model_async(std::function<void(state_ikfom&, const dyn_share_datastruct&)> begin,
+                                     std::function<void(dyn_share_datastruct&)> end) {
+        h_begin_ = std::move(begin); h_end_ = std::move(end);
+    }
     // R = LASER_POINT_COV (laserMapping.cpp:14, :2380)
     void update_iterated_dyn_share_modified(double R, double& solve_time);
     // IMU propagation over dt with input i_in and process noise Q (12 x 12 row-major), esekfom.hpp:280-383
@@ -100,6 +107,8 @@ private:
     double limit_[DOF];
     int maximum_iter_ = 0;
     measurementModel_dyn_share h_dyn_share_;
+    std::function<void(state_ikfom&, const dyn_share_datastruct&)> h_begin_;
+    std::function<void(dyn_share_datastruct&)> h_end_;
     update_stats stats_;
 };
 

@@ -15,7 +15,10 @@ struct KnnArgs {
     uint32_t         l1mask;
     const uint2*     child;         // [blocks][64] {start, count} of the level-0 cells of a level-1 cell
     Grid             grid;
-    const float4*    world_in;      // queries in the world frame
+    const float4*    world_in;      // queries in the world frame (body == nullptr)
+    const float4*    body;          // or: feats_down_body -- the kernel transforms with `pose` itself (one wavefront per
+    float4*          world_out;     //     workgroup, fp64 -> fp32, laserMapping.cpp:1894-1899) and writes feats_down_world
+    Pose14           pose;
     int              nq;
     int              nq_stride;     // leading dimension of nbr
     float4*          nbr;           // [5][nq_stride]: x, y, z, sqdist of the k-th neighbour
@@ -25,8 +28,6 @@ struct KnnArgs {
     unsigned long long* cand_total; // device counter: sum of C(q)
     int              use_hint;      // nbr/cnt hold this scan's previous neighbours: bound the search with them
 };
-// feats_down_world = pose (x) feats_down_body, fp64 -> fp32 (laserMapping.cpp:1894-1899)
-hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float4* world, hipStream_t s);
 // lanes_per_query in {4, 8, 16, 32, 64}
 // optional per-launch timing: when `start` is set the kernel is dispatched through hipExtLaunchKernelGGL,
 // which stamps the two events with the dispatch's own begin/end (no marker packets around the kernel)
@@ -34,6 +35,7 @@ struct KernelTimer { hipEvent_t start = nullptr, stop = nullptr; };
 hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s, KernelTimer t = KernelTimer());
 
 // hashed 64-ary tree: level L = grid coarsened by 4^L, tables of levels 1.. live in one buffer
+constexpr uint8_t CNT_UNPROVEN = 0x80;  // or-ed into cnt[q] by knn27_kernel: the tree walk still owes this query
 struct TreeArgs {
     const float4*    map_pts;
     const uint2*     child;         // cell directory blocks (level-0 cells), see lio_device.h
@@ -70,8 +72,15 @@ struct ResidualArgs {
     DeviceOut*     out;             // host-mapped result record
     unsigned long long seq;         // published last (system-scope release) in out->seq
     int            debug_fail;      // test hook (lio_debug_set "force_reduction_timeout"): report a timed-out wait
+    // search passes: the exact tree walk of the queries the 27-cell kernel could not prove runs INSIDE this launch, on
+    // the first n_walkers workgroups (one walking wavefront each); a model workgroup that owns such a query (marked in
+    // cnt by CNT_UNPROVEN) waits until every listed query has been walked (walk_done == number of listed queries)
+    int            n_walkers;       // 0: no walk in this launch (the stand-alone knn_tree_kernel ran, or a no-search pass)
+    uint32_t*      walk_done;       // device counter: walked queries of this pass (reset by the last workgroup)
+    TreeArgs       tree;            // map index + the list (tree.nbr / tree.cnt = the scan's neighbour arrays)
 };
 int residual_blocks(int nq);
+int residual_walkers(int nq);       // walking workgroups a search pass adds in front of the model workgroups
 hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s, KernelTimer t = KernelTimer());
 
 // ---- map construction / mutation ----------------------------------------------------------------

@@ -121,8 +121,26 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     const bool active = q < a.nq;
 
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-    if (active) {
-        const float4 w = a.world_in[q];            // world-frame query (transform_kernel / caller)
+    if (a.body != nullptr) {
+        // feats_down_world = pose (x) feats_down_body (laserMapping.cpp:1894-1899) for the WPB * GPW (<= 64) queries of
+        // this workgroup, by its first wavefront: the fp64 transform is issued once per workgroup instead of once per
+        // G-lane group (a separate 3 us launch before; every lane repeating it cost 2.6 us of this kernel's VALU time)
+        __shared__ float s_q[WPB * GPW][3];
+        if (wave == 0 && lane < WPB * GPW) {
+            const int qi = blockIdx.x * (WPB * GPW) + lane;
+            if (qi < a.nq) {
+                const float4 b = a.body[qi];
+                const PoseQ s = pose_unpack(a.pose);
+                float wx, wy, wz;
+                body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
+                a.world_out[qi] = make_float4(wx, wy, wz, b.w);
+                s_q[lane][0] = wx; s_q[lane][1] = wy; s_q[lane][2] = wz;
+            }
+        }
+        __syncthreads();
+        if (active) { qx = s_q[wave * GPW + g][0]; qy = s_q[wave * GPW + g][1]; qz = s_q[wave * GPW + g][2]; }
+    } else if (active) {
+        const float4 w = a.world_in[q];            // world-frame query (the caller's)
         qx = w.x; qy = w.y; qz = w.z;
     }
     const float inv_cell = a.grid.inv_cell;
@@ -138,7 +156,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         uint32_t db = 0u;
         bool have = false;
         if (active) {
-            have = a.cnt[q] >= K;
+            have = (a.cnt[q] & ~CNT_UNPROVEN) >= K;
             for (int k = r; k < K; k += G) {           // G < K (4 lanes per query): lane 0 measures two
                 const float4 p = a.nbr[(size_t)k * a.nq_stride + q];
                 const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
@@ -317,7 +335,6 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
 
     // ---- proof: every point outside the searched block is farther than the 5th neighbour ------
     if (active && r == 0) {
-        a.cnt[q] = (uint8_t)nvalid;
         const float cell = a.grid.cell;
         bool proven = false;
         if (nvalid == K && cx >= 1 && cy >= 1 && cz >= 1 && (uint32_t)cx < CELL_MAX &&
@@ -330,7 +347,10 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             // a point outside has |delta| >= gmin on one axis -> its computed sqdist >= fl(gmin*gmin)
             proven = __uint_as_float(d5bits) < gmin * gmin;
         }
-        if (!proven) {                             // unproven queries are redone by knn_tree_kernel
+        // unproven queries are redone by the exact tree walk (inside the measurement kernel of the pass, or
+        // knn_tree_kernel); until then their count carries the mark the owner of the query looks for
+        a.cnt[q] = (uint8_t)nvalid | (proven ? (uint8_t)0 : CNT_UNPROVEN);
+        if (!proven) {
             const uint32_t slot = atomicAdd(a.n_unres, 1u);
             a.ulist[slot] = make_float4(qx, qy, qz, __uint_as_float((uint32_t)q));
         }
@@ -358,22 +378,6 @@ static void launch_knn27_g(const KnnArgs& a, hipStream_t s, KernelTimer t) {
     else if (a.use_hint)         hipLaunchKernelGGL((knn27_kernel<G, false, true>), grid, block, 0, s, a);
     else                         hipLaunchKernelGGL((knn27_kernel<G, false, false>), grid, block, 0, s, a);
 }
-// feats_down_world = pose (x) feats_down_body (laserMapping.cpp:1894-1899), one lane per point
-__global__ __launch_bounds__(256) void transform_kernel(const float4* body, int n, Pose14 pose, float4* world) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float4 b = body[i];
-    const PoseQ s = pose_unpack(pose);
-    float wx, wy, wz;
-    body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
-    world[i] = make_float4(wx, wy, wz, b.w);
-}
-hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float4* world, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(transform_kernel, dim3((n + 255) / 256), dim3(256), 0, s, body, n, pose, world);
-    return hipGetLastError();
-}
-
 hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s, KernelTimer t) {
     if (a.nq <= 0) return hipSuccess;
     switch (lanes_per_query) {

@@ -14,8 +14,11 @@
 //       the read: no arrival counters), the last one expands the symmetric matrix and writes the DeviceOut record straight into
 //       host-mapped memory, publishing it with a system-scope release of a sequence number: one
 //       launch per pass, no separate reduction kernel, no device-to-host copy.
-#include "lio_kernels.h"
-#include "lio_math.h"
+//       A search pass also carries the exact tree walk (lio_tree.h) of the queries the 27-cell kernel could not
+//       prove: the first n_walkers workgroups of the grid walk the listed queries (one wavefront each) while the
+//       model workgroups already work; only a model workgroup that OWNS such a query (cnt marked CNT_UNPROVEN)
+//       waits for the walk -- this replaced a separate 7 us launch for ~40 of 100 000 queries.
+#include "lio_tree.h"
 
 namespace lio {
 
@@ -50,15 +53,49 @@ __device__ __forceinline__ void entry_columns(int e, int& ca, int& cb) {
     }
 }
 
+template <bool EXT, int BS> struct ModelSmem {
+    typedef RedShape<EXT, BS> S;
+    double rows[BS][S::NCOLS];
+    double part[S::SEG][S::NEP];
+    double own[S::NEP];
+    double fin[S::NEP];
+};
+
 template <bool EXT, bool SEARCH, int BS>
 __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     typedef RedShape<EXT, BS> S;
-    __shared__ double s_rows[BS][S::NCOLS];
-    __shared__ double s_part[S::SEG][S::NEP];
-
+    // a workgroup is either a walker (TreeScratch, search passes only) or a model workgroup: one LDS allocation
+    constexpr size_t SMEM = SEARCH && sizeof(TreeScratch) > sizeof(ModelSmem<EXT, BS>) ? sizeof(TreeScratch) : sizeof(ModelSmem<EXT, BS>);
+    __shared__ __align__(16) unsigned char s_raw[SMEM];
+    __shared__ uint32_t s_failed;                  // a bounded wait ran out (reported, never silent)
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * BS + tid;
-    __shared__ uint32_t s_failed;                  // a bounded wait of the reduction ran out (reported, never silent)
+    constexpr unsigned SPIN_LIMIT = 1u << 18;
+
+    // ---- walkers: the exact tree walk of the listed queries, one wavefront per workgroup -------------------------
+    const int n_walkers = SEARCH ? a.n_walkers : 0;
+    if (SEARCH && (int)blockIdx.x < n_walkers) {
+        if (tid >= 64) return;
+        TreeScratch& ts = *reinterpret_cast<TreeScratch*>(s_raw);
+        const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;        // complete: written by the k-NN launch before this one
+        uint32_t walked = 0;
+        for (uint32_t e = blockIdx.x; e < n; e += (uint32_t)n_walkers) {
+            const float4 q = a.tree.ulist[e];
+            tree_search_one(a.tree, __float_as_uint(q.w), q.x, q.y, q.z, tid, ts);
+            ++walked;
+        }
+        if (walked != 0 && tid == 0) {
+            // results (plain stores of this wavefront) -> agent-scope release -> drained -> the counter the owners poll
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(a.walk_done, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    ModelSmem<EXT, BS>& sm = *reinterpret_cast<ModelSmem<EXT, BS>*>(s_raw);
+    double (&s_rows)[BS][S::NCOLS] = sm.rows;
+    double (&s_part)[S::SEG][S::NEP] = sm.part;
+    const int bid = (int)blockIdx.x - n_walkers;   // index among the model workgroups
+    const int i = bid * BS + tid;
     if (tid == 0) s_failed = 0u;
     bool sel = false;
     double row[12];
@@ -67,40 +104,69 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
 #pragma unroll
     for (int c = 0; c < 12; ++c) row[c] = 0.0;
 
-    if (i < a.nq) {
-        // every load of this point is issued up front (one memory round trip instead of a dependent chain -- the
-        // kernel is latency-bound at ~1.5 waves per SIMD).  A search pass fits the plane through the five neighbours;
-        // the passes after it re-evaluate only the points it accepted (:1916), on the SAME neighbours, so the plane
-        // they would re-fit is the one stored here (16 bytes instead of 80, no QR).
-        const float4 b = a.body[i];
-        const PoseQ s = pose_unpack(a.pose);
-        float wx, wy, wz, nx = 0.f, ny = 0.f, nz = 0.f;
-        if (SEARCH) {
-            float4 nb[K];
+    // Every load of a point is issued up front (one memory round trip instead of a dependent chain -- the kernel is
+    // latency-bound at ~1.5 waves per SIMD).  A search pass fits the plane through the five neighbours; the passes
+    // after it re-evaluate only the points it accepted (:1916), on the SAME neighbours, so the plane they would re-fit
+    // is the one stored here (16 bytes instead of 80, no QR).
+    const bool in = i < a.nq;
+    const PoseQ s = pose_unpack(a.pose);
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    float wx = 0.f, wy = 0.f, wz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    if (SEARCH) {
+        float4 nb[K];
+        uint8_t cnt_i = 0;
+        float4 wpt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) {
+            b = a.body[i];
 #pragma unroll
             for (int k = 0; k < K; ++k) nb[k] = a.nbr[(size_t)k * a.nq_stride + i];
-            const uint8_t cnt_i = a.cnt[i];
-            const float4 wpt = a.world[i];        // a search pass already holds feats_down_world (transform_kernel)
-            wx = wpt.x; wy = wpt.y; wz = wpt.z;
-            // points_near.size() < 5 ? false : sqdis[4] > 5 ? false : true          :1911
-            if ((cnt_i >= K) && !(nb[4].w > 5.0f)) {
-                float px[5], py[5], pz[5];
+            cnt_i = a.cnt[i];
+            wpt = a.world[i];                     // a search pass already holds feats_down_world (the k-NN launch wrote it)
+        }
+        // Does this workgroup own a query the walkers still owe (marked by the k-NN kernel)?  Then wait for the walk
+        // (bounded; a timeout is reported like a reduction timeout), acquire, and read those neighbours again.  Walkers
+        // have the lowest workgroup indices, i.e. they are dispatched first.
+        if (n_walkers > 0) {
+            const bool owes = __syncthreads_or((in && (cnt_i & CNT_UNPROVEN) != 0) ? 1 : 0) != 0;
+            if (owes) {
+                if (tid == 0) {
+                    const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(a.walk_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n && ++spins < SPIN_LIMIT)
+                        __builtin_amdgcn_s_sleep(2);
+                    if (spins >= SPIN_LIMIT) s_failed = 1u;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                if (in) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) { px[k] = nb[k].x; py[k] = nb[k].y; pz[k] = nb[k].z; }
-                float pd = 0.0f;
-                sel = point_residual(px, py, pz, wx, wy, wz, b.x, b.y, b.z, nx, ny, nz, pd2, &pd);
-                if (sel) a.plane[i] = make_float4(nx, ny, nz, pd);
-            }
-        } else {
-            const uint8_t sel_prev = a.sel[i];                             // :1916 (previous flag)
-            const float4 pl = a.plane[i];
-            body_to_world(s, b.x, b.y, b.z, wx, wy, wz);                   // :1894-1899
-            a.world[i] = make_float4(wx, wy, wz, b.w);
-            if (sel_prev != 0) {
-                nx = pl.x; ny = pl.y; nz = pl.z;
-                sel = residual_from_plane(pl.x, pl.y, pl.z, pl.w, wx, wy, wz, b.x, b.y, b.z, pd2);
+                    for (int k = 0; k < K; ++k) nb[k] = a.nbr[(size_t)k * a.nq_stride + i];
+                    cnt_i = a.cnt[i];
+                }
             }
         }
+        wx = wpt.x; wy = wpt.y; wz = wpt.z;
+        // points_near.size() < 5 ? false : sqdis[4] > 5 ? false : true          :1911
+        if (in && ((cnt_i & ~CNT_UNPROVEN) >= K) && !(nb[4].w > 5.0f)) {
+            float px[5], py[5], pz[5];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { px[k] = nb[k].x; py[k] = nb[k].y; pz[k] = nb[k].z; }
+            float pd = 0.0f;
+            sel = point_residual(px, py, pz, wx, wy, wz, b.x, b.y, b.z, nx, ny, nz, pd2, &pd);
+            if (sel) a.plane[i] = make_float4(nx, ny, nz, pd);
+        }
+    } else if (in) {
+        b = a.body[i];
+        const uint8_t sel_prev = a.sel[i];                             // :1916 (previous flag)
+        const float4 pl = a.plane[i];
+        body_to_world(s, b.x, b.y, b.z, wx, wy, wz);                   // :1894-1899
+        a.world[i] = make_float4(wx, wy, wz, b.w);
+        if (sel_prev != 0) {
+            nx = pl.x; ny = pl.y; nz = pl.z;
+            sel = residual_from_plane(pl.x, pl.y, pl.z, pl.w, wx, wy, wz, b.x, b.y, b.z, pd2);
+        }
+    }
+    if (in) {
         if (sel) {
             a.normvec[i] = make_float4(nx, ny, nz, pd2);                   // :1933-1936
             jacobian_row<EXT>(s, b.x, b.y, b.z, nx, ny, nz, pd2, row, h);
@@ -142,17 +208,16 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     // Workgroups are dispatched in index order and a reducer only ever waits for lower indices, so what it
     // waits for is running or done.  Every sum has a fixed order; the waits are bounded (a timeout is reported).
     typedef unsigned long long u64;
-    __shared__ double s_own[S::NEP];
-    const int nblocks = (int)gridDim.x;
-    const int grp = (int)blockIdx.x / RED_GROUP;
+    double (&s_own)[S::NEP] = sm.own;
+    const int nblocks = (int)gridDim.x - n_walkers;
+    const int grp = bid / RED_GROUP;
     const int ngroups = (nblocks + RED_GROUP - 1) / RED_GROUP;
     const int grp_first = grp * RED_GROUP;
     const int grp_size = (grp_first + RED_GROUP <= nblocks) ? RED_GROUP : nblocks - grp_first;
-    const bool grp_reducer = (int)blockIdx.x == grp_first + grp_size - 1;
-    const bool final_reducer = (int)blockIdx.x == nblocks - 1;
+    const bool grp_reducer = bid == grp_first + grp_size - 1;
+    const bool final_reducer = bid == nblocks - 1;
     const u64 stamp_hi = (u64)(uint32_t)a.seq << 32;
     constexpr u64 HI_MASK = 0xffffffff00000000ull;
-    constexpr unsigned SPIN_LIMIT = 1u << 18;
     if (tid < S::NE) {
         double t = 0.0;
 #pragma unroll
@@ -161,7 +226,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             s_own[tid] = t;                                 // its own partial never leaves the workgroup
         } else {
             const u64 bits = (u64)__double_as_longlong(t);
-            u64* dst = a.units + ((size_t)blockIdx.x * RED_STRIDE + tid) * 2;
+            u64* dst = a.units + ((size_t)bid * RED_STRIDE + tid) * 2;
             __hip_atomic_store(dst + 0, (bits & 0xffffffffull) | stamp_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(dst + 1, (bits >> 32) | stamp_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -226,7 +291,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     __syncthreads();
     s_part[seg][e] = f;
     __syncthreads();
-    __shared__ double s_fin[S::NEP];
+    double (&s_fin)[S::NEP] = sm.fin;
     if (tid < S::NE) {
         double t = 0.0;
 #pragma unroll
@@ -257,7 +322,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             out->n_unresolved = SEARCH ? (int)*a.n_unresolved : 0;
             out->n_candidates = SEARCH ? *a.cand_total : 0ull;
             // consumed: zero the counters for the next pass
-            if (SEARCH) { *a.n_unresolved = 0u; *a.cand_total = 0ull; }
+            if (SEARCH) { *a.n_unresolved = 0u; *a.cand_total = 0ull; if (n_walkers > 0) *a.walk_done = 0u; }
         }
         __threadfence_system();
         if (tid == 0) __hip_atomic_store(&out->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -265,12 +330,20 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
 }
 
 int residual_blocks(int nq) { return (nq + 255) / 256; }
+// walking workgroups of a search pass: one wavefront each; unproven queries are tens per 100 k in-map queries and
+// a few per thousand at the map's edge -- entries beyond the walkers are strided
+int residual_walkers(int nq) {
+    int w = nq / 512;
+    if (w < 32) w = 32;
+    if (w > 1024) w = 1024;
+    return w;
+}
 
 // 256 lanes per workgroup: 512 measured the same and 1024 slower on MI355X (the kernel is a chain of
 // dependent round trips, not throughput-bound)
 template <bool EXT, bool SEARCH>
 static void launch_residual_v(const ResidualArgs& a, hipStream_t s, KernelTimer t) {
-    const dim3 grid(residual_blocks(a.nq)), block(256);
+    const dim3 grid(residual_blocks(a.nq) + (SEARCH ? a.n_walkers : 0)), block(256);
     if (t.start != nullptr) hipExtLaunchKernelGGL((residual_kernel<EXT, SEARCH, 256>), grid, block, 0, s, t.start, t.stop, 0, a);
     else hipLaunchKernelGGL((residual_kernel<EXT, SEARCH, 256>), grid, block, 0, s, a);
 }

@@ -200,6 +200,12 @@ int  lio_scan_get_cloud(lio_ctx* ctx, int which, float* out_xyz, int cap, int* n
 /* One pass.  do_search = ekfom_data.converge (laserMapping.cpp:1906); out->valid = ekfom_data.valid.*/
 int  lio_measure(lio_ctx* ctx, const double state14[14], int do_search, int extrinsic_est_en,
                  lio_out* out);
+/* The same pass in two halves: lio_measure_begin enqueues the kernels and returns at once, lio_measure_end waits for
+ * the result.  Host work that does not depend on the result (in update_iterated_dyn_share_modified: x [-] x_prop, the
+ * Jacobian-corrected P_ and (P_/R).inverse(), esekfom.hpp:1655-1703, :1788) can run between the two, beside the GPU.
+ * Exactly one pass may be in flight per context; every begin must be followed by its end.                  */
+int  lio_measure_begin(lio_ctx* ctx, const double state14[14], int do_search, int extrinsic_est_en);
+int  lio_measure_end(lio_ctx* ctx, lio_out* out);
 /* h_x (m x 12) and h (m) of the LAST lio_measure, compacted in scan order exactly like
  * laserCloudOri / corr_normvect (laserMapping.cpp:1942-2002).  col_major != 0 writes h_x in
  * Eigen's default (column-major, leading dimension m).  cap_rows >= m required.                    */
@@ -228,7 +234,9 @@ int  lio_census_enable(lio_ctx* ctx, int on);
 int  lio_profile_reset(lio_ctx* ctx);
 /* test hooks (never needed by a caller): key "force_reduction_timeout" (value != 0) makes the next measurement
  * passes report what a timed-out wait of the cross-workgroup reduction reports -> lio_measure fails with
- * LIO_ERR_HIP instead of returning incomplete sums.  Unknown key: LIO_ERR_INVALID_ARG.                       */
+ * LIO_ERR_HIP instead of returning incomplete sums; "separate_tree_walk" runs the exact tree walk of a search pass as
+ * its own launch (knn_tree_kernel) instead of inside the measurement kernel (an A/B switch for timing; identical
+ * results).  Unknown key: LIO_ERR_INVALID_ARG.                                                                */
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
 /* accumulated milliseconds and launch count of one kernel family since the last reset             */
 int  lio_profile_get(lio_ctx* ctx, int which, double* total_ms, long long* launches);

@@ -65,6 +65,41 @@ def test_nearest_search_bit_exact(gpu_capi, oracle, small_case, lanes):
     ctx.close()
 
 
+@pytest.mark.parametrize("ext", [False, True])
+def test_tree_walk_inside_the_measurement_kernel(gpu_capi, oracle, small_case, ext):
+    """A search pass walks the queries the 27-cell kernel could not prove INSIDE the measurement kernel (walker
+    workgroups in front of the model workgroups; the owners of such queries wait for them).  With a scan that is
+    mostly edge / far / above-the-map points (thousands of walks, clustered and scattered) the pass must equal the
+    same pass with the stand-alone walk kernel bit for bit, and the neighbours must equal the oracle's."""
+    q = _hard_queries(small_case, oracle)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float64)      # world frame == body frame
+    om = oracle.OracleMap(0.2); om.build(small_case["world"].points)
+    ox, od, oc, _ = om.knn(q)
+    res = {}
+    for separate in (0, 1):
+        ctx = gpu_capi.LioContext(0.2, max_scan_points=len(q), max_map_points=400_000)
+        ctx.map_build(small_case["world"].points)
+        ctx.debug_set("separate_tree_walk", separate)
+        ctx.scan_set(q)
+        g = ctx.measure(ident, True, ext)
+        g2 = ctx.measure(ident, True, ext)          # the bounded re-search walks its unproven queries the same way
+        world, sel, nv = ctx.scan_state()
+        nx, nd, nc = ctx.neighbors()
+        res[separate] = (g, g2, sel, nv, nx, nd, nc)
+        ctx.close()
+    a, b = res[0], res[1]
+    assert a[0]["n_unresolved"] == b[0]["n_unresolved"] > 1000
+    for k in (0, 1):
+        assert a[k]["m"] == b[k]["m"] and np.array_equal(a[k]["HTH"], b[k]["HTH"]) and np.array_equal(a[k]["HTh"], b[k]["HTh"])
+    assert np.array_equal(a[0]["HTH"], a[1]["HTH"])
+    assert np.array_equal(a[2], b[2]) and bits_equal(a[3], b[3])
+    assert bits_equal(a[4], b[4]) and bits_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
+    assert np.array_equal(a[6], oc) and bits_equal(a[5], od)
+    x6, d6, c6, _ = om.knn(q, 6, 1)
+    tie_free = (np.diff(d6, axis=1) > 0).all(1)
+    assert bits_equal(a[4][tie_free], ox[tie_free])
+
+
 @pytest.mark.parametrize("case_name,ext", [("small_case", False), ("small_case", True), ("hap_case", True)])
 def test_measurement_pass_parity(gpu_capi, oracle, request, case_name, ext):
     """h_share_model: search pass, then a no-search pass at a moved pose (reuses neighbours and the
