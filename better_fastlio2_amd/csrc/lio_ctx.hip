@@ -268,6 +268,7 @@ int finish_index(lio_ctx* c, uint32_t n) {
     c->n_points = n; c->n_live = n; c->n_cells = 0;
     c->n_retired = 0; c->n_dead = 0; c->n_new_cells = 0; c->n_cells_built = 0;
     c->grid.n_points = n;
+    HIPCHK(c, hipMemsetAsync(c->d_apply + APPLY_LEVEL_NEW, 0, TREE_MAX_LEVELS * sizeof(uint32_t), s));
     HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_mkeys, n, c->d_cell_keys, c->d_cell_counts,
                                     c->d_counters + 4, s));
     uint32_t n_cells = 0;
@@ -449,7 +450,7 @@ int apply_pending(lio_ctx* c) {
     // entries past the touched cells are zero (written by the plan kernel), so element n of the scan is the total
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pnewsize, c->d_pnewoff, (size_t)n + 1, s));
     HIPCHK(c, launch_cell_apply(a, n, s));
-    uint32_t st[4] = {0, 0, 0, 0};
+    uint32_t st[32] = {};
     HIPCHK(c, read_back(c, st, c->d_apply, sizeof(st)));
     const uint32_t total = st[3];
     if (st[2] & APPLY_FLAG_NO_ROOM) return rebuild_full(c);    // nothing was changed: the pending points go in there
@@ -460,12 +461,12 @@ int apply_pending(lio_ctx* c) {
     c->n_cells += st[0]; c->n_new_cells += st[0]; c->n_retired += st[1];
     ++c->n_incremental_updates;
     const uint32_t retired_budget = c->n_live / 8 > 65536u ? c->n_live / 8 : 65536u;
-    // Every new grid cell adds at most one entry to each hashed level: keep every table at most half full (they are
-    // built a quarter full), so that probe sequences stay short and a look-up of an absent key always meets an empty
-    // slot -- small maps have 64-slot tables that the cell budget below would let run full.
+    // Keep every hashed level at most half full (they are built a quarter full; the apply kernel counts the entries a
+    // level gains), so that probe sequences stay short and a look-up of an absent key always meets an empty slot --
+    // small maps have 64-slot tables that the cell budget below would let run full.
     bool table_crowded = false;
     for (int L = 1; L < c->levels.top_level; ++L)
-        table_crowded = table_crowded || ((size_t)c->level_entries[L] + (size_t)c->n_new_cells) * 2 > (size_t)c->levels.mask[L] + 1;
+        table_crowded = table_crowded || ((size_t)c->level_entries[L] + (size_t)st[APPLY_LEVEL_NEW + L]) * 2 > (size_t)c->levels.mask[L] + 1;
     if (st[2] != 0 || table_crowded || (size_t)c->n_retired + (size_t)c->n_dead > (size_t)retired_budget ||
         (size_t)c->n_new_cells * 4 > (size_t)c->n_cells_built + 1024)
         return rebuild_full(c);
@@ -588,8 +589,8 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     if (c->slots_cap > 0xfffffff0ull) c->slots_cap = 0xfffffff0ull;
     CREATE_CHK(hipMalloc((void**)&c->d_pts, c->slots_cap * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_pts_tmp, c->slots_cap * sizeof(float4)));
-    CREATE_CHK(hipMalloc((void**)&c->d_apply, 16 * sizeof(uint32_t)));
-    CREATE_CHK(hipMemset(c->d_apply, 0, 16 * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_apply, 32 * sizeof(uint32_t)));
+    CREATE_CHK(hipMemset(c->d_apply, 0, 32 * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_mkeys, nm * sizeof(uint64_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_mkeys_tmp, nm * sizeof(uint64_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_vals, nm * sizeof(uint32_t)));

@@ -35,7 +35,9 @@ struct KernelTimer { hipEvent_t start = nullptr, stop = nullptr; };
 hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s, KernelTimer t = KernelTimer());
 
 // hashed 64-ary tree: level L = grid coarsened by 4^L, tables of levels 1.. live in one buffer
-constexpr uint8_t CNT_UNPROVEN = 0x80;  // or-ed into cnt[q] by knn27_kernel: the tree walk still owes this query
+// or-ed into cnt[q] by knn27_kernel: the exact tree walk owes / has answered this query (the walk keeps the mark, every
+// reader of a count masks it)
+constexpr uint8_t CNT_UNPROVEN = 0x80;
 struct TreeArgs {
     const float4*    map_pts;
     const uint2*     child;         // cell directory blocks (level-0 cells), see lio_device.h

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void unpack_neighbors_kernel(const float4* nbr
         }
         if (out_d != nullptr) out_d[(size_t)i * K + k] = p.w;
     }
-    if (out_cnt != nullptr) out_cnt[i] = (int)cnt[i];
+    if (out_cnt != nullptr) out_cnt[i] = (int)(cnt[i] & ~CNT_UNPROVEN);
 }
 
 static inline dim3 grid_for(uint32_t n) {

@@ -61,8 +61,10 @@ struct ApplyArgs {
     uint32_t         tail;          // first free slot of the point array
     uint32_t         slots_cap;     // physical slots of the point array
     uint32_t         n_scan;        // new_off[n_scan] = total number of slots the re-written buckets need
-    uint32_t*        stats;         // [0] new cells, [1] old slots retired, [2] flags (APPLY_FLAG_*), [3] total new slots
+    uint32_t*        stats;         // [0] new cells, [1] old slots retired, [2] flags (APPLY_FLAG_*), [3] total new slots,
+                                    // [APPLY_LEVEL_NEW + L] new entries of level L (not reset per batch)
 };
+constexpr int APPLY_LEVEL_NEW = 16;                // stats[16 + L]: entries hashed level L gained since the last full rebuild
 constexpr uint32_t APPLY_FLAG_OUTSIDE_TOP = 1u;   // a new cell lies outside the root node of the tree
 constexpr uint32_t APPLY_FLAG_TABLE_FULL = 2u;    // an insertion probe wrapped around a table
 constexpr uint32_t APPLY_FLAG_NO_BLOCKS = 8u;     // the pool of child blocks is exhausted

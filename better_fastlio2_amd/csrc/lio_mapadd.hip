@@ -397,12 +397,13 @@ __global__ __launch_bounds__(64) void cell_plan_kernel(ApplyArgs a) {
 }
 
 // find-or-insert of a cell key; returns the slot, or 0xffffffff when the table is full
-__device__ __forceinline__ uint32_t table_claim(HashEntry* table, uint32_t mask, uint64_t key) {
+__device__ __forceinline__ uint32_t table_claim(HashEntry* table, uint32_t mask, uint64_t key, bool& is_new) {
     uint32_t slot = hash_key(key) & mask;
+    is_new = false;
     for (uint32_t probes = 0; probes <= mask; ++probes) {
         unsigned long long* kp = reinterpret_cast<unsigned long long*>(&table[slot]);
         const unsigned long long prev = atomicCAS(kp, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
-        if (prev == KEY_EMPTY || prev == key) return slot;
+        if (prev == KEY_EMPTY || prev == key) { is_new = prev == KEY_EMPTY; return slot; }
         slot = (slot + 1) & mask;
     }
     return 0xffffffffu;
@@ -461,8 +462,10 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
         for (int L = 1; L < a.levels.top_level; ++L) {
             const uint64_t ck = pack_key(cx >> (2 * L), cy >> (2 * L), cz >> (2 * L));
             HashEntry* lt = a.ltable + a.levels.off[L];
-            const uint32_t ls = table_claim(lt, a.levels.mask[L], ck);
+            bool fresh;
+            const uint32_t ls = table_claim(lt, a.levels.mask[L], ck, fresh);
             if (ls == 0xffffffffu) { atomicOr(a.stats + 2, APPLY_FLAG_TABLE_FULL); break; }
+            if (fresh) atomicAdd(a.stats + APPLY_LEVEL_NEW + L, 1u);   // entries this level gained since the last full rebuild
             if (L == 1) {
                 uint32_t* sp = &lt[ls].start;
                 uint32_t blk = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(256) void map_incremental_kernel(IncrArgs a) {
     body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
     a.world[i] = make_float4(wx, wy, wz, 0.0f);
     uint8_t cls = 1;                                            // :1487 (no neighbours / EKF not inited)
-    const int cnt = a.cnt[i];
+    const int cnt = a.cnt[i] & ~CNT_UNPROVEN;      // (the mark of a walked query is not part of the count)
     if (cnt > 0 && a.flg_EKF_inited) {                          // :1453
         const double fs = a.filter_size_map_min;                // a double in the reference (:56)
         const float mx = (float)(floor((double)wx / fs) * fs + 0.5 * fs);   // :1459-1461

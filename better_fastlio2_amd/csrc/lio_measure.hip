@@ -69,7 +69,10 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     __shared__ __align__(16) unsigned char s_raw[SMEM];
     __shared__ uint32_t s_failed;                  // a bounded wait ran out (reported, never silent)
     const int tid = threadIdx.x;
-    constexpr unsigned SPIN_LIMIT = 1u << 18;
+    // bounded waits: seconds, not microseconds -- a pathological search (every query inside a slab of deleted points:
+    // ~1 ms per walk) must still finish; the bound only turns a hang into a reported error
+    constexpr unsigned SPIN_LIMIT = 1u << 22;
+    constexpr double POISON = -1.0e300;           // row count of a workgroup whose bounded wait ran out
 
     // ---- walkers: the exact tree walk of the listed queries, one wavefront per workgroup -------------------------
     const int n_walkers = SEARCH ? a.n_walkers : 0;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             ++walked;
         }
         if (walked != 0 && tid == 0) {
-            // results (plain stores of this wavefront) -> agent-scope release -> drained -> the counter the owners poll
+            // results (write-through stores of this wavefront, lio_tree.h) -> drained -> the counter the owners poll
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(a.walk_done, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -138,10 +141,10 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();
-                if (in) {
+                if (in && (cnt_i & CNT_UNPROVEN) != 0) {   // the walked queries only; written through by the walkers
 #pragma unroll
-                    for (int k = 0; k < K; ++k) nb[k] = a.nbr[(size_t)k * a.nq_stride + i];
-                    cnt_i = a.cnt[i];
+                    for (int k = 0; k < K; ++k) nb[k] = load_walked_neighbor(a.nbr, (size_t)k * a.nq_stride + i);
+                    cnt_i = __hip_atomic_load(a.cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -222,6 +225,9 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         double t = 0.0;
 #pragma unroll
         for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
+        // a wait of THIS workgroup that ran out (the walk above) poisons its row count: the sum of the counts then
+        // comes out negative at the last workgroup, which reports the pass as failed
+        if (tid == S::NE - 1 && s_failed != 0u) t = POISON;
         if (grp_reducer) {
             s_own[tid] = t;                                 // its own partial never leaves the workgroup
         } else {
@@ -275,6 +281,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
 #pragma unroll
         for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
         t += s_own[tid];                                    // workgroups of the group in index order, the reducer's own last
+        if (tid == S::NE - 1 && s_failed != 0u) t = POISON;  // (a fold of this group reducer that ran out)
         if (final_reducer) {
             s_own[tid] = t;
         } else {
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         s_fin[tid] = t + s_own[tid];
     }
     __syncthreads();
-    const bool failed = s_failed != 0u || a.debug_fail != 0;
+    const bool failed = s_failed != 0u || a.debug_fail != 0 || s_fin[S::NE - 1] < -0.5;
     // One wavefront writes the whole record into host-mapped memory, fences at system scope and only
     // then publishes the sequence number the host is polling.
     if (tid < 64) {
@@ -330,12 +337,13 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
 }
 
 int residual_blocks(int nq) { return (nq + 255) / 256; }
-// walking workgroups of a search pass: one wavefront each; unproven queries are tens per 100 k in-map queries and
-// a few per thousand at the map's edge -- entries beyond the walkers are strided
+// walking workgroups of a search pass: one wavefront each (the stand-alone kernel's sizing); unproven queries are tens
+// per 100 k in-map queries and a few per thousand at the map's edge -- entries beyond the walkers are strided.  An idle
+// walker exits at once.
 int residual_walkers(int nq) {
-    int w = nq / 512;
-    if (w < 32) w = 32;
-    if (w > 1024) w = 1024;
+    int w = nq / 256;
+    if (w < 256) w = 256;
+    if (w > 2048) w = 2048;
     return w;
 }
 

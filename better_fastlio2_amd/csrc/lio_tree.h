@@ -122,9 +122,26 @@ __device__ __forceinline__ void write_wave_result(const TreeArgs& a, uint32_t q,
             const float nanv = __uint_as_float(0x7fc00000u);
             o = make_float4(nanv, nanv, nanv, __uint_as_float(INF_BITS));
         }
-        a.nbr[(size_t)lane * a.nq_stride + q] = o;
+        // Results are written THROUGH (agent-scope 8-byte stores; the owner of the query reads them back with agent-scope
+        // loads): a walk may run inside the same launch as its consumer (lio_measure.hip), on another XCD, whose L2 may
+        // still hold the line from before the walk -- plain stores + a release fence were observed stale there.
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.nbr + (size_t)lane * a.nq_stride + q);
+        const unsigned long long lo = ((unsigned long long)__float_as_uint(o.y) << 32) | (unsigned long long)__float_as_uint(o.x);
+        const unsigned long long hi = ((unsigned long long)__float_as_uint(o.w) << 32) | (unsigned long long)__float_as_uint(o.z);
+        __hip_atomic_store(dst + 0, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane == 0) a.cnt[q] = (uint8_t)nvalid;
+    // the mark stays: whoever owns the query decides from the MARK (written by the k-NN launch, i.e. reliably visible)
+    // that it has to wait for the walk
+    if (lane == 0) __hip_atomic_store(a.cnt + q, (uint8_t)((uint8_t)nvalid | CNT_UNPROVEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the owner's side of the hand-off: neighbour k of query q / its count, read past the caches the walk did not write
+__device__ __forceinline__ float4 load_walked_neighbor(const float4* nbr, size_t index) {
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(nbr + index);
+    const unsigned long long lo = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
+                       __uint_as_float((uint32_t)(hi >> 32)));
 }
 
 // LDS of one walking wavefront

@@ -284,7 +284,7 @@ def test_reduction_timeout_is_an_error(gpu_capi, small_case):
     ok = ctx.measure(st, True, False)
     assert ok["m"] > 1000
     ctx.debug_set("force_reduction_timeout", 1)
-    with pytest.raises(gpu_capi.LioError, match="reduction"):
+    with pytest.raises(gpu_capi.LioError, match="bounded wait"):
         ctx.measure(st, True, False)
     kf = gpu_capi.Esekf(3)
     kf.change_x(np.concatenate([st, np.zeros(9), [0, 0, -9.809]]))
