@@ -416,17 +416,17 @@ def main():
             if dist is None:
                 r = ctx.map_incremental(post, voxel, True, apply=True)
             else:
-                from better_fastlio2_amd import replicate
-                pa, na, pb, nb = ctx.map_incremental_device(post, voxel, True)
-                A, _ = replicate.exchange_inserts_device(pa, na, nq, device)
-                B, _ = replicate.exchange_inserts_device(pb, nb, nq, device)
-                torch.cuda.synchronize(device)                 # torch's stream -> the library's stream
-                ctx.map_add_pair_device(A.data_ptr(), A.shape[0], B.data_ptr(), B.shape[0])
-                r = {"n_add": na, "n_nodown": nb}
+                # every rank contributes its lists; every replica applies all of them, rank 0 first.  One ncclAllGather
+                # (RCCL over xGMI) on the library's stream inside liblio_hip.so: no torch, no host copy of the lists
+                r = ctx.replicate_step(post, voxel, True)
             maint["n_add"] += r["n_add"]; maint["n_nodown"] += r["n_nodown"]
             maint["seconds"] += time.perf_counter() - t0
             maint["steps"] += 1
 
+        if dist is not None:
+            uid = [capi.replicate_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.replicate_init(uid[0], rank, world_size)
         k_node = max(8, min(a.steps, 48))
         ctx.profile_enable(False)
         ctx.profile_reset()
@@ -439,7 +439,7 @@ def main():
         extras["node_loop"] = {"value": world_size * k_node / t_node, "unit": "scans/s", "ms_per_step": t_node / k_node * 1e3,
                                "steps": k_node, "map_update_ms_per_step": maint["seconds"] / max(maint["steps"], 1) * 1e3,
                                "inserted_per_step": (maint["n_add"] + maint["n_nodown"]) / max(maint["steps"], 1),
-                               "exchange": "all_gather_into_tensor (RCCL)" if dist is not None else "none (1 rank)",
+                               "exchange": "lio_replicate_step: one ncclAllGather (RCCL over xGMI) on the library's stream" if dist is not None else "none (1 rank)",
                                "incremental_index_updates": info["n_incremental_updates"], "full_index_rebuilds": info["n_full_rebuilds"]}
     else:
         cold_ms = None

@@ -62,7 +62,7 @@ class lio_imu_info(C.Structure):
 # every symbol include/lio_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_stream", "lio_synchronize",
-    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_fov_segment", "lio_map_reconstruct",
+    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_replicate_unique_id", "lio_replicate_init", "lio_replicate_finalize", "lio_replicate_queue_boxes", "lio_replicate_step", "lio_fov_segment", "lio_map_reconstruct",
     "lio_map_set_downsample_param", "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_acquire_removed_points", "lio_map_get_info", "lio_map_nearest_search",
     "lio_scan_set", "lio_scan_set_device", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get", "lio_debug_set",
@@ -117,6 +117,12 @@ def load(build_if_missing: bool = True):
     L.lio_map_build_device.argtypes = [_vp, _vp, C.c_longlong]
     L.lio_map_add.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.lio_map_delete_boxes.argtypes = [_vp, _vp, C.c_int, C.POINTER(C.c_int)]
+    L.lio_replicate_unique_id.argtypes = [_vp]
+    L.lio_replicate_init.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int]
+    L.lio_replicate_finalize.argtypes = [_vp]
+    L.lio_replicate_finalize.restype = None
+    L.lio_replicate_queue_boxes.argtypes = [_vp, _vp, C.c_int]
+    L.lio_replicate_step.argtypes = [_vp, _vp, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lio_map_add_pair.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.lio_map_incremental_device.argtypes = [_vp, _vp, C.c_double, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int), C.POINTER(_vp), C.POINTER(C.c_int)]
     L.lio_map_add_pair_device.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.POINTER(C.c_int)]
@@ -203,6 +209,16 @@ def pinned_points(xyz) -> np.ndarray:
 
 
 _pinned_keepalive = []
+
+
+def replicate_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0); hand the bytes to every rank's replicate_init."""
+    L = load()
+    buf = (C.c_char * 128)()
+    rc = L.lio_replicate_unique_id(buf)
+    if rc != LIO_OK:
+        raise LioError("lio_replicate_unique_id failed (librccl not loadable?)")
+    return bytes(buf)
 
 
 def _ptr(a: np.ndarray):
@@ -310,6 +326,23 @@ class LioContext:
             out["add"] = a[:na.value].copy()
             out["nodown"] = b[:nb.value].copy()
         return out
+
+    # ---- replicated maps (one rank per GPU) ---------------------------------------------------------
+    def replicate_init(self, unique_id: bytes, rank: int, world: int, list_capacity: int = 0):
+        """lio_replicate_init: unique_id = the 128 bytes of replicate_unique_id() made by rank 0 (ignored for world 1)."""
+        buf = (C.c_char * 128).from_buffer_copy(unique_id.ljust(128, b"\0")[:128]) if unique_id else None
+        self._chk(self.L.lio_replicate_init(self.h, buf, rank, world, list_capacity), "lio_replicate_init")
+
+    def replicate_queue_boxes(self, boxes):
+        b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+        self._chk(self.L.lio_replicate_queue_boxes(self.h, _ptr(b), len(b)), "lio_replicate_queue_boxes")
+
+    def replicate_step(self, state14, filter_size_map_min: float = 0.2, flg_EKF_inited: bool = True) -> dict:
+        s = np.ascontiguousarray(state14, dtype=np.float64)
+        na, nb, nd, cnt = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self.L.lio_replicate_step(self.h, _ptr(s), float(filter_size_map_min), int(flg_EKF_inited), C.byref(na),
+                                            C.byref(nb), C.byref(nd), C.byref(cnt)), "lio_replicate_step")
+        return {"n_add": na.value, "n_nodown": nb.value, "n_deleted": nd.value, "add_counter": cnt.value}
 
     def map_delete_boxes(self, boxes) -> int:
         b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)

@@ -2,6 +2,7 @@
 // One context = one GPU = one HIP stream; every device buffer is allocated once at lio_create
 // (capacities from lio_config) so that a scan step performs no allocation.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cmath>
@@ -140,6 +141,14 @@ struct lio_ctx {
     uint32_t *d_add_dlist = nullptr, *d_add_dlist2 = nullptr;
     uint64_t *d_add_keys = nullptr, *d_add_keys2 = nullptr, *d_add_ukeys = nullptr;
     uint32_t *d_add_order = nullptr, *d_add_order2 = nullptr, *d_add_gcount = nullptr, *d_add_gstart = nullptr;
+
+    // ---- replica exchange (lio_replicate_*) ---------------------------------------------
+    void* rep_comm = nullptr;                  // ncclComm_t (RCCL), created by lio_replicate_init
+    int rep_rank = 0, rep_world = 0;           // rep_world == 0: not initialised
+    uint32_t rep_cap = 0;                      // points per list and message
+    float4 *d_rep_send = nullptr, *d_rep_recv = nullptr;
+    float rep_boxes[6 * REP_MAX_BOXES]{};      // delete boxes queued for the next exchange
+    int rep_n_boxes = 0;
 
     // ---- profiling ----------------------------------------------------------------------------
     // one HIP-event pair per timed launch, stamped by the dispatch (hipExtLaunchKernelGGL); resolved when
@@ -650,6 +659,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
 void lio_destroy(lio_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    lio_replicate_finalize(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
@@ -658,7 +668,8 @@ void lio_destroy(lio_ctx* c) {
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
-                   c->d_add_order, c->d_add_order2, c->d_add_gcount, c->d_add_gstart, c->d_add_dirty, c->d_add_dlist, c->d_add_dlist2};
+                   c->d_add_order, c->d_add_order2, c->d_add_gcount, c->d_add_gstart, c->d_add_dirty, c->d_add_dlist, c->d_add_dlist2,
+                   c->d_rep_send, c->d_rep_recv};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -872,13 +883,16 @@ int lio_map_add_pair(lio_ctx* c, const float* add_pts, int n_add, const float* n
 // map_incremental's classification + the two order-preserving lists, left on the device
 // (c->d_add_pts = PointToAdd, c->d_add_pts2 = PointNoNeedDownsample).
 static int map_incremental_lists(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
-                                 uint32_t cnts[2]) {
-    cnts[0] = cnts[1] = 0;
+                                 uint32_t* cnts /* [2], or nullptr: the counts stay in d_counters[5..6] */) {
+    if (cnts) cnts[0] = cnts[1] = 0;
     if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_map_incremental", "no scan set");
     const int nq = c->nq;
-    if (nq == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    if (nq == 0) {
+        if (!cnts) HIPCHK(c, hipMemsetAsync(c->d_counters + 5, 0, 2 * sizeof(uint32_t), s));
+        return LIO_OK;
+    }
     int rc = ensure_add_buffers(c, (size_t)nq);
     if (rc != LIO_OK) return rc;
     if (!c->have_search) {
@@ -893,7 +907,7 @@ static int map_incremental_lists(lio_ctx* c, const double state14[14], double fi
     HIPCHK(c, launch_map_incremental(ia, s));
     HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 1, c->d_add_pts, c->d_counters + 5, (size_t)nq, s));
     HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 2, c->d_add_pts2, c->d_counters + 6, (size_t)nq, s));
-    HIPCHK(c, read_back(c, cnts, c->d_counters + 5, 2 * sizeof(uint32_t)));
+    if (cnts) HIPCHK(c, read_back(c, cnts, c->d_counters + 5, 2 * sizeof(uint32_t)));
     return LIO_OK;
 }
 
@@ -981,6 +995,179 @@ int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const v
     return rebuild_from_stored(c);
 }
 
+// ---- replica exchange behind the C ABI ------------------------------------------------
+static int delete_boxes_resident(lio_ctx* c, int nbb, int* total);
+static void account_deleted(lio_ctx* c, int total);
+// RCCL is loaded at run time (dlopen): a single-GPU user of this library needs no librccl.  `backend "nccl" IS RCCL on
+// ROCm`: a process that already carries one (PyTorch bundles its own librccl.so) shares it through the SONAME.
+namespace {
+typedef struct { char internal[128]; } rep_unique_id;                           // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(rep_unique_id*) = nullptr;
+    int (*CommInitRank)(void**, int, rep_unique_id, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi* rccl_api(std::string* why) {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (api.lib) {
+            api.GetUniqueId = reinterpret_cast<int (*)(rep_unique_id*)>(dlsym(api.lib, "ncclGetUniqueId"));
+            api.CommInitRank = reinterpret_cast<int (*)(void**, int, rep_unique_id, int)>(dlsym(api.lib, "ncclCommInitRank"));
+            api.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(api.lib, "ncclCommDestroy"));
+            api.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(api.lib, "ncclAllGather"));
+            api.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(api.lib, "ncclGetErrorString"));
+        }
+    }
+    if (!api.lib || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) {
+        if (why) *why = api.lib ? "librccl lacks an entry point" : (std::string("librccl.so not loadable: ") + (dlerror() ? dlerror() : ""));
+        return nullptr;
+    }
+    return &api;
+}
+constexpr int RCCL_FLOAT32 = 7;                                               // ncclFloat32 (rccl.h)
+}  // namespace
+
+int lio_replicate_unique_id(void* id128) {
+    if (!id128) return LIO_ERR_INVALID_ARG;
+    RcclApi* r = rccl_api(nullptr);
+    if (!r) return LIO_ERR_HIP;
+    rep_unique_id id;
+    if (r->GetUniqueId(&id) != 0) return LIO_ERR_HIP;
+    std::memcpy(id128, id.internal, sizeof(id.internal));
+    return LIO_OK;
+}
+
+int lio_replicate_init(lio_ctx* c, const void* id128, int rank, int world, int list_capacity) {
+    if (!c || world < 1 || rank < 0 || rank >= world || world * REP_MAX_BOXES > REP_MAX_BOXES_TOTAL || list_capacity < 0 ||
+        (world > 1 && !id128))
+        return LIO_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    lio_replicate_finalize(c);
+    // points per list and rank in one message: a scan inserts a few thousand points (5-30 % of N_q in the reference's
+    // runs); 32 Ki points = 1 MiB per rank and message keeps an 8-rank all-gather at ~8 MiB.  A rank with more points
+    // is flagged, the exchange is repeated with the full scan capacity (lio_replicate_step does that itself).
+    uint32_t cap = list_capacity > 0 ? (uint32_t)list_capacity : 32768u;
+    if (cap > (uint32_t)c->cap_q) cap = (uint32_t)c->cap_q;
+    const size_t msg_f4 = (size_t)REP_HEADER_F4 + 2 * (size_t)c->cap_q;        // buffers sized for the fallback capacity
+    HIPCHK(c, hipMalloc((void**)&c->d_rep_send, msg_f4 * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_rep_recv, msg_f4 * (size_t)world * sizeof(float4)));
+    int rc = ensure_add_buffers(c, (size_t)world * (size_t)c->cap_q);
+    if (rc != LIO_OK) return rc;
+    if (world > 1 || id128 != nullptr) {              // (a single rank WITH an id runs the same collective: tests)
+        std::string why;
+        RcclApi* r = rccl_api(&why);
+        if (!r) return c->fail(LIO_ERR_HIP, "lio_replicate_init", why.c_str());
+        rep_unique_id id;
+        std::memcpy(id.internal, id128, sizeof(id.internal));
+        const int e = r->CommInitRank(&c->rep_comm, world, id, rank);
+        if (e != 0) return c->fail(LIO_ERR_HIP, "ncclCommInitRank", r->GetErrorString ? r->GetErrorString(e) : "failed");
+    }
+    c->rep_rank = rank; c->rep_world = world; c->rep_cap = cap; c->rep_n_boxes = 0;
+    return LIO_OK;
+}
+
+void lio_replicate_finalize(lio_ctx* c) {
+    if (!c) return;
+    if (c->rep_comm) {
+        RcclApi* r = rccl_api(nullptr);
+        if (r) (void)r->CommDestroy(c->rep_comm);
+        c->rep_comm = nullptr;
+    }
+    if (c->d_rep_send) (void)hipFree(c->d_rep_send);
+    if (c->d_rep_recv) (void)hipFree(c->d_rep_recv);
+    c->d_rep_send = nullptr; c->d_rep_recv = nullptr;
+    c->rep_world = 0; c->rep_n_boxes = 0;
+}
+
+int lio_replicate_queue_boxes(lio_ctx* c, const float* minmax6, int nb) {
+    if (!c || nb < 0 || (nb > 0 && !minmax6)) return LIO_ERR_INVALID_ARG;
+    if (c->rep_world == 0) return c->fail(LIO_ERR_INVALID_ARG, "lio_replicate_queue_boxes", "lio_replicate_init has not been called");
+    if (c->rep_n_boxes + nb > REP_MAX_BOXES) return c->fail(LIO_ERR_CAPACITY, "lio_replicate_queue_boxes", "more than 4 boxes queued for one exchange");
+    std::memcpy(c->rep_boxes + 6 * c->rep_n_boxes, minmax6, (size_t)nb * 6 * sizeof(float));
+    c->rep_n_boxes += nb;
+    return LIO_OK;
+}
+
+// One exchange: this rank's two lists (device, counts in d_counters[5..6]) + queued boxes -> message -> ncclAllGather on
+// the library's stream -> concatenation in rank order -> one read-back of the four totals -> Delete_Point_Boxes, then
+// Add_Points(all PointToAdd, true) and Add_Points(all PointNoNeedDownsample, false) on this replica.
+static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4]) {
+    hipStream_t s = c->stream;
+    const size_t msg_f4 = (size_t)REP_HEADER_F4 + 2 * (size_t)cap;
+    RepPackArgs pa{};
+    pa.counts = c->d_counters + 5; pa.cap = cap; pa.add = c->d_add_pts; pa.nodown = c->d_add_pts2;
+    pa.msg = c->rep_comm ? c->d_rep_send : c->d_rep_recv;                     // no communicator: the message IS the gathered buffer
+    std::memcpy(pa.boxes, c->rep_boxes, sizeof(pa.boxes)); pa.n_boxes = c->rep_n_boxes;
+    HIPCHK(c, launch_replicate_pack(pa, s));
+    if (c->rep_comm) {
+        RcclApi* r = rccl_api(nullptr);
+        const int e = r->AllGather(c->d_rep_send, c->d_rep_recv, msg_f4 * 4, RCCL_FLOAT32, c->rep_comm, s);
+        if (e != 0) return c->fail(LIO_ERR_HIP, "ncclAllGather", r->GetErrorString ? r->GetErrorString(e) : "failed");
+    }
+    RepCompactArgs ca{};
+    ca.gathered = c->d_rep_recv; ca.world = c->rep_world; ca.cap = cap; ca.add_out = c->d_add_pts; ca.nodown_out = c->d_add_pts2;
+    ca.boxes_out = c->d_boxes; ca.totals = c->d_counters + 8;
+    HIPCHK(c, launch_replicate_compact(ca, s));
+    HIPCHK(c, read_back(c, tot, c->d_counters + 8, 4 * sizeof(uint32_t)));
+    return LIO_OK;
+}
+
+int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
+                       int* n_add_total, int* n_nodown_total, int* n_deleted, int* add_counter) {
+    if (!c || !state14 || !(filter_size_map_min > 0.0)) return LIO_ERR_INVALID_ARG;
+    if (c->rep_world == 0) return c->fail(LIO_ERR_INVALID_ARG, "lio_replicate_step", "lio_replicate_init has not been called");
+    if (n_add_total) *n_add_total = 0;
+    if (n_nodown_total) *n_nodown_total = 0;
+    if (n_deleted) *n_deleted = 0;
+    if (add_counter) *add_counter = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    // map_incremental's two lists of this rank stay on the device, and so do their counts
+    int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, nullptr);
+    if (rc != LIO_OK) return rc;
+    uint32_t tot[4] = {0, 0, 0, 0};
+    rc = replicate_exchange_apply(c, c->rep_cap, tot);
+    if (rc != LIO_OK) return rc;
+    if ((tot[3] & REP_FLAG_OVERFLOW) != 0 && c->rep_cap < (uint32_t)c->cap_q) {
+        // some rank had more points than a message holds: every rank sees the flag, every rank repeats the exchange at
+        // the full scan capacity (the lists and counters of this rank are still in place: compact wrote elsewhere only
+        // if ... the first round's outputs are overwritten by the second)
+        rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, nullptr);
+        if (rc != LIO_OK) return rc;
+        rc = replicate_exchange_apply(c, (uint32_t)c->cap_q, tot);
+        if (rc != LIO_OK) return rc;
+    }
+    c->rep_n_boxes = 0;
+    if ((size_t)c->n_live + (size_t)tot[0] + (size_t)tot[1] > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "lio_replicate_step", "live points + gathered lists exceed max_map_points");
+    // every replica: the boxes of all ranks (rank order), then the insert lists of all ranks (rank order)
+    int deleted = 0;
+    if (tot[2] > 0 && c->n_points > 0) {
+        c->hint_valid = false;
+        rc = delete_boxes_resident(c, (int)tot[2], &deleted);
+        if (rc != LIO_OK) return rc;
+        account_deleted(c, deleted);
+    }
+    rc = add_batch_device(c, c->d_add_pts, tot[0], true, add_counter);
+    if (rc != LIO_OK) return rc;
+    rc = add_batch_device(c, c->d_add_pts2, tot[1], false, nullptr);
+    if (rc != LIO_OK) return rc;
+    rc = rebuild_from_stored(c);
+    if (n_add_total) *n_add_total = (int)tot[0];
+    if (n_nodown_total) *n_nodown_total = (int)tot[1];
+    if (n_deleted) *n_deleted = deleted;
+    return rc;
+}
+
 int lio_map_set_downsample_param(lio_ctx* c, float downsample_size) {
     if (!c || !(downsample_size > 0.0f)) return LIO_ERR_INVALID_ARG;
     if (c->n_points == 0 && c->cfg.cell_size == 0.0f) {       // nothing indexed yet: the grid may still follow
@@ -996,6 +1183,20 @@ int lio_map_set_downsample_param(lio_ctx* c, float downsample_size) {
 long long lio_map_size(lio_ctx* c) { return c ? (long long)c->n_points - (long long)c->n_retired : 0; }
 long long lio_map_validnum(lio_ctx* c) { return c ? (long long)c->n_live : 0; }
 
+// Delete_by_range over the boxes already sitting in c->d_boxes (<= 64)
+static int delete_boxes_resident(lio_ctx* c, int nbb, int* total) {
+    HIPCHK(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(c, launch_delete_boxes(c->d_pts, c->n_points, c->d_boxes, nbb, c->d_counters + 2, c->stream));
+    uint32_t cnt = 0;
+    HIPCHK(c, read_back(c, &cnt, c->d_counters + 2, sizeof(uint32_t)));
+    *total += (int)cnt;
+    return LIO_OK;
+}
+static void account_deleted(lio_ctx* c, int total) {
+    c->n_live -= (uint32_t)total;
+    c->box_deleted_pending += (uint32_t)total;
+    c->n_dead += (uint32_t)total;              // dead slots count towards the budget that triggers the next full rebuild
+}
 int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_deleted) {
     if (!c || nb < 0 || (nb > 0 && !minmax6)) return LIO_ERR_INVALID_ARG;
     if (n_deleted) *n_deleted = 0;
@@ -1007,15 +1208,10 @@ int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_delete
         const int nbb = nb - b0 < 64 ? nb - b0 : 64;
         HIPCHK(c, hipMemcpyAsync(c->d_boxes, minmax6 + 6 * (size_t)b0, (size_t)nbb * 6 * sizeof(float),
                                  hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(uint32_t), c->stream));
-        HIPCHK(c, launch_delete_boxes(c->d_pts, c->n_points, c->d_boxes, nbb, c->d_counters + 2, c->stream));
-        uint32_t cnt = 0;
-        HIPCHK(c, read_back(c, &cnt, c->d_counters + 2, sizeof(uint32_t)));
-        total += (int)cnt;
+        const int rc = delete_boxes_resident(c, nbb, &total);
+        if (rc != LIO_OK) return rc;
     }
-    c->n_live -= (uint32_t)total;
-    c->box_deleted_pending += (uint32_t)total;
-    c->n_dead += (uint32_t)total;              // dead slots count towards the budget that triggers the next full rebuild
+    account_deleted(c, total);
     if (n_deleted) *n_deleted = total;
     return LIO_OK;
 }

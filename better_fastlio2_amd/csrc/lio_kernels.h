@@ -109,6 +109,32 @@ hipError_t launch_mark_reported(float4* pts, uint32_t n, hipStream_t s);
 hipError_t launch_unpack_neighbors(const float4* nbr, const uint8_t* cnt, int nq, int nq_stride,
                                    float* out_xyz, float* out_d, int* out_cnt, hipStream_t s);
 
+// ---- replica exchange (lio_replicate.hip) -------------------------------------------------
+constexpr int REP_HEADER_F4 = 8;             // float4s in front of the lists: {n_add, n_nodown, n_boxes, flags}, 24 floats of boxes, pad
+constexpr int REP_MAX_BOXES = 4;             // delete boxes per rank and exchange (cub_needrm holds <= 3, laserMapping.cpp:1183-1198)
+constexpr int REP_MAX_BOXES_TOTAL = 64;      // all ranks together (the context's box buffer)
+constexpr uint32_t REP_FLAG_OVERFLOW = 1u;   // a rank had more points than the message holds
+struct RepPackArgs {
+    const uint32_t* counts;         // device: [0] points in add, [1] points in nodown
+    uint32_t        cap;            // points per list and message
+    const float4*   add;
+    const float4*   nodown;
+    float4*         msg;            // this rank's message
+    float           boxes[6 * REP_MAX_BOXES];
+    int             n_boxes;
+};
+struct RepCompactArgs {
+    const float4*   gathered;       // [world] messages
+    int             world;
+    uint32_t        cap;
+    float4*         add_out;        // concatenation in rank order
+    float4*         nodown_out;
+    float*          boxes_out;      // [<= REP_MAX_BOXES_TOTAL][6]
+    uint32_t*       totals;         // [0] add, [1] nodown, [2] boxes, [3] flags
+};
+hipError_t launch_replicate_pack(const RepPackArgs& a, hipStream_t s);
+hipError_t launch_replicate_compact(const RepCompactArgs& a, hipStream_t s);
+
 // ---- rocPRIM-backed helpers (lio_sort.hip) ------------------------------------------------------
 size_t sort_pairs_temp_bytes(size_t n);
 hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,

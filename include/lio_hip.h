@@ -123,6 +123,29 @@ int  lio_map_add_pair_device(lio_ctx* ctx, const void* d_add_f4, int n_add, cons
  * single index rebuild; *add_counter = return value of the first call.  Applies replicated insert lists. */
 int  lio_map_add_pair(lio_ctx* ctx, const float* add_pts, int n_add, const float* nodown_pts, int n_nodown,
                       int stride_bytes, int* add_counter);
+/* ---- replicated maps: one rank per GPU, every rank its own scan stream and a full replica of the map (BASELINE.json
+ * configs[3]).  The reference has ONE map and ONE stream (globals `ikdtree`, `kf`,
+ * src/laserMapping.cpp:116,136); what a multi-stream node adds after each scan step is the exchange below: every
+ * rank's map_incremental lists (PointToAdd / PointNoNeedDownsample, :1442-1493) and delete boxes (cub_needrm,
+ * :1183-1198) travel in ONE ncclAllGather (RCCL over xGMI, enqueued on lio_stream -- no host copy of the lists, no
+ * device-wide synchronisation) and every replica applies all of them in rank order, so the replicas stay bit-identical.
+ * RCCL is loaded with dlopen at lio_replicate_init (world > 1 only); world == 1 runs the same code without it.
+ *   rank 0:  lio_replicate_unique_id(id)  -> hand the 128 bytes to the other ranks (any side channel)
+ *   all   :  lio_replicate_init(ctx, id, rank, world, 0)
+ *   per scan, after the iterated update:  [lio_replicate_queue_boxes(ctx, boxes, nb)]  lio_replicate_step(ctx, ...)   */
+int  lio_replicate_unique_id(void* id128);          /* ncclGetUniqueId: 128 bytes                                        */
+/* list_capacity: points per list, rank and message (0 = 32768, clamped to max_scan_points); a scan step with more
+ * points on some rank repeats the exchange at max_scan_points by itself.                                           */
+int  lio_replicate_init(lio_ctx* ctx, const void* id128, int rank, int world, int list_capacity);
+void lio_replicate_finalize(lio_ctx* ctx);
+/* Delete boxes of THIS rank for the next exchange (<= 4 per exchange): applied by every replica, this one included, at
+ * the exchange -- call it INSTEAD of lio_map_delete_boxes / with the boxes lio_fov_segment would delete.             */
+int  lio_replicate_queue_boxes(lio_ctx* ctx, const float* minmax6, int nb);
+/* map_incremental of this rank's scan at its posterior pose (as lio_map_incremental), the all-gather, and on every
+ * replica: Delete_Point_Boxes(all boxes), Add_Points(all PointToAdd, true), Add_Points(all PointNoNeedDownsample,
+ * false), rank order inside each.  Totals over all ranks are returned; *add_counter as Add_Points' return value.   */
+int  lio_replicate_step(lio_ctx* ctx, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
+                        int* n_add_total, int* n_nodown_total, int* n_deleted, int* add_counter);
 /* KD_TREE::Delete_Point_Boxes (ikd_Tree.cpp:536-556): boxes = nb x {min xyz, max xyz}, half-open.  */
 int  lio_map_delete_boxes(lio_ctx* ctx, const float* minmax6, int nb, int* n_deleted);
 /* lasermap_fov_segment (src/laserMapping.cpp:1136-1200): the local-map cube (edge cube_len) follows the

@@ -1,0 +1,144 @@
+"""The replica exchange behind the C ABI (lio_replicate_*): map_incremental lists and delete
+boxes of every rank in one ncclAllGather on the library's stream, applied in rank order on every replica.
+
+ - one rank, no communicator and one rank THROUGH RCCL (dlopen'd librccl, ncclCommInitRank with one rank): the exchange
+   path must equal lio_map_incremental / lio_map_delete_boxes on a twin context and the reference ikd-Tree;
+ - the overflow path (a message too small for the lists) repeats the exchange and gives the same map;
+ - two ranks on two GPUs (skipped on a one-GPU box): replicas bit-identical and equal to the reference tree fed the
+   rank-ordered lists.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _key(p):
+    return p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+
+
+def _drive(synth, world, n, k, seed_off=0):
+    sc = synth.make_scan(world, n, seed=synth.SEED + 31 + 17 * k + seed_off, pos=(2.0 + 0.9 * k, -1.5 + 0.4 * k, 0.0),
+                         rpy=(0.004, -0.006, 0.3 + 0.05 * k))
+    ps, rt = synth.perturb_state(sc, dpos=0.05, drot_deg=0.3, seed=synth.SEED + 5 + k)
+    return sc, ps, rt
+
+
+@pytest.mark.parametrize("mode", ["no_comm", "rccl_one_rank", "overflow"])
+def test_exchange_equals_local_map_incremental(gpu_capi, oracle, synth, small_case, mode):
+    w = small_case["world"]
+    thin = np.ascontiguousarray(w.points[::2])            # a thinned map: scans really add points
+    nq = 8000
+    a = gpu_capi.LioContext(0.2, max_scan_points=nq, max_map_points=400_000)     # exchange path
+    b = gpu_capi.LioContext(0.2, max_scan_points=nq, max_map_points=400_000)     # plain path
+    a.map_build(thin); b.map_build(thin)
+    ref = oracle.RefIkdTree(0.2) if oracle.ref_available() else None
+    if ref is not None:
+        ref.build(thin)
+    uid = gpu_capi.replicate_unique_id() if mode != "no_comm" else b""
+    a.replicate_init(uid, 0, 1, 64 if mode == "overflow" else 0)
+    kfa, kfb = gpu_capi.Esekf(3), gpu_capi.Esekf(3)
+    for k in range(4):
+        sc, ps, rt = _drive(synth, w, nq, k)
+        x0 = gpu_capi.make_state26(ps, rt, sc.off_R, sc.off_T)
+        for ctx, kf in ((a, kfa), (b, kfb)):
+            kf.change_x(x0); kf.change_P(synth.init_cov())
+            ctx.scan_set(sc.body)
+            kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+        assert np.array_equal(kfa.get_x(), kfb.get_x())
+        post = kfa.get_x()[:14]
+        boxes = np.array([[-30.0 + 2 * k, -30.0, -1.0, -27.0 + 2 * k, 30.0, 5.0]], np.float32) if k % 2 == 1 else np.zeros((0, 6), np.float32)
+        if len(boxes):
+            a.replicate_queue_boxes(boxes)
+        ra = a.replicate_step(post, 0.2, True)
+        nd_b = b.map_delete_boxes(boxes) if len(boxes) else 0
+        rb = b.map_incremental(post, 0.2, True, apply=True, want_lists=True)
+        assert (ra["n_add"], ra["n_nodown"], ra["add_counter"], ra["n_deleted"]) == (rb["n_add"], rb["n_nodown"], rb["add_counter"], nd_b)
+        assert ra["n_add"] + ra["n_nodown"] > 100
+        assert a.map_validnum() == b.map_validnum()
+        assert bits_equal(_key(a.map_flatten()), _key(b.map_flatten()))
+        if ref is not None:
+            if len(boxes):
+                assert ref.delete_boxes(boxes) == nd_b
+            assert ref.add(rb["add"], True) == rb["add_counter"]
+            ref.add(rb["nodown"], False)
+            assert ref.validnum() == a.map_validnum()
+            ref.quiesce(50)
+            assert bits_equal(_key(a.map_flatten()), _key(ref.flatten()))
+    a.close(); b.close()
+
+
+_WORKER = r"""
+import os, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+rank, world, idfile, outdir = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+from better_fastlio2_amd import capi, synth
+uid = open(idfile, "rb").read()
+w = synth.make_world(200_000, 0.2)
+thin = np.ascontiguousarray(w.points[::2])
+nq = 8000
+ctx = capi.LioContext(0.2, max_scan_points=nq, max_map_points=600_000, device=rank)
+ctx.map_build(thin)
+ctx.replicate_init(uid, rank, world, 0)
+kf = capi.Esekf(3)
+lists = []
+for k in range(3):
+    sc = synth.make_scan(w, nq, seed=synth.SEED + 31 + 17 * k + 1000 * rank, pos=(2.0 + 0.9 * k + 6.0 * rank, -1.5 + 0.4 * k, 0.0),
+                         rpy=(0.004, -0.006, 0.3 + 0.05 * k + 0.7 * rank))
+    ps, rt = synth.perturb_state(sc, dpos=0.05, drot_deg=0.3, seed=synth.SEED + 5 + k + rank)
+    kf.change_x(capi.make_state26(ps, rt, sc.off_R, sc.off_T)); kf.change_P(synth.init_cov())
+    ctx.scan_set(sc.body)
+    kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+    post = kf.get_x()[:14]
+    mine = ctx.map_incremental(post, 0.2, True, apply=False, want_lists=True)      # this rank's lists, for the reference replay
+    if rank == 1 and k == 1:
+        ctx.replicate_queue_boxes(np.array([[-30.0, -30.0, -1.0, -27.0, 30.0, 5.0]], np.float32))
+    r = ctx.replicate_step(post, 0.2, True)
+    lists.append((mine["add"], mine["nodown"], r))
+np.savez(os.path.join(outdir, f"rank{rank}.npz"), flat=ctx.map_flatten(), valid=ctx.map_validnum(),
+         **{f"add{k}": l[0] for k, l in enumerate(lists)}, **{f"nodown{k}": l[1] for k, l in enumerate(lists)},
+         totals=np.array([[l[2]["n_add"], l[2]["n_nodown"], l[2]["n_deleted"]] for l in lists]))
+ctx.close()
+"""
+
+
+def test_two_ranks_two_gpus(gpu_capi, oracle, synth):
+    import ctypes as C
+    n_dev = C.c_int(0)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipGetDeviceCount(C.byref(n_dev))
+    if n_dev.value < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU node); one rank through RCCL is covered above")
+    uid = gpu_capi.replicate_unique_id()
+    with tempfile.TemporaryDirectory() as td:
+        idfile = os.path.join(td, "id.bin")
+        open(idfile, "wb").write(uid)
+        script = os.path.join(td, "worker.py")
+        open(script, "w").write(_WORKER)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, script, ROOT, str(r), "2", idfile, td], env=env) for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        r0, r1 = np.load(os.path.join(td, "rank0.npz")), np.load(os.path.join(td, "rank1.npz"))
+    assert int(r0["valid"]) == int(r1["valid"]) and np.array_equal(r0["totals"], r1["totals"])
+    assert bits_equal(_key(r0["flat"]), _key(r1["flat"]))                       # replicas bit-identical
+    if oracle.ref_available():
+        w = synth.make_world(200_000, 0.2)
+        ref = oracle.RefIkdTree(0.2)
+        ref.build(np.ascontiguousarray(w.points[::2]))
+        for k in range(3):                                                       # boxes, then rank-ordered lists
+            if k == 1:
+                ref.delete_boxes(np.array([[-30.0, -30.0, -1.0, -27.0, 30.0, 5.0]], np.float32))
+            ref.add(np.concatenate([r0[f"add{k}"], r1[f"add{k}"]]), True)
+            ref.add(np.concatenate([r0[f"nodown{k}"], r1[f"nodown{k}"]]), False)
+        ref.quiesce(100)
+        assert ref.validnum() == int(r0["valid"])
+        assert bits_equal(_key(r0["flat"]), _key(ref.flatten()))
