@@ -548,7 +548,11 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
 
 extern "C" {
 
-const char* lio_version(void) { return "lio_hip 0.1 (gfx950)"; }
+const char* lio_version(void) { return "lio_hip 0.2 (gfx950)"; }
+int lio_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 int lio_create(const lio_config* cfg, lio_ctx** out) {
     if (!cfg || !out) return LIO_ERR_INVALID_ARG;

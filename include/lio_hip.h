@@ -91,6 +91,7 @@ int  lio_create(const lio_config* cfg, lio_ctx** out);
 void lio_destroy(lio_ctx* ctx);
 const char* lio_last_error(lio_ctx* ctx);           /* text of the last failure on this context        */
 const char* lio_version(void);
+int  lio_device_count(void);                          /* HIP devices visible to this process (0 without a GPU)   */
 void* lio_stream(lio_ctx* ctx);                     /* the hipStream_t every kernel of ctx runs on     */
 int  lio_synchronize(lio_ctx* ctx);
 

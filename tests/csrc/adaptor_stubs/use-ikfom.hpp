@@ -15,6 +15,8 @@ struct StubMatrix {
     void resize(long rows, long cols) { r = rows; c = cols; a.assign((size_t)(rows * cols), 0.0); }
     void resize(long rows) { resize(rows, 1); }
     double* data() { return a.data(); }
+    long rows() const { return r; }
+    long cols() const { return c; }
 };
 namespace esekfom {
 template <class T> struct dyn_share_datastruct { bool valid = true, converge = true; StubMatrix h_x, h; };

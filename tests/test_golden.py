@@ -51,6 +51,90 @@ def test_oracle_step_reproduces_golden(oracle, step):
         assert np.array_equal(x1, step[f"{k}_x_post"]) and np.array_equal(P1, step[f"{k}_P_post"])
 
 
+# ------------------------------------------------------------------ the MODEL half against the reference itself
+MODEL_REF = os.path.join(G, "model_ref.npz")
+_UNPINNED = ("tests/golden/model_ref.npz does not exist: the model half (esti_plane, h_share_model, IKFoM update) is PARITY "
+             "UNPINNED -- the vectors need the reference compiled against Eigen (make -C oracle ref_model EIGEN=...; "
+             "python tests/golden/make_model_golden.py), and Eigen is not installed in this image")
+
+
+@pytest.fixture(scope="module")
+def model_ref():
+    if not os.path.exists(MODEL_REF):
+        pytest.skip(_UNPINNED)
+    return np.load(MODEL_REF)
+
+
+def test_oracle_planes_reproduce_the_reference_model(oracle, model_ref):
+    """esti_plane<float> of the reference (Eigen's ColPivHouseholderQR): accept / reject decisions identical, accepted
+    planes bit-equal (the restatement follows Eigen 3.3.7 operation by operation)."""
+    ok = np.zeros(len(model_ref["planes_in"]), np.uint8)
+    out = np.zeros((len(ok), 4), np.float32)
+    for i, p in enumerate(model_ref["planes_in"]):
+        good, pl = oracle.esti_plane(p, 0.1)
+        ok[i] = good; out[i] = pl
+    assert np.array_equal(ok, model_ref["planes_ok"])
+    finite = np.isfinite(model_ref["planes_out"]).all(1)
+    assert bits_equal(out[finite], model_ref["planes_out"][finite])
+
+
+def test_oracle_step_reproduces_the_reference_model(oracle, model_ref):
+    """h_share_model and update_iterated_dyn_share_modified of the reference (real Eigen, real IKFoM, real ikd-Tree):
+    the accept mask and the rows bit-equal, manifold operations and the posterior within 1e-12 (libm / summation order)."""
+    for i in range(len(model_ref["xs"])):
+        assert np.abs(oracle.state_boxplus(model_ref["xs"][i], model_ref["dxs"][i]) - model_ref["xplus"][i]).max() < 1e-12
+        assert np.abs(oracle.state_boxminus(model_ref["xplus"][i], model_ref["xs"][i]) - model_ref["xminus"][i]).max() < 1e-12
+    om = oracle.OracleMap(0.2); om.build(model_ref["map"])
+    body = model_ref["body"]
+    for ext, k in ((False, "noext"), (True, "ext")):
+        arr = oracle.ScanArrays(len(body))
+        valid, hx, h, m, rm = oracle.h_share_model(om, model_ref["x0"][:14], body, arr, True, ext)
+        assert m == int(model_ref[f"{k}_m"]) and np.array_equal(arr.selected, model_ref[f"{k}_sel"])
+        assert bits_equal(arr.world, model_ref[f"{k}_world"])
+        s = arr.selected.astype(bool)
+        assert bits_equal(arr.normvec[s], model_ref[f"{k}_normvec"][s])
+        assert np.array_equal(hx, model_ref[f"{k}_hx"]) and np.array_equal(h, model_ref[f"{k}_h"])
+        x1, P1, _, _ = oracle.update_iterated(om, model_ref["x0"], model_ref["P0"], body, 0.001, 3, None, ext)
+        assert np.abs(x1 - model_ref[f"{k}_x_post"]).max() < 1e-10
+        assert np.abs(P1 - model_ref[f"{k}_P_post"]).max() <= 1e-9 * np.abs(model_ref[f"{k}_P_post"]).max()
+
+
+@pytest.mark.gpu
+def test_gpu_step_reproduces_the_reference_model(gpu_capi, model_ref):
+    body = model_ref["body"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=len(body), max_map_points=100_000)
+    ctx.map_build(model_ref["map"])
+    for ext, k in ((False, "noext"), (True, "ext")):
+        ctx.scan_set(body)
+        g = ctx.measure(model_ref["x0"][:14], True, ext)
+        world, sel, nv = ctx.scan_state()
+        assert g["m"] == int(model_ref[f"{k}_m"]) and np.array_equal(sel, model_ref[f"{k}_sel"])
+        assert bits_equal(world, model_ref[f"{k}_world"])
+        s = sel.astype(bool)
+        assert bits_equal(nv[s], model_ref[f"{k}_normvec"][s])
+        ghx, gh = ctx.measure_rows(g["m"])
+        assert np.array_equal(ghx, model_ref[f"{k}_hx"]) and np.array_equal(gh, model_ref[f"{k}_h"])
+        kf = gpu_capi.Esekf(3)
+        kf.change_x(model_ref["x0"]); kf.change_P(model_ref["P0"])
+        ctx.scan_set(body)
+        kf.update_iterated_dyn_share_modified(ctx, 0.001, ext)
+        x1 = kf.get_x()
+        assert np.abs(x1[:3] - model_ref[f"{k}_x_post"][:3]).max() < 1e-4 and np.abs(x1[3:11] - model_ref[f"{k}_x_post"][3:11]).max() < 0.5e-5
+        assert np.abs(x1 - model_ref[f"{k}_x_post"]).max() < 1e-10
+    ctx.close()
+
+
+def test_decision_margins_of_the_golden_step(oracle, step):
+    """Decision-flip audit on the committed golden step: how many points sit within 1e-5 of the two fp32 thresholds an
+    ulp of difference in Eigen's QR could flip (0.1 m inlier test common_lib.h:530, s > 0.9 laserMapping.cpp:1930)."""
+    om = oracle.OracleMap(0.2); om.build(step["map"])
+    arr = oracle.ScanArrays(len(step["body"]))
+    oracle.h_share_model(om, step["state14"], step["body"], arr, True, False)
+    mp, ms = oracle.decision_margins(arr.nbr_xyz, arr.nbr_d, arr.nbr_cnt, arr.world, step["body"])
+    assert np.isfinite(mp).sum() > 1000
+    assert (mp < 1e-5).sum() <= 2 and (ms < 1e-5).sum() <= 2      # (counts, not zero: the margins are what they are)
+
+
 # ------------------------------------------------------------------ GPU path vs the same files
 @pytest.mark.gpu
 def test_gpu_knn_reproduces_reference_golden(gpu_capi, knn_ref):

@@ -111,11 +111,7 @@ ctx.close()
 
 
 def test_two_ranks_two_gpus(gpu_capi, oracle, synth):
-    import ctypes as C
-    n_dev = C.c_int(0)
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipGetDeviceCount(C.byref(n_dev))
-    if n_dev.value < 2:
+    if gpu_capi.load().lio_device_count() < 2:
         pytest.skip("needs two GPUs (the driver's multi-GPU node); one rank through RCCL is covered above")
     uid = gpu_capi.replicate_unique_id()
     with tempfile.TemporaryDirectory() as td:

@@ -15,32 +15,70 @@ def _cpp_blocks():
     return re.findall(r"```cpp\n(.*?)```", text, re.S)
 
 
-def test_adaptor_of_integration_md_type_checks_against_the_header():
+def _gxx_syntax(args, src_text=None, path=None):
+    with tempfile.TemporaryDirectory() as d:
+        if src_text is not None:
+            path = os.path.join(d, "check.cpp")
+            open(path, "w").write(src_text)
+        return subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include")] + args + [path],
+                              capture_output=True, text=True)
+
+
+def test_adaptor_header_and_demo_compile_against_the_stand_in_types():
+    """include/lio_hip_adaptor.hpp + examples/adaptor_demo.cpp (the reference's globals and call sites, statement by
+    statement) against tests/csrc/adaptor_stubs: a renamed entry point or a changed argument list in lio_hip.h, or a
+    facade member that no longer matches a call site of src/laserMapping.cpp, breaks this test, not a user."""
+    r = _gxx_syntax(["-I", os.path.join(ROOT, "tests", "csrc", "adaptor_stubs")], path=os.path.join(ROOT, "examples", "adaptor_demo.cpp"))
+    assert r.returncode == 0, r.stderr
+
+
+def test_adaptor_compiles_against_the_real_headers_when_they_exist():
+    """Where Eigen, PCL and the reference checkout are installed the same demo is built against the REAL state_ikfom,
+    dyn_share_datastruct<double> and pcl::PointXYZINormal (-DLIO_ADAPTOR_REAL_HEADERS).  Not in this image."""
+    import glob
+    import pytest
+    eigen = [p for p in ("/usr/include/eigen3", "/usr/local/include/eigen3") if os.path.exists(os.path.join(p, "Eigen", "Core"))]
+    pcl = sorted(glob.glob("/usr/include/pcl-*")) + sorted(glob.glob("/usr/local/include/pcl-*"))
+    ref = "/root/reference/include"
+    if not (eigen and pcl and os.path.exists(ref)):
+        pytest.skip("Eigen / PCL / the reference headers are not installed: the adaptor is checked against stand-ins only")
+    r = _gxx_syntax(["-DLIO_ADAPTOR_REAL_HEADERS", "-I", eigen[0], "-I", pcl[-1], "-I", ref, "-I", os.path.join(ref, "IKFoM_toolkit")],
+                    path=os.path.join(ROOT, "examples", "adaptor_demo.cpp"))
+    assert r.returncode == 0, r.stderr
+
+
+def test_the_edits_quoted_in_integration_md_compile_with_the_adaptor():
+    """Section 3's diff of src/laserMapping.cpp, pasted behind the globals it names."""
     blocks = _cpp_blocks()
-    adaptor = [b for b in blocks if "struct LioHip" in b]
-    model = [b for b in blocks if "void h_share_model(" in b]
-    assert len(adaptor) == 1 and len(model) == 1
+    edits = [b for b in blocks if "lio::KdTreeFacade<PointType> ikdtree;" in b]
+    assert len(edits) == 1
+    body = edits[0]
+    # statements (c) and (d) live inside functions of the node
+    head, tail = body.split("// (c)")
     src = "\n".join([
-        adaptor[0],
-        "// file-scope globals of src/laserMapping.cpp the callback reaches (laserMapping.cpp:44-116)",
-        "static bool scan_dirty = true, extrinsic_est_en = false;",
-        "static StubCloud* feats_down_body = nullptr;",
-        "static int feats_down_size = 0, effct_feat_num = 0;",
-        "static double res_mean_last = 0.0;",
-        "static LioHip ikdtree(0.2f);",
-        model[0],
+        "#include <memory>",
+        '#include "use-ikfom.hpp"',
+        "#include <ikd-Tree/ikd_Tree.h>",
+        "using std::vector;",
+        "struct PointCloudXYZI { typedef std::shared_ptr<StubCloud> Ptr; };",
+        "static PointCloudXYZI::Ptr feats_down_body, feats_down_world, normvec, laserCloudOri, corr_normvect;",
+        "static vector<PointVector> Nearest_Points;",
+        "static bool point_selected_surf[100000], extrinsic_est_en;",
+        "static float res_last[100000];",
+        "static int feats_down_size, effct_feat_num;",
+        "static double res_mean_last;",
+        head,
+        "void node_body() {",
+        "// (c)" + tail,
+        "}",
         "int main() { return 0; }",
     ])
-    with tempfile.TemporaryDirectory() as d:
-        path = os.path.join(d, "adaptor_check.cpp")
-        open(path, "w").write(src)
-        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"),
-                            "-I", os.path.join(ROOT, "tests", "csrc", "adaptor_stubs"), path], capture_output=True, text=True)
+    r = _gxx_syntax(["-I", os.path.join(ROOT, "tests", "csrc", "adaptor_stubs")], src_text=src)
     assert r.returncode == 0, r.stderr
 
 
 def test_every_abi_call_in_integration_md_exists_in_the_header():
-    header = open(os.path.join(ROOT, "include", "lio_hip.h")).read()
+    header = open(os.path.join(ROOT, "include", "lio_hip.h")).read() + open(os.path.join(ROOT, "include", "lio_hip_adaptor.hpp")).read()
     declared = set(re.findall(r"\b(lio_[A-Za-z0-9_]+)\s*\(", header))
     used = set(re.findall(r"\b(lio_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
     assert used and used <= declared, sorted(used - declared)
