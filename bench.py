@@ -314,11 +314,7 @@ def main():
         """`value`: scan k was uploaded while scan k-1 was processed; swap it in, start the copy of scan k+1, update."""
         k = tick[0] % n_rot
         tick[0] += 1
-        rc = L.lio_scan_swap(ctx.h)
-        if rc == 0:
-            rc = L.lio_scan_upload_async(ctx.h, h_p[(k + 1) % n_rot], nq)
-        if rc == 0:
-            rc = L.lio_eskf_scan_step_device(kf.h, ctx.h, x_p[k], P0_p, None, nq, 0.001, ext_i, ulog_ref)
+        rc = L.lio_eskf_scan_step_pipelined(kf.h, ctx.h, x_p[k], P0_p, h_p[(k + 1) % n_rot], nq, 0.001, ext_i, ulog_ref)
         if rc != 0:
             fail("pipelined scan step", rc)
 

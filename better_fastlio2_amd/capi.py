@@ -67,7 +67,7 @@ EXPORTS = [
     "lio_scan_set", "lio_scan_set_device", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get", "lio_debug_set",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
-    "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_eskf_scan_step_device", "lio_state_boxplus",
+    "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_eskf_scan_step_device", "lio_eskf_scan_step_pipelined", "lio_state_boxplus",
     "lio_state_boxminus", "lio_eskf_predict", "lio_process_noise_cov",
     "lio_imu_create", "lio_imu_destroy", "lio_imu_reset", "lio_imu_set_extrinsic", "lio_imu_set_cov", "lio_imu_process",
     "lio_imu_get_poses", "lio_imu_get_info",
@@ -173,6 +173,7 @@ def load(build_if_missing: bool = True):
     L.lio_eskf_get_P.argtypes = [_vp, _vp]
     L.lio_eskf_update_iterated_dyn_share_modified.argtypes = [_vp, _vp, C.c_double, C.c_int, C.POINTER(lio_update_log)]
     L.lio_eskf_scan_step_device.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int, C.POINTER(lio_update_log)]
+    L.lio_eskf_scan_step_pipelined.argtypes = [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int, C.POINTER(lio_update_log)]
     L.lio_state_boxplus.argtypes = [_vp, _vp]
     L.lio_state_boxminus.argtypes = [_vp, _vp, _vp]
     L.lio_eskf_predict.argtypes = [_vp, C.c_double, _vp, _vp, _vp]

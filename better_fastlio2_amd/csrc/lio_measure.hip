@@ -80,14 +80,48 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         if (tid >= 64) return;
         TreeScratch& ts = *reinterpret_cast<TreeScratch*>(s_raw);
         const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;        // complete: written by the k-NN launch before this one
+        const bool fix = n <= (uint32_t)FIX_MAX;
         uint32_t walked = 0;
         for (uint32_t e = blockIdx.x; e < n; e += (uint32_t)n_walkers) {
             const float4 q = a.tree.ulist[e];
-            tree_search_one(a.tree, __float_as_uint(q.w), q.x, q.y, q.z, tid, ts);
+            const uint32_t qi = __float_as_uint(q.w);
+            int nvalid = 0;
+            const float4 own = tree_search_one(a.tree, qi, q.x, q.y, q.z, tid, ts, &nvalid);
+            if (fix) {
+                // the model of this query, here (every lane computes the same; lane 0 writes): gate, plane, residual,
+                // Jacobian row -- exactly what the owner's lane would have done with these neighbours
+                float px[5], py[5], pz[5];
+#pragma unroll
+                for (int k = 0; k < K; ++k) { px[k] = __shfl(own.x, k, 64); py[k] = __shfl(own.y, k, 64); pz[k] = __shfl(own.z, k, 64); }
+                const float d5 = __shfl(own.w, K - 1, 64);
+                const float4 b = a.body[qi];
+                const PoseQ s = pose_unpack(a.pose);
+                bool sel = false;
+                float nx = 0.f, ny = 0.f, nz = 0.f, pd2 = 0.f, pd = 0.f;
+                double row[12], h = 0.0;
+#pragma unroll
+                for (int c = 0; c < 12; ++c) row[c] = 0.0;
+                if (nvalid >= K && !(d5 > 5.0f))                               // :1911
+                    sel = point_residual(px, py, pz, q.x, q.y, q.z, b.x, b.y, b.z, nx, ny, nz, pd2, &pd);
+                if (sel) jacobian_row<EXT>(s, b.x, b.y, b.z, nx, ny, nz, pd2, row, h);
+                if (tid == 0) {
+                    if (sel) { a.plane[qi] = make_float4(nx, ny, nz, pd); a.normvec[qi] = make_float4(nx, ny, nz, pd2); }
+                    a.sel[qi] = sel ? 1 : 0;
+                    unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.fix_rows + (size_t)e * FIX_STRIDE);
+#pragma unroll
+                    for (int c = 0; c < S::NC; ++c)
+                        __hip_atomic_store(dst + c, (unsigned long long)__double_as_longlong(row[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + S::COL_H, (unsigned long long)__double_as_longlong(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + S::COL_RES, (unsigned long long)__double_as_longlong(sel ? (double)__builtin_fabsf(pd2) : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + S::COL_ONE, (unsigned long long)__double_as_longlong(sel ? 1.0 : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // FIX_STRIDE - 1: the query number, the key the last workgroup orders the rows by
+                    __hip_atomic_store(dst + FIX_STRIDE - 1, (unsigned long long)qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             ++walked;
         }
         if (walked != 0 && tid == 0) {
-            // results (write-through stores of this wavefront, lio_tree.h) -> drained -> the counter the owners poll
+            // results (write-through stores of this wavefront, lio_tree.h) -> drained -> the counter the waiters poll
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(a.walk_done, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -112,6 +146,9 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     // after it re-evaluate only the points it accepted (:1916), on the SAME neighbours, so the plane they would re-fit
     // is the one stored here (16 bytes instead of 80, no QR).
     const bool in = i < a.nq;
+    // few listed queries: their walkers also evaluate the model, nobody waits (FIX_MAX, lio_kernels.h)
+    const bool fix_mode = SEARCH && n_walkers > 0 && (*a.n_unresolved & ~TREE_OVERFLOW) <= (uint32_t)FIX_MAX;
+    bool walked_elsewhere = false;
     const PoseQ s = pose_unpack(a.pose);
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     float wx = 0.f, wy = 0.f, wz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
@@ -129,7 +166,10 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         // Does this workgroup own a query the walkers still owe (marked by the k-NN kernel)?  Then wait for the walk
         // (bounded; a timeout is reported like a reduction timeout), acquire, and read those neighbours again.  Walkers
         // have the lowest workgroup indices, i.e. they are dispatched first.
-        if (n_walkers > 0) {
+        if (n_walkers > 0 && fix_mode) {
+            // the walker of a listed query evaluates its model and writes its outputs; here it counts as not selected
+            walked_elsewhere = in && (cnt_i & CNT_UNPROVEN) != 0;
+        } else if (n_walkers > 0) {
             const bool owes = __syncthreads_or((in && (cnt_i & CNT_UNPROVEN) != 0) ? 1 : 0) != 0;
             if (owes) {
                 if (tid == 0) {
@@ -150,7 +190,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         }
         wx = wpt.x; wy = wpt.y; wz = wpt.z;
         // points_near.size() < 5 ? false : sqdis[4] > 5 ? false : true          :1911
-        if (in && ((cnt_i & ~CNT_UNPROVEN) >= K) && !(nb[4].w > 5.0f)) {
+        if (in && !walked_elsewhere && ((cnt_i & ~CNT_UNPROVEN) >= K) && !(nb[4].w > 5.0f)) {
             float px[5], py[5], pz[5];
 #pragma unroll
             for (int k = 0; k < K; ++k) { px[k] = nb[k].x; py[k] = nb[k].y; pz[k] = nb[k].z; }
@@ -174,7 +214,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             a.normvec[i] = make_float4(nx, ny, nz, pd2);                   // :1933-1936
             jacobian_row<EXT>(s, b.x, b.y, b.z, nx, ny, nz, pd2, row, h);
         }
-        a.sel[i] = sel ? 1 : 0;
+        if (!walked_elsewhere) a.sel[i] = sel ? 1 : 0;
         if (a.rows != nullptr && sel) {
             double* dst = a.rows + (size_t)i * 13;
 #pragma unroll
@@ -306,6 +346,65 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         s_fin[tid] = t + s_own[tid];
     }
     __syncthreads();
+    // ---- the rows of the walked queries (fix mode): wait for the walkers (they ran beside everything above), order the
+    // rows by query number, stage them like a workgroup's own rows and reduce them with the same code
+    if (fix_mode) {
+        const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;
+        if (n > 0) {
+            static_assert(FIX_MAX == BS, "one sort key per lane");
+            __shared__ unsigned long long s_key[FIX_MAX];
+            if (tid == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(a.walk_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n && ++spins < SPIN_LIMIT)
+                    __builtin_amdgcn_s_sleep(2);
+                if (spins >= SPIN_LIMIT) s_failed = 1u;
+            }
+            __syncthreads();
+            const unsigned long long* fr = reinterpret_cast<const unsigned long long*>(a.fix_rows);
+            // key = query number << 32 | list entry; FIX_MAX == BS: one key per lane, bitonic sort in LDS
+            unsigned long long key = ~0ull;
+            if ((uint32_t)tid < n)
+                key = (__hip_atomic_load(fr + (size_t)tid * FIX_STRIDE + FIX_STRIDE - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32) | (unsigned long long)tid;
+            s_key[tid] = key;
+            __syncthreads();
+            for (int k2 = 2; k2 <= FIX_MAX; k2 <<= 1) {
+                for (int j = k2 >> 1; j > 0; j >>= 1) {
+                    const int partner = tid ^ j;
+                    if (partner > tid) {
+                        const unsigned long long x = s_key[tid], y = s_key[partner];
+                        const bool up = (tid & k2) == 0;
+                        if ((x > y) == up) { s_key[tid] = y; s_key[partner] = x; }
+                    }
+                    __syncthreads();
+                }
+            }
+            const uint32_t src = (uint32_t)s_key[tid];                  // list entry of the tid-th smallest query number
+#pragma unroll
+            for (int c = 0; c < S::NCOLS; ++c) {
+                double v = 0.0;
+                if ((uint32_t)tid < n)
+                    v = __longlong_as_double((long long)__hip_atomic_load(fr + (size_t)src * FIX_STRIDE + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                s_rows[tid][c] = v;
+            }
+            __syncthreads();
+            double facc = 0.0;
+            if (e < S::NE) {
+                int ca, cb;
+                entry_columns<EXT>(e, ca, cb);
+                const int r0 = seg * S::RS;
+                for (int r = 0; r < S::RS; ++r) facc += s_rows[r0 + r][ca] * s_rows[r0 + r][cb];
+            }
+            s_part[seg][e] = facc;
+            __syncthreads();
+            if (tid < S::NE) {
+                double t = 0.0;
+#pragma unroll
+                for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
+                s_fin[tid] += t;
+            }
+            __syncthreads();
+        }
+    }
     const bool failed = s_failed != 0u || a.debug_fail != 0 || s_fin[S::NE - 1] < -0.5;
     // One wavefront writes the whole record into host-mapped memory, fences at system scope and only
     // then publishes the sequence number the host is polling.

@@ -103,12 +103,15 @@ struct WaveTop5 {
     }
 };
 
-// lanes 0..4 write the five results (ascending) of query q; lane 0 the count
-__device__ __forceinline__ void write_wave_result(const TreeArgs& a, uint32_t q, int lane, const WaveTop5& top) {
+// lanes 0..4 write the five results (ascending) of query q; lane 0 the count.  Returns the lane's own result (lane k < 5:
+// neighbour k as x, y, z, sqdist) and the number of valid results, for a caller that goes on with them.
+__device__ __forceinline__ float4 write_wave_result(const TreeArgs& a, uint32_t q, int lane, const WaveTop5& top, int& nvalid_out) {
     const u64 res[K] = {top.g0, top.g1, top.g2, top.g3, top.g4};
     int nvalid = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) nvalid += ((uint32_t)(res[k] >> 32) < INF_BITS) ? 1 : 0;
+    nvalid_out = nvalid;
+    float4 own = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < K) {
         u64 mine = res[0];
 #pragma unroll
@@ -130,10 +133,12 @@ __device__ __forceinline__ void write_wave_result(const TreeArgs& a, uint32_t q,
         const unsigned long long hi = ((unsigned long long)__float_as_uint(o.w) << 32) | (unsigned long long)__float_as_uint(o.z);
         __hip_atomic_store(dst + 0, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(dst + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        own = o;
     }
     // the mark stays: whoever owns the query decides from the MARK (written by the k-NN launch, i.e. reliably visible)
     // that it has to wait for the walk
     if (lane == 0) __hip_atomic_store(a.cnt + q, (uint8_t)((uint8_t)nvalid | CNT_UNPROVEN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return own;
 }
 // the owner's side of the hand-off: neighbour k of query q / its count, read past the caches the walk did not write
 __device__ __forceinline__ float4 load_walked_neighbor(const float4* nbr, size_t index) {
@@ -152,9 +157,11 @@ struct TreeScratch {
     uint32_t pre[128];               //          exclusive prefix of their counts
 };
 
-// Exact 5-NN of query q = (qx, qy, qz); all 64 lanes of the wavefront must call it together.
-__device__ __forceinline__ void tree_search_one(const TreeArgs& a, uint32_t q, float qx, float qy, float qz, int lane,
-                                                TreeScratch& ts) {
+// Exact 5-NN of query q = (qx, qy, qz); all 64 lanes of the wavefront must call it together.  Returns what
+// write_wave_result returns (lane k < 5: neighbour k), *nvalid = neighbours found.
+__device__ __forceinline__ float4 tree_search_one(const TreeArgs& a, uint32_t q, float qx, float qy, float qz, int lane,
+                                                  TreeScratch& ts, int* nvalid = nullptr) {
+    int nv_local = 0;
     uint4* const s_node = ts.node;
     uint4* const s_cell = ts.cell;
     uint2* const s_bk = ts.bk;
@@ -241,7 +248,12 @@ __device__ __forceinline__ void tree_search_one(const TreeArgs& a, uint32_t q, f
             proven = top.tau() < gmin * gmin;
         }
         __builtin_amdgcn_wave_barrier();
-        if (proven) { write_wave_result(a, q, lane, top); __builtin_amdgcn_wave_barrier(); return; }
+        if (proven) {
+            const float4 own = write_wave_result(a, q, lane, top, nv_local);
+            if (nvalid) *nvalid = nv_local;
+            __builtin_amdgcn_wave_barrier();
+            return own;
+        }
     }
 
     // ---- phase B: best-first walk of the whole tree, pruned by what phase A already holds
@@ -333,8 +345,10 @@ __device__ __forceinline__ void tree_search_one(const TreeArgs& a, uint32_t q, f
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    write_wave_result(a, q, lane, top);
+    const float4 own = write_wave_result(a, q, lane, top, nv_local);
+    if (nvalid) *nvalid = nv_local;
     __builtin_amdgcn_wave_barrier();
+    return own;
 }
 
 }  // namespace lio

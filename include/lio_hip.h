@@ -297,6 +297,12 @@ int  lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, dou
  * iterated update runs.  Equivalent to the four calls it names.                                             */
 int  lio_eskf_scan_step_device(lio_eskf* kf, lio_ctx* ctx, const double x26[26], const double P[23 * 23],
                                const void* d_body_f4, int n, double R, int extrinsic_est_en, lio_update_log* log);
+/* The same for a node that receives scan k+1 while scan k is being processed: the scan handed over with
+ * lio_scan_upload_async during the previous step becomes the current one (lio_scan_swap), the copy of the next scan
+ * (next_host_f4, n_next float4 records in pinned host memory; NULL = none) is started behind this step's first
+ * kernels, then the update runs.  Before the first step: lio_scan_upload_async(ctx, first_scan, n).            */
+int  lio_eskf_scan_step_pipelined(lio_eskf* kf, lio_ctx* ctx, const double x26[26], const double P[23 * 23],
+                                  const void* next_host_f4, int n_next, double R, int extrinsic_est_en, lio_update_log* log);
 /* esekf::predict(dt, Q, i_in) (esekfom.hpp:280-383) with the process model f / df_dx / df_dw of
  * use-ikfom.hpp:56-99: propagates x and P over dt with the IMU input (acc, gyro); Q = 12 x 12 process noise
  * (ng, na, nbg, nba), row-major.                                                                             */
