@@ -88,6 +88,7 @@ struct DeviceOut {                            // written by the final reduction 
     int      m;
     int      n_unresolved;
     unsigned long long seq;                   // written LAST (system-scope release): the host polls it
+    unsigned long long dbg[8];                // wall_clock64 stamps of the last workgroup (100 MHz; diagnostics only)
 };
 
 // ---- cell / key arithmetic (host + device) ----------------------------------------------------

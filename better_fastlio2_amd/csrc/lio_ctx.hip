@@ -93,7 +93,6 @@ struct lio_ctx {
     float4* d_ulist = nullptr;                 // queries the 27-cell kernel could not prove (count: d_counters[0])
     double* d_rows = nullptr;
     unsigned long long *d_units = nullptr, *d_gunits = nullptr;   // stamped partial sums of the residual kernel's reduction
-    double* d_fix_rows = nullptr;              // staged rows of walked queries (search passes with few of them)
     DeviceOut* h_out = nullptr;                // pinned + mapped: the final reduction writes it directly
     DeviceOut* d_out = nullptr;                // device alias of h_out
     unsigned long long seq = 0;                // sequence number of the last pass (polled in h_out->seq)
@@ -645,7 +644,6 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_cnt, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_sel, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_ulist, nq * sizeof(float4)));
-    CREATE_CHK(hipMalloc((void**)&c->d_fix_rows, (size_t)FIX_MAX * FIX_STRIDE * sizeof(double)));
     {
         const size_t blocks = (size_t)residual_blocks((int)nq), groups = (blocks + RED_GROUP - 1) / RED_GROUP;
         CREATE_CHK(hipMalloc((void**)&c->d_units, blocks * RED_STRIDE * 2 * sizeof(unsigned long long)));
@@ -669,7 +667,7 @@ void lio_destroy(lio_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
-                   c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_fix_rows, c->d_rows,
+                   c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_rows,
                    c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
@@ -1653,7 +1651,6 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     if (do_search && !c->dbg_separate_walk) {
         ra.n_walkers = residual_walkers(nq); ra.walk_done = c->d_counters + 16;
         ra.tree = tree_args(c, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist);
-        ra.fix_rows = c->d_fix_rows;
     }
     const hipError_t le = launch_residual(ra, do_search != 0, ext, s, prof_timer(c, LIO_PROF_RESIDUAL));
     if (le != hipSuccess) { c->pass_in_flight = false; return c->fail(LIO_ERR_HIP, "launch_residual", hipGetErrorString(le)); }
@@ -1823,6 +1820,11 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "force_reduction_timeout") == 0) { c->dbg_force_timeout = value != 0; return LIO_OK; }
     if (std::strcmp(key, "separate_tree_walk") == 0) { c->dbg_separate_walk = value != 0; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "unknown key");
+}
+int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {
+    if (!c || !out8) return LIO_ERR_INVALID_ARG;
+    for (int i = 0; i < 8; ++i) out8[i] = c->h_out->dbg[i];
+    return LIO_OK;
 }
 int lio_census_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; c->census = on != 0; return LIO_OK; }
 int lio_profile_reset(lio_ctx* c) {

@@ -80,13 +80,12 @@ struct ResidualArgs {
     int            n_walkers;       // 0: no walk in this launch (the stand-alone knn_tree_kernel ran, or a no-search pass)
     uint32_t*      walk_done;       // device counter: walked queries of this pass (reset by the last workgroup)
     TreeArgs       tree;            // map index + the list (tree.nbr / tree.cnt = the scan's neighbour arrays)
-    // Few listed queries (<= FIX_MAX, the normal case): nobody waits for the walk.  A walker also evaluates the model of
-    // its query and leaves the staged row in fix_rows[entry]; the owners count such a query as not selected; the LAST
-    // workgroup adds the rows, in query order, after its own fold.  More listed queries: the owners wait (see above).
-    double*        fix_rows;        // [max_scan_points][FIX_STRIDE]: staged row of a walked query (written through)
+    // Few listed queries (<= FIX_MAX, the normal case): nobody but the LAST workgroup waits for the walk -- the owners
+    // count such a query as not selected, the last workgroup evaluates the models of all of them (one lane each) while
+    // the partial sums it is going to fold are still arriving, and adds their rows in query order.  More listed
+    // queries: the owners wait (see above).
 };
-constexpr int FIX_MAX = 256;                 // listed queries up to which the last workgroup adds the walked rows
-constexpr int FIX_STRIDE = 16;               // doubles per staged row (>= 12 + 3)
+constexpr int FIX_MAX = 256;                 // listed queries up to which the last workgroup evaluates the walked queries
 int residual_blocks(int nq);
 int residual_walkers(int nq);       // walking workgroups a search pass adds in front of the model workgroups
 hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s, KernelTimer t = KernelTimer());

@@ -78,46 +78,13 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     const int n_walkers = SEARCH ? a.n_walkers : 0;
     if (SEARCH && (int)blockIdx.x < n_walkers) {
         if (tid >= 64) return;
+        __builtin_amdgcn_s_setprio(3);             // the walk is on the critical path of the pass: ahead of the model waves
         TreeScratch& ts = *reinterpret_cast<TreeScratch*>(s_raw);
         const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;        // complete: written by the k-NN launch before this one
-        const bool fix = n <= (uint32_t)FIX_MAX;
         uint32_t walked = 0;
         for (uint32_t e = blockIdx.x; e < n; e += (uint32_t)n_walkers) {
             const float4 q = a.tree.ulist[e];
-            const uint32_t qi = __float_as_uint(q.w);
-            int nvalid = 0;
-            const float4 own = tree_search_one(a.tree, qi, q.x, q.y, q.z, tid, ts, &nvalid);
-            if (fix) {
-                // the model of this query, here (every lane computes the same; lane 0 writes): gate, plane, residual,
-                // Jacobian row -- exactly what the owner's lane would have done with these neighbours
-                float px[5], py[5], pz[5];
-#pragma unroll
-                for (int k = 0; k < K; ++k) { px[k] = __shfl(own.x, k, 64); py[k] = __shfl(own.y, k, 64); pz[k] = __shfl(own.z, k, 64); }
-                const float d5 = __shfl(own.w, K - 1, 64);
-                const float4 b = a.body[qi];
-                const PoseQ s = pose_unpack(a.pose);
-                bool sel = false;
-                float nx = 0.f, ny = 0.f, nz = 0.f, pd2 = 0.f, pd = 0.f;
-                double row[12], h = 0.0;
-#pragma unroll
-                for (int c = 0; c < 12; ++c) row[c] = 0.0;
-                if (nvalid >= K && !(d5 > 5.0f))                               // :1911
-                    sel = point_residual(px, py, pz, q.x, q.y, q.z, b.x, b.y, b.z, nx, ny, nz, pd2, &pd);
-                if (sel) jacobian_row<EXT>(s, b.x, b.y, b.z, nx, ny, nz, pd2, row, h);
-                if (tid == 0) {
-                    if (sel) { a.plane[qi] = make_float4(nx, ny, nz, pd); a.normvec[qi] = make_float4(nx, ny, nz, pd2); }
-                    a.sel[qi] = sel ? 1 : 0;
-                    unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.fix_rows + (size_t)e * FIX_STRIDE);
-#pragma unroll
-                    for (int c = 0; c < S::NC; ++c)
-                        __hip_atomic_store(dst + c, (unsigned long long)__double_as_longlong(row[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + S::COL_H, (unsigned long long)__double_as_longlong(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + S::COL_RES, (unsigned long long)__double_as_longlong(sel ? (double)__builtin_fabsf(pd2) : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + S::COL_ONE, (unsigned long long)__double_as_longlong(sel ? 1.0 : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // FIX_STRIDE - 1: the query number, the key the last workgroup orders the rows by
-                    __hip_atomic_store(dst + FIX_STRIDE - 1, (unsigned long long)qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            tree_search_one(a.tree, __float_as_uint(q.w), q.x, q.y, q.z, tid, ts);
             ++walked;
         }
         if (walked != 0 && tid == 0) {
@@ -132,6 +99,8 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     double (&s_rows)[BS][S::NCOLS] = sm.rows;
     double (&s_part)[S::SEG][S::NEP] = sm.part;
     const int bid = (int)blockIdx.x - n_walkers;   // index among the model workgroups
+    const unsigned long long t_dbg0 = wall_clock64();
+    unsigned long long t_dbg1 = 0, t_dbg2 = 0, t_dbg3 = 0, t_dbg4 = 0, t_dbg5 = 0, t_dbg6 = 0;
     const int i = bid * BS + tid;
     if (tid == 0) s_failed = 0u;
     bool sel = false;
@@ -277,7 +246,85 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             __hip_atomic_store(dst + 1, (bits >> 32) | stamp_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    t_dbg1 = wall_clock64();
     if (!grp_reducer) return;
+
+    // ---- fix mode, last workgroup: the model of the walked queries, one lane each, BEFORE the folds (the partial sums
+    // it is going to fold are still on their way, the walkers have been running since the launch began): wait for the
+    // walk, evaluate gate / plane / residual / Jacobian row exactly as the owner's lane would have, order the rows by
+    // query number (the list is in arrival order) and reduce them with the code every workgroup uses for its rows
+    __shared__ double s_fix[S::NEP];
+    if (tid < S::NEP) s_fix[tid] = 0.0;
+    if (fix_mode && final_reducer) {
+        const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;
+        if (n > 0) {
+            static_assert(FIX_MAX == BS, "one walked query per lane");
+            __shared__ uint32_t s_key[FIX_MAX];
+            if (tid == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(a.walk_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n && ++spins < SPIN_LIMIT)
+                    __builtin_amdgcn_s_sleep(2);
+                if (spins >= SPIN_LIMIT) s_failed = 1u;
+            }
+            const bool has = (uint32_t)tid < n;
+            float4 lq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has) lq = a.tree.ulist[tid];                           // (world point, query number) written by the k-NN launch
+            const uint32_t qi = has ? __float_as_uint(lq.w) : 0xffffffffu;
+            s_key[tid] = qi;
+            __syncthreads();                                           // s_rows / s_part are free again, the walk is done
+            t_dbg4 = wall_clock64();
+            int rank = tid;                                            // lanes without a query keep their own (zero) row
+            bool fsel = false;
+            double frow[12], fh = 0.0;
+            float fpd2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) frow[c] = 0.0;
+            if (has) {
+                rank = 0;
+                for (uint32_t j = 0; j < n; ++j) rank += s_key[j] < qi ? 1 : 0;
+                float4 nb[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) nb[k] = load_walked_neighbor(a.nbr, (size_t)k * a.nq_stride + qi);
+                const uint8_t cq = __hip_atomic_load(a.cnt + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float4 fb = a.body[qi];
+                float fnx = 0.f, fny = 0.f, fnz = 0.f, fpd = 0.f;
+                if (((cq & ~CNT_UNPROVEN) >= K) && !(nb[4].w > 5.0f)) {      // :1911
+                    float px[5], py[5], pz[5];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { px[k] = nb[k].x; py[k] = nb[k].y; pz[k] = nb[k].z; }
+                    fsel = point_residual(px, py, pz, lq.x, lq.y, lq.z, fb.x, fb.y, fb.z, fnx, fny, fnz, fpd2, &fpd);
+                }
+                if (fsel) {
+                    a.plane[qi] = make_float4(fnx, fny, fnz, fpd);
+                    a.normvec[qi] = make_float4(fnx, fny, fnz, fpd2);
+                    jacobian_row<EXT>(s, fb.x, fb.y, fb.z, fnx, fny, fnz, fpd2, frow, fh);
+                }
+                a.sel[qi] = fsel ? 1 : 0;
+            }
+            t_dbg5 = wall_clock64();
+#pragma unroll
+            for (int c = 0; c < S::NC; ++c) s_rows[rank][c] = frow[c];
+            s_rows[rank][S::COL_H] = fh;
+            s_rows[rank][S::COL_RES] = fsel ? (double)__builtin_fabsf(fpd2) : 0.0;
+            s_rows[rank][S::COL_ONE] = fsel ? 1.0 : 0.0;
+            __syncthreads();
+            double facc = 0.0;
+            if (e < S::NE) {
+                int ca, cb;
+                entry_columns<EXT>(e, ca, cb);
+                const int r0 = seg * S::RS;
+                for (int r = 0; r < S::RS; ++r) facc += s_rows[r0 + r][ca] * s_rows[r0 + r][cb];
+            }
+            s_part[seg][e] = facc;
+            __syncthreads();
+            if (tid < S::NE) {
+                double t = 0.0;
+#pragma unroll
+                for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
+                s_fix[tid] = t;
+            }
+        }
+    }
 
     // poll-and-read `count` stamped partials starting at `src` (stride RED_STRIDE entries), fixed order per lane
     auto fold = [&](const u64* src, int count) -> double {
@@ -331,6 +378,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             __hip_atomic_store(dst + 1, (bits >> 32) | stamp_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    t_dbg2 = wall_clock64();
     if (!final_reducer) return;
 
     // ---- the last workgroup of the grid: the group sums in index order, its own group's last ---------------
@@ -343,68 +391,11 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         double t = 0.0;
 #pragma unroll
         for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
-        s_fin[tid] = t + s_own[tid];
+        s_fin[tid] = (t + s_own[tid]) + s_fix[tid];      // + the rows of the walked queries (zero outside fix mode)
     }
     __syncthreads();
-    // ---- the rows of the walked queries (fix mode): wait for the walkers (they ran beside everything above), order the
-    // rows by query number, stage them like a workgroup's own rows and reduce them with the same code
-    if (fix_mode) {
-        const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;
-        if (n > 0) {
-            static_assert(FIX_MAX == BS, "one sort key per lane");
-            __shared__ unsigned long long s_key[FIX_MAX];
-            if (tid == 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(a.walk_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n && ++spins < SPIN_LIMIT)
-                    __builtin_amdgcn_s_sleep(2);
-                if (spins >= SPIN_LIMIT) s_failed = 1u;
-            }
-            __syncthreads();
-            const unsigned long long* fr = reinterpret_cast<const unsigned long long*>(a.fix_rows);
-            // key = query number << 32 | list entry; FIX_MAX == BS: one key per lane, bitonic sort in LDS
-            unsigned long long key = ~0ull;
-            if ((uint32_t)tid < n)
-                key = (__hip_atomic_load(fr + (size_t)tid * FIX_STRIDE + FIX_STRIDE - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32) | (unsigned long long)tid;
-            s_key[tid] = key;
-            __syncthreads();
-            for (int k2 = 2; k2 <= FIX_MAX; k2 <<= 1) {
-                for (int j = k2 >> 1; j > 0; j >>= 1) {
-                    const int partner = tid ^ j;
-                    if (partner > tid) {
-                        const unsigned long long x = s_key[tid], y = s_key[partner];
-                        const bool up = (tid & k2) == 0;
-                        if ((x > y) == up) { s_key[tid] = y; s_key[partner] = x; }
-                    }
-                    __syncthreads();
-                }
-            }
-            const uint32_t src = (uint32_t)s_key[tid];                  // list entry of the tid-th smallest query number
-#pragma unroll
-            for (int c = 0; c < S::NCOLS; ++c) {
-                double v = 0.0;
-                if ((uint32_t)tid < n)
-                    v = __longlong_as_double((long long)__hip_atomic_load(fr + (size_t)src * FIX_STRIDE + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                s_rows[tid][c] = v;
-            }
-            __syncthreads();
-            double facc = 0.0;
-            if (e < S::NE) {
-                int ca, cb;
-                entry_columns<EXT>(e, ca, cb);
-                const int r0 = seg * S::RS;
-                for (int r = 0; r < S::RS; ++r) facc += s_rows[r0 + r][ca] * s_rows[r0 + r][cb];
-            }
-            s_part[seg][e] = facc;
-            __syncthreads();
-            if (tid < S::NE) {
-                double t = 0.0;
-#pragma unroll
-                for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
-                s_fin[tid] += t;
-            }
-            __syncthreads();
-        }
-    }
+    t_dbg3 = wall_clock64();
+    t_dbg6 = wall_clock64();
     const bool failed = s_failed != 0u || a.debug_fail != 0 || s_fin[S::NE - 1] < -0.5;
     // One wavefront writes the whole record into host-mapped memory, fences at system scope and only
     // then publishes the sequence number the host is polling.
@@ -427,6 +418,8 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             out->m = failed ? -1 : (int)(s_fin[S::NP + S::NC + 1] + 0.5);
             out->n_unresolved = SEARCH ? (int)*a.n_unresolved : 0;
             out->n_candidates = SEARCH ? *a.cand_total : 0ull;
+            out->dbg[0] = t_dbg0; out->dbg[1] = t_dbg1; out->dbg[2] = t_dbg2; out->dbg[3] = t_dbg3; out->dbg[4] = t_dbg4;
+            out->dbg[5] = t_dbg5; out->dbg[6] = t_dbg6; out->dbg[7] = wall_clock64();
             // consumed: zero the counters for the next pass
             if (SEARCH) { *a.n_unresolved = 0u; *a.cand_total = 0ull; if (n_walkers > 0) *a.walk_done = 0u; }
         }

@@ -262,6 +262,9 @@ int  lio_profile_reset(lio_ctx* ctx);
  * its own launch (knn_tree_kernel) instead of inside the measurement kernel (an A/B switch for timing; identical
  * results).  Unknown key: LIO_ERR_INVALID_ARG.                                                                */
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
+/* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: its start, own partial
+ * published, group folded, grid folded, walk awaited, rows ordered, rows added, record written (diagnostics)  */
+int  lio_debug_stamps(lio_ctx* ctx, unsigned long long out8[8]);
 /* accumulated milliseconds and launch count of one kernel family since the last reset             */
 int  lio_profile_get(lio_ctx* ctx, int which, double* total_ms, long long* launches);
 
