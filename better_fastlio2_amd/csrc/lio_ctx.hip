@@ -1019,10 +1019,17 @@ RcclApi* rccl_api(std::string* why) {
     static bool tried = false;
     if (!tried) {
         tried = true;
+        // an RCCL the process already carries comes first (PyTorch-ROCm loads its bundled copy under the name
+        // "librccl.so"): one RCCL instance per process, whoever brought it
+        const char* loaded[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : loaded) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+            if (api.lib) break;
+        }
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
-            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (api.lib) break;
+            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
         if (api.lib) {
             api.GetUniqueId = reinterpret_cast<int (*)(rep_unique_id*)>(dlsym(api.lib, "ncclGetUniqueId"));
