@@ -20,6 +20,15 @@
  * each record, so the reference's pcl::PointXYZINormal (48-byte records, include/common_lib.h:161)
  * can be passed without repacking (stride 48) as well as packed xyz (stride 12) or float4 (16).
  *
+ * Streams: every kernel and copy of a context runs on ITS OWN non-blocking stream (lio_stream); nothing is ordered
+ * against the null stream or anybody else's.  Entry points that take DEVICE pointers (lio_scan_set_device,
+ * lio_map_build_device, lio_map_add_pair_device, lio_eskf_scan_step_device) enqueue their reads on that stream and may
+ * return before the reads have happened: (1) whatever produced the buffer (another stream, torch, RCCL) must have
+ * FINISHED before the call -- synchronise the producer, or make lio_stream wait for it (hipStreamWaitEvent on
+ * (hipStream_t)lio_stream(ctx)); (2) the buffer must stay untouched until lio_synchronize(ctx) or the next call on the
+ * context that returns results to the host (lio_measure / lio_eskf_update...: they wait for the stream).  Host pointers
+ * are consumed before the call returns unless the entry point says otherwise (lio_scan_upload_async).
+ *
  * Pose block `state14`: pos(3), rot quaternion x,y,z,w (4), offset_R_L_I quaternion x,y,z,w (4),
  * offset_T_L_I (3) -- the members of state_ikfom read by h_share_model
  * (include/use-ikfom.hpp:21-30; Eigen::Quaternion coefficient order).

@@ -297,3 +297,67 @@ def test_reduction_timeout_is_an_error(gpu_capi, small_case):
     with pytest.raises(gpu_capi.LioError):
         ctx.debug_set("no_such_key", 1)
     ctx.close()
+
+
+def test_two_contexts_share_the_gpu(gpu_capi, small_case):
+    """The measurement kernel's cross-workgroup waits (reducers on partial sums, owners / the last workgroup on the tree
+    walk) assume that what they wait for is running or done.  Two contexts on two host threads keep two streams busy on
+    the same GPU at once -- workgroups of both kernels interleave on the CUs: every pass must complete (no timeout
+    reported) and give the bits of a solo run."""
+    import threading
+    sc, st = small_case["scan"], small_case["state14"]
+    st2 = st.copy(); st2[:3] += [0.012, -0.02, 0.006]
+    solo = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+    solo.map_build(small_case["world"].points)
+    solo.scan_set(sc.body)
+    want = [solo.measure(p, s, False) for p, s in ((st, True), (st2, False), (st2, True))]
+    solo.close()
+    errors, results = [], {}
+
+    def worker(k):
+        try:
+            ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+            ctx.map_build(small_case["world"].points)
+            ctx.scan_set(sc.body)
+            out = []
+            for _ in range(150):
+                out = [ctx.measure(p, s, False) for p, s in ((st, True), (st2, False), (st2, True))]
+            results[k] = out
+            ctx.close()
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        for got, ref in zip(results[k], want):
+            assert got["m"] == ref["m"] and np.array_equal(got["HTH"], ref["HTH"]) and np.array_equal(got["HTh"], ref["HTh"])
+
+
+def test_voxel_filtered_scan_has_no_rank_ties(gpu_capi, oracle, synth, small_case):
+    """Tie semantics differ by design (equal distances: by map index here, by traversal order in the reference,
+    ikd_Tree.cpp:887).  On a scan shaped like the node's -- a raw sweep through pcl::VoxelGrid's centroids
+    (lio_scan_voxel_filter) -- count the ties among ranks 1..6 of the reference tree: none, and every neighbour equal."""
+    _need_ref(oracle)
+    w = small_case["world"]
+    raw = synth.make_scan(w, 60_000, seed=synth.SEED + 77)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=60_000, max_map_points=400_000)
+    ctx.map_build(w.points)
+    ref = oracle.RefIkdTree(0.2)
+    ref.build(w.points)
+    raw4 = np.zeros((len(raw.body), 4), np.float32); raw4[:, :3] = raw.body
+    ctx.scan_undistort(raw4)                      # upload only (no IMU poses): feats_undistort = the raw sweep
+    n = ctx.scan_voxel_filter(0.5)
+    assert 2000 < n < 60_000
+    pos, rot = synth.perturb_state(raw)
+    st = synth.state_vector(pos, rot, raw.off_R, raw.off_T)
+    ctx.measure(st, True, False)
+    wq, _, _ = ctx.scan_state()
+    gx, gd, gc = ctx.neighbors()
+    nq, d_bad, p_bad, ties, r56 = _compare_all_neighbours(ref, wq, gx, gd, gc)
+    assert (nq, d_bad, p_bad, ties, r56) == (n, 0, 0, 0, 0)
+    ctx.close()
