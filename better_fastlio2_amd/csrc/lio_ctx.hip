@@ -91,6 +91,8 @@ struct lio_ctx {
     bool pass_in_flight = false, pass_empty = false;   // between lio_measure_begin and lio_measure_end
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
     float4* d_ulist = nullptr;                 // queries the 27-cell kernel could not prove (count: d_counters[0])
+    unsigned long long* d_useeds = nullptr;    // [list entry][8]: keys of their 27-cell results, the seeds of the walk; [5] = its verdict
+    double* d_spec_rows = nullptr;             // [scan point][SPEC_STRIDE]: staged rows of listed queries (search passes with few of them)
     double* d_rows = nullptr;
     unsigned long long *d_units = nullptr, *d_gunits = nullptr;   // stamped partial sums of the residual kernel's reduction
     DeviceOut* h_out = nullptr;                // pinned + mapped: the final reduction writes it directly
@@ -122,6 +124,7 @@ struct lio_ctx {
     float4 *d_qs_world = nullptr, *d_qs_nbr = nullptr;
     uint8_t* d_qs_cnt = nullptr;
     float4* d_qs_ulist = nullptr;
+    unsigned long long* d_qs_useeds = nullptr;
 
     // raw-scan preparation (lio_scan_undistort / lio_scan_voxel_filter)
     size_t cap_raw = 0;
@@ -156,6 +159,7 @@ struct lio_ctx {
     unsigned prof = 0;                         // bit w set: time kernel family w
     bool census = false;                       // count C(q) in the k-NN kernel (one atomic per wavefront)
     int dbg_force_timeout = 0;                 // lio_debug_set("force_reduction_timeout")
+    int dbg_stamps = 0;                        // lio_debug_set("stamps"): the last workgroup takes wall_clock64 stamps (lio_debug_stamps)
     int dbg_separate_walk = 0;                 // lio_debug_set("separate_tree_walk"): the stand-alone knn_tree_kernel per search pass
     std::vector<hipEvent_t> ev_pool[LIO_PROF_COUNT];   // start, stop, start, stop, ...
     size_t ev_next[LIO_PROF_COUNT]{};          // events of the pool in use
@@ -519,15 +523,15 @@ KernelTimer prof_timer(lio_ctx* c, int which) {
 // receives them otherwise (the kernel transforms).  walk_now: settle the unproven queries with the stand-alone tree
 // kernel; otherwise they stay listed (count in d_counters[0], cnt marked CNT_UNPROVEN) for the measurement kernel of
 // the pass, which carries the walk itself.
-TreeArgs tree_args(lio_ctx* c, int nq, int stride, float4* nbr, uint8_t* cnt, float4* ulist) {
+TreeArgs tree_args(lio_ctx* c, int nq, int stride, float4* nbr, uint8_t* cnt, float4* ulist, unsigned long long* useeds) {
     TreeArgs ta{};
     ta.map_pts = c->d_pts; ta.child = c->d_child; ta.ltable = c->d_ltable; ta.levels = c->levels; ta.grid = c->grid;
-    ta.ulist = ulist; ta.n_unres = c->d_counters;
+    ta.ulist = ulist; ta.useeds = useeds; ta.n_unres = c->d_counters;
     ta.nq = nq; ta.nq_stride = stride; ta.nbr = nbr; ta.cnt = cnt;
     return ta;
 }
 int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14& pose, int nq, int stride,
-            float4* nbr, uint8_t* cnt, float4* ulist, bool use_hint, bool walk_now) {
+            float4* nbr, uint8_t* cnt, float4* ulist, unsigned long long* useeds, bool use_hint, bool walk_now) {
     hipStream_t s = c->stream;
     // d_counters[0] / d_cand are zero here: zeroed at creation and re-zeroed by whoever consumes them
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
@@ -536,11 +540,11 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.l1table = c->d_ltable + c->levels.off[1]; ka.l1mask = c->levels.mask[1]; ka.child = c->d_child;
     ka.world_in = queries_world; ka.body = body; ka.world_out = queries_world; ka.pose = pose;
     ka.nq = nq; ka.nq_stride = stride;
-    ka.nbr = nbr; ka.cnt = cnt; ka.ulist = ulist; ka.n_unres = c->d_counters; ka.cand_total = c->census ? c->d_cand : nullptr;
+    ka.nbr = nbr; ka.cnt = cnt; ka.ulist = ulist; ka.useeds = useeds; ka.n_unres = c->d_counters; ka.cand_total = c->census ? c->d_cand : nullptr;
     ka.use_hint = use_hint ? 1 : 0;
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
-    if (walk_now) HIPCHK(c, launch_knn_tree(tree_args(c, nq, stride, nbr, cnt, ulist), s, prof_timer(c, LIO_PROF_FALLBACK)));
+    if (walk_now) HIPCHK(c, launch_knn_tree(tree_args(c, nq, stride, nbr, cnt, ulist, useeds), s, prof_timer(c, LIO_PROF_FALLBACK)));
     return LIO_OK;
 }
 
@@ -644,6 +648,8 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_cnt, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_sel, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_ulist, nq * sizeof(float4)));
+    CREATE_CHK(hipMalloc((void**)&c->d_useeds, nq * 8 * sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc((void**)&c->d_spec_rows, nq * SPEC_STRIDE * sizeof(double)));
     {
         const size_t blocks = (size_t)residual_blocks((int)nq), groups = (blocks + RED_GROUP - 1) / RED_GROUP;
         CREATE_CHK(hipMalloc((void**)&c->d_units, blocks * RED_STRIDE * 2 * sizeof(unsigned long long)));
@@ -667,8 +673,8 @@ void lio_destroy(lio_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
-                   c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_rows,
-                   c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist,
+                   c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_useeds, c->d_spec_rows, c->d_rows,
+                   c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, c->d_qs_useeds,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
@@ -1344,19 +1350,20 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
     if (n == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
     if (n > c->cap_qs) {
-        void* old[] = {c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist};
+        void* old[] = {c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, c->d_qs_useeds};
         for (void* p : old) if (p) (void)hipFree(p);
-        c->d_qs_world = nullptr; c->d_qs_nbr = nullptr; c->d_qs_cnt = nullptr; c->d_qs_ulist = nullptr; c->cap_qs = 0;
+        c->d_qs_world = nullptr; c->d_qs_nbr = nullptr; c->d_qs_cnt = nullptr; c->d_qs_ulist = nullptr; c->d_qs_useeds = nullptr; c->cap_qs = 0;
         HIPCHK(c, hipMalloc((void**)&c->d_qs_world, (size_t)n * sizeof(float4)));
         HIPCHK(c, hipMalloc((void**)&c->d_qs_nbr, (size_t)n * K * sizeof(float4)));
         HIPCHK(c, hipMalloc((void**)&c->d_qs_cnt, (size_t)n));
         HIPCHK(c, hipMalloc((void**)&c->d_qs_ulist, (size_t)n * sizeof(float4)));
+        HIPCHK(c, hipMalloc((void**)&c->d_qs_useeds, (size_t)n * 8 * sizeof(unsigned long long)));
         c->cap_qs = n;
     }
     int rc = upload_points(c, q_xyz, (size_t)n, stride_bytes, c->d_qs_world);
     if (rc != LIO_OK) return rc;
     Pose14 ident{};
-    rc = run_knn(c, nullptr, c->d_qs_world, ident, n, n, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, false, true);
+    rc = run_knn(c, nullptr, c->d_qs_world, ident, n, n, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, c->d_qs_useeds, false, true);
     if (rc != LIO_OK) return rc;
     const size_t b_xyz = (size_t)n * K * 3 * sizeof(float), b_d = (size_t)n * K * sizeof(float), b_c = (size_t)n * sizeof(int);
     rc = ensure_scratch(c, b_xyz + b_d + b_c);
@@ -1645,7 +1652,7 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
 
     if (do_search) {
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
-        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->hint_valid, c->dbg_separate_walk != 0);
+        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, c->dbg_separate_walk != 0);
         if (rc != LIO_OK) { c->pass_in_flight = false; return rc; }
         c->have_search = true; c->hint_valid = true;
     }
@@ -1654,10 +1661,11 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.rows = nullptr; ra.units = c->d_units; ra.gunits = c->d_gunits;
     const unsigned long long seq = ++c->seq;
     ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
-    ra.debug_fail = c->dbg_force_timeout;
+    ra.debug_fail = (c->dbg_force_timeout ? 1 : 0) | (c->dbg_stamps ? 2 : 0);
     if (do_search && !c->dbg_separate_walk) {
         ra.n_walkers = residual_walkers(nq); ra.walk_done = c->d_counters + 16;
-        ra.tree = tree_args(c, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist);
+        ra.tree = tree_args(c, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds);
+        ra.spec_rows = c->d_spec_rows;
     }
     const hipError_t le = launch_residual(ra, do_search != 0, ext, s, prof_timer(c, LIO_PROF_RESIDUAL));
     if (le != hipSuccess) { c->pass_in_flight = false; return c->fail(LIO_ERR_HIP, "launch_residual", hipGetErrorString(le)); }
@@ -1826,6 +1834,7 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (!c || !key) return LIO_ERR_INVALID_ARG;
     if (std::strcmp(key, "force_reduction_timeout") == 0) { c->dbg_force_timeout = value != 0; return LIO_OK; }
     if (std::strcmp(key, "separate_tree_walk") == 0) { c->dbg_separate_walk = value != 0; return LIO_OK; }
+    if (std::strcmp(key, "stamps") == 0) { c->dbg_stamps = value != 0; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "unknown key");
 }
 int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {

@@ -25,6 +25,7 @@ struct KnnArgs {
     uint8_t*         cnt;           // [nq] neighbours found (0..5)
     float4*          ulist;         // queries the 27-cell search could not prove: (x, y, z, query number as bits),
     uint32_t*        n_unres;       // appended here (one atomic per unproven query: tens per 100 k) for the tree walk
+    unsigned long long* useeds;     // [list entry][8]: the five (sqdist bits << 32 | map index) keys of the unproven 27-cell result
     unsigned long long* cand_total; // device counter: sum of C(q)
     int              use_hint;      // nbr/cnt hold this scan's previous neighbours: bound the search with them
 };
@@ -45,6 +46,7 @@ struct TreeArgs {
     TreeLevels       levels;
     Grid             grid;
     const float4*    ulist;         // the unproven queries: (x, y, z, query number as bits)
+    const unsigned long long* useeds;  // [list entry][8] keys of their 27-cell results (nullptr: the walk starts from nothing)
     uint32_t*        n_unres;       // how many (written by knn27_kernel; consumed and zeroed by whoever reads the result;
                                     // bit 31 = TREE_OVERFLOW report)
     int              nq;
@@ -73,19 +75,25 @@ struct ResidualArgs {
     unsigned long long* cand_total; // ditto
     DeviceOut*     out;             // host-mapped result record
     unsigned long long seq;         // published last (system-scope release) in out->seq
-    int            debug_fail;      // test hook (lio_debug_set "force_reduction_timeout"): report a timed-out wait
+    int            debug_fail;      // test hooks (lio_debug_set): bit 0 "force_reduction_timeout" reports a timed-out wait, bit 1 "stamps"
     // search passes: the exact tree walk of the queries the 27-cell kernel could not prove runs INSIDE this launch, on
     // the first n_walkers workgroups (one walking wavefront each); a model workgroup that owns such a query (marked in
     // cnt by CNT_UNPROVEN) waits until every listed query has been walked (walk_done == number of listed queries)
     int            n_walkers;       // 0: no walk in this launch (the stand-alone knn_tree_kernel ran, or a no-search pass)
     uint32_t*      walk_done;       // device counter: walked queries of this pass (reset by the last workgroup)
     TreeArgs       tree;            // map index + the list (tree.nbr / tree.cnt = the scan's neighbour arrays)
-    // Few listed queries (<= FIX_MAX, the normal case): nobody but the LAST workgroup waits for the walk -- the owners
-    // count such a query as not selected, the last workgroup evaluates the models of all of them (one lane each) while
-    // the partial sums it is going to fold are still arriving, and adds their rows in query order.  More listed
-    // queries: the owners wait (see above).
+    // Few listed queries (<= FIX_MAX, the normal case): nobody but the LAST workgroup waits for the walk, and the walk
+    // only VERIFIES.  knn27_kernel's unproven result is nearly always the exact one (a walk finds nothing better): the
+    // owner evaluates the model of such a query like any other but PARKS what it found (staged row, plane, pd2, accept
+    // flag) in spec_rows[q] instead of writing outputs / adding to its workgroup's sums, the walker of the query reports whether the walk changed the
+    // result (useeds[entry][5]), and the last workgroup, after its folds, adds the rows of the listed queries in query
+    // order -- the owner's row where the walk confirmed the result, a re-evaluated one where it did not -- and writes
+    // their outputs (one writer per query).  More listed
+    // queries: the owners wait for the walk (see above).
+    double*        spec_rows;       // [max_scan_points][SPEC_STRIDE]: staged row of a listed query (written through)
 };
-constexpr int FIX_MAX = 256;                 // listed queries up to which the last workgroup evaluates the walked queries
+constexpr int FIX_MAX = 256;                 // listed queries up to which the last workgroup adds the listed queries' rows
+constexpr int SPEC_STRIDE = 20;              // doubles per parked query: staged row (<= 15), then n^ | d | pd2 | sel as 3 x 2 floats at [16..18]
 int residual_blocks(int nq);
 int residual_walkers(int nq);       // walking workgroups a search pass adds in front of the model workgroups
 hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s, KernelTimer t = KernelTimer());

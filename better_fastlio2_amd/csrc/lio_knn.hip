@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     }
 
     // ---- proof: every point outside the searched block is farther than the 5th neighbour ------
+    uint32_t slot = 0xffffffffu;                   // list entry of this query when it stays unproven (lane r == 0)
     if (active && r == 0) {
         const float cell = a.grid.cell;
         bool proven = false;
@@ -351,8 +352,19 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         // knn_tree_kernel); until then their count carries the mark the owner of the query looks for
         a.cnt[q] = (uint8_t)nvalid | (proven ? (uint8_t)0 : CNT_UNPROVEN);
         if (!proven) {
-            const uint32_t slot = atomicAdd(a.n_unres, 1u);
+            slot = atomicAdd(a.n_unres, 1u);
             a.ulist[slot] = make_float4(qx, qy, qz, __uint_as_float((uint32_t)q));
+        }
+    }
+    // The walk does not start from nothing: the five keys of this result are the best five of the 27 cells (of the
+    // cells the bound left, in a bounded search -- the others hold nothing that can enter), so the walk seeds its list
+    // with them and only looks at what lies OUTSIDE the block and within their 5th distance.
+    {
+        const uint32_t gslot = (uint32_t)__shfl((int)slot, lane - r, 64);
+        if (gslot != 0xffffffffu) {
+            unsigned long long* dst = a.useeds + (size_t)gslot * 8u;
+            if (r < K) dst[r] = (unsigned long long)__double_as_longlong(mine0);
+            if (G < K && r + G < K) dst[r + G] = (unsigned long long)__double_as_longlong(mine1);
         }
     }
     // candidate census for the byte model (opt-in: one atomic per wavefront)
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(64) void knn_tree_kernel(TreeArgs a) {
     const uint32_t n = __hip_atomic_load(a.n_unres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~TREE_OVERFLOW;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         if (i != blockIdx.x) e = a.ulist[i];
-        tree_search_one(a, __float_as_uint(e.w), e.x, e.y, e.z, lane, ts);
+        tree_search_one(a, __float_as_uint(e.w), e.x, e.y, e.z, lane, ts, nullptr, a.useeds ? a.useeds + (size_t)i * 8u : nullptr);
     }
 }
 

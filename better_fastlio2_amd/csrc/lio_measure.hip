@@ -81,16 +81,28 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         __builtin_amdgcn_s_setprio(3);             // the walk is on the critical path of the pass: ahead of the model waves
         TreeScratch& ts = *reinterpret_cast<TreeScratch*>(s_raw);
         const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;        // complete: written by the k-NN launch before this one
-        uint32_t walked = 0;
+        uint32_t walked = 0, n_changed = 0;
         for (uint32_t e = blockIdx.x; e < n; e += (uint32_t)n_walkers) {
             const float4 q = a.tree.ulist[e];
-            tree_search_one(a.tree, __float_as_uint(q.w), q.x, q.y, q.z, tid, ts);
+            bool changed = true;
+            tree_search_one(a.tree, __float_as_uint(q.w), q.x, q.y, q.z, tid, ts, nullptr, a.tree.useeds ? a.tree.useeds + (size_t)e * 8u : nullptr, &changed);
+            // the verdict of this walk, for the last workgroup (fix mode): did it change Nearest_Points[q]?
+            if (tid == 0 && a.tree.useeds)
+                __hip_atomic_store(const_cast<unsigned long long*>(a.tree.useeds) + (size_t)e * 8u + 5u, (unsigned long long)(changed ? 1u : 0u),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ++walked;
+            n_changed += changed ? 1u : 0u;
         }
         if (walked != 0 && tid == 0) {
-            // results (write-through stores of this wavefront, lio_tree.h) -> drained -> the counter the waiters poll
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // results and verdicts are written THROUGH (agent-scope stores, lio_tree.h): drained = in memory; then the
+            // counter the waiters poll (no L2 write-back needed, and buffer_wbl2 costs ~1.7 us)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // walk_done[1]: walks that changed a result (rare) -- added first, so whoever sees the full count of walked
+            // entries also sees every change that belongs to them
+            if (n_changed != 0) {
+                __hip_atomic_fetch_add(a.walk_done + 1, n_changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __hip_atomic_fetch_add(a.walk_done, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
@@ -99,7 +111,9 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     double (&s_rows)[BS][S::NCOLS] = sm.rows;
     double (&s_part)[S::SEG][S::NEP] = sm.part;
     const int bid = (int)blockIdx.x - n_walkers;   // index among the model workgroups
-    const unsigned long long t_dbg0 = wall_clock64();
+    const bool stamps = (a.debug_fail & 2) != 0;   // lio_debug_set("stamps"): s_memrealtime answers through the scalar memory path,
+                                                   // every stamp delays the next lgkmcnt wait -- off unless asked for
+    const unsigned long long t_dbg0 = stamps ? wall_clock64() : 0ull;
     unsigned long long t_dbg1 = 0, t_dbg2 = 0, t_dbg3 = 0, t_dbg4 = 0, t_dbg5 = 0, t_dbg6 = 0;
     const int i = bid * BS + tid;
     if (tid == 0) s_failed = 0u;
@@ -118,9 +132,12 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     // few listed queries: their walkers also evaluate the model, nobody waits (FIX_MAX, lio_kernels.h)
     const bool fix_mode = SEARCH && n_walkers > 0 && (*a.n_unresolved & ~TREE_OVERFLOW) <= (uint32_t)FIX_MAX;
     bool walked_elsewhere = false;
+    // (the last workgroup orders the listed queries later: their list entries are fetched now, off the critical path)
+    float4 lq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fix_mode && bid == (int)gridDim.x - n_walkers - 1 && (uint32_t)tid < (*a.n_unresolved & ~TREE_OVERFLOW)) lq = a.tree.ulist[tid];
     const PoseQ s = pose_unpack(a.pose);
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-    float wx = 0.f, wy = 0.f, wz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    float wx = 0.f, wy = 0.f, wz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, plane_d = 0.f;
     if (SEARCH) {
         float4 nb[K];
         uint8_t cnt_i = 0;
@@ -136,7 +153,9 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         // (bounded; a timeout is reported like a reduction timeout), acquire, and read those neighbours again.  Walkers
         // have the lowest workgroup indices, i.e. they are dispatched first.
         if (n_walkers > 0 && fix_mode) {
-            // the walker of a listed query evaluates its model and writes its outputs; here it counts as not selected
+            // a listed query is evaluated like any other (its 27-cell result is nearly always the exact one), but its
+            // staged row goes to spec_rows instead of this workgroup's sums: the last workgroup adds it once the walk
+            // has confirmed the result, or re-evaluates it
             walked_elsewhere = in && (cnt_i & CNT_UNPROVEN) != 0;
         } else if (n_walkers > 0) {
             const bool owes = __syncthreads_or((in && (cnt_i & CNT_UNPROVEN) != 0) ? 1 : 0) != 0;
@@ -159,13 +178,12 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         }
         wx = wpt.x; wy = wpt.y; wz = wpt.z;
         // points_near.size() < 5 ? false : sqdis[4] > 5 ? false : true          :1911
-        if (in && !walked_elsewhere && ((cnt_i & ~CNT_UNPROVEN) >= K) && !(nb[4].w > 5.0f)) {
+        if (in && ((cnt_i & ~CNT_UNPROVEN) >= K) && !(nb[4].w > 5.0f)) {
             float px[5], py[5], pz[5];
 #pragma unroll
             for (int k = 0; k < K; ++k) { px[k] = nb[k].x; py[k] = nb[k].y; pz[k] = nb[k].z; }
-            float pd = 0.0f;
-            sel = point_residual(px, py, pz, wx, wy, wz, b.x, b.y, b.z, nx, ny, nz, pd2, &pd);
-            if (sel) a.plane[i] = make_float4(nx, ny, nz, pd);
+            sel = point_residual(px, py, pz, wx, wy, wz, b.x, b.y, b.z, nx, ny, nz, pd2, &plane_d);
+            if (sel && !walked_elsewhere) a.plane[i] = make_float4(nx, ny, nz, plane_d);
         }
     } else if (in) {
         b = a.body[i];
@@ -180,7 +198,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     }
     if (in) {
         if (sel) {
-            a.normvec[i] = make_float4(nx, ny, nz, pd2);                   // :1933-1936
+            if (!walked_elsewhere) a.normvec[i] = make_float4(nx, ny, nz, pd2);   // :1933-1936
             jacobian_row<EXT>(s, b.x, b.y, b.z, nx, ny, nz, pd2, row, h);
         }
         if (!walked_elsewhere) a.sel[i] = sel ? 1 : 0;
@@ -193,6 +211,24 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     }
 
     // ---- stage the row (zeros when not selected) ---------------------------------------------
+    if (walked_elsewhere) {
+        // a listed query: the staged row is parked (written through, read by the last workgroup after the walk) ...
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.spec_rows + (size_t)i * SPEC_STRIDE);
+#pragma unroll
+        for (int c = 0; c < S::NC; ++c)
+            __hip_atomic_store(dst + c, (unsigned long long)__double_as_longlong(row[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + S::COL_H, (unsigned long long)__double_as_longlong(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + S::COL_RES, (unsigned long long)__double_as_longlong(sel ? (double)__builtin_fabsf(pd2) : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + S::COL_ONE, (unsigned long long)__double_as_longlong(sel ? 1.0 : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        auto pack2 = [](float lo, float hi) { return ((unsigned long long)__float_as_uint(hi) << 32) | (unsigned long long)__float_as_uint(lo); };
+        __hip_atomic_store(dst + 16, pack2(nx, ny), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 17, pack2(nz, plane_d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 18, pack2(pd2, sel ? 1.0f : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ... the outputs of the query are written by the last workgroup, and this workgroup's sums do not contain it
+#pragma unroll
+        for (int c = 0; c < 12; ++c) row[c] = 0.0;
+        h = 0.0; sel = false;
+    }
 #pragma unroll
     for (int c = 0; c < S::NC; ++c) s_rows[tid][c] = row[c];
     s_rows[tid][S::COL_H] = h;
@@ -246,85 +282,8 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             __hip_atomic_store(dst + 1, (bits >> 32) | stamp_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    t_dbg1 = wall_clock64();
+    if (stamps) t_dbg1 = wall_clock64();
     if (!grp_reducer) return;
-
-    // ---- fix mode, last workgroup: the model of the walked queries, one lane each, BEFORE the folds (the partial sums
-    // it is going to fold are still on their way, the walkers have been running since the launch began): wait for the
-    // walk, evaluate gate / plane / residual / Jacobian row exactly as the owner's lane would have, order the rows by
-    // query number (the list is in arrival order) and reduce them with the code every workgroup uses for its rows
-    __shared__ double s_fix[S::NEP];
-    if (tid < S::NEP) s_fix[tid] = 0.0;
-    if (fix_mode && final_reducer) {
-        const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;
-        if (n > 0) {
-            static_assert(FIX_MAX == BS, "one walked query per lane");
-            __shared__ uint32_t s_key[FIX_MAX];
-            if (tid == 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(a.walk_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n && ++spins < SPIN_LIMIT)
-                    __builtin_amdgcn_s_sleep(2);
-                if (spins >= SPIN_LIMIT) s_failed = 1u;
-            }
-            const bool has = (uint32_t)tid < n;
-            float4 lq = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (has) lq = a.tree.ulist[tid];                           // (world point, query number) written by the k-NN launch
-            const uint32_t qi = has ? __float_as_uint(lq.w) : 0xffffffffu;
-            s_key[tid] = qi;
-            __syncthreads();                                           // s_rows / s_part are free again, the walk is done
-            t_dbg4 = wall_clock64();
-            int rank = tid;                                            // lanes without a query keep their own (zero) row
-            bool fsel = false;
-            double frow[12], fh = 0.0;
-            float fpd2 = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 12; ++c) frow[c] = 0.0;
-            if (has) {
-                rank = 0;
-                for (uint32_t j = 0; j < n; ++j) rank += s_key[j] < qi ? 1 : 0;
-                float4 nb[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) nb[k] = load_walked_neighbor(a.nbr, (size_t)k * a.nq_stride + qi);
-                const uint8_t cq = __hip_atomic_load(a.cnt + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float4 fb = a.body[qi];
-                float fnx = 0.f, fny = 0.f, fnz = 0.f, fpd = 0.f;
-                if (((cq & ~CNT_UNPROVEN) >= K) && !(nb[4].w > 5.0f)) {      // :1911
-                    float px[5], py[5], pz[5];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) { px[k] = nb[k].x; py[k] = nb[k].y; pz[k] = nb[k].z; }
-                    fsel = point_residual(px, py, pz, lq.x, lq.y, lq.z, fb.x, fb.y, fb.z, fnx, fny, fnz, fpd2, &fpd);
-                }
-                if (fsel) {
-                    a.plane[qi] = make_float4(fnx, fny, fnz, fpd);
-                    a.normvec[qi] = make_float4(fnx, fny, fnz, fpd2);
-                    jacobian_row<EXT>(s, fb.x, fb.y, fb.z, fnx, fny, fnz, fpd2, frow, fh);
-                }
-                a.sel[qi] = fsel ? 1 : 0;
-            }
-            t_dbg5 = wall_clock64();
-#pragma unroll
-            for (int c = 0; c < S::NC; ++c) s_rows[rank][c] = frow[c];
-            s_rows[rank][S::COL_H] = fh;
-            s_rows[rank][S::COL_RES] = fsel ? (double)__builtin_fabsf(fpd2) : 0.0;
-            s_rows[rank][S::COL_ONE] = fsel ? 1.0 : 0.0;
-            __syncthreads();
-            double facc = 0.0;
-            if (e < S::NE) {
-                int ca, cb;
-                entry_columns<EXT>(e, ca, cb);
-                const int r0 = seg * S::RS;
-                for (int r = 0; r < S::RS; ++r) facc += s_rows[r0 + r][ca] * s_rows[r0 + r][cb];
-            }
-            s_part[seg][e] = facc;
-            __syncthreads();
-            if (tid < S::NE) {
-                double t = 0.0;
-#pragma unroll
-                for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
-                s_fix[tid] = t;
-            }
-        }
-    }
 
     // poll-and-read `count` stamped partials starting at `src` (stride RED_STRIDE entries), fixed order per lane
     auto fold = [&](const u64* src, int count) -> double {
@@ -378,7 +337,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             __hip_atomic_store(dst + 1, (bits >> 32) | stamp_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    t_dbg2 = wall_clock64();
+    if (stamps) t_dbg2 = wall_clock64();
     if (!final_reducer) return;
 
     // ---- the last workgroup of the grid: the group sums in index order, its own group's last ---------------
@@ -391,12 +350,127 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         double t = 0.0;
 #pragma unroll
         for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
-        s_fin[tid] = (t + s_own[tid]) + s_fix[tid];      // + the rows of the walked queries (zero outside fix mode)
+        s_fin[tid] = t + s_own[tid];
     }
     __syncthreads();
-    t_dbg3 = wall_clock64();
-    t_dbg6 = wall_clock64();
-    const bool failed = s_failed != 0u || a.debug_fail != 0 || s_fin[S::NE - 1] < -0.5;
+    if (stamps) t_dbg3 = wall_clock64();
+    // ---- fix mode: the rows of the listed queries.  The walkers have been running since the launch began and only had
+    // to verify; their verdicts are long there when the folds above are done.  One lane per listed query: the row the
+    // owner parked (walk confirmed the 27-cell result) or a re-evaluation on the walked neighbours (it did not), ordered
+    // by query number (the list is in arrival order) and reduced with the code every workgroup uses for its own rows.
+    if (fix_mode) {
+        const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;
+        if (n > 0) {
+            static_assert(FIX_MAX == BS, "one listed query per lane");
+            __shared__ __align__(16) uint32_t s_key[FIX_MAX];
+            __shared__ uint32_t s_any_changed;
+            if (tid == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(a.walk_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n && ++spins < SPIN_LIMIT)
+                    __builtin_amdgcn_s_sleep(2);
+                if (spins >= SPIN_LIMIT) s_failed = 1u;
+                s_any_changed = __hip_atomic_load(a.walk_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const bool has = (uint32_t)tid < n;
+            const uint32_t qi = has ? __float_as_uint(lq.w) : 0xffffffffu;   // lq: (world point, query number), fetched at the start
+            s_key[tid] = qi;
+            __syncthreads();                                           // the walk is done (lane 0 saw it), s_rows / s_part are free
+            if (stamps) t_dbg4 = wall_clock64();
+            int rank = tid;                                            // lanes without a query keep their own (zero) row
+            double frow[S::NCOLS];
+#pragma unroll
+            for (int c = 0; c < S::NCOLS; ++c) frow[c] = 0.0;
+            if (has) {
+                // the verdict and the parked row in ONE round trip (the row is simply not used if the walk changed the result)
+                const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.spec_rows + (size_t)qi * SPEC_STRIDE);
+                // (the per-entry verdict is only fetched when some walk of this pass changed a result at all)
+                const unsigned long long verdict = s_any_changed == 0u ? 0ull :
+                    __hip_atomic_load(a.tree.useeds + (size_t)tid * 8u + 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the parked row was written THROUGH by its owner before that owner's partial sums (folded above) and
+                // neither this CU's L1 nor this XCD's L2 has seen these lines in this launch: plain 16-byte loads
+                unsigned long long raw[SPEC_STRIDE];
+                {
+                    const ulonglong2* src2 = reinterpret_cast<const ulonglong2*>(src);
+#pragma unroll
+                    for (int c = 0; c < SPEC_STRIDE / 2; ++c) { const ulonglong2 v = src2[c]; raw[2 * c] = v.x; raw[2 * c + 1] = v.y; }
+                }
+                const unsigned long long p0 = raw[16], p1 = raw[17], p2 = raw[18];
+                // rank among the listed queries = position of the row (while the loads are in flight): 16-byte LDS reads,
+                // eight keys per iteration (lanes beyond n hold 0xffffffff, never smaller than a query number)
+                rank = 0;
+                for (uint32_t j = 0; j < n; j += 8) {
+                    const uint4 k0 = *reinterpret_cast<const uint4*>(&s_key[j]);
+                    const uint4 k1 = *reinterpret_cast<const uint4*>(&s_key[j + 4]);
+                    rank += (k0.x < qi) + (k0.y < qi) + (k0.z < qi) + (k0.w < qi) + (k1.x < qi) + (k1.y < qi) + (k1.z < qi) + (k1.w < qi);
+                }
+                const bool changed = verdict != 0ull;
+                if (!changed) {
+#pragma unroll
+                    for (int c = 0; c < S::NCOLS; ++c) frow[c] = __longlong_as_double((long long)raw[c]);
+                    const float onx = __uint_as_float((uint32_t)p0), ony = __uint_as_float((uint32_t)(p0 >> 32));
+                    const float onz = __uint_as_float((uint32_t)p1), opd = __uint_as_float((uint32_t)(p1 >> 32));
+                    const float opd2 = __uint_as_float((uint32_t)p2);
+                    const bool osel = __uint_as_float((uint32_t)(p2 >> 32)) != 0.0f;
+                    if (osel) {
+                        a.plane[qi] = make_float4(onx, ony, onz, opd);
+                        a.normvec[qi] = make_float4(onx, ony, onz, opd2);
+                    }
+                    a.sel[qi] = osel ? 1 : 0;
+                } else {
+                    // the walk found closer points: the owner's outputs for this query are replaced
+                    float4 nb[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) nb[k] = load_walked_neighbor(a.nbr, (size_t)k * a.nq_stride + qi);
+                    const uint8_t cq = __hip_atomic_load(a.cnt + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float4 fb = a.body[qi];
+                    bool fsel = false;
+                    float fnx = 0.f, fny = 0.f, fnz = 0.f, fpd = 0.f, fpd2 = 0.f;
+                    double jrow[12], fh = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) jrow[c] = 0.0;
+                    if (((cq & ~CNT_UNPROVEN) >= K) && !(nb[4].w > 5.0f)) {      // :1911
+                        float px[5], py[5], pz[5];
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { px[k] = nb[k].x; py[k] = nb[k].y; pz[k] = nb[k].z; }
+                        fsel = point_residual(px, py, pz, lq.x, lq.y, lq.z, fb.x, fb.y, fb.z, fnx, fny, fnz, fpd2, &fpd);
+                    }
+                    if (fsel) {
+                        a.plane[qi] = make_float4(fnx, fny, fnz, fpd);
+                        a.normvec[qi] = make_float4(fnx, fny, fnz, fpd2);
+                        jacobian_row<EXT>(s, fb.x, fb.y, fb.z, fnx, fny, fnz, fpd2, jrow, fh);
+                    }
+                    a.sel[qi] = fsel ? 1 : 0;
+#pragma unroll
+                    for (int c = 0; c < S::NC; ++c) frow[c] = jrow[c];
+                    frow[S::COL_H] = fh;
+                    frow[S::COL_RES] = fsel ? (double)__builtin_fabsf(fpd2) : 0.0;
+                    frow[S::COL_ONE] = fsel ? 1.0 : 0.0;
+                }
+            }
+            if (stamps) t_dbg5 = wall_clock64();
+#pragma unroll
+            for (int c = 0; c < S::NCOLS; ++c) s_rows[rank][c] = frow[c];
+            __syncthreads();
+            double facc = 0.0;
+            if (e < S::NE) {
+                int ca, cb;
+                entry_columns<EXT>(e, ca, cb);
+                const int r0 = seg * S::RS;
+                for (int r = 0; r < S::RS; ++r) facc += s_rows[r0 + r][ca] * s_rows[r0 + r][cb];
+            }
+            s_part[seg][e] = facc;
+            __syncthreads();
+            if (tid < S::NE) {
+                double t = 0.0;
+#pragma unroll
+                for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
+                s_fin[tid] += t;
+            }
+            __syncthreads();
+        }
+    }
+    if (stamps) t_dbg6 = wall_clock64();
+    const bool failed = s_failed != 0u || (a.debug_fail & 1) != 0 || s_fin[S::NE - 1] < -0.5;
     // One wavefront writes the whole record into host-mapped memory, fences at system scope and only
     // then publishes the sequence number the host is polling.
     if (tid < 64) {
@@ -419,9 +493,9 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             out->n_unresolved = SEARCH ? (int)*a.n_unresolved : 0;
             out->n_candidates = SEARCH ? *a.cand_total : 0ull;
             out->dbg[0] = t_dbg0; out->dbg[1] = t_dbg1; out->dbg[2] = t_dbg2; out->dbg[3] = t_dbg3; out->dbg[4] = t_dbg4;
-            out->dbg[5] = t_dbg5; out->dbg[6] = t_dbg6; out->dbg[7] = wall_clock64();
+            out->dbg[5] = t_dbg5; out->dbg[6] = t_dbg6; out->dbg[7] = stamps ? wall_clock64() : 0ull;
             // consumed: zero the counters for the next pass
-            if (SEARCH) { *a.n_unresolved = 0u; *a.cand_total = 0ull; if (n_walkers > 0) *a.walk_done = 0u; }
+            if (SEARCH) { *a.n_unresolved = 0u; *a.cand_total = 0ull; if (n_walkers > 0) { a.walk_done[0] = 0u; a.walk_done[1] = 0u; } }
         }
         __threadfence_system();
         if (tid == 0) __hip_atomic_store(&out->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

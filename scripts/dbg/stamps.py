@@ -7,6 +7,7 @@ world = synth.make_world(nm, 0.2); scan = synth.make_scan(world, nq)
 pos, rot = synth.perturb_state(scan); st = synth.state_vector(pos, rot, scan.off_R, scan.off_T)
 ctx = capi.LioContext(0.2, max_scan_points=nq, max_map_points=nm + 1000)
 ctx.map_build(world.points); ctx.scan_set(scan.body)
+ctx.debug_set("stamps", 1)
 st2 = st.copy(); st2[:3] += [0.01, -0.02, 0.005]
 buf = np.zeros(8, np.uint64)
 for search, pose in [(True, st), (False, st2), (True, st2), (False, st), (True, st), (True, st2), (False, st)] * 2:
