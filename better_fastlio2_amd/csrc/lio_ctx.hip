@@ -89,6 +89,8 @@ struct lio_ctx {
     const void* upload_src = nullptr;
     int upload_n = 0;
     bool pass_in_flight = false, pass_empty = false;   // between lio_measure_begin and lio_measure_end
+    bool pass_searched = false;                // the pass in flight is a search pass
+    int listed_last_search = 0;                // unproven queries of the most recent search pass: predicts the next one's
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
     float4* d_ulist = nullptr;                 // queries the 27-cell kernel could not prove (count: d_counters[0])
     unsigned long long* d_useeds = nullptr;    // [list entry][8]: keys of their 27-cell results, the seeds of the walk; [5] = its verdict
@@ -523,6 +525,9 @@ KernelTimer prof_timer(lio_ctx* c, int which) {
 // receives them otherwise (the kernel transforms).  walk_now: settle the unproven queries with the stand-alone tree
 // kernel; otherwise they stay listed (count in d_counters[0], cnt marked CNT_UNPROVEN) for the measurement kernel of
 // the pass, which carries the walk itself.
+constexpr int FUSED_TRANSFORM_MAX_QUERIES = 262144;
+// listed (unproven) queries of the last search pass above which the next one walks them in a launch of its own
+constexpr int INLINE_WALK_MAX_LISTED = 1024;
 TreeArgs tree_args(lio_ctx* c, int nq, int stride, float4* nbr, uint8_t* cnt, float4* ulist, unsigned long long* useeds) {
     TreeArgs ta{};
     ta.map_pts = c->d_pts; ta.child = c->d_child; ta.ltable = c->d_ltable; ta.levels = c->levels; ta.grid = c->grid;
@@ -539,6 +544,10 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.map_pts = c->d_pts; ka.grid = c->grid;
     ka.l1table = c->d_ltable + c->levels.off[1]; ka.l1mask = c->levels.mask[1]; ka.child = c->d_child;
     ka.world_in = queries_world; ka.body = body; ka.world_out = queries_world; ka.pose = pose;
+    if (body != nullptr && nq > FUSED_TRANSFORM_MAX_QUERIES) {       // (see transform_kernel, lio_knn.hip)
+        HIPCHK(c, launch_transform(body, nq, pose, queries_world, s));
+        ka.body = nullptr;
+    }
     ka.nq = nq; ka.nq_stride = stride;
     ka.nbr = nbr; ka.cnt = cnt; ka.ulist = ulist; ka.useeds = useeds; ka.n_unres = c->d_counters; ka.cand_total = c->census ? c->d_cand : nullptr;
     ka.use_hint = use_hint ? 1 : 0;
@@ -1650,9 +1659,16 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     if (nq == 0) return LIO_OK;                               // "No Effective Points" laserMapping.cpp:1956
     hipStream_t s = c->stream;
 
+    // The exact walk of the unproven queries normally rides inside the measurement kernel (tens of queries: nobody waits
+    // for it).  When the LAST search pass listed many (a scan at the map's edge, C5's 1 M-point scan: thousands), nearly
+    // every model workgroup would sit waiting for 1-wavefront walkers: then the walk gets the whole GPU in a launch of
+    // its own, as in round 1 -- and so it does for scans far beyond the node's 100 k points, where the measurement kernel
+    // is throughput-bound and the lean variant (without the walk's registers) runs at nearly twice the occupancy.
+    const bool separate_walk = c->dbg_separate_walk != 0 || c->listed_last_search > INLINE_WALK_MAX_LISTED || nq > FUSED_TRANSFORM_MAX_QUERIES;
+    c->pass_searched = do_search != 0;
     if (do_search) {
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
-        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, c->dbg_separate_walk != 0);
+        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk);
         if (rc != LIO_OK) { c->pass_in_flight = false; return rc; }
         c->have_search = true; c->hint_valid = true;
     }
@@ -1662,7 +1678,7 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     const unsigned long long seq = ++c->seq;
     ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
     ra.debug_fail = (c->dbg_force_timeout ? 1 : 0) | (c->dbg_stamps ? 2 : 0);
-    if (do_search && !c->dbg_separate_walk) {
+    if (do_search && !separate_walk) {
         ra.n_walkers = residual_walkers(nq); ra.walk_done = c->d_counters + 16;
         ra.tree = tree_args(c, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds);
         ra.spec_rows = c->d_spec_rows;
@@ -1721,6 +1737,7 @@ int lio_measure_end(lio_ctx* c, lio_out* out) {
     std::memcpy(out->HTh, d.HTh, sizeof(out->HTh));
     out->n_candidates = d.n_candidates;
     c->last_m = d.m; c->have_pass = true;
+    if (c->pass_searched) c->listed_last_search = d.n_unresolved;
     return LIO_OK;
 }
 

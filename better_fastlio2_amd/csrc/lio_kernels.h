@@ -29,6 +29,8 @@ struct KnnArgs {
     unsigned long long* cand_total; // device counter: sum of C(q)
     int              use_hint;      // nbr/cnt hold this scan's previous neighbours: bound the search with them
 };
+// feats_down_world = pose (x) feats_down_body as a launch of its own (large scans only; otherwise inside knn27_kernel)
+hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float4* world, hipStream_t s);
 // lanes_per_query in {4, 8, 16, 32, 64}
 // optional per-launch timing: when `start` is set the kernel is dispatched through hipExtLaunchKernelGGL,
 // which stamps the two events with the dispatch's own begin/end (no marker packets around the kernel)

@@ -390,6 +390,25 @@ static void launch_knn27_g(const KnnArgs& a, hipStream_t s, KernelTimer t) {
     else if (a.use_hint)         hipLaunchKernelGGL((knn27_kernel<G, false, true>), grid, block, 0, s, a);
     else                         hipLaunchKernelGGL((knn27_kernel<G, false, false>), grid, block, 0, s, a);
 }
+// feats_down_world = pose (x) feats_down_body (laserMapping.cpp:1894-1899) as its own launch, one lane per point: for scans
+// far beyond the 100 k of the node (C5: 1 M queries against a map that does not fit the Infinity Cache) the transform
+// inside knn27_kernel -- one wavefront per workgroup, the others waiting at a barrier for a body-point load that now
+// comes from HBM -- costs more than this launch (+35 us vs ~12 us at 1 M queries); at 100 k it is the other way round.
+__global__ __launch_bounds__(256) void transform_kernel(const float4* body, int n, Pose14 pose, float4* world) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 b = body[i];
+    const PoseQ s = pose_unpack(pose);
+    float wx, wy, wz;
+    body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
+    world[i] = make_float4(wx, wy, wz, b.w);
+}
+hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float4* world, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(transform_kernel, dim3((n + 255) / 256), dim3(256), 0, s, body, n, pose, world);
+    return hipGetLastError();
+}
+
 hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s, KernelTimer t) {
     if (a.nq <= 0) return hipSuccess;
     switch (lanes_per_query) {

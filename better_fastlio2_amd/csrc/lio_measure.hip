@@ -61,11 +61,15 @@ template <bool EXT, int BS> struct ModelSmem {
     double fin[S::NEP];
 };
 
-template <bool EXT, bool SEARCH, int BS>
+// WALK: a search pass that carries the exact tree walk of the listed queries (walker workgroups in front, the last
+// workgroup adds their rows).  Without it (the walk ran as its own launch, or a pass that re-uses neighbours) the kernel
+// is the lean one: 62 instead of 104 VGPRs -- at 1 M points (C5) that is 45 us instead of 160.
+template <bool EXT, bool SEARCH, bool WALK, int BS>
 __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
+    static_assert(SEARCH || !WALK, "only a search pass walks");
     typedef RedShape<EXT, BS> S;
     // a workgroup is either a walker (TreeScratch, search passes only) or a model workgroup: one LDS allocation
-    constexpr size_t SMEM = SEARCH && sizeof(TreeScratch) > sizeof(ModelSmem<EXT, BS>) ? sizeof(TreeScratch) : sizeof(ModelSmem<EXT, BS>);
+    constexpr size_t SMEM = WALK && sizeof(TreeScratch) > sizeof(ModelSmem<EXT, BS>) ? sizeof(TreeScratch) : sizeof(ModelSmem<EXT, BS>);
     __shared__ __align__(16) unsigned char s_raw[SMEM];
     __shared__ uint32_t s_failed;                  // a bounded wait ran out (reported, never silent)
     const int tid = threadIdx.x;
@@ -75,8 +79,8 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     constexpr double POISON = -1.0e300;           // row count of a workgroup whose bounded wait ran out
 
     // ---- walkers: the exact tree walk of the listed queries, one wavefront per workgroup -------------------------
-    const int n_walkers = SEARCH ? a.n_walkers : 0;
-    if (SEARCH && (int)blockIdx.x < n_walkers) {
+    const int n_walkers = WALK ? a.n_walkers : 0;
+    if (WALK && (int)blockIdx.x < n_walkers) {
         if (tid >= 64) return;
         __builtin_amdgcn_s_setprio(3);             // the walk is on the critical path of the pass: ahead of the model waves
         TreeScratch& ts = *reinterpret_cast<TreeScratch*>(s_raw);
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     // is the one stored here (16 bytes instead of 80, no QR).
     const bool in = i < a.nq;
     // few listed queries: their walkers also evaluate the model, nobody waits (FIX_MAX, lio_kernels.h)
-    const bool fix_mode = SEARCH && n_walkers > 0 && (*a.n_unresolved & ~TREE_OVERFLOW) <= (uint32_t)FIX_MAX;
+    const bool fix_mode = WALK && n_walkers > 0 && (*a.n_unresolved & ~TREE_OVERFLOW) <= (uint32_t)FIX_MAX;
     bool walked_elsewhere = false;
     // (the last workgroup orders the listed queries later: their list entries are fetched now, off the critical path)
     float4 lq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -152,12 +156,12 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         // Does this workgroup own a query the walkers still owe (marked by the k-NN kernel)?  Then wait for the walk
         // (bounded; a timeout is reported like a reduction timeout), acquire, and read those neighbours again.  Walkers
         // have the lowest workgroup indices, i.e. they are dispatched first.
-        if (n_walkers > 0 && fix_mode) {
+        if (WALK && n_walkers > 0 && fix_mode) {
             // a listed query is evaluated like any other (its 27-cell result is nearly always the exact one), but its
             // staged row goes to spec_rows instead of this workgroup's sums: the last workgroup adds it once the walk
             // has confirmed the result, or re-evaluates it
             walked_elsewhere = in && (cnt_i & CNT_UNPROVEN) != 0;
-        } else if (n_walkers > 0) {
+        } else if (WALK && n_walkers > 0) {
             const bool owes = __syncthreads_or((in && (cnt_i & CNT_UNPROVEN) != 0) ? 1 : 0) != 0;
             if (owes) {
                 if (tid == 0) {
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     }
 
     // ---- stage the row (zeros when not selected) ---------------------------------------------
-    if (walked_elsewhere) {
+    if (WALK && walked_elsewhere) {
         // a listed query: the staged row is parked (written through, read by the last workgroup after the walk) ...
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.spec_rows + (size_t)i * SPEC_STRIDE);
 #pragma unroll
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     // to verify; their verdicts are long there when the folds above are done.  One lane per listed query: the row the
     // owner parked (walk confirmed the 27-cell result) or a re-evaluation on the walked neighbours (it did not), ordered
     // by query number (the list is in arrival order) and reduced with the code every workgroup uses for its own rows.
-    if (fix_mode) {
+    if (WALK && fix_mode) {
         const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;
         if (n > 0) {
             static_assert(FIX_MAX == BS, "one listed query per lane");
@@ -515,20 +519,23 @@ int residual_walkers(int nq) {
 
 // 256 lanes per workgroup: 512 measured the same and 1024 slower on MI355X (the kernel is a chain of
 // dependent round trips, not throughput-bound)
-template <bool EXT, bool SEARCH>
+template <bool EXT, bool SEARCH, bool WALK>
 static void launch_residual_v(const ResidualArgs& a, hipStream_t s, KernelTimer t) {
-    const dim3 grid(residual_blocks(a.nq) + (SEARCH ? a.n_walkers : 0)), block(256);
-    if (t.start != nullptr) hipExtLaunchKernelGGL((residual_kernel<EXT, SEARCH, 256>), grid, block, 0, s, t.start, t.stop, 0, a);
-    else hipLaunchKernelGGL((residual_kernel<EXT, SEARCH, 256>), grid, block, 0, s, a);
+    const dim3 grid(residual_blocks(a.nq) + (WALK ? a.n_walkers : 0)), block(256);
+    if (t.start != nullptr) hipExtLaunchKernelGGL((residual_kernel<EXT, SEARCH, WALK, 256>), grid, block, 0, s, t.start, t.stop, 0, a);
+    else hipLaunchKernelGGL((residual_kernel<EXT, SEARCH, WALK, 256>), grid, block, 0, s, a);
 }
 hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool ext, hipStream_t s, KernelTimer t) {
     if (a.nq <= 0) return hipSuccess;
+    const bool walk = do_search && a.n_walkers > 0;
     if (ext) {
-        if (do_search) launch_residual_v<true, true>(a, s, t);
-        else           launch_residual_v<true, false>(a, s, t);
+        if (walk)           launch_residual_v<true, true, true>(a, s, t);
+        else if (do_search) launch_residual_v<true, true, false>(a, s, t);
+        else                launch_residual_v<true, false, false>(a, s, t);
     } else {
-        if (do_search) launch_residual_v<false, true>(a, s, t);
-        else           launch_residual_v<false, false>(a, s, t);
+        if (walk)           launch_residual_v<false, true, true>(a, s, t);
+        else if (do_search) launch_residual_v<false, true, false>(a, s, t);
+        else                launch_residual_v<false, false, false>(a, s, t);
     }
     return hipGetLastError();
 }
