@@ -127,6 +127,9 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         // G-lane group (a separate 3 us launch before; every lane repeating it cost 2.6 us of this kernel's VALU time)
         __shared__ float s_q[WPB * GPW][3];
         if (wave == 0 && lane < WPB * GPW) {
+            // everyone else in the workgroup waits for this wavefront: ahead of the other workgroups' wavefronts on its SIMD
+            // (A/B on one box, scripts/dbg/knn_ab.py: -0.3 ... -1.0 us per launch)
+            if (!(a.tune & 1)) __builtin_amdgcn_s_setprio(3);
             const int qi = blockIdx.x * (WPB * GPW) + lane;
             if (qi < a.nq) {
                 const float4 b = a.body[qi];
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
                 a.world_out[qi] = make_float4(wx, wy, wz, b.w);
                 s_q[lane][0] = wx; s_q[lane][1] = wy; s_q[lane][2] = wz;
             }
+            if (!(a.tune & 1)) __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         if (active) { qx = s_q[wave * GPW + g][0]; qy = s_q[wave * GPW + g][1]; qz = s_q[wave * GPW + g][2]; }
