@@ -1459,7 +1459,8 @@ int lio_scan_swap(lio_ctx* c) {
 }
 void* lio_host_alloc(size_t bytes) {
     void* p = nullptr;
-    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    // portable: pinned for every device of the process (one rank per GPU allocates before or after it picks its device)
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
     return p;
 }
 void lio_host_free(void* p) { if (p) (void)hipHostFree(p); }
