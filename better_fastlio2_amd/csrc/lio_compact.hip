@@ -1,0 +1,192 @@
+// lio_compact.hip -- single-launch, order-preserving stream compaction / run detection / exclusive scan for the batch
+// sizes of map maintenance (up to ~260 k items), gfx950 only.
+//
+// rocPRIM's device-wide select / run_length_encode / exclusive_scan are two to three launches each (an init kernel for
+// the look-back state, the sweep, sometimes a fix-up); a map update strings a dozen of them together on batches of a few
+// thousand points, where every launch costs more than its work ("launch storm").  Here every primitive is
+// ONE launch: a workgroup handles a tile of 256 items, publishes the tile's count(s) as {count | stamp << 32} -- an
+// 8-byte store is single-copy atomic, the stamp is this launch's sequence number, so whoever reads the stamp has the
+// count (the same idea as the measurement kernel's partial sums, lio_measure.hip) -- and sums the counts of all tiles
+// before it, which it polls.  All tiles of a launch are resident together (<= 1024 workgroups of 256 threads) and a
+// tile only ever waits for lower-numbered ones; the waits are bounded and a timeout is reported (bit 0 of *err, counts
+// set to zero so that nothing downstream runs wild), never silent.  Larger inputs go to rocPRIM (lio_sort.hip).
+#include "lio_kernels.h"
+#include "lio_mapadd.h"
+#include "lio_incr.h"
+
+namespace lio {
+
+typedef unsigned long long u64;
+constexpr unsigned COMPACT_SPIN_LIMIT = 1u << 22;
+
+// exclusive prefix of `mine` over the tiles before this one (K independent streams), the tile's own count published
+// first.  All 256 threads call it; returns false when a wait ran out.
+template <int K>
+__device__ __forceinline__ bool tile_exclusive_prefix(const uint32_t (&mine)[K], u64* agg, uint32_t stamp, uint32_t (&before)[K]) {
+    __shared__ uint32_t s_sum[K][4];
+    __shared__ uint32_t s_bad;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid == 0) s_bad = 0u;
+    __syncthreads();
+    if (tid < K) __hip_atomic_store(agg + (size_t)b * K + tid, (u64)mine[tid] | ((u64)stamp << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0u;
+    bool bad = false;
+    for (int p = tid; p < b; p += 256) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            u64 v;
+            unsigned spins = 0;
+            do { v = __hip_atomic_load(agg + (size_t)p * K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            while ((uint32_t)(v >> 32) != stamp && ++spins < COMPACT_SPIN_LIMIT);
+            bad = bad || (uint32_t)(v >> 32) != stamp;
+            acc[k] += (uint32_t)v;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        uint32_t v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+        if ((tid & 63) == 0) s_sum[k][tid >> 6] = v;
+    }
+    if (bad) s_bad = 1u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) before[k] = s_sum[k][0] + s_sum[k][1] + s_sum[k][2] + s_sum[k][3];
+    return s_bad == 0u;
+}
+
+// position of this thread's item among the flagged items of its 256-item tile (exclusive), and the tile's total
+__device__ __forceinline__ uint32_t tile_rank(bool flag, uint32_t& tile_total, uint32_t (&s_wave)[4]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 m = __ballot(flag);
+    const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    tile_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    return off + in_wave;
+}
+
+// ---- map_incremental's classification (laserMapping.cpp:1448-1489) AND its two order-preserving lists, one launch --
+__global__ __launch_bounds__(256) void map_incremental_lists_kernel(IncrArgs a, float4* add_out, float4* nodown_out, uint32_t* counts,
+                                                                    u64* agg, uint32_t stamp, uint32_t* err) {
+    __shared__ uint32_t s_w1[4], s_w2[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint8_t cls = 0;
+    float4 wp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < a.nq) {
+        cls = map_incremental_classify_point(a, i, wp);
+        a.world[i] = wp;
+        a.cls[i] = cls;
+    }
+    uint32_t tot1, tot2;
+    const uint32_t r1 = tile_rank(cls == 1, tot1, s_w1);
+    const uint32_t r2 = tile_rank(cls == 2, tot2, s_w2);
+    const uint32_t mine[2] = {tot1, tot2};
+    uint32_t before[2];
+    const bool ok = tile_exclusive_prefix<2>(mine, agg, stamp, before);
+    if (ok && cls == 1) add_out[before[0] + r1] = wp;
+    if (ok && cls == 2) nodown_out[before[1] + r2] = wp;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        counts[0] = ok ? before[0] + tot1 : 0u;
+        counts[1] = ok ? before[1] + tot2 : 0u;
+        if (!ok) atomicOr(err, 1u);
+    }
+}
+hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, float4* nodown_out, uint32_t* counts, u64* agg,
+                                        uint32_t stamp, uint32_t* err, hipStream_t s) {
+    if (a.nq <= 0) return hipSuccess;
+    hipLaunchKernelGGL(map_incremental_lists_kernel, dim3((a.nq + 255) / 256), dim3(256), 0, s, a, add_out, nodown_out, counts, agg, stamp, err);
+    return hipGetLastError();
+}
+
+// ---- live points (w == 0) of src[0..n) to the front of dst, order kept; *n_out = their number ----------------------
+__global__ __launch_bounds__(256) void compact_live_kernel(const float4* src, uint32_t n, float4* dst, uint32_t* n_out, u64* agg, uint32_t stamp, uint32_t* err) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (i < n) p = src[i];
+    const bool live = i < n && p.w == 0.0f;
+    uint32_t tot;
+    const uint32_t r = tile_rank(live, tot, s_w);
+    const uint32_t mine[1] = {tot};
+    uint32_t before[1];
+    const bool ok = tile_exclusive_prefix<1>(mine, agg, stamp, before);
+    if (ok && live) dst[before[0] + r] = p;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *n_out = ok ? before[0] + tot : 0u; if (!ok) atomicOr(err, 1u); }
+}
+hipError_t launch_compact_live(const float4* src, uint32_t n, float4* dst, uint32_t* n_out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s) {
+    if (n == 0) return hipMemsetAsync(n_out, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(compact_live_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, src, n, dst, n_out, agg, stamp, err);
+    return hipGetLastError();
+}
+
+// ---- runs of equal keys in a sorted array: unique[r], starts[r] (= exclusive scan of the run lengths), *n_runs ------
+// (counts[r] = starts[r + 1] - starts[r] follows in run_counts_kernel: the next run's head may sit in a later tile)
+__global__ __launch_bounds__(256) void run_heads_kernel(const uint64_t* keys, uint32_t n, uint64_t* unique_out, uint32_t* starts_out,
+                                                        uint32_t* n_runs_out, u64* agg, uint32_t stamp, uint32_t* err) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint64_t k = 0;
+    bool head = false;
+    if (i < n) {
+        k = keys[i];
+        head = i == 0u || keys[i - 1] != k;
+    }
+    uint32_t tot;
+    const uint32_t r = tile_rank(head, tot, s_w);
+    const uint32_t mine[1] = {tot};
+    uint32_t before[1];
+    const bool ok = tile_exclusive_prefix<1>(mine, agg, stamp, before);
+    if (ok && head) { unique_out[before[0] + r] = k; starts_out[before[0] + r] = i; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *n_runs_out = ok ? before[0] + tot : 0u; if (!ok) atomicOr(err, 1u); }
+}
+__global__ __launch_bounds__(256) void run_counts_kernel(const uint32_t* starts, const uint32_t* n_runs, uint32_t n, uint32_t* counts_out) {
+    const uint32_t nr = *n_runs;
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nr; r += gridDim.x * 256u)
+        counts_out[r] = (r + 1u < nr ? starts[r + 1u] : n) - starts[r];
+}
+hipError_t launch_run_lengths(const uint64_t* keys, uint32_t n, uint64_t* unique_out, uint32_t* counts_out, uint32_t* starts_out,
+                              uint32_t* n_runs_out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s) {
+    if (n == 0) return hipMemsetAsync(n_runs_out, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(run_heads_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, keys, n, unique_out, starts_out, n_runs_out, agg, stamp, err);
+    uint32_t b = (n + 255u) / 256u;
+    if (b > 256u) b = 256u;
+    hipLaunchKernelGGL(run_counts_kernel, dim3(b), dim3(256), 0, s, starts_out, n_runs_out, n, counts_out);
+    return hipGetLastError();
+}
+
+// ---- exclusive scan of u32[n] ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void exclusive_scan_kernel(const uint32_t* in, uint32_t n, uint32_t* out, u64* agg, uint32_t stamp, uint32_t* err) {
+    __shared__ uint32_t s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t i = blockIdx.x * 256u + tid;
+    const uint32_t v = i < n ? in[i] : 0u;
+    uint32_t inc = v;                                        // inclusive scan inside the wavefront
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+    const uint32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    const uint32_t mine[1] = {tot};
+    uint32_t before[1];
+    const bool ok = tile_exclusive_prefix<1>(mine, agg, stamp, before);
+    if (i < n) out[i] = ok ? before[0] + off + inc - v : 0u;
+    if (!ok && tid == 0) atomicOr(err, 1u);
+}
+hipError_t launch_exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, in, n, out, agg, stamp, err);
+    return hipGetLastError();
+}
+
+}  // namespace lio

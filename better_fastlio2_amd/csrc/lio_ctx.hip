@@ -66,6 +66,8 @@ struct lio_ctx {
     uint32_t* d_apply = nullptr;               // [0..2] apply stats, [3] new slots, [4] fold: replaced, [5] fold: tmp_counter,
                                                // [6] survivors, [7] voxel groups, [8] touched cells
     bool have_map = false;
+    unsigned long long* d_cagg = nullptr;      // scratch of the single-launch compaction primitives (lio_compact.hip)
+    uint32_t compact_seq = 0;                  // their stamp: one number per launch
     // acquire_removed_points: box-deleted points whose storage was reclaimed by a rebuild, not yet handed out
     float4* d_removed = nullptr;
     size_t cap_removed = 0;
@@ -276,6 +278,18 @@ int upload_points(lio_ctx* c, const float* pts, size_t n, int stride_bytes, floa
     return LIO_OK;
 }
 
+// stamp of the next single-launch compaction (lio_compact.hip): never 0 (the scratch starts zeroed), never repeated within
+// 2^32 launches; *err lives in d_apply[15]
+static uint32_t next_compact_stamp(lio_ctx* c) {
+    if (++c->compact_seq == 0u) ++c->compact_seq;
+    return c->compact_seq;
+}
+static int check_compact_error(lio_ctx* c, uint32_t flag_word) {
+    if (flag_word == 0u) return LIO_OK;
+    (void)hipMemsetAsync(c->d_apply + 15, 0, sizeof(uint32_t), c->stream);
+    return c->fail(LIO_ERR_HIP, "map maintenance", "a bounded wait of a compaction kernel ran out");
+}
+
 // Second half of every (re)build: c->d_pts[0..n) is Morton-sorted and live, c->d_mkeys[0..n) holds the
 // keys.  Run-length encode the cells, derive the coarser tree levels (hash tables), fill the child blocks of the
 // cell directory.
@@ -452,8 +466,14 @@ int apply_pending(lio_ctx* c) {
     const uint32_t n = c->n_pend;
     HIPCHK(c, launch_pend_keys(c->d_pend, n, c->grid, c->d_pkeys, c->d_porder, s));
     HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_pkeys, c->d_pkeys2, c->d_porder, c->d_porder2, (size_t)n, s));
-    HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_pkeys2, (size_t)n, c->d_pcell, c->d_pgcount, c->d_apply + 8, s));
-    HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pgcount, c->d_pgstart, (size_t)n, s));
+    const bool small = n + 1u <= COMPACT_MAX_ITEMS;
+    if (small) {
+        HIPCHK(c, launch_run_lengths(c->d_pkeys2, n, c->d_pcell, c->d_pgcount, c->d_pgstart, c->d_apply + 8, c->d_cagg,
+                                     next_compact_stamp(c), c->d_apply + 15, s));
+    } else {
+        HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_pkeys2, (size_t)n, c->d_pcell, c->d_pgcount, c->d_apply + 8, s));
+        HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pgcount, c->d_pgstart, (size_t)n, s));
+    }
     ApplyArgs a{};
     a.map_pts = c->d_pts; a.grid = c->grid; a.ltable = c->d_ltable;
     a.child = c->d_child; a.block_bump = c->d_apply + 9; a.blocks_cap = (uint32_t)c->child_blocks_cap;
@@ -464,11 +484,16 @@ int apply_pending(lio_ctx* c) {
     a.slots_cap = (uint32_t)c->slots_cap; a.n_scan = n;
     HIPCHK(c, launch_cell_plan(a, n, s));
     // entries past the touched cells are zero (written by the plan kernel), so element n of the scan is the total
-    HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pnewsize, c->d_pnewoff, (size_t)n + 1, s));
+    if (small) HIPCHK(c, launch_exclusive_scan(c->d_pnewsize, n + 1u, c->d_pnewoff, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+    else HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pnewsize, c->d_pnewoff, (size_t)n + 1, s));
     HIPCHK(c, launch_cell_apply(a, n, s));
     uint32_t st[32] = {};
     HIPCHK(c, read_back(c, st, c->d_apply, sizeof(st)));
     const uint32_t total = st[3];
+    {
+        const int rc = check_compact_error(c, st[15]);
+        if (rc != LIO_OK) return rc;
+    }
     if (st[2] & APPLY_FLAG_NO_ROOM) return rebuild_full(c);    // nothing was changed: the pending points go in there
     c->n_points += total;
     c->grid.n_points = c->n_points;
@@ -640,6 +665,8 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     c->child_blocks_cap = 4096;
     CREATE_CHK(hipMalloc((void**)&c->d_child, c->child_blocks_cap * 64 * sizeof(uint2)));
     CREATE_CHK(hipMemset(c->d_child, 0, c->child_blocks_cap * 64 * sizeof(uint2)));
+    CREATE_CHK(hipMalloc((void**)&c->d_cagg, COMPACT_AGG_WORDS * sizeof(unsigned long long)));
+    CREATE_CHK(hipMemset(c->d_cagg, 0, COMPACT_AGG_WORDS * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc((void**)&c->d_counters, 32 * sizeof(uint32_t)));
     CREATE_CHK(hipMemset(c->d_counters, 0, 32 * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_cand, sizeof(unsigned long long)));
@@ -683,7 +710,7 @@ void lio_destroy(lio_ctx* c) {
     lio_replicate_finalize(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
-                   c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cand, c->d_boxes,
+                   c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cagg, c->d_cand, c->d_boxes,
                    c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_useeds, c->d_spec_rows, c->d_rows,
                    c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, c->d_qs_useeds,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
@@ -813,11 +840,16 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
                                     c->d_add_out, s));
         HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_add_keys, c->d_add_keys2, c->d_add_order,
                                      c->d_add_order2, (size_t)n, s));
-        HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_add_keys2, (size_t)n, c->d_add_ukeys,
-                                        c->d_add_gcount, c->d_apply + 7, s));
         // the number of voxel groups stays on the device: launches are sized for the batch, the kernels read the
-        // real count (entries of the scan past it are never used)
-        HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, (size_t)n, s));
+        // real count (entries past it are never used)
+        if (n <= COMPACT_MAX_ITEMS) {
+            HIPCHK(c, launch_run_lengths(c->d_add_keys2, n, c->d_add_ukeys, c->d_add_gcount, c->d_add_gstart, c->d_apply + 7,
+                                         c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+        } else {
+            HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_add_keys2, (size_t)n, c->d_add_ukeys,
+                                            c->d_add_gcount, c->d_apply + 7, s));
+            HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, (size_t)n, s));
+        }
         // boundary points (outside their own fp32 box / inside a neighbour's): their groups leave the parallel fold
         // and are replayed point by point
         BoundaryArgs ba{};
@@ -839,7 +871,10 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
         fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
         HIPCHK(c, launch_fold_groups(fa, s));
         // survivors (w == 0) of both passes -> front of `batch` (the batch itself is no longer needed)
-        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_apply + 6, 2 * (size_t)n, s));
+        if (2 * n <= COMPACT_MAX_ITEMS)
+            HIPCHK(c, launch_compact_live(c->d_add_out, 2 * n, batch, c->d_apply + 6, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+        else
+            HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_apply + 6, 2 * (size_t)n, s));
         uint32_t host_cnt[3] = {0, 0, 0};                  // replaced, tmp_counter, survivors
         HIPCHK(c, read_back(c, host_cnt, c->d_apply + 4, sizeof(host_cnt)));
         if (n_added) *n_added = (int)host_cnt[1];
@@ -925,9 +960,15 @@ static int map_incremental_lists(lio_ctx* c, const double state14[14], double fi
     for (int i = 0; i < 14; ++i) ia.pose.v[i] = state14[i];
     ia.nbr = c->d_nbr; ia.cnt = c->d_cnt; ia.filter_size_map_min = filter_size_map_min;
     ia.flg_EKF_inited = flg_EKF_inited; ia.world = c->d_world; ia.cls = c->d_add_cls;
-    HIPCHK(c, launch_map_incremental(ia, s));
-    HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 1, c->d_add_pts, c->d_counters + 5, (size_t)nq, s));
-    HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 2, c->d_add_pts2, c->d_counters + 6, (size_t)nq, s));
+    if ((uint32_t)nq <= COMPACT_MAX_ITEMS) {
+        // classification + both lists + their counts in ONE launch (was: a classification kernel and two rocPRIM selects)
+        HIPCHK(c, launch_map_incremental_lists(ia, c->d_add_pts, c->d_add_pts2, c->d_counters + 5, c->d_cagg, next_compact_stamp(c),
+                                               c->d_apply + 15, s));
+    } else {
+        HIPCHK(c, launch_map_incremental(ia, s));
+        HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 1, c->d_add_pts, c->d_counters + 5, (size_t)nq, s));
+        HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 2, c->d_add_pts2, c->d_counters + 6, (size_t)nq, s));
+    }
     if (cnts) HIPCHK(c, read_back(c, cnts, c->d_counters + 5, 2 * sizeof(uint32_t)));
     return LIO_OK;
 }

@@ -103,6 +103,22 @@ hipError_t launch_detect_shared_points(const BoundaryArgs& a, hipStream_t s);
 hipError_t launch_gather_dirty(const BoundaryArgs& a, hipStream_t s);
 hipError_t launch_fold_sequential(const BoundaryArgs& a, const uint32_t* dlist_sorted, hipStream_t s);
 hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s);
+// ---- single-launch compaction primitives (lio_compact.hip) for inputs up to COMPACT_MAX_ITEMS; agg = COMPACT_AGG_WORDS
+// 8-byte words of scratch shared by all of them, stamp = a number no earlier launch on this buffer used, *err |= 1 on a
+// timed-out wait
+constexpr uint32_t COMPACT_MAX_ITEMS = 262144;    // 1024 tiles of 256: all resident at once
+constexpr size_t COMPACT_AGG_WORDS = 2 * 1024;
+// map_incremental's classification + PointToAdd / PointNoNeedDownsample in scan order + their counts, one launch
+hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, float4* nodown_out, uint32_t* counts,
+                                        unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s);
+// live points (w == 0) to the front of dst, order kept
+hipError_t launch_compact_live(const float4* src, uint32_t n, float4* dst, uint32_t* n_out, unsigned long long* agg, uint32_t stamp,
+                               uint32_t* err, hipStream_t s);
+// runs of a sorted key array: unique keys, run lengths, run starts (exclusive scan of the lengths), number of runs
+hipError_t launch_run_lengths(const uint64_t* keys, uint32_t n, uint64_t* unique_out, uint32_t* counts_out, uint32_t* starts_out,
+                              uint32_t* n_runs_out, unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s);
+hipError_t launch_exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, unsigned long long* agg, uint32_t stamp, uint32_t* err,
+                                 hipStream_t s);
 hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, uint32_t* zero2,
                              uint8_t* dirty, uint32_t* dlist, float4* out2n, hipStream_t s);
 hipError_t launch_fold_groups(const FoldArgs& a, hipStream_t s);

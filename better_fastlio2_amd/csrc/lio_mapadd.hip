@@ -15,6 +15,7 @@
 #include "lio_kernels.h"
 #include "lio_mapadd.h"
 #include "lio_math.h"
+#include "lio_incr.h"
 
 namespace lio {
 
@@ -484,40 +485,14 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
     }
 }
 
-// map_incremental's per-point decision (src/laserMapping.cpp:1448-1489): world point at the POSTERIOR
-// pose (pointBodyToWorld :1451), then skip / add with down-sampling / add without, from the neighbours
-// of the last search pass.  cls: 0 skip, 1 PointToAdd, 2 PointNoNeedDownsample.
+// map_incremental's per-point decision (src/laserMapping.cpp:1448-1489): lio_incr.h; this kernel is the classification
+// alone (scans beyond the single-launch compaction's size, lio_compact.hip)
 __global__ __launch_bounds__(256) void map_incremental_kernel(IncrArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.nq) return;
-    const float4 b = a.body[i];
-    const PoseQ s = pose_unpack(a.pose);
-    float wx, wy, wz;
-    body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
-    a.world[i] = make_float4(wx, wy, wz, 0.0f);
-    uint8_t cls = 1;                                            // :1487 (no neighbours / EKF not inited)
-    const int cnt = a.cnt[i] & ~CNT_UNPROVEN;      // (the mark of a walked query is not part of the count)
-    if (cnt > 0 && a.flg_EKF_inited) {                          // :1453
-        const double fs = a.filter_size_map_min;                // a double in the reference (:56)
-        const float mx = (float)(floor((double)wx / fs) * fs + 0.5 * fs);   // :1459-1461
-        const float my = (float)(floor((double)wy / fs) * fs + 0.5 * fs);
-        const float mz = (float)(floor((double)wz / fs) * fs + 0.5 * fs);
-        const float dist = sqdist3(wx, wy, wz, mx, my, mz);     // :1462
-        const float4 n0 = a.nbr[i];
-        if ((double)fabsf(n0.x - mx) > 0.5 * fs && (double)fabsf(n0.y - my) > 0.5 * fs && (double)fabsf(n0.z - mz) > 0.5 * fs) {
-            cls = 2;                                            // :1465-1469
-        } else {
-            bool need_add = true;
-            if (cnt >= K) {                                     // :1474-1475
-                for (int k = 0; k < K; ++k) {
-                    const float4 p = a.nbr[(size_t)k * a.nq_stride + i];
-                    if (sqdist3(p.x, p.y, p.z, mx, my, mz) < dist) { need_add = false; break; }   // :1476-1480
-                }
-            }
-            cls = need_add ? 1 : 0;
-        }
-    }
-    a.cls[i] = cls;
+    float4 wp;
+    a.cls[i] = map_incremental_classify_point(a, i, wp);
+    a.world[i] = wp;
 }
 hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s) {
     if (a.nq <= 0) return hipSuccess;
