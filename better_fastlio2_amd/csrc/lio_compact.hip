@@ -125,9 +125,29 @@ hipError_t launch_compact_live(const float4* src, uint32_t n, float4* dst, uint3
     return hipGetLastError();
 }
 
+// ---- entries != 0xffffffff of src[0..n) to the front of dst, order kept; *n_out = their number -----------------------
+__global__ __launch_bounds__(256) void compact_marked_kernel(const uint32_t* src, uint32_t n, uint32_t* dst, uint32_t* n_out, u64* agg, uint32_t stamp, uint32_t* err) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t v = i < n ? src[i] : 0xffffffffu;
+    const bool live = v != 0xffffffffu;
+    uint32_t tot;
+    const uint32_t r = tile_rank(live, tot, s_w);
+    const uint32_t mine[1] = {tot};
+    uint32_t before[1];
+    const bool ok = tile_exclusive_prefix<1>(mine, agg, stamp, before);
+    if (ok && live) dst[before[0] + r] = v;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *n_out = ok ? before[0] + tot : 0u; if (!ok) atomicOr(err, 1u); }
+}
+hipError_t launch_compact_marked(const uint32_t* src, uint32_t n, uint32_t* dst, uint32_t* n_out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s) {
+    if (n == 0) return hipMemsetAsync(n_out, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(compact_marked_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, src, n, dst, n_out, agg, stamp, err);
+    return hipGetLastError();
+}
+
 // ---- runs of equal keys in a sorted array: unique[r], starts[r] (= exclusive scan of the run lengths), *n_runs ------
 // (counts[r] = starts[r + 1] - starts[r] follows in run_counts_kernel: the next run's head may sit in a later tile)
-__global__ __launch_bounds__(256) void run_heads_kernel(const uint64_t* keys, uint32_t n, uint64_t* unique_out, uint32_t* starts_out,
+__global__ __launch_bounds__(256) void run_heads_kernel(const uint64_t* keys, uint32_t n, int shift, uint64_t* unique_out, uint32_t* starts_out,
                                                         uint32_t* n_runs_out, u64* agg, uint32_t stamp, uint32_t* err) {
     __shared__ uint32_t s_w[4];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -135,14 +155,17 @@ __global__ __launch_bounds__(256) void run_heads_kernel(const uint64_t* keys, ui
     bool head = false;
     if (i < n) {
         k = keys[i];
-        head = i == 0u || keys[i - 1] != k;
+        head = i == 0u || (keys[i - 1] >> shift) != (k >> shift);
     }
     uint32_t tot;
     const uint32_t r = tile_rank(head, tot, s_w);
     const uint32_t mine[1] = {tot};
     uint32_t before[1];
     const bool ok = tile_exclusive_prefix<1>(mine, agg, stamp, before);
-    if (ok && head) { unique_out[before[0] + r] = k; starts_out[before[0] + r] = i; }
+    if (ok && head) {
+        if (unique_out != nullptr) unique_out[before[0] + r] = k;
+        starts_out[before[0] + r] = i;
+    }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *n_runs_out = ok ? before[0] + tot : 0u; if (!ok) atomicOr(err, 1u); }
 }
 __global__ __launch_bounds__(256) void run_counts_kernel(const uint32_t* starts, const uint32_t* n_runs, uint32_t n, uint32_t* counts_out) {
@@ -153,10 +176,17 @@ __global__ __launch_bounds__(256) void run_counts_kernel(const uint32_t* starts,
 hipError_t launch_run_lengths(const uint64_t* keys, uint32_t n, uint64_t* unique_out, uint32_t* counts_out, uint32_t* starts_out,
                               uint32_t* n_runs_out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s) {
     if (n == 0) return hipMemsetAsync(n_runs_out, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(run_heads_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, keys, n, unique_out, starts_out, n_runs_out, agg, stamp, err);
+    hipLaunchKernelGGL(run_heads_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, keys, n, 0, unique_out, starts_out, n_runs_out, agg, stamp, err);
     uint32_t b = (n + 255u) / 256u;
     if (b > 256u) b = 256u;
     hipLaunchKernelGGL(run_counts_kernel, dim3(b), dim3(256), 0, s, starts_out, n_runs_out, n, counts_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_run_heads(const uint64_t* keys, uint32_t n, int shift, uint32_t* starts_out, uint32_t* n_runs_out, u64* agg, uint32_t stamp,
+                            uint32_t* err, hipStream_t s) {
+    if (n == 0) return hipMemsetAsync(n_runs_out, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(run_heads_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, keys, n, shift, (uint64_t*)nullptr, starts_out, n_runs_out, agg, stamp, err);
     return hipGetLastError();
 }
 
@@ -186,6 +216,63 @@ __global__ __launch_bounds__(256) void exclusive_scan_kernel(const uint32_t* in,
 hipError_t launch_exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(exclusive_scan_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, in, n, out, agg, stamp, err);
+    return hipGetLastError();
+}
+
+// ---- stable sort of (u64 key, u32 value) pairs, n <= SORT_MAX_ITEMS, ONE launch ------------------------------------
+// rocPRIM sorts a batch of this size with a block sort and log2(n / block) merge launches (nine launches, ~40 us, for
+// the 8 k keys of an insert batch).  At these sizes the whole chip can afford the quadratic answer in one launch with
+// no workspace, no hand-off between workgroups and nothing to get wrong: the rank of a record is the number of records
+// that sort before it -- smaller key, or equal key and earlier position (= the stable order).  A workgroup takes 64
+// records, one per lane; its sixteen wavefronts each count over a sixteenth of the batch, the key of the record under
+// comparison is wave-uniform (scalar loads, one 64-bit compare + one add per pair), the counts meet in LDS and the
+// record is scattered to its rank.  8.6 k records: 74 M pairs, ~10 us; the cost is n^2, so the library takes over above
+// SORT_MAX_ITEMS.  (Tried first and dropped: bitonic tiles in LDS + a multi-way rank search behind a stamped hand-off;
+// a 1024-record tile alone took ~30 us -- two wavefronts issuing ~220 instructions per round of the network.)
+constexpr uint32_t RANK_WAVES = 16;
+__global__ __launch_bounds__(1024) void rank_sort_pairs_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t n,
+                                                               uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t s_cnt[RANK_WAVES][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t i0 = blockIdx.x * 64u, i = i0 + lane;
+    const bool in = i < n;
+    const uint64_t ki = in ? keys_in[i] : ~0ull;
+    const uint32_t per = (n + RANK_WAVES - 1u) / RANK_WAVES;
+    const uint32_t j0 = min(n, wave * per), j1 = min(n, j0 + per);
+    uint32_t cnt = 0;
+    // records before the workgroup's own 64: "not after" = key <=; after them: key <; the 64 themselves: by position
+    {
+        const uint32_t e = min(j1, i0);
+#pragma unroll 16
+        for (uint32_t j = j0; j < e; ++j) cnt += keys_in[j] <= ki ? 1u : 0u;
+    }
+    {
+        const uint32_t sj = max(j0, i0), e = min(j1, i0 + 64u);
+        for (uint32_t j = sj; j < e; ++j) {
+            const uint64_t kj = keys_in[j];
+            cnt += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
+        }
+    }
+    {
+        const uint32_t sj = max(j0, i0 + 64u);
+#pragma unroll 16
+        for (uint32_t j = sj; j < j1; ++j) cnt += keys_in[j] < ki ? 1u : 0u;
+    }
+    s_cnt[wave][lane] = cnt;
+    __syncthreads();
+    if (wave == 0u && in) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int w = 0; w < (int)RANK_WAVES; ++w) r += s_cnt[w][lane];
+        keys_out[r] = ki;
+        vals_out[r] = vals_in[i];
+    }
+}
+hipError_t launch_sort_pairs_small(const uint64_t* keys_in, const uint32_t* vals_in, uint32_t n, uint64_t* keys_out, uint32_t* vals_out,
+                                   hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (n > SORT_MAX_ITEMS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rank_sort_pairs_kernel, dim3((n + 63u) / 64u), dim3(64 * RANK_WAVES), 0, s, keys_in, vals_in, n, keys_out, vals_out);
     return hipGetLastError();
 }
 

@@ -164,6 +164,7 @@ struct lio_ctx {
     bool census = false;                       // count C(q) in the k-NN kernel (one atomic per wavefront)
     int dbg_force_timeout = 0;                 // lio_debug_set("force_reduction_timeout")
     int dbg_knn_tune = 0;                      // lio_debug_set("knn_tune")
+    int dbg_library_sort = 0;                  // lio_debug_set("library_sort"): rocPRIM for every sort / compaction (A/B switch)
     int dbg_stamps = 0;                        // lio_debug_set("stamps"): the last workgroup takes wall_clock64 stamps (lio_debug_stamps)
     int dbg_separate_walk = 0;                 // lio_debug_set("separate_tree_walk"): the stand-alone knn_tree_kernel per search pass
     std::vector<hipEvent_t> ev_pool[LIO_PROF_COUNT];   // start, stop, start, stop, ...
@@ -289,6 +290,16 @@ static int check_compact_error(lio_ctx* c, uint32_t flag_word) {
     (void)hipMemsetAsync(c->d_apply + 15, 0, sizeof(uint32_t), c->stream);
     return c->fail(LIO_ERR_HIP, "map maintenance", "a bounded wait of a compaction kernel ran out");
 }
+
+// stable sort of (key, value) pairs: the single-launch kernel for the batch sizes of map maintenance and scan
+// preparation, rocPRIM above them
+static hipError_t sort_pairs_any(lio_ctx* c, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                                 size_t n, hipStream_t s, uint32_t* err = nullptr) {
+    (void)err;
+    if (!c->dbg_library_sort && n <= SORT_MAX_ITEMS) return launch_sort_pairs_small(keys_in, vals_in, (uint32_t)n, keys_out, vals_out, s);
+    return sort_pairs_u64_u32(c->d_temp, c->temp_bytes, keys_in, keys_out, vals_in, vals_out, n, s);
+}
+static bool compact_small(const lio_ctx* c, size_t n) { return !c->dbg_library_sort && n <= COMPACT_MAX_ITEMS; }
 
 // Second half of every (re)build: c->d_pts[0..n) is Morton-sorted and live, c->d_mkeys[0..n) holds the
 // keys.  Run-length encode the cells, derive the coarser tree levels (hash tables), fill the child blocks of the
@@ -465,8 +476,8 @@ int apply_pending(lio_ctx* c) {
     if (!c->have_map || c->n_live == 0 || c->n_points == 0) return rebuild_full(c);
     const uint32_t n = c->n_pend;
     HIPCHK(c, launch_pend_keys(c->d_pend, n, c->grid, c->d_pkeys, c->d_porder, s));
-    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_pkeys, c->d_pkeys2, c->d_porder, c->d_porder2, (size_t)n, s));
-    const bool small = n + 1u <= COMPACT_MAX_ITEMS;
+    HIPCHK(c, sort_pairs_any(c, c->d_pkeys, c->d_pkeys2, c->d_porder, c->d_porder2, (size_t)n, s));
+    const bool small = compact_small(c, (size_t)n + 1);
     if (small) {
         HIPCHK(c, launch_run_lengths(c->d_pkeys2, n, c->d_pcell, c->d_pgcount, c->d_pgstart, c->d_apply + 8, c->d_cagg,
                                      next_compact_stamp(c), c->d_apply + 15, s));
@@ -838,11 +849,10 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
         const float ds = c->cfg.filter_size_map_min;
         HIPCHK(c, launch_voxel_keys(batch, n, ds, c->d_add_keys, c->d_add_order, c->d_apply + 4, c->d_add_dirty, c->d_add_dlist,
                                     c->d_add_out, s));
-        HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_add_keys, c->d_add_keys2, c->d_add_order,
-                                     c->d_add_order2, (size_t)n, s));
+        HIPCHK(c, sort_pairs_any(c, c->d_add_keys, c->d_add_keys2, c->d_add_order, c->d_add_order2, (size_t)n, s));
         // the number of voxel groups stays on the device: launches are sized for the batch, the kernels read the
         // real count (entries past it are never used)
-        if (n <= COMPACT_MAX_ITEMS) {
+        if (compact_small(c, n)) {
             HIPCHK(c, launch_run_lengths(c->d_add_keys2, n, c->d_add_ukeys, c->d_add_gcount, c->d_add_gstart, c->d_apply + 7,
                                          c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
         } else {
@@ -861,7 +871,11 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
         HIPCHK(c, launch_classify_boundary(ba, s));
         HIPCHK(c, launch_detect_shared_points(ba, s));
         HIPCHK(c, launch_gather_dirty(ba, s));
-        HIPCHK(c, sort_keys_u32(c->d_temp, c->temp_bytes, c->d_add_dlist, c->d_add_dlist2, (size_t)n, s));   // batch order
+        // the marked points in batch order (the marks are the indices: a sort does it too)
+        if (compact_small(c, n))
+            HIPCHK(c, launch_compact_marked(c->d_add_dlist, n, c->d_add_dlist2, c->d_apply + 10, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+        else
+            HIPCHK(c, sort_keys_u32(c->d_temp, c->temp_bytes, c->d_add_dlist, c->d_add_dlist2, (size_t)n, s));
         HIPCHK(c, launch_fold_sequential(ba, c->d_add_dlist2, s));
         FoldArgs fa{};
         fa.map_pts = c->d_pts; fa.l1table = c->d_ltable + c->levels.off[1]; fa.l1mask = c->levels.mask[1]; fa.child = c->d_child;
@@ -871,7 +885,7 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
         fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
         HIPCHK(c, launch_fold_groups(fa, s));
         // survivors (w == 0) of both passes -> front of `batch` (the batch itself is no longer needed)
-        if (2 * n <= COMPACT_MAX_ITEMS)
+        if (compact_small(c, 2 * (size_t)n))
             HIPCHK(c, launch_compact_live(c->d_add_out, 2 * n, batch, c->d_apply + 6, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
         else
             HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_apply + 6, 2 * (size_t)n, s));
@@ -960,7 +974,7 @@ static int map_incremental_lists(lio_ctx* c, const double state14[14], double fi
     for (int i = 0; i < 14; ++i) ia.pose.v[i] = state14[i];
     ia.nbr = c->d_nbr; ia.cnt = c->d_cnt; ia.filter_size_map_min = filter_size_map_min;
     ia.flg_EKF_inited = flg_EKF_inited; ia.world = c->d_world; ia.cls = c->d_add_cls;
-    if ((uint32_t)nq <= COMPACT_MAX_ITEMS) {
+    if (compact_small(c, (size_t)nq)) {
         // classification + both lists + their counts in ONE launch (was: a classification kernel and two rocPRIM selects)
         HIPCHK(c, launch_map_incremental_lists(ia, c->d_add_pts, c->d_add_pts2, c->d_counters + 5, c->d_cagg, next_compact_stamp(c),
                                                c->d_apply + 15, s));
@@ -1618,7 +1632,7 @@ static int sort_undistorted_by_time(lio_ctx* c) {
     hipStream_t s = c->stream;
     const int n = c->n_raw;
     HIPCHK(c, launch_time_keys(c->d_undist, n, c->d_raw_keys, c->d_raw_order, s));
-    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s));
+    HIPCHK(c, sort_pairs_any(c, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s));
     HIPCHK(c, launch_gather_points(c->d_undist, c->d_raw_order2, (uint32_t)n, c->d_leafpts, s));
     float4* t = c->d_undist; c->d_undist = c->d_leafpts; c->d_leafpts = t;
     c->undist_sorted = true;
@@ -1643,13 +1657,17 @@ int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
     HIPCHK(c, launch_minmax(c->d_undist, n, vox, s));
     HIPCHK(c, launch_voxel_params(vox, 1.0f / leaf_size, s));           // inverse_leaf_size_ = 1 / leaf_size_
     HIPCHK(c, launch_voxel_index(c->d_undist, n, vox, c->raw_time_keyed && !c->undist_sorted, c->d_raw_keys, c->d_raw_order, s));
-    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s));
-    HIPCHK(c, select_run_heads_u64(c->d_temp, c->temp_bytes, c->d_raw_keys2, (size_t)n, c->d_leaf_start, &vox->n_leaves, s));
+    HIPCHK(c, sort_pairs_any(c, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s, &vox->summary[3]));
+    if (compact_small(c, (size_t)n))
+        HIPCHK(c, launch_run_heads(c->d_raw_keys2, (uint32_t)n, 32, c->d_leaf_start, &vox->n_leaves, c->d_cagg, next_compact_stamp(c), &vox->summary[3], s));
+    else
+        HIPCHK(c, select_run_heads_u64(c->d_temp, c->temp_bytes, c->d_raw_keys2, (size_t)n, c->d_leaf_start, &vox->n_leaves, s));
     const uint32_t max_leaves = (uint32_t)n < (uint32_t)c->cap_q + 1u ? (uint32_t)n : (uint32_t)c->cap_q + 1u;
     HIPCHK(c, launch_centroids(c->d_undist, c->d_raw_order2, c->d_raw_keys2, c->d_leaf_start, vox, (uint32_t)n, max_leaves,
                                (uint32_t)c->cap_q, c->d_body, s));
     uint32_t summary[4] = {0, 0, 0, 0};
     HIPCHK(c, read_back(c, summary, vox->summary, sizeof(summary)));
+    if (summary[3] != 0u) return c->fail(LIO_ERR_HIP, "lio_scan_voxel_filter", "a bounded wait of a sort / compaction kernel ran out");
     if (summary[2] & VOX_OVERFLOW)
         return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "leaf size too small for the extent of the scan (index overflow, as in PCL)");
     if (summary[2] & VOX_EMPTY) return scan_reset(c, 0);                // no finite point
@@ -1895,6 +1913,7 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (!c || !key) return LIO_ERR_INVALID_ARG;
     if (std::strcmp(key, "force_reduction_timeout") == 0) { c->dbg_force_timeout = value != 0; return LIO_OK; }
     if (std::strcmp(key, "separate_tree_walk") == 0) { c->dbg_separate_walk = value != 0; return LIO_OK; }
+    if (std::strcmp(key, "library_sort") == 0) { c->dbg_library_sort = value != 0; return LIO_OK; }
     if (std::strcmp(key, "stamps") == 0) { c->dbg_stamps = value != 0; return LIO_OK; }
     if (std::strcmp(key, "knn_tune") == 0) { c->dbg_knn_tune = (int)value; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "unknown key");

@@ -114,9 +114,19 @@ hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, floa
 // live points (w == 0) to the front of dst, order kept
 hipError_t launch_compact_live(const float4* src, uint32_t n, float4* dst, uint32_t* n_out, unsigned long long* agg, uint32_t stamp,
                                uint32_t* err, hipStream_t s);
+// entries != 0xffffffff to the front of dst, order kept
+hipError_t launch_compact_marked(const uint32_t* src, uint32_t n, uint32_t* dst, uint32_t* n_out, unsigned long long* agg, uint32_t stamp,
+                                 uint32_t* err, hipStream_t s);
 // runs of a sorted key array: unique keys, run lengths, run starts (exclusive scan of the lengths), number of runs
 hipError_t launch_run_lengths(const uint64_t* keys, uint32_t n, uint64_t* unique_out, uint32_t* counts_out, uint32_t* starts_out,
                               uint32_t* n_runs_out, unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s);
+// stable sort of (u64 key, u32 value) pairs, one launch, no workspace (rank by counting: O(n^2))
+constexpr uint32_t SORT_MAX_ITEMS = 16384;
+hipError_t launch_sort_pairs_small(const uint64_t* keys_in, const uint32_t* vals_in, uint32_t n, uint64_t* keys_out, uint32_t* vals_out,
+                                   hipStream_t s);
+// run starts only, runs of equal keys >> shift (the voxel filter's leaves: the leaf index is the upper half of the key)
+hipError_t launch_run_heads(const uint64_t* keys, uint32_t n, int shift, uint32_t* starts_out, uint32_t* n_runs_out, unsigned long long* agg,
+                            uint32_t stamp, uint32_t* err, hipStream_t s);
 hipError_t launch_exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, unsigned long long* agg, uint32_t stamp, uint32_t* err,
                                  hipStream_t s);
 hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, uint32_t* zero2,

@@ -256,14 +256,15 @@ __global__ __launch_bounds__(64) void detect_shared_points_kernel(BoundaryArgs a
     }
 }
 
-// one lane per group: the batch indices of the points of dirty groups
+// one lane per group: the points of dirty groups are marked with their own batch index (dlist[i] = i, 0xffffffff
+// otherwise); the marks, compacted in order, are the replay list
 __global__ __launch_bounds__(256) void gather_dirty_kernel(BoundaryArgs a) {
     const uint32_t n_groups = *a.n_groups;
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
         if (a.dirty[g] == 0) continue;
         const uint32_t gs = a.group_start[g], gc = a.group_count[g];
-        const uint32_t slot = atomicAdd(a.n_dirty, gc);
-        for (uint32_t j = 0; j < gc; ++j) a.dlist[slot + j] = a.order[gs + j];
+        atomicAdd(a.n_dirty, gc);
+        for (uint32_t j = 0; j < gc; ++j) { const uint32_t pt = a.order[gs + j]; a.dlist[pt] = pt; }
     }
 }
 

@@ -17,7 +17,7 @@ struct VoxelGridDev {
     VoxelGridParams g;
     uint32_t flags;                 // VOX_EMPTY | VOX_OVERFLOW
     uint32_t n_leaves;              // runs of equal leaf index (the run of dropped points included)
-    uint32_t summary[4];            // {n_leaves, 1 if the last run is the dropped one, flags, 0}
+    uint32_t summary[4];            // {n_leaves, 1 if the last run is the dropped one, flags, != 0: a sort / compaction wait ran out}
 };
 constexpr uint32_t VOX_EMPTY = 1u, VOX_OVERFLOW = 2u;
 

@@ -181,7 +181,6 @@ __global__ __launch_bounds__(256) void centroid_kernel(const float4* pts, const 
         vox->summary[0] = n_leaves;
         vox->summary[1] = (n_leaves > 0 && (sorted_keys[n - 1] >> 32) == 0xffffffffull) ? 1u : 0u;
         vox->summary[2] = flags;
-        vox->summary[3] = 0u;
     }
     if (flags != 0u || l >= n_leaves) return;
     const uint32_t st = leaf_start[l], en = l + 1 < n_leaves ? leaf_start[l + 1] : n;

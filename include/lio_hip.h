@@ -269,7 +269,8 @@ int  lio_profile_reset(lio_ctx* ctx);
  * passes report what a timed-out wait of the cross-workgroup reduction reports -> lio_measure fails with
  * LIO_ERR_HIP instead of returning incomplete sums; "separate_tree_walk" runs the exact tree walk of a search pass as
  * its own launch (knn_tree_kernel) instead of inside the measurement kernel (an A/B switch for timing; identical
-results); "stamps" makes the last workgroup of a measurement kernel take the time stamps lio_debug_stamps returns
+results); "library_sort" sends every sort / compaction of map maintenance and scan preparation to rocPRIM
+ * instead of the single-launch kernels of lio_compact.hip (identical results); "stamps" makes the last workgroup of a measurement kernel take the time stamps lio_debug_stamps returns
  * (they perturb what they measure: ~0.5 us each).  Unknown key: LIO_ERR_INVALID_ARG.                                                                */
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
 /* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: its start, own partial
