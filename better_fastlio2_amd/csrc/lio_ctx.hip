@@ -833,8 +833,7 @@ static int ensure_add_buffers(lio_ctx* c, size_t n) {
 
 // One Add_Points call on a device-resident batch (float4, batch order = insertion order), WITHOUT
 // touching the index: down-sampled inserts fold per voxel against the indexed points (tomb-stoning
-// what they replace) and leave the survivors pending; plain inserts are left pending as they are.  `batch`
-// is clobbered when downsample_on.  At most one down-sampled call per apply_pending (pending points are
+// what they replace) and leave the survivors pending; plain inserts are left pending as they are.  At most one down-sampled call per apply_pending (pending points are
 // not in the index yet).
 static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsample_on, int* n_added) {
     hipStream_t s = c->stream;
@@ -844,7 +843,6 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
         return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
     if ((size_t)c->n_pend + (size_t)n > c->cap_pend)
         return c->fail(LIO_ERR_CAPACITY, "Add_Points", "pending buffer too small");
-    uint32_t n_append = n;
     if (downsample_on) {
         const float ds = c->cfg.filter_size_map_min;
         HIPCHK(c, launch_voxel_keys(batch, n, ds, c->d_add_keys, c->d_add_order, c->d_apply + 4, c->d_add_dirty, c->d_add_dlist,
@@ -884,20 +882,21 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
         fa.n_groups = 0; fa.n_groups_dev = c->d_apply + 7; fa.n_groups_max = n;
         fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
         HIPCHK(c, launch_fold_groups(fa, s));
-        // survivors (w == 0) of both passes -> front of `batch` (the batch itself is no longer needed)
+        // survivors (w == 0) of both passes -> the tail of the pending list, in order
+        float4* tail = c->d_pend + c->n_pend;
         if (compact_small(c, 2 * (size_t)n))
-            HIPCHK(c, launch_compact_live(c->d_add_out, 2 * n, batch, c->d_apply + 6, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+            HIPCHK(c, launch_compact_live(c->d_add_out, 2 * n, tail, c->d_apply + 6, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
         else
-            HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, batch, c->d_apply + 6, 2 * (size_t)n, s));
+            HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, tail, c->d_apply + 6, 2 * (size_t)n, s));
         uint32_t host_cnt[3] = {0, 0, 0};                  // replaced, tmp_counter, survivors
         HIPCHK(c, read_back(c, host_cnt, c->d_apply + 4, sizeof(host_cnt)));
         if (n_added) *n_added = (int)host_cnt[1];
-        n_append = host_cnt[2];
+        c->n_pend += host_cnt[2];
         c->n_live -= host_cnt[0];                     // points of the map replaced inside their down-sample voxel
+        return LIO_OK;
     }
-    if (n_append > 0)
-        HIPCHK(c, hipMemcpyAsync(c->d_pend + c->n_pend, batch, (size_t)n_append * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    c->n_pend += n_append;
+    HIPCHK(c, hipMemcpyAsync(c->d_pend + c->n_pend, batch, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    c->n_pend += n;
     return LIO_OK;
 }
 

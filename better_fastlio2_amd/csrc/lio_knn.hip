@@ -112,7 +112,6 @@ template <int G, bool CENSUS, bool HINT>
 __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     constexpr int WPB = 4;
     constexpr int GPW = 64 / G;                    // queries per wavefront
-    constexpr int SLOTS = (27 + G - 1) / G;        // cells per lane
     __shared__ uint2 s_bucket[WPB][GPW][28];       // LDS-staged non-empty buckets {start, count}
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -183,7 +182,13 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     // entry names a block of 64 {start, count} records, and the 27 cells are then read at FIXED positions of those
     // blocks -- one 8-byte load per cell, no key compare, no probe sequence.
     constexpr int L1SLOTS = (8 + G - 1) / G;
-    uint32_t st[SLOTS], ct[SLOTS];
+    // z-columns per lane: all nine in one round when the group has the lanes; with 8 or 4 lanes the first eight columns
+    // in full rounds and the ninth (x + 1, y + 1) cell by cell on lanes 0..2 -- a ninth column round would cost every
+    // lane three more records to compact for one busy lane
+    constexpr int CSLOTS = G >= 9 ? 1 : 8 / G;
+    constexpr bool EXTRA = G < 9;
+    constexpr int NREC = 3 * CSLOTS + (EXTRA ? 1 : 0);   // cell records per lane
+    uint32_t st[NREC], ct[NREC];
     {
         const uint4* l1 = reinterpret_cast<const uint4*>(a.l1table);
         const uint32_t l1mask = a.l1mask;
@@ -232,45 +237,79 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             }
         }
         const int gbase = lane - r;                                  // first lane of this group
-        uint2 ch[SLOTS];
-        bool ok[SLOTS];
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int j = r + s * G;
-            const int ox = (j / 9) - 1, oy = ((j / 3) % 3) - 1, oz = (j % 3) - 1;
-            const int nx = cx + ox, ny = cy + oy, nz = cz + oz;
-            bool live = active && j < 27 && (uint32_t)nx <= CELL_MAX && (uint32_t)ny <= CELL_MAX && (uint32_t)nz <= CELL_MAX;
-            if (HINT) {
-                // box distance of the neighbour cell, same fp32 form as sqdist3 (a lower bound of every
-                // computed point distance inside it)
-                const float bx = ox < 0 ? glo[0] : (ox > 0 ? ghi[0] : 0.0f);
-                const float by = oy < 0 ? glo[1] : (oy > 0 ? ghi[1] : 0.0f);
-                const float bz = oz < 0 ? glo[2] : (oz > 0 ? ghi[2] : 0.0f);
-                live = live && ((bx * bx + by * by) + bz * bz <= tau);
-            }
-            // which of the (up to) eight level-1 cells, i.e. which lane of the group holds its block number
-            const uint32_t li = live ? (((((uint32_t)nx >> 2) - b0x) << 2) | ((((uint32_t)ny >> 2) - b0y) << 1) | (((uint32_t)nz >> 2) - b0z)) : 0u;
+        // block number held by lane li of the group (li = which of the up to eight level-1 cells)
+        auto block_of = [&](uint32_t li) {
             uint32_t bv = 0xffffffffu;
 #pragma unroll
             for (int s1 = 0; s1 < L1SLOTS; ++s1) {
                 const uint32_t v = (uint32_t)__shfl((int)blk[s1], gbase + (int)(li % (uint32_t)G), 64);
                 if ((int)(li / (uint32_t)G) == s1) bv = v;
             }
-            ok[s] = live && bv != 0xffffffffu;
+            return bv;
+        };
+        // One lane per z-COLUMN of three cells (9 columns instead of 27 cells): x, y, their level-1 cell, the bounds
+        // and the position inside the block are worked out once per column, the column's cells lie in at most two
+        // level-1 cells (z below / above a multiple of four) whose block numbers come with two shuffles, and the
+        // three records differ in the two low address bits only.
+        uint2 ch[NREC];
+        bool ok[NREC];
+#pragma unroll
+        for (int s = 0; s < CSLOTS; ++s) {
+            const int j = r + s * G;
+            const int ox = (j / 3) - 1, oy = (j % 3) - 1;
+            const int nx = cx + ox, ny = cy + oy;
+            const bool col = active && j < (EXTRA ? 8 : 9) && (uint32_t)nx <= CELL_MAX && (uint32_t)ny <= CELL_MAX;
+            const uint32_t li0 = col ? (((((uint32_t)nx >> 2) - b0x) << 2) | ((((uint32_t)ny >> 2) - b0y) << 1)) : 0u;
+            const uint32_t bv_lo = block_of(li0), bv_hi = block_of(li0 + 1u);
+            const uint32_t posxy = (((uint32_t)nx & 3u) << 4) | (((uint32_t)ny & 3u) << 2);
+            float bxy = 0.0f;
+            if (HINT) {
+                // box distance of the neighbour cell, same fp32 form as sqdist3 (a lower bound of every
+                // computed point distance inside it)
+                const float bx = ox < 0 ? glo[0] : (ox > 0 ? ghi[0] : 0.0f);
+                const float by = oy < 0 ? glo[1] : (oy > 0 ? ghi[1] : 0.0f);
+                bxy = bx * bx + by * by;
+            }
+#pragma unroll
+            for (int z = 0; z < 3; ++z) {
+                const int e = 3 * s + z;
+                const int nz = cz + z - 1;
+                bool live = col && (uint32_t)nz <= CELL_MAX;
+                if (HINT) {
+                    const float bz = z == 0 ? glo[2] : (z == 2 ? ghi[2] : 0.0f);
+                    live = live && (bxy + bz * bz <= tau);
+                }
+                const uint32_t bv = (live && ((uint32_t)nz >> 2) != b0z) ? bv_hi : bv_lo;
+                ok[e] = live && bv != 0xffffffffu;
+                ch[e] = a.child[ok[e] ? (size_t)bv * 64u + (posxy | ((uint32_t)nz & 3u)) : 0u];   // unconditional load: the loads overlap
+            }
+        }
+        if (EXTRA) {
+            // the ninth column, one cell per lane
+            constexpr int e = 3 * CSLOTS;
+            const int nx = cx + 1, ny = cy + 1, nz = cz + r - 1;
+            bool live = active && r < 3 && (uint32_t)nx <= CELL_MAX && (uint32_t)ny <= CELL_MAX && (uint32_t)nz <= CELL_MAX;
+            if (HINT) {
+                const float bz = r == 0 ? glo[2] : (r == 2 ? ghi[2] : 0.0f);
+                live = live && ((ghi[0] * ghi[0] + ghi[1] * ghi[1]) + bz * bz <= tau);
+            }
+            const uint32_t li = live ? (((((uint32_t)nx >> 2) - b0x) << 2) | ((((uint32_t)ny >> 2) - b0y) << 1) | (((uint32_t)nz >> 2) - b0z)) : 0u;
+            const uint32_t bv = block_of(li);
+            ok[e] = live && bv != 0xffffffffu;
             const uint32_t pos = (((uint32_t)nx & 3u) << 4) | (((uint32_t)ny & 3u) << 2) | ((uint32_t)nz & 3u);
-            ch[s] = a.child[ok[s] ? (size_t)bv * 64u + pos : 0u];       // unconditional load: the SLOTS loads overlap
+            ch[e] = a.child[ok[e] ? (size_t)bv * 64u + pos : 0u];
         }
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            st[s] = ok[s] ? ch[s].x : 0u;
-            ct[s] = ok[s] ? ch[s].y : 0u;
+        for (int e = 0; e < NREC; ++e) {
+            st[e] = ok[e] ? ch[e].x : 0u;
+            ct[e] = ok[e] ? ch[e].y : 0u;
         }
     }
 
     // ---- compact the non-empty buckets of each group into LDS ---------------------------------
     int n_ne = 0;
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
+    for (int s = 0; s < NREC; ++s) {
         const bool ne = ct[s] != 0;
         const u64 b = __ballot(ne);
         const u64 gb = (G == 64) ? b : ((b >> (g * G)) & ((1ull << (G & 63)) - 1ull));

@@ -174,33 +174,36 @@ __global__ __launch_bounds__(256) void voxel_index_kernel(const float4* pts, int
 __global__ __launch_bounds__(256) void centroid_kernel(const float4* pts, const uint32_t* order, const uint64_t* sorted_keys,
                                                        const uint32_t* leaf_start, VoxelGridDev* vox, uint32_t n, uint32_t cap_out,
                                                        float4* out) {
-    const uint32_t l = (blockIdx.x * 256 + threadIdx.x) >> 4, r = threadIdx.x & 15;
+    const uint32_t r = threadIdx.x & 15;
     const uint32_t n_leaves = vox->n_leaves;
     const uint32_t flags = vox->flags;
-    if (l == 0 && r == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         vox->summary[0] = n_leaves;
         vox->summary[1] = (n_leaves > 0 && (sorted_keys[n - 1] >> 32) == 0xffffffffull) ? 1u : 0u;
         vox->summary[2] = flags;
     }
-    if (flags != 0u || l >= n_leaves) return;
-    const uint32_t st = leaf_start[l], en = l + 1 < n_leaves ? leaf_start[l + 1] : n;
-    if ((sorted_keys[st] >> 32) == 0xffffffffull) return;               // the run of dropped points (always last)
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (st + r < en) nxt = pts[order[st + r]];
-    for (uint32_t j0 = st; j0 < en; j0 += 16) {
-        const float4 p = nxt;
-        const uint32_t jn = j0 + 16 + r;                                // the next sixteen are in flight while these are added
-        if (jn < en) nxt = pts[order[jn]];
-        const int cnt = (int)min(16u, en - j0);
-        for (int k = 0; k < cnt; ++k) {
-            sx += __shfl(p.x, k, 16);
-            sy += __shfl(p.y, k, 16);
-            sz += __shfl(p.z, k, 16);
+    if (flags != 0u) return;
+    // the grid covers 16 k leaves at a time (it is launched before the leaf count is known to the host)
+    for (uint32_t l = (blockIdx.x * 256 + threadIdx.x) >> 4; l < n_leaves; l += gridDim.x * 16u) {
+        const uint32_t st = leaf_start[l], en = l + 1 < n_leaves ? leaf_start[l + 1] : n;
+        if ((sorted_keys[st] >> 32) == 0xffffffffull) continue;          // the run of dropped points (always last)
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (st + r < en) nxt = pts[order[st + r]];
+        for (uint32_t j0 = st; j0 < en; j0 += 16) {
+            const float4 p = nxt;
+            const uint32_t jn = j0 + 16 + r;                            // the next sixteen are in flight while these are added
+            if (jn < en) nxt = pts[order[jn]];
+            const int cnt = (int)min(16u, en - j0);
+            for (int k = 0; k < cnt; ++k) {
+                sx += __shfl(p.x, k, 16);
+                sy += __shfl(p.y, k, 16);
+                sz += __shfl(p.z, k, 16);
+            }
         }
+        const float fn = (float)(en - st);
+        if (r == 0 && l < cap_out) out[l] = make_float4(sx / fn, sy / fn, sz / fn, 0.0f);
     }
-    const float fn = (float)(en - st);
-    if (r == 0 && l < cap_out) out[l] = make_float4(sx / fn, sy / fn, sz / fn, 0.0f);
 }
 
 hipError_t launch_time_keys(const float4* pts, int n, uint64_t* keys, uint32_t* order, hipStream_t s) {
@@ -234,7 +237,8 @@ hipError_t launch_voxel_index(const float4* pts, int n, const VoxelGridDev* vox,
 hipError_t launch_centroids(const float4* pts, const uint32_t* order, const uint64_t* sorted_keys, const uint32_t* leaf_start,
                             VoxelGridDev* vox, uint32_t n, uint32_t max_leaves, uint32_t cap_out, float4* out, hipStream_t s) {
     if (n == 0 || max_leaves == 0) return hipSuccess;
-    const uint32_t blocks = (uint32_t)(((size_t)max_leaves * 16 + 255) / 256);
+    uint32_t blocks = (uint32_t)(((size_t)max_leaves * 16 + 255) / 256);
+    if (blocks > 1024u) blocks = 1024u;
     hipLaunchKernelGGL(centroid_kernel, dim3(blocks), dim3(256), 0, s, pts, order, sorted_keys, leaf_start, vox, n, cap_out, out);
     return hipGetLastError();
 }

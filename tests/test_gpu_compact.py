@@ -9,10 +9,11 @@ from conftest import bits_equal
 pytestmark = pytest.mark.gpu
 
 
-def _drive(gpu_capi, synth, world, n_raw, library, seed):
+def _drive(gpu_capi, synth, world, n_raw, mode, seed, leaf=None):
     rng = np.random.default_rng(seed)
     ctx = gpu_capi.LioContext(0.2, max_scan_points=131072, max_map_points=600_000)
-    ctx.debug_set("library_sort", int(library))
+    if mode:
+        ctx.debug_set(mode, 1)
     ctx.map_build(world.points)
     half = world.ground_half
     out = []
@@ -34,7 +35,7 @@ def _drive(gpu_capi, synth, world, n_raw, library, seed):
             ctx.scan_undistort(raw)                                   # already compensated: leaf index is the whole key
         else:
             ctx.scan_undistort(raw, poses, synth.state_vector(poses[-1, 10:13], [0, 0, 0, 1], [0, 0, 0, 1.0], np.zeros(3)))
-        m = ctx.scan_voxel_filter(0.5 if n_raw > 20000 else 0.1)
+        m = ctx.scan_voxel_filter(leaf if leaf else (0.5 if n_raw > 20000 else 0.1))
         down = ctx.scan_cloud(1).copy()
         und = ctx.scan_cloud(0).copy()                                # time order (a second sort of the sweep)
         st = synth.state_vector([0.05 * k, 0.02, 0.0], [0, 0, 0, 1], np.array([0, 0, 0, 1.0]), np.zeros(3))
@@ -46,12 +47,17 @@ def _drive(gpu_capi, synth, world, n_raw, library, seed):
     return out, flat
 
 
-@pytest.mark.parametrize("n_raw", [60, 1024, 1025, 3000, 9000, 16384, 131072])
-def test_single_launch_sort_and_compaction_equal_the_library(gpu_capi, synth, small_case, n_raw):
-    a, fa = _drive(gpu_capi, synth, small_case["world"], n_raw, False, 3)
-    b, fb = _drive(gpu_capi, synth, small_case["world"], n_raw, True, 3)
+def _same(a, fa, b, fb):
     for x, y in zip(a, b):
         assert x[0] == y[0] and x[3:] == y[3:]
         assert bits_equal(x[1], y[1]) and bits_equal(x[2], y[2])
     assert fa.shape == fb.shape and bits_equal(fa, fb)               # the maps, point for point IN ORDER
-    assert a[0][0] > 0 and a[-1][4] + a[-1][5] > 0                   # something was filtered and inserted
+
+
+@pytest.mark.parametrize("n_raw", [60, 1024, 1025, 3000, 9000, 16384, 131072])
+def test_single_launch_sort_and_compaction_equal_the_library(gpu_capi, synth, small_case, n_raw):
+    """default (rank sort, single-launch compactions) == rocPRIM everywhere"""
+    b, fb = _drive(gpu_capi, synth, small_case["world"], n_raw, "library_sort", 3)
+    a, fa = _drive(gpu_capi, synth, small_case["world"], n_raw, None, 3)
+    _same(a, fa, b, fb)
+    assert b[0][0] > 0 and b[-1][4] + b[-1][5] > 0                   # something was filtered and inserted
