@@ -147,7 +147,13 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         qx = w.x; qy = w.y; qz = w.z;
     }
     const float inv_cell = a.grid.inv_cell;
-    const int cx = cell_coord(qx, inv_cell), cy = cell_coord(qy, inv_cell), cz = cell_coord(qz, inv_cell);
+    // cell_coord (lio_common.h) with the clamp as one v_med3_f32: the same cell for every finite coordinate and for +-inf;
+    // a NaN lands in SOME valid cell instead of the middle one, which is all it needs (none of its distances is a number:
+    // no candidate counts, the query goes to the tree walk, which does its own arithmetic)
+    auto query_cell = [inv_cell](float v) {
+        return (int)__builtin_amdgcn_fmed3f(__builtin_floorf(v * inv_cell), -1048576.0f, 1048575.0f) + CELL_OFF;
+    };
+    const int cx = query_cell(qx), cy = query_cell(qy), cz = query_cell(qz);
 
     // ---- HINT (second and later searches of a scan): the previous neighbours of this scan point,
     // re-measured from the new query, bound the new 5th distance from above: tau = max_k d(q, nbr_k).
