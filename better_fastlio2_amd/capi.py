@@ -205,7 +205,7 @@ def pinned_points(xyz) -> np.ndarray:
     buf = (C.c_float * (max(n, 1) * 4)).from_address(p)
     arr = np.frombuffer(buf, np.float32).reshape(-1, 4)[:n]
     arr[:] = 0.0
-    arr[:, :3] = xyz[:, :3]
+    arr[:, :xyz.shape[1]] = xyz[:, :4]            # [n, 4] input: x, y, z, t records (a raw sweep)
     _pinned_keepalive.append((arr, p))
     return arr
 

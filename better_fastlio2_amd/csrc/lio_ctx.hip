@@ -1520,6 +1520,12 @@ void* lio_host_alloc(size_t bytes) {
 void lio_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 // ---- raw-scan preparation: UndistortPcl's compensation + pcl::VoxelGrid ----
+// page-locked host memory known to the HIP runtime (lio_host_alloc, hipHostMalloc, hipHostRegister)?
+static bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
 static int ensure_raw_buffers(lio_ctx* c, size_t n) {
     if (!c->d_imu_poses) HIPCHK(c, hipMalloc((void**)&c->d_imu_poses, 512 * 22 * sizeof(double)));
     if (!c->d_vox) HIPCHK(c, hipMalloc((void**)&c->d_vox, sizeof(VoxelGridDev)));
@@ -1564,6 +1570,13 @@ int lio_scan_upload_raw(lio_ctx* c, const float* raw_pts, int n, int stride_byte
     rc = ensure_stage(c, (size_t)n + POSE_STAGE_SLOTS);                        // the IMU poses travel behind the points
     if (rc != LIO_OK) return rc;
     const char* src = reinterpret_cast<const char*>(raw_pts);
+    if (time_offset_bytes == 12 && stride_bytes == 16 && is_pinned_host(raw_pts)) {
+        // x, y, z, t records in page-locked memory (lio_host_alloc): the copy engine reads them where they are -- no
+        // staging copy (60 us of host time for a 120 k-point sweep).  The caller leaves them alone until a call that
+        // waits for the stream has returned (lio_scan_voxel_filter does).
+        HIPCHK(c, hipMemcpyAsync(c->d_raw, raw_pts, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s));
+        return LIO_OK;
+    }
     if (time_offset_bytes == 12 && stride_bytes == 16) {
         std::memcpy(c->h_stage, raw_pts, (size_t)n * sizeof(float4));         // the records already are x, y, z, t
     } else {

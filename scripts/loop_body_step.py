@@ -20,7 +20,8 @@ scans = []
 for k in range(6):
     sc = synth.make_scan(world, n_raw, seed=synth.SEED + 10 + k, pos=(3.0 + 0.8 * k, -2.0 + 0.1 * k, 0.0), rpy=(0.004, -0.006, 0.5 + 0.02 * k))
     t_ms = np.sort(rng.uniform(0, 99.0, n_raw)).astype(np.float32)
-    scans.append((sc, np.concatenate([sc.body, t_ms[:, None]], 1).astype(np.float32)))
+    # the sweep where a sensor driver would put it: x, y, z, t records in page-locked memory (read in place by the copy engine)
+    scans.append((sc, capi.pinned_points(np.concatenate([sc.body, t_ms[:, None]], 1).astype(np.float32))))
 def qmat(q):
     x, y, z, w = q
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],

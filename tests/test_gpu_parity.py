@@ -860,6 +860,9 @@ def test_scan_undistort_and_voxel_filter(gpu_capi, oracle, synth, small_case):
     ctx.map_build(w.points)
     ctx.scan_undistort(raw, poses, end)
     und_g = ctx.scan_cloud(0)
+    # the same sweep from page-locked memory (read in place by the copy engine, no staging copy): same bits
+    ctx.scan_undistort(gpu_capi.pinned_points(raw), poses, end)
+    assert bits_equal(ctx.scan_cloud(0), und_g)
     und_o, ts = oracle.undistort(raw, poses, end)
     assert und_g.shape == und_o.shape == (n, 3)
     # fp64 arithmetic with device sin/cos vs glibc: sub-ulp differences may flip an fp32 rounding
