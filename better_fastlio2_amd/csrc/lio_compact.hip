@@ -1,9 +1,9 @@
-// lio_compact.hip -- single-launch, order-preserving stream compaction / run detection / exclusive scan for the batch
-// sizes of map maintenance (up to ~260 k items), gfx950 only.
+// lio_compact.hip -- single-launch, order-preserving stream compaction / run detection / exclusive scan (up to ~260 k
+// items) and stable sort (up to 16 k records) for the batch sizes of map maintenance and scan preparation, gfx950 only.
 //
 // rocPRIM's device-wide select / run_length_encode / exclusive_scan are two to three launches each (an init kernel for
 // the look-back state, the sweep, sometimes a fix-up); a map update strings a dozen of them together on batches of a few
-// thousand points, where every launch costs more than its work ("launch storm").  Here every primitive is
+// thousand points, where every launch costs more than its work.  Here every primitive is
 // ONE launch: a workgroup handles a tile of 256 items, publishes the tile's count(s) as {count | stamp << 32} -- an
 // 8-byte store is single-copy atomic, the stamp is this launch's sequence number, so whoever reads the stamp has the
 // count (the same idea as the measurement kernel's partial sums, lio_measure.hip) -- and sums the counts of all tiles
