@@ -12,5 +12,5 @@ python - <<PY
 import json
 d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1])
 print('value', round(d['value'],1), {k: round(v['value'],1) for k,v in d.items() if isinstance(v,dict) and 'value' in v and k!='cpu_baseline'})
-print({k:v for k,v in d.items() if 'map' in k})
+print({k: v for k, v in d['node_loop'].items() if k != 'value'})
 PY
