@@ -148,14 +148,14 @@ hipError_t launch_compact_marked(const uint32_t* src, uint32_t n, uint32_t* dst,
 // ---- runs of equal keys in a sorted array: unique[r], starts[r] (= exclusive scan of the run lengths), *n_runs ------
 // (counts[r] = starts[r + 1] - starts[r] follows in run_counts_kernel: the next run's head may sit in a later tile)
 __global__ __launch_bounds__(256) void run_heads_kernel(const uint64_t* keys, uint32_t n, int shift, uint64_t* unique_out, uint32_t* starts_out,
-                                                        uint32_t* n_runs_out, u64* agg, uint32_t stamp, uint32_t* err) {
+                                                        uint32_t* n_runs_out, u64* agg, uint32_t stamp, uint32_t* err, bool drop_filler) {
     __shared__ uint32_t s_w[4];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     uint64_t k = 0;
     bool head = false;
     if (i < n) {
         k = keys[i];
-        head = i == 0u || (keys[i - 1] >> shift) != (k >> shift);
+        head = (i == 0u || (keys[i - 1] >> shift) != (k >> shift)) && !(drop_filler && k == ~0ull);
     }
     uint32_t tot;
     const uint32_t r = tile_rank(head, tot, s_w);
@@ -168,25 +168,27 @@ __global__ __launch_bounds__(256) void run_heads_kernel(const uint64_t* keys, ui
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *n_runs_out = ok ? before[0] + tot : 0u; if (!ok) atomicOr(err, 1u); }
 }
-__global__ __launch_bounds__(256) void run_counts_kernel(const uint32_t* starts, const uint32_t* n_runs, uint32_t n, uint32_t* counts_out) {
+__global__ __launch_bounds__(256) void run_counts_kernel(const uint32_t* starts, const uint32_t* n_runs, uint32_t n, uint32_t* counts_out,
+                                                         const uint32_t* n_head, uint32_t n_after) {
     const uint32_t nr = *n_runs;
+    if (n_head != nullptr) n = min(n, *n_head + n_after);           // the last run ends where the real keys end
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nr; r += gridDim.x * 256u)
         counts_out[r] = (r + 1u < nr ? starts[r + 1u] : n) - starts[r];
 }
 hipError_t launch_run_lengths(const uint64_t* keys, uint32_t n, uint64_t* unique_out, uint32_t* counts_out, uint32_t* starts_out,
-                              uint32_t* n_runs_out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s) {
+                              uint32_t* n_runs_out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s, const uint32_t* n_head, uint32_t n_after) {
     if (n == 0) return hipMemsetAsync(n_runs_out, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(run_heads_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, keys, n, 0, unique_out, starts_out, n_runs_out, agg, stamp, err);
+    hipLaunchKernelGGL(run_heads_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, keys, n, 0, unique_out, starts_out, n_runs_out, agg, stamp, err, n_head != nullptr);
     uint32_t b = (n + 255u) / 256u;
     if (b > 256u) b = 256u;
-    hipLaunchKernelGGL(run_counts_kernel, dim3(b), dim3(256), 0, s, starts_out, n_runs_out, n, counts_out);
+    hipLaunchKernelGGL(run_counts_kernel, dim3(b), dim3(256), 0, s, starts_out, n_runs_out, n, counts_out, n_head, n_after);
     return hipGetLastError();
 }
 
 hipError_t launch_run_heads(const uint64_t* keys, uint32_t n, int shift, uint32_t* starts_out, uint32_t* n_runs_out, u64* agg, uint32_t stamp,
                             uint32_t* err, hipStream_t s) {
     if (n == 0) return hipMemsetAsync(n_runs_out, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(run_heads_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, keys, n, shift, (uint64_t*)nullptr, starts_out, n_runs_out, agg, stamp, err);
+    hipLaunchKernelGGL(run_heads_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, keys, n, shift, (uint64_t*)nullptr, starts_out, n_runs_out, agg, stamp, err, false);
     return hipGetLastError();
 }
 

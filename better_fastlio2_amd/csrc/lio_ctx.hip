@@ -59,6 +59,11 @@ struct lio_ctx {
     float4* d_pend = nullptr;
     size_t cap_pend = 0;
     uint32_t n_pend = 0;
+    // the pending list's length may still be on the device: [d_apply[6] survivors of a down-sampled batch][pend_after
+    // points appended behind them]; n_pend is then the number of SLOTS (an upper bound), see add_batch_device
+    bool pend_lazy = false;
+    uint32_t pend_after = 0;
+    int last_add_counter = 0;                  // tmp_counter of the last down-sampled Add_Points (ikd_Tree.cpp:414-489)
     uint64_t *d_pkeys = nullptr, *d_pkeys2 = nullptr, *d_pcell = nullptr;
     uint32_t *d_porder = nullptr, *d_porder2 = nullptr, *d_pgcount = nullptr, *d_pgstart = nullptr, *d_pnewsize = nullptr,
              *d_pnewoff = nullptr;
@@ -441,11 +446,28 @@ int collect_box_deleted(lio_ctx* c) {
     return LIO_OK;
 }
 
+// the counts a down-sampled Add_Points left on the device (replaced, tmp_counter, survivors), when nobody has read them yet
+static int resolve_lazy_pending(lio_ctx* c) {
+    if (!c->pend_lazy) return LIO_OK;
+    uint32_t host_cnt[3] = {0, 0, 0};
+    HIPCHK(c, read_back(c, host_cnt, c->d_apply + 4, sizeof(host_cnt)));
+    c->pend_lazy = false;
+    c->n_live -= host_cnt[0];
+    c->last_add_counter = (int)host_cnt[1];
+    c->n_pend = host_cnt[2] + c->pend_after;
+    c->pend_after = 0;
+    return LIO_OK;
+}
+
 // Full rebuild: the live points in array order (a bucket is contiguous, so the order inside a cell is kept),
 // then the pending points, re-sorted and re-hashed.  Run when the tail is full, when the retired slots or
 // the new cells have grown past their budget, or when a new cell lies outside the root of the tree.
 int rebuild_full(lio_ctx* c) {
     hipStream_t s = c->stream;
+    {
+        const int rc = resolve_lazy_pending(c);
+        if (rc != LIO_OK) return rc;
+    }
     c->have_map = false;
     c->hint_valid = false;
     const uint32_t n_all = c->n_points;
@@ -474,13 +496,21 @@ int apply_pending(lio_ctx* c) {
     c->hint_valid = false;
     if (c->n_pend == 0) return LIO_OK;
     if (!c->have_map || c->n_live == 0 || c->n_points == 0) return rebuild_full(c);
-    const uint32_t n = c->n_pend;
-    HIPCHK(c, launch_pend_keys(c->d_pend, n, c->grid, c->d_pkeys, c->d_porder, s));
+    // n slots; with a lazy list only the first d_apply[6] + pend_after hold points (the kernels read the count where it is)
+    const bool small = compact_small(c, (size_t)c->n_pend + 1);
+    if (c->pend_lazy && !small) {
+        const int rc = resolve_lazy_pending(c);
+        if (rc != LIO_OK) return rc;
+        if (c->n_pend == 0) return LIO_OK;
+    }
+    const bool lazy = c->pend_lazy;
+    const uint32_t n = c->n_pend, n_after = c->pend_after;
+    const uint32_t* n_head = lazy ? c->d_apply + 6 : nullptr;
+    HIPCHK(c, launch_pend_keys(c->d_pend, n, c->grid, c->d_pkeys, c->d_porder, n_head, n_after, s));
     HIPCHK(c, sort_pairs_any(c, c->d_pkeys, c->d_pkeys2, c->d_porder, c->d_porder2, (size_t)n, s));
-    const bool small = compact_small(c, (size_t)n + 1);
     if (small) {
         HIPCHK(c, launch_run_lengths(c->d_pkeys2, n, c->d_pcell, c->d_pgcount, c->d_pgstart, c->d_apply + 8, c->d_cagg,
-                                     next_compact_stamp(c), c->d_apply + 15, s));
+                                     next_compact_stamp(c), c->d_apply + 15, s, n_head, n_after));
     } else {
         HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_pkeys2, (size_t)n, c->d_pcell, c->d_pgcount, c->d_apply + 8, s));
         HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pgcount, c->d_pgstart, (size_t)n, s));
@@ -501,6 +531,15 @@ int apply_pending(lio_ctx* c) {
     uint32_t st[32] = {};
     HIPCHK(c, read_back(c, st, c->d_apply, sizeof(st)));
     const uint32_t total = st[3];
+    uint32_t n_real = n;
+    if (lazy) {
+        // the counts of the down-sampled Add_Points arrive with this read-back (one host round trip less per scan)
+        c->pend_lazy = false; c->pend_after = 0;
+        c->n_live -= st[4];
+        c->last_add_counter = (int)st[5];
+        n_real = st[6] + n_after;
+        c->n_pend = n_real;
+    }
     {
         const int rc = check_compact_error(c, st[15]);
         if (rc != LIO_OK) return rc;
@@ -508,7 +547,7 @@ int apply_pending(lio_ctx* c) {
     if (st[2] & APPLY_FLAG_NO_ROOM) return rebuild_full(c);    // nothing was changed: the pending points go in there
     c->n_points += total;
     c->grid.n_points = c->n_points;
-    c->n_live += n;
+    c->n_live += n_real;
     c->n_pend = 0;
     c->n_cells += st[0]; c->n_new_cells += st[0]; c->n_retired += st[1];
     ++c->n_incremental_updates;
@@ -839,11 +878,17 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
     hipStream_t s = c->stream;
     if (n_added) *n_added = 0;
     if (n == 0) return LIO_OK;
+    // (bounds when the pending list is lazy: exact numbers first if they do not fit)
+    if (c->pend_lazy && ((size_t)c->n_live + (size_t)c->n_pend + (size_t)n > c->cap_map || (size_t)c->n_pend + (size_t)n > c->cap_pend || downsample_on)) {
+        const int rc = resolve_lazy_pending(c);
+        if (rc != LIO_OK) return rc;
+    }
     if ((size_t)c->n_live + (size_t)c->n_pend + (size_t)n > c->cap_map)
         return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
     if ((size_t)c->n_pend + (size_t)n > c->cap_pend)
         return c->fail(LIO_ERR_CAPACITY, "Add_Points", "pending buffer too small");
     if (downsample_on) {
+        c->last_add_counter = 0;
         const float ds = c->cfg.filter_size_map_min;
         HIPCHK(c, launch_voxel_keys(batch, n, ds, c->d_add_keys, c->d_add_order, c->d_apply + 4, c->d_add_dirty, c->d_add_dlist,
                                     c->d_add_out, s));
@@ -884,24 +929,44 @@ static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsamp
         HIPCHK(c, launch_fold_groups(fa, s));
         // survivors (w == 0) of both passes -> the tail of the pending list, in order
         float4* tail = c->d_pend + c->n_pend;
-        if (compact_small(c, 2 * (size_t)n))
+        const bool small = compact_small(c, 2 * (size_t)n);
+        if (small)
             HIPCHK(c, launch_compact_live(c->d_add_out, 2 * n, tail, c->d_apply + 6, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
         else
             HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, tail, c->d_apply + 6, 2 * (size_t)n, s));
+        if (small && c->n_pend == 0 && !c->dbg_library_sort) {
+            // The counts (replaced, tmp_counter, survivors) stay where they are: the pending list is "d_apply[6] points in
+            // n slots" until apply_pending's own read-back brings them along -- one host round trip less per scan.
+            c->pend_lazy = true; c->pend_after = 0;
+            c->n_pend = n;
+            return LIO_OK;
+        }
         uint32_t host_cnt[3] = {0, 0, 0};                  // replaced, tmp_counter, survivors
         HIPCHK(c, read_back(c, host_cnt, c->d_apply + 4, sizeof(host_cnt)));
+        c->last_add_counter = (int)host_cnt[1];
         if (n_added) *n_added = (int)host_cnt[1];
         c->n_pend += host_cnt[2];
         c->n_live -= host_cnt[0];                     // points of the map replaced inside their down-sample voxel
         return LIO_OK;
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_pend + c->n_pend, batch, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    if (c->pend_lazy) {
+        // behind the survivors, wherever they end
+        HIPCHK(c, launch_append_points(c->d_pend, c->d_apply + 6, batch, n, s));
+        c->pend_after += n;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_pend + c->n_pend, batch, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    }
     c->n_pend += n;
     return LIO_OK;
 }
 
 // the appended points enter the index (incrementally, or through a full rebuild when budgets are exceeded)
-static int rebuild_from_stored(lio_ctx* c) { return apply_pending(c); }
+// (*add_counter: tmp_counter of the down-sampled batch of this call, which may only have arrived with apply_pending's read-back)
+static int rebuild_from_stored(lio_ctx* c, int* add_counter = nullptr) {
+    const int rc = apply_pending(c);
+    if (rc == LIO_OK && add_counter) *add_counter = c->last_add_counter;
+    return rc;
+}
 
 // Add_Points (ikd_Tree.cpp:414-489).  Returns through *n_added what the reference returns: the number
 // of down-sampled inserts that changed the tree (tmp_counter), 0 when downsample_on is false.
@@ -916,9 +981,10 @@ int lio_map_add(lio_ctx* c, const float* pts, int n, int stride_bytes, int downs
     if (rc != LIO_OK) return rc;
     rc = upload_points(c, pts, (size_t)n, stride_bytes, c->d_add_pts);
     if (rc != LIO_OK) return rc;
+    c->last_add_counter = 0;
     rc = add_batch_device(c, c->d_add_pts, (uint32_t)n, downsample_on != 0, n_added);
     if (rc != LIO_OK) return rc;
-    return rebuild_from_stored(c);
+    return rebuild_from_stored(c, n_added);
 }
 
 // Add_Points(add, true) followed by Add_Points(nodown, false) -- the pair map_incremental issues
@@ -937,6 +1003,7 @@ int lio_map_add_pair(lio_ctx* c, const float* add_pts, int n_add, const float* n
     if (n_add > 0) {
         rc = upload_points(c, add_pts, (size_t)n_add, stride_bytes, c->d_add_pts);
         if (rc != LIO_OK) return rc;
+        c->last_add_counter = 0;
         rc = add_batch_device(c, c->d_add_pts, (uint32_t)n_add, true, add_counter);
         if (rc != LIO_OK) return rc;
     }
@@ -946,7 +1013,7 @@ int lio_map_add_pair(lio_ctx* c, const float* add_pts, int n_add, const float* n
         rc = add_batch_device(c, c->d_add_pts2, (uint32_t)n_nodown, false, nullptr);
         if (rc != LIO_OK) return rc;
     }
-    return rebuild_from_stored(c);
+    return rebuild_from_stored(c, add_counter);
 }
 
 // map_incremental's classification + the two order-preserving lists, left on the device
@@ -1015,11 +1082,12 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
     }
     if (!apply) return LIO_OK;
     // ikdtree.Add_Points(PointToAdd, true); ikdtree.Add_Points(PointNoNeedDownsample, false);   :1492-1493
+    c->last_add_counter = 0;
     rc = add_batch_device(c, c->d_add_pts, cnts[0], true, add_counter);
     if (rc != LIO_OK) return rc;
     rc = add_batch_device(c, c->d_add_pts2, cnts[1], false, nullptr);
     if (rc != LIO_OK) return rc;
-    return rebuild_from_stored(c);
+    return rebuild_from_stored(c, add_counter);
 }
 
 // Device-resident variants for replicated maps: the lists stay in HBM (float4 records), are exchanged
@@ -1063,11 +1131,12 @@ int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const v
         if (n_nodown && d_nodown_f4 != c->d_add_pts2)
             HIPCHK(c, hipMemcpyAsync(c->d_add_pts2, d_nodown_f4, (size_t)n_nodown * sizeof(float4), hipMemcpyDeviceToDevice, s));
     }
+    c->last_add_counter = 0;
     int rc = add_batch_device(c, c->d_add_pts, (uint32_t)n_add, true, add_counter);
     if (rc != LIO_OK) return rc;
     rc = add_batch_device(c, c->d_add_pts2, (uint32_t)n_nodown, false, nullptr);
     if (rc != LIO_OK) return rc;
-    return rebuild_from_stored(c);
+    return rebuild_from_stored(c, add_counter);
 }
 
 // ---- replica exchange behind the C ABI ------------------------------------------------
@@ -1239,11 +1308,12 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
         if (rc != LIO_OK) return rc;
         account_deleted(c, deleted);
     }
+    c->last_add_counter = 0;
     rc = add_batch_device(c, c->d_add_pts, tot[0], true, add_counter);
     if (rc != LIO_OK) return rc;
     rc = add_batch_device(c, c->d_add_pts2, tot[1], false, nullptr);
     if (rc != LIO_OK) return rc;
-    rc = rebuild_from_stored(c);
+    rc = rebuild_from_stored(c, add_counter);
     if (n_add_total) *n_add_total = (int)tot[0];
     if (n_nodown_total) *n_nodown_total = (int)tot[1];
     if (n_deleted) *n_deleted = deleted;

@@ -69,7 +69,10 @@ constexpr uint32_t APPLY_FLAG_OUTSIDE_TOP = 1u;   // a new cell lies outside the
 constexpr uint32_t APPLY_FLAG_TABLE_FULL = 2u;    // an insertion probe wrapped around a table
 constexpr uint32_t APPLY_FLAG_NO_BLOCKS = 8u;     // the pool of child blocks is exhausted
 constexpr uint32_t APPLY_FLAG_NO_ROOM = 4u;       // the tail cannot hold the re-written buckets: nothing was changed
-hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, hipStream_t s);
+// (n_head: the list is [*n_head][n_after] points in n slots, the rest get the key ~0 -- see the kernel)
+hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, const uint32_t* n_head,
+                            uint32_t n_after, hipStream_t s);
+hipError_t launch_append_points(float4* dst_base, const uint32_t* offset, const float4* src, uint32_t n, hipStream_t s);
 hipError_t launch_cell_plan(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);
 hipError_t launch_cell_apply(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);
 // Boundary points of a down-sampled batch.  The reference's down-sample box is computed in fp32
@@ -118,8 +121,10 @@ hipError_t launch_compact_live(const float4* src, uint32_t n, float4* dst, uint3
 hipError_t launch_compact_marked(const uint32_t* src, uint32_t n, uint32_t* dst, uint32_t* n_out, unsigned long long* agg, uint32_t stamp,
                                  uint32_t* err, hipStream_t s);
 // runs of a sorted key array: unique keys, run lengths, run starts (exclusive scan of the lengths), number of runs
+// (n_head != nullptr: only the first *n_head + n_after keys are real, the rest are ~0 and form no run)
 hipError_t launch_run_lengths(const uint64_t* keys, uint32_t n, uint64_t* unique_out, uint32_t* counts_out, uint32_t* starts_out,
-                              uint32_t* n_runs_out, unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s);
+                              uint32_t* n_runs_out, unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s,
+                              const uint32_t* n_head = nullptr, uint32_t n_after = 0);
 // stable sort of (u64 key, u32 value) pairs, one launch, no workspace (rank by counting: O(n^2))
 constexpr uint32_t SORT_MAX_ITEMS = 16384;
 hipError_t launch_sort_pairs_small(const uint64_t* keys_in, const uint32_t* vals_in, uint32_t n, uint64_t* keys_out, uint32_t* vals_out,

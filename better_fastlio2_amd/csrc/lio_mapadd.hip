@@ -369,14 +369,27 @@ __global__ __launch_bounds__(64) void fold_sequential_kernel(BoundaryArgs a, con
 }
 
 // ---- incremental index update -------------------------------------------------------------------------
+// n_head != nullptr: the list is [*n_head points][n_after points] inside a buffer of n slots (the first count is still on
+// the device, lio_ctx.hip: add_batch_device); the slots behind them get a key no cell has, sort last and are dropped
+// by the run detection
 __global__ __launch_bounds__(256) void pend_keys_kernel(const float4* pend, uint32_t n, Grid grid, uint64_t* keys,
-                                                        uint32_t* order) {
+                                                        uint32_t* order, const uint32_t* n_head, uint32_t n_after) {
+    const uint32_t n_real = n_head != nullptr ? min(n, *n_head + n_after) : n;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 p = pend[i];
-        keys[i] = pack_key((uint32_t)cell_coord(p.x, grid.inv_cell), (uint32_t)cell_coord(p.y, grid.inv_cell),
-                           (uint32_t)cell_coord(p.z, grid.inv_cell));
+        uint64_t k = ~0ull;
+        if (i < n_real) {
+            const float4 p = pend[i];
+            k = pack_key((uint32_t)cell_coord(p.x, grid.inv_cell), (uint32_t)cell_coord(p.y, grid.inv_cell),
+                         (uint32_t)cell_coord(p.z, grid.inv_cell));
+        }
+        keys[i] = k;
         order[i] = i;
     }
+}
+// dst_base[*offset + i] = src[i]: a batch appended behind a list whose length is still on the device
+__global__ __launch_bounds__(256) void append_points_kernel(float4* dst_base, const uint32_t* offset, const float4* src, uint32_t n) {
+    const uint32_t off = *offset;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst_base[off + i] = src[i];
 }
 
 // one lane per touched cell: where the cell is now and how large its re-written bucket will be
@@ -524,10 +537,17 @@ hipError_t launch_fold_sequential(const BoundaryArgs& a, const uint32_t* dlist_s
     hipLaunchKernelGGL(fold_sequential_kernel, dim3(1), dim3(64), 0, s, a, dlist_sorted);
     return hipGetLastError();
 }
-hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, hipStream_t s) {
+hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, const uint32_t* n_head,
+                            uint32_t n_after, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint32_t b = (n + 255u) / 256u; if (b > 4096u) b = 4096u;
-    hipLaunchKernelGGL(pend_keys_kernel, dim3(b), dim3(256), 0, s, pend, n, grid, keys, order);
+    hipLaunchKernelGGL(pend_keys_kernel, dim3(b), dim3(256), 0, s, pend, n, grid, keys, order, n_head, n_after);
+    return hipGetLastError();
+}
+hipError_t launch_append_points(float4* dst_base, const uint32_t* offset, const float4* src, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint32_t b = (n + 255u) / 256u; if (b > 1024u) b = 1024u;
+    hipLaunchKernelGGL(append_points_kernel, dim3(b), dim3(256), 0, s, dst_base, offset, src, n);
     return hipGetLastError();
 }
 hipError_t launch_cell_plan(const ApplyArgs& a, uint32_t max_groups, hipStream_t s) {
