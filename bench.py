@@ -108,8 +108,19 @@ def dist_setup(n_gpus: int):
     return dist.get_rank(), dist.get_world_size(), local, dist
 
 
-def timed_steps(step_fn, steps: int, warmup: int, dist, device):
-    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
+def latency_summary(lat_s):
+    """p50 / p90 / p99 / max of per-step wall times (a real-time node cares about the tail, not the mean:
+    the reference logs per-frame times, laserMapping.cpp:2438-2448)."""
+    if not lat_s:
+        return None
+    v = np.sort(np.asarray(lat_s, np.float64)) * 1e3
+    q = lambda f: float(v[min(len(v) - 1, int(np.ceil(f * len(v))) - 1)])
+    return {"unit": "ms", "steps": int(len(v)), "p50": q(0.50), "p90": q(0.90), "p99": q(0.99), "max": float(v[-1])}
+
+
+def timed_steps(step_fn, steps: int, warmup: int, dist, device, lat=None):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.  lat (a list) receives
+    the wall time of every timed step (a step returns when its result is on the host: two clock reads per step)."""
     import torch
     for _ in range(warmup):
         step_fn()
@@ -118,8 +129,16 @@ def timed_steps(step_fn, steps: int, warmup: int, dist, device):
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step_fn()
+    if lat is None:
+        for _ in range(steps):
+            step_fn()
+    else:
+        tp = t0
+        for _ in range(steps):
+            step_fn()
+            tn = time.perf_counter()
+            lat.append(tn - tp)
+            tp = tn
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
@@ -231,6 +250,80 @@ def cpu_baseline(world_pts, scan, x0, P0, max_iter: int, ext: bool, sample_every
     return out
 
 
+def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, P0_p, ulog_ref, k_steps, n_rot, step_own, tick,
+                        device, node_loop_1):
+    """What ONE rank of a W-GPU job does per scan, measured on one GPU ("the only serial term is
+    applying W x the inserts per replica"): its own scan step, then lio_replicate_step with the lists of all W ranks --
+    the library's loop-back mode packs W - 1 PARKED ranks' messages into the gathered buffer where ncclAllGather would
+    put them (the wire time of W x ~0.4 MB over xGMI is not in the figure), then compaction in rank order and the
+    Delete_Point_Boxes / Add_Points pair over everything.  The other W - 1 virtual ranks drive their own streets; their scan
+    steps and the parking of their lists run between the timed segments, untimed."""
+    import ctypes as C
+    import torch
+    L = ctx.L
+    # streets of the virtual ranks 0 .. W-2 (the timed rank, W - 1, keeps rank 0's drive: step_own)
+    v_scans, v_priors = [], []
+    for v in range(1, W):
+        rng = np.random.default_rng(1000 + v)
+        px, py = tuple(rng.uniform(-0.3, 0.3, 2) * world.ground_half)
+        yaw = float(rng.uniform(-3.1, 3.1))
+        ds, xs = [], []
+        for k in range(n_rot):
+            sc = synth.make_scan(world, nq, kind=kind, seed=synth.SEED + 1 + v + 17 * k,
+                                 pos=(px + 0.9 * k, py + 0.4 * k, 0.0), rpy=(0.004, -0.006, yaw + 0.05 * k))
+            ps, rt = synth.perturb_state(sc, seed=synth.SEED + 2 + v + 7 * k)
+            xs.append(np.ascontiguousarray(capi.make_state26(ps, rt, sc.off_R, sc.off_T), np.float64))
+            b4 = np.zeros((nq, 4), np.float32); b4[:, :3] = sc.body
+            ds.append(torch.from_numpy(b4).to(device))
+        v_scans.append(ds); v_priors.append(xs)
+    ctx.debug_set("replicate_loopback", 1)
+    ctx.replicate_init(b"", W - 1, W)
+    kfv = capi.Esekf(kf.maximum_iter)
+    acc = {"own": 0.0, "exchange": 0.0, "n_add": 0, "n_nodown": 0, "steps": 0}
+    lat = []
+    info0 = ctx.map_info()
+
+    def one(timed):
+        k = tick[0] % n_rot
+        for v in range(W - 1):                                  # untimed: the other ranks' scan steps, lists parked
+            rc = L.lio_eskf_scan_step_device(kfv.h, ctx.h, v_priors[v][k].ctypes.data_as(C.c_void_p), P0_p,
+                                             C.c_void_p(v_scans[v][k].data_ptr()), nq, 0.001, ext_i, ulog_ref)
+            if rc != 0:
+                raise capi.LioError("virtual rank scan step failed: " + L.lio_last_error(ctx.h).decode())
+            ctx.debug_set("replicate_loopback_rank", v)
+            ctx.replicate_step(kfv.get_x()[:14], voxel, True)
+        ctx.debug_set("replicate_loopback_rank", W - 1)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        step_own()                                              # timed: this rank's scan step ...
+        t1 = time.perf_counter()
+        r = ctx.replicate_step(kf.get_x()[:14], voxel, True)    # ... its lists, the (emulated) exchange, the apply of all W
+        t2 = time.perf_counter()
+        if timed:
+            acc["own"] += t1 - t0; acc["exchange"] += t2 - t1; acc["steps"] += 1
+            acc["n_add"] += r["n_add"]; acc["n_nodown"] += r["n_nodown"]
+            lat.append(t2 - t0)
+
+    tick[0] = 0
+    for _ in range(2):
+        one(False)
+    for _ in range(k_steps):
+        one(True)
+    info = ctx.map_info()
+    n = max(acc["steps"], 1)
+    per_step = (acc["own"] + acc["exchange"]) / n
+    out = {"value": 1.0 / per_step, "unit": "scans/s per rank", "ms_per_step": per_step * 1e3, "steps": acc["steps"], "world": W,
+           "scan_step_ms": acc["own"] / n * 1e3, "map_update_ms_per_step": acc["exchange"] / n * 1e3,
+           "inserted_per_step": (acc["n_add"] + acc["n_nodown"]) / n,
+           "incremental_index_updates": info["n_incremental_updates"] - info0["n_incremental_updates"],
+           "full_index_rebuilds": info["n_full_rebuilds"] - info0["n_full_rebuilds"],
+           "vs_node_loop_world1": (1.0 / per_step) / node_loop_1["value"],
+           "latency": latency_summary(lat),
+           "how": f"one GPU, lio_debug_set replicate_loopback: {W - 1} virtual ranks park their lists (untimed), the timed rank "
+                  "runs its scan step + lio_replicate_step over all lists; no wire time"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +335,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the contract loop (no resident / replay / node-loop figures)")
     ap.add_argument("--map-update", action="store_true", help="(kept for compatibility: the node loop is always reported)")
+    ap.add_argument("--emulate-world", type=int, default=8,
+                    help="N = 1 only: also time this rank's node loop with the insert lists of W replicas applied (loop-back exchange; 0 = off)")
     a = ap.parse_args()
 
     rank, world_size, local, dist = dist_setup(a.gpus)
@@ -386,7 +481,8 @@ def main():
     rc = L.lio_scan_upload_async(ctx.h, h_p[0], nq)            # scan 0 is on its way before the loop starts
     if rc != 0:
         fail("first upload", rc)
-    elapsed = timed_steps(sampled(step_pipelined), a.steps, a.warmup, dist, device)
+    lat_value = []
+    elapsed = timed_steps(sampled(step_pipelined), a.steps, a.warmup, dist, device, lat_value)
     L.lio_scan_swap(ctx.h)                                     # consume the upload left in flight by the last step
     prof = ctx.profile()
     ctx.profile_enable(False)
@@ -427,7 +523,8 @@ def main():
         ctx.profile_enable(False)
         ctx.profile_reset()
         tick[0] = 0
-        t_node = timed_steps(sampled(step_node), k_node, 4, dist, device)
+        lat_node = []
+        t_node = timed_steps(sampled(step_node), k_node, 4, dist, device, lat_node)
         prof_node = ctx.profile()
         ctx.profile_enable(False)
         cold_ms = prof_node["knn27"]["total_ms"] / max(prof_node["knn27"]["launches"], 1) if prof_node["knn27"]["launches"] else None
@@ -436,7 +533,12 @@ def main():
                                "steps": k_node, "map_update_ms_per_step": maint["seconds"] / max(maint["steps"], 1) * 1e3,
                                "inserted_per_step": (maint["n_add"] + maint["n_nodown"]) / max(maint["steps"], 1),
                                "exchange": "lio_replicate_step: one ncclAllGather (RCCL over xGMI) on the library's stream" if dist is not None else "none (1 rank)",
-                               "incremental_index_updates": info["n_incremental_updates"], "full_index_rebuilds": info["n_full_rebuilds"]}
+                               "incremental_index_updates": info["n_incremental_updates"], "full_index_rebuilds": info["n_full_rebuilds"],
+                               "latency": latency_summary(lat_node)}
+        if dist is None and a.emulate_world > 1:
+            extras["node_loop_emulated_world%d" % a.emulate_world] = emulated_world_loop(
+                a.emulate_world, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, P0_p, ulog_ref, max(8, min(a.steps, 24)),
+                n_rot, step_resident, tick, device, extras["node_loop"])
     else:
         cold_ms = None
 
@@ -488,6 +590,7 @@ def main():
                    "parallelism": f"{world_size} independent scan stream(s), replicated map",
                    "lanes_per_query": a.lanes or "auto", "C_mean": cand_mean_per_scan / nq, "unresolved_queries": float(np.mean(unresolved)),
                    "pos_err_to_truth_m": pos_err},
+        "latency": latency_summary(lat_value),
         "knn_us_per_point": knn_ms * 1e3 / nq,
         "kernels_us": kernels_us,
         "roofline": {"bound": "hbm", "kernel": "knn27_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -11,6 +11,7 @@ but creating a LioContext needs a gfx950 GPU and raises LioError otherwise.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import importlib.util
 import os
 import sys
@@ -203,14 +204,13 @@ def pinned_points(xyz) -> np.ndarray:
     if not p:
         raise LioError("lio_host_alloc failed")
     buf = (C.c_float * (max(n, 1) * 4)).from_address(p)
+    # the ctypes array is the base object of every view numpy hands out: when the last view dies it dies, and the
+    # page-locked memory goes back (a per-scan caller would otherwise leak it for the life of the process)
+    weakref.finalize(buf, L.lio_host_free, p)
     arr = np.frombuffer(buf, np.float32).reshape(-1, 4)[:n]
     arr[:] = 0.0
     arr[:, :xyz.shape[1]] = xyz[:, :4]            # [n, 4] input: x, y, z, t records (a raw sweep)
-    _pinned_keepalive.append((arr, p))
     return arr
-
-
-_pinned_keepalive = []
 
 
 def replicate_unique_id() -> bytes:
@@ -512,6 +512,7 @@ class Esekf:
     def __init__(self, maximum_iter: int = 3, limit=None):
         self.L = load()
         self.h = _vp(self.L.lio_eskf_create())
+        self.maximum_iter = maximum_iter
         lim = np.full(23, 0.001) if limit is None else np.ascontiguousarray(limit, np.float64)   # laserMapping.cpp:2148
         rc = self.L.lio_eskf_init_dyn_share(self.h, maximum_iter, _ptr(lim))
         if rc != LIO_OK:

@@ -91,10 +91,11 @@ __global__ __launch_bounds__(256) void map_incremental_lists_kernel(IncrArgs a, 
     const bool ok = tile_exclusive_prefix<2>(mine, agg, stamp, before);
     if (ok && cls == 1) add_out[before[0] + r1] = wp;
     if (ok && cls == 2) nodown_out[before[1] + r2] = wp;
+    // a tile whose wait ran out has skipped its writes: EVERY such tile reports (the last tile's own wait may well succeed)
+    if (!ok && threadIdx.x == 0) atomicOr(err, 1u);
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         counts[0] = ok ? before[0] + tot1 : 0u;
         counts[1] = ok ? before[1] + tot2 : 0u;
-        if (!ok) atomicOr(err, 1u);
     }
 }
 hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, float4* nodown_out, uint32_t* counts, u64* agg,
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(256) void compact_live_kernel(const float4* src, ui
     uint32_t before[1];
     const bool ok = tile_exclusive_prefix<1>(mine, agg, stamp, before);
     if (ok && live) dst[before[0] + r] = p;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *n_out = ok ? before[0] + tot : 0u; if (!ok) atomicOr(err, 1u); }
+    if (!ok && threadIdx.x == 0) atomicOr(err, 1u);                 // every tile that skipped its writes reports
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = ok ? before[0] + tot : 0u;
 }
 hipError_t launch_compact_live(const float4* src, uint32_t n, float4* dst, uint32_t* n_out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s) {
     if (n == 0) return hipMemsetAsync(n_out, 0, sizeof(uint32_t), s);
@@ -137,7 +139,8 @@ __global__ __launch_bounds__(256) void compact_marked_kernel(const uint32_t* src
     uint32_t before[1];
     const bool ok = tile_exclusive_prefix<1>(mine, agg, stamp, before);
     if (ok && live) dst[before[0] + r] = v;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *n_out = ok ? before[0] + tot : 0u; if (!ok) atomicOr(err, 1u); }
+    if (!ok && threadIdx.x == 0) atomicOr(err, 1u);                 // every tile that skipped its writes reports
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = ok ? before[0] + tot : 0u;
 }
 hipError_t launch_compact_marked(const uint32_t* src, uint32_t n, uint32_t* dst, uint32_t* n_out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s) {
     if (n == 0) return hipMemsetAsync(n_out, 0, sizeof(uint32_t), s);
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(256) void run_heads_kernel(const uint64_t* keys, ui
         if (unique_out != nullptr) unique_out[before[0] + r] = k;
         starts_out[before[0] + r] = i;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { *n_runs_out = ok ? before[0] + tot : 0u; if (!ok) atomicOr(err, 1u); }
+    if (!ok && threadIdx.x == 0) atomicOr(err, 1u);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_runs_out = ok ? before[0] + tot : 0u;
 }
 __global__ __launch_bounds__(256) void run_counts_kernel(const uint32_t* starts, const uint32_t* n_runs, uint32_t n, uint32_t* counts_out,
                                                          const uint32_t* n_head, uint32_t n_after) {

@@ -161,6 +161,17 @@ struct lio_ctx {
     float4 *d_rep_send = nullptr, *d_rep_recv = nullptr;
     float rep_boxes[6 * REP_MAX_BOXES]{};      // delete boxes queued for the next exchange
     int rep_n_boxes = 0;
+    // loop-back test mode (lio_debug_set "replicate_loopback", then lio_replicate_init without an id): rep_world VIRTUAL
+    // ranks on this one GPU.  lio_replicate_step as virtual rank r < world - 1 ("replicate_loopback_rank") parks that
+    // rank's lists, counts and boxes; as rank world - 1 it packs every parked rank's message into its slot of the gathered
+    // buffer (what ncclAllGather would deliver) and goes on exactly like a real rank: compact, read-back, rank-ordered apply.
+    int dbg_rep_loopback = 0;
+    bool rep_loopback = false;
+    float4* d_rep_stage = nullptr;             // [world - 1][2][cap_q] parked lists
+    uint32_t* d_rep_stage_cnt = nullptr;       // [world - 1][2] their counts
+    float rep_stage_boxes[REP_MAX_BOXES_TOTAL / REP_MAX_BOXES][6 * REP_MAX_BOXES]{};
+    int rep_stage_nb[REP_MAX_BOXES_TOTAL / REP_MAX_BOXES]{};
+    unsigned rep_staged = 0;                   // bit r: virtual rank r has parked its lists for the next exchange
 
     // ---- profiling ----------------------------------------------------------------------------
     // one HIP-event pair per timed launch, stamped by the dispatch (hipExtLaunchKernelGGL); resolved when
@@ -1016,6 +1027,11 @@ int lio_map_add_pair(lio_ctx* c, const float* add_pts, int n_add, const float* n
     return rebuild_from_stored(c, add_counter);
 }
 
+// a bounded wait of map_incremental_lists_kernel ran out (d_counters[12] != 0): its counts are zero, its lists have holes
+static int list_kernel_failed(lio_ctx* c) {
+    (void)hipMemsetAsync(c->d_counters + 12, 0, sizeof(uint32_t), c->stream);
+    return c->fail(LIO_ERR_HIP, "map_incremental", "a bounded wait of the list compaction kernel ran out");
+}
 // map_incremental's classification + the two order-preserving lists, left on the device
 // (c->d_add_pts = PointToAdd, c->d_add_pts2 = PointNoNeedDownsample).
 static int map_incremental_lists(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
@@ -1042,14 +1058,20 @@ static int map_incremental_lists(lio_ctx* c, const double state14[14], double fi
     ia.flg_EKF_inited = flg_EKF_inited; ia.world = c->d_world; ia.cls = c->d_add_cls;
     if (compact_small(c, (size_t)nq)) {
         // classification + both lists + their counts in ONE launch (was: a classification kernel and two rocPRIM selects)
+        // (its error word is d_counters[12]: it travels with every read-back of the two counts, here and in the exchange)
         HIPCHK(c, launch_map_incremental_lists(ia, c->d_add_pts, c->d_add_pts2, c->d_counters + 5, c->d_cagg, next_compact_stamp(c),
-                                               c->d_apply + 15, s));
+                                               c->d_counters + 12, s));
     } else {
         HIPCHK(c, launch_map_incremental(ia, s));
         HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 1, c->d_add_pts, c->d_counters + 5, (size_t)nq, s));
         HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 2, c->d_add_pts2, c->d_counters + 6, (size_t)nq, s));
     }
-    if (cnts) HIPCHK(c, read_back(c, cnts, c->d_counters + 5, 2 * sizeof(uint32_t)));
+    if (cnts) {
+        uint32_t w[8] = {};                                     // [5..6] counts ... [12] the list kernel's error word
+        HIPCHK(c, read_back(c, w, c->d_counters + 5, sizeof(w)));
+        if (w[7] != 0u) return list_kernel_failed(c);
+        cnts[0] = w[0]; cnts[1] = w[1];
+    }
     return LIO_OK;
 }
 
@@ -1200,10 +1222,11 @@ int lio_replicate_unique_id(void* id128) {
 
 int lio_replicate_init(lio_ctx* c, const void* id128, int rank, int world, int list_capacity) {
     if (!c || world < 1 || rank < 0 || rank >= world || world * REP_MAX_BOXES > REP_MAX_BOXES_TOTAL || list_capacity < 0 ||
-        (world > 1 && !id128))
+        (world > 1 && !id128 && !c->dbg_rep_loopback))
         return LIO_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     lio_replicate_finalize(c);
+    const bool loopback = world > 1 && !id128;
     // points per list and rank in one message: a scan inserts a few thousand points (5-30 % of N_q in the reference's
     // runs); 32 Ki points = 1 MiB per rank and message keeps an 8-rank all-gather at ~8 MiB.  A rank with more points
     // is flagged, the exchange is repeated with the full scan capacity (lio_replicate_step does that itself).
@@ -1223,6 +1246,11 @@ int lio_replicate_init(lio_ctx* c, const void* id128, int rank, int world, int l
         const int e = r->CommInitRank(&c->rep_comm, world, id, rank);
         if (e != 0) return c->fail(LIO_ERR_HIP, "ncclCommInitRank", r->GetErrorString ? r->GetErrorString(e) : "failed");
     }
+    if (loopback) {
+        HIPCHK(c, hipMalloc((void**)&c->d_rep_stage, (size_t)(world - 1) * 2 * (size_t)c->cap_q * sizeof(float4)));
+        HIPCHK(c, hipMalloc((void**)&c->d_rep_stage_cnt, (size_t)(world - 1) * 2 * sizeof(uint32_t)));
+    }
+    c->rep_loopback = loopback; c->rep_staged = 0;
     c->rep_rank = rank; c->rep_world = world; c->rep_cap = cap; c->rep_n_boxes = 0;
     return LIO_OK;
 }
@@ -1236,8 +1264,10 @@ void lio_replicate_finalize(lio_ctx* c) {
     }
     if (c->d_rep_send) (void)hipFree(c->d_rep_send);
     if (c->d_rep_recv) (void)hipFree(c->d_rep_recv);
-    c->d_rep_send = nullptr; c->d_rep_recv = nullptr;
-    c->rep_world = 0; c->rep_n_boxes = 0;
+    if (c->d_rep_stage) (void)hipFree(c->d_rep_stage);
+    if (c->d_rep_stage_cnt) (void)hipFree(c->d_rep_stage_cnt);
+    c->d_rep_send = nullptr; c->d_rep_recv = nullptr; c->d_rep_stage = nullptr; c->d_rep_stage_cnt = nullptr;
+    c->rep_world = 0; c->rep_n_boxes = 0; c->rep_loopback = false; c->rep_staged = 0;
 }
 
 int lio_replicate_queue_boxes(lio_ctx* c, const float* minmax6, int nb) {
@@ -1257,9 +1287,21 @@ static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4]) {
     const size_t msg_f4 = (size_t)REP_HEADER_F4 + 2 * (size_t)cap;
     RepPackArgs pa{};
     pa.counts = c->d_counters + 5; pa.cap = cap; pa.add = c->d_add_pts; pa.nodown = c->d_add_pts2;
-    pa.msg = c->rep_comm ? c->d_rep_send : c->d_rep_recv;                     // no communicator: the message IS the gathered buffer
+    pa.msg = c->rep_comm ? c->d_rep_send : c->d_rep_recv + (size_t)c->rep_rank * msg_f4;   // no communicator: straight into this rank's slot of the gathered buffer
     std::memcpy(pa.boxes, c->rep_boxes, sizeof(pa.boxes)); pa.n_boxes = c->rep_n_boxes;
     HIPCHK(c, launch_replicate_pack(pa, s));
+    if (c->rep_loopback) {
+        // the messages of the parked virtual ranks, by the same kernel from their parked lists and counts
+        for (int r = 0; r + 1 < c->rep_world; ++r) {
+            if (!(c->rep_staged & (1u << r))) return c->fail(LIO_ERR_INVALID_ARG, "lio_replicate_step", "loop-back: a virtual rank has not parked its lists");
+            RepPackArgs pr{};
+            pr.counts = c->d_rep_stage_cnt + 2 * (size_t)r; pr.cap = cap;
+            pr.add = c->d_rep_stage + (size_t)(2 * r) * (size_t)c->cap_q; pr.nodown = c->d_rep_stage + (size_t)(2 * r + 1) * (size_t)c->cap_q;
+            pr.msg = c->d_rep_recv + (size_t)r * msg_f4;
+            std::memcpy(pr.boxes, c->rep_stage_boxes[r], sizeof(pr.boxes)); pr.n_boxes = c->rep_stage_nb[r];
+            HIPCHK(c, launch_replicate_pack(pr, s));
+        }
+    }
     if (c->rep_comm) {
         RcclApi* r = rccl_api(nullptr);
         const int e = r->AllGather(c->d_rep_send, c->d_rep_recv, msg_f4 * 4, RCCL_FLOAT32, c->rep_comm, s);
@@ -1269,7 +1311,10 @@ static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4]) {
     ca.gathered = c->d_rep_recv; ca.world = c->rep_world; ca.cap = cap; ca.add_out = c->d_add_pts; ca.nodown_out = c->d_add_pts2;
     ca.boxes_out = c->d_boxes; ca.totals = c->d_counters + 8;
     HIPCHK(c, launch_replicate_compact(ca, s));
-    HIPCHK(c, read_back(c, tot, c->d_counters + 8, 4 * sizeof(uint32_t)));
+    uint32_t w[5] = {};                                         // the four totals and the list kernel's error word
+    HIPCHK(c, read_back(c, w, c->d_counters + 8, sizeof(w)));
+    if (w[4] != 0u) return list_kernel_failed(c);
+    std::memcpy(tot, w, 4 * sizeof(uint32_t));
     return LIO_OK;
 }
 
@@ -1285,6 +1330,18 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
     // map_incremental's two lists of this rank stay on the device, and so do their counts
     int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, nullptr);
     if (rc != LIO_OK) return rc;
+    if (c->rep_loopback && c->rep_rank + 1 < c->rep_world) {
+        // loop-back: this call speaks for a virtual rank other than the last one -- park what it would have sent
+        const int r = c->rep_rank;
+        HIPCHK(c, launch_replicate_stage(c->d_counters + 5, c->d_add_pts, c->d_add_pts2, (uint32_t)c->cap_q,
+                                         c->d_rep_stage + (size_t)(2 * r) * (size_t)c->cap_q, c->d_rep_stage + (size_t)(2 * r + 1) * (size_t)c->cap_q,
+                                         c->d_rep_stage_cnt + 2 * (size_t)r, c->stream));
+        std::memcpy(c->rep_stage_boxes[r], c->rep_boxes, sizeof(c->rep_boxes));
+        c->rep_stage_nb[r] = c->rep_n_boxes;
+        c->rep_n_boxes = 0;
+        c->rep_staged |= 1u << r;
+        return LIO_OK;
+    }
     uint32_t tot[4] = {0, 0, 0, 0};
     rc = replicate_exchange_apply(c, c->rep_cap, tot);
     if (rc != LIO_OK) return rc;
@@ -1298,6 +1355,7 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
         if (rc != LIO_OK) return rc;
     }
     c->rep_n_boxes = 0;
+    c->rep_staged = 0;
     if ((size_t)c->n_live + (size_t)tot[0] + (size_t)tot[1] > c->cap_map)
         return c->fail(LIO_ERR_CAPACITY, "lio_replicate_step", "live points + gathered lists exceed max_map_points");
     // every replica: the boxes of all ranks (rank order), then the insert lists of all ranks (rank order)
@@ -1332,8 +1390,18 @@ int lio_map_set_downsample_param(lio_ctx* c, float downsample_size) {
     c->cfg.filter_size_map_min = downsample_size;
     return LIO_OK;
 }
-long long lio_map_size(lio_ctx* c) { return c ? (long long)c->n_points - (long long)c->n_retired : 0; }
-long long lio_map_validnum(lio_ctx* c) { return c ? (long long)c->n_live : 0; }
+// (a call that failed between a down-sampled Add_Points and its index update may have left the counts of that batch on
+// the device: n_live / n_pend are upper bounds until they are fetched)
+long long lio_map_size(lio_ctx* c) {
+    if (!c) return 0;
+    if (c->pend_lazy && hipSetDevice(c->device) == hipSuccess) (void)resolve_lazy_pending(c);
+    return (long long)c->n_points - (long long)c->n_retired;
+}
+long long lio_map_validnum(lio_ctx* c) {
+    if (!c) return 0;
+    if (c->pend_lazy && hipSetDevice(c->device) == hipSuccess) (void)resolve_lazy_pending(c);
+    return (long long)c->n_live;
+}
 
 // Delete_by_range over the boxes already sitting in c->d_boxes (<= 64)
 static int delete_boxes_resident(lio_ctx* c, int nbb, int* total) {
@@ -1355,6 +1423,10 @@ int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_delete
     if (nb == 0 || c->n_points == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
     c->hint_valid = false;
+    {
+        const int rc = resolve_lazy_pending(c);
+        if (rc != LIO_OK) return rc;
+    }
     int total = 0;
     for (int b0 = 0; b0 < nb; b0 += 64) {
         const int nbb = nb - b0 < 64 ? nb - b0 : 64;
@@ -1998,6 +2070,12 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "library_sort") == 0) { c->dbg_library_sort = value != 0; return LIO_OK; }
     if (std::strcmp(key, "stamps") == 0) { c->dbg_stamps = value != 0; return LIO_OK; }
     if (std::strcmp(key, "knn_tune") == 0) { c->dbg_knn_tune = (int)value; return LIO_OK; }
+    if (std::strcmp(key, "replicate_loopback") == 0) { c->dbg_rep_loopback = value != 0; return LIO_OK; }
+    if (std::strcmp(key, "replicate_loopback_rank") == 0) {
+        if (!c->rep_loopback || value < 0 || value >= c->rep_world) return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "replicate_loopback_rank outside a loop-back world");
+        c->rep_rank = (int)value;
+        return LIO_OK;
+    }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "unknown key");
 }
 int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {

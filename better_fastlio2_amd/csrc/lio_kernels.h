@@ -96,7 +96,8 @@ struct ResidualArgs {
     double*        spec_rows;       // [max_scan_points][SPEC_STRIDE]: staged row of a listed query (written through)
 };
 constexpr int FIX_MAX = 256;                 // listed queries up to which the last workgroup adds the listed queries' rows
-constexpr int SPEC_STRIDE = 20;              // doubles per parked query: staged row (<= 15), then n^ | d | pd2 | sel as 3 x 2 floats at [16..18]
+constexpr int SPEC_STRIDE = 32;              // doubles per parked query (256 bytes: no two queries share a cache line): staged row (<= 15),
+constexpr int SPEC_USED = 19;                //   then n^ | d | pd2 | sel as 3 x 2 floats at [16..18]
 int residual_blocks(int nq);
 int residual_walkers(int nq);       // walking workgroups a search pass adds in front of the model workgroups
 hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s, KernelTimer t = KernelTimer());
@@ -150,6 +151,9 @@ struct RepCompactArgs {
 };
 hipError_t launch_replicate_pack(const RepPackArgs& a, hipStream_t s);
 hipError_t launch_replicate_compact(const RepCompactArgs& a, hipStream_t s);
+// loop-back test mode: park the lists (<= cap points each) and the two counts of one virtual rank
+hipError_t launch_replicate_stage(const uint32_t* counts, const float4* add, const float4* nodown, uint32_t cap, float4* stage_add,
+                                  float4* stage_nodown, uint32_t* stage_counts, hipStream_t s);
 
 // ---- rocPRIM-backed helpers (lio_sort.hip) ------------------------------------------------------
 size_t sort_pairs_temp_bytes(size_t n);

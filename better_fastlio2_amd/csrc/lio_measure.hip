@@ -228,6 +228,10 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         __hip_atomic_store(dst + 16, pack2(nx, ny), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(dst + 17, pack2(nz, plane_d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(dst + 18, pack2(pd2, sel ? 1.0f : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The last workgroup orders itself against this owner only through the stamped partial sums the OTHER lanes of
+        // this workgroup publish after the barriers below -- and a workgroup barrier does not drain vmcnt: the parked
+        // row has to be in memory before this wavefront reaches the barrier (the walkers drain the same way)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... the outputs of the query are written by the last workgroup, and this workgroup's sums do not contain it
 #pragma unroll
         for (int c = 0; c < 12; ++c) row[c] = 0.0;
@@ -390,14 +394,14 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
                 // (the per-entry verdict is only fetched when some walk of this pass changed a result at all)
                 const unsigned long long verdict = s_any_changed == 0u ? 0ull :
                     __hip_atomic_load(a.tree.useeds + (size_t)tid * 8u + 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // the parked row was written THROUGH by its owner before that owner's partial sums (folded above) and
-                // neither this CU's L1 nor this XCD's L2 has seen these lines in this launch: plain 16-byte loads
-                unsigned long long raw[SPEC_STRIDE];
-                {
-                    const ulonglong2* src2 = reinterpret_cast<const ulonglong2*>(src);
+                // the parked row was written THROUGH by its owner (and drained) before that owner's workgroup published the
+                // partial sums folded above; it is read past the caches (agent-scope loads, all in flight together): an
+                // owner on this XCD may have pulled a neighbouring row's line into this L2 earlier in the launch.  Rows
+                // are 256 bytes apart (SPEC_STRIDE), so no two queries share a cache line.
+                unsigned long long raw[SPEC_USED];
 #pragma unroll
-                    for (int c = 0; c < SPEC_STRIDE / 2; ++c) { const ulonglong2 v = src2[c]; raw[2 * c] = v.x; raw[2 * c + 1] = v.y; }
-                }
+                for (int c = 0; c < SPEC_USED; ++c)
+                    raw[c] = (c < S::NCOLS || c >= 16) ? __hip_atomic_load(src + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                 const unsigned long long p0 = raw[16], p1 = raw[17], p2 = raw[18];
                 // rank among the listed queries = position of the row (while the loads are in flight): 16-byte LDS reads,
                 // eight keys per iteration (lanes beyond n hold 0xffffffff, never smaller than a query number)

@@ -67,6 +67,26 @@ __global__ __launch_bounds__(256) void replicate_compact_kernel(RepCompactArgs a
     }
 }
 
+// loop-back test mode (lio_debug_set "replicate_loopback"): the lists and counts of one VIRTUAL rank are parked so that
+// several of them can later be packed into the message slots of one gathered buffer (what ncclAllGather delivers)
+__global__ __launch_bounds__(256) void replicate_stage_kernel(const uint32_t* counts, const float4* add, const float4* nodown, uint32_t cap,
+                                                              float4* stage_add, float4* stage_nodown, uint32_t* stage_counts) {
+    const uint32_t n_add = min(counts[0], cap), n_nd = min(counts[1], cap);
+    if (blockIdx.x == 0 && threadIdx.x < 2) stage_counts[threadIdx.x] = counts[threadIdx.x];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
+        if (i < n_add) stage_add[i] = add[i];
+        if (i < n_nd) stage_nodown[i] = nodown[i];
+    }
+}
+hipError_t launch_replicate_stage(const uint32_t* counts, const float4* add, const float4* nodown, uint32_t cap, float4* stage_add,
+                                  float4* stage_nodown, uint32_t* stage_counts, hipStream_t s) {
+    uint32_t blocks = (cap + 255u) / 256u;
+    if (blocks > 1024u) blocks = 1024u;
+    if (blocks == 0u) blocks = 1u;
+    hipLaunchKernelGGL(replicate_stage_kernel, dim3(blocks), dim3(256), 0, s, counts, add, nodown, cap, stage_add, stage_nodown, stage_counts);
+    return hipGetLastError();
+}
+
 hipError_t launch_replicate_pack(const RepPackArgs& a, hipStream_t s) {
     uint32_t blocks = (a.cap + 255u) / 256u;
     if (blocks > 1024u) blocks = 1024u;

@@ -275,7 +275,11 @@ int  lio_profile_reset(lio_ctx* ctx);
  * its own launch (knn_tree_kernel) instead of inside the measurement kernel (an A/B switch for timing; identical
 results); "library_sort" sends every sort / compaction of map maintenance and scan preparation to rocPRIM
  * instead of the single-launch kernels of lio_compact.hip (identical results); "stamps" makes the last workgroup of a measurement kernel take the time stamps lio_debug_stamps returns
- * (they perturb what they measure: ~0.5 us each).  Unknown key: LIO_ERR_INVALID_ARG.                                                                */
+ * (they perturb what they measure: ~0.5 us each); "replicate_loopback" (before lio_replicate_init with id128 == NULL and
+ * world > 1) runs the replica exchange with `world` VIRTUAL ranks on this one GPU: lio_replicate_step as virtual rank
+ * r < world - 1 ("replicate_loopback_rank" = r) parks that rank's lists and boxes, as rank world - 1 it packs every rank's
+ * message into its slot of the gathered buffer -- the place of ncclAllGather -- and goes on like a real rank (compaction
+ * in rank order, overflow repeat, Delete_Point_Boxes + the Add_Points pair).  Unknown key: LIO_ERR_INVALID_ARG.       */
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
 /* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: its start, own partial
  * published, group folded, grid folded, walk awaited, rows ordered, rows added, record written (diagnostics)  */

@@ -1,0 +1,47 @@
+# Round-3 GPU visit: -m gpu tests, the driver's bench command, and a kernel time line of one emulated-world step.
+#   gpurun --timeout 1200 -- 'bash scripts/r03_check.sh r03a [pytest-args]'
+tag=${1:-r03x}
+shift
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
+cd $R
+(time timeout 900 python -m pytest tests -m gpu -x -q "$@") > $O/pytest_gpu.log 2>&1
+grep -a -E "passed|failed|error" $O/pytest_gpu.log | tail -3
+grep -a -E "^(FAILED|ERROR)|Error|assert" $O/pytest_gpu.log | head -20
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+python - <<PY
+import json
+d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1])
+print('value', round(d['value'],1), 'ms/step', round(d['ms_per_step'],4), {k: round(v['value'],1) for k,v in d.items() if isinstance(v,dict) and 'value' in v and k!='cpu_baseline'})
+print('latency', d.get('latency'))
+print('kernels_us', {k: round(v,2) for k,v in d['kernels_us'].items()})
+print('roofline', [(x['kernel'][:40], round(x['avg_launch_us'],2), round(x['frac'],3)) for x in d['roofline_detail']])
+print('node_loop', {k: v for k, v in d['node_loop'].items()})
+for k in d:
+    if k.startswith('node_loop_emulated'): print(k, d[k])
+print('parity', {k: v for k, v in d.get('parity',{}).items() if k != 'neighbors_bit_exact'})
+PY
+cd /tmp && export TMPDIR=/tmp
+timeout 500 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $O/trace_bench.log 2> $O/trace_bench.err
+python - <<PY
+import csv, glob
+f = glob.glob('$O/trace/**/*kernel_trace.csv', recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+names = [r['Kernel_Name'] for r in rows]
+idx = [i for i, n in enumerate(names) if 'replicate_compact_kernel' in n]
+# one timed segment of the emulated world: from the timed rank's first k-NN launch before the last compact to the end of that apply
+b = idx[-1]
+a = b
+while a > 0 and 'replicate_stage_kernel' not in names[a]: a -= 1
+e = b
+while e + 1 < len(rows) and 'knn27' not in names[e + 1]: e += 1
+t0 = int(rows[a]['Start_Timestamp']); prev_end = t0
+out = open('$O/emulated_timeline.txt', 'w')
+for r in rows[a:e + 1]:
+    s, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    line = '%9.1f us  +gap %6.1f  dur %6.1f  %s' % ((s - t0) / 1e3, (s - prev_end) / 1e3, (en - s) / 1e3, r['Kernel_Name'][:100])
+    out.write(line + '\n'); prev_end = en
+out.close()
+print(open('$O/emulated_timeline.txt').read()[-6000:])
+PY
+rm -rf $O/trace

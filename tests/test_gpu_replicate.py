@@ -76,6 +76,81 @@ def test_exchange_equals_local_map_incremental(gpu_capi, oracle, synth, small_ca
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("W", [2, 4, 8])
+def test_loopback_world(gpu_capi, oracle, synth, small_case, W):
+    """The C-ABI exchange with world > 1 on ONE GPU (lio_debug_set "replicate_loopback"): W virtual ranks, each with its own
+    scan stream, park their lists; the last one packs every rank's message into its slot of the gathered buffer (the
+    place of ncclAllGather) and runs what a real rank runs -- replicate_pack_kernel per rank, replicate_compact_kernel's
+    cross-rank offsets, the overflow repeat, the rank-ordered Delete_Point_Boxes + Add_Points pair.  A delete box comes
+    from a middle rank, exactly one rank overflows its message in round 0.  Checked after every round against a twin
+    context that applies the rank-ordered lists through lio_map_add_pair and against the reference ikd-Tree
+    (ikd_Tree.cpp:414-489; lists laserMapping.cpp:1442-1493; boxes :1183-1198)."""
+    w = small_case["world"]
+    thin = np.ascontiguousarray(w.points[::2])
+    nq_small, nq_big = 1500, 6000
+    big_rank = W // 2                                        # the rank whose lists overflow a message in round 0
+    box_rank = max(0, W // 2 - 1) if W > 2 else 1
+    a = gpu_capi.LioContext(0.2, max_scan_points=nq_big, max_map_points=400_000)     # loop-back exchange
+    b = gpu_capi.LioContext(0.2, max_scan_points=nq_big, max_map_points=400_000)     # twin: plain calls
+    a.map_build(thin); b.map_build(thin)
+    ref = oracle.RefIkdTree(0.2) if oracle.ref_available() else None
+    if ref is not None:
+        ref.build(thin)
+    a.debug_set("replicate_loopback", 1)
+    kfa, kfb = gpu_capi.Esekf(3), gpu_capi.Esekf(3)
+    for k in range(3):
+        posts, lists, boxes_all = [], [], []
+        # every virtual rank's scan step on the twin first: its own lists (apply = False: the map only changes at the exchange)
+        for r in range(W):
+            n = nq_big if r == big_rank else nq_small
+            sc = synth.make_scan(w, n, seed=synth.SEED + 31 + 17 * k + 1000 * r, pos=(2.0 + 0.9 * k + 5.0 * r, -1.5 + 0.4 * k - 3.0 * r, 0.0),
+                                 rpy=(0.004, -0.006, 0.3 + 0.05 * k + 0.7 * r))
+            ps, rt = synth.perturb_state(sc, dpos=0.05, drot_deg=0.3, seed=synth.SEED + 5 + k + r)
+            x0 = gpu_capi.make_state26(ps, rt, sc.off_R, sc.off_T)
+            kfb.change_x(x0); kfb.change_P(synth.init_cov())
+            b.scan_set(sc.body)
+            kfb.update_iterated_dyn_share_modified(b, 0.001, False)
+            post = kfb.get_x()[:14].copy()
+            posts.append((sc, x0, post))
+            lists.append(b.map_incremental(post, 0.2, True, apply=False, want_lists=True))
+        if k == 0:
+            # a message capacity only the big rank's lists exceed
+            sizes = sorted(max(l["n_add"], l["n_nodown"]) for l in lists)
+            biggest = max(lists[big_rank]["n_add"], lists[big_rank]["n_nodown"])
+            assert biggest == sizes[-1] and sizes[-1] > sizes[-2] + 1
+            a.replicate_init(b"", W - 1, W, (sizes[-1] + sizes[-2]) // 2)
+        for r in range(W):
+            sc, x0, post = posts[r]
+            kfa.change_x(x0); kfa.change_P(synth.init_cov())
+            a.scan_set(sc.body)
+            kfa.update_iterated_dyn_share_modified(a, 0.001, False)
+            assert np.array_equal(kfa.get_x()[:14], post)
+            a.debug_set("replicate_loopback_rank", r)
+            if r == box_rank and k >= 1:
+                bx = np.array([[-30.0 + 2 * k, -30.0, -1.0, -27.0 + 2 * k, 30.0, 5.0]], np.float32)
+                a.replicate_queue_boxes(bx)
+                boxes_all.append(bx)
+            ra = a.replicate_step(post, 0.2, True)
+            if r + 1 < W:
+                assert (ra["n_add"], ra["n_nodown"]) == (0, 0)           # parked, nothing exchanged yet
+        add = np.concatenate([l["add"] for l in lists]); nodown = np.concatenate([l["nodown"] for l in lists])
+        assert (ra["n_add"], ra["n_nodown"]) == (len(add), len(nodown))
+        nd_b = b.map_delete_boxes(np.concatenate(boxes_all)) if boxes_all else 0
+        cnt_b = b.map_add_pair(add, nodown)
+        assert (ra["n_deleted"], ra["add_counter"]) == (nd_b, cnt_b)
+        assert a.map_validnum() == b.map_validnum()
+        assert bits_equal(_key(a.map_flatten()), _key(b.map_flatten()))
+        if ref is not None:
+            if boxes_all:
+                assert ref.delete_boxes(np.concatenate(boxes_all)) == nd_b
+            assert ref.add(add, True) == cnt_b
+            ref.add(nodown, False)
+            assert ref.validnum() == a.map_validnum()
+            ref.quiesce(50)
+            assert bits_equal(_key(a.map_flatten()), _key(ref.flatten()))
+    a.close(); b.close()
+
+
 _WORKER = r"""
 import os, sys, numpy as np
 sys.path.insert(0, sys.argv[1])
