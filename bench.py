@@ -231,10 +231,13 @@ def cpu_baseline(world_pts, scan, x0, P0, max_iter: int, ext: bool, sample_every
             parity_nbr["decision_flip_audit"] = {
                 "plane_inlier_0.1m_margin_lt_1e-5": int((mp < 1e-5).sum()), "s_gt_0.9_margin_lt_1e-5": int((ms < 1e-5).sum()),
                 "min_plane_margin_m": float(np.nanmin(mp)), "min_s_margin": float(np.nanmin(ms))}
+        # what "parity unpinned" can cost on this very scan step: Eigen's packet orders / random orders inside esti_plane
+        sens = po.eigen_order_sensitivity(om, x0, P0, body, max_iter, ext, knn_method=method) if sample_every == 1 else None
         po.use_reference_knn(None)
         del tree
     else:
         _, _, _, secs = om.knn(wq, 5, 1)
+        sens = None
     t_step = float(np.median(ts)) * sample_every
     out = {"value": 1.0 / t_step, "unit": "scans/s", "cores": 1, "kind": "port",
            "knn": "reference ikd-Tree (oracle/_ref, verbatim)" if use_ref else "oracle kd-tree restatement",
@@ -242,7 +245,8 @@ def cpu_baseline(world_pts, scan, x0, P0, max_iter: int, ext: bool, sample_every
            "sample": (f"the whole scan ({len(body)} points)" if sample_every == 1 else
                       f"every {sample_every}th point of the scan ({len(body)} of {len(scan.body)}), scaled x{sample_every},")
                      + f" vs the full {len(world_pts)}-point map, {len(log)} passes, median of 5; tree build {t_build:.1f}s untimed",
-           "passes": int(len(log)), "host": host_description(), "posterior": xo, "neighbors": parity_nbr}
+           "passes": int(len(log)), "host": host_description(), "posterior": xo, "neighbors": parity_nbr,
+           "eigen_order_sensitivity": sens}
     if t3 is not None:
         out["three_threads"] = {"value": 1.0 / t3, "unit": "scans/s", "cores": 3,
                                 "how": "3 threads, each a third of the scan through the same pass sequence (the per-point OMP loop "
@@ -619,13 +623,17 @@ def main():
         # the GPU's (bar: 1e-4 m / 1e-5 rad)
         x_cpu = cb.pop("posterior")
         nbr = cb.pop("neighbors")
+        sens = cb.pop("eigen_order_sensitivity")
         if cb["sample"].startswith("the whole scan"):
             q1, q2 = x_gpu[3:7], x_cpu[3:7]
             out["parity"] = {"pos_diff_m": float(np.linalg.norm(x_gpu[:3] - x_cpu[:3])),
                              "rot_diff_rad": float(4.0 * np.arcsin(min(1.0, 0.5 * min(np.linalg.norm(q1 - q2), np.linalg.norm(q1 + q2))))),
                              "state_max_abs_diff": float(np.max(np.abs(x_gpu - x_cpu))),
                              "against": "oracle h_share_model + IKFoM update on the reference ikd-Tree, same prior, same scan",
-                             "neighbors_bit_exact": nbr}
+                             "neighbors_bit_exact": nbr,
+                             # the model half is pinned on a restatement of Eigen (no Eigen in this image): how far the
+                             # reference's own build could be from it -- every reduction of esti_plane's QR re-ordered
+                             "eigen_order_sensitivity": sens}
         out["cpu_baseline"] = cb
     print(json.dumps(out), flush=True)
     if dist is not None:

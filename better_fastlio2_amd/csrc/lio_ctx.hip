@@ -1237,7 +1237,7 @@ int lio_replicate_init(lio_ctx* c, const void* id128, int rank, int world, int l
     HIPCHK(c, hipMalloc((void**)&c->d_rep_recv, msg_f4 * (size_t)world * sizeof(float4)));
     int rc = ensure_add_buffers(c, (size_t)world * (size_t)c->cap_q);
     if (rc != LIO_OK) return rc;
-    if (world > 1 || id128 != nullptr) {              // (a single rank WITH an id runs the same collective: tests)
+    if (!loopback && (world > 1 || id128 != nullptr)) {   // (a single rank WITH an id runs the same collective: tests)
         std::string why;
         RcclApi* r = rccl_api(&why);
         if (!r) return c->fail(LIO_ERR_HIP, "lio_replicate_init", why.c_str());

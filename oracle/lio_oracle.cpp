@@ -270,6 +270,50 @@ inline bool same_point(P3 a, P3 b) {                       // ikd_Tree.cpp:1365-
 //  esti_plane<float>  (include/common_lib.h:506-536) on Eigen 3.3.7's
 //  ColPivHouseholderQR<Matrix<float,5,3>>::computeInPlace + _solve_impl, fp32 throughout
 // =====================================================================================
+// ---- summation order of the reductions inside Eigen's QR (TEST SWITCH, orc_set_sum_order) ------------------------
+// "Parity unpinned" in numbers: every squaredNorm() / dot product of ColPivHouseholderQR runs through Eigen's redux,
+// whose association depends on how the reference was built.  Un-vectorised (EIGEN_DONT_VECTORIZE, or a block the
+// packet path rejects) it is the sequential sum restated here (mode 0).  Vectorised with SSE2 (x86-64 default,
+// CMakeLists.txt sets no -m flags) a 4-float packet is reduced as (a0 + a2) + (a1 + a3) and the scalar tail is added
+// afterwards (mode 1); with -msse3 and later the packet is reduced by hadd, (a0 + a1) + (a2 + a3) (mode 2); where the
+// packet starts depends on the alignment of the 60-byte matrix on the stack, which no source fixes: mode 3 draws, per
+// reduction, a random permutation and a random association (seeded, reproducible) and so bounds every such variant.
+// The modes change NOTHING but the order in which the same fp32 terms are added.
+static int g_sum_mode = 0;
+static uint64_t g_sum_rng = 0x9e3779b97f4a7c15ull;
+static inline uint32_t sum_rand() {                        // xorshift64*
+    g_sum_rng ^= g_sum_rng >> 12; g_sum_rng ^= g_sum_rng << 25; g_sum_rng ^= g_sum_rng >> 27;
+    return (uint32_t)((g_sum_rng * 0x2545F4914F6CDD1Dull) >> 32);
+}
+static float sum_terms(const float* t, int n) {
+    if (n <= 0) return 0.0f;
+    if (g_sum_mode == 0 || n < 3) {                        // sequential (two terms have one order)
+        float s = t[0];
+        for (int i = 1; i < n; ++i) s += t[i];
+        return s;
+    }
+    if (g_sum_mode == 1 || g_sum_mode == 2) {
+        if (n == 3) return t[0] + (t[1] + t[2]);           // Eigen's unrolled scalar redux of a fixed 3-vector splits 1 | 2
+        float s = g_sum_mode == 1 ? (t[0] + t[2]) + (t[1] + t[3]) : (t[0] + t[1]) + (t[2] + t[3]);
+        for (int i = 4; i < n; ++i) s += t[i];
+        return s;
+    }
+    // random permutation, random association: repeatedly add two randomly chosen partial sums
+    float v[8];
+    for (int i = 0; i < n; ++i) v[i] = t[i];
+    int m = n;
+    while (m > 1) {
+        const int i = (int)(sum_rand() % (uint32_t)m);
+        int j = (int)(sum_rand() % (uint32_t)(m - 1));
+        if (j >= i) ++j;
+        const float sij = v[i] + v[j];
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        v[lo] = sij; v[hi] = v[m - 1];
+        --m;
+    }
+    return v[0];
+}
+
 bool esti_plane_f(float pabcd[4], const P3 pt[5], float threshold) {
     const int rows = 5, cols = 3;
     float A[5][3];
@@ -280,9 +324,9 @@ bool esti_plane_f(float pabcd[4], const P3 pt[5], float threshold) {
     int trans[3] = {0, 1, 2};
     float cnu[3], cnd[3];                                  // m_colNormsUpdated / m_colNormsDirect
     auto colnorm = [&](int c, int r0) {
-        float s = 0.0f;
-        for (int r = r0; r < rows; ++r) s += A[r][c] * A[r][c];
-        return std::sqrt(s);
+        float t[5]; int n = 0;
+        for (int r = r0; r < rows; ++r) t[n++] = A[r][c] * A[r][c];
+        return std::sqrt(sum_terms(t, n));
     };
     for (int k = 0; k < cols; ++k) { cnd[k] = colnorm(k, 0); cnu[k] = cnd[k]; }
     const float eps = std::numeric_limits<float>::epsilon();
@@ -303,8 +347,12 @@ bool esti_plane_f(float pabcd[4], const P3 pt[5], float threshold) {
             std::swap(cnd[k], cnd[big]);
         }
         // makeHouseholderInPlace on A[k:,k]
-        float tailSq = 0.0f;
-        for (int r = k + 1; r < rows; ++r) tailSq += A[r][k] * A[r][k];
+        float tailSq;
+        {
+            float t[5]; int n = 0;
+            for (int r = k + 1; r < rows; ++r) t[n++] = A[r][k] * A[r][k];
+            tailSq = sum_terms(t, n);
+        }
         float c0 = A[k][k];
         float beta, tau;
         const float tol = std::numeric_limits<float>::min();
@@ -325,8 +373,9 @@ bool esti_plane_f(float pabcd[4], const P3 pt[5], float threshold) {
             for (int j = k + 1; j < cols; ++j) A[k][j] *= (1.0f - tau);
         } else if (tau != 0.0f) {
             for (int j = k + 1; j < cols; ++j) {
-                float tmp = 0.0f;
-                for (int r = k + 1; r < rows; ++r) tmp += A[r][k] * A[r][j];
+                float t[5]; int n = 0;
+                for (int r = k + 1; r < rows; ++r) t[n++] = A[r][k] * A[r][j];
+                float tmp = sum_terms(t, n);
                 tmp += A[k][j];
                 A[k][j] -= tau * tmp;
                 for (int r = k + 1; r < rows; ++r) A[r][j] -= (tau * A[r][k]) * tmp;
@@ -362,8 +411,9 @@ bool esti_plane_f(float pabcd[4], const P3 pt[5], float threshold) {
             float tau = hc[k];
             if (rows - k == 1) { c[k] *= (1.0f - tau); continue; }
             if (tau != 0.0f) {
-                float tmp = 0.0f;
-                for (int r = k + 1; r < rows; ++r) tmp += A[r][k] * c[r];
+                float t[5]; int n = 0;
+                for (int r = k + 1; r < rows; ++r) t[n++] = A[r][k] * c[r];
+                float tmp = sum_terms(t, n);
                 tmp += c[k];
                 c[k] -= tau * tmp;
                 for (int r = k + 1; r < rows; ++r) c[r] -= (tau * A[r][k]) * tmp;
@@ -377,7 +427,11 @@ bool esti_plane_f(float pabcd[4], const P3 pt[5], float threshold) {
         for (int i = 0; i < nonzero_pivots; ++i) nv[perm[i]] = c[i];
         for (int i = nonzero_pivots; i < cols; ++i) nv[perm[i]] = 0.0f;
     }
-    float n = std::sqrt((nv[0] * nv[0] + nv[1] * nv[1]) + nv[2] * nv[2]);    // common_lib.h:522
+    float n;                                                                 // normvec.norm(), common_lib.h:522
+    {
+        const float t[3] = {nv[0] * nv[0], nv[1] * nv[1], nv[2] * nv[2]};
+        n = std::sqrt(sum_terms(t, 3));
+    }
     pabcd[0] = nv[0] / n; pabcd[1] = nv[1] / n; pabcd[2] = nv[2] / n;
     pabcd[3] = (float)(1.0 / (double)n);                                     // `1.0 / n` :526
     for (int j = 0; j < rows; ++j) {
@@ -717,6 +771,14 @@ double orc_map_knn(void* mp, const float* q, int nq, int k, float* out_xyz, floa
         }
     }
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// test switch: summation order of every reduction inside esti_plane (see sum_terms).  0 = sequential (the order the GPU
+// path is bit-equal to), 1 = SSE2 packet order, 2 = SSE3 hadd order, 3 = random permutation + association from `seed`
+void orc_set_sum_order(int mode, unsigned long long seed) {
+    g_sum_mode = mode;
+    g_sum_rng = seed * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull;
+    if (g_sum_rng == 0) g_sum_rng = 1;
 }
 
 int orc_esti_plane(const float* p, float threshold, float* pabcd) {

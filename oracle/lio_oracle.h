@@ -45,6 +45,11 @@ void   orc_set_external_knn(void* fn, void* handle);
 /* ---- measurement model ------------------------------------------------------------------------ */
 /* esti_plane<float> (include/common_lib.h:506-536); pts = 5 x (x,y,z); returns 1 if plane ok. */
 int    orc_esti_plane(const float* pts5x3, float threshold, float* pabcd);
+/* TEST SWITCH -- how much can "parity unpinned" matter?  Order in which the reductions (squaredNorm / dot) inside the
+ * QR of esti_plane add their fp32 terms: 0 sequential (default; what the GPU path is bit-equal to), 1 Eigen's SSE2
+ * packet order (a0+a2)+(a1+a3)+tail, 2 its SSE3 hadd order (a0+a1)+(a2+a3)+tail, 3 a random permutation and association
+ * per reduction (seeded).  Not thread-safe: set it while no other thread runs the model. */
+void   orc_set_sum_order(int mode, unsigned long long seed);
 /* decision-flip audit: distance of the fp32 plane-inlier (0.1 m) and weight (s > 0.9) decisions to their thresholds */
 void   orc_decision_margins(const float* nbr_xyz, const float* nbr_d, const int* nbr_cnt, const float* world_xyz,
                             const float* body_xyz, int n, float* margin_plane, float* margin_s);

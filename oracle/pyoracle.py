@@ -54,6 +54,7 @@ def lib():
         L.orc_map_flatten.argtypes = [C.c_void_p, _f32p, C.c_int]
         L.orc_map_knn.restype = C.c_double
         L.orc_map_knn.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, _f32p, _f32p, _i32p, C.c_int]
+        L.orc_set_sum_order.argtypes = [C.c_int, C.c_ulonglong]
         L.orc_esti_plane.restype = C.c_int
         L.orc_esti_plane.argtypes = [_f32p, C.c_float, _f32p]
         L.orc_body_to_world.argtypes = [_f64p, _f32p, C.c_int, _f32p]
@@ -131,6 +132,55 @@ def esti_plane(pts5, threshold: float = 0.1):
     out = np.zeros(4, np.float32)
     ok = lib().orc_esti_plane(_c32(pts5).reshape(5, 3), threshold, out)
     return bool(ok), out
+
+
+SUM_ORDERS = {"sequential": 0, "eigen_sse2_packet": 1, "eigen_sse3_hadd": 2, "random": 3}
+
+
+def set_sum_order(mode="sequential", seed: int = 0):
+    """Order of the fp32 reductions inside esti_plane's QR (orc_set_sum_order); "sequential" is the default."""
+    lib().orc_set_sum_order(SUM_ORDERS[mode] if isinstance(mode, str) else int(mode), int(seed))
+
+
+def eigen_order_sensitivity(omap, x26, P, body, max_iter: int = 3, extrinsic_est_en: bool = False, knn_method: int = 1,
+                            random_seeds=(1, 2, 3)):
+    """What "parity unpinned" can cost on one scan step: the model is re-run with every reduction of esti_plane's QR
+    added in Eigen's two packet orders and in random orders (same neighbours, same prior); returned per variant, against
+    the sequential oracle: accept-mask flips / max |d n^| / max |d pd2| of the FIRST pass (identical pose, so nothing but
+    the order differs), and the posterior's position / rotation difference after the whole iterated update."""
+    body = _c32(body)
+    variants = [("eigen_sse2_packet", 0), ("eigen_sse3_hadd", 0)] + [("random", s) for s in random_seeds]
+
+    def run():
+        arr = ScanArrays(len(body))
+        h_share_model(omap, np.ascontiguousarray(x26[:14], np.float64), body, arr, True, extrinsic_est_en, knn_method)
+        x, _, _, _ = update_iterated(omap, x26, P, body, 0.001, max_iter, None, extrinsic_est_en, knn_method)
+        return arr, x
+
+    set_sum_order("sequential")
+    a0, x0 = run()
+    out = {}
+    try:
+        for name, seed in variants:
+            set_sum_order(name, seed)
+            a, x = run()
+            both = (a.selected != 0) & (a0.selected != 0)
+            dn = np.abs(a.normvec[both, :3] - a0.normvec[both, :3])
+            dp = np.abs(a.normvec[both, 3] - a0.normvec[both, 3])
+            q1, q2 = x[3:7], x0[3:7]
+            out[name if name != "random" else f"random_seed{seed}"] = {
+                "accept_mask_flips": int((a.selected != a0.selected).sum()),
+                "max_abs_dn": float(dn.max()) if dn.size else 0.0,
+                "max_abs_dpd2_m": float(dp.max()) if dp.size else 0.0,
+                "planes_with_any_bit_changed": int((a.normvec[both].view(np.uint32) != a0.normvec[both].view(np.uint32)).any(axis=1).sum()),
+                "posterior_dpos_m": float(np.linalg.norm(x[:3] - x0[:3])),
+                "posterior_drot_rad": float(4.0 * np.arcsin(min(1.0, 0.5 * min(np.linalg.norm(q1 - q2), np.linalg.norm(q1 + q2))))),
+            }
+    finally:
+        set_sum_order("sequential")
+    out["points"] = int(len(body))
+    out["selected_sequential"] = int((a0.selected != 0).sum())
+    return out
 
 
 def decision_margins(nbr_xyz, nbr_d, nbr_cnt, world, body):

@@ -110,3 +110,31 @@ def test_map_incremental_classification_is_total(oracle, small_case):
     cls = oracle.map_incremental_classify(wq, x, c, 0.2)
     assert set(np.unique(cls)) <= {0, 1, 2}
     assert (cls == 0).sum() > 0 and (cls == 1).sum() > 0
+
+
+def test_eigen_summation_order_sensitivity(oracle, synth, small_case):
+    """"Parity unpinned", quantified: the oracle adds the terms of every squaredNorm / dot product of
+    esti_plane's QR sequentially; the reference's Eigen build adds them in a packet order that depends on its flags
+    (common_lib.h:520, CMakeLists.txt sets none -> SSE2 (a0+a2)+(a1+a3), with -msse3 (a0+a1)+(a2+a3)) and on stack
+    alignment.  Re-running one scan step under those orders and under random orders moves thousands of planes by an ulp
+    or more -- and the pose by < 1e-6 m / 1e-7 rad, three orders inside the 1e-4 m / 1e-5 rad bar."""
+    from better_fastlio2_amd import capi
+    sc = small_case["scan"]
+    x0 = capi.make_state26(small_case["pos"], small_case["rot"], sc.off_R, sc.off_T)
+    om = oracle.OracleMap(0.2)
+    om.build(small_case["world"].points)
+    # the default order is untouched by the switch: same bits before and after a detour through another mode
+    ok0, p0 = oracle.esti_plane(small_case["world"].points[:5])
+    oracle.set_sum_order("random", 7)
+    oracle.set_sum_order("sequential")
+    ok1, p1 = oracle.esti_plane(small_case["world"].points[:5])
+    assert ok0 == ok1 and np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+    r = oracle.eigen_order_sensitivity(om, x0, synth.init_cov(), sc.body)
+    variants = [k for k in r if isinstance(r[k], dict)]
+    assert len(variants) == 5
+    for k in variants:
+        v = r[k]
+        assert v["planes_with_any_bit_changed"] > 100, "the switch must really change the arithmetic"
+        assert v["accept_mask_flips"] <= 5
+        assert v["max_abs_dpd2_m"] < 1e-3
+        assert v["posterior_dpos_m"] < 1e-6 and v["posterior_drot_rad"] < 1e-7
