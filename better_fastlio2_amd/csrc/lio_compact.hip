@@ -13,6 +13,7 @@
 #include "lio_kernels.h"
 #include "lio_mapadd.h"
 #include "lio_incr.h"
+#include "lio_bbox.h"
 
 namespace lio {
 
@@ -22,10 +23,10 @@ constexpr unsigned COMPACT_SPIN_LIMIT = 1u << 22;
 // exclusive prefix of `mine` over the tiles before this one (K independent streams), the tile's own count published
 // first.  All 256 threads call it; returns false when a wait ran out.
 template <int K>
-__device__ __forceinline__ bool tile_exclusive_prefix(const uint32_t (&mine)[K], u64* agg, uint32_t stamp, uint32_t (&before)[K]) {
+__device__ __forceinline__ bool tile_exclusive_prefix(const uint32_t (&mine)[K], u64* agg, uint32_t stamp, uint32_t (&before)[K], int tile = -1) {
     __shared__ uint32_t s_sum[K][4];
     __shared__ uint32_t s_bad;
-    const int tid = threadIdx.x, b = blockIdx.x;
+    const int tid = threadIdx.x, b = tile >= 0 ? tile : (int)blockIdx.x;
     if (tid == 0) s_bad = 0u;
     __syncthreads();
     if (tid < K) __hip_atomic_store(agg + (size_t)b * K + tid, (u64)mine[tid] | ((u64)stamp << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -71,9 +72,26 @@ __device__ __forceinline__ uint32_t tile_rank(bool flag, uint32_t& tile_total, u
     return off + in_wave;
 }
 
+__global__ __launch_bounds__(256) void bbox_kernel(const float4* pts, uint32_t n, uint32_t* bbox) {
+    for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {     // (block-uniform: every lane reaches the barriers)
+        const uint32_t i = i0 + threadIdx.x;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) p = pts[i];
+        block_bbox(p, i < n, bbox);
+        __syncthreads();
+    }
+}
+hipError_t launch_bbox(const float4* pts, uint32_t n, uint32_t* bbox, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint32_t b = (n + 255u) / 256u;
+    if (b > 512u) b = 512u;
+    hipLaunchKernelGGL(bbox_kernel, dim3(b), dim3(256), 0, s, pts, n, bbox);
+    return hipGetLastError();
+}
+
 // ---- map_incremental's classification (laserMapping.cpp:1448-1489) AND its two order-preserving lists, one launch --
 __global__ __launch_bounds__(256) void map_incremental_lists_kernel(IncrArgs a, float4* add_out, float4* nodown_out, uint32_t* counts,
-                                                                    u64* agg, uint32_t stamp, uint32_t* err) {
+                                                                    uint32_t* bbox, u64* agg, uint32_t stamp, uint32_t* err) {
     __shared__ uint32_t s_w1[4], s_w2[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     uint8_t cls = 0;
@@ -83,6 +101,7 @@ __global__ __launch_bounds__(256) void map_incremental_lists_kernel(IncrArgs a, 
         a.world[i] = wp;
         a.cls[i] = cls;
     }
+    block_bbox(wp, cls != 0, bbox);                              // of both lists: the frames of the batch's keys (lio_mapadd.h)
     uint32_t tot1, tot2;
     const uint32_t r1 = tile_rank(cls == 1, tot1, s_w1);
     const uint32_t r2 = tile_rank(cls == 2, tot2, s_w2);
@@ -98,10 +117,10 @@ __global__ __launch_bounds__(256) void map_incremental_lists_kernel(IncrArgs a, 
         counts[1] = ok ? before[1] + tot2 : 0u;
     }
 }
-hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, float4* nodown_out, uint32_t* counts, u64* agg,
+hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, float4* nodown_out, uint32_t* counts, uint32_t* bbox, u64* agg,
                                         uint32_t stamp, uint32_t* err, hipStream_t s) {
     if (a.nq <= 0) return hipSuccess;
-    hipLaunchKernelGGL(map_incremental_lists_kernel, dim3((a.nq + 255) / 256), dim3(256), 0, s, a, add_out, nodown_out, counts, agg, stamp, err);
+    hipLaunchKernelGGL(map_incremental_lists_kernel, dim3((a.nq + 255) / 256), dim3(256), 0, s, a, add_out, nodown_out, counts, bbox, agg, stamp, err);
     return hipGetLastError();
 }
 
@@ -127,29 +146,7 @@ hipError_t launch_compact_live(const float4* src, uint32_t n, float4* dst, uint3
     return hipGetLastError();
 }
 
-// ---- entries != 0xffffffff of src[0..n) to the front of dst, order kept; *n_out = their number -----------------------
-__global__ __launch_bounds__(256) void compact_marked_kernel(const uint32_t* src, uint32_t n, uint32_t* dst, uint32_t* n_out, u64* agg, uint32_t stamp, uint32_t* err) {
-    __shared__ uint32_t s_w[4];
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t v = i < n ? src[i] : 0xffffffffu;
-    const bool live = v != 0xffffffffu;
-    uint32_t tot;
-    const uint32_t r = tile_rank(live, tot, s_w);
-    const uint32_t mine[1] = {tot};
-    uint32_t before[1];
-    const bool ok = tile_exclusive_prefix<1>(mine, agg, stamp, before);
-    if (ok && live) dst[before[0] + r] = v;
-    if (!ok && threadIdx.x == 0) atomicOr(err, 1u);                 // every tile that skipped its writes reports
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = ok ? before[0] + tot : 0u;
-}
-hipError_t launch_compact_marked(const uint32_t* src, uint32_t n, uint32_t* dst, uint32_t* n_out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s) {
-    if (n == 0) return hipMemsetAsync(n_out, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(compact_marked_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, src, n, dst, n_out, agg, stamp, err);
-    return hipGetLastError();
-}
-
 // ---- runs of equal keys in a sorted array: unique[r], starts[r] (= exclusive scan of the run lengths), *n_runs ------
-// (counts[r] = starts[r + 1] - starts[r] follows in run_counts_kernel: the next run's head may sit in a later tile)
 __global__ __launch_bounds__(256) void run_heads_kernel(const uint64_t* keys, uint32_t n, int shift, uint64_t* unique_out, uint32_t* starts_out,
                                                         uint32_t* n_runs_out, u64* agg, uint32_t stamp, uint32_t* err, bool drop_filler) {
     __shared__ uint32_t s_w[4];
@@ -172,27 +169,85 @@ __global__ __launch_bounds__(256) void run_heads_kernel(const uint64_t* keys, ui
     if (!ok && threadIdx.x == 0) atomicOr(err, 1u);
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_runs_out = ok ? before[0] + tot : 0u;
 }
-__global__ __launch_bounds__(256) void run_counts_kernel(const uint32_t* starts, const uint32_t* n_runs, uint32_t n, uint32_t* counts_out,
-                                                         const uint32_t* n_head, uint32_t n_after) {
-    const uint32_t nr = *n_runs;
-    if (n_head != nullptr) n = min(n, *n_head + n_after);           // the last run ends where the real keys end
-    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < nr; r += gridDim.x * 256u)
-        counts_out[r] = (r + 1u < nr ? starts[r + 1u] : n) - starts[r];
-}
-hipError_t launch_run_lengths(const uint64_t* keys, uint32_t n, uint64_t* unique_out, uint32_t* counts_out, uint32_t* starts_out,
-                              uint32_t* n_runs_out, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s, const uint32_t* n_head, uint32_t n_after) {
-    if (n == 0) return hipMemsetAsync(n_runs_out, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(run_heads_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, keys, n, 0, unique_out, starts_out, n_runs_out, agg, stamp, err, n_head != nullptr);
-    uint32_t b = (n + 255u) / 256u;
-    if (b > 256u) b = 256u;
-    hipLaunchKernelGGL(run_counts_kernel, dim3(b), dim3(256), 0, s, starts_out, n_runs_out, n, counts_out, n_head, n_after);
-    return hipGetLastError();
-}
-
 hipError_t launch_run_heads(const uint64_t* keys, uint32_t n, int shift, uint32_t* starts_out, uint32_t* n_runs_out, u64* agg, uint32_t stamp,
                             uint32_t* err, hipStream_t s) {
     if (n == 0) return hipMemsetAsync(n_runs_out, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(run_heads_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, keys, n, shift, (uint64_t*)nullptr, starts_out, n_runs_out, agg, stamp, err, false);
+    return hipGetLastError();
+}
+
+// ---- the replay list of a down-sampled batch: the batch indices whose dirty_pt mark is set, ascending ------------------
+__global__ __launch_bounds__(256) void compact_dirty_kernel(BoundaryArgs a, u64* agg, uint32_t stamp, uint32_t* err) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool live = i < a.view.n && a.dirty_pt[i] != 0;
+    uint32_t tot;
+    const uint32_t r = tile_rank(live, tot, s_w);
+    const uint32_t mine[1] = {tot};
+    uint32_t before[1];
+    const bool ok = tile_exclusive_prefix<1>(mine, agg, stamp, before);
+    if (ok && live) a.dlist[before[0] + r] = i;
+    if (!ok && threadIdx.x == 0) atomicOr(err, 1u);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *a.n_dirty = ok ? before[0] + tot : 0u;
+}
+hipError_t launch_compact_dirty(const BoundaryArgs& a, u64* agg, uint32_t stamp, uint32_t* err, hipStream_t s) {
+    if (a.view.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(compact_dirty_kernel, dim3((a.view.n + 255u) / 256u), dim3(256), 0, s, a, agg, stamp, err);
+    return hipGetLastError();
+}
+
+// ---- the pending list of an index update, its (cell, list) keys and their partition histogram, one launch -------------
+// tiles 0 .. Tp-1 copy the plain inserts (PointNoNeedDownsample) to the front, the tiles behind them compact the
+// survivors (w == 0) of the fold and of the replay behind those, in order
+__global__ __launch_bounds__(256) void pend_build_kernel(PendBuildArgs a) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_hist[256];
+    const int tid = threadIdx.x;
+    const uint32_t tp = (a.n_plain + 255u) / 256u;
+    const int kb = frame_bits(a.frame) + 1;
+    s_hist[tid] = 0u;
+    __syncthreads();
+    auto emit = [&](uint32_t pos, float4 p, uint32_t list) {
+        // (a non-finite coordinate -- a plain insert may carry one, the reference stores whatever it is given -- is filed under
+        // the cell of 0: the bounding box counted it as 0 too)
+        auto fin = [](float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u ? v : 0.0f; };
+        const int cx = cell_coord(fin(p.x), a.grid.inv_cell), cy = cell_coord(fin(p.y), a.grid.inv_cell), cz = cell_coord(fin(p.z), a.grid.inv_cell);
+        if (!frame_holds(a.frame, cx, cy, cz)) atomicOr(a.flags, 2u);          // the host's frame is wrong: reported
+        const uint64_t key = (frame_key(a.frame, cx, cy, cz) << 1) | (uint64_t)list;
+        a.pend[pos] = make_float4(p.x, p.y, p.z, 0.0f);
+        a.keys[pos] = key;
+        a.order[pos] = pos;
+        if (a.hist != nullptr) atomicAdd(&s_hist[gsort_digit(key, kb)], 1u);
+    };
+    if (blockIdx.x < tp) {
+        const uint32_t i = blockIdx.x * 256u + (uint32_t)tid;
+        if (i < a.n_plain) emit(i, a.plain[i], 1u);
+        if (a.n_surv_slots == 0u && blockIdx.x == 0 && tid == 0) *a.n_surv = 0u;
+    } else {
+        const uint32_t b = blockIdx.x - tp;
+        const uint32_t i = b * 256u + (uint32_t)tid;
+        float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
+        if (i < a.n_surv_slots) p = a.surv[i];
+        const bool live = i < a.n_surv_slots && p.w == 0.0f;
+        uint32_t tot;
+        const uint32_t r = tile_rank(live, tot, s_w);
+        const uint32_t mine[1] = {tot};
+        uint32_t before[1];
+        const bool ok = tile_exclusive_prefix<1>(mine, a.agg, a.stamp, before, (int)b);
+        if (ok && live) emit(a.n_plain + before[0] + r, p, 0u);
+        if (!ok && tid == 0) atomicOr(a.err, 1u);
+        if (blockIdx.x == gridDim.x - 1 && tid == 0) *a.n_surv = ok ? before[0] + tot : 0u;
+    }
+    if (a.hist != nullptr) {
+        __syncthreads();
+        const uint32_t v = s_hist[tid];
+        if (v != 0u) atomicAdd(a.hist + tid, v);
+    }
+}
+hipError_t launch_pend_build(const PendBuildArgs& a, hipStream_t s) {
+    const uint32_t tiles = (a.n_plain + 255u) / 256u + (a.n_surv_slots + 255u) / 256u;
+    if (tiles == 0u) return hipMemsetAsync(a.n_surv, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(pend_build_kernel, dim3(tiles), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -237,8 +292,11 @@ hipError_t launch_exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, 
 // a 1024-record tile alone took ~30 us -- two wavefronts issuing ~220 instructions per round of the network.)
 constexpr uint32_t RANK_WAVES = 16;
 __global__ __launch_bounds__(1024) void rank_sort_pairs_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t n,
-                                                               uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+                                                               uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                               const uint32_t* __restrict__ n_dev, uint32_t n_dev_add) {
     __shared__ uint32_t s_cnt[RANK_WAVES][64];
+    if (n_dev != nullptr) n = min(n, *n_dev + n_dev_add);          // the count is still on the device: n was the launch bound
+    if (blockIdx.x * 64u >= n) return;
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t i0 = blockIdx.x * 64u, i = i0 + lane;
     const bool in = i < n;
@@ -275,10 +333,10 @@ __global__ __launch_bounds__(1024) void rank_sort_pairs_kernel(const uint64_t* _
     }
 }
 hipError_t launch_sort_pairs_small(const uint64_t* keys_in, const uint32_t* vals_in, uint32_t n, uint64_t* keys_out, uint32_t* vals_out,
-                                   hipStream_t s) {
+                                   hipStream_t s, const uint32_t* n_dev, uint32_t n_dev_add) {
     if (n == 0) return hipSuccess;
     if (n > SORT_MAX_ITEMS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rank_sort_pairs_kernel, dim3((n + 63u) / 64u), dim3(64 * RANK_WAVES), 0, s, keys_in, vals_in, n, keys_out, vals_out);
+    hipLaunchKernelGGL(rank_sort_pairs_kernel, dim3((n + 63u) / 64u), dim3(64 * RANK_WAVES), 0, s, keys_in, vals_in, n, keys_out, vals_out, n_dev, n_dev_add);
     return hipGetLastError();
 }
 

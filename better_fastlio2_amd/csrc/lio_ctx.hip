@@ -20,6 +20,25 @@
 
 using namespace lio;
 
+// bounding box of an insert batch on the host (it arrives with the list lengths): the frames of the compressed keys
+struct HostBox {
+    float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
+    bool any = false;
+    void add(float x, float y, float z) {
+        const float v[3] = {std::isfinite(x) ? x : 0.0f, std::isfinite(y) ? y : 0.0f, std::isfinite(z) ? z : 0.0f};   // non-finite: filed under 0
+        for (int i = 0; i < 3; ++i) {
+            if (!any || v[i] < lo[i]) lo[i] = v[i];
+            if (!any || v[i] > hi[i]) hi[i] = v[i];
+        }
+        any = true;
+    }
+    void merge(const HostBox& o) {
+        if (!o.any) return;
+        add(o.lo[0], o.lo[1], o.lo[2]);
+        add(o.hi[0], o.hi[1], o.hi[2]);
+    }
+};
+
 struct lio_ctx {
     lio_config cfg{};
     int device = 0;
@@ -55,21 +74,28 @@ struct lio_ctx {
     long long n_incremental_updates = 0, n_full_rebuilds = 0;
     uint32_t n_new_cells = 0, n_cells_built = 0;   // cells inserted since / present at the last full rebuild
     uint32_t level_entries[TREE_MAX_LEVELS]{};     // entries of each hashed level at the last full rebuild
-    // points appended by Add_Points, waiting for apply_pending (batch order)
+    // An index update in the making (Add_Points called, the index not yet updated): the survivor slots of ONE down-sampled
+    // batch (d_add_out[0 .. 2 fold_n): the fold's, then the sequential replay's; their number is still on the device) and ONE
+    // plain batch (plain_ptr, plain_n points).  apply_pending builds the pending list d_pend = [plain][survivors] from them.
     float4* d_pend = nullptr;
     size_t cap_pend = 0;
-    uint32_t n_pend = 0;
-    // the pending list's length may still be on the device: [d_apply[6] survivors of a down-sampled batch][pend_after
-    // points appended behind them]; n_pend is then the number of SLOTS (an upper bound), see add_batch_device
-    bool pend_lazy = false;
-    uint32_t pend_after = 0;
+    uint32_t fold_n = 0;                       // points of the down-sampled batch (0: none); survivors <= fold_n
+    const float4* plain_ptr = nullptr;
+    uint32_t plain_n = 0;
+    bool pend_built = false;                   // d_pend holds [plain_n][d_apply[6] survivors]
+    HostBox batch_box{};                       // bounding box of the batch(es): the frames of the compressed keys
     int last_add_counter = 0;                  // tmp_counter of the last down-sampled Add_Points (ikd_Tree.cpp:414-489)
-    uint64_t *d_pkeys = nullptr, *d_pkeys2 = nullptr, *d_pcell = nullptr;
-    uint32_t *d_porder = nullptr, *d_porder2 = nullptr, *d_pgcount = nullptr, *d_pgstart = nullptr, *d_pnewsize = nullptr,
-             *d_pnewoff = nullptr;
+    uint64_t *d_pkeys = nullptr, *d_pkeys2 = nullptr, *d_gs_part = nullptr, *d_gs_part2 = nullptr;
+    uint32_t *d_porder = nullptr, *d_porder2 = nullptr, *d_pnewoff = nullptr;
     CellPlan* d_plan = nullptr;
     uint32_t* d_apply = nullptr;               // [0..2] apply stats, [3] new slots, [4] fold: replaced, [5] fold: tmp_counter,
-                                               // [6] survivors, [7] voxel groups, [8] touched cells
+                                               // [6] survivors, [10] boundary points, [14] key-frame violations, [15] compaction time-outs
+    uint32_t* d_ghist = nullptr;               // two partition histograms of the group sort (lio_gsort.hip), used alternately
+    int ghist_cur = 0;
+    bool ghist_dirty = false;                  // a key kernel filled a histogram whose sort never ran
+    unsigned long long* d_gagg = nullptr;      // stamped tile counts of the group sort's partition
+    uint32_t gsort_seq = 0;
+    size_t cagg_words = 0;                     // size of d_cagg
     bool have_map = false;
     unsigned long long* d_cagg = nullptr;      // scratch of the single-launch compaction primitives (lio_compact.hip)
     uint32_t compact_seq = 0;                  // their stamp: one number per launch
@@ -149,10 +175,10 @@ struct lio_ctx {
     size_t cap_add = 0;
     float4 *d_add_pts = nullptr, *d_add_pts2 = nullptr, *d_add_out = nullptr;
     uint8_t* d_add_cls = nullptr;
-    uint8_t* d_add_dirty = nullptr;            // boundary points of a down-sampled batch (lio_mapadd.hip)
-    uint32_t *d_add_dlist = nullptr, *d_add_dlist2 = nullptr;
-    uint64_t *d_add_keys = nullptr, *d_add_keys2 = nullptr, *d_add_ukeys = nullptr;
-    uint32_t *d_add_order = nullptr, *d_add_order2 = nullptr, *d_add_gcount = nullptr, *d_add_gstart = nullptr;
+    uint8_t *d_add_dirty = nullptr, *d_add_dirty_pt = nullptr;   // boundary points of a down-sampled batch (lio_mapadd.hip)
+    uint32_t* d_add_dlist = nullptr;
+    uint64_t *d_add_keys = nullptr, *d_add_keys2 = nullptr;
+    uint32_t *d_add_order = nullptr, *d_add_order2 = nullptr;
 
     // ---- replica exchange (lio_replicate_*) ---------------------------------------------
     void* rep_comm = nullptr;                  // ncclComm_t (RCCL), created by lio_replicate_init
@@ -317,6 +343,95 @@ static hipError_t sort_pairs_any(lio_ctx* c, const uint64_t* keys_in, uint64_t* 
 }
 static bool compact_small(const lio_ctx* c, size_t n) { return !c->dbg_library_sort && n <= COMPACT_MAX_ITEMS; }
 
+// ---- grouping sorts of map maintenance (lio_gsort.hip): which implementation, and its partition histogram ----------------
+enum SortKind { SORT_LIBRARY, SORT_RANK, SORT_LARGE };
+static SortKind sort_kind(const lio_ctx* c, size_t n_bound, int kb) {
+    if (c->dbg_library_sort) return SORT_LIBRARY;
+    if (n_bound <= GSORT_RANK_MAX) return SORT_RANK;
+    if (n_bound <= GSORT_MAX && kb + GSORT_INDEX_BITS <= 64) return SORT_LARGE;
+    return SORT_LIBRARY;
+}
+// the histogram the key-generating kernel of a SORT_LARGE sort has to accumulate (zero on entry); nullptr otherwise
+static int sort_hist(lio_ctx* c, SortKind k, uint32_t** hist) {
+    *hist = nullptr;
+    if (k != SORT_LARGE) return LIO_OK;
+    if (c->ghist_dirty) {                       // a key kernel filled it and its sort never ran (an error path)
+        HIPCHK(c, hipMemsetAsync(c->d_ghist, 0, 512 * sizeof(uint32_t), c->stream));
+        c->ghist_dirty = false;
+    }
+    *hist = c->d_ghist + 256 * c->ghist_cur;
+    c->ghist_dirty = true;
+    return LIO_OK;
+}
+// stable sort by key of n_bound records of which *n_dev + n_dev_add are real (n_dev == nullptr: all); with SORT_LIBRARY the
+// unused slots must hold keys that sort last.  Result in keys_out / vals_out.
+static int run_sort(lio_ctx* c, SortKind k, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+                    size_t n_bound, const uint32_t* n_dev, uint32_t n_dev_add, int kb) {
+    hipStream_t s = c->stream;
+    if (n_bound == 0) return LIO_OK;
+    if (k == SORT_RANK) {
+        HIPCHK(c, launch_sort_pairs_small(keys_in, vals_in, (uint32_t)n_bound, keys_out, vals_out, s, n_dev, n_dev_add));
+    } else if (k == SORT_LARGE) {
+        GsortArgs g{};
+        g.keys = keys_in; g.vals = vals_in; g.n = (uint32_t)n_bound; g.n_dev = n_dev; g.n_dev_add = n_dev_add; g.kb = kb;
+        g.keys_out = keys_out; g.vals_out = vals_out; g.part = c->d_gs_part; g.part2 = c->d_gs_part2;
+        g.hist = c->d_ghist + 256 * c->ghist_cur; g.hist_other = c->d_ghist + 256 * (c->ghist_cur ^ 1);
+        g.agg = c->d_gagg; g.stamp = (++c->gsort_seq == 0u) ? ++c->gsort_seq : c->gsort_seq; g.err = c->d_apply + 15;
+        HIPCHK(c, launch_gsort_large(g, s));
+        c->ghist_cur ^= 1;
+        c->ghist_dirty = false;
+    } else {
+        HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, keys_in, keys_out, vals_in, vals_out, n_bound, s));
+    }
+    return LIO_OK;
+}
+// frame of the integer coordinates lo .. hi (inclusive) of a batch: one spare coordinate per axis above hi, so that the
+// all-ones key is never a point's (the group of the non-finite points, lio_mapadd.hip)
+static KeyFrame frame_of(const int lo[3], const int hi[3]) {
+    KeyFrame f{};
+    f.ox = lo[0]; f.oy = lo[1]; f.oz = lo[2];
+    int* b[3] = {&f.bx, &f.by, &f.bz};
+    for (int i = 0; i < 3; ++i) {
+        const long long extent = (long long)hi[i] - (long long)lo[i] + 2;
+        int bits = 1;
+        while ((1ll << bits) < extent) ++bits;
+        *b[i] = bits;
+    }
+    return f;
+}
+static KeyFrame voxel_frame(const HostBox& box, float ds) {
+    int lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) { lo[i] = voxel_coord(box.lo[i], ds); hi[i] = voxel_coord(box.hi[i], ds); }   // floor(v / ds) is monotone in v
+    return frame_of(lo, hi);
+}
+// the grid cells the pending points of a batch can fall into: survivors are batch points or map points inside the
+// down-sample boxes of batch points, i.e. within one box edge of the batch's bounding box
+static KeyFrame cell_frame(const HostBox& box, float ds, float inv_cell) {
+    int lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) {
+        lo[i] = cell_coord(box.lo[i] - 2.0f * ds, inv_cell) - 1;
+        hi[i] = cell_coord(box.hi[i] + 2.0f * ds, inv_cell) + 1;
+    }
+    return frame_of(lo, hi);
+}
+static const uint32_t BBOX_RESET[6] = {BBOX_MIN_INIT, BBOX_MIN_INIT, BBOX_MIN_INIT, BBOX_MAX_INIT, BBOX_MAX_INIT, BBOX_MAX_INIT};
+// the bounding-box accumulators of the insert lists (d_counters[24..29]) back to "empty": by the host when no kernel that
+// consumes the lists (voxel_keys_kernel resets them itself) is going to run
+static hipError_t reset_list_box(lio_ctx* c) {
+    return hipMemcpyAsync(c->d_counters + 24, BBOX_RESET, sizeof(BBOX_RESET), hipMemcpyHostToDevice, c->stream);
+}
+static void box_from_images(const uint32_t img[6], HostBox& box) {
+    box.any = img[0] != BBOX_MIN_INIT;
+    for (int i = 0; i < 3; ++i) { box.lo[i] = float_from_order_image(img[i]); box.hi[i] = float_from_order_image(img[3 + i]); }
+}
+static void box_of_host_points(HostBox& box, const float* pts, size_t n, int stride_bytes) {
+    const char* src = reinterpret_cast<const char*>(pts);
+    for (size_t i = 0; i < n; ++i) {
+        const float* p = reinterpret_cast<const float*>(src + i * (size_t)stride_bytes);
+        box.add(p[0], p[1], p[2]);
+    }
+}
+
 // Second half of every (re)build: c->d_pts[0..n) is Morton-sorted and live, c->d_mkeys[0..n) holds the
 // keys.  Run-length encode the cells, derive the coarser tree levels (hash tables), fill the child blocks of the
 // cell directory.
@@ -457,17 +572,84 @@ int collect_box_deleted(lio_ctx* c) {
     return LIO_OK;
 }
 
-// the counts a down-sampled Add_Points left on the device (replaced, tmp_counter, survivors), when nobody has read them yet
-static int resolve_lazy_pending(lio_ctx* c) {
-    if (!c->pend_lazy) return LIO_OK;
-    uint32_t host_cnt[3] = {0, 0, 0};
-    HIPCHK(c, read_back(c, host_cnt, c->d_apply + 4, sizeof(host_cnt)));
-    c->pend_lazy = false;
-    c->n_live -= host_cnt[0];
-    c->last_add_counter = (int)host_cnt[1];
-    c->n_pend = host_cnt[2] + c->pend_after;
-    c->pend_after = 0;
+// ---- Add_Points machinery (ikd_Tree.cpp:414-489) --------------------------------------------------
+int apply_pending(lio_ctx* c);
+static int ensure_add_buffers(lio_ctx* c, size_t n) {
+    if (n <= c->cap_add) return LIO_OK;
+    if (c->fold_n != 0 || c->plain_n != 0) {   // left behind by a call that failed half-way: index them first
+        const int rc = apply_pending(c);
+        if (rc != LIO_OK) return rc;
+    }
+    void* old[] = {c->d_add_pts, c->d_add_pts2, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_order, c->d_add_order2,
+                   c->d_add_cls, c->d_add_dirty, c->d_add_dirty_pt, c->d_add_dlist, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_porder,
+                   c->d_porder2, c->d_pnewoff, c->d_plan, c->d_gs_part, c->d_gs_part2, c->d_cagg};
+    for (void* p : old) if (p) (void)hipFree(p);
+    c->d_add_pts = c->d_add_pts2 = c->d_add_out = nullptr; c->d_add_keys = c->d_add_keys2 = nullptr;
+    c->d_add_order = c->d_add_order2 = nullptr; c->d_add_cls = nullptr; c->d_add_dirty = c->d_add_dirty_pt = nullptr; c->d_add_dlist = nullptr;
+    c->cap_add = 0;
+    c->d_pend = nullptr; c->d_pkeys = c->d_pkeys2 = c->d_gs_part = c->d_gs_part2 = nullptr;
+    c->d_porder = c->d_porder2 = c->d_pnewoff = nullptr; c->d_plan = nullptr; c->d_cagg = nullptr;
+    c->cap_pend = 0;
+    HIPCHK(c, hipMalloc((void**)&c->d_add_pts, n * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_pts2, n * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_out, 2 * n * sizeof(float4)));      // [fold survivors by position | sequential replay]
+    HIPCHK(c, hipMalloc((void**)&c->d_add_dirty, n));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_dirty_pt, n));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_dlist, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_keys, n * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_keys2, n * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_order, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_order2, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_cls, n));
+    c->cap_add = n;
+    // the pair Add_Points(add, true) + Add_Points(nodown, false) is applied together: two batches pending
+    const size_t np = 2 * n + 2;
+    HIPCHK(c, hipMalloc((void**)&c->d_pend, np * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_pkeys, np * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_pkeys2, np * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_gs_part, np * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_gs_part2, np * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_porder, np * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_porder2, np * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_pnewoff, np * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_plan, np * sizeof(CellPlan)));
+    c->cap_pend = np;
+    // stamped tile counts of the single-launch scans: one word per tile of 256 (the survivor slots are 2 n), two streams at most
+    c->cagg_words = 2 * (np / 256 + 2);
+    if (c->cagg_words < COMPACT_AGG_WORDS) c->cagg_words = COMPACT_AGG_WORDS;
+    HIPCHK(c, hipMalloc((void**)&c->d_cagg, c->cagg_words * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(c->d_cagg, 0, c->cagg_words * sizeof(unsigned long long), c->stream));
     return LIO_OK;
+}
+
+// The pending list d_pend = [plain inserts][survivors of the fold and of the replay, compacted in order] with the (cell, list)
+// key of every pending point, one launch (lio_compact.hip); the number of survivors stays on the device (d_apply[6]).
+static int build_pending(lio_ctx* c, const KeyFrame& cf, SortKind kind) {
+    hipStream_t s = c->stream;
+    PendBuildArgs pb{};
+    pb.surv = c->d_add_out; pb.n_surv_slots = 2u * c->fold_n; pb.plain = c->plain_ptr; pb.n_plain = c->plain_n;
+    pb.pend = c->d_pend; pb.grid = c->grid; pb.frame = cf; pb.keys = c->d_pkeys; pb.order = c->d_porder;
+    {
+        const int rc = sort_hist(c, kind, &pb.hist);
+        if (rc != LIO_OK) return rc;
+    }
+    pb.n_surv = c->d_apply + 6; pb.flags = c->d_apply + 14; pb.agg = c->d_cagg; pb.stamp = next_compact_stamp(c); pb.err = c->d_apply + 15;
+    if (kind == SORT_LIBRARY)                   // the library sorts every slot: the unused ones must sort last
+        HIPCHK(c, hipMemsetAsync(c->d_pkeys, 0xFF, ((size_t)c->plain_n + (size_t)c->fold_n) * sizeof(uint64_t), s));
+    HIPCHK(c, launch_pend_build(pb, s));
+    c->pend_built = true;
+    return LIO_OK;
+}
+
+// the counts a down-sampled Add_Points left on the device: replaced map points, tmp_counter, survivors (d_apply[4..6]),
+// with the flags of the kernels that ran (frame violations [14], compaction time-outs [15])
+static int fetch_batch_counts(lio_ctx* c, uint32_t st[32]) {
+    HIPCHK(c, read_back(c, st, c->d_apply, 32 * sizeof(uint32_t)));
+    if (st[14] != 0u) {
+        (void)hipMemsetAsync(c->d_apply + 14, 0, sizeof(uint32_t), c->stream);
+        return c->fail(LIO_ERR_HIP, "Add_Points", "a batch point lies outside the key frame derived from the batch's bounding box");
+    }
+    return check_compact_error(c, st[15]);
 }
 
 // Full rebuild: the live points in array order (a bucket is contiguous, so the order inside a cell is kept),
@@ -475,9 +657,19 @@ static int resolve_lazy_pending(lio_ctx* c) {
 // the new cells have grown past their budget, or when a new cell lies outside the root of the tree.
 int rebuild_full(lio_ctx* c) {
     hipStream_t s = c->stream;
-    {
-        const int rc = resolve_lazy_pending(c);
+    uint32_t n_pend = 0;
+    if (c->fold_n != 0 || c->plain_n != 0) {
+        // the pending points as one list (the frame is only needed for keys nobody will look at: any frame that holds them)
+        if (!c->pend_built) {
+            const int rc = build_pending(c, cell_frame(c->batch_box, c->cfg.filter_size_map_min, c->grid.inv_cell), SORT_RANK);
+            if (rc != LIO_OK) return rc;
+        }
+        uint32_t st[32] = {};
+        const int rc = fetch_batch_counts(c, st);
         if (rc != LIO_OK) return rc;
+        if (c->fold_n != 0) { c->n_live -= st[4]; c->last_add_counter = (int)st[5]; }
+        n_pend = c->plain_n + (c->fold_n != 0 ? st[6] : 0u);
+        c->fold_n = 0; c->plain_n = 0; c->plain_ptr = nullptr; c->pend_built = false; c->batch_box = HostBox{};
     }
     c->have_map = false;
     c->hint_valid = false;
@@ -492,84 +684,68 @@ int rebuild_full(lio_ctx* c) {
         HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_pts_tmp, c->d_counters + 3, n_all, s));
         HIPCHK(c, read_back(c, &live, c->d_counters + 3, sizeof(uint32_t)));
     }
-    if ((size_t)live + (size_t)c->n_pend > c->cap_map)
+    if ((size_t)live + (size_t)n_pend > c->cap_map)
         return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
-    if (c->n_pend > 0)
-        HIPCHK(c, hipMemcpyAsync(c->d_pts_tmp + live, c->d_pend, (size_t)c->n_pend * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    const uint32_t n = live + c->n_pend;
-    c->n_pend = 0;
-    return build_index(c, c->d_pts_tmp, n);
+    if (n_pend > 0)
+        HIPCHK(c, hipMemcpyAsync(c->d_pts_tmp + live, c->d_pend, (size_t)n_pend * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    return build_index(c, c->d_pts_tmp, live + n_pend);
 }
 
 // The pending points enter the index: O(batch), the rest of the map is not touched (lio_mapadd.hip).
+// Launches: pend_build, the sort by (cell, list) (1 or 2), cell_plan (with the scan of the new bucket sizes), cell_apply,
+// and ONE read-back that brings the statistics of this update together with the counts the fold left on the device.
 int apply_pending(lio_ctx* c) {
     hipStream_t s = c->stream;
+    if (c->fold_n == 0 && c->plain_n == 0) return LIO_OK;
     c->hint_valid = false;
-    if (c->n_pend == 0) return LIO_OK;
     if (!c->have_map || c->n_live == 0 || c->n_points == 0) return rebuild_full(c);
-    // n slots; with a lazy list only the first d_apply[6] + pend_after hold points (the kernels read the count where it is)
-    const bool small = compact_small(c, (size_t)c->n_pend + 1);
-    if (c->pend_lazy && !small) {
-        const int rc = resolve_lazy_pending(c);
-        if (rc != LIO_OK) return rc;
-        if (c->n_pend == 0) return LIO_OK;
-    }
-    const bool lazy = c->pend_lazy;
-    const uint32_t n = c->n_pend, n_after = c->pend_after;
-    const uint32_t* n_head = lazy ? c->d_apply + 6 : nullptr;
-    HIPCHK(c, launch_pend_keys(c->d_pend, n, c->grid, c->d_pkeys, c->d_porder, n_head, n_after, s));
-    HIPCHK(c, sort_pairs_any(c, c->d_pkeys, c->d_pkeys2, c->d_porder, c->d_porder2, (size_t)n, s));
-    if (small) {
-        HIPCHK(c, launch_run_lengths(c->d_pkeys2, n, c->d_pcell, c->d_pgcount, c->d_pgstart, c->d_apply + 8, c->d_cagg,
-                                     next_compact_stamp(c), c->d_apply + 15, s, n_head, n_after));
-    } else {
-        HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_pkeys2, (size_t)n, c->d_pcell, c->d_pgcount, c->d_apply + 8, s));
-        HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pgcount, c->d_pgstart, (size_t)n, s));
-    }
+    const KeyFrame cf = cell_frame(c->batch_box, c->cfg.filter_size_map_min, c->grid.inv_cell);
+    const int kb = frame_bits(cf) + 1;                            // + the bit that orders the two lists inside a cell
+    if (kb > 63) return c->fail(LIO_ERR_CAPACITY, "Add_Points", "the batch spans more grid cells than a 63-bit key can number");
+    const uint32_t n_bound = c->plain_n + c->fold_n;              // (a batch leaves at most as many survivors as it has points)
+    const SortKind kind = sort_kind(c, n_bound, kb);
+    int rc = build_pending(c, cf, kind);
+    if (rc != LIO_OK) return rc;
+    const uint32_t* n_dev = c->fold_n != 0 ? c->d_apply + 6 : nullptr;
+    rc = run_sort(c, kind, c->d_pkeys, c->d_porder, c->d_pkeys2, c->d_porder2, n_bound, n_dev, c->plain_n, kb);
+    if (rc != LIO_OK) return rc;
     ApplyArgs a{};
     a.map_pts = c->d_pts; a.grid = c->grid; a.ltable = c->d_ltable;
     a.child = c->d_child; a.block_bump = c->d_apply + 9; a.blocks_cap = (uint32_t)c->child_blocks_cap;
     a.levels = c->levels;
-    a.pend = c->d_pend; a.order = c->d_porder2; a.cell_key = c->d_pcell; a.group_start = c->d_pgstart;
-    a.group_count = c->d_pgcount; a.n_groups = c->d_apply + 8; a.plan = c->d_plan; a.new_size = c->d_pnewsize;
-    a.new_off = c->d_pnewoff; a.tail = c->n_points; a.stats = c->d_apply;
-    a.slots_cap = (uint32_t)c->slots_cap; a.n_scan = n;
-    HIPCHK(c, launch_cell_plan(a, n, s));
-    // entries past the touched cells are zero (written by the plan kernel), so element n of the scan is the total
-    if (small) HIPCHK(c, launch_exclusive_scan(c->d_pnewsize, n + 1u, c->d_pnewoff, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
-    else HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_pnewsize, c->d_pnewoff, (size_t)n + 1, s));
-    HIPCHK(c, launch_cell_apply(a, n, s));
+    a.pend = c->d_pend;
+    a.view.skey = c->d_pkeys2; a.view.sord = c->d_porder2; a.view.n_dev = n_dev; a.view.n_add = c->plain_n; a.view.n = n_bound;
+    a.frame = cf; a.plan = c->d_plan; a.new_off = c->d_pnewoff; a.tail = c->n_points; a.stats = c->d_apply;
+    a.slots_cap = (uint32_t)c->slots_cap;
+    a.agg = c->d_cagg; a.stamp = next_compact_stamp(c); a.err = c->d_apply + 15;
+    HIPCHK(c, launch_cell_plan(a, s));
+    HIPCHK(c, launch_cell_apply(a, s));
     uint32_t st[32] = {};
-    HIPCHK(c, read_back(c, st, c->d_apply, sizeof(st)));
-    const uint32_t total = st[3];
-    uint32_t n_real = n;
-    if (lazy) {
-        // the counts of the down-sampled Add_Points arrive with this read-back (one host round trip less per scan)
-        c->pend_lazy = false; c->pend_after = 0;
-        c->n_live -= st[4];
-        c->last_add_counter = (int)st[5];
-        n_real = st[6] + n_after;
-        c->n_pend = n_real;
-    }
-    {
-        const int rc = check_compact_error(c, st[15]);
-        if (rc != LIO_OK) return rc;
-    }
+    rc = fetch_batch_counts(c, st);
+    if (rc != LIO_OK) return rc;
     if (st[2] & APPLY_FLAG_NO_ROOM) return rebuild_full(c);    // nothing was changed: the pending points go in there
+    // the counts of the down-sampled Add_Points arrive with this read-back (no host round trip of their own)
+    const uint32_t n_real = c->plain_n + (c->fold_n != 0 ? st[6] : 0u);
+    if (c->fold_n != 0) { c->n_live -= st[4]; c->last_add_counter = (int)st[5]; }
+    c->fold_n = 0; c->plain_n = 0; c->plain_ptr = nullptr; c->pend_built = false; c->batch_box = HostBox{};
+    const uint32_t total = st[3];
     c->n_points += total;
     c->grid.n_points = c->n_points;
     c->n_live += n_real;
-    c->n_pend = 0;
     c->n_cells += st[0]; c->n_new_cells += st[0]; c->n_retired += st[1];
     ++c->n_incremental_updates;
-    const uint32_t retired_budget = c->n_live / 8 > 65536u ? c->n_live / 8 : 65536u;
+    // Retired copies of re-written buckets (TOMB_MOVED) cost memory and nothing else -- no search ever reads them: they may
+    // grow until the array would be half dead.  Box-deleted points sit INSIDE live buckets and are streamed by every
+    // search that passes: their budget stays tight.
+    const uint32_t retired_budget = c->n_live / 2 > 262144u ? c->n_live / 2 : 262144u;
+    const uint32_t dead_budget = c->n_live / 8 > 65536u ? c->n_live / 8 : 65536u;
     // Keep every hashed level at most half full (they are built a quarter full; the apply kernel counts the entries a
     // level gains), so that probe sequences stay short and a look-up of an absent key always meets an empty slot --
     // small maps have 64-slot tables that the cell budget below would let run full.
     bool table_crowded = false;
     for (int L = 1; L < c->levels.top_level; ++L)
         table_crowded = table_crowded || ((size_t)c->level_entries[L] + (size_t)st[APPLY_LEVEL_NEW + L]) * 2 > (size_t)c->levels.mask[L] + 1;
-    if (st[2] != 0 || table_crowded || (size_t)c->n_retired + (size_t)c->n_dead > (size_t)retired_budget ||
+    if (st[2] != 0 || table_crowded || (size_t)c->n_retired > (size_t)retired_budget || (size_t)c->n_dead > (size_t)dead_budget ||
         (size_t)c->n_new_cells * 4 > (size_t)c->n_cells_built + 1024)
         return rebuild_full(c);
     return LIO_OK;
@@ -699,7 +875,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     c->cap_map = nm;
     // buckets that receive points are re-written at the tail of the array; the room for that is ours, not the
     // caller's (max_map_points bounds the live points)
-    c->slots_cap = nm + nm / 4 + 262144;
+    c->slots_cap = nm + nm / 2 + 524288;
     if (c->slots_cap > 0xfffffff0ull) c->slots_cap = 0xfffffff0ull;
     CREATE_CHK(hipMalloc((void**)&c->d_pts, c->slots_cap * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_pts_tmp, c->slots_cap * sizeof(float4)));
@@ -726,10 +902,16 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     c->child_blocks_cap = 4096;
     CREATE_CHK(hipMalloc((void**)&c->d_child, c->child_blocks_cap * 64 * sizeof(uint2)));
     CREATE_CHK(hipMemset(c->d_child, 0, c->child_blocks_cap * 64 * sizeof(uint2)));
+    c->cagg_words = COMPACT_AGG_WORDS;
     CREATE_CHK(hipMalloc((void**)&c->d_cagg, COMPACT_AGG_WORDS * sizeof(unsigned long long)));
     CREATE_CHK(hipMemset(c->d_cagg, 0, COMPACT_AGG_WORDS * sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc((void**)&c->d_ghist, 512 * sizeof(uint32_t)));
+    CREATE_CHK(hipMemset(c->d_ghist, 0, 512 * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_gagg, GSORT_AGG_WORDS * sizeof(unsigned long long)));
+    CREATE_CHK(hipMemset(c->d_gagg, 0, GSORT_AGG_WORDS * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc((void**)&c->d_counters, 32 * sizeof(uint32_t)));
     CREATE_CHK(hipMemset(c->d_counters, 0, 32 * sizeof(uint32_t)));
+    CREATE_CHK(hipMemcpy(c->d_counters + 24, BBOX_RESET, sizeof(BBOX_RESET), hipMemcpyHostToDevice));   // [24..29] bounding box of the insert lists: empty
     CREATE_CHK(hipMalloc((void**)&c->d_cand, sizeof(unsigned long long)));
     CREATE_CHK(hipMemset(c->d_cand, 0, sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc((void**)&c->d_boxes, 64 * 6 * sizeof(float)));
@@ -771,13 +953,13 @@ void lio_destroy(lio_ctx* c) {
     lio_replicate_finalize(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
-                   c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart, c->d_pnewsize, c->d_pnewoff, c->d_plan, c->d_apply, c->d_temp, c->d_counters, c->d_cagg, c->d_cand, c->d_boxes,
+                   c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_gs_part, c->d_gs_part2, c->d_porder, c->d_porder2, c->d_pnewoff, c->d_plan, c->d_ghist, c->d_gagg, c->d_apply, c->d_temp, c->d_counters, c->d_cagg, c->d_cand, c->d_boxes,
                    c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_useeds, c->d_spec_rows, c->d_rows,
                    c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, c->d_qs_useeds,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
-                   c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys,
-                   c->d_add_order, c->d_add_order2, c->d_add_gcount, c->d_add_gstart, c->d_add_dirty, c->d_add_dlist, c->d_add_dlist2,
+                   c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2,
+                   c->d_add_order, c->d_add_order2, c->d_add_dirty, c->d_add_dirty_pt, c->d_add_dlist,
                    c->d_rep_send, c->d_rep_recv};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_out) (void)hipHostFree(c->h_out);
@@ -832,147 +1014,74 @@ int lio_map_reconstruct(lio_ctx* c, const float* pts, long long n, int stride_by
     return lio_map_build(c, pts, n, stride_bytes);       // ikd_Tree.cpp:1394-1405: delete all, Build
 }
 
-// ---- Add_Points machinery (ikd_Tree.cpp:414-489) --------------------------------------------------
-static int ensure_add_buffers(lio_ctx* c, size_t n) {
-    if (n <= c->cap_add) return LIO_OK;
-    if (c->n_pend != 0) {                      // left behind by a call that failed half-way: index them first
+// One Add_Points(.., true) call on a device-resident batch (float4, batch order = insertion order), WITHOUT touching the
+// index: the batch is grouped by down-sample voxel, every group folds against the indexed points (tomb-stoning what it
+// replaces) and leaves its survivor in d_add_out; the counts stay on the device until the index update's read-back.
+// At most one down-sampled batch per index update (pending points are not in the index yet).
+static int fold_batch_device(lio_ctx* c, const float4* batch, uint32_t n, const HostBox& box) {
+    hipStream_t s = c->stream;
+    if (n == 0) return LIO_OK;
+    if (c->fold_n != 0) {
         const int rc = apply_pending(c);
         if (rc != LIO_OK) return rc;
     }
-    void* old[] = {c->d_add_pts, c->d_add_pts2, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_ukeys, c->d_add_order,
-                   c->d_add_order2, c->d_add_gcount, c->d_add_gstart, c->d_add_cls, c->d_add_dirty, c->d_add_dlist, c->d_add_dlist2,
-                   c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_pcell, c->d_porder, c->d_porder2, c->d_pgcount, c->d_pgstart,
-                   c->d_pnewsize, c->d_pnewoff, c->d_plan};
-    for (void* p : old) if (p) (void)hipFree(p);
-    c->d_add_pts = c->d_add_pts2 = c->d_add_out = nullptr; c->d_add_keys = c->d_add_keys2 = c->d_add_ukeys = nullptr;
-    c->d_add_order = c->d_add_order2 = c->d_add_gcount = c->d_add_gstart = nullptr; c->d_add_cls = nullptr; c->d_add_dirty = nullptr; c->d_add_dlist = c->d_add_dlist2 = nullptr; c->cap_add = 0;
-    c->d_pend = nullptr; c->d_pkeys = c->d_pkeys2 = c->d_pcell = nullptr;
-    c->d_porder = c->d_porder2 = c->d_pgcount = c->d_pgstart = c->d_pnewsize = c->d_pnewoff = nullptr; c->d_plan = nullptr;
-    c->cap_pend = 0;
-    HIPCHK(c, hipMalloc((void**)&c->d_add_pts, n * sizeof(float4)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_pts2, n * sizeof(float4)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_out, 2 * n * sizeof(float4)));      // [group survivors | sequential pass]
-    HIPCHK(c, hipMalloc((void**)&c->d_add_dirty, n));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_dlist, n * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_dlist2, n * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_keys, n * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_keys2, n * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_ukeys, n * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_order, n * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_order2, n * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_gcount, n * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_gstart, n * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_add_cls, n));
-    c->cap_add = n;
-    // the pair Add_Points(add, true) + Add_Points(nodown, false) is applied together: two batches pending
-    const size_t np = 2 * n + 2;
-    HIPCHK(c, hipMalloc((void**)&c->d_pend, np * sizeof(float4)));
-    HIPCHK(c, hipMalloc((void**)&c->d_pkeys, np * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_pkeys2, np * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_pcell, np * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_porder, np * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_porder2, np * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_pgcount, np * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_pgstart, np * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_pnewsize, np * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_pnewoff, np * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_plan, np * sizeof(CellPlan)));
-    c->cap_pend = np;
-    return LIO_OK;
-}
-
-// One Add_Points call on a device-resident batch (float4, batch order = insertion order), WITHOUT
-// touching the index: down-sampled inserts fold per voxel against the indexed points (tomb-stoning
-// what they replace) and leave the survivors pending; plain inserts are left pending as they are.  At most one down-sampled call per apply_pending (pending points are
-// not in the index yet).
-static int add_batch_device(lio_ctx* c, float4* batch, uint32_t n, bool downsample_on, int* n_added) {
-    hipStream_t s = c->stream;
-    if (n_added) *n_added = 0;
-    if (n == 0) return LIO_OK;
-    // (bounds when the pending list is lazy: exact numbers first if they do not fit)
-    if (c->pend_lazy && ((size_t)c->n_live + (size_t)c->n_pend + (size_t)n > c->cap_map || (size_t)c->n_pend + (size_t)n > c->cap_pend || downsample_on)) {
-        const int rc = resolve_lazy_pending(c);
+    if ((size_t)c->n_live + (size_t)c->plain_n + (size_t)n > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
+    if ((size_t)n > c->cap_add) return c->fail(LIO_ERR_CAPACITY, "Add_Points", "batch buffers too small");
+    c->last_add_counter = 0;
+    const float ds = c->cfg.filter_size_map_min;
+    const KeyFrame vf = voxel_frame(box, ds);
+    const int kb = frame_bits(vf);
+    if (kb > 63) return c->fail(LIO_ERR_CAPACITY, "Add_Points", "the batch spans more down-sample voxels than a 63-bit key can number");
+    const SortKind kind = sort_kind(c, n, kb);
+    VoxelKeyArgs vk{};
+    vk.pts = batch; vk.n = n; vk.ds = ds; vk.frame = vf; vk.keys = c->d_add_keys; vk.order = c->d_add_order;
+    {
+        const int rc = sort_hist(c, kind, &vk.hist);
         if (rc != LIO_OK) return rc;
     }
-    if ((size_t)c->n_live + (size_t)c->n_pend + (size_t)n > c->cap_map)
+    vk.zero_counters = c->d_apply + 4; vk.dirty = c->d_add_dirty; vk.dirty_pt = c->d_add_dirty_pt; vk.out2n = c->d_add_out;
+    vk.bbox = c->d_counters + 24; vk.flags = c->d_apply + 14;
+    HIPCHK(c, launch_voxel_keys(vk, s));
+    int rc = run_sort(c, kind, c->d_add_keys, c->d_add_order, c->d_add_keys2, c->d_add_order2, n, nullptr, 0, kb);
+    if (rc != LIO_OK) return rc;
+    GroupView view{};
+    view.skey = c->d_add_keys2; view.sord = c->d_add_order2; view.n_dev = nullptr; view.n_add = 0; view.n = n;
+    // boundary points (outside their own fp32 box / inside a neighbour's): their groups leave the parallel fold
+    // and are replayed point by point
+    BoundaryArgs ba{};
+    ba.map_pts = c->d_pts; ba.l1table = c->d_ltable + c->levels.off[1]; ba.l1mask = c->levels.mask[1]; ba.child = c->d_child;
+    ba.grid = c->grid; ba.ds = ds; ba.new_pts = batch; ba.view = view; ba.frame = vf;
+    ba.dirty = c->d_add_dirty; ba.dirty_pt = c->d_add_dirty_pt; ba.dlist = c->d_add_dlist; ba.n_dirty = c->d_apply + 10;
+    ba.seq_out = c->d_add_out + n; ba.n_added = c->d_apply + 5; ba.n_replaced = c->d_apply + 4;
+    HIPCHK(c, launch_mark_boundary(ba, s));
+    HIPCHK(c, launch_compact_dirty(ba, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+    FoldArgs fa{};
+    fa.map_pts = c->d_pts; fa.l1table = ba.l1table; fa.l1mask = ba.l1mask; fa.child = c->d_child;
+    fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch; fa.view = view;
+    fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
+    HIPCHK(c, launch_fold(fa, ba, s));
+    c->fold_n = n;
+    c->batch_box.merge(box);
+    return LIO_OK;
+}
+// One Add_Points(.., false) call: the points are simply pending (they must stay where they are until the index update)
+static int plain_batch_device(lio_ctx* c, const float4* batch, uint32_t n, const HostBox& box) {
+    if (n == 0) return LIO_OK;
+    if (c->plain_n != 0) {
+        const int rc = apply_pending(c);
+        if (rc != LIO_OK) return rc;
+    }
+    if ((size_t)c->n_live + (size_t)c->fold_n + (size_t)n > c->cap_map)
         return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
-    if ((size_t)c->n_pend + (size_t)n > c->cap_pend)
-        return c->fail(LIO_ERR_CAPACITY, "Add_Points", "pending buffer too small");
-    if (downsample_on) {
-        c->last_add_counter = 0;
-        const float ds = c->cfg.filter_size_map_min;
-        HIPCHK(c, launch_voxel_keys(batch, n, ds, c->d_add_keys, c->d_add_order, c->d_apply + 4, c->d_add_dirty, c->d_add_dlist,
-                                    c->d_add_out, s));
-        HIPCHK(c, sort_pairs_any(c, c->d_add_keys, c->d_add_keys2, c->d_add_order, c->d_add_order2, (size_t)n, s));
-        // the number of voxel groups stays on the device: launches are sized for the batch, the kernels read the
-        // real count (entries past it are never used)
-        if (compact_small(c, n)) {
-            HIPCHK(c, launch_run_lengths(c->d_add_keys2, n, c->d_add_ukeys, c->d_add_gcount, c->d_add_gstart, c->d_apply + 7,
-                                         c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
-        } else {
-            HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_add_keys2, (size_t)n, c->d_add_ukeys,
-                                            c->d_add_gcount, c->d_apply + 7, s));
-            HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_add_gcount, c->d_add_gstart, (size_t)n, s));
-        }
-        // boundary points (outside their own fp32 box / inside a neighbour's): their groups leave the parallel fold
-        // and are replayed point by point
-        BoundaryArgs ba{};
-        ba.map_pts = c->d_pts; ba.l1table = c->d_ltable + c->levels.off[1]; ba.l1mask = c->levels.mask[1]; ba.child = c->d_child;
-        ba.grid = c->grid; ba.ds = ds; ba.new_pts = batch; ba.order = c->d_add_order2; ba.ukeys = c->d_add_ukeys;
-        ba.group_start = c->d_add_gstart; ba.group_count = c->d_add_gcount; ba.n_groups = c->d_apply + 7; ba.n = n;
-        ba.dirty = c->d_add_dirty; ba.dlist = c->d_add_dlist; ba.n_dirty = c->d_apply + 10; ba.seq_out = c->d_add_out + n;
-        ba.n_added = c->d_apply + 5; ba.n_replaced = c->d_apply + 4;
-        HIPCHK(c, launch_classify_boundary(ba, s));
-        HIPCHK(c, launch_detect_shared_points(ba, s));
-        HIPCHK(c, launch_gather_dirty(ba, s));
-        // the marked points in batch order (the marks are the indices: a sort does it too)
-        if (compact_small(c, n))
-            HIPCHK(c, launch_compact_marked(c->d_add_dlist, n, c->d_add_dlist2, c->d_apply + 10, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
-        else
-            HIPCHK(c, sort_keys_u32(c->d_temp, c->temp_bytes, c->d_add_dlist, c->d_add_dlist2, (size_t)n, s));
-        HIPCHK(c, launch_fold_sequential(ba, c->d_add_dlist2, s));
-        FoldArgs fa{};
-        fa.map_pts = c->d_pts; fa.l1table = c->d_ltable + c->levels.off[1]; fa.l1mask = c->levels.mask[1]; fa.child = c->d_child;
-        fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch;
-        fa.order = c->d_add_order2; fa.group_start = c->d_add_gstart; fa.group_count = c->d_add_gcount;
-        fa.n_groups = 0; fa.n_groups_dev = c->d_apply + 7; fa.n_groups_max = n;
-        fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
-        HIPCHK(c, launch_fold_groups(fa, s));
-        // survivors (w == 0) of both passes -> the tail of the pending list, in order
-        float4* tail = c->d_pend + c->n_pend;
-        const bool small = compact_small(c, 2 * (size_t)n);
-        if (small)
-            HIPCHK(c, launch_compact_live(c->d_add_out, 2 * n, tail, c->d_apply + 6, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
-        else
-            HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_add_out, tail, c->d_apply + 6, 2 * (size_t)n, s));
-        if (small && c->n_pend == 0 && !c->dbg_library_sort) {
-            // The counts (replaced, tmp_counter, survivors) stay where they are: the pending list is "d_apply[6] points in
-            // n slots" until apply_pending's own read-back brings them along -- one host round trip less per scan.
-            c->pend_lazy = true; c->pend_after = 0;
-            c->n_pend = n;
-            return LIO_OK;
-        }
-        uint32_t host_cnt[3] = {0, 0, 0};                  // replaced, tmp_counter, survivors
-        HIPCHK(c, read_back(c, host_cnt, c->d_apply + 4, sizeof(host_cnt)));
-        c->last_add_counter = (int)host_cnt[1];
-        if (n_added) *n_added = (int)host_cnt[1];
-        c->n_pend += host_cnt[2];
-        c->n_live -= host_cnt[0];                     // points of the map replaced inside their down-sample voxel
-        return LIO_OK;
-    }
-    if (c->pend_lazy) {
-        // behind the survivors, wherever they end
-        HIPCHK(c, launch_append_points(c->d_pend, c->d_apply + 6, batch, n, s));
-        c->pend_after += n;
-    } else {
-        HIPCHK(c, hipMemcpyAsync(c->d_pend + c->n_pend, batch, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    }
-    c->n_pend += n;
+    if ((size_t)c->fold_n + (size_t)n > c->cap_pend) return c->fail(LIO_ERR_CAPACITY, "Add_Points", "pending buffer too small");
+    c->plain_ptr = batch; c->plain_n = n;
+    c->batch_box.merge(box);
     return LIO_OK;
 }
 
-// the appended points enter the index (incrementally, or through a full rebuild when budgets are exceeded)
-// (*add_counter: tmp_counter of the down-sampled batch of this call, which may only have arrived with apply_pending's read-back)
+// the batches enter the index (incrementally, or through a full rebuild when budgets are exceeded)
+// (*add_counter: tmp_counter of the down-sampled batch of this call: it arrives with the index update's read-back)
 static int rebuild_from_stored(lio_ctx* c, int* add_counter = nullptr) {
     const int rc = apply_pending(c);
     if (rc == LIO_OK && add_counter) *add_counter = c->last_add_counter;
@@ -992,10 +1101,12 @@ int lio_map_add(lio_ctx* c, const float* pts, int n, int stride_bytes, int downs
     if (rc != LIO_OK) return rc;
     rc = upload_points(c, pts, (size_t)n, stride_bytes, c->d_add_pts);
     if (rc != LIO_OK) return rc;
+    HostBox box;
+    box_of_host_points(box, pts, (size_t)n, stride_bytes);
     c->last_add_counter = 0;
-    rc = add_batch_device(c, c->d_add_pts, (uint32_t)n, downsample_on != 0, n_added);
+    rc = downsample_on ? fold_batch_device(c, c->d_add_pts, (uint32_t)n, box) : plain_batch_device(c, c->d_add_pts, (uint32_t)n, box);
     if (rc != LIO_OK) return rc;
-    return rebuild_from_stored(c, n_added);
+    return rebuild_from_stored(c, downsample_on ? n_added : nullptr);
 }
 
 // Add_Points(add, true) followed by Add_Points(nodown, false) -- the pair map_incremental issues
@@ -1011,17 +1122,21 @@ int lio_map_add_pair(lio_ctx* c, const float* add_pts, int n_add, const float* n
         return c->fail(LIO_ERR_CAPACITY, "lio_map_add_pair", "live points + batches exceed max_map_points");
     int rc = ensure_add_buffers(c, (size_t)(n_add > n_nodown ? n_add : n_nodown));
     if (rc != LIO_OK) return rc;
+    c->last_add_counter = 0;
     if (n_add > 0) {
         rc = upload_points(c, add_pts, (size_t)n_add, stride_bytes, c->d_add_pts);
         if (rc != LIO_OK) return rc;
-        c->last_add_counter = 0;
-        rc = add_batch_device(c, c->d_add_pts, (uint32_t)n_add, true, add_counter);
+        HostBox box;
+        box_of_host_points(box, add_pts, (size_t)n_add, stride_bytes);
+        rc = fold_batch_device(c, c->d_add_pts, (uint32_t)n_add, box);
         if (rc != LIO_OK) return rc;
     }
     if (n_nodown > 0) {
         rc = upload_points(c, nodown_pts, (size_t)n_nodown, stride_bytes, c->d_add_pts2);
         if (rc != LIO_OK) return rc;
-        rc = add_batch_device(c, c->d_add_pts2, (uint32_t)n_nodown, false, nullptr);
+        HostBox box;
+        box_of_host_points(box, nodown_pts, (size_t)n_nodown, stride_bytes);
+        rc = plain_batch_device(c, c->d_add_pts2, (uint32_t)n_nodown, box);
         if (rc != LIO_OK) return rc;
     }
     return rebuild_from_stored(c, add_counter);
@@ -1032,17 +1147,28 @@ static int list_kernel_failed(lio_ctx* c) {
     (void)hipMemsetAsync(c->d_counters + 12, 0, sizeof(uint32_t), c->stream);
     return c->fail(LIO_ERR_HIP, "map_incremental", "a bounded wait of the list compaction kernel ran out");
 }
+// the block of device words a list-producing kernel leaves: d_counters[5..6] the two list lengths, [12] its error word,
+// [24..29] the bounding box of both lists (order images)
+struct ListWords { uint32_t n_add = 0, n_plain = 0; HostBox box; };
+static int fetch_list_words(lio_ctx* c, ListWords& w) {
+    uint32_t v[25] = {};                                        // d_counters[5 .. 29]
+    HIPCHK(c, read_back(c, v, c->d_counters + 5, sizeof(v)));
+    if (v[7] != 0u) return list_kernel_failed(c);
+    w.n_add = v[0]; w.n_plain = v[1];
+    box_from_images(v + 19, w.box);
+    return LIO_OK;
+}
 // map_incremental's classification + the two order-preserving lists, left on the device
-// (c->d_add_pts = PointToAdd, c->d_add_pts2 = PointNoNeedDownsample).
+// (c->d_add_pts = PointToAdd, c->d_add_pts2 = PointNoNeedDownsample), their lengths and bounding box too.
 static int map_incremental_lists(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
-                                 uint32_t* cnts /* [2], or nullptr: the counts stay in d_counters[5..6] */) {
-    if (cnts) cnts[0] = cnts[1] = 0;
+                                 ListWords* words /* nullptr: everything stays on the device */) {
+    if (words) *words = ListWords{};
     if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_map_incremental", "no scan set");
     const int nq = c->nq;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     if (nq == 0) {
-        if (!cnts) HIPCHK(c, hipMemsetAsync(c->d_counters + 5, 0, 2 * sizeof(uint32_t), s));
+        if (!words) HIPCHK(c, hipMemsetAsync(c->d_counters + 5, 0, 2 * sizeof(uint32_t), s));
         return LIO_OK;
     }
     int rc = ensure_add_buffers(c, (size_t)nq);
@@ -1057,21 +1183,17 @@ static int map_incremental_lists(lio_ctx* c, const double state14[14], double fi
     ia.nbr = c->d_nbr; ia.cnt = c->d_cnt; ia.filter_size_map_min = filter_size_map_min;
     ia.flg_EKF_inited = flg_EKF_inited; ia.world = c->d_world; ia.cls = c->d_add_cls;
     if (compact_small(c, (size_t)nq)) {
-        // classification + both lists + their counts in ONE launch (was: a classification kernel and two rocPRIM selects)
+        // classification + both lists + their counts + their bounding box in ONE launch
         // (its error word is d_counters[12]: it travels with every read-back of the two counts, here and in the exchange)
-        HIPCHK(c, launch_map_incremental_lists(ia, c->d_add_pts, c->d_add_pts2, c->d_counters + 5, c->d_cagg, next_compact_stamp(c),
-                                               c->d_counters + 12, s));
+        HIPCHK(c, launch_map_incremental_lists(ia, c->d_add_pts, c->d_add_pts2, c->d_counters + 5, c->d_counters + 24, c->d_cagg,
+                                               next_compact_stamp(c), c->d_counters + 12, s));
     } else {
         HIPCHK(c, launch_map_incremental(ia, s));
         HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 1, c->d_add_pts, c->d_counters + 5, (size_t)nq, s));
         HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 2, c->d_add_pts2, c->d_counters + 6, (size_t)nq, s));
+        HIPCHK(c, launch_bbox(c->d_world, (uint32_t)nq, c->d_counters + 24, s));    // (of every scan point: a superset, which is all a frame needs)
     }
-    if (cnts) {
-        uint32_t w[8] = {};                                     // [5..6] counts ... [12] the list kernel's error word
-        HIPCHK(c, read_back(c, w, c->d_counters + 5, sizeof(w)));
-        if (w[7] != 0u) return list_kernel_failed(c);
-        cnts[0] = w[0]; cnts[1] = w[1];
-    }
+    if (words) return fetch_list_words(c, *words);
     return LIO_OK;
 }
 
@@ -1084,16 +1206,16 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
     if (n_nodown) *n_nodown = 0;
     if (add_counter) *add_counter = 0;
     HIPCHK(c, hipSetDevice(c->device));
-    uint32_t cnts[2];
-    int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, cnts);
+    ListWords w;
+    int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, &w);
     if (rc != LIO_OK) return rc;
     hipStream_t s = c->stream;
-    if (n_add) *n_add = (int)cnts[0];
-    if (n_nodown) *n_nodown = (int)cnts[1];
+    if (n_add) *n_add = (int)w.n_add;
+    if (n_nodown) *n_nodown = (int)w.n_plain;
     // the lists, for the caller that replicates them to other GPUs
     for (int which = 0; which < 2; ++which) {
         float* dst = which == 0 ? out_add_xyz : out_nodown_xyz;
-        const uint32_t m = cnts[which];
+        const uint32_t m = which == 0 ? w.n_add : w.n_plain;
         if (!dst || m == 0) continue;
         rc = ensure_scratch(c, (size_t)m * 3 * sizeof(float));
         if (rc != LIO_OK) return rc;
@@ -1102,12 +1224,13 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
         HIPCHK(c, stream_wait(c));
         std::memcpy(dst, c->h_scratch, (size_t)m * 3 * sizeof(float));
     }
+    if (!apply || w.n_add == 0) HIPCHK(c, reset_list_box(c));     // (no voxel_keys_kernel will do it)
     if (!apply) return LIO_OK;
     // ikdtree.Add_Points(PointToAdd, true); ikdtree.Add_Points(PointNoNeedDownsample, false);   :1492-1493
     c->last_add_counter = 0;
-    rc = add_batch_device(c, c->d_add_pts, cnts[0], true, add_counter);
+    rc = fold_batch_device(c, c->d_add_pts, w.n_add, w.box);
     if (rc != LIO_OK) return rc;
-    rc = add_batch_device(c, c->d_add_pts2, cnts[1], false, nullptr);
+    rc = plain_batch_device(c, c->d_add_pts2, w.n_plain, w.box);
     if (rc != LIO_OK) return rc;
     return rebuild_from_stored(c, add_counter);
 }
@@ -1118,11 +1241,12 @@ int lio_map_incremental_device(lio_ctx* c, const double state14[14], double filt
                                void** d_add_f4, int* n_add, void** d_nodown_f4, int* n_nodown) {
     if (!c || !state14 || !(filter_size_map_min > 0.0) || !d_add_f4 || !n_add || !d_nodown_f4 || !n_nodown)
         return LIO_ERR_INVALID_ARG;
-    uint32_t cnts[2];
-    int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, cnts);
+    ListWords w;
+    int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, &w);
     if (rc != LIO_OK) return rc;
-    *d_add_f4 = c->d_add_pts; *n_add = (int)cnts[0];
-    *d_nodown_f4 = c->d_add_pts2; *n_nodown = (int)cnts[1];
+    *d_add_f4 = c->d_add_pts; *n_add = (int)w.n_add;
+    *d_nodown_f4 = c->d_add_pts2; *n_nodown = (int)w.n_plain;
+    HIPCHK(c, reset_list_box(c));
     return LIO_OK;
 }
 int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const void* d_nodown_f4, int n_nodown,
@@ -1133,7 +1257,7 @@ int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const v
     HIPCHK(c, hipSetDevice(c->device));
     if ((size_t)c->n_live + (size_t)n_add + (size_t)n_nodown > c->cap_map)
         return c->fail(LIO_ERR_CAPACITY, "lio_map_add_pair_device", "live points + batches exceed max_map_points");
-    // stage into the context's own batch buffers (the fold clobbers its input; the caller's may be ours)
+    // stage into the context's own batch buffers (the caller's may be ours)
     const size_t need = (size_t)(n_add > n_nodown ? n_add : n_nodown);
     if (need > c->cap_add) {
         // growing would free buffers the caller may be pointing into: copy out first
@@ -1153,10 +1277,20 @@ int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const v
         if (n_nodown && d_nodown_f4 != c->d_add_pts2)
             HIPCHK(c, hipMemcpyAsync(c->d_add_pts2, d_nodown_f4, (size_t)n_nodown * sizeof(float4), hipMemcpyDeviceToDevice, s));
     }
+    // the bounding box of lists the host has never seen: one small kernel and one read-back (this entry point is not on
+    // the per-scan path: lio_replicate_step carries the box in its own read-back)
+    hipStream_t s = c->stream;
+    HIPCHK(c, reset_list_box(c));
+    if (n_add) HIPCHK(c, launch_bbox(c->d_add_pts, (uint32_t)n_add, c->d_counters + 24, s));
+    if (n_nodown) HIPCHK(c, launch_bbox(c->d_add_pts2, (uint32_t)n_nodown, c->d_counters + 24, s));
+    uint32_t img[6] = {};
+    HIPCHK(c, read_back(c, img, c->d_counters + 24, sizeof(img)));
+    HostBox box;
+    box_from_images(img, box);
     c->last_add_counter = 0;
-    int rc = add_batch_device(c, c->d_add_pts, (uint32_t)n_add, true, add_counter);
+    int rc = fold_batch_device(c, c->d_add_pts, (uint32_t)n_add, box);
     if (rc != LIO_OK) return rc;
-    rc = add_batch_device(c, c->d_add_pts2, (uint32_t)n_nodown, false, nullptr);
+    rc = plain_batch_device(c, c->d_add_pts2, (uint32_t)n_nodown, box);
     if (rc != LIO_OK) return rc;
     return rebuild_from_stored(c, add_counter);
 }
@@ -1282,7 +1416,18 @@ int lio_replicate_queue_boxes(lio_ctx* c, const float* minmax6, int nb) {
 // One exchange: this rank's two lists (device, counts in d_counters[5..6]) + queued boxes -> message -> ncclAllGather on
 // the library's stream -> concatenation in rank order -> one read-back of the four totals -> Delete_Point_Boxes, then
 // Add_Points(all PointToAdd, true) and Add_Points(all PointNoNeedDownsample, false) on this replica.
-static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4]) {
+// loop-back: the message of parked virtual rank r into its slot of the gathered buffer
+static int pack_parked_rank(lio_ctx* c, int r, uint32_t cap) {
+    const size_t msg_f4 = (size_t)REP_HEADER_F4 + 2 * (size_t)cap;
+    RepPackArgs pr{};
+    pr.counts = c->d_rep_stage_cnt + 2 * (size_t)r; pr.cap = cap;
+    pr.add = c->d_rep_stage + (size_t)(2 * r) * (size_t)c->cap_q; pr.nodown = c->d_rep_stage + (size_t)(2 * r + 1) * (size_t)c->cap_q;
+    pr.msg = c->d_rep_recv + (size_t)r * msg_f4;
+    std::memcpy(pr.boxes, c->rep_stage_boxes[r], sizeof(pr.boxes)); pr.n_boxes = c->rep_stage_nb[r];
+    HIPCHK(c, launch_replicate_pack(pr, c->stream));
+    return LIO_OK;
+}
+static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4], HostBox& box) {
     hipStream_t s = c->stream;
     const size_t msg_f4 = (size_t)REP_HEADER_F4 + 2 * (size_t)cap;
     RepPackArgs pa{};
@@ -1291,15 +1436,13 @@ static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4]) {
     std::memcpy(pa.boxes, c->rep_boxes, sizeof(pa.boxes)); pa.n_boxes = c->rep_n_boxes;
     HIPCHK(c, launch_replicate_pack(pa, s));
     if (c->rep_loopback) {
-        // the messages of the parked virtual ranks, by the same kernel from their parked lists and counts
+        // the messages of the parked virtual ranks: packed when they parked (their own GPUs would do it concurrently);
+        // here only when the exchange is repeated at a larger capacity -- by the same kernel, from the parked lists
         for (int r = 0; r + 1 < c->rep_world; ++r) {
             if (!(c->rep_staged & (1u << r))) return c->fail(LIO_ERR_INVALID_ARG, "lio_replicate_step", "loop-back: a virtual rank has not parked its lists");
-            RepPackArgs pr{};
-            pr.counts = c->d_rep_stage_cnt + 2 * (size_t)r; pr.cap = cap;
-            pr.add = c->d_rep_stage + (size_t)(2 * r) * (size_t)c->cap_q; pr.nodown = c->d_rep_stage + (size_t)(2 * r + 1) * (size_t)c->cap_q;
-            pr.msg = c->d_rep_recv + (size_t)r * msg_f4;
-            std::memcpy(pr.boxes, c->rep_stage_boxes[r], sizeof(pr.boxes)); pr.n_boxes = c->rep_stage_nb[r];
-            HIPCHK(c, launch_replicate_pack(pr, s));
+            if (cap == c->rep_cap) continue;
+            const int rc = pack_parked_rank(c, r, cap);
+            if (rc != LIO_OK) return rc;
         }
     }
     if (c->rep_comm) {
@@ -1309,12 +1452,13 @@ static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4]) {
     }
     RepCompactArgs ca{};
     ca.gathered = c->d_rep_recv; ca.world = c->rep_world; ca.cap = cap; ca.add_out = c->d_add_pts; ca.nodown_out = c->d_add_pts2;
-    ca.boxes_out = c->d_boxes; ca.totals = c->d_counters + 8;
+    ca.boxes_out = c->d_boxes; ca.totals = c->d_counters + 8; ca.bbox = c->d_counters + 24;
     HIPCHK(c, launch_replicate_compact(ca, s));
-    uint32_t w[5] = {};                                         // the four totals and the list kernel's error word
+    uint32_t w[22] = {};                                        // d_counters[8 .. 29]: the four totals, the list kernel's error word, ... the bounding box
     HIPCHK(c, read_back(c, w, c->d_counters + 8, sizeof(w)));
     if (w[4] != 0u) return list_kernel_failed(c);
     std::memcpy(tot, w, 4 * sizeof(uint32_t));
+    box_from_images(w + 16, box);
     return LIO_OK;
 }
 
@@ -1340,10 +1484,11 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
         c->rep_stage_nb[r] = c->rep_n_boxes;
         c->rep_n_boxes = 0;
         c->rep_staged |= 1u << r;
-        return LIO_OK;
+        return pack_parked_rank(c, r, c->rep_cap);
     }
     uint32_t tot[4] = {0, 0, 0, 0};
-    rc = replicate_exchange_apply(c, c->rep_cap, tot);
+    HostBox box;
+    rc = replicate_exchange_apply(c, c->rep_cap, tot, box);
     if (rc != LIO_OK) return rc;
     if ((tot[3] & REP_FLAG_OVERFLOW) != 0 && c->rep_cap < (uint32_t)c->cap_q) {
         // some rank had more points than a message holds: every rank sees the flag, every rank repeats the exchange at
@@ -1351,7 +1496,7 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
         // if ... the first round's outputs are overwritten by the second)
         rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, nullptr);
         if (rc != LIO_OK) return rc;
-        rc = replicate_exchange_apply(c, (uint32_t)c->cap_q, tot);
+        rc = replicate_exchange_apply(c, (uint32_t)c->cap_q, tot, box);
         if (rc != LIO_OK) return rc;
     }
     c->rep_n_boxes = 0;
@@ -1367,9 +1512,10 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
         account_deleted(c, deleted);
     }
     c->last_add_counter = 0;
-    rc = add_batch_device(c, c->d_add_pts, tot[0], true, add_counter);
+    if (tot[0] == 0) HIPCHK(c, reset_list_box(c));                // (no voxel_keys_kernel will do it)
+    rc = fold_batch_device(c, c->d_add_pts, tot[0], box);
     if (rc != LIO_OK) return rc;
-    rc = add_batch_device(c, c->d_add_pts2, tot[1], false, nullptr);
+    rc = plain_batch_device(c, c->d_add_pts2, tot[1], box);
     if (rc != LIO_OK) return rc;
     rc = rebuild_from_stored(c, add_counter);
     if (n_add_total) *n_add_total = (int)tot[0];
@@ -1390,16 +1536,16 @@ int lio_map_set_downsample_param(lio_ctx* c, float downsample_size) {
     c->cfg.filter_size_map_min = downsample_size;
     return LIO_OK;
 }
-// (a call that failed between a down-sampled Add_Points and its index update may have left the counts of that batch on
-// the device: n_live / n_pend are upper bounds until they are fetched)
+// (a call that failed between an Add_Points and its index update leaves the batch pending, its counts on the device: it is
+// indexed first, so that the numbers are exact)
 long long lio_map_size(lio_ctx* c) {
     if (!c) return 0;
-    if (c->pend_lazy && hipSetDevice(c->device) == hipSuccess) (void)resolve_lazy_pending(c);
+    if ((c->fold_n != 0 || c->plain_n != 0) && hipSetDevice(c->device) == hipSuccess) (void)apply_pending(c);
     return (long long)c->n_points - (long long)c->n_retired;
 }
 long long lio_map_validnum(lio_ctx* c) {
     if (!c) return 0;
-    if (c->pend_lazy && hipSetDevice(c->device) == hipSuccess) (void)resolve_lazy_pending(c);
+    if ((c->fold_n != 0 || c->plain_n != 0) && hipSetDevice(c->device) == hipSuccess) (void)apply_pending(c);
     return (long long)c->n_live;
 }
 
@@ -1424,7 +1570,7 @@ int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_delete
     HIPCHK(c, hipSetDevice(c->device));
     c->hint_valid = false;
     {
-        const int rc = resolve_lazy_pending(c);
+        const int rc = apply_pending(c);                          // (a batch left behind by a call that failed half-way)
         if (rc != LIO_OK) return rc;
     }
     int total = 0;

@@ -148,6 +148,7 @@ struct RepCompactArgs {
     float4*         nodown_out;
     float*          boxes_out;      // [<= REP_MAX_BOXES_TOTAL][6]
     uint32_t*       totals;         // [0] add, [1] nodown, [2] boxes, [3] flags
+    uint32_t*       bbox;           // [6] bounding box of every gathered point (order images, lio_mapadd.h): += 
 };
 hipError_t launch_replicate_pack(const RepPackArgs& a, hipStream_t s);
 hipError_t launch_replicate_compact(const RepCompactArgs& a, hipStream_t s);

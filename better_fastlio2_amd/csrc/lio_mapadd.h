@@ -1,9 +1,53 @@
-// lio_mapadd.h -- launch interface of the Add_Points kernels (lio_mapadd.hip).
+// lio_mapadd.h -- launch interface of the Add_Points kernels (lio_mapadd.hip), the single-launch compaction primitives
+// (lio_compact.hip) and the group sort (lio_gsort.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "lio_common.h"
 
 namespace lio {
+
+// ---- compressed keys ----------------------------------------------------------------------------------------------
+// A batch is grouped twice: by down-sample voxel (Add_Points' fold) and by grid cell (the index update).  The key of a
+// point is its integer voxel / cell coordinate RELATIVE to the batch's own bounding box -- the host knows that box (it
+// arrives with the list lengths) -- so a key has as many bits as the batch has extent: 20-30 for a scan, where the
+// packed 3 x 21-bit key had 63.  Fewer bits = fewer radix passes (lio_gsort.hip).  A coordinate outside the frame
+// cannot belong to a batch point: look-ups of such keys answer "no such group".
+struct KeyFrame {
+    int ox, oy, oz;                 // smallest coordinate of the batch per axis
+    int bx, by, bz;                 // bits per axis: coordinates are in [o, o + 2^b)
+};
+LIO_HD int frame_bits(const KeyFrame& f) { return f.bx + f.by + f.bz; }
+LIO_HD bool frame_holds(const KeyFrame& f, int x, int y, int z) {
+    const long long dx = (long long)x - f.ox, dy = (long long)y - f.oy, dz = (long long)z - f.oz;
+    return dx >= 0 && dx < (1ll << f.bx) && dy >= 0 && dy < (1ll << f.by) && dz >= 0 && dz < (1ll << f.bz);
+}
+LIO_HD uint64_t frame_key(const KeyFrame& f, int x, int y, int z) {
+    return ((uint64_t)(uint32_t)(x - f.ox) << (f.by + f.bz)) | ((uint64_t)(uint32_t)(y - f.oy) << f.bz) | (uint64_t)(uint32_t)(z - f.oz);
+}
+LIO_HD void frame_decode(const KeyFrame& f, uint64_t key, int& x, int& y, int& z) {
+    z = f.oz + (int)(key & ((1ull << f.bz) - 1ull));
+    y = f.oy + (int)((key >> f.bz) & ((1ull << f.by) - 1ull));
+    x = f.ox + (int)(key >> (f.by + f.bz));
+}
+// integer down-sample voxel of a coordinate: floor(v / ds) (ikd_Tree.cpp:424), clamped like the grid cells
+LIO_HD int voxel_coord(float v, float ds) {
+    float f = __builtin_floorf(v / ds);
+    f = f < -1048576.0f ? -1048576.0f : (f > 1048575.0f ? 1048575.0f : f);
+    if (!(f == f)) f = 0.0f;
+    return (int)f;
+}
+
+// ---- a batch grouped by key: what lio_gsort.hip leaves --------------------------------------------------------------
+// Sorted keys + the batch index of the record at every sorted position.  Equal keys are contiguous and in batch order;
+// a GROUP is named by the position of its first record (its HEAD): position s is a head iff s == 0 or skey[s-1] != skey[s].
+// No run-length arrays, no dense group numbers: kernels take one lane (group) per POSITION and only heads act.
+struct GroupView {
+    const uint64_t* skey;
+    const uint32_t* sord;
+    const uint32_t* n_dev;          // optional: *n_dev + n_add records are real (the count is still on the device)
+    uint32_t        n_add;
+    uint32_t        n;              // records, or the launch bound when n_dev != nullptr
+};
 
 struct FoldArgs {
     float4*          map_pts;       // tomb-stones are written here
@@ -13,16 +57,11 @@ struct FoldArgs {
     Grid             grid;
     float            ds;            // downsample_size (ikd_Tree.h:197)
     const float4*    new_pts;       // the batch, in the caller's order
-    const uint32_t*  order;         // batch indices sorted by voxel key (stable)
-    const uint32_t*  group_start;   // per voxel group: first position in `order`
-    const uint32_t*  group_count;
-    uint32_t         n_groups;      // number of voxel groups (used when n_groups_dev is null)
-    const uint32_t*  n_groups_dev;  // device-resident number of voxel groups (no host round trip)
-    uint32_t         n_groups_max;  // launch bound (>= the real number); groups past the real count emit "nothing"
-    float4*          out_pts;       // per group: survivor to append (w == 0) or nothing (w == 1)
+    GroupView        view;          // the batch grouped by down-sample voxel
+    float4*          out_pts;       // per POSITION: a head's survivor to append (w == 0) or nothing (w == 1); pre-set to "nothing"
     uint32_t*        n_added;       // += tmp_counter of ikd_Tree.cpp:448
     uint32_t*        n_replaced;    // += points of the map tomb-stoned by the fold (validnum bookkeeping)
-    const uint8_t*   dirty;         // per group: 1 = left to the sequential pass (lio_mapadd.hip, "boundary points")
+    const uint8_t*   dirty;         // per head position: 1 = left to the sequential replay ("boundary points")
 };
 struct IncrArgs {
     const float4*  body;            // feats_down_body
@@ -35,8 +74,22 @@ struct IncrArgs {
     float4*        world;           // feats_down_world at the posterior pose
     uint8_t*       cls;             // 0 skip, 1 PointToAdd, 2 PointNoNeedDownsample
 };
+// Bounding box of a batch as six order-preserving unsigned images of floats (min x, y, z, max x, y, z): accumulated
+// with atomicMin / atomicMax by the kernels that produce the insert lists, read back with the list lengths, reset by
+// the first kernel that consumes the lists.  A stale (wider) box is harmless: keys only get more bits.
+constexpr uint32_t BBOX_MIN_INIT = 0xffffffffu, BBOX_MAX_INIT = 0u;
+LIO_HD uint32_t float_order_image(float v) {
+    union { float f; uint32_t u; } c; c.f = v;
+    return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+}
+LIO_HD float float_from_order_image(uint32_t u) {
+    union { float f; uint32_t u; } c;
+    c.u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return c.f;
+}
+
 // ---- incremental index update: appended points enter the index without re-sorting the map ---------------
-// The batch is grouped by grid cell (stable sort: batch order inside a cell).  A touched cell's bucket is
+// The batch is grouped by grid cell (stable: batch order inside a cell).  A touched cell's bucket is
 // re-written at the tail of the point array -- its live points in their old order, then the new ones --
 // the old slots become TOMB_MOVED, and only that cell's table entry changes.  New cells are inserted into
 // the cell directory and, as existence marks, into the coarser levels of the tree.
@@ -49,32 +102,28 @@ struct ApplyArgs {
     uint32_t*        block_bump;    // next free child block
     uint32_t         blocks_cap;
     TreeLevels       levels;
-    const float4*    pend;          // appended points, batch order
-    const uint32_t*  order;         // pending indices sorted by cell key (stable)
-    const uint64_t*  cell_key;      // per touched cell: packed key
-    const uint32_t*  group_start;   // per touched cell: first position in `order`
-    const uint32_t*  group_count;
-    const uint32_t*  n_groups;      // device-resident count of touched cells
-    CellPlan*        plan;          // [touched cells]
-    uint32_t*        new_size;      // [touched cells] live old points + new points
-    const uint32_t*  new_off;       // exclusive scan of new_size
+    const float4*    pend;          // appended points: [PointNoNeedDownsample ...][survivors of the fold ...]
+    GroupView        view;          // pending points grouped by (grid cell, list): key = cell key * 2 + (1 for the plain list), so
+                                    // that inside a cell the survivors of Add_Points(.., true) precede the plain inserts (:1492-1493)
+    KeyFrame         frame;         // of the cell keys
+    CellPlan*        plan;          // [position] (heads)
+    uint32_t*        new_size;      // [position] live old points + new points of a head, 0 elsewhere
+    uint32_t*        new_off;       // [position] exclusive scan of new_size (written by the plan kernel)
     uint32_t         tail;          // first free slot of the point array
     uint32_t         slots_cap;     // physical slots of the point array
-    uint32_t         n_scan;        // new_off[n_scan] = total number of slots the re-written buckets need
     uint32_t*        stats;         // [0] new cells, [1] old slots retired, [2] flags (APPLY_FLAG_*), [3] total new slots,
                                     // [APPLY_LEVEL_NEW + L] new entries of level L (not reset per batch)
+    unsigned long long* agg;        // stamped tile sums of the plan kernel's scan (lio_compact.hip)
+    uint32_t         stamp;
+    uint32_t*        err;
 };
 constexpr int APPLY_LEVEL_NEW = 16;                // stats[16 + L]: entries hashed level L gained since the last full rebuild
 constexpr uint32_t APPLY_FLAG_OUTSIDE_TOP = 1u;   // a new cell lies outside the root node of the tree
 constexpr uint32_t APPLY_FLAG_TABLE_FULL = 2u;    // an insertion probe wrapped around a table
 constexpr uint32_t APPLY_FLAG_NO_BLOCKS = 8u;     // the pool of child blocks is exhausted
 constexpr uint32_t APPLY_FLAG_NO_ROOM = 4u;       // the tail cannot hold the re-written buckets: nothing was changed
-// (n_head: the list is [*n_head][n_after] points in n slots, the rest get the key ~0 -- see the kernel)
-hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, const uint32_t* n_head,
-                            uint32_t n_after, hipStream_t s);
-hipError_t launch_append_points(float4* dst_base, const uint32_t* offset, const float4* src, uint32_t n, hipStream_t s);
-hipError_t launch_cell_plan(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);
-hipError_t launch_cell_apply(const ApplyArgs& a, uint32_t max_groups, hipStream_t s);
+hipError_t launch_cell_plan(const ApplyArgs& a, hipStream_t s);
+hipError_t launch_cell_apply(const ApplyArgs& a, hipStream_t s);
 // Boundary points of a down-sampled batch.  The reference's down-sample box is computed in fp32
 // (floor(p / ds) * ds, + ds): next to a voxel boundary a point can lie outside its own box, or inside the box of
 // the neighbouring voxel.  Such points make the inserts of neighbouring voxels depend on each other, so their
@@ -88,54 +137,113 @@ struct BoundaryArgs {
     Grid             grid;
     float            ds;
     const float4*    new_pts;       // the batch, caller's order
-    const uint32_t*  order;         // batch indices sorted by voxel key
-    const uint64_t*  ukeys;         // sorted voxel keys of the groups
-    const uint32_t*  group_start;
-    const uint32_t*  group_count;
-    const uint32_t*  n_groups;      // device-resident
-    uint32_t         n;             // batch size
-    uint8_t*         dirty;         // [n] per group
-    uint32_t*        dlist;         // [n] batch indices of the points of dirty groups (0xffffffff = unused)
+    GroupView        view;          // grouped by voxel
+    KeyFrame         frame;         // of the voxel keys
+    uint8_t*         dirty;         // [n] per head position
+    uint8_t*         dirty_pt;      // [n] per batch index: the point belongs to a dirty group
+    uint32_t*        dlist;         // [n] batch indices of the points of dirty groups, ascending (compact_dirty)
     uint32_t*        n_dirty;
     float4*          seq_out;       // [n] points appended by the sequential pass (w == 0 live)
     uint32_t*        n_added;
     uint32_t*        n_replaced;
 };
-hipError_t launch_classify_boundary(const BoundaryArgs& a, hipStream_t s);
-hipError_t launch_detect_shared_points(const BoundaryArgs& a, hipStream_t s);
-hipError_t launch_gather_dirty(const BoundaryArgs& a, hipStream_t s);
-hipError_t launch_fold_sequential(const BoundaryArgs& a, const uint32_t* dlist_sorted, hipStream_t s);
+// classify_boundary + detect_shared_points of round 2 in one launch: marks dirty / dirty_pt
+hipError_t launch_mark_boundary(const BoundaryArgs& a, hipStream_t s);
+// the replay list: batch indices with dirty_pt set, in batch order (single-launch compaction)
+hipError_t launch_compact_dirty(const BoundaryArgs& a, unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s);
+// the parallel fold over the clean groups AND (its first workgroup) the sequential replay of the dirty points
+hipError_t launch_fold(const FoldArgs& fa, const BoundaryArgs& ba, hipStream_t s);
 hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s);
+
+// first kernel of a down-sampled batch: voxel keys (compressed, frame) + order = iota, the partition histogram of the
+// sort that follows (hist: 256 words, zero on entry; nullptr = none), and the scratch of the later kernels reset
+// (counters, dirty marks, "nothing" in every survivor slot, the bounding box accumulators for the next batch)
+struct VoxelKeyArgs {
+    const float4* pts;
+    uint32_t      n;
+    float         ds;
+    KeyFrame      frame;
+    uint64_t*     keys;
+    uint32_t*     order;
+    uint32_t*     hist;
+    uint32_t*     zero_counters;    // [0..1] fold counters, [6] number of boundary points  (d_apply + 4)
+    uint8_t*      dirty;
+    uint8_t*      dirty_pt;
+    float4*       out2n;            // [2n] survivor slots of the fold and of the replay
+    uint32_t*     bbox;             // [6] reset to "empty"
+    uint32_t*     flags;            // |= 1 when a point lies outside the frame (must not happen: reported)
+};
+hipError_t launch_voxel_keys(const VoxelKeyArgs& a, hipStream_t s);
+
+// The pending list of an index update in ONE launch: [the plain inserts, copied][the survivors of the fold and of the replay,
+// compacted in order]; the (cell, list) key of every pending point for the sort by grid cell, its partition histogram, the
+// number of survivors (*n_surv) -- the count stays on the device.
+struct PendBuildArgs {
+    const float4* surv;             // [n_surv_slots] w == 0: a survivor
+    uint32_t      n_surv_slots;
+    const float4* plain;            // PointNoNeedDownsample (may be nullptr)
+    uint32_t      n_plain;
+    float4*       pend;             // out: [n_plain][survivors]
+    Grid          grid;
+    KeyFrame      frame;            // cell frame
+    uint64_t*     keys;             // out: per pending point
+    uint32_t*     order;            // out: iota
+    uint32_t*     hist;             // partition histogram of the cell sort (nullptr = none)
+    uint32_t*     n_surv;
+    uint32_t*     flags;
+    unsigned long long* agg;
+    uint32_t      stamp;
+    uint32_t*     err;
+};
+hipError_t launch_pend_build(const PendBuildArgs& a, hipStream_t s);
+
 // ---- single-launch compaction primitives (lio_compact.hip) for inputs up to COMPACT_MAX_ITEMS; agg = COMPACT_AGG_WORDS
 // 8-byte words of scratch shared by all of them, stamp = a number no earlier launch on this buffer used, *err |= 1 on a
 // timed-out wait
 constexpr uint32_t COMPACT_MAX_ITEMS = 262144;    // 1024 tiles of 256: all resident at once
 constexpr size_t COMPACT_AGG_WORDS = 2 * 1024;
-// map_incremental's classification + PointToAdd / PointNoNeedDownsample in scan order + their counts, one launch
-hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, float4* nodown_out, uint32_t* counts,
+// map_incremental's classification + PointToAdd / PointNoNeedDownsample in scan order + their counts + their bounding box, one launch
+hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, float4* nodown_out, uint32_t* counts, uint32_t* bbox,
                                         unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s);
 // live points (w == 0) to the front of dst, order kept
 hipError_t launch_compact_live(const float4* src, uint32_t n, float4* dst, uint32_t* n_out, unsigned long long* agg, uint32_t stamp,
                                uint32_t* err, hipStream_t s);
-// entries != 0xffffffff to the front of dst, order kept
-hipError_t launch_compact_marked(const uint32_t* src, uint32_t n, uint32_t* dst, uint32_t* n_out, unsigned long long* agg, uint32_t stamp,
-                                 uint32_t* err, hipStream_t s);
-// runs of a sorted key array: unique keys, run lengths, run starts (exclusive scan of the lengths), number of runs
-// (n_head != nullptr: only the first *n_head + n_after keys are real, the rest are ~0 and form no run)
-hipError_t launch_run_lengths(const uint64_t* keys, uint32_t n, uint64_t* unique_out, uint32_t* counts_out, uint32_t* starts_out,
-                              uint32_t* n_runs_out, unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s,
-                              const uint32_t* n_head = nullptr, uint32_t n_after = 0);
 // stable sort of (u64 key, u32 value) pairs, one launch, no workspace (rank by counting: O(n^2))
 constexpr uint32_t SORT_MAX_ITEMS = 16384;
 hipError_t launch_sort_pairs_small(const uint64_t* keys_in, const uint32_t* vals_in, uint32_t n, uint64_t* keys_out, uint32_t* vals_out,
-                                   hipStream_t s);
+                                   hipStream_t s, const uint32_t* n_dev = nullptr, uint32_t n_dev_add = 0);
 // run starts only, runs of equal keys >> shift (the voxel filter's leaves: the leaf index is the upper half of the key)
 hipError_t launch_run_heads(const uint64_t* keys, uint32_t n, int shift, uint32_t* starts_out, uint32_t* n_runs_out, unsigned long long* agg,
                             uint32_t stamp, uint32_t* err, hipStream_t s);
 hipError_t launch_exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, unsigned long long* agg, uint32_t stamp, uint32_t* err,
                                  hipStream_t s);
-hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, uint32_t* zero2,
-                             uint8_t* dirty, uint32_t* dlist, float4* out2n, hipStream_t s);
-hipError_t launch_fold_groups(const FoldArgs& a, hipStream_t s);
+// bounding box (order images, six atomics per workgroup) of n float4 points
+hipError_t launch_bbox(const float4* pts, uint32_t n, uint32_t* bbox, hipStream_t s);
+
+// ---- group sort (lio_gsort.hip): stable sort of (key, value) records with keys of `kb` bits, two launches --------------
+constexpr int GSORT_INDEX_BITS = 18;
+constexpr uint32_t GSORT_MAX = 1u << GSORT_INDEX_BITS;      // records (the input position rides in the low bits of the record)
+constexpr uint32_t GSORT_RANK_MAX = 8192;                   // up to here the one-launch rank sort is used instead
+constexpr size_t GSORT_AGG_WORDS = (size_t)(GSORT_MAX / 2048u) * 256u;
+LIO_HD uint32_t gsort_digit(uint64_t key, int kb) { return (uint32_t)(key >> (kb > 8 ? kb - 8 : 0)) & 255u; }   // the partition's digit
+struct GsortArgs {
+    const uint64_t* keys;           // [n] keys (< 2^kb), input order = the order inside equal keys
+    const uint32_t* vals;           // [n] values
+    uint32_t        n;              // records, or the launch bound with n_dev
+    const uint32_t* n_dev;          // optional device-resident count: *n_dev + n_dev_add records are real
+    uint32_t        n_dev_add;
+    int             kb;
+    uint64_t*       keys_out;
+    uint32_t*       vals_out;
+    uint64_t*       part;           // [n] scratch
+    uint64_t*       part2;          // [n] scratch (oversized buckets only)
+    const uint32_t* hist;           // [256] histogram of gsort_digit over the real records (accumulated by the key kernel)
+    uint32_t*       hist_other;     // [256] zeroed here: the histogram buffer of the NEXT sort
+    unsigned long long* agg;        // [GSORT_AGG_WORDS]
+    uint32_t        stamp;
+    uint32_t*       err;
+};
+hipError_t launch_gsort_large(const GsortArgs& a, hipStream_t s);
+hipError_t launch_gsort_hist(const uint64_t* keys, uint32_t n, const uint32_t* n_dev, uint32_t n_dev_add, int kb, uint32_t* hist, hipStream_t s);
 
 }  // namespace lio

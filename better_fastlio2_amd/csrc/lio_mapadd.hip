@@ -5,12 +5,14 @@
 // and the points found, the one nearest the voxel centre (the new point wins ties, strict `<`
 // :440), and (c) if the voxel held more than one point or the winner is the new point, deletes
 // the voxel's points and adds the winner (:445-448).  Inserts interact only through their voxel,
-// so the batch is grouped by voxel (stable radix sort keeps the batch order inside a group) and
-// one lane folds each group sequentially -- the result equals the sequential one.
-//   voxel_keys_kernel     voxel key of each new point
-//   fold_groups_kernel    per voxel: existing points in the box (directory look-ups of the <= 8 grid
-//                         cells the box touches), sequential fold, tomb-stone + emit the survivor
-// The caller then appends the survivors and rebuilds the index (sort + hash), see lio_ctx.hip.
+// so the batch is grouped by voxel (stable sort: batch order inside a group, lio_gsort.hip) and every
+// group is folded on its own -- the result equals the sequential one.
+//
+// Round 3: groups are named by the POSITION of their first record in the sorted batch (GroupView, lio_mapadd.h); kernels
+// take one lane (or eight) per position and only heads act.  That removed the run-length kernels (two launches per
+// sort), the dense group numbering and the per-group count arrays; the keys are compressed (KeyFrame).  Launches of a
+// down-sampled batch:  voxel_keys -> sort (1 or 2) -> mark_boundary -> compact_dirty -> fold (parallel fold + sequential
+// replay side by side); of the index update:  pend_build -> sort -> cell_plan (with its scan) -> cell_apply.
 #include "lio_device.h"
 #include "lio_kernels.h"
 #include "lio_mapadd.h"
@@ -21,25 +23,53 @@ namespace lio {
 
 __device__ __forceinline__ float voxel_floor(float v, float ds) { return floorf(v / ds); }   // :424
 
-__global__ __launch_bounds__(256) void voxel_keys_kernel(const float4* pts, uint32_t n, float ds, uint64_t* vkeys,
-                                                         uint32_t* order, uint32_t* zero2, uint8_t* dirty, uint32_t* dlist,
-                                                         float4* out2n) {
+__device__ __forceinline__ uint32_t view_count(const GroupView& v) { return v.n_dev != nullptr ? min(v.n, *v.n_dev + v.n_add) : v.n; }
+__device__ __forceinline__ bool view_is_head(const GroupView& v, uint32_t s) { return s == 0u || v.skey[s - 1u] != v.skey[s]; }
+// head position of the group with this key, or 0xffffffff
+__device__ __forceinline__ uint32_t view_find(const GroupView& v, uint32_t n, uint64_t key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (v.skey[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && v.skey[lo] == key) ? lo : 0xffffffffu;
+}
+__device__ __forceinline__ bool finite3(float4 p) {
+    return (__float_as_uint(p.x) & 0x7f800000u) != 0x7f800000u && (__float_as_uint(p.y) & 0x7f800000u) != 0x7f800000u &&
+           (__float_as_uint(p.z) & 0x7f800000u) != 0x7f800000u;
+}
+
+__global__ __launch_bounds__(256) void voxel_keys_kernel(VoxelKeyArgs a) {
+    __shared__ uint32_t s_hist[256];
     // first kernel of an Add_Points(downsample) batch: it also clears what the later kernels accumulate into
-    // (zero2[0..1] fold counters, zero2[6] number of boundary points) and marks every output slot "nothing"
-    if (zero2 != nullptr && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u;
-    if (zero2 != nullptr && blockIdx.x == 0 && threadIdx.x == 2) zero2[6] = 0u;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        dirty[i] = 0;
-        dlist[i] = 0xffffffffu;
-        out2n[i] = make_float4(0.f, 0.f, 0.f, 1.0f);
-        out2n[n + i] = make_float4(0.f, 0.f, 0.f, 1.0f);
-        const float4 p = pts[i];
-        float kx = voxel_floor(p.x, ds), ky = voxel_floor(p.y, ds), kz = voxel_floor(p.z, ds);
-        kx = fminf(fmaxf(kx, -1048576.0f), 1048575.0f);
-        ky = fminf(fmaxf(ky, -1048576.0f), 1048575.0f);
-        kz = fminf(fmaxf(kz, -1048576.0f), 1048575.0f);
-        vkeys[i] = pack_key((uint32_t)((int)kx + CELL_OFF), (uint32_t)((int)ky + CELL_OFF), (uint32_t)((int)kz + CELL_OFF));
-        order[i] = i;
+    // (fold counters, number of boundary points, the bounding box of the NEXT batch) and marks every output slot "nothing"
+    if (blockIdx.x == 0 && threadIdx.x < 2) a.zero_counters[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 2) a.zero_counters[6] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 14) a.bbox[threadIdx.x - 8] = threadIdx.x < 11 ? BBOX_MIN_INIT : BBOX_MAX_INIT;
+    s_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const int kb = frame_bits(a.frame);
+    const uint64_t junk = kb >= 64 ? ~0ull : (1ull << kb) - 1ull;      // a key no point of the frame has (lio_mapadd.h)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+        a.dirty[i] = 0;
+        a.dirty_pt[i] = 0;
+        a.out2n[i] = make_float4(0.f, 0.f, 0.f, 1.0f);
+        a.out2n[a.n + i] = make_float4(0.f, 0.f, 0.f, 1.0f);
+        const float4 p = a.pts[i];
+        const int ix = voxel_coord(p.x, a.ds), iy = voxel_coord(p.y, a.ds), iz = voxel_coord(p.z, a.ds);
+        // a point with a non-finite coordinate never enters the map through Add_Points(.., true) (its box holds nothing and
+        // same_point(p, p) is false, :440-445): all of them form one group of their own, behind every real key
+        const bool fin = finite3(p), held = frame_holds(a.frame, ix, iy, iz);
+        if (fin && !held) atomicOr(a.flags, 1u);                   // the host's frame is wrong: reported, never silent
+        const uint64_t key = (fin && held) ? frame_key(a.frame, ix, iy, iz) : junk;
+        a.keys[i] = key;
+        a.order[i] = i;
+        if (a.hist != nullptr) atomicAdd(&s_hist[gsort_digit(key, kb)], 1u);
+    }
+    if (a.hist != nullptr) {
+        __syncthreads();
+        const uint32_t v = s_hist[threadIdx.x];
+        if (v != 0u) atomicAdd(a.hist + threadIdx.x, v);
     }
 }
 
@@ -51,132 +81,119 @@ __device__ __forceinline__ bool same_point(float4 a, float4 b) {         // ikd_
 // t = 4 dx + 2 dy + dz takes one of them -- probe, bucket scan and tomb-stoning of the eight cells run side by
 // side instead of one after the other.  The reference visits the cells in (x, y, z) order and keeps the FIRST
 // minimum (strict `<`), which is the minimum over (distance, t) here.
-__global__ __launch_bounds__(64) void fold_groups_kernel(FoldArgs a) {
-    const uint32_t n_groups = a.n_groups_dev != nullptr ? *a.n_groups_dev : a.n_groups;
-    const int t = threadIdx.x & 7;
-    const uint32_t gpw = 8u;                                    // groups per wavefront
-    for (uint32_t g0 = blockIdx.x * gpw; g0 < a.n_groups_max; g0 += gridDim.x * gpw) {
-        const uint32_t g = g0 + (threadIdx.x >> 3);
-        if (g >= n_groups) {
-            if (g < a.n_groups_max && t == 0) a.out_pts[g] = make_float4(0.f, 0.f, 0.f, 1.0f);   // nothing to append
-            continue;                                           // whole sub-group leaves together
-        }
-        if (a.dirty[g] != 0) continue;                         // boundary points around: replayed by fold_sequential_kernel
-        const uint32_t gs = a.group_start[g], gc = a.group_count[g];
-        const float ds = a.ds;
-        const float4 p0 = a.new_pts[a.order[gs]];
-        // Box_of_Point and mid_point (:424-432): fp32 box, centre through double
-        float bmin[3], bmax[3], mid[3];
-        const float pc[3] = {p0.x, p0.y, p0.z};
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            bmin[ax] = voxel_floor(pc[ax], ds) * ds;
-            bmax[ax] = bmin[ax] + ds;
-            mid[ax] = (float)((double)bmin[ax] + (double)(bmax[ax] - bmin[ax]) / 2.0);
-        }
-        int c0[3], c1[3];
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            c0[ax] = cell_coord(bmin[ax], a.grid.inv_cell);
-            c1[ax] = cell_coord(bmax[ax], a.grid.inv_cell);
-        }
-        const int cx = c0[0] + ((t >> 2) & 1), cy = c0[1] + ((t >> 1) & 1), cz = c0[2] + (t & 1);
-        const bool mine = cx <= c1[0] && cy <= c1[1] && cz <= c1[2];
-        // ---- pass 1: existing live points inside the box (Search_by_range :1015-1045) -------------
-        uint32_t st = 0, ct = 0;
-        if (mine) cell_find(a.l1table, a.l1mask, a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, st, ct);
-        uint32_t n_e = 0;
-        float d_e = __uint_as_float(INF_BITS);
-        float4 e_best = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t i = st; i < st + ct; ++i) {
-            const float4 sp = a.map_pts[i];
-            if (sp.w != 0.0f) continue;
-            if (bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z) {
-                ++n_e;
-                const float d = sqdist3(sp.x, sp.y, sp.z, mid[0], mid[1], mid[2]);
-                if (d < d_e) { d_e = d; e_best = sp; }
-            }
-        }
-        // combine the eight cells: count, and the first minimum in cell order
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            n_e += __shfl_xor(n_e, o, 64);
-            const float od = __shfl_xor(d_e, o, 64);
-            const float ox = __shfl_xor(e_best.x, o, 64), oy = __shfl_xor(e_best.y, o, 64), oz = __shfl_xor(e_best.z, o, 64);
-            // the partner holds the lower cell numbers iff its lane number is lower
-            const bool partner_first = ((t ^ o) < t);
-            const bool take = partner_first ? (od <= d_e) : (od < d_e);
-            if (take) { d_e = od; e_best = make_float4(ox, oy, oz, 0.0f); }
-        }
-        // ---- sequential fold over the group's new points (:433-449), identical in all eight lanes ------
-        bool touched = false;
-        float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
-        float d_cur = 0.0f;
-        uint32_t counter = 0;
-        for (uint32_t j = 0; j < gc; ++j) {
-            const float4 p = a.new_pts[a.order[gs + j]];
-            const float d_p = sqdist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
-            if (!touched) {
-                const bool best_is_p = !(n_e > 0 && d_e < d_p);
-                const float4 best = best_is_p ? p : e_best;
-                if (n_e > 1 || same_point(p, best)) {
-                    touched = true; cur = best; d_cur = best_is_p ? d_p : d_e; ++counter;
-                }
+//
+// The fold over the group's new points (ikd_Tree.cpp:433-449, one insert after the other) is a running minimum:
+// once the voxel has been "touched" (Delete_by_range + Add_by_point happened) it holds exactly one point, cur, and a later
+// point p replaces it iff !(d_cur < d_p).  Small groups run that loop as it stands; a group with many points -- an
+// un-down-sampled 100 k-point scan puts hundreds of returns of a near wall into one 0.2 m voxel, and eight replicas'
+// lists make it worse -- would hold its wavefront for a dependent load per point (836 points: 200 us, measured), so
+// the whole wavefront folds it 64 points at a time: prefix-min of the distances (who sets a new record), prefix-max of
+// the record positions (which point is cur when a later one is compared with it), the counter from two ballots.
+constexpr uint32_t FOLD_WAVE_MIN = 16;          // group sizes from which the 64-lane fold takes over
+
+struct FoldResult { bool touched; float x, y, z, d; uint32_t counter; };
+
+// all 64 lanes, wave-uniform arguments and result; the group = the records from position gs on that carry `key`
+__device__ __forceinline__ FoldResult fold_members_wave(const FoldArgs& a, uint32_t n, uint32_t gs, uint64_t key, uint32_t n_e, float d_e,
+                                                        float ex, float ey, float ez, float mx, float my, float mz, int lane) {
+    FoldResult r{false, 0.f, 0.f, 0.f, 0.f, 0u};
+    const float inf = __uint_as_float(INF_BITS);
+    for (uint32_t base = 0;; base += 64u) {
+        const uint32_t s = gs + base + (uint32_t)lane;
+        const bool has = s < n && a.view.skey[s] == key;           // members are contiguous: the first miss ends the group
+        const bool more = __ballot(has) == ~0ull;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has) p = a.new_pts[a.view.sord[s]];
+        const float d = sqdist3(p.x, p.y, p.z, mx, my, mz);
+        const bool selfsame = has && same_point(p, p);          // false for a point with a NaN coordinate: it never enters
+        int first_after = 0;
+        bool skip = false;
+        if (!r.touched) {
+            const bool best_is_p = !(n_e > 0 && d_e < d);
+            const float4 best = best_is_p ? p : make_float4(ex, ey, ez, 0.0f);
+            const bool tc = has && (n_e > 1 || same_point(p, best));
+            const unsigned long long m = __ballot(tc);
+            if (m == 0ull) {
+                skip = true;
             } else {
-                const bool best_is_p = !(d_cur < d_p);
-                const float4 best = best_is_p ? p : cur;
-                if (same_point(p, best)) { cur = best; d_cur = best_is_p ? d_p : d_cur; ++counter; }
+                const int lt = __ffsll((long long)m) - 1;
+                const bool bip = __shfl((int)best_is_p, lt, 64) != 0;
+                const float px = __shfl(p.x, lt, 64), py = __shfl(p.y, lt, 64), pz = __shfl(p.z, lt, 64), pd = __shfl(d, lt, 64);
+                r.touched = true; r.counter = 1u;
+                r.x = bip ? px : ex; r.y = bip ? py : ey; r.z = bip ? pz : ez; r.d = bip ? pd : d_e;
+                first_after = lt + 1;
             }
         }
-        // ---- pass 2: Delete_by_range of the box + Add_by_point of the survivor --------------------
-        uint32_t replaced = 0;
-        if (touched) {
-            for (uint32_t i = st; i < st + ct; ++i) {
-                float4 sp = a.map_pts[i];
-                if (sp.w != 0.0f) continue;
-                if (bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z) {
-                    // exchange, not store: the bookkeeping stays exact even if two boxes ever claimed the same point
-                    const uint32_t was = atomicExch(reinterpret_cast<uint32_t*>(&a.map_pts[i].w), __float_as_uint(TOMB_DOWNSAMPLE));
-                    if (was == 0u) ++replaced;
-                }
+        if (!skip) {
+            const bool in = has && lane >= first_after;
+            // who sets a new record: d <= the minimum of everything before it (cur's distance included)
+            float pm = (in && selfsame) ? d : inf;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float u = __shfl_up(pm, o, 64);
+                if (lane >= o) pm = fminf(pm, u);
+            }
+            float em = __shfl_up(pm, 1, 64);
+            if (lane == 0) em = inf;
+            em = fminf(em, r.d);
+            const bool rec = in && selfsame && !(em < d);
+            // cur as this lane sees it: the latest record before it, else the state carried in
+            int pr = rec ? lane : -1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(pr, o, 64);
+                if (lane >= o) pr = pr > u ? pr : u;
+            }
+            int er = __shfl_up(pr, 1, 64);
+            if (lane == 0) er = -1;
+            const int src = er < 0 ? 0 : er;
+            float bx = __shfl(p.x, src, 64), by = __shfl(p.y, src, 64), bz = __shfl(p.z, src, 64);
+            if (er < 0) { bx = r.x; by = r.y; bz = r.z; }
+            const bool dup = in && !rec && same_point(p, make_float4(bx, by, bz, 0.0f));
+            r.counter += (uint32_t)__popcll(__ballot(rec || dup));
+            const unsigned long long rm = __ballot(rec);
+            if (rm != 0ull) {
+                const int last = 63 - __clzll((long long)rm);
+                r.x = __shfl(p.x, last, 64); r.y = __shfl(p.y, last, 64); r.z = __shfl(p.z, last, 64); r.d = __shfl(d, last, 64);
             }
         }
-        if (replaced != 0) atomicAdd(a.n_replaced, replaced);
-        if (t == 0) {
-            a.out_pts[g] = touched ? make_float4(cur.x, cur.y, cur.z, 0.0f) : make_float4(0.f, 0.f, 0.f, 1.0f);
-            if (counter != 0) atomicAdd(a.n_added, counter);
-        }
+        if (!more) break;
     }
+    return r;
 }
 
 // ---- boundary points -----------------------------------------------------------------------------------
-// index of `key` in the sorted group keys, or 0xffffffff
-__device__ __forceinline__ uint32_t find_group(const uint64_t* ukeys, uint32_t n_groups, uint64_t key) {
-    uint32_t lo = 0, hi = n_groups;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (ukeys[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return (lo < n_groups && ukeys[lo] == key) ? lo : 0xffffffffu;
+// the group at head position h is dirty: itself (the parallel fold skips it) and every one of its points (the replay list)
+__device__ __forceinline__ void mark_group_dirty(const BoundaryArgs& a, uint32_t n, uint32_t h) {
+    a.dirty[h] = 1;
+    const uint64_t key = a.view.skey[h];
+    for (uint32_t s = h; s < n && a.view.skey[s] == key; ++s) a.dirty_pt[a.view.sord[s]] = 1;
+}
+__device__ __forceinline__ uint32_t find_voxel_group(const BoundaryArgs& a, uint32_t n, int x, int y, int z) {
+    if (!frame_holds(a.frame, x, y, z)) return 0xffffffffu;       // no batch point lives outside the frame
+    return view_find(a.view, n, frame_key(a.frame, x, y, z));
 }
 
-// one lane per batch point: is it outside its own fp32 box, or inside a neighbour's?  Then its group and the groups
-// of the voxels it reaches are dirty.
-__global__ __launch_bounds__(256) void classify_boundary_kernel(BoundaryArgs a) {
-    const uint32_t n_groups = *a.n_groups;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+// (1) one lane per batch point: is it outside its own fp32 box, or inside a neighbour's?  Then its group and the groups
+// of the voxels it reaches are dirty.  (2) eight lanes per group, the fold's layout: a LIVE MAP POINT inside the box of a
+// group that also lies inside the box of a neighbouring voxel (fp32 boxes of neighbours can overlap by an ulp) couples
+// the two groups -- if the neighbour has points in this batch, both go to the sequential pass.
+__global__ __launch_bounds__(64) void mark_boundary_kernel(BoundaryArgs a) {
+    const uint32_t n = view_count(a.view);
+    const float ds = a.ds;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = a.new_pts[i];
+        if (!finite3(p)) continue;
         const float pc[3] = {p.x, p.y, p.z};
-        int dir[3];
-        float kf[3];
+        int dir[3], iv[3];
         bool irregular = false;
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            const float ds = a.ds;
-            kf[ax] = voxel_floor(pc[ax], ds);
-            const float bmin = kf[ax] * ds, bmax = bmin + ds;
-            const float up_min = (kf[ax] + 1.0f) * ds;              // lower bound of the upper neighbour's box
-            const float dn_max = (kf[ax] - 1.0f) * ds + ds;         // upper bound of the lower neighbour's box
+            iv[ax] = voxel_coord(pc[ax], ds);
+            const float kf = (float)iv[ax];
+            const float bmin = kf * ds, bmax = bmin + ds;
+            const float up_min = (kf + 1.0f) * ds;              // lower bound of the upper neighbour's box
+            const float dn_max = (kf - 1.0f) * ds + ds;         // upper bound of the lower neighbour's box
             const bool up = !(pc[ax] < bmax) || pc[ax] >= up_min;
             const bool dn = !(bmin <= pc[ax]) || pc[ax] < dn_max;
             dir[ax] = up ? 1 : (dn ? -1 : 0);
@@ -185,39 +202,33 @@ __global__ __launch_bounds__(256) void classify_boundary_kernel(BoundaryArgs a) 
         if (!irregular) continue;
         for (int m = 0; m < 8; ++m) {                              // own voxel (m = 0) and every combination of the reached sides
             bool use = true;
-            float k[3];
+            int k[3];
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
                 const bool bit = (m >> ax) & 1;
                 if (bit && dir[ax] == 0) use = false;
-                k[ax] = fminf(fmaxf(kf[ax] + (bit ? (float)dir[ax] : 0.0f), -1048576.0f), 1048575.0f);
+                k[ax] = iv[ax] + (bit ? dir[ax] : 0);
             }
             if (!use) continue;
-            const uint64_t key = pack_key((uint32_t)((int)k[0] + CELL_OFF), (uint32_t)((int)k[1] + CELL_OFF), (uint32_t)((int)k[2] + CELL_OFF));
-            const uint32_t g = find_group(a.ukeys, n_groups, key);
-            if (g != 0xffffffffu) a.dirty[g] = 1;
+            const uint32_t g = find_voxel_group(a, n, k[0], k[1], k[2]);
+            if (g != 0xffffffffu) mark_group_dirty(a, n, g);
         }
     }
-}
-
-// Pre-pass of the fold, same lane layout: a LIVE MAP POINT inside the box of a group that also lies inside the box
-// of a neighbouring voxel (fp32 boxes of neighbours can overlap by an ulp) couples the two groups -- if the
-// neighbour has points in this batch, both go to the sequential pass.
-__global__ __launch_bounds__(64) void detect_shared_points_kernel(BoundaryArgs a) {
-    const uint32_t n_groups = *a.n_groups;
     const int t = threadIdx.x & 7;
-    for (uint32_t g0 = blockIdx.x * 8u; g0 < a.n; g0 += gridDim.x * 8u) {
-        const uint32_t g = g0 + (threadIdx.x >> 3);
-        if (g >= n_groups) continue;
-        const float ds = a.ds;
-        const float4 p0 = a.new_pts[a.order[a.group_start[g]]];
+    for (uint32_t s0 = blockIdx.x * 8u; s0 < a.view.n; s0 += gridDim.x * 8u) {
+        const uint32_t s = s0 + (threadIdx.x >> 3);
+        if (s >= n || !view_is_head(a.view, s)) continue;
+        const float4 p0 = a.new_pts[a.view.sord[s]];
+        if (!finite3(p0)) continue;
         const float pc[3] = {p0.x, p0.y, p0.z};
-        float kf[3], bmin[3], bmax[3], up_min[3], dn_max[3];
+        int iv[3];
+        float bmin[3], bmax[3], up_min[3], dn_max[3];
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            kf[ax] = voxel_floor(pc[ax], ds);
-            bmin[ax] = kf[ax] * ds; bmax[ax] = bmin[ax] + ds;
-            up_min[ax] = (kf[ax] + 1.0f) * ds; dn_max[ax] = (kf[ax] - 1.0f) * ds + ds;
+            iv[ax] = voxel_coord(pc[ax], ds);
+            const float kf = (float)iv[ax];
+            bmin[ax] = kf * ds; bmax[ax] = bmin[ax] + ds;
+            up_min[ax] = (kf + 1.0f) * ds; dn_max[ax] = (kf - 1.0f) * ds + ds;
         }
         int c0[3], c1[3];
 #pragma unroll
@@ -240,31 +251,18 @@ __global__ __launch_bounds__(64) void detect_shared_points_kernel(BoundaryArgs a
             if (!shared) continue;
             for (int m = 1; m < 8; ++m) {
                 bool use = true;
-                float k[3];
+                int k[3];
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax) {
                     const bool bit = (m >> ax) & 1;
                     if (bit && dir[ax] == 0) use = false;
-                    k[ax] = fminf(fmaxf(kf[ax] + (bit ? (float)dir[ax] : 0.0f), -1048576.0f), 1048575.0f);
+                    k[ax] = iv[ax] + (bit ? dir[ax] : 0);
                 }
                 if (!use) continue;
-                const uint64_t key = pack_key((uint32_t)((int)k[0] + CELL_OFF), (uint32_t)((int)k[1] + CELL_OFF), (uint32_t)((int)k[2] + CELL_OFF));
-                const uint32_t h = find_group(a.ukeys, n_groups, key);
-                if (h != 0xffffffffu) { a.dirty[h] = 1; a.dirty[g] = 1; }
+                const uint32_t h = find_voxel_group(a, n, k[0], k[1], k[2]);
+                if (h != 0xffffffffu) { mark_group_dirty(a, n, h); mark_group_dirty(a, n, s); }
             }
         }
-    }
-}
-
-// one lane per group: the points of dirty groups are marked with their own batch index (dlist[i] = i, 0xffffffff
-// otherwise); the marks, compacted in order, are the replay list
-__global__ __launch_bounds__(256) void gather_dirty_kernel(BoundaryArgs a) {
-    const uint32_t n_groups = *a.n_groups;
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
-        if (a.dirty[g] == 0) continue;
-        const uint32_t gs = a.group_start[g], gc = a.group_count[g];
-        atomicAdd(a.n_dirty, gc);
-        for (uint32_t j = 0; j < gc; ++j) { const uint32_t pt = a.order[gs + j]; a.dlist[pt] = pt; }
     }
 }
 
@@ -273,16 +271,16 @@ __global__ __launch_bounds__(256) void gather_dirty_kernel(BoundaryArgs a) {
 // directory, lanes 0..7 one cell each; points added earlier in this pass from a list), nearest to the box centre
 // wins (the new point on ties), delete-and-re-add when Storage held more than one point or the new point wins.
 // Everything that later iterations read back goes through agent-scope atomics (no stale L1 lines).
-__global__ __launch_bounds__(64) void fold_sequential_kernel(BoundaryArgs a, const uint32_t* dlist_sorted) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane) {
     const uint32_t n_dirty = *a.n_dirty;
+    if (n_dirty == 0u) return;
     uint32_t n_seq = 0, counter = 0, replaced = 0;
     float* seq = reinterpret_cast<float*>(a.seq_out);
     float* mp = reinterpret_cast<float*>(a.map_pts);
     auto ld = [](const float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto st = [](float* q, float v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     for (uint32_t it = 0; it < n_dirty; ++it) {
-        const float4 p = a.new_pts[dlist_sorted[it]];
+        const float4 p = a.new_pts[a.dlist[it]];
         const float ds = a.ds;
         float bmin[3], bmax[3], mid[3];
         const float pc[3] = {p.x, p.y, p.z};
@@ -368,47 +366,191 @@ __global__ __launch_bounds__(64) void fold_sequential_kernel(BoundaryArgs a, con
     }
 }
 
-// ---- incremental index update -------------------------------------------------------------------------
-// n_head != nullptr: the list is [*n_head points][n_after points] inside a buffer of n slots (the first count is still on
-// the device, lio_ctx.hip: add_batch_device); the slots behind them get a key no cell has, sort last and are dropped
-// by the run detection
-__global__ __launch_bounds__(256) void pend_keys_kernel(const float4* pend, uint32_t n, Grid grid, uint64_t* keys,
-                                                        uint32_t* order, const uint32_t* n_head, uint32_t n_after) {
-    const uint32_t n_real = n_head != nullptr ? min(n, *n_head + n_after) : n;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint64_t k = ~0ull;
-        if (i < n_real) {
-            const float4 p = pend[i];
-            k = pack_key((uint32_t)cell_coord(p.x, grid.inv_cell), (uint32_t)cell_coord(p.y, grid.inv_cell),
-                         (uint32_t)cell_coord(p.z, grid.inv_cell));
+// The parallel fold of the clean groups (workgroups 1 ..) and the sequential replay of the dirty points (workgroup 0) in
+// ONE launch: the two touch disjoint voxels and disjoint map points (a map point inside two boxes makes both groups dirty).
+__global__ __launch_bounds__(64) void fold_kernel(FoldArgs a, BoundaryArgs ba) {
+    const int lane = threadIdx.x, t = lane & 7;
+    if (blockIdx.x == 0) { fold_sequential(ba, lane); return; }
+    const uint32_t n = view_count(a.view);
+    const uint32_t spw = 8u;                                    // positions per wavefront
+    for (uint32_t s0 = (blockIdx.x - 1u) * spw; s0 < a.view.n; s0 += (gridDim.x - 1u) * spw) {    // (wave-uniform: all 64 lanes iterate together)
+        const uint32_t s = s0 + ((uint32_t)lane >> 3);
+        // heads only; boundary points around (dirty): replayed by workgroup 0
+        const bool valid = s < n && view_is_head(a.view, s) && a.dirty[s] == 0;
+        const uint64_t key = valid ? a.view.skey[s] : 0ull;
+        const float ds = a.ds;
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) p0 = a.new_pts[a.view.sord[s]];
+        // Box_of_Point and mid_point (:424-432): fp32 box, centre through double
+        float bmin[3], bmax[3], mid[3];
+        const float pc[3] = {p0.x, p0.y, p0.z};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            bmin[ax] = voxel_floor(pc[ax], ds) * ds;
+            bmax[ax] = bmin[ax] + ds;
+            mid[ax] = (float)((double)bmin[ax] + (double)(bmax[ax] - bmin[ax]) / 2.0);
         }
-        keys[i] = k;
-        order[i] = i;
+        int c0[3], c1[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            c0[ax] = cell_coord(bmin[ax], a.grid.inv_cell);
+            c1[ax] = cell_coord(bmax[ax], a.grid.inv_cell);
+        }
+        const int cx = c0[0] + ((t >> 2) & 1), cy = c0[1] + ((t >> 1) & 1), cz = c0[2] + (t & 1);
+        const bool mine = valid && cx <= c1[0] && cy <= c1[1] && cz <= c1[2];
+        // ---- pass 1: existing live points inside the box (Search_by_range :1015-1045) -------------
+        uint32_t st = 0, ct = 0;
+        if (mine) cell_find(a.l1table, a.l1mask, a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, st, ct);
+        uint32_t n_e = 0;
+        float d_e = __uint_as_float(INF_BITS);
+        float4 e_best = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t i = st; i < st + ct; ++i) {
+            const float4 sp = a.map_pts[i];
+            if (sp.w != 0.0f) continue;
+            if (bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z) {
+                ++n_e;
+                const float d = sqdist3(sp.x, sp.y, sp.z, mid[0], mid[1], mid[2]);
+                if (d < d_e) { d_e = d; e_best = sp; }
+            }
+        }
+        // combine the eight cells: count, and the first minimum in cell order
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            n_e += __shfl_xor(n_e, o, 64);
+            const float od = __shfl_xor(d_e, o, 64);
+            const float ox = __shfl_xor(e_best.x, o, 64), oy = __shfl_xor(e_best.y, o, 64), oz = __shfl_xor(e_best.z, o, 64);
+            // the partner holds the lower cell numbers iff its lane number is lower
+            const bool partner_first = ((t ^ o) < t);
+            const bool take = partner_first ? (od <= d_e) : (od < d_e);
+            if (take) { d_e = od; e_best = make_float4(ox, oy, oz, 0.0f); }
+        }
+        // ---- the fold over the group's new points (:433-449) ------------------------------------------------------
+        bool touched = false;
+        float4 cur = make_float4(0.f, 0.f, 0.f, 0.f);
+        float d_cur = 0.0f;
+        uint32_t counter = 0;
+        // a large group: its FOLD_WAVE_MIN-th record still carries the key
+        const bool big = valid && s + (FOLD_WAVE_MIN - 1u) < n && a.view.skey[s + (FOLD_WAVE_MIN - 1u)] == key;
+        if (valid && !big) {
+            // small group: point after point, identical in all eight lanes
+            for (uint32_t j = 0; j < FOLD_WAVE_MIN - 1u; ++j) {
+                if (j != 0u && (s + j >= n || a.view.skey[s + j] != key)) break;
+                const float4 p = a.new_pts[a.view.sord[s + j]];
+                const float d_p = sqdist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
+                if (!touched) {
+                    const bool best_is_p = !(n_e > 0 && d_e < d_p);
+                    const float4 best = best_is_p ? p : e_best;
+                    if (n_e > 1 || same_point(p, best)) {
+                        touched = true; cur = best; d_cur = best_is_p ? d_p : d_e; ++counter;
+                    }
+                } else {
+                    const bool best_is_p = !(d_cur < d_p);
+                    const float4 best = best_is_p ? p : cur;
+                    if (same_point(p, best)) { cur = best; d_cur = best_is_p ? d_p : d_cur; ++counter; }
+                }
+            }
+        }
+        // large groups of this wavefront, one after the other, by all 64 lanes
+        for (unsigned long long bm = __ballot(big && t == 0); bm != 0ull; bm &= bm - 1ull) {
+            const int l0 = __ffsll((long long)bm) - 1;
+            const uint32_t klo = (uint32_t)__shfl((int)(uint32_t)key, l0, 64), khi = (uint32_t)__shfl((int)(uint32_t)(key >> 32), l0, 64);
+            const FoldResult fr = fold_members_wave(a, n, (uint32_t)__shfl((int)s, l0, 64), ((uint64_t)khi << 32) | (uint64_t)klo,
+                                                    (uint32_t)__shfl((int)n_e, l0, 64), __shfl(d_e, l0, 64), __shfl(e_best.x, l0, 64),
+                                                    __shfl(e_best.y, l0, 64), __shfl(e_best.z, l0, 64), __shfl(mid[0], l0, 64),
+                                                    __shfl(mid[1], l0, 64), __shfl(mid[2], l0, 64), lane);
+            if ((lane >> 3) == (l0 >> 3)) {
+                touched = fr.touched; cur = make_float4(fr.x, fr.y, fr.z, 0.0f); d_cur = fr.d; counter = fr.counter;
+            }
+        }
+        // ---- pass 2: Delete_by_range of the box + Add_by_point of the survivor --------------------
+        uint32_t replaced = 0;
+        if (touched) {
+            for (uint32_t i = st; i < st + ct; ++i) {
+                float4 sp = a.map_pts[i];
+                if (sp.w != 0.0f) continue;
+                if (bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z) {
+                    // exchange, not store: the bookkeeping stays exact even if two boxes ever claimed the same point
+                    const uint32_t was = atomicExch(reinterpret_cast<uint32_t*>(&a.map_pts[i].w), __float_as_uint(TOMB_DOWNSAMPLE));
+                    if (was == 0u) ++replaced;
+                }
+            }
+        }
+        if (replaced != 0) atomicAdd(a.n_replaced, replaced);
+        if (valid && t == 0) {
+            if (touched) a.out_pts[s] = make_float4(cur.x, cur.y, cur.z, 0.0f);      // (every slot starts as "nothing")
+            if (counter != 0) atomicAdd(a.n_added, counter);
+        }
     }
 }
-// dst_base[*offset + i] = src[i]: a batch appended behind a list whose length is still on the device
-__global__ __launch_bounds__(256) void append_points_kernel(float4* dst_base, const uint32_t* offset, const float4* src, uint32_t n) {
-    const uint32_t off = *offset;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst_base[off + i] = src[i];
+
+// ---- incremental index update -------------------------------------------------------------------------
+// exclusive prefix over the tiles before tile b of one stamped count (lio_compact.hip's scheme), the tile's own count published first
+__device__ __forceinline__ bool plan_tile_prefix(uint32_t mine, uint32_t b, unsigned long long* agg, uint32_t stamp, uint32_t& before) {
+    __shared__ uint32_t s_sum[4];
+    __shared__ uint32_t s_bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_bad = 0u;
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(agg + b, (unsigned long long)mine | ((unsigned long long)stamp << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t acc = 0u;
+    bool bad = false;
+    for (uint32_t p = tid; p < b; p += 256u) {
+        unsigned long long v;
+        unsigned spins = 0;
+        do { v = __hip_atomic_load(agg + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        while ((uint32_t)(v >> 32) != stamp && ++spins < (1u << 22));
+        bad = bad || (uint32_t)(v >> 32) != stamp;
+        acc += (uint32_t)v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, 64);
+    if ((tid & 63) == 0) s_sum[tid >> 6] = acc;
+    if (bad) s_bad = 1u;
+    __syncthreads();
+    before = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    return s_bad == 0u;
 }
 
-// one lane per touched cell: where the cell is now and how large its re-written bucket will be
-__global__ __launch_bounds__(64) void cell_plan_kernel(ApplyArgs a) {
-    const uint32_t n_groups = *a.n_groups;
+// one lane per position of the cell-sorted pending list; heads: where the cell is now and how large its re-written bucket
+// will be -- and, in the same launch, the exclusive scan of those sizes (tiles of 256 positions, stamped tile sums)
+__global__ __launch_bounds__(256) void cell_plan_kernel(ApplyArgs a) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t n = view_count(a.view);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the statistics the apply kernel accumulates start from zero (nothing reads them before it)
-    if (blockIdx.x == 0 && threadIdx.x < 3) a.stats[threadIdx.x] = 0u;
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g <= a.n_scan; g += gridDim.x * blockDim.x) {
-        if (g >= n_groups) { a.new_size[g] = 0u; continue; }      // the scan of new_size runs over n_scan + 1 entries
-        const uint64_t key = a.cell_key[g];
-        const uint32_t cx = (uint32_t)(key >> 42) & 0x1fffffu, cy = (uint32_t)(key >> 21) & 0x1fffffu, cz = (uint32_t)key & 0x1fffffu;
+    if (blockIdx.x == 0 && tid < 3) a.stats[tid] = 0u;
+    const uint32_t s = blockIdx.x * 256u + (uint32_t)tid;
+    uint32_t size = 0u;
+    if (s < n && view_is_head(a.view, s)) {
+        const uint64_t key = a.view.skey[s] >> 1;                  // (the low bit tells the two lists apart, not the cells)
+        int cx, cy, cz;
+        frame_decode(a.frame, key, cx, cy, cz);
         CellPlan pl{0u, 0u, 0xffffffffu, 0u};
-        cell_find(a.ltable + a.levels.off[1], a.levels.mask[1], a.child, cx, cy, cz, pl.old_start, pl.old_count, &pl.index);
+        cell_find(a.ltable + a.levels.off[1], a.levels.mask[1], a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, pl.old_start, pl.old_count, &pl.index);
         pl.found = pl.old_count != 0u ? 1u : 0u;                  // records are only ever written with count >= 1
         uint32_t live = 0;
         for (uint32_t i = 0; i < pl.old_count; ++i) live += a.map_pts[pl.old_start + i].w == 0.0f ? 1u : 0u;
-        a.plan[g] = pl;
-        a.new_size[g] = live + a.group_count[g];
+        uint32_t gc = 1u;
+        while (s + gc < n && (a.view.skey[s + gc] >> 1) == key) ++gc;
+        a.plan[s] = pl;
+        size = live + gc;
     }
+    uint32_t inc = size;                                         // inclusive scan inside the wavefront
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+    const uint32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    uint32_t before;
+    const bool ok = plan_tile_prefix(tot, blockIdx.x, a.agg, a.stamp, before);
+    if (s < a.view.n) a.new_off[s] = ok ? before + off + inc - size : 0u;
+    if (!ok && tid == 0) atomicOr(a.err, 1u);
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) a.stats[3] = ok ? before + tot : 0xffffffffu;   // (a failed scan applies nothing)
 }
 
 // find-or-insert of a cell key; returns the slot, or 0xffffffff when the table is full
@@ -425,17 +567,17 @@ __device__ __forceinline__ uint32_t table_claim(HashEntry* table, uint32_t mask,
 }
 
 __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
-    const uint32_t n_groups = *a.n_groups;
+    const uint32_t n = view_count(a.view);
     // room check on the device (every lane sees the same total): either the whole batch is applied or nothing is
-    const uint32_t total = a.new_off[a.n_scan];
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.stats[3] = total;
+    const uint32_t total = a.stats[3];
     if ((uint64_t)a.tail + (uint64_t)total > (uint64_t)a.slots_cap) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.stats + 2, APPLY_FLAG_NO_ROOM);
         return;
     }
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += gridDim.x * blockDim.x) {
-        const CellPlan pl = a.plan[g];
-        const uint32_t dst0 = a.tail + a.new_off[g];
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        if (!view_is_head(a.view, s)) continue;
+        const CellPlan pl = a.plan[s];
+        const uint32_t dst0 = a.tail + a.new_off[s];
         uint32_t dst = dst0;
         uint32_t retired = 0;
         for (uint32_t i = 0; i < pl.old_count; ++i) {           // live points keep their order
@@ -446,15 +588,16 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
             a.map_pts[pl.old_start + i] = p;
             ++retired;
         }
-        const uint32_t gs = a.group_start[g], gc = a.group_count[g];
-        for (uint32_t j = 0; j < gc; ++j) {                      // then the new ones, in batch order
-            const float4 p = a.pend[a.order[gs + j]];
+        const uint64_t key = a.view.skey[s] >> 1;
+        for (uint32_t j = 0; s + j < n && (j == 0u || (a.view.skey[s + j] >> 1) == key); ++j) {   // then the new ones: survivors, then plain inserts, batch order
+            const float4 p = a.pend[a.view.sord[s + j]];
             a.map_pts[dst++] = make_float4(p.x, p.y, p.z, 0.0f);
         }
         const uint32_t count = dst - dst0;
         if (retired != 0) atomicAdd(a.stats + 1, retired);
-        const uint64_t key = a.cell_key[g];
-        const uint32_t cx = (uint32_t)(key >> 42) & 0x1fffffu, cy = (uint32_t)(key >> 21) & 0x1fffffu, cz = (uint32_t)key & 0x1fffffu;
+        int icx, icy, icz;
+        frame_decode(a.frame, key, icx, icy, icz);
+        const uint32_t cx = (uint32_t)icx, cy = (uint32_t)icy, cz = (uint32_t)icz;
         const uint32_t pos = ((cx & 3u) << 4) | ((cy & 3u) << 2) | (cz & 3u);        // place inside the child block
         if (pl.found) {
             a.child[pl.index] = make_uint2(dst0, count);
@@ -514,65 +657,33 @@ hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_classify_boundary(const BoundaryArgs& a, hipStream_t s) {
+hipError_t launch_voxel_keys(const VoxelKeyArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    uint32_t b = (a.n + 255u) / 256u; if (b > 4096u) b = 4096u;
-    hipLaunchKernelGGL(classify_boundary_kernel, dim3(b), dim3(256), 0, s, a);
+    uint32_t b = (a.n + 255u) / 256u; if (b > 1024u) b = 1024u;
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3(b), dim3(256), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_detect_shared_points(const BoundaryArgs& a, hipStream_t s) {
-    if (a.n == 0) return hipSuccess;
-    uint32_t b = (a.n + 7u) / 8u; if (b > 16384u) b = 16384u;
-    hipLaunchKernelGGL(detect_shared_points_kernel, dim3(b), dim3(64), 0, s, a);
+hipError_t launch_mark_boundary(const BoundaryArgs& a, hipStream_t s) {
+    if (a.view.n == 0) return hipSuccess;
+    uint32_t b = (a.view.n + 7u) / 8u; if (b > 16384u) b = 16384u;
+    hipLaunchKernelGGL(mark_boundary_kernel, dim3(b), dim3(64), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_gather_dirty(const BoundaryArgs& a, hipStream_t s) {
-    if (a.n == 0) return hipSuccess;
-    uint32_t b = (a.n + 255u) / 256u; if (b > 4096u) b = 4096u;
-    hipLaunchKernelGGL(gather_dirty_kernel, dim3(b), dim3(256), 0, s, a);
+hipError_t launch_fold(const FoldArgs& fa, const BoundaryArgs& ba, hipStream_t s) {
+    if (fa.view.n == 0) return hipSuccess;
+    uint32_t b = (fa.view.n + 7u) / 8u; if (b > 16384u) b = 16384u;
+    hipLaunchKernelGGL(fold_kernel, dim3(b + 1u), dim3(64), 0, s, fa, ba);
     return hipGetLastError();
 }
-hipError_t launch_fold_sequential(const BoundaryArgs& a, const uint32_t* dlist_sorted, hipStream_t s) {
-    if (a.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(fold_sequential_kernel, dim3(1), dim3(64), 0, s, a, dlist_sorted);
+hipError_t launch_cell_plan(const ApplyArgs& a, hipStream_t s) {
+    if (a.view.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(cell_plan_kernel, dim3((a.view.n + 255u) / 256u), dim3(256), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_pend_keys(const float4* pend, uint32_t n, Grid grid, uint64_t* keys, uint32_t* order, const uint32_t* n_head,
-                            uint32_t n_after, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    uint32_t b = (n + 255u) / 256u; if (b > 4096u) b = 4096u;
-    hipLaunchKernelGGL(pend_keys_kernel, dim3(b), dim3(256), 0, s, pend, n, grid, keys, order, n_head, n_after);
-    return hipGetLastError();
-}
-hipError_t launch_append_points(float4* dst_base, const uint32_t* offset, const float4* src, uint32_t n, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    uint32_t b = (n + 255u) / 256u; if (b > 1024u) b = 1024u;
-    hipLaunchKernelGGL(append_points_kernel, dim3(b), dim3(256), 0, s, dst_base, offset, src, n);
-    return hipGetLastError();
-}
-hipError_t launch_cell_plan(const ApplyArgs& a, uint32_t max_groups, hipStream_t s) {
-    if (max_groups == 0) return hipSuccess;
-    uint32_t b = (max_groups + 1u + 63u) / 64u; if (b > 8192u) b = 8192u;
-    hipLaunchKernelGGL(cell_plan_kernel, dim3(b), dim3(64), 0, s, a);
-    return hipGetLastError();
-}
-hipError_t launch_cell_apply(const ApplyArgs& a, uint32_t max_groups, hipStream_t s) {
-    if (max_groups == 0) return hipSuccess;
-    uint32_t b = (max_groups + 63u) / 64u; if (b > 8192u) b = 8192u;
+hipError_t launch_cell_apply(const ApplyArgs& a, hipStream_t s) {
+    if (a.view.n == 0) return hipSuccess;
+    uint32_t b = (a.view.n + 63u) / 64u; if (b > 8192u) b = 8192u;
     hipLaunchKernelGGL(cell_apply_kernel, dim3(b), dim3(64), 0, s, a);
-    return hipGetLastError();
-}
-hipError_t launch_voxel_keys(const float4* pts, uint32_t n, float ds, uint64_t* vkeys, uint32_t* order, uint32_t* zero2,
-                             uint8_t* dirty, uint32_t* dlist, float4* out2n, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    uint32_t b = (n + 255u) / 256u; if (b > 4096u) b = 4096u;
-    hipLaunchKernelGGL(voxel_keys_kernel, dim3(b), dim3(256), 0, s, pts, n, ds, vkeys, order, zero2, dirty, dlist, out2n);
-    return hipGetLastError();
-}
-hipError_t launch_fold_groups(const FoldArgs& a, hipStream_t s) {
-    if (a.n_groups_max == 0) return hipSuccess;
-    uint32_t b = (a.n_groups_max + 7u) / 8u; if (b > 16384u) b = 16384u;
-    hipLaunchKernelGGL(fold_groups_kernel, dim3(b), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

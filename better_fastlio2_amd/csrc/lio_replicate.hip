@@ -10,6 +10,7 @@
 //
 //   message = [ RepHeader 16 B | boxes 4 x 6 floats (96 B) | pad 16 B ] [ add: cap float4 ] [ nodown: cap float4 ]
 #include "lio_kernels.h"
+#include "lio_bbox.h"
 
 namespace lio {
 
@@ -52,9 +53,18 @@ __global__ __launch_bounds__(256) void replicate_compact_kernel(RepCompactArgs a
         flags |= __float_as_uint(h.w);
     }
     const float4* src = a.gathered + (size_t)r * stride + REP_HEADER_F4;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
-        if (i < n_add) a.add_out[off_add + i] = src[i];
-        if (i < n_nd) a.nodown_out[off_nd + i] = src[cap + i];
+    const uint32_t n_max = n_add > n_nd ? n_add : n_nd;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n_max; i0 += gridDim.x * blockDim.x) {      // (block-uniform: the box reduction has barriers)
+        const uint32_t i = i0 + threadIdx.x;
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pn = pa;
+        if (i < n_add) { pa = src[i]; a.add_out[off_add + i] = pa; }
+        if (i < n_nd) { pn = src[cap + i]; a.nodown_out[off_nd + i] = pn; }
+        // the bounding box of everything that was gathered: the frames of the batch's keys (lio_mapadd.h); it reaches the host
+        // with the totals
+        block_bbox(pa, i < n_add, a.bbox);
+        __syncthreads();
+        block_bbox(pn, i < n_nd, a.bbox);
+        __syncthreads();
     }
     if (blockIdx.x == 0) {
         const uint32_t nb = __float_as_uint(hdr.z);

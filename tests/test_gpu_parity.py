@@ -348,6 +348,105 @@ def test_map_mutation_parity(gpu_capi, oracle, small_case):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", [3, 4])
+def test_add_points_dense_voxels(gpu_capi, oracle, small_case, seed):
+    """Voxel groups of hundreds of points in ONE batch (an un-down-sampled scan on a near wall; eight replicas' lists): the
+    fold over such a group runs 64 points at a time (prefix-min, lio_mapadd.hip) and must leave what the reference's
+    one-insert-after-the-other rule leaves (ikd_Tree.cpp:422-449): same survivor, same tmp_counter -- with exact
+    duplicates, points equal to map points, equal distances to the voxel centre (mirror images: the later one wins),
+    voxels the map already holds zero / one / several points of, and group sizes on both sides of the 16-point and
+    64-point edges."""
+    w = small_case["world"]
+    rng = np.random.default_rng(seed)
+    base = np.ascontiguousarray(w.points[:60000])
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=1024, max_map_points=400_000)
+    ctx.map_build(base)
+    ref = oracle.RefIkdTree(0.2) if oracle.ref_available() else None
+    om = oracle.OracleMap(0.2); om.build(base)
+    if ref is not None:
+        ref.build(base)
+    key = lambda p: p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+    for rnd in range(3):
+        parts = []
+        sizes = [1, 2, 15, 16, 17, 63, 64, 65, 130, 400, 900] + list(rng.integers(1, 40, 30))
+        for n in sizes:
+            if rng.random() < 0.6:
+                anchor = base[rng.integers(0, len(base))]            # a voxel the map knows
+            else:
+                anchor = rng.uniform(-20, 20, 3).astype(np.float32) + np.float32([0, 0, 60])   # an empty one, far above the map
+            lo = np.floor(anchor / np.float32(0.2)) * np.float32(0.2)
+            pts = (lo + rng.uniform(0.01, 0.19, (n, 3))).astype(np.float32)
+            if n >= 4:
+                pts[n // 2] = pts[0]                                  # exact duplicates inside the group
+                mid = lo + np.float32(0.1)
+                pts[n - 1] = (2 * mid - pts[1]).astype(np.float32)    # (nearly) the same distance to the centre, later in the batch
+            if n >= 16 and rng.random() < 0.5:
+                pts[3] = anchor                                       # a point equal to a map point
+            parts.append(pts)
+        batch = np.concatenate(parts)
+        batch = np.ascontiguousarray(batch[rng.permutation(len(batch))])     # group members scattered over the batch
+        c_gpu = ctx.map_add(batch, True)
+        assert c_gpu == om.add(batch, True)
+        if ref is not None:
+            assert c_gpu == ref.add(batch, True)
+            assert ctx.map_validnum() == ref.validnum()
+            ref.quiesce(50)
+            assert bits_equal(key(ctx.map_flatten()), key(ref.flatten()))
+        assert bits_equal(key(ctx.map_flatten()), key(om.flatten()))
+    ctx.close()
+
+
+@pytest.mark.parametrize("shape", ["wide", "slab", "clumps"])
+def test_add_points_large_batches(gpu_capi, oracle, small_case, shape):
+    """Batches beyond the one-launch rank sort (lio_gsort.hip: partition by the top key digit + LDS bucket sorts): a wide batch
+    (every bucket small), a thin slab along the axis of the top digit (ONE bucket holds everything: the bucket that does not
+    fit LDS) and dense clumps (buckets on both sides of the LDS capacity, large voxel groups).  Down-sampled adds, plain adds
+    and the pair, against the reference tree: Add_Points' counter, validnum, the live set, searches afterwards."""
+    w = small_case["world"]
+    rng = np.random.default_rng(11)
+    base = np.ascontiguousarray(w.points[:60000])
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=1024, max_map_points=600_000)
+    ctx.map_build(base)
+    om = oracle.OracleMap(0.2); om.build(base)
+    ref = oracle.RefIkdTree(0.2) if oracle.ref_available() else None
+    if ref is not None:
+        ref.build(base)
+    key = lambda p: p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+
+    def batch(n):
+        if shape == "wide":
+            b = rng.uniform(-40, 40, (n, 3)); b[:, 2] = rng.uniform(-1, 3, n)
+        elif shape == "slab":
+            b = np.stack([rng.uniform(5.0, 5.3, n), rng.uniform(-60, 60, n), rng.uniform(-2, 10, n)], 1)
+        else:
+            centres = rng.uniform(-30, 30, (6, 3)); centres[:, 2] = rng.uniform(0, 2, 6)
+            b = centres[rng.integers(0, 6, n)] + rng.normal(0, 0.6, (n, 3))
+        return np.ascontiguousarray(b.astype(np.float32))
+
+    for rnd, n in enumerate((30000, 9000, 70000)):
+        add, plain = batch(n), batch(n // 3)
+        if rnd == 0:
+            assert ctx.map_add(add, True) == om.add(add, True)
+            assert ctx.map_add(plain, False) == om.add(plain, False) == 0
+        else:
+            cnt = ctx.map_add_pair(add, plain)
+            assert cnt == om.add(add, True)
+            om.add(plain, False)
+        if ref is not None:
+            ref.add(add, True); ref.add(plain, False)
+            assert ref.validnum() == ctx.map_validnum()
+        assert ctx.map_validnum() == om.validnum()
+        assert bits_equal(key(ctx.map_flatten()), key(om.flatten()))
+        q = batch(2000)
+        gx, gd, gc = ctx.nearest_search(q)
+        ox, od, oc, _ = om.knn(q)
+        assert np.array_equal(gc, oc) and bits_equal(gd, od)
+    if ref is not None:
+        ref.quiesce(100)
+        assert bits_equal(key(ctx.map_flatten()), key(ref.flatten()))
+    ctx.close()
+
+
 def test_edge_cases(gpu_capi, oracle, small_case):
     sc, st = small_case["scan"], small_case["state14"]
     ctx = gpu_capi.LioContext(0.2, max_scan_points=1000, max_map_points=10_000)
