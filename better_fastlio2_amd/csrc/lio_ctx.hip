@@ -714,7 +714,7 @@ int apply_pending(lio_ctx* c) {
     a.child = c->d_child; a.block_bump = c->d_apply + 9; a.blocks_cap = (uint32_t)c->child_blocks_cap;
     a.levels = c->levels;
     a.pend = c->d_pend;
-    a.view.skey = c->d_pkeys2; a.view.sord = c->d_porder2; a.view.n_dev = n_dev; a.view.n_add = c->plain_n; a.view.n = n_bound;
+    a.view.skey = c->d_pkeys2; a.view.sord = c->d_porder2; a.view.n_dev = n_dev; a.view.n_add = c->plain_n; a.view.n = n_bound; a.view.shift = 1;
     a.frame = cf; a.plan = c->d_plan; a.new_off = c->d_pnewoff; a.tail = c->n_points; a.stats = c->d_apply;
     a.slots_cap = (uint32_t)c->slots_cap;
     a.agg = c->d_cagg; a.stamp = next_compact_stamp(c); a.err = c->d_apply + 15;
@@ -1046,7 +1046,7 @@ static int fold_batch_device(lio_ctx* c, const float4* batch, uint32_t n, const 
     int rc = run_sort(c, kind, c->d_add_keys, c->d_add_order, c->d_add_keys2, c->d_add_order2, n, nullptr, 0, kb);
     if (rc != LIO_OK) return rc;
     GroupView view{};
-    view.skey = c->d_add_keys2; view.sord = c->d_add_order2; view.n_dev = nullptr; view.n_add = 0; view.n = n;
+    view.skey = c->d_add_keys2; view.sord = c->d_add_order2; view.n_dev = nullptr; view.n_add = 0; view.n = n; view.shift = 0;
     // boundary points (outside their own fp32 box / inside a neighbour's): their groups leave the parallel fold
     // and are replayed point by point
     BoundaryArgs ba{};

@@ -39,7 +39,7 @@ LIO_HD int voxel_coord(float v, float ds) {
 
 // ---- a batch grouped by key: what lio_gsort.hip leaves --------------------------------------------------------------
 // Sorted keys + the batch index of the record at every sorted position.  Equal keys are contiguous and in batch order;
-// a GROUP is named by the position of its first record (its HEAD): position s is a head iff s == 0 or skey[s-1] != skey[s].
+// a GROUP is named by the position of its first record (its HEAD): position s is a head iff s == 0 or the keys at s-1 and s differ.
 // No run-length arrays, no dense group numbers: kernels take one lane (group) per POSITION and only heads act.
 struct GroupView {
     const uint64_t* skey;
@@ -47,6 +47,8 @@ struct GroupView {
     const uint32_t* n_dev;          // optional: *n_dev + n_add records are real (the count is still on the device)
     uint32_t        n_add;
     uint32_t        n;              // records, or the launch bound when n_dev != nullptr
+    int             shift;          // groups are runs of equal (skey >> shift): 1 for the cell view, whose low key bit only orders
+                                    // the two insert lists INSIDE a cell
 };
 
 struct FoldArgs {

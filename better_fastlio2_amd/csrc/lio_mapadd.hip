@@ -24,7 +24,7 @@ namespace lio {
 __device__ __forceinline__ float voxel_floor(float v, float ds) { return floorf(v / ds); }   // :424
 
 __device__ __forceinline__ uint32_t view_count(const GroupView& v) { return v.n_dev != nullptr ? min(v.n, *v.n_dev + v.n_add) : v.n; }
-__device__ __forceinline__ bool view_is_head(const GroupView& v, uint32_t s) { return s == 0u || v.skey[s - 1u] != v.skey[s]; }
+__device__ __forceinline__ bool view_is_head(const GroupView& v, uint32_t s) { return s == 0u || (v.skey[s - 1u] >> v.shift) != (v.skey[s] >> v.shift); }
 // head position of the group with this key, or 0xffffffff
 __device__ __forceinline__ uint32_t view_find(const GroupView& v, uint32_t n, uint64_t key) {
     uint32_t lo = 0, hi = n;

@@ -4,7 +4,7 @@ tag=${1:-r03x}
 shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
-(time timeout 900 python -m pytest tests -m gpu -x -q "$@") > $O/pytest_gpu.log 2>&1
+(time timeout 900 python -m pytest tests -m gpu -q "$@") > $O/pytest_gpu.log 2>&1
 grep -a -E "passed|failed|error" $O/pytest_gpu.log | tail -3
 grep -a -E "^(FAILED|ERROR)|Error|assert" $O/pytest_gpu.log | head -20
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
