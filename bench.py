@@ -254,6 +254,75 @@ def cpu_baseline(world_pts, scan, x0, P0, max_iter: int, ext: bool, sample_every
     return out
 
 
+def callback_figures(ctx, capi, synth, world, scans, scan_poses, priors, P0_p, ulog_ref, ext_i, nq, kind, max_iter, k_steps, w_steps, step_own, tick, device):
+    """The ZERO-PATCH drop-in, timed (north_star: "exposed behind the same C++ callback signature so it drops into the existing
+    ROS node"): kf.update_iterated_dyn_share_modified -> h_share_model(state_ikfom&, dyn_share_datastruct&) with
+    include/lio_hip_adaptor.hpp behind the callback (examples/callback_bench.cpp), the down-sampled scan a host-resident PCL
+    cloud (48-byte points, uploaded by the first pass of every scan), every pass synchronous, h_x (m x 12, column-major) and h
+    brought back and h_x^T h_x formed on one host core (esekfom.hpp:1790,1810).  value_callback_patched: the callback hands
+    over lio_measure's reduced form instead (INTEGRATION.md section 3's two-line edit of esekfom.hpp).  Both at the bench's
+    scan size and at the size a node's 0.5 m voxel filter leaves of such a sweep (~8.6 k points)."""
+    import ctypes as C
+    B = capi.callback_bench()
+    out = {}
+    kf = capi.Esekf(max_iter)
+    n_rot = len(scans)
+
+    def run(name, scan_ids, x_ptrs, patched, k_steps):
+        def f():
+            k = tick[0] % n_rot
+            tick[0] += 1
+            rc = B.cbb_step(kf.h, scan_ids[k], x_ptrs[k], P0_p, 0.001, ext_i, patched, ulog_ref)
+            if rc != 0:
+                raise capi.LioError(f"{name}: cbb_step failed ({rc}): " + ctx.L.lio_last_error(ctx.h).decode())
+        tick[0] = 0
+        lat = []
+        t = timed_steps(f, k_steps, w_steps, None, device, lat)
+        return {"value": k_steps / t, "unit": "scans/s", "ms_per_step": t / k_steps * 1e3, "steps": k_steps, "rows_per_pass": int(B.cbb_last_m()),
+                "latency": latency_summary(lat)}
+
+    B.cbb_setup(ctx.h, nq)
+    x_p = [x.ctypes.data_as(C.c_void_p) for x in priors]
+    ids = []
+    for sc in scans:
+        b = np.ascontiguousarray(sc.body, np.float32)
+        ids.append(B.cbb_add_scan(b.ctypes.data_as(C.c_void_p), len(b), 3))
+    out["value_callback"] = run("value_callback", ids, x_p, 0, k_steps)
+    out["value_callback_patched"] = run("value_callback_patched", ids, x_p, 1, k_steps)
+    # the node's real scan size: the same drive, sweeps down-sampled to ~8.6 k points
+    n_small = 8600
+    small, small_x, small_ids = [], [], []
+    for k, sc in enumerate(scans):
+        s2 = synth.make_scan(world, n_small, kind=kind, seed=synth.SEED + 101 + 17 * k, pos=scan_poses[k][0], rpy=scan_poses[k][1])
+        ps, rt = synth.perturb_state(s2, seed=synth.SEED + 2 + 7 * k)
+        small.append(s2)
+        small_x.append(np.ascontiguousarray(capi.make_state26(ps, rt, s2.off_R, s2.off_T), np.float64))
+        b = np.ascontiguousarray(s2.body, np.float32)
+        small_ids.append(B.cbb_add_scan(b.ctypes.data_as(C.c_void_p), len(b), 3))
+    sx_p = [x.ctypes.data_as(C.c_void_p) for x in small_x]
+    node = {"scan_points": n_small,
+            "value_callback": run("value_callback@8.6k", small_ids, sx_p, 0, max(k_steps, 40)),
+            "value_callback_patched": run("value_callback_patched@8.6k", small_ids, sx_p, 1, max(k_steps, 40))}
+    # the library's own overlapped filter on the same small scans, each uploaded with a blocking lio_scan_set (like the callback does)
+    L = ctx.L
+    bodies = [np.ascontiguousarray(np.concatenate([s2.body, np.zeros((len(s2.body), 1), np.float32)], 1)) for s2 in small]
+
+    def own():
+        k = tick[0] % n_rot
+        tick[0] += 1
+        rc = L.lio_scan_set(ctx.h, bodies[k].ctypes.data_as(C.c_void_p), n_small, 16)
+        if rc == 0:
+            rc = L.lio_eskf_scan_step_device(kf.h, ctx.h, sx_p[k], P0_p, None, n_small, 0.001, ext_i, ulog_ref)
+        if rc != 0:
+            raise capi.LioError("own filter @8.6k failed")
+    tick[0] = 0
+    t = timed_steps(own, max(k_steps, 40), w_steps, None, device)
+    node["value_library_filter_serial_upload"] = {"value": max(k_steps, 40) / t, "unit": "scans/s", "ms_per_step": t / max(k_steps, 40) * 1e3}
+    out["callback_at_node_scan_size"] = node
+    ctx.measure_want_rows(False)
+    return out
+
+
 def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, P0_p, ulog_ref, k_steps, n_rot, step_own, tick,
                         device, node_loop_1):
     """What ONE rank of a W-GPU job does per scan, measured on one GPU ("the only serial term is
@@ -321,6 +390,7 @@ def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, 
            "inserted_per_step": (acc["n_add"] + acc["n_nodown"]) / n,
            "incremental_index_updates": info["n_incremental_updates"] - info0["n_incremental_updates"],
            "full_index_rebuilds": info["n_full_rebuilds"] - info0["n_full_rebuilds"],
+           "boundary_points_replayed_per_step": (info["n_boundary_points"] - info0["n_boundary_points"]) / max(info["n_incremental_updates"] - info0["n_incremental_updates"], 1),
            "vs_node_loop_world1": (1.0 / per_step) / node_loop_1["value"],
            "latency": latency_summary(lat),
            "how": f"one GPU, lio_debug_set replicate_loopback: {W - 1} virtual ranks park their lists (untimed), the timed rank "
@@ -379,10 +449,11 @@ def main():
     px, py = (3.1, -2.2) if rank == 0 else tuple(rng.uniform(-0.3, 0.3, 2) * world.ground_half)
     yaw = 0.52 if rank == 0 else float(rng.uniform(-3.1, 3.1))
     P0 = synth.init_cov()
-    scans, priors, h_scans, d_scans = [], [], [], []
+    scans, priors, h_scans, d_scans, scan_poses = [], [], [], [], []
     for k in range(max(1, a.rotate)):
+        scan_poses.append(((px + 0.9 * k, py + 0.4 * k, 0.0), (0.004, -0.006, yaw + 0.05 * k)))
         sc = synth.make_scan(world, nq, kind=kind, seed=synth.SEED + 1 + rank + 17 * k,
-                             pos=(px + 0.9 * k, py + 0.4 * k, 0.0), rpy=(0.004, -0.006, yaw + 0.05 * k))
+                             pos=scan_poses[-1][0], rpy=scan_poses[-1][1])
         ps, rt = synth.perturb_state(sc, seed=synth.SEED + 2 + rank + 7 * k)
         scans.append(sc)
         priors.append(np.ascontiguousarray(capi.make_state26(ps, rt, sc.off_R, sc.off_T), np.float64))
@@ -502,6 +573,9 @@ def main():
             tick[0] = 0
             t = timed_steps(fn, k_extra, w_extra, dist, device)
             extras[name] = {"value": world_size * k_extra / t, "unit": "scans/s", "ms_per_step": t / k_extra * 1e3, "steps": k_extra}
+        if dist is None:
+            extras.update(callback_figures(ctx, capi, synth, world, scans, scan_poses, priors, P0_p, ulog_ref, ext_i, nq, kind, max_iter, k_extra, w_extra,
+                                           step_resident, tick, device))
         # node loop: scan step + map_incremental (+ exchange) -- mutates the map, so it runs last
         maint = {"n_add": 0, "n_nodown": 0, "seconds": 0.0, "steps": 0}
 
@@ -538,6 +612,7 @@ def main():
                                "inserted_per_step": (maint["n_add"] + maint["n_nodown"]) / max(maint["steps"], 1),
                                "exchange": "lio_replicate_step: one ncclAllGather (RCCL over xGMI) on the library's stream" if dist is not None else "none (1 rank)",
                                "incremental_index_updates": info["n_incremental_updates"], "full_index_rebuilds": info["n_full_rebuilds"],
+                               "boundary_points_replayed_per_step": info["n_boundary_points"] / max(info["n_incremental_updates"], 1),
                                "latency": latency_summary(lat_node)}
         if dist is None and a.emulate_world > 1:
             extras["node_loop_emulated_world%d" % a.emulate_world] = emulated_world_loop(

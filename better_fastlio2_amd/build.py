@@ -77,5 +77,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_callback_bench() -> str:
+    """examples/callback_bench.cpp -> lib/libcallback_bench.so: the zero-patch drop-in chain (the adaptor header behind the
+    reference's callback signature) as a small host library that bench.py and the tests drive; plain g++ against the C ABI."""
+    lib = build()
+    src = os.path.join(ROOT, "examples", "callback_bench.cpp")
+    out = os.path.join(PKG, "lib", "libcallback_bench.so")
+    deps = [src, os.path.join(ROOT, "include", "lio_hip_adaptor.hpp"), os.path.join(ROOT, "include", "lio_hip.h"), lib]
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+        return out
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "tests", "csrc", "adaptor_stubs"), src, "-o", out, "-L", os.path.dirname(lib), "-llio_hip",
+           "-Wl,-rpath," + os.path.dirname(lib)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed on callback_bench.cpp:\n{r.stdout}\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    print(build_callback_bench())

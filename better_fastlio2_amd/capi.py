@@ -47,7 +47,7 @@ class lio_map_info(C.Structure):
     _fields_ = [("n_points", C.c_longlong), ("n_live", C.c_longlong), ("n_cells", C.c_longlong),
                 ("table_slots", C.c_longlong), ("cell_size", C.c_float), ("downsample_size", C.c_float),
                 ("bytes_resident", C.c_longlong), ("n_retired", C.c_longlong), ("n_incremental_updates", C.c_longlong),
-                ("n_full_rebuilds", C.c_longlong)]
+                ("n_full_rebuilds", C.c_longlong), ("n_boundary_points", C.c_longlong)]
 
 
 class lio_update_log(C.Structure):
@@ -65,7 +65,7 @@ EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_device_count", "lio_stream", "lio_synchronize",
     "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_replicate_unique_id", "lio_replicate_init", "lio_replicate_finalize", "lio_replicate_queue_boxes", "lio_replicate_step", "lio_fov_segment", "lio_map_reconstruct",
     "lio_map_set_downsample_param", "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_acquire_removed_points", "lio_map_get_info", "lio_map_nearest_search",
-    "lio_scan_set", "lio_scan_set_device", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_get_neighbors",
+    "lio_scan_set", "lio_scan_set_device", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_measure_want_rows", "lio_eskf_update_iterated_dyn_share_callback", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get", "lio_debug_set", "lio_debug_stamps",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
     "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_eskf_scan_step_device", "lio_eskf_scan_step_pipelined", "lio_state_boxplus",
@@ -145,6 +145,7 @@ def load(build_if_missing: bool = True):
     L.lio_scan_swap.argtypes = [_vp]
     L.lio_host_alloc.argtypes = [C.c_size_t]
     L.lio_host_alloc.restype = _vp
+    L.lio_measure_want_rows.argtypes = [_vp, C.c_int]
     L.lio_host_free.argtypes = [_vp]
     L.lio_host_free.restype = None
     L.lio_scan_undistort.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]
@@ -211,6 +212,23 @@ def pinned_points(xyz) -> np.ndarray:
     arr[:] = 0.0
     arr[:, :xyz.shape[1]] = xyz[:, :4]            # [n, 4] input: x, y, z, t records (a raw sweep)
     return arr
+
+
+_cbb = None
+
+
+def callback_bench():
+    """ctypes handle of lib/libcallback_bench.so (examples/callback_bench.cpp): the zero-patch callback chain."""
+    global _cbb
+    if _cbb is None:
+        load()
+        B = C.CDLL(_build.build_callback_bench())
+        B.cbb_setup.argtypes = [_vp, C.c_int]
+        B.cbb_add_scan.argtypes = [_vp, C.c_int, C.c_int]
+        B.cbb_step.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp]
+        B.cbb_last_m.restype = C.c_int
+        _cbb = B
+    return _cbb
 
 
 def replicate_unique_id() -> bytes:
@@ -450,11 +468,17 @@ class LioContext:
                 "HTH": np.array(o.HTH, dtype=np.float64).reshape(12, 12), "HTh": np.array(o.HTh, dtype=np.float64),
                 "n_candidates": int(o.n_candidates)}
 
-    def measure_rows(self, m: int):
-        h_x = np.zeros((max(m, 1), 12), np.float64)
+    def measure_rows(self, m: int, col_major: bool = False):
+        h_x = np.zeros((12, max(m, 1)) if col_major else (max(m, 1), 12), np.float64)
         h = np.zeros(max(m, 1), np.float64)
-        self._chk(self.L.lio_measure_rows(self.h, _ptr(h_x), _ptr(h), m, 0), "lio_measure_rows")
+        self._chk(self.L.lio_measure_rows(self.h, _ptr(h_x), _ptr(h), m, int(col_major)), "lio_measure_rows")
+        if col_major:                                           # Eigen's layout, leading dimension m: as a [m, 12] view
+            return h_x.reshape(-1)[:12 * m].reshape(12, m).T, h[:m]
         return h_x[:m], h[:m]
+
+    def measure_want_rows(self, on: bool = True):
+        """lio_measure_want_rows: the following passes stage h_x / h compacted on the device (the callback path)."""
+        self._chk(self.L.lio_measure_want_rows(self.h, int(on)), "lio_measure_want_rows")
 
     def neighbors(self):
         n = self.L.lio_scan_size(self.h)

@@ -251,6 +251,32 @@ hipError_t launch_pend_build(const PendBuildArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- the rows of a measurement pass for the unmodified callback path: selected points only, scan order, column-major ----
+__global__ __launch_bounds__(256) void rows_compact_kernel(RowsCompactArgs a) {
+    __shared__ uint32_t s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < a.nq && a.sel[i] != 0;
+    uint32_t tot;
+    const uint32_t r = tile_rank(live, tot, s_w);
+    const uint32_t mine[1] = {tot};
+    uint32_t before[1];
+    const bool ok = tile_exclusive_prefix<1>(mine, a.agg, a.stamp, before);
+    if (ok && live) {
+        const size_t m = (size_t)*a.m_dev, row = (size_t)before[0] + r;
+        if (row < m) {                                                     // (m == 0: the pass failed; nothing is written)
+            const double* src = a.rows + (size_t)i * 13;
+#pragma unroll
+            for (int c = 0; c < 13; ++c) a.dst[(size_t)c * m + row] = src[c];
+        }
+    }
+    if (!ok && threadIdx.x == 0) atomicOr(a.err, 1u);
+}
+hipError_t launch_rows_compact(const RowsCompactArgs& a, hipStream_t s) {
+    if (a.nq <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rows_compact_kernel, dim3((a.nq + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // ---- exclusive scan of u32[n] ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void exclusive_scan_kernel(const uint32_t* in, uint32_t n, uint32_t* out, u64* agg, uint32_t stamp, uint32_t* err) {
     __shared__ uint32_t s_w[4];

@@ -71,7 +71,8 @@ struct lio_ctx {
     size_t slots_cap = 0;                      // physical slots of d_pts / d_pts_tmp (cap_map + room for re-written buckets)
     uint32_t n_retired = 0;                    // TOMB_MOVED slots since the last full rebuild
     uint32_t n_dead = 0;                       // box-deleted slots since the last full rebuild
-    long long n_incremental_updates = 0, n_full_rebuilds = 0;
+    long long n_incremental_updates = 0, n_full_rebuilds = 0, n_boundary_points = 0;
+    long long dbg_retired_budget = 0;          // lio_debug_set("retired_budget"): overrides the budget of retired slots (tests)
     uint32_t n_new_cells = 0, n_cells_built = 0;   // cells inserted since / present at the last full rebuild
     uint32_t level_entries[TREE_MAX_LEVELS]{};     // entries of each hashed level at the last full rebuild
     // An index update in the making (Add_Points called, the index not yet updated): the survivor slots of ONE down-sampled
@@ -129,6 +130,13 @@ struct lio_ctx {
     unsigned long long* d_useeds = nullptr;    // [list entry][8]: keys of their 27-cell results, the seeds of the walk; [5] = its verdict
     double* d_spec_rows = nullptr;             // [scan point][SPEC_STRIDE]: staged rows of listed queries (search passes with few of them)
     double* d_rows = nullptr;
+    // the unmodified-callback path (lio_measure_want_rows): every pass also leaves h_x / h compacted and column-major
+    bool want_rows = false;
+    bool rows_staged = false;                  // the last pass did
+    double* d_rows_c = nullptr;                // device copy of the compacted rows (large scans: moved by the copy engine)
+    double* h_rows = nullptr;                  // pinned + mapped: the kernel writes small results straight into it
+    double* d_rows_mapped = nullptr;           // device alias of h_rows
+    int dbg_rows_direct = -1;                  // lio_debug_set("rows_direct"): -1 auto, 0 always through d_rows_c, 1 always direct
     unsigned long long *d_units = nullptr, *d_gunits = nullptr;   // stamped partial sums of the residual kernel's reduction
     DeviceOut* h_out = nullptr;                // pinned + mapped: the final reduction writes it directly
     DeviceOut* d_out = nullptr;                // device alias of h_out
@@ -667,7 +675,7 @@ int rebuild_full(lio_ctx* c) {
         uint32_t st[32] = {};
         const int rc = fetch_batch_counts(c, st);
         if (rc != LIO_OK) return rc;
-        if (c->fold_n != 0) { c->n_live -= st[4]; c->last_add_counter = (int)st[5]; }
+        if (c->fold_n != 0) { c->n_live -= st[4]; c->last_add_counter = (int)st[5]; c->n_boundary_points += st[10]; }
         n_pend = c->plain_n + (c->fold_n != 0 ? st[6] : 0u);
         c->fold_n = 0; c->plain_n = 0; c->plain_ptr = nullptr; c->pend_built = false; c->batch_box = HostBox{};
     }
@@ -726,7 +734,7 @@ int apply_pending(lio_ctx* c) {
     if (st[2] & APPLY_FLAG_NO_ROOM) return rebuild_full(c);    // nothing was changed: the pending points go in there
     // the counts of the down-sampled Add_Points arrive with this read-back (no host round trip of their own)
     const uint32_t n_real = c->plain_n + (c->fold_n != 0 ? st[6] : 0u);
-    if (c->fold_n != 0) { c->n_live -= st[4]; c->last_add_counter = (int)st[5]; }
+    if (c->fold_n != 0) { c->n_live -= st[4]; c->last_add_counter = (int)st[5]; c->n_boundary_points += st[10]; }
     c->fold_n = 0; c->plain_n = 0; c->plain_ptr = nullptr; c->pend_built = false; c->batch_box = HostBox{};
     const uint32_t total = st[3];
     c->n_points += total;
@@ -737,7 +745,7 @@ int apply_pending(lio_ctx* c) {
     // Retired copies of re-written buckets (TOMB_MOVED) cost memory and nothing else -- no search ever reads them: they may
     // grow until the array would be half dead.  Box-deleted points sit INSIDE live buckets and are streamed by every
     // search that passes: their budget stays tight.
-    const uint32_t retired_budget = c->n_live / 2 > 262144u ? c->n_live / 2 : 262144u;
+    const uint32_t retired_budget = c->dbg_retired_budget > 0 ? (uint32_t)c->dbg_retired_budget : (c->n_live / 2 > 262144u ? c->n_live / 2 : 262144u);
     const uint32_t dead_budget = c->n_live / 8 > 65536u ? c->n_live / 8 : 65536u;
     // Keep every hashed level at most half full (they are built a quarter full; the apply kernel counts the entries a
     // level gains), so that probe sequences stay short and a look-up of an absent key always meets an empty slot --
@@ -954,7 +962,7 @@ void lio_destroy(lio_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_gs_part, c->d_gs_part2, c->d_porder, c->d_porder2, c->d_pnewoff, c->d_plan, c->d_ghist, c->d_gagg, c->d_apply, c->d_temp, c->d_counters, c->d_cagg, c->d_cand, c->d_boxes,
-                   c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_useeds, c->d_spec_rows, c->d_rows,
+                   c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_useeds, c->d_spec_rows, c->d_rows, c->d_rows_c,
                    c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, c->d_qs_useeds,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
@@ -963,6 +971,7 @@ void lio_destroy(lio_ctx* c) {
                    c->d_rep_send, c->d_rep_recv};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->h_rows) (void)hipHostFree(c->h_rows);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_scratch) (void)hipHostFree(c->h_scratch);
     for (int w = 0; w < LIO_PROF_COUNT; ++w)
@@ -1692,6 +1701,7 @@ int lio_map_get_info(lio_ctx* c, lio_map_info* info) {
     info->table_slots = (long long)c->levels.mask[1] + 1;
     info->cell_size = c->grid.cell; info->downsample_size = c->cfg.filter_size_map_min;
     info->n_retired = c->n_retired; info->n_incremental_updates = c->n_incremental_updates; info->n_full_rebuilds = c->n_full_rebuilds;
+    info->n_boundary_points = c->n_boundary_points;
     info->bytes_resident = (long long)c->n_points * (long long)(sizeof(float4) + sizeof(uint64_t)) +
                            (long long)c->ltable_slots * (long long)sizeof(HashEntry) + (long long)c->child_blocks_cap * 512ll;
     return LIO_OK;
@@ -2003,6 +2013,25 @@ int lio_scan_get_cloud(lio_ctx* c, int which, float* out_xyz, int cap, int* n) {
     return LIO_OK;
 }
 
+// buffers of the callback path's rows (lio_measure_want_rows): staged [nq][13], compacted 13 x m on the device and in pinned
+// host memory the kernels can write
+static int ensure_rows_buffers(lio_ctx* c) {
+    const size_t bytes = (size_t)c->cap_q * 13 * sizeof(double);
+    if (!c->d_rows) HIPCHK(c, hipMalloc((void**)&c->d_rows, bytes));
+    if (!c->d_rows_c) HIPCHK(c, hipMalloc((void**)&c->d_rows_c, bytes));
+    if (!c->h_rows) {
+        HIPCHK(c, hipHostMalloc((void**)&c->h_rows, bytes, hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_rows_mapped, c->h_rows, 0));
+    }
+    return LIO_OK;
+}
+// small results are written over PCIe by the compaction kernel itself (they arrive with the pass, no copy to wait for);
+// large ones go through device memory and the copy engine (twice the rate of a kernel's stores to host memory)
+static bool rows_direct(const lio_ctx* c, int nq) {
+    if (c->dbg_rows_direct >= 0) return c->dbg_rows_direct != 0;
+    return (size_t)nq * 13 * sizeof(double) <= (2u << 20);
+}
+
 // One pass = lio_measure_begin (enqueue the kernels, return at once) + lio_measure_end (wait for the result record).
 // The host work of the caller that does not depend on the result -- in the iterated update: x [-] x_prop, the
 // Jacobian-corrected P and its first inversion (esekfom.hpp:1655-1703, :1788) -- runs between the two, beside the GPU.
@@ -2040,6 +2069,12 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     const unsigned long long seq = ++c->seq;
     ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
     ra.debug_fail = (c->dbg_force_timeout ? 1 : 0) | (c->dbg_stamps ? 2 : 0);
+    c->rows_staged = false;
+    if (c->want_rows) {
+        const int rc = ensure_rows_buffers(c);
+        if (rc != LIO_OK) { c->pass_in_flight = false; return rc; }
+        ra.rows = c->d_rows; ra.m_dev = reinterpret_cast<int*>(c->d_counters + 18);
+    }
     if (do_search && !separate_walk) {
         ra.n_walkers = residual_walkers(nq); ra.walk_done = c->d_counters + 16;
         ra.tree = tree_args(c, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds);
@@ -2047,6 +2082,16 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     }
     const hipError_t le = launch_residual(ra, do_search != 0, ext, s, prof_timer(c, LIO_PROF_RESIDUAL));
     if (le != hipSuccess) { c->pass_in_flight = false; return c->fail(LIO_ERR_HIP, "launch_residual", hipGetErrorString(le)); }
+    if (c->want_rows) {
+        // right behind the pass: the rows of the selected points, compacted in scan order, column-major (m read on the device)
+        RowsCompactArgs rc{};
+        rc.rows = c->d_rows; rc.sel = c->d_sel; rc.nq = nq; rc.m_dev = reinterpret_cast<const int*>(c->d_counters + 18);
+        rc.dst = rows_direct(c, nq) ? c->d_rows_mapped : c->d_rows_c;
+        rc.agg = c->d_cagg; rc.stamp = next_compact_stamp(c); rc.err = c->d_apply + 15;
+        const hipError_t ce = launch_rows_compact(rc, s);
+        if (ce != hipSuccess) { lio_out dropped; (void)lio_measure_end(c, &dropped); return c->fail(LIO_ERR_HIP, "launch_rows_compact", hipGetErrorString(ce)); }
+        c->rows_staged = true;
+    }
     // the next scan's upload, if one was handed over (lio_scan_upload_async): issued here, behind this pass's
     // launches, so that the runtime calls of the copy run while the GPU is busy with the pass
     if (c->upload_pending) {
@@ -2110,6 +2155,12 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
     return lio_measure_end(c, out);
 }
 
+int lio_measure_want_rows(lio_ctx* c, int on) {
+    if (!c) return LIO_ERR_INVALID_ARG;
+    c->want_rows = on != 0;
+    return LIO_OK;
+}
+
 int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_major) {
     if (!c || !h_x || !h) return LIO_ERR_INVALID_ARG;
     if (!c->have_pass) return c->fail(LIO_ERR_NO_SCAN, "lio_measure_rows", "no measurement pass yet");
@@ -2118,6 +2169,22 @@ int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_m
     if (cap_rows < m) return c->fail(LIO_ERR_CAPACITY, "lio_measure_rows", "cap_rows < m");
     if (m == 0) return LIO_OK;
     hipStream_t s = c->stream;
+    if (c->rows_staged) {
+        // the pass left them compacted and column-major (lio_measure_want_rows): nothing is re-evaluated, nothing but the m
+        // rows crosses PCIe -- written by the kernel itself (small scans) or moved by the copy engine (large ones)
+        if (!rows_direct(c, nq))
+            HIPCHK(c, hipMemcpyAsync(c->h_rows, c->d_rows_c, (size_t)m * 13 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, stream_wait(c));
+        const double* src = c->h_rows;
+        if (col_major) {
+            std::memcpy(h_x, src, (size_t)m * 12 * sizeof(double));
+        } else {
+            for (int cidx = 0; cidx < 12; ++cidx)
+                for (int r = 0; r < m; ++r) h_x[(size_t)r * 12 + cidx] = src[(size_t)cidx * m + r];
+        }
+        std::memcpy(h, src + (size_t)12 * m, (size_t)m * sizeof(double));
+        return LIO_OK;
+    }
     if (!c->d_rows) HIPCHK(c, hipMalloc((void**)&c->d_rows, (size_t)c->cap_q * 13 * sizeof(double)));
     // Re-evaluate the rows of the selected points with the pose of the last pass: selection flags
     // are a fixed point of the no-search pass (same neighbours, same pose -> same decisions).
@@ -2216,6 +2283,8 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "library_sort") == 0) { c->dbg_library_sort = value != 0; return LIO_OK; }
     if (std::strcmp(key, "stamps") == 0) { c->dbg_stamps = value != 0; return LIO_OK; }
     if (std::strcmp(key, "knn_tune") == 0) { c->dbg_knn_tune = (int)value; return LIO_OK; }
+    if (std::strcmp(key, "rows_direct") == 0) { c->dbg_rows_direct = (int)value; return LIO_OK; }
+    if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
     if (std::strcmp(key, "replicate_loopback") == 0) { c->dbg_rep_loopback = value != 0; return LIO_OK; }
     if (std::strcmp(key, "replicate_loopback_rank") == 0) {
         if (!c->rep_loopback || value < 0 || value >= c->rep_world) return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "replicate_loopback_rank outside a loop-back world");
@@ -2317,6 +2386,70 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
         log->solve_seconds = st.solve_seconds; log->measure_seconds = st.measure_seconds;
     }
     return status;
+}
+// esekf with a caller-supplied h_dyn_share (esekfom.hpp:239-258): the callback answers with rows, the products
+// h_x^T h_x / h_x^T h are formed here (esekfom.hpp:1790,1810) -- column blocks that stay in the L1 / L2 of one core
+int lio_eskf_update_iterated_dyn_share_callback(lio_eskf* kf, double R, lio_h_dyn_share_fn h, void* user, lio_update_log* log) {
+    if (!kf || !h || !(R > 0.0)) return LIO_ERR_INVALID_ARG;
+    kf->kf.set_measurement_model([&](lio::state_ikfom& s, lio::dyn_share_datastruct& d) {
+        double x26[26];
+        s.to_array(x26);
+        lio_dyn_share ds{};
+        ds.converge = d.converge ? 1 : 0;
+        ds.valid = 1;
+        h(user, x26, &ds);
+        d.valid = ds.valid != 0;
+        d.m = ds.m;
+        d.res_mean = 0.0;
+        if (!d.valid) return;
+        if (ds.h_x == nullptr) {
+            std::memcpy(d.HTH, ds.HTH, sizeof(d.HTH));
+            std::memcpy(d.HTh, ds.HTh, sizeof(d.HTh));
+        } else {
+            const size_t m = (size_t)ds.m;
+            double acc[12][13] = {};
+            constexpr size_t BLK = 256;                         // 13 column slices of 2 KB
+            for (size_t i0 = 0; i0 < m; i0 += BLK) {
+                const size_t len = m - i0 < BLK ? m - i0 : BLK;
+                for (int a = 0; a < 12; ++a) {
+                    const double* ca = ds.h_x + (size_t)a * m + i0;
+                    for (int b = a; b < 12; ++b) {
+                        const double* cb = ds.h_x + (size_t)b * m + i0;
+                        double t = 0.0;
+                        for (size_t i = 0; i < len; ++i) t += ca[i] * cb[i];
+                        acc[a][b] += t;
+                    }
+                    const double* ch = ds.h + i0;
+                    double t = 0.0;
+                    for (size_t i = 0; i < len; ++i) t += ca[i] * ch[i];
+                    acc[a][12] += t;
+                }
+            }
+            for (int a = 0; a < 12; ++a) {
+                for (int b = a; b < 12; ++b) { d.HTH[a * 12 + b] = acc[a][b]; d.HTH[b * 12 + a] = acc[a][b]; }
+                d.HTh[a] = acc[a][12];
+            }
+        }
+        if (ds.m < lio::DOF && ds.h_x != nullptr) {            // dense-gain branch (esekfom.hpp:1720-1750): rows, row-major
+            d.h_x.assign((size_t)ds.m * 12, 0.0);
+            d.h.assign((size_t)ds.m, 0.0);
+            for (int r = 0; r < ds.m; ++r) {
+                for (int cidx = 0; cidx < 12; ++cidx) d.h_x[(size_t)r * 12 + cidx] = ds.h_x[(size_t)cidx * ds.m + r];
+                d.h[r] = ds.h[r];
+            }
+        } else if (ds.m < lio::DOF) {
+            d.valid = false;                                    // the reduced form cannot feed the dense gain
+        }
+    });
+    double solve_time = 0.0;
+    kf->kf.update_iterated_dyn_share_modified(R, solve_time);
+    if (log) {
+        const lio::update_stats& st = kf->kf.stats();
+        log->n_calls = st.n_calls; log->n_search = st.n_search; log->converged = st.converged ? 1 : 0;
+        log->last_m = st.last_m; log->last_res_mean = st.last_res_mean;
+        log->solve_seconds = st.solve_seconds; log->measure_seconds = st.measure_seconds;
+    }
+    return LIO_OK;
 }
 int lio_eskf_scan_step_device(lio_eskf* kf, lio_ctx* ctx, const double x26[26], const double P[23 * 23],
                               const void* d_body_f4, int n, double R, int extrinsic_est_en, lio_update_log* log) {

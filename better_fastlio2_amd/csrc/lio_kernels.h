@@ -72,6 +72,7 @@ struct ResidualArgs {
     float4*        normvec;         // normvec (n^, pd2)
     float4*        plane;           // (n^, d) of the plane fitted in the last search pass, valid where sel
     double*        rows;            // optional [nq][13]: h_x row (12) + h, valid where sel
+    int*           m_dev;           // optional device word: receives m (the callback path's row compaction reads it)
     unsigned long long* units;      // [nblocks][RED_STRIDE][2] stamped halves of the workgroup partial sums
     unsigned long long* gunits;     // [groups][RED_STRIDE][2] the same for the group sums
     uint32_t*      n_unresolved;    // read into the record and reset (search passes)
@@ -101,6 +102,21 @@ constexpr int SPEC_USED = 19;                //   then n^ | d | pd2 | sel as 3 x
 int residual_blocks(int nq);
 int residual_walkers(int nq);       // walking workgroups a search pass adds in front of the model workgroups
 hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s, KernelTimer t = KernelTimer());
+
+// h_x (m x 12) and h (m) of a pass, compacted in scan order and COLUMN-major with leading dimension m -- the layout of
+// ekfom_data.h_x / .h the unmodified update_iterated_dyn_share_modified reads (esekfom.hpp:1790,1810): dst = [12 columns of
+// h_x | h], one launch (stamped tile prefix, lio_compact.hip).  dst may be device memory or host-mapped pinned memory.
+struct RowsCompactArgs {
+    const double*  rows;            // [nq][13] staged by residual_kernel (valid where sel)
+    const uint8_t* sel;
+    int            nq;
+    const int*     m_dev;           // m, written by the residual kernel of the same pass
+    double*        dst;             // 13 * m doubles
+    unsigned long long* agg;
+    uint32_t       stamp;
+    uint32_t*      err;
+};
+hipError_t launch_rows_compact(const RowsCompactArgs& a, hipStream_t s);
 
 // ---- map construction / mutation ----------------------------------------------------------------
 // mkeys[i] = Morton key of pts[i], vals[i] = base_index + i

@@ -412,6 +412,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
                     rank += (k0.x < qi) + (k0.y < qi) + (k0.z < qi) + (k0.w < qi) + (k1.x < qi) + (k1.y < qi) + (k1.z < qi) + (k1.w < qi);
                 }
                 const bool changed = verdict != 0ull;
+                bool final_sel = false;
                 if (!changed) {
 #pragma unroll
                     for (int c = 0; c < S::NCOLS; ++c) frow[c] = __longlong_as_double((long long)raw[c]);
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
                         a.normvec[qi] = make_float4(onx, ony, onz, opd2);
                     }
                     a.sel[qi] = osel ? 1 : 0;
+                    final_sel = osel;
                 } else {
                     // the walk found closer points: the owner's outputs for this query are replaced
                     float4 nb[K];
@@ -453,6 +455,14 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
                     frow[S::COL_H] = fh;
                     frow[S::COL_RES] = fsel ? (double)__builtin_fabsf(fpd2) : 0.0;
                     frow[S::COL_ONE] = fsel ? 1.0 : 0.0;
+                    final_sel = fsel;
+                }
+                // (the callback path's staged rows: the final row of a listed query is this one, not its owner's guess)
+                if (a.rows != nullptr && final_sel) {
+                    double* dst = a.rows + (size_t)qi * 13;
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) dst[c] = c < S::NC ? frow[c < S::NC ? c : 0] : 0.0;
+                    dst[12] = frow[S::COL_H];
                 }
             }
             if (stamps) t_dbg5 = wall_clock64();
@@ -498,6 +508,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         if (tid == 0) {
             out->res_sum = s_fin[S::NP + S::NC];
             out->m = failed ? -1 : (int)(s_fin[S::NP + S::NC + 1] + 0.5);
+            if (a.m_dev != nullptr) *a.m_dev = failed ? 0 : (int)(s_fin[S::NP + S::NC + 1] + 0.5);
             out->n_unresolved = SEARCH ? (int)*a.n_unresolved : 0;
             out->n_candidates = SEARCH ? *a.cand_total : 0ull;
             out->dbg[0] = t_dbg0; out->dbg[1] = t_dbg1; out->dbg[2] = t_dbg2; out->dbg[3] = t_dbg3; out->dbg[4] = t_dbg4;

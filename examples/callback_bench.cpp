@@ -1,0 +1,113 @@
+// callback_bench.cpp -- the ZERO-PATCH drop-in, timed: the reference's own call chain
+//     kf.update_iterated_dyn_share_modified(..)  ->  h_dyn_share(x_, dyn_share) = h_share_model(state_ikfom&, dyn_share_datastruct&)
+// (src/laserMapping.cpp:2380 -> esekfom.hpp:1639 -> laserMapping.cpp:1876) with include/lio_hip_adaptor.hpp behind the
+// callback and a filter that really forms h_x^T h_x / h_x^T h from the returned m x 12 rows (esekfom.hpp:1790,1810;
+// lio_eskf_update_iterated_dyn_share_callback).  Built as a small shared library (better_fastlio2_amd/build.py) that
+// bench.py and the tests drive through ctypes; the node-side types are the stand-ins of tests/csrc/adaptor_stubs (Eigen and
+// PCL are not in the image), laid out like the real ones (48-byte PointXYZINormal, column-major h_x).
+//   patched != 0: the "two-line patch" of INTEGRATION.md section 3 -- the callback hands over lio_measure's reduced form
+//                 (HTH / HTh) instead of rows; everything else (host-resident scan, synchronous passes) stays.
+#include "use-ikfom.hpp"            // stand-ins: state_ikfom, esekfom::dyn_share_datastruct
+#include <ikd-Tree/ikd_Tree.h>     // stand-ins: PointType, PointVector, StubCloud
+#include <memory>
+typedef std::shared_ptr<StubCloud> CloudPtr;
+typedef esekfom::dyn_share_datastruct<double> DynShare;
+#include <lio_hip_adaptor.hpp>
+
+#include <cstring>
+
+namespace {
+// ---- the file-scope globals of src/laserMapping.cpp the measurement path touches (:44-116) -------------------------
+bool extrinsic_est_en = false;
+double res_mean_last = 0.05;
+std::vector<float> res_last;
+int effct_feat_num = 0, feats_down_size = 0;
+std::unique_ptr<bool[]> point_selected_surf;
+std::vector<PointVector> Nearest_Points;
+CloudPtr feats_down_body = std::make_shared<StubCloud>(), feats_down_world = std::make_shared<StubCloud>(),
+         normvec = std::make_shared<StubCloud>(), laserCloudOri = std::make_shared<StubCloud>(),
+         corr_normvect = std::make_shared<StubCloud>();
+lio::KdTreeFacade<PointType> ikdtree;                                   // :116
+std::unique_ptr<lio::NodeGlobals<PointType, CloudPtr, std::vector<PointVector>>> G;
+std::vector<CloudPtr> scans;                                            // what downSizeFilterSurf.filter left, one cloud per scan of the drive
+DynShare dyn;                                                           // the filter's dyn_share (esekfom.hpp:1636)
+bool patched_mode = false;
+
+void h_share_model(state_ikfom& s, DynShare& ekfom_data) { lio::h_share_model(ikdtree, s, ekfom_data, *G); }   // :1876
+
+state_ikfom state_of(const double x[26]) {
+    state_ikfom s{};
+    s.pos = {{x[0], x[1], x[2]}}; s.rot = {{x[3], x[4], x[5], x[6]}};
+    s.offset_R_L_I = {{x[7], x[8], x[9], x[10]}}; s.offset_T_L_I = {{x[11], x[12], x[13]}};
+    return s;
+}
+
+// h_dyn_share of the filter = the node's callback, unmodified signature
+void model(void*, const double x26[26], lio_dyn_share* d) {
+    state_ikfom s = state_of(x26);
+    if (!patched_mode) {
+        dyn.converge = d->converge != 0; dyn.valid = true;
+        h_share_model(s, dyn);
+        d->valid = dyn.valid ? 1 : 0; d->m = effct_feat_num;
+        d->h_x = dyn.h_x.data(); d->h = dyn.h.data();
+        return;
+    }
+    // two-line patch: same callback position, the reduced form instead of rows
+    lio_ctx* ctx = ikdtree.ctx();
+    if (ikdtree.scan_dirty) {
+        const auto& pts = feats_down_body->points;
+        if (lio_scan_set(ctx, pts.size() ? &pts[0].x : nullptr, feats_down_size, (int)sizeof(PointType)) != LIO_OK) { d->valid = 0; return; }
+        ikdtree.scan_dirty = false;
+    }
+    lio_out o;
+    if (lio_measure(ctx, x26, d->converge, extrinsic_est_en ? 1 : 0, &o) != LIO_OK) { d->valid = 0; return; }
+    d->valid = o.valid; d->m = o.m; d->h_x = nullptr; d->h = nullptr;
+    std::memcpy(d->HTH, o.HTH, sizeof(o.HTH)); std::memcpy(d->HTh, o.HTh, sizeof(o.HTh));
+}
+}  // namespace
+
+extern "C" {
+// the facade works on an existing context (the bench built the 5 M-point map in it)
+int cbb_setup(lio_ctx* ctx, int max_scan_points) {
+    ikdtree.adopt(ctx);
+    res_last.assign((size_t)max_scan_points, 0.0f);
+    point_selected_surf.reset(new bool[(size_t)max_scan_points]());
+    normvec->points.resize((size_t)max_scan_points); laserCloudOri->points.resize((size_t)max_scan_points); corr_normvect->points.resize((size_t)max_scan_points);
+    G.reset(new lio::NodeGlobals<PointType, CloudPtr, std::vector<PointVector>>{
+        feats_down_body, feats_down_world, normvec, laserCloudOri, corr_normvect, Nearest_Points, point_selected_surf.get(), res_last.data(),
+        feats_down_size, effct_feat_num, res_mean_last, extrinsic_est_en});
+    scans.clear();
+    return 0;
+}
+// one down-sampled scan of the drive as the node holds it: a PCL cloud of 48-byte points on the host
+int cbb_add_scan(const float* xyz, int n, int stride_floats) {
+    CloudPtr c = std::make_shared<StubCloud>();
+    c->points.resize((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        PointType p{};
+        p.x = xyz[(size_t)i * stride_floats]; p.y = xyz[(size_t)i * stride_floats + 1]; p.z = xyz[(size_t)i * stride_floats + 2];
+        c->points[(size_t)i] = p;
+    }
+    scans.push_back(c);
+    return (int)scans.size() - 1;
+}
+// one scan step: feats_down_body = scan k (laserMapping.cpp:2322-2325), kf.change_x / change_P, the iterated update
+int cbb_step(lio_eskf* kf, int k, const double* x26, const double* P, double R, int ext, int patched, lio_update_log* log) {
+    if (k < 0 || k >= (int)scans.size()) return LIO_ERR_INVALID_ARG;
+    try {
+        feats_down_body = scans[(size_t)k];
+        feats_down_size = (int)feats_down_body->points.size();
+        lio::scan_changed(ikdtree);
+        extrinsic_est_en = ext != 0;
+        patched_mode = patched != 0;
+        int rc = lio_eskf_change_x(kf, x26);
+        if (rc == LIO_OK) rc = lio_eskf_change_P(kf, P);
+        if (rc == LIO_OK) rc = lio_eskf_update_iterated_dyn_share_callback(kf, R, model, nullptr, log);
+        return rc;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "callback_bench: %s\n", e.what());
+        return LIO_ERR_HIP;
+    }
+}
+int cbb_last_m(void) { return effct_feat_num; }
+}

@@ -93,6 +93,8 @@ typedef struct lio_map_info {
     long long n_retired;        /* slots whose bucket has been re-written at the tail since the last full rebuild */
     long long n_incremental_updates;  /* Add_Points batches indexed in O(batch) since lio_create          */
     long long n_full_rebuilds;  /* full re-sort + re-hash passes since lio_create (Build included)        */
+    long long n_boundary_points; /* points of down-sampled batches that were replayed one after the other since lio_create
+                                    (they, or a point of their voxel, sit within an ulp of a voxel face)  */
 } lio_map_info;
 
 /* ---- context -------------------------------------------------------------------------------- */
@@ -247,6 +249,12 @@ int  lio_measure_end(lio_ctx* ctx, lio_out* out);
  * laserCloudOri / corr_normvect (laserMapping.cpp:1942-2002).  col_major != 0 writes h_x in
  * Eigen's default (column-major, leading dimension m).  cap_rows >= m required.                    */
 int  lio_measure_rows(lio_ctx* ctx, double* h_x, double* h, int cap_rows, int col_major);
+/* For a node that keeps the UNMODIFIED update_iterated_dyn_share_modified, which reads ekfom_data.h_x / .h
+ * (esekfom.hpp:1790,1810): on != 0 makes every following pass also leave its rows compacted in scan order and
+ * column-major on the device (one more launch behind the pass), so that lio_measure_rows only moves m x 13 doubles --
+ * written by the kernel straight into pinned host memory for scans whose rows fit 2 MB, through the copy engine above.
+ * Off (default): lio_measure_rows re-evaluates the pass (the m < 23 dense-gain branch of the library's own filter).   */
+int  lio_measure_want_rows(lio_ctx* ctx, int on);
 /* Nearest_Points of the last search pass (consumed by map_incremental, laserMapping.cpp:1453-1481):
  * xyz [n*5*3], sqdist [n*5], count [n] (any of them may be NULL).                                  */
 int  lio_get_neighbors(lio_ctx* ctx, float* out_xyz, float* out_sqdist, int* out_count);
@@ -313,6 +321,25 @@ int  lio_eskf_get_P(lio_eskf* kf, double P[23 * 23]);             /* esekfom.hpp
  * model bound to lio_measure on ctx (the scan must have been set with lio_scan_set).             */
 int  lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, double R,
                                                  int extrinsic_est_en, lio_update_log* log);
+/* The same update around a measurement model SUPPLIED BY THE CALLER -- esekf::init_dyn_share(.., h_dyn_share, ..)
+ * (esekfom.hpp:239-258, laserMapping.cpp:2151): h is called like the reference calls h_dyn_share(x_, dyn_share)
+ * (esekfom.hpp:1639) with the iterate's state and ekfom_data.converge set, and answers like h_share_model does: valid, m
+ * and the rows h_x (m x 12, Eigen's column-major default, leading dimension m) and h (m) -- the filter then forms
+ * h_x^T h_x and h_x^T h itself, as esekfom.hpp:1790,1810 do.  A callback that already holds the reduced form (lio_measure's
+ * HTH / HTh: the "two-line patch" of INTEGRATION.md) leaves h_x NULL and fills HTH / HTh instead.  The pointers must stay
+ * valid until h is called again or the update returns.                                                            */
+typedef struct lio_dyn_share {
+    int           converge;         /* in:  ekfom_data.converge (search again)                                  */
+    int           valid;            /* out: ekfom_data.valid                                                    */
+    int           m;                /* out: rows (effct_feat_num)                                               */
+    int           reserved;
+    const double* h_x;              /* out: m x 12 column-major, or NULL                                        */
+    const double* h;                /* out: m                                                                   */
+    double        HTH[144];         /* out when h_x == NULL: h_x^T h_x, 12 x 12 row-major                       */
+    double        HTh[12];          /* out when h_x == NULL: h_x^T h                                            */
+} lio_dyn_share;
+typedef void (*lio_h_dyn_share_fn)(void* user, const double x26[26], lio_dyn_share* ekfom_data);
+int  lio_eskf_update_iterated_dyn_share_callback(lio_eskf* kf, double R, lio_h_dyn_share_fn h, void* user, lio_update_log* log);
 /* One scan of the node's loop body (laserMapping.cpp:2320-2325 + :2380) in one call: the propagated state and
  * covariance go in (kf.change_x / kf.change_P; NULL = keep the filter's), the down-sampled scan goes in from
  * device memory (lio_scan_set_device; d_body_f4 == NULL: the current scan, e.g. after lio_scan_swap, is kept), the

@@ -68,7 +68,10 @@ public:
                           int device = 0, int max_scan_points = 100000 /* laserMapping.cpp:52,65 */,
                           long long max_map_points = 20000000)
         : box_length_(box_length), device_(device), max_scan_(max_scan_points), max_map_(max_map_points) {}
-    ~KdTreeFacade() { if (ctx_) lio_destroy(ctx_); }
+    ~KdTreeFacade() { if (ctx_ && owns_) lio_destroy(ctx_); }
+    // a process that created its context elsewhere (e.g. next to other users of the same GPU) hands it over; the facade
+    // then neither creates nor destroys one
+    void adopt(lio_ctx* ctx) { if (ctx_ && owns_) lio_destroy(ctx_); ctx_ = ctx; owns_ = false; rows_requested = false; }
     KdTreeFacade(const KdTreeFacade&) = delete;
     KdTreeFacade& operator=(const KdTreeFacade&) = delete;
 
@@ -147,6 +150,7 @@ public:
 
     // ---- per-scan state of the adaptor (not part of the reference's class) ---------------------------------------
     bool scan_dirty = true;       // feats_down_body changed since the last lio_scan_set
+    bool rows_requested = false;  // lio_measure_want_rows(ctx, 1) has been issued (the unmodified IKFoM reads h_x / h)
     bool globals_stale = false;   // a measurement pass ran since the last sync_globals
 
 private:
@@ -164,6 +168,7 @@ private:
         if (rc != LIO_OK) throw std::runtime_error(std::string(what) + ": " + lio_last_error(ctx_));
     }
     lio_ctx* ctx_ = nullptr;
+    bool owns_ = true;
     float box_length_;
     int device_, max_scan_;
     long long max_map_;
@@ -194,6 +199,12 @@ template <class PointT> inline void scan_changed(KdTreeFacade<PointT>& tree) { t
 template <class PointT, class State, class DynShare, class G>
 inline void h_share_model(KdTreeFacade<PointT>& tree, State& s, DynShare& ekfom_data, G& g) {
     lio_ctx* ctx = tree.ctx();
+    if (!tree.rows_requested) {
+        // the unmodified update_iterated_dyn_share_modified reads ekfom_data.h_x / .h: every pass stages them on the device,
+        // compacted and column-major, so that lio_measure_rows below only moves m x 13 doubles
+        if (lio_measure_want_rows(ctx, 1) != LIO_OK) throw std::runtime_error("lio_measure_want_rows failed");
+        tree.rows_requested = true;
+    }
     if (tree.scan_dirty) {                                             // once per scan, before its first pass
         const auto& pts = g.feats_down_body->points;
         const int rc = lio_scan_set(ctx, pts.size() ? &pts[0].x : nullptr, g.feats_down_size, (int)sizeof(PointT));

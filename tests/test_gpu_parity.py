@@ -636,7 +636,9 @@ def test_incremental_index_stress(gpu_capi, oracle, small_case):
     check(strip[:200] + np.float32(0.01))
     info2 = ctx.map_info()
     assert info2["n_cells"] > info1["n_cells"]
-    # 3. a batch large enough to exceed the retired-slot budget: full rebuild, same answers
+    # 3. a batch large enough to exceed the retired-slot budget (here: the budget of round 2, a map this small never reaches
+    #    the default of half its live points): full rebuild, same answers
+    ctx.debug_set("retired_budget", 65536)
     big = (w.points[1::2] + rng.uniform(-0.02, 0.02, w.points[1::2].shape)).astype(np.float32)
     assert ctx.map_add(big, True) == ref.add(big, True)
     ref.quiesce(300)
