@@ -62,3 +62,22 @@ def test_product_does_not_touch_the_oracle():
                 if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip")):
                     text = open(os.path.join(dp, f), errors="ignore").read()
                     assert "pyoracle" not in text and "lio_oracle" not in text and "libikd_ref" not in text, f
+
+
+def test_kitti_bin_reader(tmp_path):
+    """KITTI velodyne .bin sweeps (common_lib.h:594-614 readBin): x, y, z, intensity fp32 records; the reference's loop
+    appends one all-zero point after the failed read at end of file."""
+    import numpy as np
+    from better_fastlio2_amd import kitti
+    rng = np.random.default_rng(2)
+    xyz = rng.normal(0, 20, (1000, 3)).astype(np.float32)
+    inten = rng.uniform(0, 1, 1000).astype(np.float32)
+    p = str(tmp_path / "000000.bin")
+    kitti.write_bin(p, xyz, inten)
+    got = kitti.read_bin(p)
+    assert got.shape == (1000, 4) and np.array_equal(got[:, :3], xyz) and np.array_equal(got[:, 3], inten)
+    quirk = kitti.read_bin(p, reference_eof_quirk=True)
+    assert quirk.shape == (1001, 4) and not quirk[-1].any()
+    with open(p, "ab") as fh:
+        fh.write(b"\x00\x01\x02")                                # a truncated record is dropped
+    assert kitti.read_bin(p).shape == (1000, 4)

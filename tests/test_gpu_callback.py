@@ -72,3 +72,18 @@ def test_callback_chain_equals_the_library_update(gpu_capi, synth, small_case, p
         assert np.abs(x_cb - x_lib).max() < 1e-11 and np.abs(P_cb - P_lib).max() < 1e-12
     ctx.measure_want_rows(False)
     ctx.close()
+
+
+def test_kitti_bin_step_script():
+    """scripts/kitti_bin_step.py on a sweep in KITTI's .bin format (a synthetic one: no data set ships here): read, no-pose
+    lio_scan_undistort, lio_scan_voxel_filter(0.5), the scan step; neighbours against the reference tree."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "kitti_bin_step.py"), "--synthetic", "--check"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["scan_points"] == 120000 and 5000 < out["feats_down_size"] < 60000
+    assert out["effct_feat_num"] > out["feats_down_size"] // 2 and out["pos_err_to_truth_m"] < 0.02
+    if "neighbors_vs_reference" in out:
+        assert out["neighbors_vs_reference"]["sqdist_mismatches"] == 0 and out["neighbors_vs_reference"]["count_mismatches"] == 0
