@@ -2406,29 +2406,7 @@ int lio_eskf_update_iterated_dyn_share_callback(lio_eskf* kf, double R, lio_h_dy
             std::memcpy(d.HTH, ds.HTH, sizeof(d.HTH));
             std::memcpy(d.HTh, ds.HTh, sizeof(d.HTh));
         } else {
-            const size_t m = (size_t)ds.m;
-            double acc[12][13] = {};
-            constexpr size_t BLK = 256;                         // 13 column slices of 2 KB
-            for (size_t i0 = 0; i0 < m; i0 += BLK) {
-                const size_t len = m - i0 < BLK ? m - i0 : BLK;
-                for (int a = 0; a < 12; ++a) {
-                    const double* ca = ds.h_x + (size_t)a * m + i0;
-                    for (int b = a; b < 12; ++b) {
-                        const double* cb = ds.h_x + (size_t)b * m + i0;
-                        double t = 0.0;
-                        for (size_t i = 0; i < len; ++i) t += ca[i] * cb[i];
-                        acc[a][b] += t;
-                    }
-                    const double* ch = ds.h + i0;
-                    double t = 0.0;
-                    for (size_t i = 0; i < len; ++i) t += ca[i] * ch[i];
-                    acc[a][12] += t;
-                }
-            }
-            for (int a = 0; a < 12; ++a) {
-                for (int b = a; b < 12; ++b) { d.HTH[a * 12 + b] = acc[a][b]; d.HTH[b * 12 + a] = acc[a][b]; }
-                d.HTh[a] = acc[a][12];
-            }
+            lio::hth_from_rows_colmajor(ds.h_x, ds.h, (size_t)ds.m, d.HTH, d.HTh);
         }
         if (ds.m < lio::DOF && ds.h_x != nullptr) {            // dense-gain branch (esekfom.hpp:1720-1750): rows, row-major
             d.h_x.assign((size_t)ds.m * 12, 0.0);

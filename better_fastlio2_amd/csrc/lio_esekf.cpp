@@ -303,6 +303,53 @@ double now_seconds() {
 
 }  // namespace
 
+// h_x^T h_x and h_x^T h (esekfom.hpp:1790,1810) from rows the measurement callback returned: h_x is m x 12 COLUMN-major
+// (Eigen's default, leading dimension m), h has m entries.  Blocks of 128 rows (13 column slices of 1 KB: L1-resident),
+// per block and column pair two 4-lane partial sums -- a plain `t += a[i] * b[i]` is one dependent add per row (strict fp
+// order forbids the compiler to split it): 8 ms for 90 k rows, against ~0.5 ms here.  The order of the sums is fixed.
+typedef double hth_v4 __attribute__((vector_size(32), aligned(8)));
+// column A against columns A .. 12 over `len` rows: one 4-lane accumulator per partner, all of them in registers (the
+// trip counts are compile-time constants), column A's lanes loaded once per four rows
+template <int A>
+static inline __attribute__((always_inline)) void hth_column_block(const double* const col[13], size_t len, double (&acc)[12][13]) {
+    constexpr int NB = 13 - A;
+    hth_v4 s[NB];
+#pragma GCC unroll 13
+    for (int k = 0; k < NB; ++k) s[k] = hth_v4{0.0, 0.0, 0.0, 0.0};
+    const size_t len4 = len & ~(size_t)3;
+    for (size_t i = 0; i < len4; i += 4) {
+        const hth_v4 va = *reinterpret_cast<const hth_v4*>(col[A] + i);
+#pragma GCC unroll 13
+        for (int k = 0; k < NB; ++k) s[k] += va * *reinterpret_cast<const hth_v4*>(col[A + k] + i);
+    }
+#pragma GCC unroll 13
+    for (int k = 0; k < NB; ++k) {
+        double t = (s[k][0] + s[k][1]) + (s[k][2] + s[k][3]);
+        for (size_t i = len4; i < len; ++i) t += col[A][i] * col[A + k][i];
+        acc[A][A + k] += t;
+    }
+}
+LIO_HOST_CLONES void hth_from_rows_colmajor(const double* hx, const double* h, size_t m, double HTH[144], double HTh[12]) {
+    double acc[12][13];
+    for (int a = 0; a < 12; ++a)
+        for (int b = 0; b < 13; ++b) acc[a][b] = 0.0;
+    constexpr size_t BLK = 128;
+    for (size_t i0 = 0; i0 < m; i0 += BLK) {
+        const size_t len = m - i0 < BLK ? m - i0 : BLK;
+        const double* col[13];
+        for (int b = 0; b < 12; ++b) col[b] = hx + (size_t)b * m + i0;
+        col[12] = h + i0;
+        hth_column_block<0>(col, len, acc); hth_column_block<1>(col, len, acc); hth_column_block<2>(col, len, acc);
+        hth_column_block<3>(col, len, acc); hth_column_block<4>(col, len, acc); hth_column_block<5>(col, len, acc);
+        hth_column_block<6>(col, len, acc); hth_column_block<7>(col, len, acc); hth_column_block<8>(col, len, acc);
+        hth_column_block<9>(col, len, acc); hth_column_block<10>(col, len, acc); hth_column_block<11>(col, len, acc);
+    }
+    for (int a = 0; a < 12; ++a) {
+        for (int b = a; b < 12; ++b) { HTH[a * 12 + b] = acc[a][b]; HTH[b * 12 + a] = acc[a][b]; }
+        HTh[a] = acc[a][12];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // quaternion helpers shared with the IMU front end (lio_imu.cpp)
 // ------------------------------------------------------------------------------------------

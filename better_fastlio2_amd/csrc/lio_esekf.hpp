@@ -18,6 +18,7 @@
 // (d.HTH = h_x^T h_x, d.HTh = h_x^T h, d.m rows) instead of the m x 12 matrix; d.h_x / d.h are
 // filled only when m < 23, where the reference switches to the dense gain (esekfom.hpp:1720-1750).
 #pragma once
+#include <cstddef>
 #include <functional>
 #include <vector>
 
@@ -72,6 +73,9 @@ Vec3 quat_rotate(const Quat& q, const Vec3& v);             // q * v
 void quat_to_matrix(const Quat& q, double R[9]);            // toRotationMatrix, row-major
 Quat quat_from_matrix(const double R[9]);                   // Quaternion(Matrix3)
 Vec3 s2_from_vector(const Vec3& v);                         // S2(vec): direction of v, length 9.809
+
+// h_x^T h_x (12 x 12 row-major) and h_x^T h from m rows, h_x column-major with leading dimension m (esekfom.hpp:1790,1810)
+void hth_from_rows_colmajor(const double* hx, const double* h, size_t m, double HTH[144], double HTh[12]);
 
 struct update_stats {
     int n_calls = 0, n_search = 0, last_m = 0;

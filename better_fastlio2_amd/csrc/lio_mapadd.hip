@@ -475,10 +475,18 @@ __global__ __launch_bounds__(64) void fold_kernel(FoldArgs a, BoundaryArgs ba) {
                 }
             }
         }
-        if (replaced != 0) atomicAdd(a.n_replaced, replaced);
-        if (valid && t == 0) {
-            if (touched) a.out_pts[s] = make_float4(cur.x, cur.y, cur.z, 0.0f);      // (every slot starts as "nothing")
-            if (counter != 0) atomicAdd(a.n_added, counter);
+        if (valid && t == 0 && touched) a.out_pts[s] = make_float4(cur.x, cur.y, cur.z, 0.0f);      // (every slot starts as "nothing")
+        // the two counters: summed over the wavefront first -- 10^5 atomics on ONE address serialise at the memory side
+        // (~2 ns each: they were most of this kernel's 200 us when eight replicas' lists arrived)
+        uint32_t c_add = (valid && t == 0) ? counter : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            replaced += (uint32_t)__shfl_xor((int)replaced, o, 64);
+            c_add += (uint32_t)__shfl_xor((int)c_add, o, 64);
+        }
+        if (lane == 0) {
+            if (replaced != 0) atomicAdd(a.n_replaced, replaced);
+            if (c_add != 0) atomicAdd(a.n_added, c_add);
         }
     }
 }
@@ -574,6 +582,7 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.stats + 2, APPLY_FLAG_NO_ROOM);
         return;
     }
+    uint32_t retired_sum = 0, new_cells = 0;                   // summed over the wavefront at the end: one atomic each, not one per cell
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
         if (!view_is_head(a.view, s)) continue;
         const CellPlan pl = a.plan[s];
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
             a.map_pts[dst++] = make_float4(p.x, p.y, p.z, 0.0f);
         }
         const uint32_t count = dst - dst0;
-        if (retired != 0) atomicAdd(a.stats + 1, retired);
+        retired_sum += retired;
         int icx, icy, icz;
         frame_decode(a.frame, key, icx, icy, icz);
         const uint32_t cx = (uint32_t)icx, cy = (uint32_t)icy, cz = (uint32_t)icz;
@@ -604,7 +613,7 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
             continue;
         }
         // ---- a cell the map did not have ----------------------------------------------------------
-        atomicAdd(a.stats + 0, 1u);
+        ++new_cells;
         // the cell must hang under one of the root cells of the tree
         {
             const int sh_top = 2 * a.levels.top_level;
@@ -639,6 +648,15 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
             }
             lt[ls].count = 1u;
         }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        retired_sum += (uint32_t)__shfl_xor((int)retired_sum, o, 64);
+        new_cells += (uint32_t)__shfl_xor((int)new_cells, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (new_cells != 0) atomicAdd(a.stats + 0, new_cells);
+        if (retired_sum != 0) atomicAdd(a.stats + 1, retired_sum);
     }
 }
 

@@ -76,6 +76,8 @@ def host_harness():
     H.hh_sqdist.restype = C.c_float
     H.hh_boxplus.argtypes = [f64, f64]
     H.hh_boxminus.argtypes = [f64, f64, f64]
+    H.hh_hth_rows.argtypes = [f64, f64, C.c_int, f64, f64, C.c_int]
+    H.hh_hth_rows.restype = C.c_double
     return H
 
 

@@ -2,6 +2,7 @@
 // it includes the very same headers the kernels include (csrc/lio_math.h, csrc/lio_common.h) and
 // the host-side filter (csrc/lio_esekf.cpp), and exposes them to the CPU test-suite so that they
 // can be checked against the oracle without a GPU.  Nothing in the product links this file.
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 
@@ -105,6 +106,12 @@ void hh_boxminus(const double* x26, const double* y26, double* dx23) {
     state_ikfom::from_array(x26).boxminus(dx23, state_ikfom::from_array(y26));
 }
 
+// h_x^T h_x / h_x^T h from column-major rows (the callback path's filter side), and its time for m rows
+double hh_hth_rows(const double* hx, const double* h, int m, double* HTH, double* HTh, int reps) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < (reps > 0 ? reps : 1); ++r) lio::hth_from_rows_colmajor(hx, h, (size_t)m, HTH, HTh);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (reps > 0 ? reps : 1);
+}
 }  // extern "C"
 
 // micro-benchmark of the host-side algebra of one scan step (no GPU, synthetic H^T H): seconds per update
