@@ -61,6 +61,11 @@ def main():
     n_down = ctx.scan_voxel_filter(a.leaf)
     # LiDAR -> IMU extrinsics of config/velodyne64_kitti_dataset.yaml (the synthetic sweeps use the same)
     x0 = capi.make_state26(prior_pos, prior_rot, synth._quat_from_rot(synth.KITTI_EXTRINSIC_R), synth.KITTI_EXTRINSIC_T)
+    check = None
+    if a.check:
+        # neighbours and world points of ONE search pass at the prior pose (the update below searches again elsewhere)
+        ctx.measure(x0[:14], True, False)
+        check = (ctx.neighbors(), ctx.scan_state()[0])
     kf = capi.Esekf(3)
     kf.change_x(x0); kf.change_P(synth.init_cov())
     ctx.profile_enable(True)
@@ -71,8 +76,7 @@ def main():
     if a.check:
         from oracle import pyoracle as po
         if po.ref_available():
-            nx, nd, nc = ctx.neighbors()
-            wq, _, _ = ctx.scan_state()
+            (nx, nd, nc), wq = check
             tree = po.RefIkdTree(a.voxel); tree.build(map_pts)
             rx, rd, rc, _ = tree.knn(wq, 6)
             out["neighbors_vs_reference"] = {"sqdist_mismatches": int((nd.view(np.uint32) != rd[:, :5].view(np.uint32)).any(1).sum()),

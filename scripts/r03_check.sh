@@ -43,5 +43,18 @@ for r in rows[a:e + 1]:
     out.write(line + '\n'); prev_end = en
 out.close()
 print(open('$O/emulated_timeline.txt').read()[-6000:])
+# one step of the N = 1 node loop: the last map update before the first replicate_stage_kernel
+first_stage = next(i for i, n in enumerate(names) if 'replicate_stage_kernel' in n)
+b = max(i for i in range(first_stage) if 'cell_apply_kernel' in names[i])
+a = max(i for i in range(b) if 'map_incremental_lists_kernel' in names[i])
+while a > 0 and 'knn27_kernel<8, false, false>' not in names[a]: a -= 1
+t0 = int(rows[a]['Start_Timestamp']); prev_end = t0
+out = open('$O/node_loop_timeline.txt', 'w')
+for r in rows[a:b + 2]:
+    s, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    line = '%9.1f us  +gap %6.1f  dur %6.1f  %s' % ((s - t0) / 1e3, (s - prev_end) / 1e3, (en - s) / 1e3, r['Kernel_Name'][:100])
+    out.write(line + '\n'); prev_end = en
+out.close()
+print('---- N = 1 node loop step'); print(open('$O/node_loop_timeline.txt').read())
 PY
 rm -rf $O/trace
