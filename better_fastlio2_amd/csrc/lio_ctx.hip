@@ -185,6 +185,8 @@ struct lio_ctx {
     uint8_t* d_add_cls = nullptr;
     uint8_t *d_add_dirty = nullptr, *d_add_dirty_pt = nullptr;   // boundary points of a down-sampled batch (lio_mapadd.hip)
     uint32_t* d_add_dlist = nullptr;
+    float4* d_add_plan = nullptr;              // [2 n] the speculative fold's plan per head position (lio_mapadd.hip)
+    uint2* d_add_ranges = nullptr;             // [8 n] the bucket ranges of its eight lanes
     uint64_t *d_add_keys = nullptr, *d_add_keys2 = nullptr;
     uint32_t *d_add_order = nullptr, *d_add_order2 = nullptr;
 
@@ -589,11 +591,12 @@ static int ensure_add_buffers(lio_ctx* c, size_t n) {
         if (rc != LIO_OK) return rc;
     }
     void* old[] = {c->d_add_pts, c->d_add_pts2, c->d_add_out, c->d_add_keys, c->d_add_keys2, c->d_add_order, c->d_add_order2,
-                   c->d_add_cls, c->d_add_dirty, c->d_add_dirty_pt, c->d_add_dlist, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_porder,
+                   c->d_add_cls, c->d_add_dirty, c->d_add_dirty_pt, c->d_add_dlist, c->d_add_plan, c->d_add_ranges, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_porder,
                    c->d_porder2, c->d_pnewoff, c->d_plan, c->d_gs_part, c->d_gs_part2, c->d_cagg};
     for (void* p : old) if (p) (void)hipFree(p);
     c->d_add_pts = c->d_add_pts2 = c->d_add_out = nullptr; c->d_add_keys = c->d_add_keys2 = nullptr;
     c->d_add_order = c->d_add_order2 = nullptr; c->d_add_cls = nullptr; c->d_add_dirty = c->d_add_dirty_pt = nullptr; c->d_add_dlist = nullptr;
+    c->d_add_plan = nullptr; c->d_add_ranges = nullptr;
     c->cap_add = 0;
     c->d_pend = nullptr; c->d_pkeys = c->d_pkeys2 = c->d_gs_part = c->d_gs_part2 = nullptr;
     c->d_porder = c->d_porder2 = c->d_pnewoff = nullptr; c->d_plan = nullptr; c->d_cagg = nullptr;
@@ -604,6 +607,8 @@ static int ensure_add_buffers(lio_ctx* c, size_t n) {
     HIPCHK(c, hipMalloc((void**)&c->d_add_dirty, n));
     HIPCHK(c, hipMalloc((void**)&c->d_add_dirty_pt, n));
     HIPCHK(c, hipMalloc((void**)&c->d_add_dlist, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_plan, 2 * n * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_add_ranges, 8 * n * sizeof(uint2)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_keys, n * sizeof(uint64_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_keys2, n * sizeof(uint64_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_order, n * sizeof(uint32_t)));
@@ -967,7 +972,7 @@ void lio_destroy(lio_ctx* c) {
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2,
-                   c->d_add_order, c->d_add_order2, c->d_add_dirty, c->d_add_dirty_pt, c->d_add_dlist,
+                   c->d_add_order, c->d_add_order2, c->d_add_dirty, c->d_add_dirty_pt, c->d_add_dlist, c->d_add_plan, c->d_add_ranges,
                    c->d_rep_send, c->d_rep_recv};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_out) (void)hipHostFree(c->h_out);
@@ -1063,13 +1068,14 @@ static int fold_batch_device(lio_ctx* c, const float4* batch, uint32_t n, const 
     ba.grid = c->grid; ba.ds = ds; ba.new_pts = batch; ba.view = view; ba.frame = vf;
     ba.dirty = c->d_add_dirty; ba.dirty_pt = c->d_add_dirty_pt; ba.dlist = c->d_add_dlist; ba.n_dirty = c->d_apply + 10;
     ba.seq_out = c->d_add_out + n; ba.n_added = c->d_apply + 5; ba.n_replaced = c->d_apply + 4;
-    HIPCHK(c, launch_mark_boundary(ba, s));
-    HIPCHK(c, launch_compact_dirty(ba, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
     FoldArgs fa{};
     fa.map_pts = c->d_pts; fa.l1table = ba.l1table; fa.l1mask = ba.l1mask; fa.child = c->d_child;
     fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch; fa.view = view;
     fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
-    HIPCHK(c, launch_fold(fa, ba, s));
+    fa.plan = c->d_add_plan; fa.ranges = c->d_add_ranges;
+    HIPCHK(c, launch_fold_plan(fa, ba, s));
+    HIPCHK(c, launch_compact_dirty(ba, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+    HIPCHK(c, launch_fold_commit(fa, ba, s));
     c->fold_n = n;
     c->batch_box.merge(box);
     return LIO_OK;

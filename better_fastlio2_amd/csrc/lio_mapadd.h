@@ -64,6 +64,8 @@ struct FoldArgs {
     uint32_t*        n_added;       // += tmp_counter of ikd_Tree.cpp:448
     uint32_t*        n_replaced;    // += points of the map tomb-stoned by the fold (validnum bookkeeping)
     const uint8_t*   dirty;         // per head position: 1 = left to the sequential replay ("boundary points")
+    float4*          plan;          // [2 n] per head position: {survivor xyz, tmp_counter bits (0: nothing to do)}, {box min xyz, -}
+    uint2*           ranges;        // [8 n] per head position and lane: the bucket {start, count} that lane scanned
 };
 struct IncrArgs {
     const float4*  body;            // feats_down_body
@@ -149,12 +151,12 @@ struct BoundaryArgs {
     uint32_t*        n_added;
     uint32_t*        n_replaced;
 };
-// classify_boundary + detect_shared_points of round 2 in one launch: marks dirty / dirty_pt
-hipError_t launch_mark_boundary(const BoundaryArgs& a, hipStream_t s);
+// boundary marks (dirty / dirty_pt) AND the speculative fold of every group (FoldArgs.plan / .ranges), one launch
+hipError_t launch_fold_plan(const FoldArgs& fa, const BoundaryArgs& ba, hipStream_t s);
 // the replay list: batch indices with dirty_pt set, in batch order (single-launch compaction)
 hipError_t launch_compact_dirty(const BoundaryArgs& a, unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s);
-// the parallel fold over the clean groups AND (its first workgroup) the sequential replay of the dirty points
-hipError_t launch_fold(const FoldArgs& fa, const BoundaryArgs& ba, hipStream_t s);
+// the plans of the clean groups carried out AND (its first workgroup) the sequential replay of the dirty points
+hipError_t launch_fold_commit(const FoldArgs& fa, const BoundaryArgs& ba, hipStream_t s);
 hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s);
 
 // first kernel of a down-sampled batch: voxel keys (compressed, frame) + order = iota, the partition histogram of the

@@ -11,8 +11,8 @@
 // Round 3: groups are named by the POSITION of their first record in the sorted batch (GroupView, lio_mapadd.h); kernels
 // take one lane (or eight) per position and only heads act.  That removed the run-length kernels (two launches per
 // sort), the dense group numbering and the per-group count arrays; the keys are compressed (KeyFrame).  Launches of a
-// down-sampled batch:  voxel_keys -> sort (1 or 2) -> mark_boundary -> compact_dirty -> fold (parallel fold + sequential
-// replay side by side); of the index update:  pend_build -> sort -> cell_plan (with its scan) -> cell_apply.
+// down-sampled batch:  voxel_keys -> sort (1 or 2) -> fold_plan (boundary marks + the speculative fold) -> compact_dirty ->
+// fold_commit (the plans carried out + the sequential replay, side by side); of the index update:  pend_build -> sort -> cell_plan (with its scan) -> cell_apply.
 #include "lio_device.h"
 #include "lio_kernels.h"
 #include "lio_mapadd.h"
@@ -174,98 +174,6 @@ __device__ __forceinline__ uint32_t find_voxel_group(const BoundaryArgs& a, uint
     return view_find(a.view, n, frame_key(a.frame, x, y, z));
 }
 
-// (1) one lane per batch point: is it outside its own fp32 box, or inside a neighbour's?  Then its group and the groups
-// of the voxels it reaches are dirty.  (2) eight lanes per group, the fold's layout: a LIVE MAP POINT inside the box of a
-// group that also lies inside the box of a neighbouring voxel (fp32 boxes of neighbours can overlap by an ulp) couples
-// the two groups -- if the neighbour has points in this batch, both go to the sequential pass.
-__global__ __launch_bounds__(64) void mark_boundary_kernel(BoundaryArgs a) {
-    const uint32_t n = view_count(a.view);
-    const float ds = a.ds;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 p = a.new_pts[i];
-        if (!finite3(p)) continue;
-        const float pc[3] = {p.x, p.y, p.z};
-        int dir[3], iv[3];
-        bool irregular = false;
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            iv[ax] = voxel_coord(pc[ax], ds);
-            const float kf = (float)iv[ax];
-            const float bmin = kf * ds, bmax = bmin + ds;
-            const float up_min = (kf + 1.0f) * ds;              // lower bound of the upper neighbour's box
-            const float dn_max = (kf - 1.0f) * ds + ds;         // upper bound of the lower neighbour's box
-            const bool up = !(pc[ax] < bmax) || pc[ax] >= up_min;
-            const bool dn = !(bmin <= pc[ax]) || pc[ax] < dn_max;
-            dir[ax] = up ? 1 : (dn ? -1 : 0);
-            irregular = irregular || up || dn;
-        }
-        if (!irregular) continue;
-        for (int m = 0; m < 8; ++m) {                              // own voxel (m = 0) and every combination of the reached sides
-            bool use = true;
-            int k[3];
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                const bool bit = (m >> ax) & 1;
-                if (bit && dir[ax] == 0) use = false;
-                k[ax] = iv[ax] + (bit ? dir[ax] : 0);
-            }
-            if (!use) continue;
-            const uint32_t g = find_voxel_group(a, n, k[0], k[1], k[2]);
-            if (g != 0xffffffffu) mark_group_dirty(a, n, g);
-        }
-    }
-    const int t = threadIdx.x & 7;
-    for (uint32_t s0 = blockIdx.x * 8u; s0 < a.view.n; s0 += gridDim.x * 8u) {
-        const uint32_t s = s0 + (threadIdx.x >> 3);
-        if (s >= n || !view_is_head(a.view, s)) continue;
-        const float4 p0 = a.new_pts[a.view.sord[s]];
-        if (!finite3(p0)) continue;
-        const float pc[3] = {p0.x, p0.y, p0.z};
-        int iv[3];
-        float bmin[3], bmax[3], up_min[3], dn_max[3];
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            iv[ax] = voxel_coord(pc[ax], ds);
-            const float kf = (float)iv[ax];
-            bmin[ax] = kf * ds; bmax[ax] = bmin[ax] + ds;
-            up_min[ax] = (kf + 1.0f) * ds; dn_max[ax] = (kf - 1.0f) * ds + ds;
-        }
-        int c0[3], c1[3];
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) { c0[ax] = cell_coord(bmin[ax], a.grid.inv_cell); c1[ax] = cell_coord(bmax[ax], a.grid.inv_cell); }
-        const int cx = c0[0] + ((t >> 2) & 1), cy = c0[1] + ((t >> 1) & 1), cz = c0[2] + (t & 1);
-        uint32_t st = 0, ct = 0;
-        if (cx <= c1[0] && cy <= c1[1] && cz <= c1[2]) cell_find(a.l1table, a.l1mask, a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, st, ct);
-        for (uint32_t i = st; i < st + ct; ++i) {
-            const float4 sp = a.map_pts[i];
-            if (sp.w != 0.0f) continue;
-            const float xc[3] = {sp.x, sp.y, sp.z};
-            if (!(bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z)) continue;
-            int dir[3];
-            bool shared = false;
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                dir[ax] = xc[ax] >= up_min[ax] ? 1 : (xc[ax] < dn_max[ax] ? -1 : 0);
-                shared = shared || dir[ax] != 0;
-            }
-            if (!shared) continue;
-            for (int m = 1; m < 8; ++m) {
-                bool use = true;
-                int k[3];
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) {
-                    const bool bit = (m >> ax) & 1;
-                    if (bit && dir[ax] == 0) use = false;
-                    k[ax] = iv[ax] + (bit ? dir[ax] : 0);
-                }
-                if (!use) continue;
-                const uint32_t h = find_voxel_group(a, n, k[0], k[1], k[2]);
-                if (h != 0xffffffffu) { mark_group_dirty(a, n, h); mark_group_dirty(a, n, s); }
-            }
-        }
-    }
-}
-
 // Add_Points(downsample) for the points of dirty groups, replayed in batch order by ONE wavefront with the
 // reference's rule (ikd_Tree.cpp:422-449): Storage = live points inside the fp32 box (map points through the cell
 // directory, lanes 0..7 one cell each; points added earlier in this pass from a list), nearest to the box centre
@@ -366,29 +274,86 @@ __device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane)
     }
 }
 
-// The parallel fold of the clean groups (workgroups 1 ..) and the sequential replay of the dirty points (workgroup 0) in
-// ONE launch: the two touch disjoint voxels and disjoint map points (a map point inside two boxes makes both groups dirty).
-__global__ __launch_bounds__(64) void fold_kernel(FoldArgs a, BoundaryArgs ba) {
-    const int lane = threadIdx.x, t = lane & 7;
-    if (blockIdx.x == 0) { fold_sequential(ba, lane); return; }
+// live points of a bucket range, four loads in flight at a time (a lane's range is one contiguous run of 16-byte points)
+template <class F>
+__device__ __forceinline__ void for_each_live_point(const float4* map_pts, uint32_t st, uint32_t ct, F&& f) {
+    for (uint32_t i0 = 0; i0 < ct; i0 += 4u) {
+        float4 sp[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) sp[u] = i0 + u < ct ? map_pts[st + i0 + u] : make_float4(0.f, 0.f, 0.f, 1.f);
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u)
+            if (sp[u].w == 0.0f) f(st + i0 + u, sp[u]);
+    }
+}
+
+// ---- the PLAN of a down-sampled batch, one launch ----------------------------------------------------------------------
+// (1) one lane per batch point: is it outside its own fp32 box, or inside a neighbour's?  Then its group and the groups
+// of the voxels it reaches are dirty (replayed point by point).  (2) eight lanes per group, one per grid cell the box can
+// touch: the live map points inside the box are looked at ONCE -- a point that also lies inside a neighbouring voxel's box
+// (fp32 boxes of neighbours can overlap by an ulp) couples the two groups: if the neighbour has points in this batch, both
+// are dirty; what the fold needs of the others (how many, the nearest to the centre) stays in registers -- and the fold
+// over the group's new points runs right here, SPECULATIVELY: nothing is written to the map.  What a clean group will
+// do is parked (survivor, tmp_counter, box, the bucket ranges of its eight lanes); fold_commit_kernel carries it out once
+// every dirty mark of the batch is known.  The replay only touches the voxels of dirty groups, and a map point inside two
+// boxes makes both groups dirty, so nothing a clean group's plan was computed from changes before it is carried out.
+__global__ __launch_bounds__(64) void fold_plan_kernel(FoldArgs a, BoundaryArgs ba) {
     const uint32_t n = view_count(a.view);
+    const float ds = a.ds;
+    const int lane = threadIdx.x, t = lane & 7;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = a.new_pts[i];
+        if (!finite3(p)) continue;
+        const float pc[3] = {p.x, p.y, p.z};
+        int dir[3], iv[3];
+        bool irregular = false;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            iv[ax] = voxel_coord(pc[ax], ds);
+            const float kf = (float)iv[ax];
+            const float bmin = kf * ds, bmax = bmin + ds;
+            const float up_min = (kf + 1.0f) * ds;              // lower bound of the upper neighbour's box
+            const float dn_max = (kf - 1.0f) * ds + ds;         // upper bound of the lower neighbour's box
+            const bool up = !(pc[ax] < bmax) || pc[ax] >= up_min;
+            const bool dn = !(bmin <= pc[ax]) || pc[ax] < dn_max;
+            dir[ax] = up ? 1 : (dn ? -1 : 0);
+            irregular = irregular || up || dn;
+        }
+        if (!irregular) continue;
+        for (int m = 0; m < 8; ++m) {                              // own voxel (m = 0) and every combination of the reached sides
+            bool use = true;
+            int k[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const bool bit = (m >> ax) & 1;
+                if (bit && dir[ax] == 0) use = false;
+                k[ax] = iv[ax] + (bit ? dir[ax] : 0);
+            }
+            if (!use) continue;
+            const uint32_t g = find_voxel_group(ba, n, k[0], k[1], k[2]);
+            if (g != 0xffffffffu) mark_group_dirty(ba, n, g);
+        }
+    }
     const uint32_t spw = 8u;                                    // positions per wavefront
-    for (uint32_t s0 = (blockIdx.x - 1u) * spw; s0 < a.view.n; s0 += (gridDim.x - 1u) * spw) {    // (wave-uniform: all 64 lanes iterate together)
+    for (uint32_t s0 = blockIdx.x * spw; s0 < a.view.n; s0 += gridDim.x * spw) {    // (wave-uniform: all 64 lanes iterate together)
         const uint32_t s = s0 + ((uint32_t)lane >> 3);
-        // heads only; boundary points around (dirty): replayed by workgroup 0
-        const bool valid = s < n && view_is_head(a.view, s) && a.dirty[s] == 0;
+        const bool valid = s < n && view_is_head(a.view, s);
         const uint64_t key = valid ? a.view.skey[s] : 0ull;
-        const float ds = a.ds;
         float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) p0 = a.new_pts[a.view.sord[s]];
+        const bool fin0 = valid && finite3(p0);
         // Box_of_Point and mid_point (:424-432): fp32 box, centre through double
-        float bmin[3], bmax[3], mid[3];
+        float bmin[3], bmax[3], mid[3], up_min[3], dn_max[3];
+        int iv[3];
         const float pc[3] = {p0.x, p0.y, p0.z};
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             bmin[ax] = voxel_floor(pc[ax], ds) * ds;
             bmax[ax] = bmin[ax] + ds;
             mid[ax] = (float)((double)bmin[ax] + (double)(bmax[ax] - bmin[ax]) / 2.0);
+            iv[ax] = voxel_coord(pc[ax], ds);
+            const float kf = (float)iv[ax];
+            up_min[ax] = (kf + 1.0f) * ds; dn_max[ax] = (kf - 1.0f) * ds + ds;
         }
         int c0[3], c1[3];
 #pragma unroll
@@ -398,21 +363,42 @@ __global__ __launch_bounds__(64) void fold_kernel(FoldArgs a, BoundaryArgs ba) {
         }
         const int cx = c0[0] + ((t >> 2) & 1), cy = c0[1] + ((t >> 1) & 1), cz = c0[2] + (t & 1);
         const bool mine = valid && cx <= c1[0] && cy <= c1[1] && cz <= c1[2];
-        // ---- pass 1: existing live points inside the box (Search_by_range :1015-1045) -------------
+        // ---- existing live points inside the box (Search_by_range :1015-1045), looked at once -------------
         uint32_t st = 0, ct = 0;
         if (mine) cell_find(a.l1table, a.l1mask, a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, st, ct);
         uint32_t n_e = 0;
         float d_e = __uint_as_float(INF_BITS);
         float4 e_best = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t i = st; i < st + ct; ++i) {
-            const float4 sp = a.map_pts[i];
-            if (sp.w != 0.0f) continue;
-            if (bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z) {
-                ++n_e;
-                const float d = sqdist3(sp.x, sp.y, sp.z, mid[0], mid[1], mid[2]);
-                if (d < d_e) { d_e = d; e_best = sp; }
+        for_each_live_point(a.map_pts, st, ct, [&](uint32_t, float4 sp) {
+            if (!(bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z)) return;
+            ++n_e;
+            const float d = sqdist3(sp.x, sp.y, sp.z, mid[0], mid[1], mid[2]);
+            if (d < d_e) { d_e = d; e_best = sp; }
+            if (!fin0) return;
+            // inside a neighbouring voxel's box as well?
+            const float xc[3] = {sp.x, sp.y, sp.z};
+            int dir[3];
+            bool shared = false;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                dir[ax] = xc[ax] >= up_min[ax] ? 1 : (xc[ax] < dn_max[ax] ? -1 : 0);
+                shared = shared || dir[ax] != 0;
             }
-        }
+            if (!shared) return;
+            for (int m = 1; m < 8; ++m) {
+                bool use = true;
+                int k[3];
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    const bool bit = (m >> ax) & 1;
+                    if (bit && dir[ax] == 0) use = false;
+                    k[ax] = iv[ax] + (bit ? dir[ax] : 0);
+                }
+                if (!use) continue;
+                const uint32_t h = find_voxel_group(ba, n, k[0], k[1], k[2]);
+                if (h != 0xffffffffu) { mark_group_dirty(ba, n, h); mark_group_dirty(ba, n, s); }
+            }
+        });
         // combine the eight cells: count, and the first minimum in cell order
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) {
@@ -432,21 +418,34 @@ __global__ __launch_bounds__(64) void fold_kernel(FoldArgs a, BoundaryArgs ba) {
         // a large group: its FOLD_WAVE_MIN-th record still carries the key
         const bool big = valid && s + (FOLD_WAVE_MIN - 1u) < n && a.view.skey[s + (FOLD_WAVE_MIN - 1u)] == key;
         if (valid && !big) {
-            // small group: point after point, identical in all eight lanes
-            for (uint32_t j = 0; j < FOLD_WAVE_MIN - 1u; ++j) {
-                if (j != 0u && (s + j >= n || a.view.skey[s + j] != key)) break;
-                const float4 p = a.new_pts[a.view.sord[s + j]];
-                const float d_p = sqdist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
-                if (!touched) {
-                    const bool best_is_p = !(n_e > 0 && d_e < d_p);
-                    const float4 best = best_is_p ? p : e_best;
-                    if (n_e > 1 || same_point(p, best)) {
-                        touched = true; cur = best; d_cur = best_is_p ? d_p : d_e; ++counter;
+            // small group: point after point, identical in all eight lanes; the members' loads go out four at a time
+            bool more = true;
+            for (uint32_t j0 = 0; j0 < FOLD_WAVE_MIN - 1u && more; j0 += 4u) {
+                float4 mp[4];
+                bool has[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t j = j0 + u;
+                    has[u] = j < FOLD_WAVE_MIN - 1u && (j == 0u || (s + j < n && a.view.skey[s + j] == key));
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) mp[u] = has[u] ? a.new_pts[a.view.sord[s + j0 + u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    if (!has[u]) { more = false; break; }
+                    const float4 p = mp[u];
+                    const float d_p = sqdist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
+                    if (!touched) {
+                        const bool best_is_p = !(n_e > 0 && d_e < d_p);
+                        const float4 best = best_is_p ? p : e_best;
+                        if (n_e > 1 || same_point(p, best)) {
+                            touched = true; cur = best; d_cur = best_is_p ? d_p : d_e; ++counter;
+                        }
+                    } else {
+                        const bool best_is_p = !(d_cur < d_p);
+                        const float4 best = best_is_p ? p : cur;
+                        if (same_point(p, best)) { cur = best; d_cur = best_is_p ? d_p : d_cur; ++counter; }
                     }
-                } else {
-                    const bool best_is_p = !(d_cur < d_p);
-                    const float4 best = best_is_p ? p : cur;
-                    if (same_point(p, best)) { cur = best; d_cur = best_is_p ? d_p : d_cur; ++counter; }
                 }
             }
         }
@@ -462,23 +461,50 @@ __global__ __launch_bounds__(64) void fold_kernel(FoldArgs a, BoundaryArgs ba) {
                 touched = fr.touched; cur = make_float4(fr.x, fr.y, fr.z, 0.0f); d_cur = fr.d; counter = fr.counter;
             }
         }
-        // ---- pass 2: Delete_by_range of the box + Add_by_point of the survivor --------------------
+        // ---- the plan of this group: the survivor and tmp_counter (0: the voxel stays as it is), the box, the lanes' buckets
+        if (valid) {
+            if (t == 0) {
+                a.plan[2 * (size_t)s] = make_float4(cur.x, cur.y, cur.z, __uint_as_float(touched ? counter : 0u));
+                a.plan[2 * (size_t)s + 1] = make_float4(bmin[0], bmin[1], bmin[2], 0.0f);
+            }
+            if (touched) a.ranges[(size_t)s * 8u + (uint32_t)t] = make_uint2(st, n_e > 0 ? ct : 0u);
+        }
+    }
+}
+
+// Carries the plans of the clean groups out (workgroups 1 ..): Delete_by_range of the box + Add_by_point of the survivor
+// (:445-448) -- and, side by side (workgroup 0), replays the dirty points one after the other.  The two touch disjoint
+// voxels and disjoint map points.
+__global__ __launch_bounds__(64) void fold_commit_kernel(FoldArgs a, BoundaryArgs ba) {
+    const int lane = threadIdx.x, t = lane & 7;
+    if (blockIdx.x == 0) { fold_sequential(ba, lane); return; }
+    const uint32_t n = view_count(a.view);
+    const float ds = a.ds;
+    const uint32_t spw = 8u;
+    for (uint32_t s0 = (blockIdx.x - 1u) * spw; s0 < a.view.n; s0 += (gridDim.x - 1u) * spw) {
+        const uint32_t s = s0 + ((uint32_t)lane >> 3);
+        const bool valid = s < n && view_is_head(a.view, s) && a.dirty[s] == 0;
+        float4 pl = make_float4(0.f, 0.f, 0.f, 0.f), bx = pl;
+        if (valid) { pl = a.plan[2 * (size_t)s]; bx = a.plan[2 * (size_t)s + 1]; }
+        const uint32_t counter = __float_as_uint(pl.w);
+        const bool touched = valid && counter != 0u;
         uint32_t replaced = 0;
         if (touched) {
-            for (uint32_t i = st; i < st + ct; ++i) {
-                float4 sp = a.map_pts[i];
-                if (sp.w != 0.0f) continue;
+            const uint2 rg = a.ranges[(size_t)s * 8u + (uint32_t)t];
+            const float bmin[3] = {bx.x, bx.y, bx.z};
+            const float bmax[3] = {bmin[0] + ds, bmin[1] + ds, bmin[2] + ds};
+            for_each_live_point(a.map_pts, rg.x, rg.y, [&](uint32_t i, float4 sp) {
                 if (bmin[0] <= sp.x && bmax[0] > sp.x && bmin[1] <= sp.y && bmax[1] > sp.y && bmin[2] <= sp.z && bmax[2] > sp.z) {
-                    // exchange, not store: the bookkeeping stays exact even if two boxes ever claimed the same point
-                    const uint32_t was = atomicExch(reinterpret_cast<uint32_t*>(&a.map_pts[i].w), __float_as_uint(TOMB_DOWNSAMPLE));
-                    if (was == 0u) ++replaced;
+                    // (a plain store: no other clean group's box holds this point -- it would have made both dirty -- and the
+                    // replay stays inside the dirty voxels)
+                    a.map_pts[i].w = TOMB_DOWNSAMPLE;
+                    ++replaced;
                 }
-            }
+            });
+            if (t == 0) a.out_pts[s] = make_float4(pl.x, pl.y, pl.z, 0.0f);      // (every slot starts as "nothing")
         }
-        if (valid && t == 0 && touched) a.out_pts[s] = make_float4(cur.x, cur.y, cur.z, 0.0f);      // (every slot starts as "nothing")
         // the two counters: summed over the wavefront first -- 10^5 atomics on ONE address serialise at the memory side
-        // (~2 ns each: they were most of this kernel's 200 us when eight replicas' lists arrived)
-        uint32_t c_add = (valid && t == 0) ? counter : 0u;
+        uint32_t c_add = (touched && t == 0) ? counter : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             replaced += (uint32_t)__shfl_xor((int)replaced, o, 64);
@@ -681,16 +707,16 @@ hipError_t launch_voxel_keys(const VoxelKeyArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(voxel_keys_kernel, dim3(b), dim3(256), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_mark_boundary(const BoundaryArgs& a, hipStream_t s) {
-    if (a.view.n == 0) return hipSuccess;
-    uint32_t b = (a.view.n + 7u) / 8u; if (b > 16384u) b = 16384u;
-    hipLaunchKernelGGL(mark_boundary_kernel, dim3(b), dim3(64), 0, s, a);
-    return hipGetLastError();
-}
-hipError_t launch_fold(const FoldArgs& fa, const BoundaryArgs& ba, hipStream_t s) {
+hipError_t launch_fold_plan(const FoldArgs& fa, const BoundaryArgs& ba, hipStream_t s) {
     if (fa.view.n == 0) return hipSuccess;
     uint32_t b = (fa.view.n + 7u) / 8u; if (b > 16384u) b = 16384u;
-    hipLaunchKernelGGL(fold_kernel, dim3(b + 1u), dim3(64), 0, s, fa, ba);
+    hipLaunchKernelGGL(fold_plan_kernel, dim3(b), dim3(64), 0, s, fa, ba);
+    return hipGetLastError();
+}
+hipError_t launch_fold_commit(const FoldArgs& fa, const BoundaryArgs& ba, hipStream_t s) {
+    if (fa.view.n == 0) return hipSuccess;
+    uint32_t b = (fa.view.n + 7u) / 8u; if (b > 16384u) b = 16384u;
+    hipLaunchKernelGGL(fold_commit_kernel, dim3(b + 1u), dim3(64), 0, s, fa, ba);
     return hipGetLastError();
 }
 hipError_t launch_cell_plan(const ApplyArgs& a, hipStream_t s) {
