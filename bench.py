@@ -355,6 +355,10 @@ def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, 
     acc = {"own": 0.0, "exchange": 0.0, "n_add": 0, "n_nodown": 0, "steps": 0}
     lat = []
     info0 = ctx.map_info()
+    x_post = np.zeros(26, np.float64)
+    x_post_p = x_post.ctypes.data_as(C.c_void_p)
+    na, nb, nd, cnt = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    voxel_d = C.c_double(voxel)
 
     def one(timed):
         k = tick[0] % n_rot
@@ -370,11 +374,14 @@ def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, 
         t0 = time.perf_counter()
         step_own()                                              # timed: this rank's scan step ...
         t1 = time.perf_counter()
-        r = ctx.replicate_step(kf.get_x()[:14], voxel, True)    # ... its lists, the (emulated) exchange, the apply of all W
+        L.lio_eskf_get_x(kf.h, x_post_p)
+        rc = L.lio_replicate_step(ctx.h, x_post_p, voxel_d, 1, C.byref(na), C.byref(nb), C.byref(nd), C.byref(cnt))   # ... its lists, the (emulated) exchange, the apply of all W
         t2 = time.perf_counter()
+        if rc != 0:
+            raise capi.LioError("lio_replicate_step failed: " + L.lio_last_error(ctx.h).decode())
         if timed:
             acc["own"] += t1 - t0; acc["exchange"] += t2 - t1; acc["steps"] += 1
-            acc["n_add"] += r["n_add"]; acc["n_nodown"] += r["n_nodown"]
+            acc["n_add"] += na.value; acc["n_nodown"] += nb.value
             lat.append(t2 - t0)
 
     tick[0] = 0
@@ -579,17 +586,25 @@ def main():
         # node loop: scan step + map_incremental (+ exchange) -- mutates the map, so it runs last
         maint = {"n_add": 0, "n_nodown": 0, "seconds": 0.0, "steps": 0}
 
+        # (the C entry points with arguments converted once, as in the scan step: the reference's host is C++)
+        x_post = np.zeros(26, np.float64)
+        x_post_p = x_post.ctypes.data_as(C.c_void_p)
+        na, nb, nd, cnt = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        voxel_d = C.c_double(voxel)
+
         def step_node():
             step_resident()
             t0 = time.perf_counter()
-            post = kf.get_x()[:14]
+            L.lio_eskf_get_x(kf.h, x_post_p)                       # pos, rot, offsets lead the array: the posterior's state14
             if dist is None:
-                r = ctx.map_incremental(post, voxel, True, apply=True)
+                rc = L.lio_map_incremental(ctx.h, x_post_p, voxel_d, 1, 1, None, C.byref(na), None, C.byref(nb), C.byref(cnt))
             else:
                 # every rank contributes its lists; every replica applies all of them, rank 0 first.  One ncclAllGather
                 # (RCCL over xGMI) on the library's stream inside liblio_hip.so: no torch, no host copy of the lists
-                r = ctx.replicate_step(post, voxel, True)
-            maint["n_add"] += r["n_add"]; maint["n_nodown"] += r["n_nodown"]
+                rc = L.lio_replicate_step(ctx.h, x_post_p, voxel_d, 1, C.byref(na), C.byref(nb), C.byref(nd), C.byref(cnt))
+            if rc != 0:
+                fail("map update", rc)
+            maint["n_add"] += na.value; maint["n_nodown"] += nb.value
             maint["seconds"] += time.perf_counter() - t0
             maint["steps"] += 1
 

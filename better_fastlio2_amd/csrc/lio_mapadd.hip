@@ -280,7 +280,10 @@ __device__ __forceinline__ void for_each_live_point(const float4* map_pts, uint3
     for (uint32_t i0 = 0; i0 < ct; i0 += 4u) {
         float4 sp[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) sp[u] = i0 + u < ct ? map_pts[st + i0 + u] : make_float4(0.f, 0.f, 0.f, 1.f);
+        for (uint32_t u = 0; u < 4u; ++u) {
+            sp[u] = make_float4(0.f, 0.f, 0.f, 1.f);
+            if (i0 + u < ct) sp[u] = map_pts[st + i0 + u];
+        }
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u)
             if (sp[u].w == 0.0f) f(st + i0 + u, sp[u]);
@@ -418,34 +421,21 @@ __global__ __launch_bounds__(64) void fold_plan_kernel(FoldArgs a, BoundaryArgs 
         // a large group: its FOLD_WAVE_MIN-th record still carries the key
         const bool big = valid && s + (FOLD_WAVE_MIN - 1u) < n && a.view.skey[s + (FOLD_WAVE_MIN - 1u)] == key;
         if (valid && !big) {
-            // small group: point after point, identical in all eight lanes; the members' loads go out four at a time
-            bool more = true;
-            for (uint32_t j0 = 0; j0 < FOLD_WAVE_MIN - 1u && more; j0 += 4u) {
-                float4 mp[4];
-                bool has[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t j = j0 + u;
-                    has[u] = j < FOLD_WAVE_MIN - 1u && (j == 0u || (s + j < n && a.view.skey[s + j] == key));
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) mp[u] = has[u] ? a.new_pts[a.view.sord[s + j0 + u]] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    if (!has[u]) { more = false; break; }
-                    const float4 p = mp[u];
-                    const float d_p = sqdist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
-                    if (!touched) {
-                        const bool best_is_p = !(n_e > 0 && d_e < d_p);
-                        const float4 best = best_is_p ? p : e_best;
-                        if (n_e > 1 || same_point(p, best)) {
-                            touched = true; cur = best; d_cur = best_is_p ? d_p : d_e; ++counter;
-                        }
-                    } else {
-                        const bool best_is_p = !(d_cur < d_p);
-                        const float4 best = best_is_p ? p : cur;
-                        if (same_point(p, best)) { cur = best; d_cur = best_is_p ? d_p : d_cur; ++counter; }
+            // small group: point after point, identical in all eight lanes
+            for (uint32_t j = 0; j < FOLD_WAVE_MIN - 1u; ++j) {
+                if (j != 0u && (s + j >= n || a.view.skey[s + j] != key)) break;
+                const float4 p = a.new_pts[a.view.sord[s + j]];
+                const float d_p = sqdist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
+                if (!touched) {
+                    const bool best_is_p = !(n_e > 0 && d_e < d_p);
+                    const float4 best = best_is_p ? p : e_best;
+                    if (n_e > 1 || same_point(p, best)) {
+                        touched = true; cur = best; d_cur = best_is_p ? d_p : d_e; ++counter;
                     }
+                } else {
+                    const bool best_is_p = !(d_cur < d_p);
+                    const float4 best = best_is_p ? p : cur;
+                    if (same_point(p, best)) { cur = best; d_cur = best_is_p ? d_p : d_cur; ++counter; }
                 }
             }
         }
@@ -563,7 +553,7 @@ __global__ __launch_bounds__(256) void cell_plan_kernel(ApplyArgs a) {
         cell_find(a.ltable + a.levels.off[1], a.levels.mask[1], a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, pl.old_start, pl.old_count, &pl.index);
         pl.found = pl.old_count != 0u ? 1u : 0u;                  // records are only ever written with count >= 1
         uint32_t live = 0;
-        for (uint32_t i = 0; i < pl.old_count; ++i) live += a.map_pts[pl.old_start + i].w == 0.0f ? 1u : 0u;
+        for_each_live_point(a.map_pts, pl.old_start, pl.old_count, [&](uint32_t, float4) { ++live; });
         uint32_t gc = 1u;
         while (s + gc < n && (a.view.skey[s + gc] >> 1) == key) ++gc;
         a.plan[s] = pl;
@@ -615,14 +605,11 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
         const uint32_t dst0 = a.tail + a.new_off[s];
         uint32_t dst = dst0;
         uint32_t retired = 0;
-        for (uint32_t i = 0; i < pl.old_count; ++i) {           // live points keep their order
-            float4 p = a.map_pts[pl.old_start + i];
-            if (p.w != 0.0f) continue;
+        for_each_live_point(a.map_pts, pl.old_start, pl.old_count, [&](uint32_t i, float4 p) {   // live points keep their order
             a.map_pts[dst++] = p;
-            p.w = TOMB_MOVED;
-            a.map_pts[pl.old_start + i] = p;
+            a.map_pts[i].w = TOMB_MOVED;
             ++retired;
-        }
+        });
         const uint64_t key = a.view.skey[s] >> 1;
         for (uint32_t j = 0; s + j < n && (j == 0u || (a.view.skey[s + j] >> 1) == key); ++j) {   // then the new ones: survivors, then plain inserts, batch order
             const float4 p = a.pend[a.view.sord[s + j]];
