@@ -178,16 +178,16 @@ __device__ __forceinline__ uint32_t find_voxel_group(const BoundaryArgs& a, uint
 // reference's rule (ikd_Tree.cpp:422-449): Storage = live points inside the fp32 box (map points through the cell
 // directory, lanes 0..7 one cell each; points added earlier in this pass from a list), nearest to the box centre
 // wins (the new point on ties), delete-and-re-add when Storage held more than one point or the new point wins.
-// Everything that later iterations read back goes through agent-scope atomics (no stale L1 lines).
+// What an iteration reads may have been written by the iteration before (tomb-stones, appended points): every iteration
+// starts with an agent-scope acquire (the L1 forgets its lines) and ends with a release (its stores are in L2), so the
+// reads in between are plain 16-byte loads, four in flight -- round 2 read every coordinate with an agent-scope atomic
+// of its own, 17 us per replayed point (measured: seven points were most of the fold's 120 us).
 __device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane) {
     const uint32_t n_dirty = *a.n_dirty;
     if (n_dirty == 0u) return;
     uint32_t n_seq = 0, counter = 0, replaced = 0;
-    float* seq = reinterpret_cast<float*>(a.seq_out);
-    float* mp = reinterpret_cast<float*>(a.map_pts);
-    auto ld = [](const float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto st = [](float* q, float v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     for (uint32_t it = 0; it < n_dirty; ++it) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const float4 p = a.new_pts[a.dlist[it]];
         const float ds = a.ds;
         float bmin[3], bmax[3], mid[3];
@@ -211,25 +211,29 @@ __device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane)
         if (mine) cell_find(a.l1table, a.l1mask, a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, bst, bct);
         uint32_t cnt = 0;
         float dbest = __uint_as_float(INF_BITS), bx = 0.f, by = 0.f, bz = 0.f;
-        for (uint32_t i = bst; i < bst + bct; ++i) {
-            const float* q = mp + 4 * (size_t)i;
-            if (ld(q + 3) != 0.0f) continue;
-            const float x = ld(q), y = ld(q + 1), z = ld(q + 2);
-            if (!inbox(x, y, z)) continue;
-            ++cnt;
-            const float d = sqdist3(x, y, z, mid[0], mid[1], mid[2]);
-            if (d < dbest) { dbest = d; bx = x; by = y; bz = z; }
+        for (uint32_t i0 = 0; i0 < bct; i0 += 4u) {
+            float4 sp[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                sp[u] = make_float4(0.f, 0.f, 0.f, 1.f);
+                if (i0 + u < bct) sp[u] = a.map_pts[bst + i0 + u];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                if (sp[u].w != 0.0f || !inbox(sp[u].x, sp[u].y, sp[u].z)) continue;
+                ++cnt;
+                const float d = sqdist3(sp[u].x, sp[u].y, sp[u].z, mid[0], mid[1], mid[2]);
+                if (d < dbest) { dbest = d; bx = sp[u].x; by = sp[u].y; bz = sp[u].z; }
+            }
         }
         // ---- Storage, part 2: points added earlier in this pass (all lanes, list order); they rank after the map's
         uint32_t ord = (uint32_t)lane;                             // tie order: map cells first (lane < 8), then list index + 8
         for (uint32_t j = (uint32_t)lane; j < n_seq; j += 64) {
-            const float* q = seq + 4 * (size_t)j;
-            if (ld(q + 3) != 0.0f) continue;
-            const float x = ld(q), y = ld(q + 1), z = ld(q + 2);
-            if (!inbox(x, y, z)) continue;
+            const float4 q = a.seq_out[j];
+            if (q.w != 0.0f || !inbox(q.x, q.y, q.z)) continue;
             ++cnt;
-            const float d = sqdist3(x, y, z, mid[0], mid[1], mid[2]);
-            if (d < dbest) { dbest = d; bx = x; by = y; bz = z; ord = 8u + j; }
+            const float d = sqdist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
+            if (d < dbest) { dbest = d; bx = q.x; by = q.y; bz = q.z; ord = 8u + j; }
         }
         // combine: count, and the first minimum in (distance, order)
 #pragma unroll
@@ -247,23 +251,19 @@ __device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane)
             ++counter;
             if (cnt > 0) {                                          // Delete_by_range of the box
                 for (uint32_t i = bst; i < bst + bct; ++i) {
-                    float* q = mp + 4 * (size_t)i;
-                    if (ld(q + 3) != 0.0f) continue;
-                    if (inbox(ld(q), ld(q + 1), ld(q + 2))) { st(q + 3, TOMB_DOWNSAMPLE); ++replaced; }
+                    const float4 sp = a.map_pts[i];
+                    if (sp.w == 0.0f && inbox(sp.x, sp.y, sp.z)) { a.map_pts[i].w = TOMB_DOWNSAMPLE; ++replaced; }
                 }
                 for (uint32_t j = (uint32_t)lane; j < n_seq; j += 64) {
-                    float* q = seq + 4 * (size_t)j;
-                    if (ld(q + 3) != 0.0f) continue;
-                    if (inbox(ld(q), ld(q + 1), ld(q + 2))) st(q + 3, 1.0f);
+                    const float4 q = a.seq_out[j];
+                    if (q.w == 0.0f && inbox(q.x, q.y, q.z)) a.seq_out[j].w = 1.0f;
                 }
             }
-            if (lane == 0) {                                        // Add_by_point of the winner
-                float* q = seq + 4 * (size_t)n_seq;
-                st(q, best.x); st(q + 1, best.y); st(q + 2, best.z); st(q + 3, 0.0f);
-            }
+            if (lane == 0) a.seq_out[n_seq] = make_float4(best.x, best.y, best.z, 0.0f);   // Add_by_point of the winner
             ++n_seq;
         }
-        __builtin_amdgcn_s_waitcnt(0);                             // the appends / tomb-stones are out before the next point reads
+        // the appends / tomb-stones are in L2 before the next point reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
