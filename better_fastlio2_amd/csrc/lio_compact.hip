@@ -205,6 +205,19 @@ __global__ __launch_bounds__(256) void pend_build_kernel(PendBuildArgs a) {
     const int tid = threadIdx.x;
     const uint32_t tp = (a.n_plain + 255u) / 256u;
     const int kb = frame_bits(a.frame) + 1;
+    if (a.count_parts != nullptr && blockIdx.x == gridDim.x - 1) {
+        // the extra workgroup: the fold's counters, one pair per workgroup of fold_commit_kernel, added up (fixed order)
+        uint32_t r = 0, c = 0;
+        for (uint32_t i = tid; i < a.n_count_parts; i += 256u) { const uint2 v = a.count_parts[i]; r += v.x; c += v.y; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { r += (uint32_t)__shfl_xor((int)r, o, 64); c += (uint32_t)__shfl_xor((int)c, o, 64); }
+        __shared__ uint32_t s_rc[4][2];
+        if ((tid & 63) == 0) { s_rc[tid >> 6][0] = r; s_rc[tid >> 6][1] = c; }
+        __syncthreads();
+        if (tid < 2) a.fold_counts[tid] = s_rc[0][tid] + s_rc[1][tid] + s_rc[2][tid] + s_rc[3][tid];
+        return;
+    }
+    const uint32_t n_tiles = gridDim.x - (a.count_parts != nullptr ? 1u : 0u);     // tiles of the list proper
     s_hist[tid] = 0u;
     __syncthreads();
     auto emit = [&](uint32_t pos, float4 p, uint32_t list) {
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(256) void pend_build_kernel(PendBuildArgs a) {
         const bool ok = tile_exclusive_prefix<1>(mine, a.agg, a.stamp, before, (int)b);
         if (ok && live) emit(a.n_plain + before[0] + r, p, 0u);
         if (!ok && tid == 0) atomicOr(a.err, 1u);
-        if (blockIdx.x == gridDim.x - 1 && tid == 0) *a.n_surv = ok ? before[0] + tot : 0u;
+        if (blockIdx.x == n_tiles - 1 && tid == 0) *a.n_surv = ok ? before[0] + tot : 0u;
     }
     if (a.hist != nullptr) {
         __syncthreads();
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(256) void pend_build_kernel(PendBuildArgs a) {
 hipError_t launch_pend_build(const PendBuildArgs& a, hipStream_t s) {
     const uint32_t tiles = (a.n_plain + 255u) / 256u + (a.n_surv_slots + 255u) / 256u;
     if (tiles == 0u) return hipMemsetAsync(a.n_surv, 0, sizeof(uint32_t), s);
-    hipLaunchKernelGGL(pend_build_kernel, dim3(tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pend_build_kernel, dim3(tiles + (a.count_parts != nullptr ? 1u : 0u)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

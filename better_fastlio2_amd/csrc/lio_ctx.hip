@@ -185,6 +185,7 @@ struct lio_ctx {
     uint8_t* d_add_cls = nullptr;
     uint8_t *d_add_dirty = nullptr, *d_add_dirty_pt = nullptr;   // boundary points of a down-sampled batch (lio_mapadd.hip)
     uint32_t* d_add_dlist = nullptr;
+    uint2* d_add_parts = nullptr;              // [16385] the fold's counters, one pair per workgroup of fold_commit_kernel
     float4* d_add_plan = nullptr;              // [2 n] the speculative fold's plan per head position (lio_mapadd.hip)
     uint2* d_add_ranges = nullptr;             // [8 n] the bucket ranges of its eight lanes
     uint64_t *d_add_keys = nullptr, *d_add_keys2 = nullptr;
@@ -607,6 +608,7 @@ static int ensure_add_buffers(lio_ctx* c, size_t n) {
     HIPCHK(c, hipMalloc((void**)&c->d_add_dirty, n));
     HIPCHK(c, hipMalloc((void**)&c->d_add_dirty_pt, n));
     HIPCHK(c, hipMalloc((void**)&c->d_add_dlist, n * sizeof(uint32_t)));
+    if (!c->d_add_parts) HIPCHK(c, hipMalloc((void**)&c->d_add_parts, 16400 * sizeof(uint2)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_plan, 2 * n * sizeof(float4)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_ranges, 8 * n * sizeof(uint2)));
     HIPCHK(c, hipMalloc((void**)&c->d_add_keys, n * sizeof(uint64_t)));
@@ -646,6 +648,9 @@ static int build_pending(lio_ctx* c, const KeyFrame& cf, SortKind kind) {
         const int rc = sort_hist(c, kind, &pb.hist);
         if (rc != LIO_OK) return rc;
     }
+    // (the fold's two counters arrive as one pair per workgroup of fold_commit_kernel: this kernel's extra workgroup adds them up)
+    pb.count_parts = c->fold_n != 0 ? c->d_add_parts : nullptr; pb.n_count_parts = c->fold_n != 0 ? fold_commit_workgroups(c->fold_n) : 0u;
+    pb.fold_counts = c->d_apply + 4;
     pb.n_surv = c->d_apply + 6; pb.flags = c->d_apply + 14; pb.agg = c->d_cagg; pb.stamp = next_compact_stamp(c); pb.err = c->d_apply + 15;
     if (kind == SORT_LIBRARY)                   // the library sorts every slot: the unused ones must sort last
         HIPCHK(c, hipMemsetAsync(c->d_pkeys, 0xFF, ((size_t)c->plain_n + (size_t)c->fold_n) * sizeof(uint64_t), s));
@@ -972,7 +977,7 @@ void lio_destroy(lio_ctx* c) {
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2,
-                   c->d_add_order, c->d_add_order2, c->d_add_dirty, c->d_add_dirty_pt, c->d_add_dlist, c->d_add_plan, c->d_add_ranges,
+                   c->d_add_order, c->d_add_order2, c->d_add_dirty, c->d_add_dirty_pt, c->d_add_dlist, c->d_add_plan, c->d_add_ranges, c->d_add_parts,
                    c->d_rep_send, c->d_rep_recv};
     for (void* p : dev) if (p) (void)hipFree(p);
     if (c->h_out) (void)hipHostFree(c->h_out);
@@ -1072,7 +1077,7 @@ static int fold_batch_device(lio_ctx* c, const float4* batch, uint32_t n, const 
     fa.map_pts = c->d_pts; fa.l1table = ba.l1table; fa.l1mask = ba.l1mask; fa.child = c->d_child;
     fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch; fa.view = view;
     fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
-    fa.plan = c->d_add_plan; fa.ranges = c->d_add_ranges;
+    fa.plan = c->d_add_plan; fa.ranges = c->d_add_ranges; fa.count_parts = c->d_add_parts;
     HIPCHK(c, launch_fold_plan(fa, ba, s));
     HIPCHK(c, launch_compact_dirty(ba, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
     HIPCHK(c, launch_fold_commit(fa, ba, s));

@@ -66,6 +66,7 @@ struct FoldArgs {
     const uint8_t*   dirty;         // per head position: 1 = left to the sequential replay ("boundary points")
     float4*          plan;          // [2 n] per head position: {survivor xyz, tmp_counter bits (0: nothing to do)}, {box min xyz, -}
     uint2*           ranges;        // [8 n] per head position and lane: the bucket {start, count} that lane scanned
+    uint2*           count_parts;   // [workgroups of fold_commit] {replaced map points, tmp_counter} per workgroup: summed by pend_build
 };
 struct IncrArgs {
     const float4*  body;            // feats_down_body
@@ -157,6 +158,7 @@ hipError_t launch_fold_plan(const FoldArgs& fa, const BoundaryArgs& ba, hipStrea
 hipError_t launch_compact_dirty(const BoundaryArgs& a, unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s);
 // the plans of the clean groups carried out AND (its first workgroup) the sequential replay of the dirty points
 hipError_t launch_fold_commit(const FoldArgs& fa, const BoundaryArgs& ba, hipStream_t s);
+uint32_t fold_commit_workgroups(uint32_t n);            // its grid (= entries of FoldArgs.count_parts)
 hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s);
 
 // first kernel of a down-sampled batch: voxel keys (compressed, frame) + order = iota, the partition histogram of the
@@ -194,6 +196,9 @@ struct PendBuildArgs {
     uint32_t*     order;            // out: iota
     uint32_t*     hist;             // partition histogram of the cell sort (nullptr = none)
     uint32_t*     n_surv;
+    const uint2*  count_parts;      // the fold's per-workgroup counter pairs (nullptr: no fold ran) ...
+    uint32_t      n_count_parts;
+    uint32_t*     fold_counts;      // ... their sums: [0] replaced map points, [1] tmp_counter
     uint32_t*     flags;
     unsigned long long* agg;
     uint32_t      stamp;

@@ -182,9 +182,9 @@ __device__ __forceinline__ uint32_t find_voxel_group(const BoundaryArgs& a, uint
 // starts with an agent-scope acquire (the L1 forgets its lines) and ends with a release (its stores are in L2), so the
 // reads in between are plain 16-byte loads, four in flight -- round 2 read every coordinate with an agent-scope atomic
 // of its own, 17 us per replayed point (measured: seven points were most of the fold's 120 us).
-__device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane) {
+__device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane, uint2* count_parts) {
     const uint32_t n_dirty = *a.n_dirty;
-    if (n_dirty == 0u) return;
+    if (n_dirty == 0u) { if (lane == 0) count_parts[0] = make_uint2(0u, 0u); return; }
     uint32_t n_seq = 0, counter = 0, replaced = 0;
     for (uint32_t it = 0; it < n_dirty; ++it) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -268,10 +268,7 @@ __device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane)
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) replaced += __shfl_xor(replaced, o, 64);
-    if (lane == 0) {
-        if (counter != 0) atomicAdd(a.n_added, counter);
-        if (replaced != 0) atomicAdd(a.n_replaced, replaced);
-    }
+    if (lane == 0) count_parts[0] = make_uint2(replaced, counter);
 }
 
 // live points of a bucket range, four loads in flight at a time (a lane's range is one contiguous run of 16-byte points)
@@ -467,10 +464,11 @@ __global__ __launch_bounds__(64) void fold_plan_kernel(FoldArgs a, BoundaryArgs 
 // voxels and disjoint map points.
 __global__ __launch_bounds__(64) void fold_commit_kernel(FoldArgs a, BoundaryArgs ba) {
     const int lane = threadIdx.x, t = lane & 7;
-    if (blockIdx.x == 0) { fold_sequential(ba, lane); return; }
+    if (blockIdx.x == 0) { fold_sequential(ba, lane, a.count_parts); return; }
     const uint32_t n = view_count(a.view);
     const float ds = a.ds;
     const uint32_t spw = 8u;
+    uint32_t replaced_sum = 0, added_sum = 0;
     for (uint32_t s0 = (blockIdx.x - 1u) * spw; s0 < a.view.n; s0 += (gridDim.x - 1u) * spw) {
         const uint32_t s = s0 + ((uint32_t)lane >> 3);
         const bool valid = s < n && view_is_head(a.view, s) && a.dirty[s] == 0;
@@ -493,18 +491,18 @@ __global__ __launch_bounds__(64) void fold_commit_kernel(FoldArgs a, BoundaryArg
             });
             if (t == 0) a.out_pts[s] = make_float4(pl.x, pl.y, pl.z, 0.0f);      // (every slot starts as "nothing")
         }
-        // the two counters: summed over the wavefront first -- 10^5 atomics on ONE address serialise at the memory side
-        uint32_t c_add = (touched && t == 0) ? counter : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            replaced += (uint32_t)__shfl_xor((int)replaced, o, 64);
-            c_add += (uint32_t)__shfl_xor((int)c_add, o, 64);
-        }
-        if (lane == 0) {
-            if (replaced != 0) atomicAdd(a.n_replaced, replaced);
-            if (c_add != 0) atomicAdd(a.n_added, c_add);
-        }
+        replaced_sum += replaced;
+        added_sum += (touched && t == 0) ? counter : 0u;
     }
+    // The two counters of the batch (replaced map points, tmp_counter) leave as ONE pair per workgroup; pend_build_kernel, the
+    // next launch, adds the pairs up.  Atomics on one address serialise at the memory side of an eight-XCD part (~7 ns each,
+    // measured): one per voxel group was 170 us of this kernel with eight replicas' lists, one per wavefront still 120 us.
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        replaced_sum += (uint32_t)__shfl_xor((int)replaced_sum, o, 64);
+        added_sum += (uint32_t)__shfl_xor((int)added_sum, o, 64);
+    }
+    if (lane == 0) a.count_parts[blockIdx.x] = make_uint2(replaced_sum, added_sum);
 }
 
 // ---- incremental index update -------------------------------------------------------------------------
@@ -590,7 +588,8 @@ __device__ __forceinline__ uint32_t table_claim(HashEntry* table, uint32_t mask,
     return 0xffffffffu;
 }
 
-__global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
+__global__ __launch_bounds__(256) void cell_apply_kernel(ApplyArgs a) {
+    __shared__ uint32_t s_stat[4][2];
     const uint32_t n = view_count(a.view);
     // room check on the device (every lane sees the same total): either the whole batch is applied or nothing is
     const uint32_t total = a.stats[3];
@@ -667,9 +666,11 @@ __global__ __launch_bounds__(64) void cell_apply_kernel(ApplyArgs a) {
         retired_sum += (uint32_t)__shfl_xor((int)retired_sum, o, 64);
         new_cells += (uint32_t)__shfl_xor((int)new_cells, o, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (new_cells != 0) atomicAdd(a.stats + 0, new_cells);
-        if (retired_sum != 0) atomicAdd(a.stats + 1, retired_sum);
+    if ((threadIdx.x & 63) == 0) { s_stat[threadIdx.x >> 6][0] = new_cells; s_stat[threadIdx.x >> 6][1] = retired_sum; }
+    __syncthreads();
+    if (threadIdx.x < 2) {                                        // (few workgroups: a few hundred atomics, not one per cell)
+        const uint32_t v = s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x] + s_stat[2][threadIdx.x] + s_stat[3][threadIdx.x];
+        if (v != 0) atomicAdd(a.stats + threadIdx.x, v);
     }
 }
 
@@ -700,10 +701,13 @@ hipError_t launch_fold_plan(const FoldArgs& fa, const BoundaryArgs& ba, hipStrea
     hipLaunchKernelGGL(fold_plan_kernel, dim3(b), dim3(64), 0, s, fa, ba);
     return hipGetLastError();
 }
+uint32_t fold_commit_workgroups(uint32_t n) {
+    uint32_t b = (n + 7u) / 8u; if (b > 16384u) b = 16384u;
+    return b + 1u;
+}
 hipError_t launch_fold_commit(const FoldArgs& fa, const BoundaryArgs& ba, hipStream_t s) {
     if (fa.view.n == 0) return hipSuccess;
-    uint32_t b = (fa.view.n + 7u) / 8u; if (b > 16384u) b = 16384u;
-    hipLaunchKernelGGL(fold_commit_kernel, dim3(b + 1u), dim3(64), 0, s, fa, ba);
+    hipLaunchKernelGGL(fold_commit_kernel, dim3(fold_commit_workgroups(fa.view.n)), dim3(64), 0, s, fa, ba);
     return hipGetLastError();
 }
 hipError_t launch_cell_plan(const ApplyArgs& a, hipStream_t s) {
@@ -713,8 +717,8 @@ hipError_t launch_cell_plan(const ApplyArgs& a, hipStream_t s) {
 }
 hipError_t launch_cell_apply(const ApplyArgs& a, hipStream_t s) {
     if (a.view.n == 0) return hipSuccess;
-    uint32_t b = (a.view.n + 63u) / 64u; if (b > 8192u) b = 8192u;
-    hipLaunchKernelGGL(cell_apply_kernel, dim3(b), dim3(64), 0, s, a);
+    uint32_t b = (a.view.n + 255u) / 256u; if (b > 512u) b = 512u;
+    hipLaunchKernelGGL(cell_apply_kernel, dim3(b), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
