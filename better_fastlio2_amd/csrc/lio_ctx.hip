@@ -396,6 +396,15 @@ static int run_sort(lio_ctx* c, SortKind k, const uint64_t* keys_in, const uint3
     }
     return LIO_OK;
 }
+// the live points of the point array to the front of dst, order kept: three streaming launches (lio_compact.hip), or the library
+static hipError_t compact_live_any(lio_ctx* c, const float4* src, uint32_t n, float4* dst, uint32_t* n_out) {
+    if (c->dbg_library_sort) return select_live_points(c->d_temp, c->temp_bytes, src, dst, n_out, n, c->stream);
+    // (tile counts and offsets live in the sort workspace, which is idle here)
+    uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(c->d_temp);
+    uint32_t* tile_off = tile_cnt + (n / 2048u + 4u);
+    if (((size_t)n / 2048u + 4u) * 2u * sizeof(uint32_t) > c->temp_bytes) return select_live_points(c->d_temp, c->temp_bytes, src, dst, n_out, n, c->stream);
+    return launch_compact_live_large(src, n, dst, n_out, tile_cnt, tile_off, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, c->stream);
+}
 // frame of the integer coordinates lo .. hi (inclusive) of a batch: one spare coordinate per axis above hi, so that the
 // all-ones key is never a point's (the group of the non-finite points, lio_mapadd.hip)
 static KeyFrame frame_of(const int lo[3], const int hi[3]) {
@@ -510,8 +519,10 @@ int finish_index(lio_ctx* c, uint32_t n) {
         if (L == 1) {
             // cell directory: one block of 64 {start, count} per level-1 cell, with room for the level-1 cells that
             // incremental updates will add
-            const size_t need = (size_t)n_l + (size_t)n_l / 4 + 4096;
+            size_t need = (size_t)n_l + (size_t)n_l / 4 + 4096;
             if (need > c->child_blocks_cap) {
+                // (grown by half at least: a re-allocation is a device synchronisation plus ~0.3 ms, not something to pay at every rebuild of a growing map)
+                if (need < c->child_blocks_cap + c->child_blocks_cap / 2) need = c->child_blocks_cap + c->child_blocks_cap / 2;
                 if (c->d_child) (void)hipFree(c->d_child);
                 c->d_child = nullptr; c->child_blocks_cap = 0;
                 HIPCHK(c, hipMalloc((void**)&c->d_child, need * 64 * sizeof(uint2)));
@@ -699,7 +710,7 @@ int rebuild_full(lio_ctx* c) {
     }
     uint32_t live = 0;
     if (n_all > 0) {
-        HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_pts_tmp, c->d_counters + 3, n_all, s));
+        HIPCHK(c, compact_live_any(c, c->d_pts, n_all, c->d_pts_tmp, c->d_counters + 3));
         HIPCHK(c, read_back(c, &live, c->d_counters + 3, sizeof(uint32_t)));
     }
     if ((size_t)live + (size_t)n_pend > c->cap_map)
@@ -1668,7 +1679,7 @@ int lio_map_flatten(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
     if (n) *n = (long long)c->n_live;
     if (c->n_points == 0 || cap == 0) return LIO_OK;
     // compact the live points (order-preserving), pack xyz, download
-    HIPCHK(c, select_live_points(c->d_temp, c->temp_bytes, c->d_pts, c->d_pts_tmp, c->d_counters + 3, c->n_points, c->stream));
+    HIPCHK(c, compact_live_any(c, c->d_pts, c->n_points, c->d_pts_tmp, c->d_counters + 3));
     uint32_t live = 0;
     HIPCHK(c, read_back(c, &live, c->d_counters + 3, sizeof(uint32_t)));
     if (n) *n = (long long)live;

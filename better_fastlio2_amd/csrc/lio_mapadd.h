@@ -226,6 +226,10 @@ hipError_t launch_run_heads(const uint64_t* keys, uint32_t n, int shift, uint32_
                             uint32_t stamp, uint32_t* err, hipStream_t s);
 hipError_t launch_exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, unsigned long long* agg, uint32_t stamp, uint32_t* err,
                                  hipStream_t s);
+// live points (w == 0) of a large array to the front of dst, order kept (three launches: tile counts, their scan, scatter);
+// tile_cnt / tile_off: n / 2048 + 2 words each
+hipError_t launch_compact_live_large(const float4* src, uint32_t n, float4* dst, uint32_t* n_out, uint32_t* tile_cnt, uint32_t* tile_off,
+                                     unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s);
 // bounding box (order images, six atomics per workgroup) of n float4 points
 hipError_t launch_bbox(const float4* pts, uint32_t n, uint32_t* bbox, hipStream_t s);
 
