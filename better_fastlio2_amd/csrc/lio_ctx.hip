@@ -335,7 +335,12 @@ int upload_points(lio_ctx* c, const float* pts, size_t n, int stride_bytes, floa
 // stamp of the next single-launch compaction (lio_compact.hip): never 0 (the scratch starts zeroed), never repeated within
 // 2^32 launches; *err lives in d_apply[15]
 static uint32_t next_compact_stamp(lio_ctx* c) {
-    if (++c->compact_seq == 0u) ++c->compact_seq;
+    if (++c->compact_seq == 0u) {
+        // the 32-bit stamp has gone round: words stamped 2^32 launches ago must not pass for this launch's -- start over from
+        // clean scratch (once in 2^32 launches; the stream orders the clear before the launch that follows)
+        (void)hipMemsetAsync(c->d_cagg, 0, c->cagg_words * sizeof(unsigned long long), c->stream);
+        ++c->compact_seq;
+    }
     return c->compact_seq;
 }
 static int check_compact_error(lio_ctx* c, uint32_t flag_word) {
@@ -387,7 +392,11 @@ static int run_sort(lio_ctx* c, SortKind k, const uint64_t* keys_in, const uint3
         g.keys = keys_in; g.vals = vals_in; g.n = (uint32_t)n_bound; g.n_dev = n_dev; g.n_dev_add = n_dev_add; g.kb = kb;
         g.keys_out = keys_out; g.vals_out = vals_out; g.part = c->d_gs_part; g.part2 = c->d_gs_part2;
         g.hist = c->d_ghist + 256 * c->ghist_cur; g.hist_other = c->d_ghist + 256 * (c->ghist_cur ^ 1);
-        g.agg = c->d_gagg; g.stamp = (++c->gsort_seq == 0u) ? ++c->gsort_seq : c->gsort_seq; g.err = c->d_apply + 15;
+        if (++c->gsort_seq == 0u) {                        // (stamp wrap-around: as next_compact_stamp)
+            HIPCHK(c, hipMemsetAsync(c->d_gagg, 0, GSORT_AGG_WORDS * sizeof(unsigned long long), s));
+            ++c->gsort_seq;
+        }
+        g.agg = c->d_gagg; g.stamp = c->gsort_seq; g.err = c->d_apply + 15;
         HIPCHK(c, launch_gsort_large(g, s));
         c->ghist_cur ^= 1;
         c->ghist_dirty = false;
@@ -2088,6 +2097,15 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
     ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.rows = nullptr; ra.units = c->d_units; ra.gunits = c->d_gunits;
+    if ((uint32_t)(c->seq + 1ull) == 0u) {
+        // The partial sums carry the low 32 bits of the sequence number as their stamp (lio_measure.hip): when those go round, a
+        // unit left by a pass 2^32 passes ago -- a larger scan's grid had workgroups this one lacks -- must not pass for this pass's.
+        // Stamp 0 is never used; the units start over from zero (once in 2^32 passes: ~39 h at 30 k passes/s).
+        const size_t blocks = (size_t)residual_blocks(c->cap_q), groups = (blocks + RED_GROUP - 1) / RED_GROUP;
+        (void)hipMemsetAsync(c->d_units, 0, blocks * RED_STRIDE * 2 * sizeof(unsigned long long), s);
+        (void)hipMemsetAsync(c->d_gunits, 0, groups * RED_STRIDE * 2 * sizeof(unsigned long long), s);
+        ++c->seq;
+    }
     const unsigned long long seq = ++c->seq;
     ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
     ra.debug_fail = (c->dbg_force_timeout ? 1 : 0) | (c->dbg_stamps ? 2 : 0);
@@ -2307,6 +2325,10 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "knn_tune") == 0) { c->dbg_knn_tune = (int)value; return LIO_OK; }
     if (std::strcmp(key, "rows_direct") == 0) { c->dbg_rows_direct = (int)value; return LIO_OK; }
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
+    if (std::strcmp(key, "sequence_numbers") == 0) {           // test hook: the next pass / compaction launch take these numbers + 1 (stamp wrap-around)
+        c->seq = (unsigned long long)value; c->compact_seq = (uint32_t)value; c->gsort_seq = (uint32_t)value;
+        return LIO_OK;
+    }
     if (std::strcmp(key, "replicate_loopback") == 0) { c->dbg_rep_loopback = value != 0; return LIO_OK; }
     if (std::strcmp(key, "replicate_loopback_rank") == 0) {
         if (!c->rep_loopback || value < 0 || value >= c->rep_world) return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "replicate_loopback_rank outside a loop-back world");

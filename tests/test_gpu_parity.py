@@ -447,6 +447,41 @@ def test_add_points_large_batches(gpu_capi, oracle, small_case, shape):
     ctx.close()
 
 
+def test_stamp_wrap_around(gpu_capi, synth, small_case):
+    """The cross-workgroup hand-offs are stamped with 32-bit sequence numbers (partial sums of the measurement kernel, tile
+    counts of the single-launch scans and of the group sort).  When a number goes round, words stamped 2^32 launches ago must
+    not pass for fresh ones -- the scratch starts over.  Driven across the wrap with the sequence numbers set just below it:
+    a large scan first (its workgroups leave stamps a smaller scan's grid never overwrites), then smaller scans and map
+    updates across the boundary; every result equals the one of a context that never wrapped."""
+    w = small_case["world"]
+    big = synth.make_scan(w, 20_000)
+    small = [synth.make_scan(w, 3_000 + 500 * k, seed=synth.SEED + 60 + k, pos=(2.0 + k, -1.0, 0.0), rpy=(0.0, 0.0, 0.3 + 0.1 * k)) for k in range(4)]
+    res = []
+    for wrap in (False, True):
+        ctx = gpu_capi.LioContext(0.2, max_scan_points=20_000, max_map_points=400_000)
+        ctx.map_build(np.ascontiguousarray(w.points[::2]))
+        if wrap:
+            ctx.debug_set("sequence_numbers", 2 ** 32 - 3)
+        out = []
+        st = synth.state_vector(*synth.perturb_state(big), big.off_R, big.off_T)
+        ctx.scan_set(big.body)
+        out.append(ctx.measure(st, True, False)["HTH"].copy())
+        for sc in small:
+            st = synth.state_vector(*synth.perturb_state(sc), sc.off_R, sc.off_T)
+            ctx.scan_set(sc.body)
+            g1 = ctx.measure(st, True, False)
+            g2 = ctx.measure(st, False, False)
+            r = ctx.map_incremental(st, 0.2, True, apply=True)
+            out.append((g1["m"], g1["HTH"].copy(), g2["HTH"].copy(), r["n_add"], r["n_nodown"], r["add_counter"], ctx.map_validnum()))
+        out.append(ctx.map_flatten().copy())
+        res.append(out)
+        ctx.close()
+    a, b = res
+    assert np.array_equal(a[0], b[0]) and bits_equal(a[-1], b[-1])
+    for x, y in zip(a[1:-1], b[1:-1]):
+        assert x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and x[3:] == y[3:]
+
+
 def test_edge_cases(gpu_capi, oracle, small_case):
     sc, st = small_case["scan"], small_case["state14"]
     ctx = gpu_capi.LioContext(0.2, max_scan_points=1000, max_map_points=10_000)
