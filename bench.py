@@ -277,8 +277,17 @@ def callback_figures(ctx, capi, synth, world, scans, scan_poses, priors, P0_p, u
                 raise capi.LioError(f"{name}: cbb_step failed ({rc}): " + ctx.L.lio_last_error(ctx.h).decode())
         tick[0] = 0
         lat = []
-        t = timed_steps(f, k_steps, w_steps, None, device, lat)
+        for _ in range(w_steps):
+            f()
+        B.cbb_take_model_seconds()
+        t = timed_steps(f, k_steps, 0, None, device, lat)
+        in_model = float(B.cbb_take_model_seconds())
+        # the callback (library + adaptor: upload of the host cloud, the pass, rows or sums back) against the rest of the step
+        # (the filter's own algebra on the returned rows: h_x^T h_x on one host core, the 12 x 12 solve, the state update)
         return {"value": k_steps / t, "unit": "scans/s", "ms_per_step": t / k_steps * 1e3, "steps": k_steps, "rows_per_pass": int(B.cbb_last_m()),
+                "ms_per_step_inside_h_share_model": in_model / k_steps * 1e3,
+                "ms_per_step_filter_algebra_on_the_rows": (t - in_model) / k_steps * 1e3,
+                "scans_per_s_if_the_filter_algebra_were_free": k_steps / in_model if in_model > 0 else None,
                 "latency": latency_summary(lat)}
 
     B.cbb_setup(ctx.h, nq)
@@ -320,6 +329,33 @@ def callback_figures(ctx, capi, synth, world, scans, scan_poses, priors, P0_p, u
     node["value_library_filter_serial_upload"] = {"value": max(k_steps, 40) / t, "unit": "scans/s", "ms_per_step": t / max(k_steps, 40) * 1e3}
     out["callback_at_node_scan_size"] = node
     ctx.measure_want_rows(False)
+    return out
+
+
+def sustained_figure(ctx, per_step_s, info0, info1, one_more_step):
+    """The loop windows of this bench are a few dozen scans: shorter than the distance between two full index rebuilds
+    (they come when the retired slots reach twice the live points).  Price them in: force ONE rebuild now (the budget knob
+    of lio_debug_set, one more step, timed), derive the steps between rebuilds from the retired slots per step this window
+    produced, and quote the rate with that share of a rebuild added to every step."""
+    upd = max(info1["n_incremental_updates"] - info0["n_incremental_updates"], 1)
+    rebuilds_in_window = info1["n_full_rebuilds"] - info0["n_full_rebuilds"]
+    retired_per_step = max(info1["n_retired"] - info0["n_retired"], 0) / upd if rebuilds_in_window == 0 else None
+    ctx.debug_set("retired_budget", 1)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    one_more_step()
+    ctx.synchronize()
+    forced_ms = (time.perf_counter() - t0) * 1e3
+    ctx.debug_set("retired_budget", 0)
+    info2 = ctx.map_info()
+    rebuild_ms = max(forced_ms - per_step_s * 1e3, 0.0)
+    out = {"rebuild_ms": rebuild_ms, "forced_rebuild_happened": info2["n_full_rebuilds"] == info1["n_full_rebuilds"] + 1,
+           "retired_slots_per_step": retired_per_step, "retired_budget": 2 * info1["n_live"]}
+    if retired_per_step:
+        between = max(2.0 * info1["n_live"] / retired_per_step, 1.0)
+        out["steps_between_rebuilds"] = between
+        out["ms_per_step"] = per_step_s * 1e3 + (rebuild_ms / between if rebuilds_in_window == 0 else 0.0)
+        out["value"] = 1e3 / out["ms_per_step"]
     return out
 
 
@@ -400,8 +436,11 @@ def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, 
            "boundary_points_replayed_per_step": (info["n_boundary_points"] - info0["n_boundary_points"]) / max(info["n_incremental_updates"] - info0["n_incremental_updates"], 1),
            "vs_node_loop_world1": (1.0 / per_step) / node_loop_1["value"],
            "latency": latency_summary(lat),
+           "sustained": sustained_figure(ctx, per_step, info0, info, lambda: one(False)),
            "how": f"one GPU, lio_debug_set replicate_loopback: {W - 1} virtual ranks park their lists (untimed), the timed rank "
                   "runs its scan step + lio_replicate_step over all lists; no wire time"}
+    if "value" in out["sustained"] and "value" in node_loop_1.get("sustained", {}):
+        out["sustained"]["vs_node_loop_world1"] = out["sustained"]["value"] / node_loop_1["sustained"]["value"]
     return out
 
 
@@ -617,6 +656,7 @@ def main():
         ctx.profile_reset()
         tick[0] = 0
         lat_node = []
+        info_n0 = ctx.map_info()
         t_node = timed_steps(sampled(step_node), k_node, 4, dist, device, lat_node)
         prof_node = ctx.profile()
         ctx.profile_enable(False)
@@ -629,6 +669,8 @@ def main():
                                "incremental_index_updates": info["n_incremental_updates"], "full_index_rebuilds": info["n_full_rebuilds"],
                                "boundary_points_replayed_per_step": info["n_boundary_points"] / max(info["n_incremental_updates"], 1),
                                "latency": latency_summary(lat_node)}
+        if dist is None:
+            extras["node_loop"]["sustained"] = sustained_figure(ctx, t_node / k_node, info_n0, info, step_node)
         if dist is None and a.emulate_world > 1:
             extras["node_loop_emulated_world%d" % a.emulate_world] = emulated_world_loop(
                 a.emulate_world, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, P0_p, ulog_ref, max(8, min(a.steps, 24)),

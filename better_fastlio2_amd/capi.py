@@ -227,6 +227,7 @@ def callback_bench():
         B.cbb_add_scan.argtypes = [_vp, C.c_int, C.c_int]
         B.cbb_step.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp]
         B.cbb_last_m.restype = C.c_int
+        B.cbb_take_model_seconds.restype = C.c_double
         _cbb = B
     return _cbb
 

@@ -298,10 +298,14 @@ __global__ __launch_bounds__(256) void live_tile_count_kernel(const float4* __re
     __shared__ uint32_t s_w[4];
     const uint32_t t = blockIdx.x;
     if (t >= n_tiles) { if (threadIdx.x == 0) tile_cnt[t] = 0u; return; }        // the entry behind the last tile: the scan's total
-    const uint32_t i0 = t * LIVE_TILE + threadIdx.x * 8u;
+    // (only the tile's total is wanted: neighbouring lanes read neighbouring slots, the eight loads of a lane are independent)
+    const uint32_t i0 = t * LIVE_TILE + threadIdx.x;
+    float w[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) w[u] = i0 + u * 256u < n ? src[i0 + u * 256u].w : 1.0f;
     uint32_t c = 0;
 #pragma unroll
-    for (uint32_t u = 0; u < 8u; ++u) c += (i0 + u < n && src[i0 + u].w == 0.0f) ? 1u : 0u;
+    for (uint32_t u = 0; u < 8u; ++u) c += w[u] == 0.0f ? 1u : 0u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -72,6 +73,7 @@ struct lio_ctx {
     uint32_t n_retired = 0;                    // TOMB_MOVED slots since the last full rebuild
     uint32_t n_dead = 0;                       // box-deleted slots since the last full rebuild
     long long n_incremental_updates = 0, n_full_rebuilds = 0, n_boundary_points = 0;
+    bool trace_rebuilds = false;               // LIO_TRACE_REBUILDS=1 in the environment: one stderr line per budget-triggered rebuild
     long long dbg_retired_budget = 0;          // lio_debug_set("retired_budget"): overrides the budget of retired slots (tests)
     uint32_t n_new_cells = 0, n_cells_built = 0;   // cells inserted since / present at the last full rebuild
     uint32_t level_entries[TREE_MAX_LEVELS]{};     // entries of each hashed level at the last full rebuild
@@ -772,10 +774,13 @@ int apply_pending(lio_ctx* c) {
     c->n_live += n_real;
     c->n_cells += st[0]; c->n_new_cells += st[0]; c->n_retired += st[1];
     ++c->n_incremental_updates;
-    // Retired copies of re-written buckets (TOMB_MOVED) cost memory and nothing else -- no search ever reads them: they may
-    // grow until the array would be half dead.  Box-deleted points sit INSIDE live buckets and are streamed by every
+    // Retired copies of re-written buckets (TOMB_MOVED) cost memory and nothing else -- no search ever reads them, and 16 bytes
+    // a slot is cheap on a 288 GB part: they may grow to twice the live points (the array is sized for that; a full tail asks
+    // for the rebuild by itself, APPLY_FLAG_NO_ROOM).  Box-deleted points sit INSIDE live buckets and are streamed by every
     // search that passes: their budget stays tight.
-    const uint32_t retired_budget = c->dbg_retired_budget > 0 ? (uint32_t)c->dbg_retired_budget : (c->n_live / 2 > 262144u ? c->n_live / 2 : 262144u);
+    const uint64_t twice_live = 2ull * c->n_live;
+    const uint32_t retired_budget = c->dbg_retired_budget > 0 ? (uint32_t)c->dbg_retired_budget
+                                  : (uint32_t)(twice_live > 1048576ull ? (twice_live < 0xfffffff0ull ? twice_live : 0xfffffff0ull) : 1048576ull);
     const uint32_t dead_budget = c->n_live / 8 > 65536u ? c->n_live / 8 : 65536u;
     // Keep every hashed level at most half full (they are built a quarter full; the apply kernel counts the entries a
     // level gains), so that probe sequences stay short and a look-up of an absent key always meets an empty slot --
@@ -784,8 +789,13 @@ int apply_pending(lio_ctx* c) {
     for (int L = 1; L < c->levels.top_level; ++L)
         table_crowded = table_crowded || ((size_t)c->level_entries[L] + (size_t)st[APPLY_LEVEL_NEW + L]) * 2 > (size_t)c->levels.mask[L] + 1;
     if (st[2] != 0 || table_crowded || (size_t)c->n_retired > (size_t)retired_budget || (size_t)c->n_dead > (size_t)dead_budget ||
-        (size_t)c->n_new_cells * 4 > (size_t)c->n_cells_built + 1024)
+        (size_t)c->n_new_cells * 4 > (size_t)c->n_cells_built + 1024) {
+        if (c->trace_rebuilds)
+            std::fprintf(stderr, "lio: full rebuild after %llu incremental updates: flags %u crowded %d retired %u/%u dead %u/%u new cells %u of %u built, live %u slots %u\n",
+                         (unsigned long long)c->n_incremental_updates, st[2], (int)table_crowded, c->n_retired, retired_budget, c->n_dead, dead_budget,
+                         c->n_new_cells, c->n_cells_built, c->n_live, c->n_points);
         return rebuild_full(c);
+    }
     return LIO_OK;
 }
 
@@ -896,6 +906,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
         }                                                                        \
     } while (0)
     CREATE_CHK(hipSetDevice(c->device));
+    { const char* e = std::getenv("LIO_TRACE_REBUILDS"); c->trace_rebuilds = e != nullptr && e[0] == '1'; }
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, c->device));
     c->arch = prop.gcnArchName;
@@ -913,7 +924,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     c->cap_map = nm;
     // buckets that receive points are re-written at the tail of the array; the room for that is ours, not the
     // caller's (max_map_points bounds the live points)
-    c->slots_cap = nm + nm / 2 + 524288;
+    c->slots_cap = 3 * nm + 1048576;           // live points + the budget of retired slots (apply_pending)
     if (c->slots_cap > 0xfffffff0ull) c->slots_cap = 0xfffffff0ull;
     CREATE_CHK(hipMalloc((void**)&c->d_pts, c->slots_cap * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_pts_tmp, c->slots_cap * sizeof(float4)));

@@ -14,6 +14,7 @@ typedef std::shared_ptr<StubCloud> CloudPtr;
 typedef esekfom::dyn_share_datastruct<double> DynShare;
 #include <lio_hip_adaptor.hpp>
 
+#include <chrono>
 #include <cstring>
 
 namespace {
@@ -32,6 +33,7 @@ std::unique_ptr<lio::NodeGlobals<PointType, CloudPtr, std::vector<PointVector>>>
 std::vector<CloudPtr> scans;                                            // what downSizeFilterSurf.filter left, one cloud per scan of the drive
 DynShare dyn;                                                           // the filter's dyn_share (esekfom.hpp:1636)
 bool patched_mode = false;
+double seconds_in_model = 0.0;                                           // inside the callback (library + adaptor), summed over the passes
 
 void h_share_model(state_ikfom& s, DynShare& ekfom_data) { lio::h_share_model(ikdtree, s, ekfom_data, *G); }   // :1876
 
@@ -43,7 +45,12 @@ state_ikfom state_of(const double x[26]) {
 }
 
 // h_dyn_share of the filter = the node's callback, unmodified signature
+struct ModelClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~ModelClock() { seconds_in_model += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 void model(void*, const double x26[26], lio_dyn_share* d) {
+    ModelClock clock;
     state_ikfom s = state_of(x26);
     if (!patched_mode) {
         dyn.converge = d->converge != 0; dyn.valid = true;
@@ -110,4 +117,6 @@ int cbb_step(lio_eskf* kf, int k, const double* x26, const double* P, double R, 
     }
 }
 int cbb_last_m(void) { return effct_feat_num; }
+// seconds spent inside the measurement-model callback since the last call (the rest of a step is the filter's own dense algebra)
+double cbb_take_model_seconds(void) { const double t = seconds_in_model; seconds_in_model = 0.0; return t; }
 }

@@ -1,25 +1,16 @@
-# Round-3 GPU visit: -m gpu tests, the driver's bench command, and a kernel time line of one emulated-world step.
-#   gpurun --timeout 1200 -- 'bash scripts/r03_check.sh r03a [pytest-args]'
+# bench time lines only (no tests): kernel trace of bench.py with the rebuild reasons on stderr
 tag=${1:-r03x}
-shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
-(time timeout 900 python -m pytest tests -m gpu -q "$@") > $O/pytest_gpu.log 2>&1
-grep -a -E "passed|failed|error" $O/pytest_gpu.log | tail -3
-grep -a -E "^(FAILED|ERROR)|Error|assert" $O/pytest_gpu.log | head -20
-timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+LIO_TRACE_REBUILDS=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
+grep -a "full rebuild" $O/bench.err | tail -20
 python - <<PY
 import json
 d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1])
-print('value', round(d['value'],1), 'ms/step', round(d['ms_per_step'],4), {k: round(v['value'],1) for k,v in d.items() if isinstance(v,dict) and 'value' in v and k!='cpu_baseline'})
-print('latency', d.get('latency'))
-print('kernels_us', {k: round(v,2) for k,v in d['kernels_us'].items()})
-print('roofline', [(x['kernel'][:40], round(x['avg_launch_us'],2), round(x['frac'],3)) for x in d['roofline_detail']])
-print('node_loop', {k: v for k, v in d['node_loop'].items()})
+print('value', round(d['value'],1), {k: round(v['value'],1) for k,v in d.items() if isinstance(v,dict) and 'value' in v and k!='cpu_baseline'})
 for k in d:
-    if k.startswith('node_loop_emulated'): print(k, d[k])
+    if k.startswith('node_loop'): print(k, d[k])
 print('sustained', {k: d[k].get('sustained') for k in d if k.startswith('node_loop')})
-print('parity', {k: v for k, v in d.get('parity',{}).items() if k != 'neighbors_bit_exact'})
 PY
 cd /tmp && export TMPDIR=/tmp
 timeout 500 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $O/trace_bench.log 2> $O/trace_bench.err
