@@ -73,6 +73,15 @@ struct lio_ctx {
     uint32_t n_retired = 0;                    // TOMB_MOVED slots since the last full rebuild
     uint32_t n_dead = 0;                       // box-deleted slots since the last full rebuild
     long long n_incremental_updates = 0, n_full_rebuilds = 0, n_boundary_points = 0;
+    // LIO_TRACE_HOST=1 in the environment: host time stamps of the measurement passes (begin entry / launches issued / end entry /
+    // record seen, with the number of polls: 0 polls = the GPU had finished before the host asked), dumped by lio_destroy
+    bool trace_host = false;
+    struct HostStamp { char tag; long long ns; unsigned polls; };
+    std::vector<HostStamp> host_trace;
+    void stamp(char tag, unsigned polls = 0) {
+        if (!trace_host || host_trace.size() >= 4096) return;
+        host_trace.push_back({tag, (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(), polls});
+    }
     bool trace_rebuilds = false;               // LIO_TRACE_REBUILDS=1 in the environment: one stderr line per budget-triggered rebuild
     long long dbg_retired_budget = 0;          // lio_debug_set("retired_budget"): overrides the budget of retired slots (tests)
     uint32_t n_new_cells = 0, n_cells_built = 0;   // cells inserted since / present at the last full rebuild
@@ -130,7 +139,7 @@ struct lio_ctx {
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
     float4* d_ulist = nullptr;                 // queries the 27-cell kernel could not prove (count: d_counters[0])
     unsigned long long* d_useeds = nullptr;    // [list entry][8]: keys of their 27-cell results, the seeds of the walk; [5] = its verdict
-    double* d_spec_rows = nullptr;             // [scan point][SPEC_STRIDE]: staged rows of listed queries (search passes with few of them)
+    unsigned long long* d_lunits = nullptr;    // [FIX_MAX][RED_STRIDE][2]: stamped terms of the listed queries (search passes with few of them)
     double* d_rows = nullptr;
     // the unmodified-callback path (lio_measure_want_rows): every pass also leaves h_x / h compacted and column-major
     bool want_rows = false;
@@ -907,6 +916,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     } while (0)
     CREATE_CHK(hipSetDevice(c->device));
     { const char* e = std::getenv("LIO_TRACE_REBUILDS"); c->trace_rebuilds = e != nullptr && e[0] == '1'; }
+    { const char* e = std::getenv("LIO_TRACE_HOST"); c->trace_host = e != nullptr && e[0] == '1'; }
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, c->device));
     c->arch = prop.gcnArchName;
@@ -979,7 +989,8 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_sel, nq));
     CREATE_CHK(hipMalloc((void**)&c->d_ulist, nq * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_useeds, nq * 8 * sizeof(unsigned long long)));
-    CREATE_CHK(hipMalloc((void**)&c->d_spec_rows, nq * SPEC_STRIDE * sizeof(double)));
+    CREATE_CHK(hipMalloc((void**)&c->d_lunits, (size_t)FIX_MAX * RED_STRIDE * 2 * sizeof(unsigned long long)));
+    CREATE_CHK(hipMemset(c->d_lunits, 0, (size_t)FIX_MAX * RED_STRIDE * 2 * sizeof(unsigned long long)));
     {
         const size_t blocks = (size_t)residual_blocks((int)nq), groups = (blocks + RED_GROUP - 1) / RED_GROUP;
         CREATE_CHK(hipMalloc((void**)&c->d_units, blocks * RED_STRIDE * 2 * sizeof(unsigned long long)));
@@ -997,13 +1008,20 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
 }
 
 void lio_destroy(lio_ctx* c) {
+    if (c && c->trace_host && c->host_trace.size() > 1) {
+        const size_t n = c->host_trace.size(), from = n > 80 ? n - 80 : 0;
+        for (size_t i = from; i < n; ++i)
+            std::fprintf(stderr, "lio host trace %c %+9.2f us%s\n", c->host_trace[i].tag,
+                         i > from ? (double)(c->host_trace[i].ns - c->host_trace[i - 1].ns) * 1e-3 : 0.0,
+                         c->host_trace[i].tag == 'S' ? (c->host_trace[i].polls == 0 ? "  (no poll: the record was there)" : "  (polled)") : "");
+    }
     if (!c) return;
     (void)hipSetDevice(c->device);
     lio_replicate_finalize(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_gs_part, c->d_gs_part2, c->d_porder, c->d_porder2, c->d_pnewoff, c->d_plan, c->d_ghist, c->d_gagg, c->d_apply, c->d_temp, c->d_counters, c->d_cagg, c->d_cand, c->d_boxes,
-                   c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_useeds, c->d_spec_rows, c->d_rows, c->d_rows_c,
+                   c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_useeds, c->d_lunits, c->d_rows, c->d_rows_c,
                    c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, c->d_qs_useeds,
                    c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
@@ -2079,6 +2097,7 @@ static bool rows_direct(const lio_ctx* c, int nq) {
 // Jacobian-corrected P and its first inversion (esekfom.hpp:1655-1703, :1788) -- runs between the two, beside the GPU.
 int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int extrinsic_est_en) {
     if (!c || !state14) return LIO_ERR_INVALID_ARG;
+    c->stamp(do_search ? 'B' : 'b');
     if (c->pass_in_flight) return c->fail(LIO_ERR_INVALID_ARG, "lio_measure_begin", "the previous pass has not been collected (lio_measure_end)");
     if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "no scan set");
     if (!do_search && !c->have_search) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "first pass of a scan must search");
@@ -2115,6 +2134,7 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
         const size_t blocks = (size_t)residual_blocks(c->cap_q), groups = (blocks + RED_GROUP - 1) / RED_GROUP;
         (void)hipMemsetAsync(c->d_units, 0, blocks * RED_STRIDE * 2 * sizeof(unsigned long long), s);
         (void)hipMemsetAsync(c->d_gunits, 0, groups * RED_STRIDE * 2 * sizeof(unsigned long long), s);
+        (void)hipMemsetAsync(c->d_lunits, 0, (size_t)FIX_MAX * RED_STRIDE * 2 * sizeof(unsigned long long), s);
         ++c->seq;
     }
     const unsigned long long seq = ++c->seq;
@@ -2129,9 +2149,10 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     if (do_search && !separate_walk) {
         ra.n_walkers = residual_walkers(nq); ra.walk_done = c->d_counters + 16;
         ra.tree = tree_args(c, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds);
-        ra.spec_rows = c->d_spec_rows;
+        ra.lunits = c->d_lunits;
     }
     const hipError_t le = launch_residual(ra, do_search != 0, ext, s, prof_timer(c, LIO_PROF_RESIDUAL));
+    c->stamp('L');
     if (le != hipSuccess) { c->pass_in_flight = false; return c->fail(LIO_ERR_HIP, "launch_residual", hipGetErrorString(le)); }
     if (c->want_rows) {
         // right behind the pass: the rows of the selected points, compacted in scan order, column-major (m read on the device)
@@ -2165,6 +2186,7 @@ int lio_measure_end(lio_ctx* c, lio_out* out) {
     if (c->pass_empty) { out->valid = 0; return LIO_OK; }
     hipStream_t s = c->stream;
     const unsigned long long seq = c->seq;
+    c->stamp('E');
     // The record lands in host-mapped memory; poll its sequence number instead of paying for a
     // device-to-host copy plus a stream synchronisation.  hipStreamQuery guards against a fault.
     {
@@ -2182,6 +2204,7 @@ int lio_measure_end(lio_ctx* c, lio_out* out) {
             }
             __builtin_ia32_pause();
         }
+        c->stamp('S', spins);
     }
 
     const DeviceOut& d = *c->h_out;

@@ -86,19 +86,14 @@ struct ResidualArgs {
     int            n_walkers;       // 0: no walk in this launch (the stand-alone knn_tree_kernel ran, or a no-search pass)
     uint32_t*      walk_done;       // device counter: walked queries of this pass (reset by the last workgroup)
     TreeArgs       tree;            // map index + the list (tree.nbr / tree.cnt = the scan's neighbour arrays)
-    // Few listed queries (<= FIX_MAX, the normal case): nobody but the LAST workgroup waits for the walk, and the walk
-    // only VERIFIES.  knn27_kernel's unproven result is nearly always the exact one (a walk finds nothing better): the
-    // owner evaluates the model of such a query like any other but PARKS what it found (staged row, plane, pd2, accept
-    // flag) in spec_rows[q] instead of writing outputs / adding to its workgroup's sums, the walker of the query reports whether the walk changed the
-    // result (useeds[entry][5]), and the last workgroup, after its folds, adds the rows of the listed queries in query
-    // order -- the owner's row where the walk confirmed the result, a re-evaluated one where it did not -- and writes
-    // their outputs (one writer per query).  More listed
+    // Few listed queries (<= FIX_MAX, the normal case): nobody waits for a walk.  The walker workgroup of a listed query
+    // walks, evaluates the model on the exact neighbours and publishes the query's term of every sum as a stamped partial
+    // in lunits[rank of the query among the listed ones]; it also writes the query's outputs.  The owner of the query
+    // contributes a zero row.  The last model workgroup folds the listed slots like the group partials.  More listed
     // queries: the owners wait for the walk (see above).
-    double*        spec_rows;       // [max_scan_points][SPEC_STRIDE]: staged row of a listed query (written through)
+    unsigned long long* lunits;     // [FIX_MAX][RED_STRIDE][2] stamped halves of the listed queries' terms
 };
-constexpr int FIX_MAX = 256;                 // listed queries up to which the last workgroup adds the listed queries' rows
-constexpr int SPEC_STRIDE = 32;              // doubles per parked query (256 bytes: no two queries share a cache line): staged row (<= 15),
-constexpr int SPEC_USED = 19;                //   then n^ | d | pd2 | sel as 3 x 2 floats at [16..18]
+constexpr int FIX_MAX = 256;                 // listed queries up to which their walkers evaluate the model
 int residual_blocks(int nq);
 int residual_walkers(int nq);       // walking workgroups a search pass adds in front of the model workgroups
 hipError_t launch_residual(const ResidualArgs& a, bool do_search, bool extrinsic_est_en, hipStream_t s, KernelTimer t = KernelTimer());

@@ -78,36 +78,114 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     constexpr unsigned SPIN_LIMIT = 1u << 22;
     constexpr double POISON = -1.0e300;           // row count of a workgroup whose bounded wait ran out
 
-    // ---- walkers: the exact tree walk of the listed queries, one wavefront per workgroup -------------------------
+    // ---- walkers: the exact tree walk of the listed queries -----------------------------------------------------------
     const int n_walkers = WALK ? a.n_walkers : 0;
+    // few listed queries (the normal case, FIX_MAX in lio_kernels.h): their walkers also evaluate the model, nobody waits
+    const uint32_t n_listed = WALK && n_walkers > 0 ? (*a.n_unresolved & ~TREE_OVERFLOW) : 0u;       // complete: written by the k-NN launch before this one
+    const bool fix_mode = WALK && n_walkers > 0 && n_listed <= (uint32_t)FIX_MAX && n_listed <= (uint32_t)n_walkers;
     if (WALK && (int)blockIdx.x < n_walkers) {
-        if (tid >= 64) return;
-        __builtin_amdgcn_s_setprio(3);             // the walk is on the critical path of the pass: ahead of the model waves
         TreeScratch& ts = *reinterpret_cast<TreeScratch*>(s_raw);
-        const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;        // complete: written by the k-NN launch before this one
-        uint32_t walked = 0, n_changed = 0;
-        for (uint32_t e = blockIdx.x; e < n; e += (uint32_t)n_walkers) {
-            const float4 q = a.tree.ulist[e];
-            bool changed = true;
-            tree_search_one(a.tree, __float_as_uint(q.w), q.x, q.y, q.z, tid, ts, nullptr, a.tree.useeds ? a.tree.useeds + (size_t)e * 8u : nullptr, &changed);
-            // the verdict of this walk, for the last workgroup (fix mode): did it change Nearest_Points[q]?
-            if (tid == 0 && a.tree.useeds)
-                __hip_atomic_store(const_cast<unsigned long long*>(a.tree.useeds) + (size_t)e * 8u + 5u, (unsigned long long)(changed ? 1u : 0u),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ++walked;
-            n_changed += changed ? 1u : 0u;
-        }
-        if (walked != 0 && tid == 0) {
-            // results and verdicts are written THROUGH (agent-scope stores, lio_tree.h): drained = in memory; then the
-            // counter the waiters poll (no L2 write-back needed, and buffer_wbl2 costs ~1.7 us)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // walk_done[1]: walks that changed a result (rare) -- added first, so whoever sees the full count of walked
-            // entries also sees every change that belongs to them
-            if (n_changed != 0) {
-                __hip_atomic_fetch_add(a.walk_done + 1, n_changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!fix_mode) {
+            // many listed queries: one walking wavefront per workgroup, entries strided; the OWNERS of the queries wait (below)
+            if (tid >= 64) return;
+            __builtin_amdgcn_s_setprio(3);         // the walk is on the critical path of the pass: ahead of the model waves
+            uint32_t walked = 0;
+            for (uint32_t e = blockIdx.x; e < n_listed; e += (uint32_t)n_walkers) {
+                const float4 q = a.tree.ulist[e];
+                tree_search_one(a.tree, __float_as_uint(q.w), q.x, q.y, q.z, tid, ts, nullptr, a.tree.useeds ? a.tree.useeds + (size_t)e * 8u : nullptr);
+                ++walked;
             }
-            __hip_atomic_fetch_add(a.walk_done, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (walked != 0 && tid == 0) {
+                // results are written THROUGH (agent-scope stores, lio_tree.h): drained = in memory; then the counter the
+                // waiters poll (no L2 write-back needed, and buffer_wbl2 costs ~1.7 us)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(a.walk_done, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        // Fix mode: entry e = this workgroup's ONE listed query, finished here; nobody waits for a walk and the last model
+        // workgroup never orders or evaluates a listed query (before: ~6.5 us of one-workgroup work at the end of every
+        // search pass).  Wavefront 0 walks, then evaluates the model on the exact neighbours it holds in registers (at C2
+        // ~85 % of the walks do change the unproven result) and publishes the PRODUCTS of the query's row -- its term of
+        // every sum -- as a stamped partial in the slot of the query's RANK among the listed queries (by query number: a
+        // fixed order whatever order the list was filled in); wavefront 1 computes that rank while the walk runs.  The last
+        // model workgroup folds the n_listed slots like any other partials (the poll is the read).  The query's owner
+        // contributes a zero row and writes no outputs: one writer per query.
+        const uint32_t e_w = blockIdx.x;
+        const int wave = tid >> 6, lane = tid & 63;
+        if (wave >= 2 || e_w >= n_listed) return;
+        __shared__ uint32_t s_rank;
+        __shared__ double s_lrow[16];
+        __builtin_amdgcn_s_setprio(3);             // the walk is on the critical path of the pass: ahead of the model waves
+        const float4 q = a.tree.ulist[e_w];
+        const uint32_t qi = __float_as_uint(q.w);
+        if (wave == 1) {
+            uint32_t rank = 0;
+#pragma unroll
+            for (uint32_t t = 0; t < (uint32_t)FIX_MAX / 64u; ++t) {
+                const uint32_t j = (uint32_t)lane + 64u * t;
+                const uint32_t kj = j < n_listed ? __float_as_uint(a.tree.ulist[j].w) : 0xffffffffu;
+                rank += (uint32_t)__popcll(__ballot(kj < qi));
+            }
+            if (lane == 0) s_rank = rank;
+            __syncthreads();
+            return;
+        }
+        bool changed = true;
+        int nv = 0;
+        float4 own = tree_search_one(a.tree, qi, q.x, q.y, q.z, lane, ts, &nv, a.tree.useeds ? a.tree.useeds + (size_t)e_w * 8u : nullptr, &changed);
+        if (!changed) {
+            // the walk confirmed knn27_kernel's result and stored nothing: Nearest_Points[q] is that launch's (plain loads)
+            if (lane < K) own = a.nbr[(size_t)lane * a.nq_stride + qi];
+            nv = (int)(a.cnt[qi] & ~CNT_UNPROVEN);
+        }
+        float px[5], py[5], pz[5];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { px[k] = __shfl(own.x, k, 64); py[k] = __shfl(own.y, k, 64); pz[k] = __shfl(own.z, k, 64); }
+        const float d4 = __shfl(own.w, 4, 64);
+        // every lane evaluates the same query (uniform; lane 0 stores)
+        const PoseQ sw = pose_unpack(a.pose);
+        const float4 fb = a.body[qi];
+        bool fsel = false;
+        float fnx = 0.f, fny = 0.f, fnz = 0.f, fpd = 0.f, fpd2 = 0.f;
+        double jrow[12], fh = 0.0;
+#pragma unroll
+        for (int c = 0; c < 12; ++c) jrow[c] = 0.0;
+        if (nv >= K && !(d4 > 5.0f))                                 // :1911
+            fsel = point_residual(px, py, pz, q.x, q.y, q.z, fb.x, fb.y, fb.z, fnx, fny, fnz, fpd2, &fpd);
+        if (fsel) jacobian_row<EXT>(sw, fb.x, fb.y, fb.z, fnx, fny, fnz, fpd2, jrow, fh);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < S::NC; ++c) s_lrow[c] = jrow[c];
+            s_lrow[S::COL_H] = fh;
+            s_lrow[S::COL_RES] = fsel ? (double)__builtin_fabsf(fpd2) : 0.0;
+            s_lrow[S::COL_ONE] = fsel ? 1.0 : 0.0;
+        }
+        __syncthreads();                                            // s_lrow and s_rank (wavefront 1 is long done)
+        {
+            const unsigned long long st_hi = (unsigned long long)(uint32_t)a.seq << 32;
+            unsigned long long* slot = a.lunits + (size_t)s_rank * RED_STRIDE * 2;
+            for (int en = lane; en < S::NE; en += 64) {
+                int ca, cb;
+                entry_columns<EXT>(en, ca, cb);
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(s_lrow[ca] * s_lrow[cb]);
+                __hip_atomic_store(slot + (size_t)en * 2 + 0, (bits & 0xffffffffull) | st_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slot + (size_t)en * 2 + 1, (bits >> 32) | st_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // the query's outputs, behind the hand-off (nobody inside this launch reads them)
+        if (lane == 0) {
+            if (fsel) {
+                a.plane[qi] = make_float4(fnx, fny, fnz, fpd);
+                a.normvec[qi] = make_float4(fnx, fny, fnz, fpd2);
+                if (a.rows != nullptr) {
+                    double* dst = a.rows + (size_t)qi * 13;
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) dst[c] = jrow[c];
+                    dst[12] = fh;
+                }
+            }
+            a.sel[qi] = fsel ? 1 : 0;
         }
         return;
     }
@@ -133,12 +211,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     // after it re-evaluate only the points it accepted (:1916), on the SAME neighbours, so the plane they would re-fit
     // is the one stored here (16 bytes instead of 80, no QR).
     const bool in = i < a.nq;
-    // few listed queries: their walkers also evaluate the model, nobody waits (FIX_MAX, lio_kernels.h)
-    const bool fix_mode = WALK && n_walkers > 0 && (*a.n_unresolved & ~TREE_OVERFLOW) <= (uint32_t)FIX_MAX;
-    bool walked_elsewhere = false;
-    // (the last workgroup orders the listed queries later: their list entries are fetched now, off the critical path)
-    float4 lq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (fix_mode && bid == (int)gridDim.x - n_walkers - 1 && (uint32_t)tid < (*a.n_unresolved & ~TREE_OVERFLOW)) lq = a.tree.ulist[tid];
+    bool walked_elsewhere = false;                 // a listed query in fix mode: its walker evaluates it and writes its outputs
     const PoseQ s = pose_unpack(a.pose);
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     float wx = 0.f, wy = 0.f, wz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, plane_d = 0.f;
@@ -157,9 +230,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         // (bounded; a timeout is reported like a reduction timeout), acquire, and read those neighbours again.  Walkers
         // have the lowest workgroup indices, i.e. they are dispatched first.
         if (WALK && n_walkers > 0 && fix_mode) {
-            // a listed query is evaluated like any other (its 27-cell result is nearly always the exact one), but its
-            // staged row goes to spec_rows instead of this workgroup's sums: the last workgroup adds it once the walk
-            // has confirmed the result, or re-evaluates it
+            // a listed query belongs to its walker (above): no outputs from here, a zero row in this workgroup's sums
             walked_elsewhere = in && (cnt_i & CNT_UNPROVEN) != 0;
         } else if (WALK && n_walkers > 0) {
             const bool owes = __syncthreads_or((in && (cnt_i & CNT_UNPROVEN) != 0) ? 1 : 0) != 0;
@@ -206,7 +277,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             jacobian_row<EXT>(s, b.x, b.y, b.z, nx, ny, nz, pd2, row, h);
         }
         if (!walked_elsewhere) a.sel[i] = sel ? 1 : 0;
-        if (a.rows != nullptr && sel) {
+        if (a.rows != nullptr && sel && !walked_elsewhere) {
             double* dst = a.rows + (size_t)i * 13;
 #pragma unroll
             for (int c = 0; c < 12; ++c) dst[c] = row[c];
@@ -216,23 +287,6 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
 
     // ---- stage the row (zeros when not selected) ---------------------------------------------
     if (WALK && walked_elsewhere) {
-        // a listed query: the staged row is parked (written through, read by the last workgroup after the walk) ...
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.spec_rows + (size_t)i * SPEC_STRIDE);
-#pragma unroll
-        for (int c = 0; c < S::NC; ++c)
-            __hip_atomic_store(dst + c, (unsigned long long)__double_as_longlong(row[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + S::COL_H, (unsigned long long)__double_as_longlong(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + S::COL_RES, (unsigned long long)__double_as_longlong(sel ? (double)__builtin_fabsf(pd2) : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + S::COL_ONE, (unsigned long long)__double_as_longlong(sel ? 1.0 : 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        auto pack2 = [](float lo, float hi) { return ((unsigned long long)__float_as_uint(hi) << 32) | (unsigned long long)__float_as_uint(lo); };
-        __hip_atomic_store(dst + 16, pack2(nx, ny), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 17, pack2(nz, plane_d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 18, pack2(pd2, sel ? 1.0f : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // The last workgroup orders itself against this owner only through the stamped partial sums the OTHER lanes of
-        // this workgroup publish after the barriers below -- and a workgroup barrier does not drain vmcnt: the parked
-        // row has to be in memory before this wavefront reaches the barrier (the walkers drain the same way)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ... the outputs of the query are written by the last workgroup, and this workgroup's sums do not contain it
 #pragma unroll
         for (int c = 0; c < 12; ++c) row[c] = 0.0;
         h = 0.0; sel = false;
@@ -362,130 +416,20 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     }
     __syncthreads();
     if (stamps) t_dbg3 = wall_clock64();
-    // ---- fix mode: the rows of the listed queries.  The walkers have been running since the launch began and only had
-    // to verify; their verdicts are long there when the folds above are done.  One lane per listed query: the row the
-    // owner parked (walk confirmed the 27-cell result) or a re-evaluation on the walked neighbours (it did not), ordered
-    // by query number (the list is in arrival order) and reduced with the code every workgroup uses for its own rows.
-    if (WALK && fix_mode) {
-        const uint32_t n = *a.n_unresolved & ~TREE_OVERFLOW;
-        if (n > 0) {
-            static_assert(FIX_MAX == BS, "one listed query per lane");
-            __shared__ __align__(16) uint32_t s_key[FIX_MAX];
-            __shared__ uint32_t s_any_changed;
-            if (tid == 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(a.walk_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n && ++spins < SPIN_LIMIT)
-                    __builtin_amdgcn_s_sleep(2);
-                if (spins >= SPIN_LIMIT) s_failed = 1u;
-                s_any_changed = __hip_atomic_load(a.walk_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            const bool has = (uint32_t)tid < n;
-            const uint32_t qi = has ? __float_as_uint(lq.w) : 0xffffffffu;   // lq: (world point, query number), fetched at the start
-            s_key[tid] = qi;
-            __syncthreads();                                           // the walk is done (lane 0 saw it), s_rows / s_part are free
-            if (stamps) t_dbg4 = wall_clock64();
-            int rank = tid;                                            // lanes without a query keep their own (zero) row
-            double frow[S::NCOLS];
+    // ---- fix mode: the listed queries' terms, published by their walkers in query order (above), folded like partials
+    if (WALK && fix_mode && n_listed > 0u) {
+        f = fold(a.lunits, (int)n_listed);
+        __syncthreads();
+        s_part[seg][e] = f;
+        __syncthreads();
+        if (stamps) t_dbg4 = wall_clock64();
+        if (tid < S::NE) {
+            double t = 0.0;
 #pragma unroll
-            for (int c = 0; c < S::NCOLS; ++c) frow[c] = 0.0;
-            if (has) {
-                // the verdict and the parked row in ONE round trip (the row is simply not used if the walk changed the result)
-                const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.spec_rows + (size_t)qi * SPEC_STRIDE);
-                // (the per-entry verdict is only fetched when some walk of this pass changed a result at all)
-                const unsigned long long verdict = s_any_changed == 0u ? 0ull :
-                    __hip_atomic_load(a.tree.useeds + (size_t)tid * 8u + 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // the parked row was written THROUGH by its owner (and drained) before that owner's workgroup published the
-                // partial sums folded above; it is read past the caches (agent-scope loads, all in flight together): an
-                // owner on this XCD may have pulled a neighbouring row's line into this L2 earlier in the launch.  Rows
-                // are 256 bytes apart (SPEC_STRIDE), so no two queries share a cache line.
-                unsigned long long raw[SPEC_USED];
-#pragma unroll
-                for (int c = 0; c < SPEC_USED; ++c)
-                    raw[c] = (c < S::NCOLS || c >= 16) ? __hip_atomic_load(src + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-                const unsigned long long p0 = raw[16], p1 = raw[17], p2 = raw[18];
-                // rank among the listed queries = position of the row (while the loads are in flight): 16-byte LDS reads,
-                // eight keys per iteration (lanes beyond n hold 0xffffffff, never smaller than a query number)
-                rank = 0;
-                for (uint32_t j = 0; j < n; j += 8) {
-                    const uint4 k0 = *reinterpret_cast<const uint4*>(&s_key[j]);
-                    const uint4 k1 = *reinterpret_cast<const uint4*>(&s_key[j + 4]);
-                    rank += (k0.x < qi) + (k0.y < qi) + (k0.z < qi) + (k0.w < qi) + (k1.x < qi) + (k1.y < qi) + (k1.z < qi) + (k1.w < qi);
-                }
-                const bool changed = verdict != 0ull;
-                bool final_sel = false;
-                if (!changed) {
-#pragma unroll
-                    for (int c = 0; c < S::NCOLS; ++c) frow[c] = __longlong_as_double((long long)raw[c]);
-                    const float onx = __uint_as_float((uint32_t)p0), ony = __uint_as_float((uint32_t)(p0 >> 32));
-                    const float onz = __uint_as_float((uint32_t)p1), opd = __uint_as_float((uint32_t)(p1 >> 32));
-                    const float opd2 = __uint_as_float((uint32_t)p2);
-                    const bool osel = __uint_as_float((uint32_t)(p2 >> 32)) != 0.0f;
-                    if (osel) {
-                        a.plane[qi] = make_float4(onx, ony, onz, opd);
-                        a.normvec[qi] = make_float4(onx, ony, onz, opd2);
-                    }
-                    a.sel[qi] = osel ? 1 : 0;
-                    final_sel = osel;
-                } else {
-                    // the walk found closer points: the owner's outputs for this query are replaced
-                    float4 nb[K];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) nb[k] = load_walked_neighbor(a.nbr, (size_t)k * a.nq_stride + qi);
-                    const uint8_t cq = __hip_atomic_load(a.cnt + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float4 fb = a.body[qi];
-                    bool fsel = false;
-                    float fnx = 0.f, fny = 0.f, fnz = 0.f, fpd = 0.f, fpd2 = 0.f;
-                    double jrow[12], fh = 0.0;
-#pragma unroll
-                    for (int c = 0; c < 12; ++c) jrow[c] = 0.0;
-                    if (((cq & ~CNT_UNPROVEN) >= K) && !(nb[4].w > 5.0f)) {      // :1911
-                        float px[5], py[5], pz[5];
-#pragma unroll
-                        for (int k = 0; k < K; ++k) { px[k] = nb[k].x; py[k] = nb[k].y; pz[k] = nb[k].z; }
-                        fsel = point_residual(px, py, pz, lq.x, lq.y, lq.z, fb.x, fb.y, fb.z, fnx, fny, fnz, fpd2, &fpd);
-                    }
-                    if (fsel) {
-                        a.plane[qi] = make_float4(fnx, fny, fnz, fpd);
-                        a.normvec[qi] = make_float4(fnx, fny, fnz, fpd2);
-                        jacobian_row<EXT>(s, fb.x, fb.y, fb.z, fnx, fny, fnz, fpd2, jrow, fh);
-                    }
-                    a.sel[qi] = fsel ? 1 : 0;
-#pragma unroll
-                    for (int c = 0; c < S::NC; ++c) frow[c] = jrow[c];
-                    frow[S::COL_H] = fh;
-                    frow[S::COL_RES] = fsel ? (double)__builtin_fabsf(fpd2) : 0.0;
-                    frow[S::COL_ONE] = fsel ? 1.0 : 0.0;
-                    final_sel = fsel;
-                }
-                // (the callback path's staged rows: the final row of a listed query is this one, not its owner's guess)
-                if (a.rows != nullptr && final_sel) {
-                    double* dst = a.rows + (size_t)qi * 13;
-#pragma unroll
-                    for (int c = 0; c < 12; ++c) dst[c] = c < S::NC ? frow[c < S::NC ? c : 0] : 0.0;
-                    dst[12] = frow[S::COL_H];
-                }
-            }
-            if (stamps) t_dbg5 = wall_clock64();
-#pragma unroll
-            for (int c = 0; c < S::NCOLS; ++c) s_rows[rank][c] = frow[c];
-            __syncthreads();
-            double facc = 0.0;
-            if (e < S::NE) {
-                int ca, cb;
-                entry_columns<EXT>(e, ca, cb);
-                const int r0 = seg * S::RS;
-                for (int r = 0; r < S::RS; ++r) facc += s_rows[r0 + r][ca] * s_rows[r0 + r][cb];
-            }
-            s_part[seg][e] = facc;
-            __syncthreads();
-            if (tid < S::NE) {
-                double t = 0.0;
-#pragma unroll
-                for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
-                s_fin[tid] += t;
-            }
-            __syncthreads();
+            for (int sg = 0; sg < S::SEG; ++sg) t += s_part[sg][tid];
+            s_fin[tid] += t;
         }
+        __syncthreads();
     }
     if (stamps) t_dbg6 = wall_clock64();
     const bool failed = s_failed != 0u || (a.debug_fail & 1) != 0 || s_fin[S::NE - 1] < -0.5;

@@ -100,6 +100,52 @@ def test_tree_walk_inside_the_measurement_kernel(gpu_capi, oracle, small_case, e
     assert bits_equal(a[4][tie_free], ox[tie_free])
 
 
+@pytest.mark.parametrize("ext", [False, True])
+def test_walk_changes_a_result_with_few_listed_queries(gpu_capi, oracle, small_case, ext):
+    """Few listed queries (<= FIX_MAX): the walker workgroup of a listed query walks, evaluates the model on the exact
+    neighbours and publishes the query's term of every sum; the last workgroup folds those terms in query order.  Queries
+    0.8 m above the ground are such queries, and their walks DO change the result (the 3x3x3 block sees only the ground
+    points with z >= 0).  Outputs, accept flags, rows and sums must be the oracle's on the exact neighbours
+    (laserMapping.cpp:1909-1938, ikd_Tree.cpp:367-397)."""
+    rng = np.random.default_rng(11)
+    half = small_case["world"].ground_half
+    wq = oracle.body_to_world(small_case["state14"], small_case["scan"].body)[:3000]
+    lifted = (rng.uniform(-0.5 * half, 0.5 * half, (120, 3)) * [1, 1, 0] + [0, 0, 0.8]).astype(np.float32)
+    q = np.ascontiguousarray(np.concatenate([wq[:1500], lifted[:60], wq[1500:], lifted[60:]]))
+    ident = np.array([0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float64)      # world frame == body frame
+    om = oracle.OracleMap(0.2); om.build(small_case["world"].points)
+    arr = oracle.ScanArrays(len(q))
+    valid, hx, h, m, rm = oracle.h_share_model(om, ident, q, arr, True, ext)
+    HTH, HTh = oracle.hth(hx, h)
+    res = {}
+    for separate in (0, 1):
+        ctx = gpu_capi.LioContext(0.2, max_scan_points=len(q), max_map_points=400_000)
+        ctx.map_build(small_case["world"].points)
+        ctx.debug_set("separate_tree_walk", separate)
+        ctx.measure_want_rows(True)                     # the rows of THIS pass, staged by it (the walkers write their queries' rows)
+        ctx.scan_set(q)
+        g = ctx.measure(ident, True, ext)
+        world, sel, nv = ctx.scan_state()
+        nx, nd, nc = ctx.neighbors()
+        ghx, gh = ctx.measure_rows(g["m"])
+        res[separate] = (g, sel, nv, nx, ghx, gh)
+        ctx.close()
+    g, sel, nv, nx, ghx, gh = res[0]
+    lifted_idx = np.r_[1500:1560, 3060:3120]
+    assert 100 <= g["n_unresolved"] <= 256                            # few listed queries: the lifted ones (and a handful of the scan's)
+    assert (nx[lifted_idx, :, 2] < 0).any(axis=1).sum() > 60           # ... whose exact neighbours lie outside the 3x3x3 block (z < 0)
+    assert g["m"] == m and np.array_equal(sel, arr.selected)
+    sb = sel.astype(bool)
+    assert bits_equal(nv[sb], arr.normvec[sb])
+    assert np.abs(g["HTH"] - HTH).max() <= 1e-9 * np.abs(HTH).max() and np.abs(g["HTh"] - HTh).max() <= 1e-9 * np.abs(HTh).max()
+    assert abs(g["res_mean"] - rm) <= 1e-12
+    assert bits_equal(ghx, hx) and bits_equal(gh, h)            # the callback's rows: the walked queries' final rows
+    # the stand-alone walk (every model row on the exact neighbours from the start): same flags, same outputs, sums within rounding
+    g1, sel1, nv1 = res[1][0], res[1][1], res[1][2]
+    assert g1["m"] == g["m"] and np.array_equal(sel1, sel) and bits_equal(nv1, nv)
+    assert np.abs(g1["HTH"] - g["HTH"]).max() <= 1e-12 * np.abs(HTH).max()
+
+
 @pytest.mark.parametrize("case_name,ext", [("small_case", False), ("small_case", True), ("hap_case", True)])
 def test_measurement_pass_parity(gpu_capi, oracle, request, case_name, ext):
     """h_share_model: search pass, then a no-search pass at a moved pose (reuses neighbours and the
