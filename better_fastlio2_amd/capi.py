@@ -66,7 +66,7 @@ EXPORTS = [
     "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_replicate_unique_id", "lio_replicate_init", "lio_replicate_finalize", "lio_replicate_queue_boxes", "lio_replicate_step", "lio_fov_segment", "lio_map_reconstruct",
     "lio_map_set_downsample_param", "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_acquire_removed_points", "lio_map_get_info", "lio_map_nearest_search",
     "lio_scan_set", "lio_scan_set_device", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_measure_want_rows", "lio_eskf_update_iterated_dyn_share_callback", "lio_get_neighbors",
-    "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get", "lio_debug_set", "lio_debug_stamps",
+    "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get", "lio_debug_set", "lio_debug_get", "lio_debug_stamps",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
     "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_eskf_scan_step_device", "lio_eskf_scan_step_pipelined", "lio_state_boxplus",
     "lio_state_boxminus", "lio_eskf_predict", "lio_process_noise_cov",
@@ -164,6 +164,7 @@ def load(build_if_missing: bool = True):
     L.lio_profile_reset.argtypes = [_vp]
     L.lio_census_enable.argtypes = [_vp, C.c_int]
     L.lio_debug_set.argtypes = [_vp, C.c_char_p, C.c_longlong]
+    L.lio_debug_get.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_longlong)]
     L.lio_debug_stamps.argtypes = [_vp, _vp]
     L.lio_profile_get.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.lio_eskf_create.restype = _vp
@@ -515,6 +516,11 @@ class LioContext:
     def debug_set(self, key: str, value: int):
         """Test hooks of the library (lio_debug_set)."""
         self._chk(self.L.lio_debug_set(self.h, key.encode(), int(value)), "lio_debug_set")
+
+    def debug_get(self, key):
+        v = C.c_longlong(0)
+        self._chk(self.L.lio_debug_get(self.h, key.encode(), C.byref(v)), "lio_debug_get")
+        return int(v.value)
 
     def profile_reset(self):
         self.L.lio_profile_reset(self.h)

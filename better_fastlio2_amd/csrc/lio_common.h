@@ -74,6 +74,20 @@ struct TreeLevels {
 // pos3, rot xyzw, offR xyzw, offT3 -- passed to kernels by value (112 bytes of kernarg)
 struct Pose14 { double v[14]; };
 
+// A pass enqueued BEFORE its pose is known (the iterated update, lio_ctx.hip): a one-wavefront gate kernel in front of the pass's
+// kernels waits for the host's word in GateMail (host-mapped, coherent) and leaves the pose -- or the order to skip the pass -- in
+// GateState (device memory), which the kernels behind it read instead of their by-value pose.
+struct GateState { uint32_t skip; uint32_t pad[3]; Pose14 pose; };
+struct GateMail { unsigned long long w[17]; };           // [0] seq, [1] cmd (1 = go, 2 = skip), [2..15] the pose's bits, [16] check word
+constexpr unsigned long long GATE_GO = 1ull, GATE_SKIP = 2ull;
+// the check word: the gate reads all 17 words in ONE round trip over PCIe, in no particular order -- a read that mixes the
+// words of two messages fails the check and is repeated
+LIO_HD unsigned long long gate_check(const unsigned long long w[16]) {
+    unsigned long long c = 0x9e3779b97f4a7c15ull;
+    for (int i = 0; i < 16; ++i) c = (c ^ w[i]) * 0xff51afd7ed558ccdull + (unsigned long long)i;
+    return c ^ (c >> 29);
+}
+
 // per-block partial of the measurement reduction: 78 + 12 unique sums, residual sum, count
 constexpr int RED_NE_EXT = 78 + 12;           // extrinsic_est_en: 12 columns
 constexpr int RED_NE_NOEXT = 21 + 6;          // otherwise columns 6..11 are zero (laserMapping.cpp:1997)

@@ -134,6 +134,19 @@ struct lio_ctx {
     const void* upload_src = nullptr;
     int upload_n = 0;
     bool pass_in_flight = false, pass_empty = false;   // between lio_measure_begin and lio_measure_end
+    unsigned long long pass_seq = 0;           // sequence number of the pass in flight (its record carries it)
+    // ---- passes enqueued ahead of their pose (the iterated update only; lio_common.h GateState) ----------------------
+    GateMail* h_gate_mail = nullptr;           // host-mapped, coherent: the host's word to the pending gate
+    GateMail* d_gate_mail = nullptr;           // its device address
+    GateState* d_gate = nullptr;               // device: what the gate leaves for the kernels behind it
+    bool gate_pending = false;                 // a gate + pass sit on the stream, waiting for the host
+    bool gate_search = false, gate_ext = false;
+    unsigned long long gate_mail_seq = 0;      // sequence number the pending gate waits for
+    unsigned long long gate_pass_seq = 0;      // sequence number of the pass behind it
+    int dbg_pre_enqueue = 1;                   // lio_debug_set("pre_enqueue", 0): never enqueue ahead
+    int dbg_gate_mispredict = 0;               // lio_debug_set("gate_mispredict", 1): predict the WRONG kind every time (tests of the call-off path)
+    long long n_gate_released = 0, n_gate_called_off = 0;
+    std::vector<signed char> pattern_prev, pattern_cur;   // converge flag per call of the previous / the running iterated update
     bool pass_searched = false;                // the pass in flight is a search pass
     int listed_last_search = 0;                // unproven queries of the most recent search pass: predicts the next one's
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
@@ -856,7 +869,7 @@ TreeArgs tree_args(lio_ctx* c, int nq, int stride, float4* nbr, uint8_t* cnt, fl
     return ta;
 }
 int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14& pose, int nq, int stride,
-            float4* nbr, uint8_t* cnt, float4* ulist, unsigned long long* useeds, bool use_hint, bool walk_now) {
+            float4* nbr, uint8_t* cnt, float4* ulist, unsigned long long* useeds, bool use_hint, bool walk_now, const GateState* gate = nullptr) {
     hipStream_t s = c->stream;
     // d_counters[0] / d_cand are zero here: zeroed at creation and re-zeroed by whoever consumes them
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
@@ -872,6 +885,7 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.nbr = nbr; ka.cnt = cnt; ka.ulist = ulist; ka.useeds = useeds; ka.n_unres = c->d_counters; ka.cand_total = c->census ? c->d_cand : nullptr;
     ka.use_hint = use_hint ? 1 : 0;
     ka.tune = c->dbg_knn_tune;
+    ka.gate = gate;
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
     if (walk_now) HIPCHK(c, launch_knn_tree(tree_args(c, nq, stride, nbr, cnt, ulist, useeds), s, prof_timer(c, LIO_PROF_FALLBACK)));
@@ -917,6 +931,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipSetDevice(c->device));
     { const char* e = std::getenv("LIO_TRACE_REBUILDS"); c->trace_rebuilds = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_TRACE_HOST"); c->trace_host = e != nullptr && e[0] == '1'; }
+    { const char* e = std::getenv("LIO_PRE_ENQUEUE"); if (e != nullptr && e[0] == '0') c->dbg_pre_enqueue = 0; }   // (A/B runs of scripts)
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, c->device));
     c->arch = prop.gcnArchName;
@@ -925,6 +940,11 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipHostMalloc(&c->h_small, 256, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->h_small, 0, 256);
     CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_small, c->h_small, 0));
+    CREATE_CHK(hipHostMalloc((void**)&c->h_gate_mail, sizeof(GateMail), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_gate_mail, 0, sizeof(GateMail));
+    CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_gate_mail, c->h_gate_mail, 0));
+    CREATE_CHK(hipMalloc((void**)&c->d_gate, sizeof(GateState)));
+    CREATE_CHK(hipMemset(c->d_gate, 0, sizeof(GateState)));
 
     c->grid.cell = cfg->cell_size != 0.0f ? cfg->cell_size : auto_cell_size(cfg->filter_size_map_min);
     c->grid.inv_cell = 1.0f / c->grid.cell;
@@ -1039,6 +1059,8 @@ void lio_destroy(lio_ctx* c) {
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->h_gate_mail) (void)hipHostFree(c->h_gate_mail);
+    if (c->d_gate) (void)hipFree(c->d_gate);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -2095,37 +2117,20 @@ static bool rows_direct(const lio_ctx* c, int nq) {
 // One pass = lio_measure_begin (enqueue the kernels, return at once) + lio_measure_end (wait for the result record).
 // The host work of the caller that does not depend on the result -- in the iterated update: x [-] x_prop, the
 // Jacobian-corrected P and its first inversion (esekfom.hpp:1655-1703, :1788) -- runs between the two, beside the GPU.
-int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int extrinsic_est_en) {
-    if (!c || !state14) return LIO_ERR_INVALID_ARG;
-    c->stamp(do_search ? 'B' : 'b');
-    if (c->pass_in_flight) return c->fail(LIO_ERR_INVALID_ARG, "lio_measure_begin", "the previous pass has not been collected (lio_measure_end)");
-    if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "no scan set");
-    if (!do_search && !c->have_search) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "first pass of a scan must search");
-    HIPCHK(c, hipSetDevice(c->device));
-    const int nq = c->nq;
-    Pose14 pose;
-    for (int i = 0; i < 14; ++i) pose.v[i] = state14[i];
-    const bool ext = extrinsic_est_en != 0;
-    c->last_pose = pose; c->last_ext = ext;
-    c->pass_in_flight = true; c->pass_empty = nq == 0;
-    if (nq == 0) return LIO_OK;                               // "No Effective Points" laserMapping.cpp:1956
+// The kernels of one pass on the stream: [k-NN (search passes)] [measurement kernel].  gate != nullptr: the pose is not known
+// yet -- the kernels take it from there (and stand down if told to).  Nothing of the context's pass state changes here
+// except the sequence number the pass consumes (*seq_out).
+static int enqueue_pass(lio_ctx* c, const Pose14& pose, bool do_search, bool ext, bool separate_walk, const GateState* gate,
+                        unsigned long long* seq_out) {
     hipStream_t s = c->stream;
-
-    // The exact walk of the unproven queries normally rides inside the measurement kernel (tens of queries: nobody waits
-    // for it).  When the LAST search pass listed many (a scan at the map's edge, C5's 1 M-point scan: thousands), nearly
-    // every model workgroup would sit waiting for 1-wavefront walkers: then the walk gets the whole GPU in a launch of
-    // its own, as in round 1 -- and so it does for scans far beyond the node's 100 k points, where the measurement kernel
-    // is throughput-bound and the lean variant (without the walk's registers) runs at nearly twice the occupancy.
-    const bool separate_walk = c->dbg_separate_walk != 0 || c->listed_last_search > INLINE_WALK_MAX_LISTED || nq > FUSED_TRANSFORM_MAX_QUERIES;
-    c->pass_searched = do_search != 0;
+    const int nq = c->nq;
     if (do_search) {
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
-        int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk);
-        if (rc != LIO_OK) { c->pass_in_flight = false; return rc; }
-        c->have_search = true; c->hint_valid = true;
+        const int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk, gate);
+        if (rc != LIO_OK) return rc;
     }
     ResidualArgs ra{};
-    ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
+    ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.gate = gate; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
     ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.rows = nullptr; ra.units = c->d_units; ra.gunits = c->d_gunits;
     if ((uint32_t)(c->seq + 1ull) == 0u) {
         // The partial sums carry the low 32 bits of the sequence number as their stamp (lio_measure.hip): when those go round, a
@@ -2138,12 +2143,12 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
         ++c->seq;
     }
     const unsigned long long seq = ++c->seq;
+    *seq_out = seq;
     ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = seq;
     ra.debug_fail = (c->dbg_force_timeout ? 1 : 0) | (c->dbg_stamps ? 2 : 0);
-    c->rows_staged = false;
-    if (c->want_rows) {
+    if (c->want_rows && gate == nullptr) {
         const int rc = ensure_rows_buffers(c);
-        if (rc != LIO_OK) { c->pass_in_flight = false; return rc; }
+        if (rc != LIO_OK) return rc;
         ra.rows = c->d_rows; ra.m_dev = reinterpret_cast<int*>(c->d_counters + 18);
     }
     if (do_search && !separate_walk) {
@@ -2151,9 +2156,97 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
         ra.tree = tree_args(c, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds);
         ra.lunits = c->d_lunits;
     }
-    const hipError_t le = launch_residual(ra, do_search != 0, ext, s, prof_timer(c, LIO_PROF_RESIDUAL));
+    const hipError_t le = launch_residual(ra, do_search, ext, s, prof_timer(c, LIO_PROF_RESIDUAL));
+    if (le != hipSuccess) return c->fail(LIO_ERR_HIP, "launch_residual", hipGetErrorString(le));
+    return LIO_OK;
+}
+// The exact walk of the unproven queries normally rides inside the measurement kernel (tens of queries: nobody waits
+// for it).  When the LAST search pass listed many (a scan at the map's edge, C5's 1 M-point scan: thousands), nearly
+// every model workgroup would sit waiting for 1-wavefront walkers: then the walk gets the whole GPU in a launch of
+// its own, as in round 1 -- and so it does for scans far beyond the node's 100 k points, where the measurement kernel
+// is throughput-bound and the lean variant (without the walk's registers) runs at nearly twice the occupancy.
+static bool walk_in_its_own_launch(const lio_ctx* c) {
+    return c->dbg_separate_walk != 0 || c->listed_last_search > INLINE_WALK_MAX_LISTED || c->nq > FUSED_TRANSFORM_MAX_QUERIES;
+}
+
+// ---- passes enqueued ahead of their pose -----------------------------------------------------------------------------------
+// Between "the host has the new pose" and "the first wavefront of the next pass runs" lie the launch calls of the pass and
+// the dispatch of its first kernel (~6 us, scripts/micro/gate_latency.hip).  Inside the iterated update the next pass is
+// predictable (the converge pattern of the previous scan's update), so it is put on the stream while the GPU still works on
+// the current one, behind a gate kernel; when the pose is known the host only writes it, with a sequence number, into the
+// gate's mail.  A wrong prediction (or the end of the update) calls the pass off: its kernels see GateState.skip and return.
+// Only lio_eskf_update_iterated_dyn_share_modified arms a gate and it never returns with one pending, so no other entry point
+// ever finds the stream blocked.
+static void gate_write(lio_ctx* c, unsigned long long cmd, const Pose14* pose) {
+    unsigned long long w[16];
+    w[0] = c->gate_mail_seq; w[1] = cmd;
+    for (int i = 0; i < 14; ++i) { double v = pose ? pose->v[i] : 0.0; std::memcpy(&w[2 + i], &v, 8); }
+    volatile unsigned long long* m = c->h_gate_mail->w;
+    for (int i = 1; i < 16; ++i) m[i] = w[i];
+    m[16] = gate_check(w);
+    __atomic_store_n(&c->h_gate_mail->w[0], w[0], __ATOMIC_RELEASE);
+}
+static void gate_call_off(lio_ctx* c) {
+    if (!c->gate_pending) return;
+    gate_write(c, GATE_SKIP, nullptr);
+    c->gate_pending = false;
+    ++c->n_gate_called_off;
+}
+// enqueue [gate][pass of the given kind] behind whatever is on the stream; LIO_OK also when the context declines (nothing armed)
+static int gate_arm(lio_ctx* c, bool do_search, bool ext) {
+    if (c->gate_pending || !c->dbg_pre_enqueue || c->prof != 0u || c->want_rows || c->nq == 0 || !c->have_search) return LIO_OK;
+    if (walk_in_its_own_launch(c)) return LIO_OK;               // (the stand-alone walk and the transform launch read no gate)
+    ++c->gate_mail_seq;
+    const hipError_t ge = launch_gate(c->d_gate_mail, c->gate_mail_seq, c->d_gate, c->stream);
+    if (ge != hipSuccess) return c->fail(LIO_ERR_HIP, "launch_gate", hipGetErrorString(ge));
+    c->gate_pending = true; c->gate_search = do_search; c->gate_ext = ext;
+    Pose14 none{};
+    const int rc = enqueue_pass(c, none, do_search, ext, false, c->d_gate, &c->gate_pass_seq);
+    if (rc != LIO_OK) { gate_call_off(c); return rc; }
+    c->stamp('G');
+    return LIO_OK;
+}
+
+int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int extrinsic_est_en) {
+    if (!c || !state14) return LIO_ERR_INVALID_ARG;
+    c->stamp(do_search ? 'B' : 'b');
+    if (c->pass_in_flight) return c->fail(LIO_ERR_INVALID_ARG, "lio_measure_begin", "the previous pass has not been collected (lio_measure_end)");
+    if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "no scan set");
+    if (!do_search && !c->have_search) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "first pass of a scan must search");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int nq = c->nq;
+    Pose14 pose;
+    for (int i = 0; i < 14; ++i) pose.v[i] = state14[i];
+    const bool ext = extrinsic_est_en != 0;
+    if (c->gate_pending) {
+        if (c->gate_search == (do_search != 0) && c->gate_ext == ext && !c->want_rows && nq != 0) {
+            // the pass is already on the stream: hand it its pose
+            gate_write(c, GATE_GO, &pose);
+            c->gate_pending = false;
+            ++c->n_gate_released;
+            c->last_pose = pose; c->last_ext = ext;
+            c->pass_in_flight = true; c->pass_empty = false;
+            c->pass_searched = do_search != 0;
+            if (do_search) { c->have_search = true; c->hint_valid = true; }
+            c->rows_staged = false;
+            c->pass_seq = c->gate_pass_seq;
+            c->stamp('L');
+            return LIO_OK;
+        }
+        gate_call_off(c);
+    }
+    c->last_pose = pose; c->last_ext = ext;
+    c->pass_in_flight = true; c->pass_empty = nq == 0;
+    if (nq == 0) return LIO_OK;                               // "No Effective Points" laserMapping.cpp:1956
+    hipStream_t s = c->stream;
+    c->pass_searched = do_search != 0;
+    c->rows_staged = false;
+    {
+        const int rc = enqueue_pass(c, pose, do_search != 0, ext, walk_in_its_own_launch(c), nullptr, &c->pass_seq);
+        if (rc != LIO_OK) { c->pass_in_flight = false; return rc; }
+        if (do_search) { c->have_search = true; c->hint_valid = true; }
+    }
     c->stamp('L');
-    if (le != hipSuccess) { c->pass_in_flight = false; return c->fail(LIO_ERR_HIP, "launch_residual", hipGetErrorString(le)); }
     if (c->want_rows) {
         // right behind the pass: the rows of the selected points, compacted in scan order, column-major (m read on the device)
         RowsCompactArgs rc{};
@@ -2185,7 +2278,7 @@ int lio_measure_end(lio_ctx* c, lio_out* out) {
     std::memset(out, 0, sizeof(*out));
     if (c->pass_empty) { out->valid = 0; return LIO_OK; }
     hipStream_t s = c->stream;
-    const unsigned long long seq = c->seq;
+    const unsigned long long seq = c->pass_seq;
     c->stamp('E');
     // The record lands in host-mapped memory; poll its sequence number instead of paying for a
     // device-to-host copy plus a stream synchronisation.  hipStreamQuery guards against a fault.
@@ -2239,6 +2332,7 @@ int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_m
     if (!c || !h_x || !h) return LIO_ERR_INVALID_ARG;
     if (!c->have_pass) return c->fail(LIO_ERR_NO_SCAN, "lio_measure_rows", "no measurement pass yet");
     HIPCHK(c, hipSetDevice(c->device));
+    gate_call_off(c);                           // (inside the iterated update: nothing may queue behind a waiting gate)
     const int nq = c->nq, m = c->last_m;
     if (cap_rows < m) return c->fail(LIO_ERR_CAPACITY, "lio_measure_rows", "cap_rows < m");
     if (m == 0) return LIO_OK;
@@ -2359,6 +2453,8 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "knn_tune") == 0) { c->dbg_knn_tune = (int)value; return LIO_OK; }
     if (std::strcmp(key, "rows_direct") == 0) { c->dbg_rows_direct = (int)value; return LIO_OK; }
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
+    if (std::strcmp(key, "pre_enqueue") == 0) { c->dbg_pre_enqueue = value != 0; return LIO_OK; }
+    if (std::strcmp(key, "gate_mispredict") == 0) { c->dbg_gate_mispredict = value != 0; return LIO_OK; }
     if (std::strcmp(key, "sequence_numbers") == 0) {           // test hook: the next pass / compaction launch take these numbers + 1 (stamp wrap-around)
         c->seq = (unsigned long long)value; c->compact_seq = (uint32_t)value; c->gsort_seq = (uint32_t)value;
         return LIO_OK;
@@ -2370,6 +2466,12 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
         return LIO_OK;
     }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "unknown key");
+}
+int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
+    if (!c || !key || !value) return LIO_ERR_INVALID_ARG;
+    if (std::strcmp(key, "gate_released") == 0) { *value = c->n_gate_released; return LIO_OK; }
+    if (std::strcmp(key, "gate_called_off") == 0) { *value = c->n_gate_called_off; return LIO_OK; }
+    return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_get", "unknown key");
 }
 int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {
     if (!c || !out8) return LIO_ERR_INVALID_ARG;
@@ -2428,6 +2530,8 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
                                                 lio_update_log* log) {
     if (!kf || !ctx || !(R > 0.0)) return LIO_ERR_INVALID_ARG;
     int status = LIO_OK;
+    // (the converge flag of every call: the prediction of the NEXT update's passes, which are enqueued ahead of their pose)
+    ctx->pattern_cur.clear();
     // the reference's h_share_model, bound to the GPU path (laserMapping.cpp:1876 <-> lio_measure), in two halves so
     // that the filter's result-independent algebra runs while the GPU works on the pass
     kf->kf.set_measurement_model_async(
@@ -2435,8 +2539,17 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
             if (status != LIO_OK) return;
             double pose[14];
             s.pose14(pose);
+            ctx->pattern_cur.push_back(d.converge ? 1 : 0);
             const int rc = lio_measure_begin(ctx, pose, d.converge ? 1 : 0, extrinsic_est_en);
-            if (rc != LIO_OK) status = rc;
+            if (rc != LIO_OK) { status = rc; return; }
+            // the pass after this one, as the previous update ran it: onto the stream now, behind a gate (lio_measure_begin)
+            const size_t next = ctx->pattern_cur.size();
+            if (next < ctx->pattern_prev.size()) {
+                bool kind = ctx->pattern_prev[next] != 0;
+                if (ctx->dbg_gate_mispredict) kind = !kind;
+                const int rc2 = gate_arm(ctx, kind, extrinsic_est_en != 0);
+                if (rc2 != LIO_OK) status = rc2;
+            }
         },
         [&](lio::dyn_share_datastruct& d) {
             if (status != LIO_OK) { d.valid = false; d.m = 0; return; }
@@ -2457,6 +2570,8 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
         });
     double solve_time = 0.0;
     kf->kf.update_iterated_dyn_share_modified(R, solve_time);
+    gate_call_off(ctx);                          // the update ended earlier than the previous one: nothing stays armed
+    ctx->pattern_prev.swap(ctx->pattern_cur);
     if (log) {
         const lio::update_stats& st = kf->kf.stats();
         log->n_calls = st.n_calls; log->n_search = st.n_search; log->converged = st.converged ? 1 : 0;

@@ -19,6 +19,7 @@ struct KnnArgs {
     const float4*    body;          // or: feats_down_body -- the kernel transforms with `pose` itself (one wavefront per
     float4*          world_out;     //     workgroup, fp64 -> fp32, laserMapping.cpp:1894-1899) and writes feats_down_world
     Pose14           pose;
+    const GateState* gate;          // non-null: the pose (and the order to skip the launch) come from there (lio_common.h)
     int              nq;
     int              nq_stride;     // leading dimension of nbr
     float4*          nbr;           // [5][nq_stride]: x, y, z, sqdist of the k-th neighbour
@@ -37,6 +38,8 @@ hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float
 // which stamps the two events with the dispatch's own begin/end (no marker packets around the kernel)
 struct KernelTimer { hipEvent_t start = nullptr, stop = nullptr; };
 hipError_t launch_knn27(const KnnArgs& a, int lanes_per_query, hipStream_t s, KernelTimer t = KernelTimer());
+// the gate in front of a pre-enqueued pass: waits (bounded) until mail->seq == expect, then st = {skip, pose}
+hipError_t launch_gate(const GateMail* mail, unsigned long long expect, GateState* st, hipStream_t s);
 
 // hashed 64-ary tree: level L = grid coarsened by 4^L, tables of levels 1.. live in one buffer
 // or-ed into cnt[q] by knn27_kernel: the exact tree walk owes / has answered this query (the walk keeps the mark, every
@@ -65,6 +68,7 @@ struct ResidualArgs {
     int            nq;
     int            nq_stride;
     Pose14         pose;
+    const GateState* gate;          // non-null: the pose (and the order to skip the launch) come from there (lio_common.h)
     const float4*  nbr;             // Nearest_Points
     const uint8_t* cnt;
     uint8_t*       sel;             // point_selected_surf (in: previous pass, out: this pass)

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     constexpr int GPW = 64 / G;                    // queries per wavefront
     __shared__ uint2 s_bucket[WPB][GPW][28];       // LDS-staged non-empty buckets {start, count}
 
+    if (a.gate != nullptr && a.gate->skip != 0u) return;      // a pre-enqueued pass the host called off
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / G, r = lane % G;
     const int q = (blockIdx.x * WPB + wave) * GPW + g;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             const int qi = blockIdx.x * (WPB * GPW) + lane;
             if (qi < a.nq) {
                 const float4 b = a.body[qi];
-                const PoseQ s = pose_unpack(a.pose);
+                const PoseQ s = pose_unpack(a.gate != nullptr ? a.gate->pose : a.pose);
                 float wx, wy, wz;
                 body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
                 a.world_out[qi] = make_float4(wx, wy, wz, b.w);
@@ -455,6 +456,38 @@ __global__ __launch_bounds__(256) void transform_kernel(const float4* body, int 
 hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float4* world, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(transform_kernel, dim3((n + 255) / 256), dim3(256), 0, s, body, n, pose, world);
+    return hipGetLastError();
+}
+
+// ---- the gate of a pre-enqueued pass --------------------------------------------------------------------------------
+// One wavefront polls the host's mail (system-scope loads of host-mapped memory: one PCIe read per poll) until the sequence
+// number it was launched for appears, then copies the pose / the order into device memory; the kernels behind it on the
+// stream start when it ends.  Bounded (~2 s of wall clock): a host that never answers turns into a skipped pass, which the
+// host then reports (the record of that pass never appears), not into a hung queue.
+__global__ __launch_bounds__(64) void gate_kernel(const GateMail* mail, unsigned long long expect, GateState* st) {
+    const int lane = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long w = 0ull;
+    bool ok = false;
+    for (;;) {
+        // lanes 0..16 fetch one word each: one round trip
+        if (lane < 17) w = __hip_atomic_load(&mail->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long seq = __shfl(w, 0, 64);
+        if (seq == expect) {
+            unsigned long long all[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) all[i] = __shfl(w, i, 64);
+            if (gate_check(all) == __shfl(w, 16, 64)) { ok = true; break; }
+        }
+        if (wall_clock64() - t0 > 200000000ull) break;             // 100 MHz: 2 s
+        __builtin_amdgcn_s_sleep(1);
+    }
+    const bool go = ok && __shfl(w, 1, 64) == GATE_GO;
+    if (lane >= 2 && lane < 16) st->pose.v[lane - 2] = go ? __longlong_as_double((long long)w) : 0.0;
+    if (lane == 0) st->skip = go ? 0u : 1u;
+}
+hipError_t launch_gate(const GateMail* mail, unsigned long long expect, GateState* st, hipStream_t s) {
+    hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, s, mail, expect, st);
     return hipGetLastError();
 }
 

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     constexpr size_t SMEM = WALK && sizeof(TreeScratch) > sizeof(ModelSmem<EXT, BS>) ? sizeof(TreeScratch) : sizeof(ModelSmem<EXT, BS>);
     __shared__ __align__(16) unsigned char s_raw[SMEM];
     __shared__ uint32_t s_failed;                  // a bounded wait ran out (reported, never silent)
+    if (a.gate != nullptr && a.gate->skip != 0u) return;      // a pre-enqueued pass the host called off (nothing is published)
     const int tid = threadIdx.x;
     // bounded waits: seconds, not microseconds -- a pathological search (every query inside a slab of deleted points:
     // ~1 ms per walk) must still finish; the bound only turns a hang into a reported error
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         for (int k = 0; k < K; ++k) { px[k] = __shfl(own.x, k, 64); py[k] = __shfl(own.y, k, 64); pz[k] = __shfl(own.z, k, 64); }
         const float d4 = __shfl(own.w, 4, 64);
         // every lane evaluates the same query (uniform; lane 0 stores)
-        const PoseQ sw = pose_unpack(a.pose);
+        const PoseQ sw = pose_unpack(a.gate != nullptr ? a.gate->pose : a.pose);
         const float4 fb = a.body[qi];
         bool fsel = false;
         float fnx = 0.f, fny = 0.f, fnz = 0.f, fpd = 0.f, fpd2 = 0.f;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     // is the one stored here (16 bytes instead of 80, no QR).
     const bool in = i < a.nq;
     bool walked_elsewhere = false;                 // a listed query in fix mode: its walker evaluates it and writes its outputs
-    const PoseQ s = pose_unpack(a.pose);
+    const PoseQ s = pose_unpack(a.gate != nullptr ? a.gate->pose : a.pose);
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     float wx = 0.f, wy = 0.f, wz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, plane_d = 0.f;
     if (SEARCH) {

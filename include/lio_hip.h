@@ -287,8 +287,13 @@ results); "library_sort" sends every sort / compaction of map maintenance and sc
  * world > 1) runs the replica exchange with `world` VIRTUAL ranks on this one GPU: lio_replicate_step as virtual rank
  * r < world - 1 ("replicate_loopback_rank" = r) parks that rank's lists and boxes, as rank world - 1 it packs every rank's
  * message into its slot of the gathered buffer -- the place of ncclAllGather -- and goes on like a real rank (compaction
- * in rank order, overflow repeat, Delete_Point_Boxes + the Add_Points pair).  Unknown key: LIO_ERR_INVALID_ARG.       */
+ * in rank order, overflow repeat, Delete_Point_Boxes + the Add_Points pair); "pre_enqueue" = 0 stops
+ * lio_eskf_update_iterated_dyn_share_modified from putting the next pass on the stream ahead of its pose (identical results),
+ * "gate_mispredict" = 1 makes it predict the wrong kind of pass every time (every pre-enqueued pass is called off; identical
+ * results).  Unknown key: LIO_ERR_INVALID_ARG.       */
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
+/* counters for tests: "gate_released" / "gate_called_off" = pre-enqueued passes that ran / were called off            */
+int  lio_debug_get(lio_ctx* ctx, const char* key, long long* value);
 /* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: its start, own partial
  * published, group folded, grid folded, walk awaited, rows ordered, rows added, record written (diagnostics)  */
 int  lio_debug_stamps(lio_ctx* ctx, unsigned long long out8[8]);

@@ -197,6 +197,45 @@ def test_scan_step_call_equals_the_four_calls(gpu_capi, synth, small_case):
     ctx.close()
 
 
+def test_passes_enqueued_ahead_of_their_pose(gpu_capi, synth, small_case):
+    """Inside the iterated update the next pass goes onto the stream while the GPU works on the current one, behind a gate
+    kernel that waits for the pose (lio_ctx.hip, gate_arm): the posterior, the covariance and the call log must be what the
+    plain sequence gives, bit for bit -- when every prediction holds, when every prediction is wrong (each armed pass is called
+    off, its kernels stand down), when the update runs fewer passes than the previous one (a pass stays armed at the end and is
+    called off), and the stream must be free for map maintenance right after (esekfom.hpp:1636-1938, laserMapping.cpp:2380)."""
+    w, sc = small_case["world"], small_case["scan"]
+    P0 = synth.init_cov()
+    scans, priors = [], []
+    for k in range(4):
+        s2 = synth.make_scan(w, len(sc.body), seed=synth.SEED + 300 + k, pos=(0.6 * k, -0.3 * k, 0.0), rpy=(0.002, -0.003, 0.04 * k))
+        ps, rt = synth.perturb_state(s2, seed=synth.SEED + 400 + k)
+        scans.append(s2); priors.append(gpu_capi.make_state26(ps, rt, s2.off_R, s2.off_T))
+    out = {}
+    for mode in ("plain", "ahead", "wrong"):
+        ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+        ctx.map_build(w.points)
+        if mode == "plain":
+            ctx.debug_set("pre_enqueue", 0)
+        if mode == "wrong":
+            ctx.debug_set("gate_mispredict", 1)
+        res = []
+        for k, iters in enumerate((3, 3, 1, 3)):               # the third update is shorter than the one before it
+            kf = gpu_capi.Esekf(iters)
+            buf = gpu_capi.scan_to_device(scans[k].body)
+            log = gpu_capi.scan_step_device(kf, ctx, priors[k], P0, buf.ptr, len(scans[k].body), 0.001, False)
+            res.append((kf.get_x(), kf.get_P(), (log["n_calls"], log["n_search"], log["last_m"], log["converged"])))
+            mi = ctx.map_incremental(kf.get_x()[:14], 0.2, True)          # the stream is free: nothing waits behind a gate
+            res.append((np.array([mi["n_add"], mi["n_nodown"]]), np.array([ctx.map_validnum()]), ()))
+        out[mode] = (res, ctx.debug_get("gate_released"), ctx.debug_get("gate_called_off"))
+        ctx.close()
+    for mode in ("ahead", "wrong"):
+        for a, b in zip(out["plain"][0], out[mode][0]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], mode
+    assert out["plain"][1] == 0 and out["plain"][2] == 0
+    assert out["ahead"][1] >= 3 and out["ahead"][2] >= 1          # passes that ran on a pre-enqueued launch; the one left armed by the short update
+    assert out["wrong"][2] >= 3                                       # (a flipped prediction is right where this update differs from the last)
+
+
 @pytest.mark.parametrize("ext", [False, True])
 def test_reduction_across_workgroup_counts(gpu_capi, oracle, small_case, ext):
     """The cross-workgroup reduction (groups of 16 workgroups folded by designated reducers, then the group sums)
