@@ -136,13 +136,15 @@ struct lio_ctx {
     bool pass_in_flight = false, pass_empty = false;   // between lio_measure_begin and lio_measure_end
     unsigned long long pass_seq = 0;           // sequence number of the pass in flight (its record carries it)
     // ---- passes enqueued ahead of their pose (the iterated update only; lio_common.h GateState) ----------------------
-    GateMail* h_gate_mail = nullptr;           // host-mapped, coherent: the host's word to the pending gate
-    GateMail* d_gate_mail = nullptr;           // its device address
-    GateState* d_gate = nullptr;               // device: what the gate leaves for the kernels behind it
-    bool gate_pending = false;                 // a gate + pass sit on the stream, waiting for the host
-    bool gate_search = false, gate_ext = false;
-    unsigned long long gate_mail_seq = 0;      // sequence number the pending gate waits for
-    unsigned long long gate_pass_seq = 0;      // sequence number of the pass behind it
+    static constexpr int GATE_SLOTS = 4;       // (a power of two > GATE_AHEAD)
+    static constexpr int GATE_AHEAD = 2;       // passes armed at most: a short pass is too short to arm the one behind it
+    GateMail* h_gate_mail = nullptr;           // [GATE_SLOTS] host-mapped, coherent: the host's word to an armed gate
+    GateMail* d_gate_mail = nullptr;           // their device address
+    GateState* d_gate = nullptr;               // [GATE_SLOTS] device: what a gate leaves for the kernels behind it
+    struct ArmedPass { bool search, ext; unsigned long long mail_seq, pass_seq; };
+    ArmedPass gate_q[GATE_AHEAD];              // gates + passes that sit on the stream waiting for the host, in stream order
+    int gate_n = 0;
+    unsigned long long gate_mail_seq = 0;      // sequence number of the gate armed last (its slot: seq % GATE_SLOTS)
     int dbg_pre_enqueue = 1;                   // lio_debug_set("pre_enqueue", 0): never enqueue ahead
     int dbg_gate_mispredict = 0;               // lio_debug_set("gate_mispredict", 1): predict the WRONG kind every time (tests of the call-off path)
     long long n_gate_released = 0, n_gate_called_off = 0;
@@ -940,11 +942,11 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipHostMalloc(&c->h_small, 256, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->h_small, 0, 256);
     CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_small, c->h_small, 0));
-    CREATE_CHK(hipHostMalloc((void**)&c->h_gate_mail, sizeof(GateMail), hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(c->h_gate_mail, 0, sizeof(GateMail));
+    CREATE_CHK(hipHostMalloc((void**)&c->h_gate_mail, lio_ctx::GATE_SLOTS * sizeof(GateMail), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_gate_mail, 0, lio_ctx::GATE_SLOTS * sizeof(GateMail));
     CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_gate_mail, c->h_gate_mail, 0));
-    CREATE_CHK(hipMalloc((void**)&c->d_gate, sizeof(GateState)));
-    CREATE_CHK(hipMemset(c->d_gate, 0, sizeof(GateState)));
+    CREATE_CHK(hipMalloc((void**)&c->d_gate, lio_ctx::GATE_SLOTS * sizeof(GateState)));
+    CREATE_CHK(hipMemset(c->d_gate, 0, lio_ctx::GATE_SLOTS * sizeof(GateState)));
 
     c->grid.cell = cfg->cell_size != 0.0f ? cfg->cell_size : auto_cell_size(cfg->filter_size_map_min);
     c->grid.inv_cell = 1.0f / c->grid.cell;
@@ -2177,31 +2179,38 @@ static bool walk_in_its_own_launch(const lio_ctx* c) {
 // gate's mail.  A wrong prediction (or the end of the update) calls the pass off: its kernels see GateState.skip and return.
 // Only lio_eskf_update_iterated_dyn_share_modified arms a gate and it never returns with one pending, so no other entry point
 // ever finds the stream blocked.
-static void gate_write(lio_ctx* c, unsigned long long cmd, const Pose14* pose) {
+static void gate_write(lio_ctx* c, unsigned long long mail_seq, unsigned long long cmd, const Pose14* pose) {
     unsigned long long w[16];
-    w[0] = c->gate_mail_seq; w[1] = cmd;
+    w[0] = mail_seq; w[1] = cmd;
     for (int i = 0; i < 14; ++i) { double v = pose ? pose->v[i] : 0.0; std::memcpy(&w[2 + i], &v, 8); }
-    volatile unsigned long long* m = c->h_gate_mail->w;
+    GateMail* mail = c->h_gate_mail + (mail_seq % lio_ctx::GATE_SLOTS);
+    volatile unsigned long long* m = mail->w;
     for (int i = 1; i < 16; ++i) m[i] = w[i];
     m[16] = gate_check(w);
-    __atomic_store_n(&c->h_gate_mail->w[0], w[0], __ATOMIC_RELEASE);
+    __atomic_store_n(&mail->w[0], w[0], __ATOMIC_RELEASE);
 }
+// every armed pass stands down (a prediction failed, the update ended, or something else needs the stream)
 static void gate_call_off(lio_ctx* c) {
-    if (!c->gate_pending) return;
-    gate_write(c, GATE_SKIP, nullptr);
-    c->gate_pending = false;
-    ++c->n_gate_called_off;
+    for (int i = 0; i < c->gate_n; ++i) {
+        gate_write(c, c->gate_q[i].mail_seq, GATE_SKIP, nullptr);
+        ++c->n_gate_called_off;
+    }
+    c->gate_n = 0;
 }
 // enqueue [gate][pass of the given kind] behind whatever is on the stream; LIO_OK also when the context declines (nothing armed)
 static int gate_arm(lio_ctx* c, bool do_search, bool ext) {
-    if (c->gate_pending || !c->dbg_pre_enqueue || c->prof != 0u || c->want_rows || c->nq == 0 || !c->have_search) return LIO_OK;
+    if (c->gate_n >= lio_ctx::GATE_AHEAD || !c->dbg_pre_enqueue || c->want_rows || c->nq == 0 || !c->have_search) return LIO_OK;
     if (walk_in_its_own_launch(c)) return LIO_OK;               // (the stand-alone walk and the transform launch read no gate)
-    ++c->gate_mail_seq;
-    const hipError_t ge = launch_gate(c->d_gate_mail, c->gate_mail_seq, c->d_gate, c->stream);
+    // (kernel timing on: a full event pool is drained with a stream synchronisation -- never behind an armed gate)
+    for (int w = 0; c->prof != 0u && w < LIO_PROF_COUNT; ++w) if (c->ev_next[w] + 16 > 8192) return LIO_OK;
+    const unsigned long long mail_seq = ++c->gate_mail_seq;
+    GateState* st = c->d_gate + (mail_seq % lio_ctx::GATE_SLOTS);
+    const hipError_t ge = launch_gate(c->d_gate_mail + (mail_seq % lio_ctx::GATE_SLOTS), mail_seq, st, c->stream);
     if (ge != hipSuccess) return c->fail(LIO_ERR_HIP, "launch_gate", hipGetErrorString(ge));
-    c->gate_pending = true; c->gate_search = do_search; c->gate_ext = ext;
+    lio_ctx::ArmedPass& ap = c->gate_q[c->gate_n++];
+    ap.search = do_search; ap.ext = ext; ap.mail_seq = mail_seq; ap.pass_seq = 0;
     Pose14 none{};
-    const int rc = enqueue_pass(c, none, do_search, ext, false, c->d_gate, &c->gate_pass_seq);
+    const int rc = enqueue_pass(c, none, do_search, ext, false, st, &ap.pass_seq);
     if (rc != LIO_OK) { gate_call_off(c); return rc; }
     c->stamp('G');
     return LIO_OK;
@@ -2218,18 +2227,20 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     Pose14 pose;
     for (int i = 0; i < 14; ++i) pose.v[i] = state14[i];
     const bool ext = extrinsic_est_en != 0;
-    if (c->gate_pending) {
-        if (c->gate_search == (do_search != 0) && c->gate_ext == ext && !c->want_rows && nq != 0) {
+    if (c->gate_n > 0) {
+        const lio_ctx::ArmedPass ap = c->gate_q[0];
+        if (ap.search == (do_search != 0) && ap.ext == ext && !c->want_rows && nq != 0) {
             // the pass is already on the stream: hand it its pose
-            gate_write(c, GATE_GO, &pose);
-            c->gate_pending = false;
+            gate_write(c, ap.mail_seq, GATE_GO, &pose);
+            for (int i = 1; i < c->gate_n; ++i) c->gate_q[i - 1] = c->gate_q[i];
+            --c->gate_n;
             ++c->n_gate_released;
             c->last_pose = pose; c->last_ext = ext;
             c->pass_in_flight = true; c->pass_empty = false;
             c->pass_searched = do_search != 0;
             if (do_search) { c->have_search = true; c->hint_valid = true; }
             c->rows_staged = false;
-            c->pass_seq = c->gate_pass_seq;
+            c->pass_seq = ap.pass_seq;
             c->stamp('L');
             return LIO_OK;
         }
@@ -2542,13 +2553,16 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
             ctx->pattern_cur.push_back(d.converge ? 1 : 0);
             const int rc = lio_measure_begin(ctx, pose, d.converge ? 1 : 0, extrinsic_est_en);
             if (rc != LIO_OK) { status = rc; return; }
-            // the pass after this one, as the previous update ran it: onto the stream now, behind a gate (lio_measure_begin)
-            const size_t next = ctx->pattern_cur.size();
-            if (next < ctx->pattern_prev.size()) {
+            // the passes after this one, as the previous update ran them: onto the stream now, each behind a gate
+            // (lio_measure_begin) -- during a search pass there is time to arm two, during a short one there is not
+            const int arm_up_to = d.converge ? lio_ctx::GATE_AHEAD : 1;
+            for (size_t next = ctx->pattern_cur.size() + (size_t)ctx->gate_n; ctx->gate_n < arm_up_to && next < ctx->pattern_prev.size(); ++next) {
                 bool kind = ctx->pattern_prev[next] != 0;
                 if (ctx->dbg_gate_mispredict) kind = !kind;
+                const int before = ctx->gate_n;
                 const int rc2 = gate_arm(ctx, kind, extrinsic_est_en != 0);
-                if (rc2 != LIO_OK) status = rc2;
+                if (rc2 != LIO_OK) { status = rc2; break; }
+                if (ctx->gate_n == before) break;              // the context declined
             }
         },
         [&](lio::dyn_share_datastruct& d) {
