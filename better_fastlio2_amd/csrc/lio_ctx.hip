@@ -2450,7 +2450,8 @@ int lio_get_scan_state(lio_ctx* c, float* world_xyz, uint8_t* selected, float* n
 int lio_profile_enable(lio_ctx* c, int on) {
     if (!c) return LIO_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    prof_collect(c);
+    // (the recorded pairs are resolved by lio_profile_get / lio_profile_reset -- that takes a drained stream -- or when a pool
+    // runs full; switching the timers on and off costs nothing, so a caller can time every n-th step of a loop)
     // on == 1: every family; otherwise a bit mask (1 << LIO_PROF_x) | ... ; 0 = off
     c->prof = on == 1 ? 0xffu : ((unsigned)on & 0xffu);
     return LIO_OK;

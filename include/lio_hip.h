@@ -294,8 +294,9 @@ results); "library_sort" sends every sort / compaction of map maintenance and sc
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
 /* counters for tests: "gate_released" / "gate_called_off" = pre-enqueued passes that ran / were called off            */
 int  lio_debug_get(lio_ctx* ctx, const char* key, long long* value);
-/* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: its start, own partial
- * published, group folded, grid folded, walk awaited, rows ordered, rows added, record written (diagnostics)  */
+/* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: [0] its start, [1] own partial
+ * published, [2] group folded, [3] grid folded, [4] the listed queries' terms folded (search passes that list any),
+ * [5] unused, [6] sums final, [7] record written (diagnostics)                                                          */
 int  lio_debug_stamps(lio_ctx* ctx, unsigned long long out8[8]);
 /* accumulated milliseconds and launch count of one kernel family since the last reset             */
 int  lio_profile_get(lio_ctx* ctx, int which, double* total_ms, long long* launches);

@@ -13,8 +13,6 @@ buf = np.zeros(8, np.uint64)
 for search, pose in [(True, st), (False, st2), (True, st2), (False, st), (True, st), (True, st2), (False, st)] * 2:
     g = ctx.measure(pose, search, False)
     ctx.L.lio_debug_stamps(ctx.h, buf.ctypes.data)
-    n_changed = int(buf[5]) if search else 0              # dbg[5] of a search pass: walks that changed a result (a count, not a time)
-    buf[5] = 0
     d = (buf[1:].astype(np.int64) - np.int64(buf[0])) / 100.0
     d = np.where(buf[1:] == 0, np.nan, d)
-    print("search" if search else "reuse ", "unres", g["n_unresolved"], "changed", n_changed, "us since last WG start: partial %.2f grp %.2f grid %.2f | walk %.2f sort %.2f fix %.2f | written %.2f" % tuple(d))
+    print("search" if search else "reuse ", "unres", g["n_unresolved"], "us since last WG start: partial %.2f grp %.2f grid %.2f | listed terms folded %.2f (-) %.2f sums final %.2f | written %.2f" % tuple(d))
