@@ -633,6 +633,8 @@ int collect_box_deleted(lio_ctx* c) {
 int apply_pending(lio_ctx* c);
 static int ensure_add_buffers(lio_ctx* c, size_t n) {
     if (n <= c->cap_add) return LIO_OK;
+    // (grown by half at least: two dozen re-allocations are a millisecond, not something a growing batch should pay step by step)
+    if (c->cap_add != 0 && n < c->cap_add + c->cap_add / 2) n = c->cap_add + c->cap_add / 2;
     if (c->fold_n != 0 || c->plain_n != 0) {   // left behind by a call that failed half-way: index them first
         const int rc = apply_pending(c);
         if (rc != LIO_OK) return rc;

@@ -10,7 +10,12 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 for name, out in (("bench_c2.json", f"{tag}_bench_c2.json"), ("bench_c3.json", f"{tag}_bench_c3.json"), ("bench_c5.json", f"{tag}_bench_c5.json"),
                   ("loopbody.log", f"{tag}_loopbody.log"), ("pytest_gpu.log", f"{tag}_pytest_gpu.log"), ("stamps.log", f"{tag}_stamps.log"),
-                  ("knn_traffic.json", "knn_traffic.json")):
+                  ("knn_traffic.json", "knn_traffic.json"),
+                  # round 3 (scripts/end_of_round_r03.sh)
+                  ("bench_c2_driver.json", f"{tag}_bench_c2_driver_cmdline.json"), ("emulated_timeline.txt", f"{tag}_emulated_world8_timeline.txt"),
+                  ("node_loop_timeline.txt", f"{tag}_node_loop_timeline.txt"), ("rebuild_timeline.txt", f"{tag}_rebuild_timeline.txt"),
+                  ("kernel_stats.txt", f"{tag}_bench_c2_extras_kernel_totals.txt"), ("host_trace.log", f"{tag}_host_trace.log"),
+                  (os.path.join("prof_loop", "kernel_stats_trim.csv"), f"{tag}_loopbody_kernel_stats.csv")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, out))
@@ -21,3 +26,12 @@ if os.path.exists(ks):
                            os.path.join(dst, f"{tag}_bench_c2_kernel_stats.csv"),
                            "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline (scripts/rocprof_bench.sh)"])
     print("copied", f"{tag}_bench_c2_kernel_stats.csv")
+
+# the fuzzers' verdict lines
+fz = [f for f in ("fuzz_map.log", "fuzz_loop.log", "fuzz_measure.log", "fuzz_scanprep.log") if os.path.exists(os.path.join(src, f))]
+if fz:
+    with open(os.path.join(dst, f"{tag}_fuzz.log"), "w") as out:
+        for f in fz:
+            lines = [l for l in open(os.path.join(src, f), errors="replace").read().splitlines() if "thread" not in l.lower() and "amdgpu.ids" not in l]
+            out.write(f"== {f}\n" + "\n".join(lines[-3:]) + "\n")
+    print("copied", f"{tag}_fuzz.log")
