@@ -792,6 +792,9 @@ int apply_pending(lio_ctx* c) {
     if (st[2] & APPLY_FLAG_NO_ROOM) return rebuild_full(c);    // nothing was changed: the pending points go in there
     // the counts of the down-sampled Add_Points arrive with this read-back (no host round trip of their own)
     const uint32_t n_real = c->plain_n + (c->fold_n != 0 ? st[6] : 0u);
+    if (c->trace_rebuilds && c->fold_n != 0 && st[10] > 32u)
+        std::fprintf(stderr, "lio: index update %llu: %u points folded, %u of them replayed one by one (voxel-boundary groups), %u survivors\n",
+                     (unsigned long long)c->n_incremental_updates + 1ull, c->fold_n, st[10], st[6]);
     if (c->fold_n != 0) { c->n_live -= st[4]; c->last_add_counter = (int)st[5]; c->n_boundary_points += st[10]; }
     c->fold_n = 0; c->plain_n = 0; c->plain_ptr = nullptr; c->pend_built = false; c->batch_box = HostBox{};
     const uint32_t total = st[3];

@@ -186,9 +186,14 @@ __device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane,
     const uint32_t n_dirty = *a.n_dirty;
     if (n_dirty == 0u) { if (lane == 0) count_parts[0] = make_uint2(0u, 0u); return; }
     uint32_t n_seq = 0, counter = 0, replaced = 0;
+    // What one point of the replay writes (tomb-stones, the list of points added so far) is read by THIS wavefront at the
+    // next point and by nobody else in the launch (a map point that a clean group could touch makes that group dirty): the
+    // ordering needed is the wavefront's own, stores drained before the next point's loads -- not an agent-scope release
+    // with its L2 write-back (that and the reload of the bucket for the deletes were most of ~9.5 us per replayed point).
+    float4 p_next = a.new_pts[a.dlist[0]];
     for (uint32_t it = 0; it < n_dirty; ++it) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const float4 p = a.new_pts[a.dlist[it]];
+        const float4 p = p_next;
+        if (it + 1u < n_dirty) p_next = a.new_pts[a.dlist[it + 1u]];   // (the batch is not written here: in flight during this point)
         const float ds = a.ds;
         float bmin[3], bmax[3], mid[3];
         const float pc[3] = {p.x, p.y, p.z};
@@ -201,39 +206,52 @@ __device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane,
         auto inbox = [&](float x, float y, float z) {
             return bmin[0] <= x && bmax[0] > x && bmin[1] <= y && bmax[1] > y && bmin[2] <= z && bmax[2] > z;
         };
-        // ---- Storage, part 1: map points (lanes 0..7)
+        // ---- Storage, part 1: map points.  Lanes 0..7 look the (up to eight) grid cells of the box up; then EIGHT lanes
+        // per cell read its bucket side by side (lane = cell * 8 + r takes slots r, r + 8, ...: the dirty groups of an 8-rank
+        // batch sit where the map is dense, a lane per cell walked 40-point buckets four slots per round trip)
         int c0[3], c1[3];
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) { c0[ax] = cell_coord(bmin[ax], a.grid.inv_cell); c1[ax] = cell_coord(bmax[ax], a.grid.inv_cell); }
-        const int cx = c0[0] + ((lane >> 2) & 1), cy = c0[1] + ((lane >> 1) & 1), cz = c0[2] + (lane & 1);
-        const bool mine = lane < 8 && cx <= c1[0] && cy <= c1[1] && cz <= c1[2];
         uint32_t bst = 0, bct = 0;
-        if (mine) cell_find(a.l1table, a.l1mask, a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, bst, bct);
+        {
+            const int cx = c0[0] + ((lane >> 2) & 1), cy = c0[1] + ((lane >> 1) & 1), cz = c0[2] + (lane & 1);
+            const bool mine = lane < 8 && cx <= c1[0] && cy <= c1[1] && cz <= c1[2];
+            uint32_t fst = 0, fct = 0;
+            if (mine) cell_find(a.l1table, a.l1mask, a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, fst, fct);
+            bst = (uint32_t)__shfl((int)fst, lane >> 3, 64);
+            bct = (uint32_t)__shfl((int)fct, lane >> 3, 64);
+        }
+        const uint32_t r8 = (uint32_t)lane & 7u;
         uint32_t cnt = 0;
         float dbest = __uint_as_float(INF_BITS), bx = 0.f, by = 0.f, bz = 0.f;
-        for (uint32_t i0 = 0; i0 < bct; i0 += 4u) {
-            float4 sp[4];
+        // tie order: map points first, by cell, then by slot (a lane meets its slots in ascending order and keeps the first
+        // minimum); points added earlier in the replay after them, by list index
+        uint32_t ord = 0x7fffffffu;
+        unsigned long long in_mask = 0ull;                         // this lane's in-box live slots: bit k = slot r + 8 k (k < 64)
+        for (uint32_t k0 = 0; r8 + 8u * k0 < bct; k0 += 2u) {
+            float4 sp[2];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {
+            for (uint32_t u = 0; u < 2u; ++u) {
                 sp[u] = make_float4(0.f, 0.f, 0.f, 1.f);
-                if (i0 + u < bct) sp[u] = a.map_pts[bst + i0 + u];
+                const uint32_t sl = r8 + 8u * (k0 + u);
+                if (sl < bct) sp[u] = a.map_pts[bst + sl];
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {
+            for (uint32_t u = 0; u < 2u; ++u) {
                 if (sp[u].w != 0.0f || !inbox(sp[u].x, sp[u].y, sp[u].z)) continue;
                 ++cnt;
+                if (k0 + u < 64u) in_mask |= 1ull << (k0 + u);
                 const float d = sqdist3(sp[u].x, sp[u].y, sp[u].z, mid[0], mid[1], mid[2]);
-                if (d < dbest) { dbest = d; bx = sp[u].x; by = sp[u].y; bz = sp[u].z; }
+                if (d < dbest) { dbest = d; bx = sp[u].x; by = sp[u].y; bz = sp[u].z; ord = ((uint32_t)(lane >> 3) << 24) | (r8 + 8u * (k0 + u)); }
             }
         }
         // ---- Storage, part 2: points added earlier in this pass (all lanes, list order); they rank after the map's
-        uint32_t ord = (uint32_t)lane;                             // tie order: map cells first (lane < 8), then list index + 8
         for (uint32_t j = (uint32_t)lane; j < n_seq; j += 64) {
             const float4 q = a.seq_out[j];
             if (q.w != 0.0f || !inbox(q.x, q.y, q.z)) continue;
             ++cnt;
             const float d = sqdist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
-            if (d < dbest) { dbest = d; bx = q.x; by = q.y; bz = q.z; ord = 8u + j; }
+            if (d < dbest) { dbest = d; bx = q.x; by = q.y; bz = q.z; ord = 0x80000000u + j; }
         }
         // combine: count, and the first minimum in (distance, order)
 #pragma unroll
@@ -250,9 +268,14 @@ __device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane,
         if (cnt > 1 || same_point(p, best)) {
             ++counter;
             if (cnt > 0) {                                          // Delete_by_range of the box
-                for (uint32_t i = bst; i < bst + bct; ++i) {
-                    const float4 sp = a.map_pts[i];
-                    if (sp.w == 0.0f && inbox(sp.x, sp.y, sp.z)) { a.map_pts[i].w = TOMB_DOWNSAMPLE; ++replaced; }
+                // (the slots the scan above found; a bucket beyond 64 slots is looked at again)
+                for (unsigned long long m = in_mask; m != 0ull; m &= m - 1ull) {
+                    a.map_pts[bst + r8 + 8u * (uint32_t)__builtin_ctzll(m)].w = TOMB_DOWNSAMPLE;
+                    ++replaced;
+                }
+                for (uint32_t sl = r8 + 8u * 64u; sl < bct; sl += 8u) {          // (a bucket beyond 512 slots)
+                    const float4 sp = a.map_pts[bst + sl];
+                    if (sp.w == 0.0f && inbox(sp.x, sp.y, sp.z)) { a.map_pts[bst + sl].w = TOMB_DOWNSAMPLE; ++replaced; }
                 }
                 for (uint32_t j = (uint32_t)lane; j < n_seq; j += 64) {
                     const float4 q = a.seq_out[j];
@@ -262,9 +285,10 @@ __device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane,
             if (lane == 0) a.seq_out[n_seq] = make_float4(best.x, best.y, best.z, 0.0f);   // Add_by_point of the winner
             ++n_seq;
         }
-        // the appends / tomb-stones are in L2 before the next point reads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // the appends / tomb-stones are out of this wavefront before the next point's loads are issued
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) replaced += __shfl_xor(replaced, o, 64);
