@@ -98,7 +98,7 @@ LIO_HD float float_from_order_image(uint32_t u) {
 // re-written at the tail of the point array -- its live points in their old order, then the new ones --
 // the old slots become TOMB_MOVED, and only that cell's table entry changes.  New cells are inserted into
 // the cell directory and, as existence marks, into the coarser levels of the tree.
-struct CellPlan { uint32_t old_start, old_count, index, found; };   // index = position of the cell's record in the directory
+struct CellPlan { uint32_t old_start, old_count, index, found, live, n_new; };   // index = position of the cell's record in the directory; live = live points of the old bucket, n_new = pending points of the cell
 struct ApplyArgs {
     float4*          map_pts;
     Grid             grid;

@@ -561,25 +561,36 @@ __device__ __forceinline__ bool plan_tile_prefix(uint32_t mine, uint32_t b, unsi
 // will be -- and, in the same launch, the exclusive scan of those sizes (tiles of 256 positions, stamped tile sums)
 __global__ __launch_bounds__(256) void cell_plan_kernel(ApplyArgs a) {
     __shared__ uint32_t s_w[4];
+    __shared__ uint8_t s_head[256];
     const uint32_t n = view_count(a.view);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the statistics the apply kernel accumulates start from zero (nothing reads them before it)
     if (blockIdx.x == 0 && tid < 3) a.stats[tid] = 0u;
     const uint32_t s = blockIdx.x * 256u + (uint32_t)tid;
-    uint32_t size = 0u;
-    if (s < n && view_is_head(a.view, s)) {
+    // One lane per pending point (they are sorted by cell).  EVERY point takes one slot of its cell's new bucket, the head of
+    // a cell also the cell's live old points in front of it: the exclusive prefix of these sizes is then every point's own
+    // destination (the head's: + live) -- no lane walks over its cell's new points, neither here nor in the apply kernel.
+    const bool head = s < n && view_is_head(a.view, s);
+    s_head[tid] = head ? 1 : 0;
+    __syncthreads();
+    uint32_t size = s < n ? 1u : 0u;
+    if (head) {
         const uint64_t key = a.view.skey[s] >> 1;                  // (the low bit tells the two lists apart, not the cells)
         int cx, cy, cz;
         frame_decode(a.frame, key, cx, cy, cz);
-        CellPlan pl{0u, 0u, 0xffffffffu, 0u};
+        CellPlan pl{0u, 0u, 0xffffffffu, 0u, 0u, 0u};
         cell_find(a.ltable + a.levels.off[1], a.levels.mask[1], a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, pl.old_start, pl.old_count, &pl.index);
         pl.found = pl.old_count != 0u ? 1u : 0u;                  // records are only ever written with count >= 1
         uint32_t live = 0;
         for_each_live_point(a.map_pts, pl.old_start, pl.old_count, [&](uint32_t, float4) { ++live; });
+        // pending points of the cell = distance to the next head: inside the tile from the flags in LDS, beyond it from the keys
         uint32_t gc = 1u;
-        while (s + gc < n && (a.view.skey[s + gc] >> 1) == key) ++gc;
+        while (tid + gc < 256u && s + gc < n && s_head[tid + gc] == 0) ++gc;
+        if (tid + gc == 256u)
+            while (s + gc < n && (a.view.skey[s + gc] >> 1) == key) ++gc;
+        pl.live = live; pl.n_new = gc;
         a.plan[s] = pl;
-        size = live + gc;
+        size += live;
     }
     uint32_t inc = size;                                         // inclusive scan inside the wavefront
 #pragma unroll
@@ -623,9 +634,15 @@ __global__ __launch_bounds__(256) void cell_apply_kernel(ApplyArgs a) {
     }
     uint32_t retired_sum = 0, new_cells = 0;                   // summed over the wavefront at the end: one atomic each, not one per cell
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
-        if (!view_is_head(a.view, s)) continue;
+        // every pending point goes to its own slot (cell_plan_kernel's prefix): behind the cell's live old points, survivors
+        // first, then plain inserts, batch order -- the order of the sort
+        const bool head = view_is_head(a.view, s);
+        const float4 np = a.pend[a.view.sord[s]];
+        const uint32_t off_s = a.new_off[s];
+        if (!head) { a.map_pts[a.tail + off_s] = make_float4(np.x, np.y, np.z, 0.0f); continue; }
         const CellPlan pl = a.plan[s];
-        const uint32_t dst0 = a.tail + a.new_off[s];
+        const uint32_t dst0 = a.tail + off_s;
+        a.map_pts[dst0 + pl.live] = make_float4(np.x, np.y, np.z, 0.0f);
         uint32_t dst = dst0;
         uint32_t retired = 0;
         for_each_live_point(a.map_pts, pl.old_start, pl.old_count, [&](uint32_t i, float4 p) {   // live points keep their order
@@ -634,11 +651,7 @@ __global__ __launch_bounds__(256) void cell_apply_kernel(ApplyArgs a) {
             ++retired;
         });
         const uint64_t key = a.view.skey[s] >> 1;
-        for (uint32_t j = 0; s + j < n && (j == 0u || (a.view.skey[s + j] >> 1) == key); ++j) {   // then the new ones: survivors, then plain inserts, batch order
-            const float4 p = a.pend[a.view.sord[s + j]];
-            a.map_pts[dst++] = make_float4(p.x, p.y, p.z, 0.0f);
-        }
-        const uint32_t count = dst - dst0;
+        const uint32_t count = pl.live + pl.n_new;
         retired_sum += retired;
         int icx, icy, icz;
         frame_decode(a.frame, key, icx, icy, icz);
