@@ -338,6 +338,65 @@ def test_two_contexts_share_the_gpu(gpu_capi, small_case):
             assert got["m"] == ref["m"] and np.array_equal(got["HTH"], ref["HTH"]) and np.array_equal(got["HTh"], ref["HTh"])
 
 
+def test_foreign_work_on_another_stream(gpu_capi, synth, small_case):
+    """A third party keeps the GPU busy on a stream of its own (large matrix products from another host thread, the way an
+    RCCL kernel or a neighbour's inference would) while scan steps -- passes enqueued ahead of their pose behind gate kernels,
+    stamped cross-workgroup folds, walkers -- and the map update's single-launch scans run: the foreign workgroups take CUs
+    away at arbitrary moments, every bounded wait must still complete (no LIO_ERR_HIP) and the results must be the bits of a
+    quiet run (posterior, covariance, call log, insert counts, live points)."""
+    import threading
+    import torch
+    w, sc = small_case["world"], small_case["scan"]
+    P0 = synth.init_cov()
+    scans, priors = [], []
+    for k in range(6):
+        s2 = synth.make_scan(w, len(sc.body), seed=synth.SEED + 500 + k, pos=(0.7 * k, 0.2 * k, 0.0), rpy=(0.002, -0.003, 0.03 * k))
+        ps, rt = synth.perturb_state(s2, seed=synth.SEED + 600 + k)
+        scans.append(gpu_capi.scan_to_device(s2.body)); priors.append(gpu_capi.make_state26(ps, rt, s2.off_R, s2.off_T))
+
+    def drive():
+        ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+        ctx.map_build(w.points)
+        out = []
+        for rep in range(5):
+            for k in range(6):
+                kf = gpu_capi.Esekf(3)
+                log = gpu_capi.scan_step_device(kf, ctx, priors[k], P0, scans[k].ptr, len(sc.body), 0.001, False)
+                mi = ctx.map_incremental(kf.get_x()[:14], 0.2, True)
+                out.append((kf.get_x(), kf.get_P(), (log["n_calls"], log["n_search"], log["last_m"]), (mi["n_add"], mi["n_nodown"], ctx.map_validnum())))
+        ctx.close()
+        return out
+
+    quiet = drive()
+    stop = threading.Event()
+    noise_err = []
+
+    def noise():
+        try:
+            dev = torch.device("cuda", 0)
+            st = torch.cuda.Stream(device=dev)
+            a = torch.randn(3072, 3072, device=dev)
+            with torch.cuda.stream(st):
+                while not stop.is_set():
+                    for _ in range(4):
+                        a = (a @ a).clamp_(-1.0, 1.0)
+                    st.synchronize()
+        except Exception as e:                                  # noqa: BLE001
+            noise_err.append(repr(e))
+
+    t = threading.Thread(target=noise)
+    t.start()
+    try:
+        busy = drive()
+    finally:
+        stop.set()
+        t.join()
+    assert not noise_err, noise_err
+    assert len(busy) == len(quiet)
+    for a, b in zip(quiet, busy):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+
+
 def test_voxel_filtered_scan_has_no_rank_ties(gpu_capi, oracle, synth, small_case):
     """Tie semantics differ by design (equal distances: by map index here, by traversal order in the reference,
     ikd_Tree.cpp:887).  On a scan shaped like the node's -- a raw sweep through pcl::VoxelGrid's centroids
