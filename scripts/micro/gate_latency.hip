@@ -49,6 +49,43 @@ __global__ __launch_bounds__(64) void gate(const Ctrl* ctrl, unsigned long long 
     if (lane == 7) { pose_dev[7] = 0.0; *state = ok ? 1u : 2u; }
 }
 
+// D: no gate kernel -- the pass's own kernel is dispatched early, every workgroup spins on a device word that workgroup 0 sets
+// after it has seen the host's word (and copied the pose); the first workgroup publishes when released
+__global__ __launch_bounds__(256) void work_self_gated(float* buf, int n, unsigned seq, unsigned* out, const Ctrl* ctrl, unsigned* armed,
+                                                      double* pose_dev, unsigned* go_dev, unsigned max_polls) {
+    __shared__ unsigned s_ok;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (blockIdx.x == 0) {
+            if (lane == 0) __hip_atomic_store(armed, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long* line = reinterpret_cast<const unsigned long long*>(ctrl);
+            unsigned long long v = 0;
+            unsigned polls = 0;
+            while (polls++ < max_polls) {
+                if (lane < 8) v = __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (__shfl(v, 7, 64) == (unsigned long long)seq) break;
+            }
+            if (lane < 7) __hip_atomic_store(reinterpret_cast<unsigned long long*>(pose_dev) + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(go_dev, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            unsigned polls = 0;
+            while (__hip_atomic_load(go_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq && polls++ < max_polls) __builtin_amdgcn_s_sleep(8);
+            s_ok = 1u;
+        }
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) __hip_atomic_store(out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (i < n) {
+        const double pz = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(pose_dev) + (i & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        float v = buf[i] + (float)pz + (float)s_ok;
+        for (int k = 0; k < 64; ++k) v = v * 1.0001f + 0.5f;
+        buf[i] = v;
+    }
+}
+
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main() {
@@ -68,7 +105,8 @@ int main() {
     const dim3 grid((n + 255) / 256), block(256);
     auto wait_out = [&](unsigned v) { while (__atomic_load_n(h_out, __ATOMIC_ACQUIRE) != v) { } };
     unsigned seq = 0;
-    for (int mode = 0; mode < 3; ++mode) {
+    unsigned* go_dev; CK(hipMalloc(&go_dev, 64)); CK(hipMemset(go_dev, 0, 64));
+    for (int mode = 0; mode < 5; ++mode) {
         std::vector<double> t(iters);
         for (int it = -100; it < iters; ++it) {
             ++seq;
@@ -80,8 +118,13 @@ int main() {
                 // mode 1: the previous kernel is long gone (the queue is idle when the gate is enqueued)
                 // mode 2: a 30 us kernel is still running in front of the gate (a pass in flight), wait for it, then 5 us of "host algebra"
                 if (mode == 2) hipLaunchKernelGGL(work, grid, block, 0, s, buf, n, 0u, d_armed + 8, (const double*)nullptr);
+                if (mode >= 3) {
+                    if (mode == 4) hipLaunchKernelGGL(work, grid, block, 0, s, buf, n, 0u, d_armed + 8, (const double*)nullptr);
+                    hipLaunchKernelGGL(work_self_gated, grid, block, 0, s, buf, n, seq, d_out, (const Ctrl*)d_ctrl, d_armed, pose_dev, go_dev, 400000u);
+                } else {
                 hipLaunchKernelGGL(gate, dim3(1), dim3(64), 0, s, (const Ctrl*)d_ctrl, (unsigned long long)seq, d_armed, pose_dev, state, 400000u);
                 hipLaunchKernelGGL(work, grid, block, 0, s, buf, n, seq, d_out, (const double*)pose_dev);
+                }
                 while (__atomic_load_n(h_armed, __ATOMIC_ACQUIRE) != seq) { }           // the gate is resident
                 const double tw = now_us();
                 while (now_us() - tw < 5.0) { }                                          // the host's own work
@@ -97,7 +140,9 @@ int main() {
         std::sort(t.begin(), t.end());
         std::printf("%s: median %.2f us  p10 %.2f  p90 %.2f\n", mode == 0 ? "A direct launch -> first workgroup -> host" :
                     mode == 1 ? "B gate (idle queue): host word -> first workgroup -> host" :
-                                "C gate (behind a running kernel): host word -> first workgroup -> host", t[iters / 2], t[iters / 10], t[iters * 9 / 10]);
+                    mode == 2 ? "C gate (behind a running kernel): host word -> first workgroup -> host" :
+                    mode == 3 ? "D self-gated kernel (idle queue): host word -> released workgroup -> host" :
+                                "E self-gated kernel (behind a running kernel): host word -> released workgroup -> host", t[iters / 2], t[iters / 10], t[iters * 9 / 10]);
     }
     unsigned st = 0; CK(hipMemcpy(&st, state, 4, hipMemcpyDeviceToHost));
     std::printf("last gate state %u (1 = released by the host, 2 = ran out)\n", st);
