@@ -243,6 +243,7 @@ struct lio_ctx {
     bool census = false;                       // count C(q) in the k-NN kernel (one atomic per wavefront)
     int dbg_force_timeout = 0;                 // lio_debug_set("force_reduction_timeout")
     int dbg_knn_tune = 0;                      // lio_debug_set("knn_tune")
+    int dbg_knn_walk = -1;                     // lio_debug_set("knn_walk") / LIO_KNN_WALK: -1 = by scan size (auto_walk), 0 / 1 / 4 = KnnArgs.walk
     int dbg_library_sort = 0;                  // lio_debug_set("library_sort"): rocPRIM for every sort / compaction (A/B switch)
     int dbg_stamps = 0;                        // lio_debug_set("stamps"): the last workgroup takes wall_clock64 stamps (lio_debug_stamps)
     int dbg_separate_walk = 0;                 // lio_debug_set("separate_tree_walk"): the stand-alone knn_tree_kernel per search pass
@@ -276,6 +277,13 @@ float auto_cell_size(float ds) {
 bool is_pow2f(float v) {
     int e;
     return v > 0.0f && std::frexp(v, &e) == 0.5f;
+}
+// Candidate walk of knn27_kernel (KnnArgs.walk): launches that leave SIMDs half empty are chains of dependent round trips --
+// there the prefix-form list with four candidates per lane in flight; a launch that fills the GPU is bound by instruction
+// issue and keeps the plain walk.
+int auto_walk(int nq, int lanes) {
+    (void)nq; (void)lanes;
+    return 0;
 }
 int auto_lanes(int nq) {
     // measured on MI355X: 8 lanes per query wins at 100 k and 1 M queries (C2/C5: the kernel is VALU-bound and
@@ -437,7 +445,7 @@ static hipError_t compact_live_any(lio_ctx* c, const float4* src, uint32_t n, fl
     // (tile counts and offsets live in the sort workspace, which is idle here)
     uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(c->d_temp);
     uint32_t* tile_off = tile_cnt + (n / 2048u + 4u);
-    if (((size_t)n / 2048u + 4u) * 2u * sizeof(uint32_t) > c->temp_bytes) return select_live_points(c->d_temp, c->temp_bytes, src, dst, n_out, n, c->stream);
+    if (((size_t)n / 2048u + 4u) * 2u * sizeof(uint32_t) > c->temp_bytes || (size_t)n / 2048u + 2u > COMPACT_MAX_ITEMS) return select_live_points(c->d_temp, c->temp_bytes, src, dst, n_out, n, c->stream);
     return launch_compact_live_large(src, n, dst, n_out, tile_cnt, tile_off, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, c->stream);
 }
 // frame of the integer coordinates lo .. hi (inclusive) of a batch: one spare coordinate per axis above hi, so that the
@@ -757,6 +765,14 @@ int rebuild_full(lio_ctx* c) {
     return build_index(c, c->d_pts_tmp, live + n_pend);
 }
 
+// how many retired slots (copies of re-written buckets) the map may carry before a full rebuild compacts them away
+constexpr uint64_t RETIRED_PER_LIVE = 4;
+static uint32_t retired_slot_budget(const lio_ctx* c) {
+    if (c->dbg_retired_budget > 0) return (uint32_t)c->dbg_retired_budget;
+    const uint64_t b = RETIRED_PER_LIVE * (uint64_t)c->n_live;
+    return (uint32_t)(b > 1048576ull ? (b < 0xfffffff0ull ? b : 0xfffffff0ull) : 1048576ull);
+}
+
 // The pending points enter the index: O(batch), the rest of the map is not touched (lio_mapadd.hip).
 // Launches: pend_build, the sort by (cell, list) (1 or 2), cell_plan (with the scan of the new bucket sizes), cell_apply,
 // and ONE read-back that brings the statistics of this update together with the counts the fold left on the device.
@@ -804,12 +820,10 @@ int apply_pending(lio_ctx* c) {
     c->n_cells += st[0]; c->n_new_cells += st[0]; c->n_retired += st[1];
     ++c->n_incremental_updates;
     // Retired copies of re-written buckets (TOMB_MOVED) cost memory and nothing else -- no search ever reads them, and 16 bytes
-    // a slot is cheap on a 288 GB part: they may grow to twice the live points (the array is sized for that; a full tail asks
-    // for the rebuild by itself, APPLY_FLAG_NO_ROOM).  Box-deleted points sit INSIDE live buckets and are streamed by every
-    // search that passes: their budget stays tight.
-    const uint64_t twice_live = 2ull * c->n_live;
-    const uint32_t retired_budget = c->dbg_retired_budget > 0 ? (uint32_t)c->dbg_retired_budget
-                                  : (uint32_t)(twice_live > 1048576ull ? (twice_live < 0xfffffff0ull ? twice_live : 0xfffffff0ull) : 1048576ull);
+    // a slot is cheap on a 288 GB part: they may grow to RETIRED_PER_LIVE times the live points (the array is sized for that; a
+    // full tail asks for the rebuild by itself, APPLY_FLAG_NO_ROOM).  Box-deleted points sit INSIDE live buckets and are
+    // streamed by every search that passes: their budget stays tight.
+    const uint32_t retired_budget = retired_slot_budget(c);
     const uint32_t dead_budget = c->n_live / 8 > 65536u ? c->n_live / 8 : 65536u;
     // Keep every hashed level at most half full (they are built a quarter full; the apply kernel counts the entries a
     // level gains), so that probe sequences stay short and a look-up of an absent key always meets an empty slot --
@@ -894,6 +908,7 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.tune = c->dbg_knn_tune;
     ka.gate = gate;
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
+    ka.walk = (lanes == 8 || lanes == 16) ? (c->dbg_knn_walk >= 0 ? c->dbg_knn_walk : auto_walk(nq, lanes)) : 0;
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
     if (walk_now) HIPCHK(c, launch_knn_tree(tree_args(c, nq, stride, nbr, cnt, ulist, useeds), s, prof_timer(c, LIO_PROF_FALLBACK)));
     return LIO_OK;
@@ -939,6 +954,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     { const char* e = std::getenv("LIO_TRACE_REBUILDS"); c->trace_rebuilds = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_TRACE_HOST"); c->trace_host = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_PRE_ENQUEUE"); if (e != nullptr && e[0] == '0') c->dbg_pre_enqueue = 0; }   // (A/B runs of scripts)
+    { const char* e = std::getenv("LIO_KNN_WALK"); if (e != nullptr && (e[0] == '0' || e[0] == '1' || e[0] == '4') && e[1] == 0) c->dbg_knn_walk = e[0] - '0'; }
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, c->device));
     c->arch = prop.gcnArchName;
@@ -961,7 +977,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     c->cap_map = nm;
     // buckets that receive points are re-written at the tail of the array; the room for that is ours, not the
     // caller's (max_map_points bounds the live points)
-    c->slots_cap = 3 * nm + 1048576;           // live points + the budget of retired slots (apply_pending)
+    c->slots_cap = (1 + RETIRED_PER_LIVE) * nm + 1048576;   // live points + the budget of retired slots (apply_pending): 80 B per map point
     if (c->slots_cap > 0xfffffff0ull) c->slots_cap = 0xfffffff0ull;
     CREATE_CHK(hipMalloc((void**)&c->d_pts, c->slots_cap * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_pts_tmp, c->slots_cap * sizeof(float4)));
@@ -2468,6 +2484,16 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "library_sort") == 0) { c->dbg_library_sort = value != 0; return LIO_OK; }
     if (std::strcmp(key, "stamps") == 0) { c->dbg_stamps = value != 0; return LIO_OK; }
     if (std::strcmp(key, "knn_tune") == 0) { c->dbg_knn_tune = (int)value; return LIO_OK; }
+    if (std::strcmp(key, "knn_walk") == 0) {
+        if (value != -1 && value != 0 && value != 1 && value != 4) return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "knn_walk: -1, 0, 1 or 4");
+        c->dbg_knn_walk = (int)value;
+        return LIO_OK;
+    }
+    if (std::strcmp(key, "lanes_per_query") == 0) {            // (0 = by scan size again)
+        if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "lanes_per_query: 0, 4, 8, 16, 32 or 64");
+        c->cfg.lanes_per_query = (int)value;
+        return LIO_OK;
+    }
     if (std::strcmp(key, "rows_direct") == 0) { c->dbg_rows_direct = (int)value; return LIO_OK; }
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
     if (std::strcmp(key, "pre_enqueue") == 0) { c->dbg_pre_enqueue = value != 0; return LIO_OK; }
@@ -2488,6 +2514,7 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (!c || !key || !value) return LIO_ERR_INVALID_ARG;
     if (std::strcmp(key, "gate_released") == 0) { *value = c->n_gate_released; return LIO_OK; }
     if (std::strcmp(key, "gate_called_off") == 0) { *value = c->n_gate_called_off; return LIO_OK; }
+    if (std::strcmp(key, "retired_budget") == 0) { *value = (long long)retired_slot_budget(c); return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_get", "unknown key");
 }
 int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {

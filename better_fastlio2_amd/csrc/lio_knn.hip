@@ -108,11 +108,20 @@ __device__ __forceinline__ double candidate_key_f(float qx, float qy, float qz, 
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int G, bool CENSUS, bool HINT>
+// U = 0: the candidate walk of rounds 1-3 (list of {start, count}, one load in flight per lane) -- the form every throughput-bound
+//        launch uses (C2, C5: the kernel is VALU-bound there and extra loads in flight bought nothing).
+// U >= 1 (G = 8 or 16): the list is turned into PREFIX form {start - candidates before, candidates up to and including} -- a lane
+//        finds the bucket of its t-th candidate with one compare per bucket and the map index with one add -- and U candidates per
+//        lane are loaded together before any of them is looked at: launches too small to fill the SIMDs (C3's 24 k queries, the
+//        node's ~9 k-point scans) are a chain of dependent round trips, one per candidate of a lane; this makes it one per U.
+//        Same candidates, same keys, same ladder: bit-identical results (the order in which a lane offers its candidates to its
+//        sorted list does not change the list).
+template <int G, bool CENSUS, bool HINT, int U = 0>
 __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     constexpr int WPB = 4;
     constexpr int GPW = 64 / G;                    // queries per wavefront
-    __shared__ uint2 s_bucket[WPB][GPW][28];       // LDS-staged non-empty buckets {start, count}
+    static_assert(U == 0 || ((G == 8 || G == 16) && !CENSUS), "prefix-form walk: 8 or 16 lanes per query, no census");
+    __shared__ uint2 s_bucket[WPB][GPW][U > 0 ? 32 : 28];   // LDS-staged non-empty buckets {start, count}
 
     if (a.gate != nullptr && a.gate->skip != 0u) return;      // a pre-enqueued pass the host called off
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -324,28 +333,91 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         if (ne) s_bucket[wave][g][pos] = make_uint2(st[s], ct[s]);
         n_ne += __popcll(gb);
     }
-    // a sentinel bucket that no candidate number reaches ends the walk below
-    if (r == 0) s_bucket[wave][g][n_ne] = make_uint2(0u, 0xffffffffu);
-    // LDS is in-order per wavefront; the fence keeps the compiler from moving the reads up
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- stream the candidates: the buckets of a query are walked as ONE concatenated list and lane r
-    // takes its candidates r, r+G, r+2G, ... -- every iteration keeps all G lanes busy whatever the
-    // bucket sizes are (points of a bucket are contiguous: consecutive lanes, consecutive addresses)
     Top5 top; top.init();
     uint32_t csum = 0;
-    if (CENSUS) for (int i = 0; i < n_ne; ++i) csum += s_bucket[wave][g][i].y;
-    {
-        uint32_t b = 0, base = 0, t = (uint32_t)r;
-        uint2 bk = s_bucket[wave][g][0];
-        while (t - base >= bk.y) { base += bk.y; ++b; bk = s_bucket[wave][g][b]; }
-        while ((int)b < n_ne) {
-            const uint32_t idx = bk.x + (t - base);
-            top.offer(candidate_key_f(qx, qy, qz, a.map_pts[idx], idx));
-            t += (uint32_t)G;
+    if constexpr (U == 0) {
+        // a sentinel bucket that no candidate number reaches ends the walk below
+        if (r == 0) s_bucket[wave][g][n_ne] = make_uint2(0u, 0xffffffffu);
+        // LDS is in-order per wavefront; the fence keeps the compiler from moving the reads up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- stream the candidates: the buckets of a query are walked as ONE concatenated list and lane r
+        // takes its candidates r, r+G, r+2G, ... -- every iteration keeps all G lanes busy whatever the
+        // bucket sizes are (points of a bucket are contiguous: consecutive lanes, consecutive addresses)
+        if (CENSUS) for (int i = 0; i < n_ne; ++i) csum += s_bucket[wave][g][i].y;
+        {
+            uint32_t b = 0, base = 0, t = (uint32_t)r;
+            uint2 bk = s_bucket[wave][g][0];
             while (t - base >= bk.y) { base += bk.y; ++b; bk = s_bucket[wave][g][b]; }
+            while ((int)b < n_ne) {
+                const uint32_t idx = bk.x + (t - base);
+                top.offer(candidate_key_f(qx, qy, qz, a.map_pts[idx], idx));
+                t += (uint32_t)G;
+                while (t - base >= bk.y) { base += bk.y; ++b; bk = s_bucket[wave][g][b]; }
+            }
+        }
+    } else {
+        // ---- prefix form of the list: lane r owns entries [r * EPL, (r + 1) * EPL) (32 slots >= the 27 + 1 a group can fill)
+        constexpr int EPL = 32 / G;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint2* lst = s_bucket[wave][g];
+        uint2 ent[EPL];
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            ent[k] = lst[r * EPL + k];                                   // (slots at and beyond n_ne hold leftovers: masked)
+            if (r * EPL + k >= n_ne) ent[k].y = 0u;
+            run += ent[k].y;
+        }
+        uint32_t inc = run;
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, o, G);
+            if (r >= o) inc += up;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)inc, lane - r + G - 1, 64);   // candidates of this query
+        uint32_t before = inc - run;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                                // every lane has read its entries
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            if (r * EPL + k < n_ne) lst[r * EPL + k] = make_uint2(ent[k].x - before, before + ent[k].y);
+            before += ent[k].y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- the walk: candidate t of the query lies in the first bucket whose cumulative count exceeds t, at map index
+        // (start - candidates before) + t; lane r takes t = r, r + G, ...; U of them are fetched together
+        uint32_t t = (uint32_t)r;
+        const uint2* cur = lst;
+        uint2 bk = *cur;                                                 // (total == 0: never used)
+        while (t < total) {
+            uint32_t idx[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t tu = t + (uint32_t)(u * G);
+                ok[u] = tu < total;
+                idx[u] = u > 0 ? idx[0] : 0u;                            // (beyond the list: a load nobody looks at)
+                if (ok[u]) {
+                    while (tu >= bk.y) { ++cur; bk = *cur; }              // ends inside the list: bucket n_ne - 1 reaches `total`
+                    idx[u] = bk.x + tu;
+                }
+            }
+            float4 p[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) p[u] = a.map_pts[idx[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double key = candidate_key_f(qx, qy, qz, p[u], idx[u]);
+                top.offer(ok[u] ? key : Top5::none());                   // offering "none" changes nothing
+            }
+            t += (uint32_t)(U * G);
         }
     }
 
@@ -426,8 +498,25 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     }
 }
 
+template <int G, int U>
+static void launch_knn27_gu(const KnnArgs& a, hipStream_t s, KernelTimer t) {
+    const int qpb = 4 * (64 / G);                  // queries per 256-thread workgroup
+    const dim3 grid((a.nq + qpb - 1) / qpb), block(256);
+    if (t.start != nullptr) {
+        if (a.use_hint) hipExtLaunchKernelGGL((knn27_kernel<G, false, true, U>), grid, block, 0, s, t.start, t.stop, 0, a);
+        else            hipExtLaunchKernelGGL((knn27_kernel<G, false, false, U>), grid, block, 0, s, t.start, t.stop, 0, a);
+        return;
+    }
+    if (a.use_hint) hipLaunchKernelGGL((knn27_kernel<G, false, true, U>), grid, block, 0, s, a);
+    else            hipLaunchKernelGGL((knn27_kernel<G, false, false, U>), grid, block, 0, s, a);
+}
 template <int G>
 static void launch_knn27_g(const KnnArgs& a, hipStream_t s, KernelTimer t) {
+    if constexpr (G == 8 || G == 16) {
+        // the prefix-form walk with U candidates per lane in flight (KnnArgs.walk; the census keeps the plain walk)
+        if (a.cand_total == nullptr && a.walk == 1) { launch_knn27_gu<G, 1>(a, s, t); return; }
+        if (a.cand_total == nullptr && a.walk == 4) { launch_knn27_gu<G, 4>(a, s, t); return; }
+    }
     const int qpb = 4 * (64 / G);                  // queries per 256-thread workgroup
     const dim3 grid((a.nq + qpb - 1) / qpb), block(256);
     if (t.start != nullptr) {

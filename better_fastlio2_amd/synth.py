@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import dataclasses
 import math
+import os
 
 import numpy as np
 
@@ -86,6 +87,12 @@ def rot_from_rpy(roll: float, pitch: float, yaw: float) -> np.ndarray:
 def make_world(n_map: int, voxel: float = 0.2, seed: int = SEED, ground_frac: float = 0.80,
                facade_frac: float = 0.15) -> World:
     """Exactly n_map float32 points, at most one per `voxel` cell."""
+    # LIO_SYNTH_CACHE=<dir>: several scripts of one GPU-box visit share the generated world (5 M points take ~20 s of numpy)
+    cache = os.environ.get("LIO_SYNTH_CACHE")
+    cfile = os.path.join(cache, "world_%d_%g_%d_%g_%g.npz" % (n_map, voxel, seed, ground_frac, facade_frac)) if cache else None
+    if cfile and os.path.exists(cfile):
+        z = np.load(cfile)
+        return World(points=z["points"], voxel=voxel, ground_half=float(z["ground_half"]), walls=z["walls"], seed=seed)
     rng = np.random.default_rng(seed)
     n_ground = int(round(ground_frac * n_map))
     side_cells = max(4, int(math.ceil(math.sqrt(n_ground))))
@@ -152,8 +159,13 @@ def make_world(n_map: int, voxel: float = 0.2, seed: int = SEED, ground_frac: fl
                       rng.uniform(0.15, 3.0, need + 64)], 1)
         pts = dedupe(np.concatenate([pts.astype(np.float64), c], 0))[:n_map]
     perm = rng.permutation(len(pts))
-    return World(points=np.ascontiguousarray(pts[perm]), voxel=voxel, ground_half=half,
-                 walls=np.array(walls, dtype=np.float64).reshape(-1, 6), seed=seed)
+    w = World(points=np.ascontiguousarray(pts[perm]), voxel=voxel, ground_half=half,
+              walls=np.array(walls, dtype=np.float64).reshape(-1, 6), seed=seed)
+    if cfile:
+        os.makedirs(cache, exist_ok=True)
+        np.savez(cfile + ".tmp.npz", points=w.points, ground_half=w.ground_half, walls=w.walls)
+        os.replace(cfile + ".tmp.npz", cfile)
+    return w
 
 
 def _raycast(world: World, origin: np.ndarray, dirs: np.ndarray, max_range: float) -> np.ndarray:

@@ -65,6 +65,40 @@ def test_nearest_search_bit_exact(gpu_capi, oracle, small_case, lanes):
     ctx.close()
 
 
+@pytest.mark.parametrize("lanes", [8, 16])
+def test_candidate_walk_variants_are_bit_identical(gpu_capi, oracle, small_case, lanes):
+    """knn27_kernel's candidate walk in prefix form with one / four candidates per lane in flight (KnnArgs.walk, lio_knn.hip)
+    sees the same candidates as the plain walk: neighbours, distances, counts, the unproven list (hence the walk's results)
+    and the sums of a search pass and of the bounded re-search at a moved pose are the same bits -- and the oracle's."""
+    q = _hard_queries(small_case, oracle)
+    om = oracle.OracleMap(0.2); om.build(small_case["world"].points)
+    ox, od, oc, _ = om.knn(q)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float64)
+    moved = ident.copy(); moved[:3] = [0.04, -0.03, 0.02]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=len(q), max_map_points=400_000, lanes_per_query=lanes)
+    ctx.map_build(small_case["world"].points)
+    res = {}
+    for walk in (0, 1, 4):
+        ctx.debug_set("knn_walk", walk)
+        gx, gd, gc = ctx.nearest_search(q)
+        ctx.scan_set(q)
+        a = ctx.measure(ident, True, False)
+        n1 = ctx.neighbors()
+        b = ctx.measure(moved, True, False)          # bounded by the previous neighbours (HINT variant of the kernel)
+        n2 = ctx.neighbors()
+        res[walk] = (gx, gd, gc, a, n1, b, n2)
+    ctx.close()
+    assert np.array_equal(res[0][2], oc) and bits_equal(res[0][1], od)
+    for walk in (1, 4):
+        r, z = res[walk], res[0]
+        assert bits_equal(r[0], z[0]) and bits_equal(r[1], z[1]) and np.array_equal(r[2], z[2])
+        for k in (3, 5):
+            assert r[k]["m"] == z[k]["m"] and r[k]["n_unresolved"] == z[k]["n_unresolved"]
+            assert np.array_equal(r[k]["HTH"], z[k]["HTH"]) and np.array_equal(r[k]["HTh"], z[k]["HTh"])
+        for k in (4, 6):
+            assert bits_equal(r[k][0], z[k][0]) and bits_equal(r[k][1], z[k][1]) and np.array_equal(r[k][2], z[k][2])
+
+
 @pytest.mark.parametrize("ext", [False, True])
 def test_tree_walk_inside_the_measurement_kernel(gpu_capi, oracle, small_case, ext):
     """A search pass walks the queries the 27-cell kernel could not prove INSIDE the measurement kernel (walker
