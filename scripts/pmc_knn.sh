@@ -2,6 +2,7 @@
 # traffic behind bench.py's roofline.traffic.  Writes gpurun_out/pmc/knn_traffic.json (copy it to profiles/).
 #   gpurun --timeout 900 -- 'bash scripts/pmc_knn.sh'
 cd /tmp && export TMPDIR=/tmp
+export LIO_SYNTH_CACHE=/tmp/lio_synth        # the four passes share the generated world
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc; mkdir -p $R/gpurun_out/pmc
 i=0
