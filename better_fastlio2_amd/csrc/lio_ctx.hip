@@ -243,7 +243,7 @@ struct lio_ctx {
     bool census = false;                       // count C(q) in the k-NN kernel (one atomic per wavefront)
     int dbg_force_timeout = 0;                 // lio_debug_set("force_reduction_timeout")
     int dbg_knn_tune = 0;                      // lio_debug_set("knn_tune")
-    int dbg_knn_walk = -1;                     // lio_debug_set("knn_walk") / LIO_KNN_WALK: -1 = by scan size (auto_walk), 0 / 1 / 4 = KnnArgs.walk
+    int dbg_knn_walk = -1;                     // lio_debug_set("knn_walk") / LIO_KNN_WALK: -1 = by scan size (auto_walk), 0 / 1 / 2 / 4 = KnnArgs.walk
     int dbg_library_sort = 0;                  // lio_debug_set("library_sort"): rocPRIM for every sort / compaction (A/B switch)
     int dbg_stamps = 0;                        // lio_debug_set("stamps"): the last workgroup takes wall_clock64 stamps (lio_debug_stamps)
     int dbg_separate_walk = 0;                 // lio_debug_set("separate_tree_walk"): the stand-alone knn_tree_kernel per search pass
@@ -278,18 +278,29 @@ bool is_pow2f(float v) {
     int e;
     return v > 0.0f && std::frexp(v, &e) == 0.5f;
 }
-// Candidate walk of knn27_kernel (KnnArgs.walk): launches that leave SIMDs half empty are chains of dependent round trips --
-// there the prefix-form list with four candidates per lane in flight; a launch that fills the GPU is bound by instruction
-// issue and keeps the plain walk.
-int auto_walk(int nq, int lanes) {
-    (void)nq; (void)lanes;
-    return 0;
+// Candidate walk of knn27_kernel (KnnArgs.walk, lio_knn.hip).  Measured on MI355X (scripts/dbg/knn_walk_ab.py, 5 M-point map, scans of
+// 3 k ... 100 k points, first / bounded search; profiles/r03z_walk_ab.log): the prefix-form list with four candidates per lane in
+// flight wins the FIRST search of a scan at every size (100 k: 23.1 -> 22.1 us, 24 k: 11.0 -> 10.1, 8.6 k: 8.2 -> 7.9); the bounded
+// re-search streams about half the candidates and gains nothing from it.  Scans beyond the fused transform's range (C5) keep the
+// plain walk (not measured there).
+int auto_walk(int nq, int lanes, bool hint) {
+    if (hint || nq > 262144) return 0;
+    return (lanes == 4 || lanes == 8 || lanes == 16) ? 4 : 0;
 }
-int auto_lanes(int nq) {
-    // measured on MI355X: 8 lanes per query wins at 100 k and 1 M queries (C2/C5: the kernel is VALU-bound and
-    // 8 lanes waste the fewest instructions); at 24 k (C3) there are too few wavefronts to fill 256 CUs and
-    // 16 lanes are 5 % faster; very small scans prefer wider groups still
-    if (nq >= 40000) return 8;
+int auto_lanes(int nq, bool hint) {
+    // measured on MI355X (the same script): the kernel is bound by instruction issue when the launch fills the GPU and by its
+    // chain of dependent round trips when it does not.  First search: 8 lanes per query from ~22 k queries up (C2, C5; at 24 k
+    // 10.1 vs 10.7 us), 16 below (8.6 k: 7.9 vs 8.6), 32 for very small scans.  The bounded re-search has about half the
+    // candidates, so the per-query fixed work (directory look-up, merge, results) weighs more: FOUR lanes per query from ~60 k
+    // queries up (100 k: 20.2 vs 21.0 us, 70 k: 16.4 vs 17.5; 50 k: 14.3 vs 13.9 the other way), 8 from ~14 k, 16 below.
+    if (hint) {
+        if (nq > 262144) return 8;
+        if (nq >= 60000) return 4;
+        if (nq >= 14000) return 8;
+        if (nq >= 2000) return 16;
+        return 32;
+    }
+    if (nq >= 22000) return 8;
     if (nq >= 2000) return 16;
     return 32;
 }
@@ -907,8 +918,8 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.use_hint = use_hint ? 1 : 0;
     ka.tune = c->dbg_knn_tune;
     ka.gate = gate;
-    const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
-    ka.walk = (lanes == 8 || lanes == 16) ? (c->dbg_knn_walk >= 0 ? c->dbg_knn_walk : auto_walk(nq, lanes)) : 0;
+    const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq, use_hint);
+    ka.walk = (lanes == 4 || lanes == 8 || lanes == 16) ? (c->dbg_knn_walk >= 0 ? c->dbg_knn_walk : auto_walk(nq, lanes, use_hint)) : 0;
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
     if (walk_now) HIPCHK(c, launch_knn_tree(tree_args(c, nq, stride, nbr, cnt, ulist, useeds), s, prof_timer(c, LIO_PROF_FALLBACK)));
     return LIO_OK;
@@ -954,7 +965,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     { const char* e = std::getenv("LIO_TRACE_REBUILDS"); c->trace_rebuilds = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_TRACE_HOST"); c->trace_host = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_PRE_ENQUEUE"); if (e != nullptr && e[0] == '0') c->dbg_pre_enqueue = 0; }   // (A/B runs of scripts)
-    { const char* e = std::getenv("LIO_KNN_WALK"); if (e != nullptr && (e[0] == '0' || e[0] == '1' || e[0] == '4') && e[1] == 0) c->dbg_knn_walk = e[0] - '0'; }
+    { const char* e = std::getenv("LIO_KNN_WALK"); if (e != nullptr && (e[0] == '0' || e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0) c->dbg_knn_walk = e[0] - '0'; }
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, c->device));
     c->arch = prop.gcnArchName;
@@ -2485,7 +2496,7 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "stamps") == 0) { c->dbg_stamps = value != 0; return LIO_OK; }
     if (std::strcmp(key, "knn_tune") == 0) { c->dbg_knn_tune = (int)value; return LIO_OK; }
     if (std::strcmp(key, "knn_walk") == 0) {
-        if (value != -1 && value != 0 && value != 1 && value != 4) return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "knn_walk: -1, 0, 1 or 4");
+        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4) return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "knn_walk: -1, 0, 1, 2 or 4");
         c->dbg_knn_walk = (int)value;
         return LIO_OK;
     }

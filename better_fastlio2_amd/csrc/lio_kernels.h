@@ -30,8 +30,8 @@ struct KnnArgs {
     unsigned long long* cand_total; // device counter: sum of C(q)
     int              use_hint;      // nbr/cnt hold this scan's previous neighbours: bound the search with them
     int              tune;          // experiment switches (lio_debug_set "knn_tune"): bit 0 = do NOT raise the transforming wavefront's priority
-    int              walk;          // candidate walk: 0 = list of {start, count}, one load in flight per lane; 1 / 4 = prefix-form
-                                    // list with that many candidates per lane in flight (8 or 16 lanes per query; lio_knn.hip)
+    int              walk;          // candidate walk: 0 = list of {start, count}, one load in flight per lane; 1 / 2 / 4 = prefix-form
+                                    // list with that many candidates per lane in flight (4, 8 or 16 lanes per query; lio_knn.hip)
 };
 // feats_down_world = pose (x) feats_down_body as a launch of its own (large scans only; otherwise inside knn27_kernel)
 hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float4* world, hipStream_t s);

@@ -120,7 +120,7 @@ template <int G, bool CENSUS, bool HINT, int U = 0>
 __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     constexpr int WPB = 4;
     constexpr int GPW = 64 / G;                    // queries per wavefront
-    static_assert(U == 0 || ((G == 8 || G == 16) && !CENSUS), "prefix-form walk: 8 or 16 lanes per query, no census");
+    static_assert(U == 0 || ((G == 4 || G == 8 || G == 16) && !CENSUS), "prefix-form walk: 4, 8 or 16 lanes per query, no census");
     __shared__ uint2 s_bucket[WPB][GPW][U > 0 ? 32 : 28];   // LDS-staged non-empty buckets {start, count}
 
     if (a.gate != nullptr && a.gate->skip != 0u) return;      // a pre-enqueued pass the host called off
@@ -512,9 +512,10 @@ static void launch_knn27_gu(const KnnArgs& a, hipStream_t s, KernelTimer t) {
 }
 template <int G>
 static void launch_knn27_g(const KnnArgs& a, hipStream_t s, KernelTimer t) {
-    if constexpr (G == 8 || G == 16) {
+    if constexpr (G == 4 || G == 8 || G == 16) {
         // the prefix-form walk with U candidates per lane in flight (KnnArgs.walk; the census keeps the plain walk)
         if (a.cand_total == nullptr && a.walk == 1) { launch_knn27_gu<G, 1>(a, s, t); return; }
+        if (a.cand_total == nullptr && a.walk == 2) { launch_knn27_gu<G, 2>(a, s, t); return; }
         if (a.cand_total == nullptr && a.walk == 4) { launch_knn27_gu<G, 4>(a, s, t); return; }
     }
     const int qpb = 4 * (64 / G);                  // queries per 256-thread workgroup

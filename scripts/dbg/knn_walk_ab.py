@@ -8,10 +8,12 @@ import numpy as np
 from better_fastlio2_amd import capi, synth
 
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+LANES = [int(v) for v in os.environ.get("AB_LANES", "8,16").split(",")]
+WALKS = [int(v) for v in os.environ.get("AB_WALKS", "0,1,4").split(",")]
 if which == "c3":
     nm, sizes, kind = 2_000_000, [24_000], "hap"
 else:
-    nm, sizes, kind = 5_000_000, [100_000, 50_000, 24_000, 8_600, 3_000], "kitti64"
+    nm, sizes, kind = 5_000_000, [int(v) for v in os.environ.get("AB_SIZES", "100000,50000,24000,8600,3000").split(",")], "kitti64"
 world = synth.make_world(nm, 0.2)
 ctx = capi.LioContext(0.2, max_scan_points=max(sizes), max_map_points=nm + 1000)
 ctx.map_build(world.points)
@@ -23,8 +25,8 @@ for nq in sizes:
         scans.append((sc, synth.state_vector(ps, rt, sc.off_R, sc.off_T)))
     best = {}
     for rep in range(2):
-        for lanes in (8, 16):
-            for walk in (0, 1, 4):
+        for lanes in LANES:
+            for walk in WALKS:
                 ctx.debug_set("lanes_per_query", lanes)
                 ctx.debug_set("knn_walk", walk)
                 ctx.profile_enable(only=[capi.PROF_KNN, capi.PROF_KNN_HINT]); ctx.profile_reset()

@@ -6,6 +6,7 @@ HBM-side bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / W
 reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated.
 """
 import collections
+import re
 import csv
 import datetime
 import glob
@@ -21,12 +22,16 @@ import bench  # noqa: E402  (knn_source_hash)
 def main():
     root = sys.argv[1]
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    shapes = collections.defaultdict(set)
     for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "knn27_kernel" not in k:
                 continue
-            variant = "hinted_search" if "true>" in k.replace(" ", "") and k.replace(" ", "").endswith("false,true>(lio::KnnArgs)") else "first_search"
+            # knn27_kernel<G, CENSUS, HINT[, U]>: the third template argument says which search it is
+            m = re.search(r"knn27_kernel<(\d+),(true|false),(true|false)(?:,(\d+))?>", k.replace(" ", ""))
+            variant = "hinted_search" if m and m.group(3) == "true" else "first_search"
+            shapes[variant].add(k.replace(" ", "").split("(")[0].split("lio::")[-1])
             acc[variant][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
     for variant, counters in acc.items():
@@ -40,7 +45,8 @@ def main():
             e["instructions_per_wavefront"] = {c: avg[c] / avg["SQ_WAVES"] for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if c in avg}
         out[variant] = e
     first = out.get("first_search", {})
-    doc = {"c2": {"kernel": "knn27_kernel<8,false,false> (first search of a scan, transform fused)",
+    doc = {"c2": {"kernel": " / ".join(sorted(shapes.get("first_search", []))) + " (first search of a scan, transform fused); bounded re-search: "
+                            + " / ".join(sorted(shapes.get("hinted_search", []))),
                   "kernel_source_sha16": bench.knn_source_hash(), "date": datetime.date.today().isoformat(),
                   "launches_averaged": first.get("launches_averaged", 0),
                   "hbm_bytes_per_launch": first.get("hbm_bytes_per_launch"),

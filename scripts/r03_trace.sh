@@ -39,7 +39,7 @@ print(open('$O/emulated_timeline.txt').read()[-6000:])
 first_stage = next(i for i, n in enumerate(names) if 'replicate_stage_kernel' in n)
 b = max(i for i in range(first_stage) if 'cell_apply_kernel' in names[i])
 a = max(i for i in range(b) if 'map_incremental_lists_kernel' in names[i])
-while a > 0 and 'knn27_kernel<8, false, false>' not in names[a]: a -= 1
+while a > 0 and not ('knn27_kernel<' in names[a] and ', false, false' in names[a]): a -= 1
 t0 = int(rows[a]['Start_Timestamp']); prev_end = t0
 out = open('$O/node_loop_timeline.txt', 'w')
 for r in rows[a:b + 2]:

@@ -65,9 +65,9 @@ def test_nearest_search_bit_exact(gpu_capi, oracle, small_case, lanes):
     ctx.close()
 
 
-@pytest.mark.parametrize("lanes", [8, 16])
+@pytest.mark.parametrize("lanes", [4, 8, 16])
 def test_candidate_walk_variants_are_bit_identical(gpu_capi, oracle, small_case, lanes):
-    """knn27_kernel's candidate walk in prefix form with one / four candidates per lane in flight (KnnArgs.walk, lio_knn.hip)
+    """knn27_kernel's candidate walk in prefix form with one / two / four candidates per lane in flight (KnnArgs.walk, lio_knn.hip)
     sees the same candidates as the plain walk: neighbours, distances, counts, the unproven list (hence the walk's results)
     and the sums of a search pass and of the bounded re-search at a moved pose are the same bits -- and the oracle's."""
     q = _hard_queries(small_case, oracle)
@@ -78,7 +78,7 @@ def test_candidate_walk_variants_are_bit_identical(gpu_capi, oracle, small_case,
     ctx = gpu_capi.LioContext(0.2, max_scan_points=len(q), max_map_points=400_000, lanes_per_query=lanes)
     ctx.map_build(small_case["world"].points)
     res = {}
-    for walk in (0, 1, 4):
+    for walk in (0, 1, 2, 4):
         ctx.debug_set("knn_walk", walk)
         gx, gd, gc = ctx.nearest_search(q)
         ctx.scan_set(q)
@@ -89,7 +89,7 @@ def test_candidate_walk_variants_are_bit_identical(gpu_capi, oracle, small_case,
         res[walk] = (gx, gd, gc, a, n1, b, n2)
     ctx.close()
     assert np.array_equal(res[0][2], oc) and bits_equal(res[0][1], od)
-    for walk in (1, 4):
+    for walk in (1, 2, 4):
         r, z = res[walk], res[0]
         assert bits_equal(r[0], z[0]) and bits_equal(r[1], z[1]) and np.array_equal(r[2], z[2])
         for k in (3, 5):
