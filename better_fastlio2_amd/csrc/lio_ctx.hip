@@ -278,28 +278,21 @@ bool is_pow2f(float v) {
     int e;
     return v > 0.0f && std::frexp(v, &e) == 0.5f;
 }
-// Candidate walk of knn27_kernel (KnnArgs.walk, lio_knn.hip).  Measured on MI355X (scripts/dbg/knn_walk_ab.py, 5 M-point map, scans of
-// 3 k ... 100 k points, first / bounded search; profiles/r03z_walk_ab.log): the prefix-form list with four candidates per lane in
-// flight wins the FIRST search of a scan at every size (100 k: 23.1 -> 22.1 us, 24 k: 11.0 -> 10.1, 8.6 k: 8.2 -> 7.9); the bounded
-// re-search streams about half the candidates and gains nothing from it.  Scans beyond the fused transform's range (C5) keep the
-// plain walk (not measured there).
-int auto_walk(int nq, int lanes, bool hint) {
-    if (hint || nq > 262144) return 0;
+// Shape of a knn27_kernel launch: lanes per query and candidate walk (KnnArgs.walk, lio_knn.hip).  Measured on MI355X
+// (scripts/dbg/knn_walk_ab.py: 5 M-point map, scans of 3 k ... 100 k points, first search at the prior and bounded re-search at the
+// converged pose; profiles/r03z_walk_ab.log).  The kernel is bound by instruction issue when the launch fills the GPU and by its
+// chain of dependent round trips when it does not:
+//   lanes  8 per query from ~22 k queries up (C2, C5; at 24 k 10.6 vs 11.5 us), 16 below (8.6 k: 8.2 vs 8.8), 32 for very small
+//          scans; 4 lanes lose at every size once the second search is taken at a realistic pose (100 k: 22.7 / 21.7 vs 22.1 / 22.2
+//          in the script, and 24.7 vs 23.3 us for the bounded search inside bench.py's drive)
+//   walk   the prefix-form list with four candidates per lane in flight wins both searches at every size (100 k: 23.3 -> 22.1 and
+//          22.6 -> 22.2 us; 24 k: 11.6 -> 10.6 and 12.1 -> 11.0; 8.6 k: 8.7 -> 8.2 and 9.4 -> 8.9).  Scans beyond the fused
+//          transform's range (C5) keep the plain walk: not measured there.
+int auto_walk(int nq, int lanes) {
+    if (nq > 262144) return 0;
     return (lanes == 4 || lanes == 8 || lanes == 16) ? 4 : 0;
 }
-int auto_lanes(int nq, bool hint) {
-    // measured on MI355X (the same script): the kernel is bound by instruction issue when the launch fills the GPU and by its
-    // chain of dependent round trips when it does not.  First search: 8 lanes per query from ~22 k queries up (C2, C5; at 24 k
-    // 10.1 vs 10.7 us), 16 below (8.6 k: 7.9 vs 8.6), 32 for very small scans.  The bounded re-search has about half the
-    // candidates, so the per-query fixed work (directory look-up, merge, results) weighs more: FOUR lanes per query from ~60 k
-    // queries up (100 k: 20.2 vs 21.0 us, 70 k: 16.4 vs 17.5; 50 k: 14.3 vs 13.9 the other way), 8 from ~14 k, 16 below.
-    if (hint) {
-        if (nq > 262144) return 8;
-        if (nq >= 60000) return 4;
-        if (nq >= 14000) return 8;
-        if (nq >= 2000) return 16;
-        return 32;
-    }
+int auto_lanes(int nq) {
     if (nq >= 22000) return 8;
     if (nq >= 2000) return 16;
     return 32;
@@ -918,8 +911,8 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.use_hint = use_hint ? 1 : 0;
     ka.tune = c->dbg_knn_tune;
     ka.gate = gate;
-    const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq, use_hint);
-    ka.walk = (lanes == 4 || lanes == 8 || lanes == 16) ? (c->dbg_knn_walk >= 0 ? c->dbg_knn_walk : auto_walk(nq, lanes, use_hint)) : 0;
+    const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
+    ka.walk = (lanes == 4 || lanes == 8 || lanes == 16) ? (c->dbg_knn_walk >= 0 ? c->dbg_knn_walk : auto_walk(nq, lanes)) : 0;
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
     if (walk_now) HIPCHK(c, launch_knn_tree(tree_args(c, nq, stride, nbr, cnt, ulist, useeds), s, prof_timer(c, LIO_PROF_FALLBACK)));
     return LIO_OK;

@@ -22,7 +22,8 @@ for nq in sizes:
     for k in range(4):
         sc = synth.make_scan(world, nq, kind=kind, seed=synth.SEED + 1 + 17 * k, pos=(3.1 + 0.9 * k, -2.2 + 0.4 * k, 0.0), rpy=(0.004, -0.006, 0.52 + 0.05 * k))
         ps, rt = synth.perturb_state(sc, seed=synth.SEED + 2 + 7 * k)
-        scans.append((sc, synth.state_vector(ps, rt, sc.off_R, sc.off_T)))
+        # first search at the prior (0.1 m / 0.5 deg off), bounded re-search at the pose the update converges to (~ the truth)
+        scans.append((sc, synth.state_vector(ps, rt, sc.off_R, sc.off_T), synth.state_vector(sc.pos, sc.rot, sc.off_R, sc.off_T)))
     best = {}
     for rep in range(2):
         for lanes in LANES:
@@ -31,10 +32,9 @@ for nq in sizes:
                 ctx.debug_set("knn_walk", walk)
                 ctx.profile_enable(only=[capi.PROF_KNN, capi.PROF_KNN_HINT]); ctx.profile_reset()
                 for it in range(12):
-                    sc, st = scans[it % 4]
+                    sc, st, st2 = scans[it % 4]
                     ctx.scan_set(sc.body)
                     ctx.measure(st, True, False)
-                    st2 = st.copy(); st2[:3] += [0.03, -0.05, 0.01]
                     ctx.measure(st2, True, False)
                 p = ctx.profile()
                 f = p["knn27"]["total_ms"] / p["knn27"]["launches"] * 1e3
