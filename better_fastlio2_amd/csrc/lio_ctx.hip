@@ -203,7 +203,12 @@ struct lio_ctx {
     uint64_t *d_raw_keys = nullptr, *d_raw_keys2 = nullptr, *d_leaf_keys = nullptr;
     uint32_t *d_raw_order = nullptr, *d_raw_order2 = nullptr, *d_leaf_count = nullptr, *d_leaf_start = nullptr;
     double* d_imu_poses = nullptr;             // up to 512 Pose6D records (22 doubles each)
-    VoxelGridDev* d_vox = nullptr;
+    VoxelGridDev* d_vox = nullptr;             // two records, used alternately: the centroid kernel of a call clears the other one
+    int vox_cur = 0;
+    bool vox_clean[2] = {false, false};
+    bool vox_saw_unsorted = false;             // the previous time-keyed sweep had a point earlier than its predecessor
+    int vox_passes_guess = 3;                  // 8-bit splits the previous sweep's leaf index needed (22-24 bits at 0.5 m leaves)
+    long long n_voxel_redone = 0;              // sweeps filtered twice (a wrong prediction)
 
     // batch buffers of lio_map_add
     size_t cap_add = 0;
@@ -243,6 +248,8 @@ struct lio_ctx {
     bool census = false;                       // count C(q) in the k-NN kernel (one atomic per wavefront)
     int dbg_force_timeout = 0;                 // lio_debug_set("force_reduction_timeout")
     int dbg_knn_tune = 0;                      // lio_debug_set("knn_tune")
+    long long n_voxel_fast = 0;                // voxel-filter calls that took the compact-key path (lio_debug_get("voxel_fast_runs"))
+    int dbg_voxel_fast = 1;                    // lio_debug_set("voxel_fast_path"): the compact-key LSD sort of time-ordered sweeps (A/B switch)
     int dbg_knn_walk = -1;                     // lio_debug_set("knn_walk") / LIO_KNN_WALK: -1 = by scan size (auto_walk), 0 / 1 / 2 / 4 = KnnArgs.walk
     int dbg_library_sort = 0;                  // lio_debug_set("library_sort"): rocPRIM for every sort / compaction (A/B switch)
     int dbg_stamps = 0;                        // lio_debug_set("stamps"): the last workgroup takes wall_clock64 stamps (lio_debug_stamps)
@@ -1935,7 +1942,7 @@ static bool is_pinned_host(const void* p) {
 }
 static int ensure_raw_buffers(lio_ctx* c, size_t n) {
     if (!c->d_imu_poses) HIPCHK(c, hipMalloc((void**)&c->d_imu_poses, 512 * 22 * sizeof(double)));
-    if (!c->d_vox) HIPCHK(c, hipMalloc((void**)&c->d_vox, sizeof(VoxelGridDev)));
+    if (!c->d_vox) HIPCHK(c, hipMalloc((void**)&c->d_vox, 2 * sizeof(VoxelGridDev)));
     if (n <= c->cap_raw) return LIO_OK;
     void* old[] = {c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start};
@@ -2071,22 +2078,67 @@ int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
     if (n == 0) return scan_reset(c, 0);
     // One pass over the stream, one read-back at the end: getMinMax3D, min_b_/divb_mul_, the leaf index of every
     // point, a stable sort by leaf, the run heads and the centroids all stay on the device (VoxelGridDev).
-    VoxelGridDev* vox = c->d_vox;
-    HIPCHK(c, hipMemsetAsync(vox, 0, sizeof(VoxelGridDev), s));
-    HIPCHK(c, launch_minmax(c->d_undist, n, vox, s));
-    HIPCHK(c, launch_voxel_params(vox, 1.0f / leaf_size, s));           // inverse_leaf_size_ = 1 / leaf_size_
-    HIPCHK(c, launch_voxel_index(c->d_undist, n, vox, c->raw_time_keyed && !c->undist_sorted, c->d_raw_keys, c->d_raw_order, s));
-    HIPCHK(c, sort_pairs_any(c, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s, &vox->summary[3]));
-    if (compact_small(c, (size_t)n))
-        HIPCHK(c, launch_run_heads(c->d_raw_keys2, (uint32_t)n, 32, c->d_leaf_start, &vox->n_leaves, c->d_cagg, next_compact_stamp(c), &vox->summary[3], s));
-    else
-        HIPCHK(c, select_run_heads_u64(c->d_temp, c->temp_bytes, c->d_raw_keys2, (size_t)n, c->d_leaf_start, &vox->n_leaves, s));
+    const bool time_minor = c->raw_time_keyed && !c->undist_sorted;     // the cloud is not KNOWN to be in time order
+    // A sweep between the single-launch sort's range and the group sort's (16 k ... 256 k points: every real one) whose points
+    // already come in time order -- most drivers deliver them so -- needs no time key: a STABLE sort by the leaf index alone is
+    // the sort by (leaf, time, input order).  That key has ~22 bits instead of 64: three stable 8-bit splits (lio_gsort.hip, LSD
+    // form) instead of the library's ten merge launches.  Whether THIS sweep is in order, and how wide its leaf index is, only
+    // the device knows (minmax_kernel checks the order while it reads the points): the host PREDICTS both from the previous sweep,
+    // enqueues the whole filter without waiting, and finds the verdict in the read-back at the end; a wrong prediction (the first
+    // out-of-order sweep of a driver, a sweep whose extent needs another digit) is followed by the filter on the general path.
+    const bool may_compact = !c->dbg_library_sort && c->dbg_voxel_fast && (size_t)n > SORT_MAX_ITEMS && (uint32_t)n <= GSORT_MAX;
+    bool compact = may_compact && !(time_minor && c->vox_saw_unsorted);
     const uint32_t max_leaves = (uint32_t)n < (uint32_t)c->cap_q + 1u ? (uint32_t)n : (uint32_t)c->cap_q + 1u;
-    HIPCHK(c, launch_centroids(c->d_undist, c->d_raw_order2, c->d_raw_keys2, c->d_leaf_start, vox, (uint32_t)n, max_leaves,
-                               (uint32_t)c->cap_q, c->d_body, s));
-    uint32_t summary[4] = {0, 0, 0, 0};
-    HIPCHK(c, read_back(c, summary, vox->summary, sizeof(summary)));
-    if (summary[3] != 0u) return c->fail(LIO_ERR_HIP, "lio_scan_voxel_filter", "a bounded wait of a sort / compaction kernel ran out");
+    uint32_t summary[6] = {0, 0, 0, 0, 0, 0};
+    for (int attempt = 0; ; ++attempt) {
+        VoxelGridDev* vox = c->d_vox + c->vox_cur;
+        VoxelGridDev* vox_next = c->d_vox + (c->vox_cur ^ 1);
+        if (!c->vox_clean[c->vox_cur]) HIPCHK(c, hipMemsetAsync(vox, 0, sizeof(VoxelGridDev), s));
+        c->vox_clean[c->vox_cur] = false;
+        c->vox_clean[c->vox_cur ^ 1] = false;                           // (until the centroid launch below is known to be enqueued)
+        // inverse_leaf_size_ = 1 / leaf_size_; the order of the points is checked whenever it matters for the next prediction
+        HIPCHK(c, launch_minmax_params(c->d_undist, n, vox, 1.0f / leaf_size, may_compact && time_minor, s));
+        int passes = 0;
+        if (compact) {
+            passes = c->vox_passes_guess;
+            ++c->n_voxel_fast;
+            if (c->gsort_seq + (uint32_t)passes < c->gsort_seq || c->gsort_seq + (uint32_t)passes == 0xffffffffu) {   // (stamp wrap-around: as run_sort)
+                HIPCHK(c, hipMemsetAsync(c->d_gagg, 0, GSORT_AGG_WORDS * sizeof(unsigned long long), s));
+                c->gsort_seq = 0u;
+            }
+            HIPCHK(c, launch_voxel_index_compact(c->d_undist, n, vox, c->d_raw_keys, s));
+            GsortLsdArgs g{};
+            g.keys = c->d_raw_keys; g.n = (uint32_t)n; g.kb = 8 * passes; g.passes = passes; g.keys_out = c->d_raw_keys2; g.vals_out = c->d_raw_order2;
+            g.part = c->d_leaf_keys; g.part2 = reinterpret_cast<uint64_t*>(c->d_leafpts);  // (scratch of this call: 8 and 16 bytes per point)
+            g.hist = &vox->hist[0][0]; g.agg = c->d_gagg; g.stamp0 = c->gsort_seq + 1u; g.err = &vox->summary[3];
+            c->gsort_seq += (uint32_t)passes;
+            HIPCHK(c, launch_gsort_lsd(g, s));
+            HIPCHK(c, launch_run_heads(c->d_raw_keys2, (uint32_t)n, 0, c->d_leaf_start, &vox->n_leaves, c->d_cagg, next_compact_stamp(c), &vox->summary[3], s));
+        } else {
+            HIPCHK(c, launch_voxel_index(c->d_undist, n, vox, time_minor, c->d_raw_keys, c->d_raw_order, s));
+            HIPCHK(c, sort_pairs_any(c, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s, &vox->summary[3]));
+            if (compact_small(c, (size_t)n))
+                HIPCHK(c, launch_run_heads(c->d_raw_keys2, (uint32_t)n, 32, c->d_leaf_start, &vox->n_leaves, c->d_cagg, next_compact_stamp(c), &vox->summary[3], s));
+            else
+                HIPCHK(c, select_run_heads_u64(c->d_temp, c->temp_bytes, c->d_raw_keys2, (size_t)n, c->d_leaf_start, &vox->n_leaves, s));
+        }
+        HIPCHK(c, launch_centroids(c->d_undist, c->d_raw_order2, c->d_raw_keys2, c->d_leaf_start, vox, (uint32_t)n, max_leaves,
+                                   (uint32_t)c->cap_q, c->d_body, s, compact, vox_next));
+        c->vox_clean[c->vox_cur ^ 1] = true;                            // (cleared by the centroid kernel)
+        c->vox_cur ^= 1;
+        static_assert(offsetof(VoxelGridDev, probe) == offsetof(VoxelGridDev, summary) + 4 * sizeof(uint32_t), "summary and probe are read together");
+        HIPCHK(c, read_back(c, summary, vox->summary, sizeof(summary)));
+        if (summary[3] != 0u) return c->fail(LIO_ERR_HIP, "lio_scan_voxel_filter", "a bounded wait of a sort / compaction kernel ran out");
+        if (may_compact && time_minor) c->vox_saw_unsorted = summary[4] != 0u;            // what the next sweep is taken for
+        if (!compact || summary[2] != 0u) break;                        // (an empty / overflowing grid: nothing was sorted, nothing to redo)
+        const int need = ((int)summary[5] + 7) / 8;
+        const bool wrong = (time_minor && summary[4] != 0u) || need > passes;
+        if (need >= 1 && need <= 4) c->vox_passes_guess = need;
+        if (!wrong) break;
+        ++c->n_voxel_redone;
+        if (attempt >= 2) return c->fail(LIO_ERR_HIP, "lio_scan_voxel_filter", "the sort prediction failed three times on one sweep");
+        compact = !(time_minor && summary[4] != 0u);                    // out of order: the general path; too few digits: again with `need`
+    }
     if (summary[2] & VOX_OVERFLOW)
         return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "leaf size too small for the extent of the scan (index overflow, as in PCL)");
     if (summary[2] & VOX_EMPTY) return scan_reset(c, 0);                // no finite point
@@ -2488,6 +2540,7 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "library_sort") == 0) { c->dbg_library_sort = value != 0; return LIO_OK; }
     if (std::strcmp(key, "stamps") == 0) { c->dbg_stamps = value != 0; return LIO_OK; }
     if (std::strcmp(key, "knn_tune") == 0) { c->dbg_knn_tune = (int)value; return LIO_OK; }
+    if (std::strcmp(key, "voxel_fast_path") == 0) { c->dbg_voxel_fast = value != 0; return LIO_OK; }
     if (std::strcmp(key, "knn_walk") == 0) {
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4) return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "knn_walk: -1, 0, 1, 2 or 4");
         c->dbg_knn_walk = (int)value;
@@ -2519,6 +2572,8 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "gate_released") == 0) { *value = c->n_gate_released; return LIO_OK; }
     if (std::strcmp(key, "gate_called_off") == 0) { *value = c->n_gate_called_off; return LIO_OK; }
     if (std::strcmp(key, "retired_budget") == 0) { *value = (long long)retired_slot_budget(c); return LIO_OK; }
+    if (std::strcmp(key, "voxel_fast_runs") == 0) { *value = c->n_voxel_fast; return LIO_OK; }
+    if (std::strcmp(key, "voxel_redone") == 0) { *value = c->n_voxel_redone; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_get", "unknown key");
 }
 int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {

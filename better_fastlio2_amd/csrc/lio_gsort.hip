@@ -252,6 +252,125 @@ hipError_t launch_gsort_large(const GsortArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- LSD form: a stable sort of up to GSORT_MAX records as ceil(kb / 8) stable splits by one 8-bit digit each, least significant
+// digit first -- every pass is the partition kernel above with the digit position as a parameter.  For keys whose DISTRIBUTION is
+// skewed (the voxel filter's leaf indices: the ground layer of a sweep fills a handful of the 256 top-digit buckets with tens of
+// thousands of records each, far beyond what gsort_bucket_kernel sorts inside LDS) the MSD form above degenerates; this one does
+// not care.  The caller's key kernel accumulates the histograms of ALL digit positions (hist[pass][256], zero on entry).
+struct LsdPassArgs {
+    const uint64_t* keys;           // first pass: the keys (< 2^kb); the record becomes key << GSORT_INDEX_BITS | input position
+    const uint64_t* in;             // later passes: records
+    uint64_t*       out;            // records (every pass but the last)
+    uint64_t*       keys_out;       // last pass: sorted keys ...
+    uint32_t*       vals_out;       // ... and the input positions in sorted order
+    uint32_t        n;
+    int             shift;          // digit = (key >> shift) & 255
+    const uint32_t* hist;           // [256] of this digit
+    unsigned long long* agg;
+    uint32_t        stamp;
+    uint32_t*       err;
+};
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(512) void gsort_lsd_pass_kernel(LsdPassArgs a) {
+    __shared__ uint32_t s_wcnt[8][256];
+    __shared__ uint32_t s_base[256];
+    __shared__ uint32_t s_half[2][256];
+    __shared__ uint32_t s_wtot[4];
+    __shared__ uint32_t s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = a.n;
+    for (int x = tid; x < 8 * 256; x += 512) (&s_wcnt[0][0])[x] = 0u;
+    if (tid == 0) s_bad = 0u;
+    __syncthreads();
+    const uint32_t i0 = blockIdx.x * GS_TILE + (uint32_t)wave * 256u;
+    u64 rec[4];
+    uint32_t off[4], dg[4];
+    bool vd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = i0 + (uint32_t)k * 64u + (uint32_t)lane;
+        vd[k] = i < n;
+        if (FIRST) rec[k] = ((vd[k] ? (u64)a.keys[i] : 0ull) << GS_IB) | (u64)i;
+        else rec[k] = vd[k] ? (u64)a.in[i] : 0ull;
+        dg[k] = (uint32_t)((rec[k] >> GS_IB) >> a.shift) & 255u;
+        const u64 peers = gs_match(dg[k], vd[k], 8);
+        const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        const int leader = vd[k] ? __ffsll((long long)peers) - 1 : lane;
+        uint32_t old = 0u;
+        if (vd[k] && lane == leader) {
+            old = s_wcnt[wave][dg[k]];
+            s_wcnt[wave][dg[k]] = old + (uint32_t)__popcll(peers);
+        }
+        gs_wave_sync();
+        old = (uint32_t)__shfl((int)old, leader, 64);
+        off[k] = old + rank;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t run = 0u;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { const uint32_t t = s_wcnt[w][tid]; s_wcnt[w][tid] = run; run += t; }
+        __hip_atomic_store(a.agg + (size_t)blockIdx.x * 256u + (uint32_t)tid, (u64)run | ((u64)a.stamp << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    {
+        const uint32_t d = (uint32_t)tid & 255u, h = (uint32_t)tid >> 8, b = blockIdx.x;
+        uint32_t acc = 0u;
+        bool bad = false;
+        for (uint32_t p0 = h; p0 < b; p0 += 16u) {
+            u64 v[8];
+            unsigned spins = 0;
+            bool ok;
+            do {
+                ok = true;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t p = p0 + 2u * (uint32_t)u;
+                    v[u] = (u64)a.stamp << 32;
+                    if (p < b) v[u] = __hip_atomic_load(a.agg + (size_t)p * 256u + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (uint32_t)(v[u] >> 32) == a.stamp;
+                }
+            } while (!ok && ++spins < GS_SPIN_LIMIT);
+            bad = bad || !ok;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (uint32_t)v[u];
+        }
+        s_half[h][d] = acc;
+        if (bad) s_bad = 1u;
+    }
+    const uint32_t hv = tid < 256 ? a.hist[tid] : 0u;
+    const uint32_t gbase = gs_scan256(hv, s_wtot);
+    if (tid < 256) s_base[tid] = gbase + s_half[0][tid] + s_half[1][tid];
+    __syncthreads();
+    const bool ok = s_bad == 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!(vd[k] && ok)) continue;
+        const uint32_t pos = s_base[dg[k]] + s_wcnt[wave][dg[k]] + off[k];
+        if (LAST) { a.keys_out[pos] = rec[k] >> GS_IB; a.vals_out[pos] = (uint32_t)(rec[k] & GS_IMASK); }
+        else a.out[pos] = rec[k];
+    }
+    if (!ok && tid == 0) atomicOr(a.err, 1u);
+}
+
+hipError_t launch_gsort_lsd(const GsortLsdArgs& g, hipStream_t s) {
+    if (g.n == 0) return hipSuccess;
+    const int passes = g.passes > 0 ? g.passes : (g.kb + 7) / 8;
+    if (g.n > GSORT_MAX || g.kb + GS_IB > 64 || passes < 1 || passes > 4) return hipErrorInvalidValue;
+    const dim3 grid((g.n + GS_TILE - 1u) / GS_TILE), block(512);
+    uint64_t* buf[2] = {g.part, g.part2};
+    for (int p = 0; p < passes; ++p) {
+        LsdPassArgs a{};
+        a.keys = g.keys; a.in = p > 0 ? buf[(p - 1) & 1] : nullptr; a.out = buf[p & 1]; a.keys_out = g.keys_out; a.vals_out = g.vals_out;
+        a.n = g.n; a.shift = 8 * p; a.hist = g.hist + 256 * p; a.agg = g.agg; a.stamp = g.stamp0 + (uint32_t)p; a.err = g.err;
+        const bool first = p == 0, last = p == passes - 1;
+        if (first && last)  hipLaunchKernelGGL((gsort_lsd_pass_kernel<true, true>), grid, block, 0, s, a);
+        else if (first)     hipLaunchKernelGGL((gsort_lsd_pass_kernel<true, false>), grid, block, 0, s, a);
+        else if (last)      hipLaunchKernelGGL((gsort_lsd_pass_kernel<false, true>), grid, block, 0, s, a);
+        else                hipLaunchKernelGGL((gsort_lsd_pass_kernel<false, false>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
 // histogram of the partition digit for callers whose key generation cannot accumulate it (fallbacks, tests)
 __global__ __launch_bounds__(256) void gsort_hist_kernel(const uint64_t* keys, uint32_t n, const uint32_t* n_dev, uint32_t n_dev_add, int kb, uint32_t* hist) {
     __shared__ uint32_t s_hist[256];

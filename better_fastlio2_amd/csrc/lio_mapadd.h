@@ -256,6 +256,23 @@ struct GsortArgs {
     uint32_t        stamp;
     uint32_t*       err;
 };
+// LSD form (lio_gsort.hip): ceil(kb / 8) <= 4 stable splits, least significant digit first; for skewed key distributions
+struct GsortLsdArgs {
+    const uint64_t* keys;           // [n] keys (< 2^kb), input order = the order inside equal keys
+    uint32_t        n;              // <= GSORT_MAX
+    int             kb;             // <= 32
+    int             passes;         // 0: ceil(kb / 8); otherwise that many 8-bit splits (>= ceil(kb / 8): a split by a digit
+                                    // that is zero in every key changes nothing)
+    uint64_t*       keys_out;       // [n] sorted keys
+    uint32_t*       vals_out;       // [n] input positions in sorted order
+    uint64_t*       part;           // [n] two record buffers
+    uint64_t*       part2;
+    const uint32_t* hist;           // [passes][256] digit histograms of the keys (the key kernel accumulates them)
+    unsigned long long* agg;        // [GSORT_AGG_WORDS]
+    uint32_t        stamp0;         // pass p is stamped stamp0 + p (none of them 0)
+    uint32_t*       err;
+};
+hipError_t launch_gsort_lsd(const GsortLsdArgs& g, hipStream_t s);
 hipError_t launch_gsort_large(const GsortArgs& a, hipStream_t s);
 hipError_t launch_gsort_hist(const uint64_t* keys, uint32_t n, const uint32_t* n_dev, uint32_t n_dev_add, int kb, uint32_t* hist, hipStream_t s);
 

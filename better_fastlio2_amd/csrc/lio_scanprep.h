@@ -18,6 +18,11 @@ struct VoxelGridDev {
     uint32_t flags;                 // VOX_EMPTY | VOX_OVERFLOW
     uint32_t n_leaves;              // runs of equal leaf index (the run of dropped points included)
     uint32_t summary[4];            // {n_leaves, 1 if the last run is the dropped one, flags, != 0: a sort / compaction wait ran out}
+    // the fast path of time-ordered sweeps (lio_scan_voxel_filter): what the host asks for before it picks the sort ...
+    uint32_t probe[2];              // {1: some point is earlier than its predecessor, bits of the leaf index (2^bits > number of leaves)}
+    uint32_t arrive;                // workgroups of minmax_kernel that have delivered their extremes (the last one derives `g`)
+    // ... and the digit histograms of the compact leaf keys for the LSD sort (lio_gsort.hip), zeroed with the record
+    uint32_t hist[4][256];
 };
 constexpr uint32_t VOX_EMPTY = 1u, VOX_OVERFLOW = 2u;
 
@@ -25,13 +30,21 @@ constexpr uint32_t VOX_EMPTY = 1u, VOX_OVERFLOW = 2u;
 hipError_t launch_time_keys(const float4* pts, int n, uint64_t* keys, uint32_t* order, hipStream_t s);
 hipError_t launch_undistort(const float4* raw, int n, const double* poses, int n_poses, const Pose14& end, float4* out,
                             hipStream_t s);
-hipError_t launch_minmax(const float4* pts, int n, VoxelGridDev* vox, hipStream_t s);
-hipError_t launch_voxel_params(VoxelGridDev* vox, float inv_leaf, hipStream_t s);
+// getMinMax3D and, by the last workgroup to arrive, min_b_ / divb_mul_ / the width of the leaf index (vox->g, flags, probe[1]);
+// check_time_order: also sets vox->probe[0] when some point's time key is below its predecessor's
+hipError_t launch_minmax_params(const float4* pts, int n, VoxelGridDev* vox, float inv_leaf, bool check_time_order, hipStream_t s);
 hipError_t launch_voxel_index(const float4* pts, int n, const VoxelGridDev* vox, bool time_minor, uint64_t* keys, uint32_t* order,
                               hipStream_t s);
+// the compact form for clouds already in time order: key = leaf index (< 2^leaf_bits; non-finite points: 2^leaf_bits - 1, beyond
+// every leaf), digit histograms of the keys into vox->hist; a stable sort by this key is the sort by (leaf, time, input order)
+hipError_t launch_voxel_index_compact(const float4* pts, int n, VoxelGridDev* vox, uint64_t* keys, hipStream_t s);
 // centroids of the runs [leaf_start[l], leaf_start[l + 1]) of the leaf-sorted order, written to out[l] (l < cap_out);
 // launched for at most max_leaves runs, the run count is read from vox->n_leaves
+// zero_for_next_call: another record, cleared here for the next call (no memset launch in front of it);
+// compact_keys: the keys are launch_voxel_index_compact's (the run of dropped points carries 2^leaf_bits - 1 instead of a leaf index
+// of all ones in the upper half)
 hipError_t launch_centroids(const float4* pts, const uint32_t* order, const uint64_t* sorted_keys, const uint32_t* leaf_start,
-                            VoxelGridDev* vox, uint32_t n, uint32_t max_leaves, uint32_t cap_out, float4* out, hipStream_t s);
+                            VoxelGridDev* vox, uint32_t n, uint32_t max_leaves, uint32_t cap_out, float4* out, hipStream_t s,
+                            bool compact_keys = false, VoxelGridDev* zero_for_next_call = nullptr);
 
 }  // namespace lio

@@ -99,11 +99,14 @@ __global__ __launch_bounds__(256) void time_keys_kernel(const float4* pts, int n
 
 // getMinMax3D: per-workgroup reduction in LDS, then six atomics per workgroup on unsigned order-preserving images
 // (min as the maximum of the complement, so that a zeroed record is the neutral element of all six)
-__global__ __launch_bounds__(256) void minmax_kernel(const float4* pts, int n, VoxelGridDev* vox) {
+__device__ void voxel_params(VoxelGridDev* vox, const uint32_t mm[6], float inv_leaf);
+__global__ __launch_bounds__(256) void minmax_kernel(const float4* pts, int n, VoxelGridDev* vox, float inv_leaf, bool check_time_order) {
     __shared__ uint32_t s_mm[4][6];
     uint32_t m[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    bool earlier = false;                                               // some point lies before its predecessor in time
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = pts[i];
+        if (check_time_order && i > 0) earlier = earlier || float_ordered_u(p.w) < float_ordered_u(pts[i - 1].w);
         if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) continue;
         const uint32_t v[3] = {float_ordered_u(p.x), float_ordered_u(p.y), float_ordered_u(p.z)};
 #pragma unroll
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float4* pts, int n, V
         for (int o = 32; o > 0; o >>= 1) m[a] = max(m[a], (uint32_t)__shfl_xor((int)m[a], o, 64));
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (check_time_order && __any(earlier) && lane == 0) atomicOr(&vox->probe[0], 1u);
     if (lane == 0) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) s_mm[wave][a] = m[a];
@@ -124,18 +128,33 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float4* pts, int n, V
         const uint32_t v = max(max(s_mm[0][threadIdx.x], s_mm[1][threadIdx.x]), max(s_mm[2][threadIdx.x], s_mm[3][threadIdx.x]));
         if (v != 0u) atomicMax(&vox->mm[threadIdx.x], v);
     }
+    // The last workgroup to arrive derives min_b_ / divb_mul_ from the extremes (a launch of its own before: one wavefront,
+    // 4.8 us).  The extremes were combined by device-scope atomics; the ticket is taken behind them (release), read back at
+    // device scope (acquire).
+    __shared__ uint32_t s_ticket;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_ticket = __hip_atomic_fetch_add(&vox->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1u || threadIdx.x != 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    uint32_t all[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) all[a] = __hip_atomic_load(&vox->mm[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    voxel_params(vox, all, inv_leaf);
 }
 
-// min_b_, div_b_, divb_mul_ from the bounding box (voxel_grid.hpp, first pass), on the device
-__global__ void voxel_params_kernel(VoxelGridDev* vox, float inv_leaf) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// min_b_, div_b_, divb_mul_ from the bounding box (voxel_grid.hpp, first pass), on the device: one lane
+__device__ void voxel_params(VoxelGridDev* vox, const uint32_t mm[6], float inv_leaf) {
     VoxelGridParams g;
     g.inv_leaf = inv_leaf;
     uint32_t flags = 0u;
-    if (vox->mm[0] == 0u) flags |= VOX_EMPTY;                           // no finite point
+    if (mm[0] == 0u) flags |= VOX_EMPTY;                                // no finite point
     long long div[3] = {1, 1, 1};
     for (int a = 0; a < 3; ++a) {
-        const float lo = ordered_float((int)((~vox->mm[a]) ^ 0x80000000u)), hi = ordered_float((int)(vox->mm[3 + a] ^ 0x80000000u));
+        const float lo = ordered_float((int)((~mm[a]) ^ 0x80000000u)), hi = ordered_float((int)(mm[3 + a] ^ 0x80000000u));
         g.min_b[a] = (int)floorf(lo * inv_leaf);
         const int max_b = (int)floorf(hi * inv_leaf);
         div[a] = (long long)max_b - g.min_b[a] + 1;
@@ -144,6 +163,13 @@ __global__ void voxel_params_kernel(VoxelGridDev* vox, float inv_leaf) {
     g.divb_mul[0] = 1; g.divb_mul[1] = (int)div[0]; g.divb_mul[2] = (int)(div[0] * div[1]);
     vox->g = g;
     vox->flags = flags;
+    // bits of a leaf index: 2^bits > number of leaves, so that 2^bits - 1 lies beyond every leaf (the key of the dropped points)
+    uint32_t bits = 1u;
+    if (flags == 0u) {
+        const unsigned long long leaves = (unsigned long long)(div[0] * div[1] * div[2]);
+        while ((1ull << bits) <= leaves) ++bits;
+    }
+    vox->probe[1] = bits;
 }
 
 // key = leaf index (major) | time offset (minor, when the cloud is not in time order yet): one stable sort yields the
@@ -168,25 +194,71 @@ __global__ __launch_bounds__(256) void voxel_index_kernel(const float4* pts, int
     order[i] = (uint32_t)i;
 }
 
+// The compact form of the key for a cloud that already is in time order: the leaf index alone (stability supplies the rest).
+// Every workgroup adds its share to the histograms of the four 8-bit digits of the key (LDS first, one atomic per non-empty bin).
+__global__ __launch_bounds__(256) void voxel_index_compact_kernel(const float4* pts, int n, VoxelGridDev* vox, uint64_t* keys) {
+    __shared__ uint32_t s_hist[4][256];
+    for (int x = threadIdx.x; x < 4 * 256; x += 256) (&s_hist[0][0])[x] = 0u;
+    __syncthreads();
+    const VoxelGridParams g = vox->g;
+    const uint32_t bits = vox->probe[1];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4 p = pts[i];
+        uint32_t key = bits >= 32u ? 0xffffffffu : (1u << bits) - 1u;   // non-finite points sort last and are dropped
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            const int i0 = (int)(floorf(p.x * g.inv_leaf) - (float)g.min_b[0]);
+            const int i1 = (int)(floorf(p.y * g.inv_leaf) - (float)g.min_b[1]);
+            const int i2 = (int)(floorf(p.z * g.inv_leaf) - (float)g.min_b[2]);
+            key = (uint32_t)(i0 * g.divb_mul[0] + i1 * g.divb_mul[1] + i2 * g.divb_mul[2]);
+        }
+        keys[i] = (uint64_t)key;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) atomicAdd(&s_hist[d][(key >> (8 * d)) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < 4 * 256; x += 256) {
+        const uint32_t v = (&s_hist[0][0])[x];
+        if (v != 0u) atomicAdd(&vox->hist[0][0] + x, v);
+    }
+}
+
+// lane K of this lane's row of 16, as a DPP operand (row_newbcast:K, gfx90a and later)
+template <int K> __device__ __forceinline__ float row_bcast16(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, true));
+}
+template <int K> __device__ __forceinline__ void centroid_add16(const float4& p, float& sx, float& sy, float& sz) {
+    sx += row_bcast16<K>(p.x);
+    sy += row_bcast16<K>(p.y);
+    sz += row_bcast16<K>(p.z);
+    if constexpr (K + 1 < 16) centroid_add16<K + 1>(p, sx, sy, sz);
+}
+
 // Sixteen lanes per leaf: the points of the leaf are fetched sixteen at a time (the two dependent loads of every
 // point -- order, then the point -- are what a single lane would wait for, one after the other), then added in
 // sorted (stable = time) order, one at a time, exactly like CentroidPoint: fp32 sums, divided by the count.
 __global__ __launch_bounds__(256) void centroid_kernel(const float4* pts, const uint32_t* order, const uint64_t* sorted_keys,
                                                        const uint32_t* leaf_start, VoxelGridDev* vox, uint32_t n, uint32_t cap_out,
-                                                       float4* out) {
+                                                       float4* out, bool compact_keys, VoxelGridDev* zero_next) {
+    if (zero_next != nullptr && blockIdx.x == gridDim.x - 1u) {          // (nobody reads that record in this call)
+        uint32_t* w = reinterpret_cast<uint32_t*>(zero_next);
+        for (uint32_t x = threadIdx.x; x < sizeof(VoxelGridDev) / 4u; x += 256u) w[x] = 0u;
+    }
     const uint32_t r = threadIdx.x & 15;
     const uint32_t n_leaves = vox->n_leaves;
     const uint32_t flags = vox->flags;
+    // the key of the run of dropped (non-finite) points: all ones in the leaf half, or 2^leaf_bits - 1 in the compact form
+    const int key_shift = compact_keys ? 0 : 32;
+    const uint64_t drop_key = compact_keys ? (vox->probe[1] >= 32u ? 0xffffffffull : (1ull << vox->probe[1]) - 1ull) : 0xffffffffull;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         vox->summary[0] = n_leaves;
-        vox->summary[1] = (n_leaves > 0 && (sorted_keys[n - 1] >> 32) == 0xffffffffull) ? 1u : 0u;
+        vox->summary[1] = (n_leaves > 0 && (sorted_keys[n - 1] >> key_shift) == drop_key) ? 1u : 0u;
         vox->summary[2] = flags;
     }
     if (flags != 0u) return;
     // the grid covers 16 k leaves at a time (it is launched before the leaf count is known to the host)
     for (uint32_t l = (blockIdx.x * 256 + threadIdx.x) >> 4; l < n_leaves; l += gridDim.x * 16u) {
         const uint32_t st = leaf_start[l], en = l + 1 < n_leaves ? leaf_start[l + 1] : n;
-        if ((sorted_keys[st] >> 32) == 0xffffffffull) continue;          // the run of dropped points (always last)
+        if ((sorted_keys[st] >> key_shift) == drop_key) continue;        // the run of dropped points (always last)
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
         float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
         if (st + r < en) nxt = pts[order[st + r]];
@@ -195,10 +267,17 @@ __global__ __launch_bounds__(256) void centroid_kernel(const float4* pts, const 
             const uint32_t jn = j0 + 16 + r;                            // the next sixteen are in flight while these are added
             if (jn < en) nxt = pts[order[jn]];
             const int cnt = (int)min(16u, en - j0);
-            for (int k = 0; k < cnt; ++k) {
-                sx += __shfl(p.x, k, 16);
-                sy += __shfl(p.y, k, 16);
-                sz += __shfl(p.z, k, 16);
+            if (cnt == 16) {
+                // a full batch: sixteen additions per coordinate, each ONE instruction (v_add_f32 with the DPP row broadcast of
+                // lane k as its operand) -- the leaf next to the sensor holds ~2 000 of a sweep's points and its sum, sequential
+                // by definition, is the tail of this kernel (same additions, same order: same bits)
+                centroid_add16<0>(p, sx, sy, sz);
+            } else {
+                for (int k = 0; k < cnt; ++k) {
+                    sx += __shfl(p.x, k, 16);
+                    sy += __shfl(p.y, k, 16);
+                    sz += __shfl(p.z, k, 16);
+                }
             }
         }
         const float fn = (float)(en - st);
@@ -217,15 +296,18 @@ hipError_t launch_undistort(const float4* raw, int n, const double* poses, int n
     hipLaunchKernelGGL(undistort_kernel, dim3((n + 255) / 256), dim3(256), 0, s, raw, n, poses, n_poses, end, out);
     return hipGetLastError();
 }
-hipError_t launch_minmax(const float4* pts, int n, VoxelGridDev* vox, hipStream_t s) {
+hipError_t launch_minmax_params(const float4* pts, int n, VoxelGridDev* vox, float inv_leaf, bool check_time_order, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     int b = (n + 255) / 256;
     if (b > 64) b = 64;                        // six atomics per workgroup on one cache line: keep them few
-    hipLaunchKernelGGL(minmax_kernel, dim3(b), dim3(256), 0, s, pts, n, vox);
+    hipLaunchKernelGGL(minmax_kernel, dim3(b), dim3(256), 0, s, pts, n, vox, inv_leaf, check_time_order);
     return hipGetLastError();
 }
-hipError_t launch_voxel_params(VoxelGridDev* vox, float inv_leaf, hipStream_t s) {
-    hipLaunchKernelGGL(voxel_params_kernel, dim3(1), dim3(64), 0, s, vox, inv_leaf);
+hipError_t launch_voxel_index_compact(const float4* pts, int n, VoxelGridDev* vox, uint64_t* keys, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    int b = (n + 1023) / 1024;                 // four points per lane: fewer, fuller histogram flushes
+    if (b > 256) b = 256;
+    hipLaunchKernelGGL(voxel_index_compact_kernel, dim3(b), dim3(256), 0, s, pts, n, vox, keys);
     return hipGetLastError();
 }
 hipError_t launch_voxel_index(const float4* pts, int n, const VoxelGridDev* vox, bool time_minor, uint64_t* keys, uint32_t* order,
@@ -235,11 +317,13 @@ hipError_t launch_voxel_index(const float4* pts, int n, const VoxelGridDev* vox,
     return hipGetLastError();
 }
 hipError_t launch_centroids(const float4* pts, const uint32_t* order, const uint64_t* sorted_keys, const uint32_t* leaf_start,
-                            VoxelGridDev* vox, uint32_t n, uint32_t max_leaves, uint32_t cap_out, float4* out, hipStream_t s) {
+                            VoxelGridDev* vox, uint32_t n, uint32_t max_leaves, uint32_t cap_out, float4* out, hipStream_t s,
+                            bool compact_keys, VoxelGridDev* zero_for_next_call) {
     if (n == 0 || max_leaves == 0) return hipSuccess;
     uint32_t blocks = (uint32_t)(((size_t)max_leaves * 16 + 255) / 256);
     if (blocks > 1024u) blocks = 1024u;
-    hipLaunchKernelGGL(centroid_kernel, dim3(blocks), dim3(256), 0, s, pts, order, sorted_keys, leaf_start, vox, n, cap_out, out);
+    hipLaunchKernelGGL(centroid_kernel, dim3(blocks), dim3(256), 0, s, pts, order, sorted_keys, leaf_start, vox, n, cap_out, out, compact_keys,
+                       zero_for_next_call);
     return hipGetLastError();
 }
 

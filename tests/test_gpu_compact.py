@@ -9,7 +9,7 @@ from conftest import bits_equal
 pytestmark = pytest.mark.gpu
 
 
-def _drive(gpu_capi, synth, world, n_raw, mode, seed, leaf=None):
+def _drive(gpu_capi, synth, world, n_raw, mode, seed, leaf=None, sorted_times=False, fast_runs=None):
     rng = np.random.default_rng(seed)
     ctx = gpu_capi.LioContext(0.2, max_scan_points=131072, max_map_points=600_000)
     if mode:
@@ -28,6 +28,10 @@ def _drive(gpu_capi, synth, world, n_raw, mode, seed, leaf=None):
         xyz = (rng.uniform(-0.6 * half, 0.6 * half, (n_raw, 3)) * [1, 1, 0.02]).astype(np.float32)
         xyz[::7] = xyz[1::7][: len(xyz[::7])] + np.float32(0.01)
         t = np.floor(rng.uniform(0, 100.0, n_raw) * 4).astype(np.float32) / 4
+        if sorted_times and k != 2:
+            t = np.sort(t)                                            # a driver that delivers its points in firing order
+        elif sorted_times:
+            t = np.sort(t); t[n_raw // 2], t[n_raw // 2 + 1] = t[n_raw // 2 + 1] + 1, t[n_raw // 2]   # ... but for one pair
         if n_raw > 100:
             xyz[5] = [np.nan, 0, 0]
         raw = np.concatenate([xyz, t[:, None]], 1).astype(np.float32)
@@ -43,6 +47,8 @@ def _drive(gpu_capi, synth, world, n_raw, mode, seed, leaf=None):
         r = ctx.map_incremental(st, 0.2, True, apply=True)
         out.append((m, down, und, g["m"], r["n_add"], r["n_nodown"], r["add_counter"], ctx.map_validnum()))
     flat = ctx.map_flatten().copy()
+    if fast_runs is not None:
+        fast_runs.append((ctx.debug_get("voxel_fast_runs"), ctx.debug_get("voxel_redone")))
     ctx.close()
     return out, flat
 
@@ -61,3 +67,21 @@ def test_single_launch_sort_and_compaction_equal_the_library(gpu_capi, synth, sm
     a, fa = _drive(gpu_capi, synth, small_case["world"], n_raw, None, 3)
     _same(a, fa, b, fb)
     assert b[0][0] > 0 and b[-1][4] + b[-1][5] > 0                   # something was filtered and inserted
+
+
+@pytest.mark.parametrize("n_raw", [16385, 40000, 131072])
+def test_time_ordered_sweeps_take_the_compact_key_sort(gpu_capi, synth, small_case, n_raw):
+    """A sweep whose points come in time order is sorted by the leaf index alone (stable LSD splits, lio_gsort.hip): the same
+    filtered cloud, bit for bit and in order, as the 64-bit (leaf | time) library sort -- with repeated time stamps (ties keep
+    the input order), non-finite points (dropped) and many points per leaf.  The host predicts "in order" from the previous sweep
+    and learns the truth with the result: the sweep with one out-of-order pair is filtered twice (compact keys, then the general
+    path), and so is a sweep whose leaf index needs more 8-bit splits than the previous one's.  pcl::VoxelGrid semantics as
+    restated in oracle/ (DESIGN.md section 3.5)."""
+    runs = []
+    b, fb = _drive(gpu_capi, synth, small_case["world"], n_raw, "library_sort", 5, sorted_times=True)
+    a, fa = _drive(gpu_capi, synth, small_case["world"], n_raw, None, 5, sorted_times=True, fast_runs=runs)
+    _same(a, fa, b, fb)
+    assert runs == [(3, 1)]                                          # three sweeps tried with compact keys; the last one (a swapped pair) redone
+    c, fc = _drive(gpu_capi, synth, small_case["world"], n_raw, "library_sort", 5, sorted_times=True, leaf=0.1)
+    d, fd = _drive(gpu_capi, synth, small_case["world"], n_raw, None, 5, sorted_times=True, leaf=0.1)
+    _same(d, fd, c, fc)                                              # a finer grid: more bits in the leaf index (more passes)
