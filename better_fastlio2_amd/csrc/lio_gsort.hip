@@ -316,14 +316,14 @@ __global__ __launch_bounds__(512) void gsort_lsd_pass_kernel(LsdPassArgs a) {
         const uint32_t d = (uint32_t)tid & 255u, h = (uint32_t)tid >> 8, b = blockIdx.x;
         uint32_t acc = 0u;
         bool bad = false;
-        for (uint32_t p0 = h; p0 < b; p0 += 16u) {
-            u64 v[8];
+        for (uint32_t p0 = h; p0 < b; p0 += 32u) {              // sixteen words in flight per lane, tiles h, h + 2, ...
+            u64 v[16];
             unsigned spins = 0;
             bool ok;
             do {
                 ok = true;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const uint32_t p = p0 + 2u * (uint32_t)u;
                     v[u] = (u64)a.stamp << 32;
                     if (p < b) v[u] = __hip_atomic_load(a.agg + (size_t)p * 256u + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(512) void gsort_lsd_pass_kernel(LsdPassArgs a) {
             } while (!ok && ++spins < GS_SPIN_LIMIT);
             bad = bad || !ok;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += (uint32_t)v[u];
+            for (int u = 0; u < 16; ++u) acc += (uint32_t)v[u];
         }
         s_half[h][d] = acc;
         if (bad) s_bad = 1u;

@@ -306,7 +306,7 @@ hipError_t launch_minmax_params(const float4* pts, int n, VoxelGridDev* vox, flo
 hipError_t launch_voxel_index_compact(const float4* pts, int n, VoxelGridDev* vox, uint64_t* keys, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     int b = (n + 1023) / 1024;                 // four points per lane: fewer, fuller histogram flushes
-    if (b > 256) b = 256;
+    if (b > 256) b = 256;                      // (64 workgroups, eight points per lane: 8.5 us instead of 7.3)
     hipLaunchKernelGGL(voxel_index_compact_kernel, dim3(b), dim3(256), 0, s, pts, n, vox, keys);
     return hipGetLastError();
 }
