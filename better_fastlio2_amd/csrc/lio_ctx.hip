@@ -293,10 +293,10 @@ bool is_pow2f(float v) {
 //          scans; 4 lanes lose at every size once the second search is taken at a realistic pose (100 k: 22.7 / 21.7 vs 22.1 / 22.2
 //          in the script, and 24.7 vs 23.3 us for the bounded search inside bench.py's drive)
 //   walk   the prefix-form list with four candidates per lane in flight wins both searches at every size (100 k: 23.3 -> 22.1 and
-//          22.6 -> 22.2 us; 24 k: 11.6 -> 10.6 and 12.1 -> 11.0; 8.6 k: 8.7 -> 8.2 and 9.4 -> 8.9).  Scans beyond the fused
-//          transform's range (C5) keep the plain walk: not measured there.
+//          22.6 -> 22.2 us; 24 k: 11.6 -> 10.6 and 12.1 -> 11.0; 8.6 k: 8.7 -> 8.2 and 9.4 -> 8.9), and C5's 1 M queries against a
+//          map beyond the Infinity Cache (bench.py --config c5, A/B on one box: 207.4 -> 196.3 and 164.9 -> 160.0 us).
 int auto_walk(int nq, int lanes) {
-    if (nq > 262144) return 0;
+    (void)nq;
     return (lanes == 4 || lanes == 8 || lanes == 16) ? 4 : 0;
 }
 int auto_lanes(int nq) {
