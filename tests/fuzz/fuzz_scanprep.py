@@ -43,6 +43,11 @@ def run_case(seed, ctx):
         t_ms = np.round(t_ms)                                  # many ties
     if rng.random() < 0.3:
         t_ms[: max(1, n // 10)] = 0.0
+    if rng.random() < 0.45:
+        t_ms = np.sort(t_ms)                                   # a sweep in firing order: the compact-key (leaf index only) sort of the filter
+        if rng.random() < 0.25 and n > 4:
+            i = int(rng.integers(1, n - 1))
+            t_ms[i - 1], t_ms[i] = t_ms[i] + np.float32(1.0), t_ms[i - 1]   # ... but for one pair (the prediction fails: redone)
     raw = np.concatenate([xyz, t_ms[:, None]], 1).astype(np.float32)
     if n > 20 and rng.random() < 0.3:
         bad = rng.choice(n, 3, replace=False)
@@ -91,4 +96,4 @@ if __name__ == "__main__":
     for seed in range(s0, s0 + n):
         r = run_case(seed, ctx)
         res[r] = res.get(r, 0) + 1
-    print("FUZZ SCANPREP OK: %d cases %s" % (n, res), flush=True)
+    print("FUZZ SCANPREP OK: %d cases %s; compact-key attempts %d, redone %d" % (n, res, ctx.debug_get("voxel_fast_runs"), ctx.debug_get("voxel_redone")), flush=True)
