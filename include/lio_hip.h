@@ -290,9 +290,15 @@ results); "library_sort" sends every sort / compaction of map maintenance and sc
  * in rank order, overflow repeat, Delete_Point_Boxes + the Add_Points pair); "pre_enqueue" = 0 stops
  * lio_eskf_update_iterated_dyn_share_modified from putting the next pass on the stream ahead of its pose (identical results),
  * "gate_mispredict" = 1 makes it predict the wrong kind of pass every time (every pre-enqueued pass is called off; identical
- * results).  Unknown key: LIO_ERR_INVALID_ARG.       */
+ * results); "knn_walk" = 0 / 1 / 2 / 4 forces the candidate walk of the k-NN kernel (plain list / prefix-form list with that
+ * many candidates per lane in flight; -1 = by scan size again) and "lanes_per_query" = 4 ... 64 its lanes per query (0 = by
+ * scan size) -- identical results, A/B switches; "voxel_fast_path" = 0 keeps lio_scan_voxel_filter on the general sort even
+ * for sweeps in time order (identical results); "retired_budget" overrides the number of retired slots that triggers a full
+ * index rebuild (0 = the default, four times the live points).  Unknown key: LIO_ERR_INVALID_ARG.       */
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
-/* counters for tests: "gate_released" / "gate_called_off" = pre-enqueued passes that ran / were called off            */
+/* counters for tests: "gate_released" / "gate_called_off" = pre-enqueued passes that ran / were called off; "voxel_fast_runs" /
+ * "voxel_redone" = voxel-filter attempts on the compact-key path / sweeps filtered twice after a wrong prediction;
+ * "retired_budget" = the retired-slot budget in force                                                                      */
 int  lio_debug_get(lio_ctx* ctx, const char* key, long long* value);
 /* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: [0] its start, [1] own partial
  * published, [2] group folded, [3] grid folded, [4] the listed queries' terms folded (search passes that list any),
