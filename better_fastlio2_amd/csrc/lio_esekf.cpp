@@ -446,6 +446,69 @@ void df_dw(const state_ikfom& s, const input_ikfom&, double W[DIM * 12]) {      
     }
 }
 
+// P <- F P F^T + W Q W^T for the sparse F (<= 9 entries per row) and W (<= 3) of predict: the products visit the non-zero
+// entries only, in ascending index order -- the same sums as the dense loops, the skipped terms being exact zeros.  Both
+// products are formed as linear combinations of ROWS (F P: rows of P; (F P) F^T: rows of (F P)^T), so that the inner loops run
+// over contiguous memory and the AVX2 clone does four columns at a time; every element still is the same sequence of separate
+// multiplications and additions (no contraction: -ffp-contract=off), i.e. the same bits as the scalar loops it replaces.
+LIO_HOST_CLONES static void propagate_covariance(const double* F, const double* W, const double* Q, double* P) {
+    constexpr int LD = 24;                                     // rows padded to six 4-wide vectors (the 24th lane carries zeros)
+    int fnz[DOF][DOF], fcnt[DOF], wnz[DOF][12], wcnt[DOF];
+    for (int r = 0; r < DOF; ++r) {
+        fcnt[r] = 0; wcnt[r] = 0;
+        for (int k = 0; k < DOF; ++k) if (F[r * DOF + k] != 0.0) fnz[r][fcnt[r]++] = k;
+        for (int k = 0; k < 12; ++k) if (W[r * 12 + k] != 0.0) wnz[r][wcnt[r]++] = k;
+    }
+    alignas(32) double Pp[DOF * LD], FP[DOF * LD], WQ[DOF * 12], FPt[LD * LD], WQt[12 * LD], Pt[DOF * LD];
+    for (int r = 0; r < DOF; ++r) {
+        for (int c = 0; c < DOF; ++c) Pp[r * LD + c] = P[r * DOF + c];
+        Pp[r * LD + DOF] = 0.0;
+    }
+    for (int r = 0; r < DOF; ++r) {
+        double* row = FP + r * LD;
+        for (int c = 0; c < LD; ++c) row[c] = 0.0;
+        for (int i = 0; i < fcnt[r]; ++i) {
+            const int k = fnz[r][i];
+            const double f = F[r * DOF + k];
+            const double* pk = Pp + k * LD;
+            for (int c = 0; c < LD; ++c) row[c] += f * pk[c];
+        }
+        double* wrow = WQ + r * 12;
+        for (int c = 0; c < 12; ++c) wrow[c] = 0.0;
+        for (int i = 0; i < wcnt[r]; ++i) {
+            const int k = wnz[r][i];
+            const double f = W[r * 12 + k];
+            for (int c = 0; c < 12; ++c) wrow[c] += f * Q[k * 12 + c];
+        }
+    }
+    for (int k = 0; k < LD; ++k) FPt[k * LD + DOF] = 0.0;
+    for (int k = 0; k < 12; ++k) WQt[k * LD + DOF] = 0.0;
+    for (int r = 0; r < DOF; ++r) {
+        for (int k = 0; k < DOF; ++k) FPt[k * LD + r] = FP[r * LD + k];
+        for (int k = 0; k < 12; ++k) WQt[k * LD + r] = WQ[r * 12 + k];
+    }
+    // column c of the result, as a row over r:  sum_k (F P)[r][k] F[c][k]  +  sum_k (W Q)[r][k] W[c][k]
+    for (int c = 0; c < DOF; ++c) {
+        alignas(32) double a1[LD], a2[LD];
+        for (int r = 0; r < LD; ++r) { a1[r] = 0.0; a2[r] = 0.0; }
+        for (int i = 0; i < fcnt[c]; ++i) {
+            const int k = fnz[c][i];
+            const double f = F[c * DOF + k];
+            const double* col = FPt + k * LD;
+            for (int r = 0; r < LD; ++r) a1[r] += col[r] * f;
+        }
+        for (int i = 0; i < wcnt[c]; ++i) {
+            const int k = wnz[c][i];
+            const double f = W[c * 12 + k];
+            const double* col = WQt + k * LD;
+            for (int r = 0; r < LD; ++r) a2[r] += col[r] * f;
+        }
+        for (int r = 0; r < LD; ++r) Pt[c * LD + r] = a1[r] + a2[r];
+    }
+    for (int r = 0; r < DOF; ++r)
+        for (int c = 0; c < DOF; ++c) P[r * DOF + c] = Pt[c * LD + r];
+}
+
 void esekf::predict(double dt, const double Q[12 * 12], const input_ikfom& in) {
     double f_[DIM], f_x_[DIM * DOF], f_w_[DIM * 12];
     get_f(x_, in, f_);                                       // esekfom.hpp:281-282, 285
@@ -526,37 +589,7 @@ void esekf::predict(double dt, const double Q[12 * 12], const input_ikfom& in) {
     // entries only, in ascending index order -- the same sums as the dense loops, the skipped terms being exact zeros.
     for (int i = 0; i < DOF * DOF; ++i) F_x1[i] += f_x_final[i] * dt;
     for (int i = 0; i < DOF * 12; ++i) f_w_final[i] = dt * f_w_final[i];
-    int fnz[DOF][DOF], fcnt[DOF], wnz[DOF][12], wcnt[DOF];
-    for (int r = 0; r < DOF; ++r) {
-        fcnt[r] = 0; wcnt[r] = 0;
-        for (int k = 0; k < DOF; ++k) if (F_x1[r * DOF + k] != 0.0) fnz[r][fcnt[r]++] = k;
-        for (int k = 0; k < 12; ++k) if (f_w_final[r * 12 + k] != 0.0) wnz[r][wcnt[r]++] = k;
-    }
-    double FP[DOF * DOF], WQ[DOF * 12];
-    for (int r = 0; r < DOF; ++r) {
-        double* row = FP + r * DOF;
-        for (int c = 0; c < DOF; ++c) row[c] = 0.0;
-        for (int i = 0; i < fcnt[r]; ++i) {
-            const int k = fnz[r][i];
-            const double f = F_x1[r * DOF + k];
-            const double* pk = P_ + k * DOF;
-            for (int c = 0; c < DOF; ++c) row[c] += f * pk[c];
-        }
-        double* wrow = WQ + r * 12;
-        for (int c = 0; c < 12; ++c) wrow[c] = 0.0;
-        for (int i = 0; i < wcnt[r]; ++i) {
-            const int k = wnz[r][i];
-            const double f = f_w_final[r * 12 + k];
-            for (int c = 0; c < 12; ++c) wrow[c] += f * Q[k * 12 + c];
-        }
-    }
-    for (int r = 0; r < DOF; ++r)
-        for (int c = 0; c < DOF; ++c) {
-            double a1 = 0.0, a2 = 0.0;
-            for (int i = 0; i < fcnt[c]; ++i) { const int k = fnz[c][i]; a1 += FP[r * DOF + k] * F_x1[c * DOF + k]; }
-            for (int i = 0; i < wcnt[c]; ++i) { const int k = wnz[c][i]; a2 += WQ[r * 12 + k] * f_w_final[c * 12 + k]; }
-            P_[r * DOF + c] = a1 + a2;
-        }
+    propagate_covariance(F_x1, f_w_final, Q, P_);
 }
 
 // ------------------------------------------------------------------------------------------
