@@ -287,14 +287,16 @@ bool is_pow2f(float v) {
 }
 // Shape of a knn27_kernel launch: lanes per query and candidate walk (KnnArgs.walk, lio_knn.hip).  Measured on MI355X
 // (scripts/dbg/knn_walk_ab.py: 5 M-point map, scans of 3 k ... 100 k points, first search at the prior and bounded re-search at the
-// converged pose; profiles/r03z_walk_ab.log).  The kernel is bound by instruction issue when the launch fills the GPU and by its
-// chain of dependent round trips when it does not:
-//   lanes  8 per query from ~22 k queries up (C2, C5; at 24 k 10.6 vs 11.5 us), 16 below (8.6 k: 8.2 vs 8.8), 32 for very small
-//          scans; 4 lanes lose at every size once the second search is taken at a realistic pose (100 k: 22.7 / 21.7 vs 22.1 / 22.2
-//          in the script, and 24.7 vs 23.3 us for the bounded search inside bench.py's drive)
-//   walk   the prefix-form list with four candidates per lane in flight wins both searches at every size (100 k: 23.3 -> 22.1 and
-//          22.6 -> 22.2 us; 24 k: 11.6 -> 10.6 and 12.1 -> 11.0; 8.6 k: 8.7 -> 8.2 and 9.4 -> 8.9), and C5's 1 M queries against a
-//          map beyond the Infinity Cache (bench.py --config c5, A/B on one box: 207.4 -> 196.3 and 164.9 -> 160.0 us).
+// converged pose; profiles/r03z_walk_ab.log, r03z_walk_ab_lanes4.log; first / bounded search in us).  The kernel is bound by
+// instruction issue when the launch fills the GPU and by its chain of dependent round trips when it does not:
+//   lanes  8 per query from ~22 k queries up (C2, C5; at 24 k: 10.3 / 11.1 with 8 lanes, 10.6 / 11.8 with 16), 16 below (8.6 k:
+//          7.8 / 8.7 vs 8.6 / 9.3), 32 for very small scans.  4 lanes lose the first search everywhere (100 k: 23.2 vs 21.9) and
+//          both searches below ~60 k queries; at 100 k they win the BOUNDED search by 0.7 us with four candidates in flight (21.2 vs
+//          21.9) and lost it with the plain walk inside bench.py's drive (24.7 vs 23.3): not adopted (0.6 % of a scan step)
+//   walk   the prefix-form list with four candidates per lane in flight wins the first search at every size (100 k: 22.8 -> 22.0;
+//          50 k: 14.8 -> 14.0; 24 k: 11.1 -> 10.3; 8.6 k, 16 lanes: 8.2 -> 7.8) and the bounded one from 50 k down (14.9 -> 14.6;
+//          11.9 -> 11.1; 8.9 -> 8.7; at 100 k it is a wash: 22.2 -> 22.1), and C5's 1 M queries against a map beyond the Infinity
+//          Cache (bench.py --config c5, A/B on one box: 207.4 -> 196.3 and 164.9 -> 160.0 us).
 int auto_walk(int nq, int lanes) {
     (void)nq;
     return (lanes == 4 || lanes == 8 || lanes == 16) ? 4 : 0;
