@@ -487,7 +487,8 @@ def main():
         dist.broadcast(pts4, src=0)
         if rank != 0:
             world = synth.World(points=None, voxel=voxel, ground_half=meta[0], walls=meta[1], seed=meta[2])
-    ctx = capi.LioContext(voxel, max_scan_points=nq, max_map_points=nm + 2_000_000, device=local, lanes_per_query=a.lanes)
+    # room for the inserts of the node loop: every replica applies the lists of ALL ranks (~0.1 nq points per rank and step)
+    ctx = capi.LioContext(voxel, max_scan_points=nq, max_map_points=nm + 2_000_000 * max(1, world_size), device=local, lanes_per_query=a.lanes)
     if dist is not None:
         torch.cuda.synchronize(device)
         ctx.map_build_device(pts4.data_ptr(), nm)

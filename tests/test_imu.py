@@ -194,3 +194,33 @@ def test_imu_init_sets_gravity_bias_and_covariance():
     assert p2.info()["need_init"] and p2.info()["init_iter_num"] == 5
     p2.process(kf, None, 0.02, 0.06, imu[4:12])
     assert not p2.info()["need_init"]
+
+
+def test_predict_keeps_the_covariance_symmetric_and_matches_the_dense_product():
+    """esekf::predict forms F P F^T + W Q W^T from the non-zero entries of F and W as combinations of padded rows (an AVX2 clone
+    exists); against the dense numpy product of the oracle's F and W the result agrees to rounding, whatever P holds -- dense,
+    diagonal (exact zeros everywhere), badly scaled -- and a symmetric P stays symmetric to rounding (esekfom.hpp:380-381)."""
+    import numpy as np
+    from better_fastlio2_amd import capi, synth
+    from oracle import imu_model as im
+    rng = np.random.default_rng(7)
+    for case in range(12):
+        x = np.zeros(26)
+        x[:3] = rng.normal(0, 1, 3)
+        for a in (3, 7):
+            q = rng.normal(size=4); x[a:a + 4] = q / np.linalg.norm(q)
+        x[11:14] = rng.normal(0, 0.1, 3); x[14:17] = rng.normal(0, 1, 3); x[17:23] = rng.normal(0, 0.01, 6)
+        g = rng.normal(size=3); x[23:26] = g / np.linalg.norm(g) * 9.81
+        A = rng.normal(size=(23, 23))
+        P = A @ A.T * 1e-3 if case % 3 else np.diag(rng.uniform(1e-8, 1e-1, 23))
+        if case % 4 == 1:
+            s = np.diag(10.0 ** rng.uniform(-4, 4, 23)); P = s @ P @ s
+        B = rng.normal(size=(12, 12)); Q = B @ B.T * 1e-4
+        kf = capi.Esekf(3); kf.change_x(x); kf.change_P(P)
+        acc = rng.normal(0, 3, 3) + [0, 0, 9.8]; gyr = rng.normal(0, 0.5, 3); dt = float(rng.uniform(0.001, 0.02))
+        kf.predict(dt, Q, acc, gyr)
+        xo, Po = im.predict(x, P, dt, Q, acc, gyr)
+        Pg = kf.get_P()
+        scale = np.sqrt(np.outer(np.abs(np.diag(Po)), np.abs(np.diag(Po)))) + 1e-300
+        assert np.abs(Pg - Po).max() <= 5e-13 * np.abs(Po).max() and (np.abs(Pg - Po) / scale).max() < 1e-9
+        assert (np.abs(Pg - Pg.T) / scale).max() < 1e-12
