@@ -588,10 +588,12 @@ def main():
         step_resident()
     kernels_us = {k: (v["total_ms"] / max(v["launches"], 1)) * 1e3 for k, v in ctx.profile().items() if v["launches"]}
 
-    # ---- the contract loop.  HIP events only on the dominant kernel (knn27, first search of a scan), on the library's
-    # stream, and only on every SAMPLE-th step: an event pair costs host time on the launch path.  SAMPLE is co-prime
-    # with the rotation so that every scan of the drive gets sampled.
-    SAMPLE = int(os.environ.get("LIO_BENCH_EVENT_EVERY", "7"))
+    # ---- the contract loop: NO instrumentation inside the timed region (round 3 stamped every 7th step with HIP events, ~14 us
+    # of host time per stamped launch, i.e. a 2-3 % pessimistic `value`).  The roofline figure of the dominant kernel is taken
+    # right after it, on the SAME drive through the SAME entry point, untimed: HIP events (stamped by the dispatch itself, on the
+    # library's stream) on the k-NN launches of every SAMPLE-th step.  SAMPLE is co-prime with the rotation so that every scan
+    # of the drive gets sampled.
+    SAMPLE = int(os.environ.get("LIO_BENCH_EVENT_EVERY", "3"))
 
     def sampled(step_fn):
         def f():
@@ -609,12 +611,18 @@ def main():
     if rc != 0:
         fail("first upload", rc)
     lat_value = []
-    elapsed = timed_steps(sampled(step_pipelined), a.steps, a.warmup, dist, device, lat_value)
+    elapsed = timed_steps(step_pipelined, a.steps, a.warmup, dist, device, lat_value)
+    ctx.profile_reset()
+    n_sampled_steps = max(3 * n_rot, min(a.steps, 96))
+    run_sampled = sampled(step_pipelined)
+    for _ in range(n_sampled_steps):
+        run_sampled()
     L.lio_scan_swap(ctx.h)                                     # consume the upload left in flight by the last step
     prof = ctx.profile()
     ctx.profile_enable(False)
     knn_ms = prof["knn27"]["total_ms"] / max(prof["knn27"]["launches"], 1)
     hint_ms = prof["knn27_hint"]["total_ms"] / max(prof["knn27_hint"]["launches"], 1) if prof["knn27_hint"]["launches"] else None
+    knn_launches_sampled = int(prof["knn27"]["launches"])
 
     extras = {}
     if not a.no_extras:
@@ -663,11 +671,18 @@ def main():
         tick[0] = 0
         lat_node = []
         info_n0 = ctx.map_info()
-        t_node = timed_steps(sampled(step_node), k_node, 4, dist, device, lat_node)
+        t_node = timed_steps(step_node, k_node, 4, dist, device, lat_node)
+        info = ctx.map_info()
+        maint_timed = dict(maint)
+        # (the first search behind a map update, event-stamped: the same loop, untimed, right behind the timed window)
+        ctx.profile_reset()
+        run_sampled_node = sampled(step_node)
+        for _ in range(2 * n_rot):
+            run_sampled_node()
         prof_node = ctx.profile()
         ctx.profile_enable(False)
+        maint = maint_timed
         cold_ms = prof_node["knn27"]["total_ms"] / max(prof_node["knn27"]["launches"], 1) if prof_node["knn27"]["launches"] else None
-        info = ctx.map_info()
         extras["node_loop"] = {"value": world_size * k_node / t_node, "unit": "scans/s", "ms_per_step": t_node / k_node * 1e3,
                                "steps": k_node, "map_update_ms_per_step": maint["seconds"] / max(maint["steps"], 1) * 1e3,
                                "inserted_per_step": (maint["n_add"] + maint["n_nodown"]) / max(maint["steps"], 1),
@@ -773,7 +788,9 @@ def main():
         "kernels_us": kernels_us,
         "roofline": {"bound": "hbm", "kernel": "knn27_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": frac, "traffic": traffic, "traffic_note": traffic_note,
-                     "algorithmic_bytes_per_launch": bytes_knn, "avg_launch_us": knn_ms * 1e3},
+                     "algorithmic_bytes_per_launch": bytes_knn, "avg_launch_us": knn_ms * 1e3,
+                     "measured": f"HIP events stamped by the dispatch (hipExtLaunchKernelGGL) on the library's stream, {knn_launches_sampled} first-search "
+                                 "launches of the timed drive repeated untimed right behind the timed region (no instrumentation inside `value`)"},
         "roofline_detail": detail,
     }
     out.update(extras)

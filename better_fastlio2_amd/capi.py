@@ -21,6 +21,7 @@ import numpy as np
 from . import build as _build
 
 LIO_OK = 0
+LIO_ERR_INVALID_ARG, LIO_ERR_NO_DEVICE, LIO_ERR_HIP, LIO_ERR_CAPACITY, LIO_ERR_NO_SCAN, LIO_ERR_NO_MAP = -1, -2, -3, -4, -5, -6
 ERRORS = {-1: "LIO_ERR_INVALID_ARG", -2: "LIO_ERR_NO_DEVICE", -3: "LIO_ERR_HIP", -4: "LIO_ERR_CAPACITY",
           -5: "LIO_ERR_NO_SCAN", -6: "LIO_ERR_NO_MAP"}
 PROF_KNN, PROF_FALLBACK, PROF_RESIDUAL, PROF_REDUCE, PROF_KNN_HINT = 0, 1, 2, 3, 4
@@ -65,7 +66,7 @@ EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_device_count", "lio_stream", "lio_synchronize",
     "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_replicate_unique_id", "lio_replicate_init", "lio_replicate_finalize", "lio_replicate_queue_boxes", "lio_replicate_step", "lio_fov_segment", "lio_map_reconstruct",
     "lio_map_set_downsample_param", "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_acquire_removed_points", "lio_map_get_info", "lio_map_nearest_search",
-    "lio_scan_set", "lio_scan_set_device", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_measure_want_rows", "lio_eskf_update_iterated_dyn_share_callback", "lio_get_neighbors",
+    "lio_scan_set", "lio_scan_set_device", "lio_scan_set_async", "lio_host_register", "lio_host_unregister", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_measure_want_rows", "lio_eskf_update_iterated_dyn_share_callback", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get", "lio_debug_set", "lio_debug_get", "lio_debug_stamps",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
     "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_eskf_scan_step_device", "lio_eskf_scan_step_pipelined", "lio_state_boxplus",
@@ -141,6 +142,9 @@ def load(build_if_missing: bool = True):
     L.lio_map_nearest_search.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
     L.lio_scan_set.argtypes = [_vp, _vp, C.c_int, C.c_int]
     L.lio_scan_set_device.argtypes = [_vp, _vp, C.c_int]
+    L.lio_scan_set_async.argtypes = [_vp, _vp, C.c_int, C.c_int]
+    L.lio_host_register.argtypes = [_vp, C.c_size_t]
+    L.lio_host_unregister.argtypes = [_vp]
     L.lio_scan_upload_async.argtypes = [_vp, _vp, C.c_int]
     L.lio_scan_swap.argtypes = [_vp]
     L.lio_host_alloc.argtypes = [C.c_size_t]
@@ -198,7 +202,11 @@ def load(build_if_missing: bool = True):
 
 def pinned_points(xyz) -> np.ndarray:
     """[n, 4] float32 copy of xyz in pinned host memory (lio_host_alloc): the buffer a sensor driver would fill.
-    The memory lives as long as the returned array (and views of it)."""
+    The memory lives as long as the returned array (and views of it).  Lifetime rule of the C interface: memory handed to
+    lio_scan_upload_async / lio_scan_upload_raw / lio_scan_set_async is read AFTER those calls return (until lio_scan_swap +
+    the next pass / a call that waits for the stream); LioContext.scan_upload_async, scan_undistort and scan_set_async hold a
+    reference for that long, so passing a temporary is safe through them -- a caller of the raw ctypes entry points keeps the
+    array alive itself."""
     L = load()
     xyz = np.ascontiguousarray(xyz, np.float32)
     n = len(xyz)
@@ -228,6 +236,9 @@ def callback_bench():
         B.cbb_add_scan.argtypes = [_vp, C.c_int, C.c_int]
         B.cbb_step.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp]
         B.cbb_last_m.restype = C.c_int
+        B.cbb_last_status.restype = C.c_int
+        B.cbb_option.argtypes = [C.c_int, C.c_int]
+        B.cbb_option.restype = None
         B.cbb_take_model_seconds.restype = C.c_double
         _cbb = B
     return _cbb
@@ -425,11 +436,22 @@ class LioContext:
         b = _points(body)
         self._chk(self.L.lio_scan_set(self.h, _ptr(b), len(b), _stride(b)), "lio_scan_set")
 
+    def scan_set_async(self, body):
+        """lio_scan_set without the wait.  Page-locked records (pinned_points, lio_host_register) are pulled by a kernel where
+        they lie: the context keeps a reference to the array until the next scan replaces it."""
+        b = _points(body)
+        self._chk(self.L.lio_scan_set_async(self.h, _ptr(b), len(b), _stride(b)), "lio_scan_set_async")
+        self._scan_keep = b
+
     def scan_undistort(self, raw_xyzt, imu_poses=None, end_state14=None):
         """UndistortPcl's point side: raw_xyzt [n, 4] = x, y, z, time offset in ms; imu_poses [K, 22]
-        (offset_time, acc3, gyr3, vel3, pos3, rot9); end_state14 = propagated state at scan end."""
+        (offset_time, acc3, gyr3, vel3, pos3, rot9); end_state14 = propagated state at scan end.
+        x, y, z, t records in page-locked memory (pinned_points) are read by the copy engine IN PLACE after this call has
+        returned: the context holds a reference to the array until the next raw scan replaces it (the C rule: untouched until a
+        call that waits for the stream has returned -- lio_scan_voxel_filter, lio_synchronize)."""
         r = np.ascontiguousarray(raw_xyzt, np.float32)
         assert r.ndim == 2 and r.shape[1] == 4
+        self._raw_keep = r
         if imu_poses is None:
             self._chk(self.L.lio_scan_undistort(self.h, _ptr(r), len(r), 16, 12, None, 0, None), "lio_scan_undistort")
             return
@@ -456,6 +478,10 @@ class LioContext:
         """Start the host-to-device copy of the NEXT scan ([n, 4] float32 in pinned memory, see pinned_points)."""
         assert pinned_f4.dtype == np.float32 and pinned_f4.ndim == 2 and pinned_f4.shape[1] == 4 and pinned_f4.flags.c_contiguous
         self._chk(self.L.lio_scan_upload_async(self.h, _ptr(pinned_f4), len(pinned_f4)), "lio_scan_upload_async")
+        # The C side only stores the pointer: the copy is issued by the next measurement pass or by lio_scan_swap and may still
+        # be in flight when lio_scan_swap returns.  Hold the array (a temporary from pinned_points would otherwise give its
+        # page-locked memory back under the copy engine) until the upload AFTER the next one has been handed over.
+        self._upload_keep = (getattr(self, "_upload_keep", (None, None))[1], pinned_f4)
 
     def scan_swap(self):
         """The scan uploaded with scan_upload_async becomes the current scan."""
@@ -628,6 +654,8 @@ class ImuProcess:
         """ImuProcess::Process.  ctx=None: propagate only.  Returns True when ctx holds feats_undistort."""
         m = np.ascontiguousarray(imu, np.float64).reshape(-1, 7)
         r = None if raw_xyzt is None else np.ascontiguousarray(raw_xyzt, np.float32).reshape(-1, 4)
+        if ctx is not None and r is not None:
+            ctx._raw_keep = r                      # page-locked records are read in place after the call (see scan_undistort)
         und = C.c_int(0)
         rc = self.L.lio_imu_process(self.h, kf.h, None if ctx is None else ctx.h, lidar_beg_time, lidar_end_time,
                                     None if r is None else _ptr(r), 0 if r is None else len(r), 16, 12,

@@ -109,6 +109,7 @@ struct lio_ctx {
     uint32_t gsort_seq = 0;
     size_t cagg_words = 0;                     // size of d_cagg
     bool have_map = false;
+    bool map_broken = false;                   // an index update failed half-way: every map / search call fails until Build / reconstruct
     unsigned long long* d_cagg = nullptr;      // scratch of the single-launch compaction primitives (lio_compact.hip)
     uint32_t compact_seq = 0;                  // their stamp: one number per launch
     // acquire_removed_points: box-deleted points whose storage was reclaimed by a rebuild, not yet handed out
@@ -150,6 +151,11 @@ struct lio_ctx {
     long long n_gate_released = 0, n_gate_called_off = 0;
     std::vector<signed char> pattern_prev, pattern_cur;   // converge flag per call of the previous / the running iterated update
     bool pass_searched = false;                // the pass in flight is a search pass
+    bool pass_gated = false;                   // ... and was released through a gate (re-enqueued directly once if its gate gave up)
+    long long n_gate_reenqueued = 0;
+    long long n_rows_direct_dma = 0;           // lio_measure_rows calls whose rows the copy engine wrote straight into the caller's page-locked buffers
+    long long n_scan_pulled = 0;               // scans a kernel pulled out of page-locked host records (lio_scan_set_async)
+    // page-locked destinations the rows of the callback path are copied into directly (lio_measure_rows)
     int listed_last_search = 0;                // unproven queries of the most recent search pass: predicts the next one's
     uint8_t *d_cnt = nullptr, *d_sel = nullptr;
     float4* d_ulist = nullptr;                 // queries the 27-cell kernel could not prove (count: d_counters[0])
@@ -180,6 +186,7 @@ struct lio_ctx {
     uint32_t* d_small = nullptr;               // device alias of h_small
     uint32_t small_seq = 0;
     bool stage_busy = false;
+    size_t stage_busy_slots = 0;               // float4 slots at the head of h_stage the copy in flight still reads
     bool undist_sorted = true;                 // d_undist is in time order (else: input order, sorted on demand)
     bool raw_time_keyed = false;               // the raw scan came with per-point times
     bool raw_uploaded = false;                 // lio_scan_upload_raw ran (lio_scan_compensate may follow)
@@ -364,18 +371,29 @@ int ensure_scratch(lio_ctx* c, size_t bytes) {
     }
     return LIO_OK;
 }
-// host records (x,y,z first, stride bytes) -> pinned float4 staging -> device
+// host records (x,y,z first, stride bytes) -> pinned float4 staging -> device.  The host records are consumed before the
+// call returns; the copy out of the staging buffer is NOT waited for (whatever follows on the stream is ordered behind it, the
+// next writer of the staging buffer waits for the event: ensure_stage) -- a blocking wait here cost every lio_scan_set the
+// copy engine's ~22 us floor plus the transfer (scripts/micro/upload_probe.hip).
+static void pack_points(const float* pts, size_t n, int stride_bytes, float4* dst) {
+    const char* src = reinterpret_cast<const char*>(pts);
+    if (stride_bytes == 16) {
+        for (size_t i = 0; i < n; ++i) { float4 v = reinterpret_cast<const float4*>(src)[i]; v.w = 0.0f; dst[i] = v; }
+        return;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const float* p = reinterpret_cast<const float*>(src + i * (size_t)stride_bytes);
+        dst[i] = make_float4(p[0], p[1], p[2], 0.0f);
+    }
+}
 int upload_points(lio_ctx* c, const float* pts, size_t n, int stride_bytes, float4* d_dst) {
     if (n == 0) return LIO_OK;
     int rc = ensure_stage(c, n);
     if (rc != LIO_OK) return rc;
-    const char* src = reinterpret_cast<const char*>(pts);
-    for (size_t i = 0; i < n; ++i) {
-        const float* p = reinterpret_cast<const float*>(src + i * (size_t)stride_bytes);
-        c->h_stage[i] = make_float4(p[0], p[1], p[2], 0.0f);
-    }
+    pack_points(pts, n, stride_bytes, c->h_stage);
     HIPCHK(c, hipMemcpyAsync(d_dst, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, stream_wait(c));          // staging is reused by the next call
+    HIPCHK(c, hipEventRecord(c->ev_stage, c->stream));
+    c->stage_busy = true; c->stage_busy_slots = n;
     return LIO_OK;
 }
 
@@ -598,7 +616,7 @@ int finish_index(lio_ctx* c, uint32_t n) {
     }
     HIPCHK(c, stream_wait(c));
     c->levels = lv;
-    c->have_map = true;
+    c->have_map = true; c->map_broken = false;
     ++c->n_full_rebuilds;
     return LIO_OK;
 }
@@ -616,7 +634,7 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
         HIPCHK(c, hipMemsetAsync(c->d_ltable, 0xFF, 64 * sizeof(HashEntry), s));
         HIPCHK(c, stream_wait(c));
         c->levels = TreeLevels{};                  // level-1 table = slot 0 of d_ltable, empty
-        c->have_map = true;
+        c->have_map = true; c->map_broken = false;
         return LIO_OK;
     }
     HIPCHK(c, launch_point_keys(src, n, c->grid, c->d_mkeys_tmp, c->d_vals_tmp, s));
@@ -791,6 +809,7 @@ static uint32_t retired_slot_budget(const lio_ctx* c) {
 // and ONE read-back that brings the statistics of this update together with the counts the fold left on the device.
 int apply_pending(lio_ctx* c) {
     hipStream_t s = c->stream;
+    if (c->map_broken) return c->fail(LIO_ERR_NO_MAP, "Add_Points", "the map index is undefined after a failed update: Build / reconstruct it");
     if (c->fold_n == 0 && c->plain_n == 0) return LIO_OK;
     c->hint_valid = false;
     if (!c->have_map || c->n_live == 0 || c->n_points == 0) return rebuild_full(c);
@@ -817,7 +836,14 @@ int apply_pending(lio_ctx* c) {
     HIPCHK(c, launch_cell_apply(a, s));
     uint32_t st[32] = {};
     rc = fetch_batch_counts(c, st);
-    if (rc != LIO_OK) return rc;
+    if (rc != LIO_OK) {
+        // cell_apply may already have re-written buckets at the tail and retired their old slots: the counts that say how far
+        // it got are what could not be read.  The batch is dropped and the index declared undefined -- loudly, for every call
+        // that would search or extend it -- instead of being re-applied over a half-updated state by the next call.
+        c->fold_n = 0; c->plain_n = 0; c->plain_ptr = nullptr; c->pend_built = false; c->batch_box = HostBox{};
+        c->map_broken = true; c->have_map = false; c->hint_valid = false;
+        return rc;
+    }
     if (st[2] & APPLY_FLAG_NO_ROOM) return rebuild_full(c);    // nothing was changed: the pending points go in there
     // the counts of the down-sampled Add_Points arrive with this read-back (no host round trip of their own)
     const uint32_t n_real = c->plain_n + (c->fold_n != 0 ? st[6] : 0u);
@@ -930,6 +956,10 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
 }  // namespace
 
 extern "C" {
+// Passes armed ahead of their pose (gate_arm) sit on the stream behind a gate kernel that waits for the host: whoever else wants
+// the stream -- every entry point that enqueues on it or waits for it -- calls them off first.
+static void gate_call_off(lio_ctx* c);
+static inline void enter(lio_ctx* c) { if (c->gate_n > 0) gate_call_off(c); }
 
 const char* lio_version(void) { return "lio_hip 0.2 (gfx950)"; }
 int lio_device_count(void) {
@@ -1105,6 +1135,7 @@ const char* lio_last_error(lio_ctx* c) { return c ? c->err.c_str() : "null conte
 void* lio_stream(lio_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int lio_synchronize(lio_ctx* c) {
     if (!c) return LIO_ERR_INVALID_ARG;
+    enter(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, stream_wait(c));
     return LIO_OK;
@@ -1113,6 +1144,7 @@ int lio_synchronize(lio_ctx* c) {
 // ---- map ---------------------------------------------------------------------------------------
 int lio_map_build(lio_ctx* c, const float* pts, long long n, int stride_bytes) {
     if (!c || n < 0 || (n > 0 && !pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if ((size_t)n > c->cap_map) return c->fail(LIO_ERR_CAPACITY, "lio_map_build", "n exceeds max_map_points");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = upload_points(c, pts, (size_t)n, stride_bytes, c->d_pts_tmp);
@@ -1126,6 +1158,7 @@ int lio_map_build(lio_ctx* c, const float* pts, long long n, int stride_bytes) {
 }
 int lio_map_build_device(lio_ctx* c, const void* d_pts_f4, long long n) {
     if (!c || n < 0 || (n > 0 && !d_pts_f4)) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if ((size_t)n > c->cap_map) return c->fail(LIO_ERR_CAPACITY, "lio_map_build_device", "n exceeds max_map_points");
     HIPCHK(c, hipSetDevice(c->device));
     if (n > 0)
@@ -1137,6 +1170,7 @@ int lio_map_build_device(lio_ctx* c, const void* d_pts_f4, long long n) {
     return build_index(c, c->d_pts_tmp, (uint32_t)n);
 }
 int lio_map_reconstruct(lio_ctx* c, const float* pts, long long n, int stride_bytes) {
+    if (c) enter(c);
     return lio_map_build(c, pts, n, stride_bytes);       // ikd_Tree.cpp:1394-1405: delete all, Build
 }
 
@@ -1219,6 +1253,7 @@ static int rebuild_from_stored(lio_ctx* c, int* add_counter = nullptr) {
 // of down-sampled inserts that changed the tree (tmp_counter), 0 when downsample_on is false.
 int lio_map_add(lio_ctx* c, const float* pts, int n, int stride_bytes, int downsample_on, int* n_added) {
     if (!c || n < 0 || (n > 0 && !pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (n_added) *n_added = 0;
     if (n == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1242,6 +1277,7 @@ int lio_map_add_pair(lio_ctx* c, const float* add_pts, int n_add, const float* n
                      int stride_bytes, int* add_counter) {
     if (!c || n_add < 0 || n_nodown < 0 || (n_add > 0 && !add_pts) || (n_nodown > 0 && !nodown_pts) || stride_bytes < 12)
         return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (add_counter) *add_counter = 0;
     if (n_add + n_nodown == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1329,6 +1365,7 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
                         int apply, float* out_add_xyz, int* n_add, float* out_nodown_xyz, int* n_nodown,
                         int* add_counter) {
     if (!c || !state14 || !(filter_size_map_min > 0.0)) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (n_add) *n_add = 0;
     if (n_nodown) *n_nodown = 0;
     if (add_counter) *add_counter = 0;
@@ -1368,6 +1405,7 @@ int lio_map_incremental_device(lio_ctx* c, const double state14[14], double filt
                                void** d_add_f4, int* n_add, void** d_nodown_f4, int* n_nodown) {
     if (!c || !state14 || !(filter_size_map_min > 0.0) || !d_add_f4 || !n_add || !d_nodown_f4 || !n_nodown)
         return LIO_ERR_INVALID_ARG;
+    enter(c);
     ListWords w;
     int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, &w);
     if (rc != LIO_OK) return rc;
@@ -1379,6 +1417,7 @@ int lio_map_incremental_device(lio_ctx* c, const double state14[14], double filt
 int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const void* d_nodown_f4, int n_nodown,
                             int* add_counter) {
     if (!c || n_add < 0 || n_nodown < 0 || (n_add > 0 && !d_add_f4) || (n_nodown > 0 && !d_nodown_f4)) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (add_counter) *add_counter = 0;
     if (n_add + n_nodown == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1485,6 +1524,7 @@ int lio_replicate_init(lio_ctx* c, const void* id128, int rank, int world, int l
     if (!c || world < 1 || rank < 0 || rank >= world || world * REP_MAX_BOXES > REP_MAX_BOXES_TOTAL || list_capacity < 0 ||
         (world > 1 && !id128 && !c->dbg_rep_loopback))
         return LIO_ERR_INVALID_ARG;
+    enter(c);
     HIPCHK(c, hipSetDevice(c->device));
     lio_replicate_finalize(c);
     const bool loopback = world > 1 && !id128;
@@ -1518,6 +1558,7 @@ int lio_replicate_init(lio_ctx* c, const void* id128, int rank, int world, int l
 
 void lio_replicate_finalize(lio_ctx* c) {
     if (!c) return;
+    enter(c);
     if (c->rep_comm) {
         RcclApi* r = rccl_api(nullptr);
         if (r) (void)r->CommDestroy(c->rep_comm);
@@ -1592,6 +1633,7 @@ static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4], H
 int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
                        int* n_add_total, int* n_nodown_total, int* n_deleted, int* add_counter) {
     if (!c || !state14 || !(filter_size_map_min > 0.0)) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (c->rep_world == 0) return c->fail(LIO_ERR_INVALID_ARG, "lio_replicate_step", "lio_replicate_init has not been called");
     if (n_add_total) *n_add_total = 0;
     if (n_nodown_total) *n_nodown_total = 0;
@@ -1667,11 +1709,13 @@ int lio_map_set_downsample_param(lio_ctx* c, float downsample_size) {
 // indexed first, so that the numbers are exact)
 long long lio_map_size(lio_ctx* c) {
     if (!c) return 0;
+    enter(c);
     if ((c->fold_n != 0 || c->plain_n != 0) && hipSetDevice(c->device) == hipSuccess) (void)apply_pending(c);
     return (long long)c->n_points - (long long)c->n_retired;
 }
 long long lio_map_validnum(lio_ctx* c) {
     if (!c) return 0;
+    enter(c);
     if ((c->fold_n != 0 || c->plain_n != 0) && hipSetDevice(c->device) == hipSuccess) (void)apply_pending(c);
     return (long long)c->n_live;
 }
@@ -1692,6 +1736,7 @@ static void account_deleted(lio_ctx* c, int total) {
 }
 int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_deleted) {
     if (!c || nb < 0 || (nb > 0 && !minmax6)) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (n_deleted) *n_deleted = 0;
     if (nb == 0 || c->n_points == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1720,6 +1765,7 @@ int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_delete
 int lio_fov_segment(lio_ctx* c, const double pos_lid[3], double cube_len, float det_range, float* boxes_out,
                     int* n_boxes, int* n_deleted) {
     if (!c || !pos_lid) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (n_boxes) *n_boxes = 0;
     if (n_deleted) *n_deleted = 0;
     const float MOV_THRESHOLD = 1.5f;                                        // :53
@@ -1771,6 +1817,7 @@ int lio_fov_segment(lio_ctx* c, const double pos_lid[3], double cube_len, float 
 
 int lio_map_flatten(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
     if (!c || cap < 0 || (cap > 0 && !out_xyz)) return LIO_ERR_INVALID_ARG;
+    enter(c);
     HIPCHK(c, hipSetDevice(c->device));
     if (n) *n = (long long)c->n_live;
     if (c->n_points == 0 || cap == 0) return LIO_OK;
@@ -1792,6 +1839,7 @@ int lio_map_flatten(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
 
 int lio_map_acquire_removed_points(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
     if (!c || !n || cap < 0) return LIO_ERR_INVALID_ARG;
+    enter(c);
     HIPCHK(c, hipSetDevice(c->device));
     {
         const int rc0 = collect_box_deleted(c);
@@ -1828,6 +1876,7 @@ int lio_map_get_info(lio_ctx* c, lio_map_info* info) {
 int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_bytes, float* out_xyz,
                            float* out_sqdist, int* out_count) {
     if (!c || n < 0 || (n > 0 && !q_xyz) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (n == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
     if (n > c->cap_qs) {
@@ -1867,6 +1916,9 @@ int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_byt
 
 // ---- scan + measurement ----------------------------------------------------------------------
 static int scan_reset(lio_ctx* c, int n) {
+    // the passes of the scan that ends here (the converge flag of every lio_measure_begin) predict the next scan's: what
+    // lio_measure_begin arms ahead of its pose (gate_arm)
+    if (!c->pattern_cur.empty()) { c->pattern_prev.swap(c->pattern_cur); c->pattern_cur.clear(); }
     c->nq = n;
     c->have_scan = true; c->have_search = false; c->have_pass = false; c->last_m = 0; c->hint_valid = false;
     // point_selected_surf starts all-true (laserMapping.cpp:2131), but nothing reads it before the first pass of
@@ -1876,6 +1928,7 @@ static int scan_reset(lio_ctx* c, int n) {
 }
 int lio_scan_set(lio_ctx* c, const float* body_pts, int n, int stride_bytes) {
     if (!c || n < 0 || (n > 0 && !body_pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_set", "n exceeds max_scan_points");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = upload_points(c, body_pts, (size_t)n, stride_bytes, c->d_body);
@@ -1884,10 +1937,48 @@ int lio_scan_set(lio_ctx* c, const float* body_pts, int n, int stride_bytes) {
 }
 int lio_scan_set_device(lio_ctx* c, const void* d_body_f4, int n) {
     if (!c || n < 0 || (n > 0 && !d_body_f4)) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_set_device", "n exceeds max_scan_points");
     HIPCHK(c, hipSetDevice(c->device));
     if (n > 0) HIPCHK(c, hipMemcpyAsync(c->d_body, d_body_f4, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     return scan_reset(c, n);
+}
+// page-locked host memory known to the HIP runtime (lio_host_alloc, lio_host_register, hipHostMalloc, hipHostRegister)?
+static bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+// feats_down_body handed over WITHOUT waiting for it to arrive (the drop-in callback path: lio::scan_changed right behind the
+// node's voxel filter, laserMapping.cpp:2322-2325).  Page-locked records the runtime knows: a kernel pulls x, y, z over PCIe
+// itself (launch_scan_pull; no host work at all, the call returns after one launch) -- the records must then stay untouched until
+// the first measurement pass of the scan has returned.  Any other memory: packed into the staging buffer before the call
+// returns, the copy is not waited for.  Either way the passes that follow are ordered behind the upload on the stream.
+int lio_scan_set_async(lio_ctx* c, const float* body_pts, int n, int stride_bytes) {
+    if (!c || n < 0 || (n > 0 && !body_pts) || stride_bytes < 12 || (stride_bytes & 3) != 0) return LIO_ERR_INVALID_ARG;
+    if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_set_async", "n exceeds max_scan_points");
+    enter(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > 0 && is_pinned_host(body_pts) && is_pinned_host(reinterpret_cast<const char*>(body_pts) + (size_t)(n - 1) * (size_t)stride_bytes + 11)) {
+        void* alias = nullptr;
+        HIPCHK(c, hipHostGetDevicePointer(&alias, const_cast<float*>(body_pts), 0));
+        HIPCHK(c, launch_scan_pull(alias, stride_bytes, n, c->d_body, c->stream));
+        ++c->n_scan_pulled;
+        return scan_reset(c, n);
+    }
+    const int rc = upload_points(c, body_pts, (size_t)n, stride_bytes, c->d_body);
+    if (rc != LIO_OK) return rc;
+    return scan_reset(c, n);
+}
+int lio_host_register(void* p, size_t bytes) {
+    if (!p || bytes == 0) return LIO_ERR_INVALID_ARG;
+    if (hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return LIO_ERR_HIP; }
+    return LIO_OK;
+}
+int lio_host_unregister(void* p) {
+    if (!p) return LIO_ERR_INVALID_ARG;
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return LIO_ERR_HIP; }
+    return LIO_OK;
 }
 int lio_scan_size(lio_ctx* c) { return c ? c->nq : 0; }
 
@@ -1911,6 +2002,7 @@ int lio_scan_upload_async(lio_ctx* c, const void* host_f4, int n) {
 }
 int lio_scan_swap(lio_ctx* c) {
     if (!c) return LIO_ERR_INVALID_ARG;
+    enter(c);
     HIPCHK(c, hipSetDevice(c->device));
     if (c->upload_pending) {
         const int rc = issue_pending_upload(c);
@@ -1936,12 +2028,6 @@ void* lio_host_alloc(size_t bytes) {
 void lio_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 // ---- raw-scan preparation: UndistortPcl's compensation + pcl::VoxelGrid ----
-// page-locked host memory known to the HIP runtime (lio_host_alloc, hipHostMalloc, hipHostRegister)?
-static bool is_pinned_host(const void* p) {
-    hipPointerAttribute_t at{};
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return at.type == hipMemoryTypeHost;
-}
 static int ensure_raw_buffers(lio_ctx* c, size_t n) {
     if (!c->d_imu_poses) HIPCHK(c, hipMalloc((void**)&c->d_imu_poses, 512 * 22 * sizeof(double)));
     if (!c->d_vox) HIPCHK(c, hipMalloc((void**)&c->d_vox, 2 * sizeof(VoxelGridDev)));
@@ -1975,6 +2061,7 @@ int lio_scan_upload_raw(lio_ctx* c, const float* raw_pts, int n, int stride_byte
     if (!c || n < 0 || (n > 0 && !raw_pts) || stride_bytes < 12 ||
         (time_offset_bytes >= 0 && (time_offset_bytes < 12 || time_offset_bytes + 4 > stride_bytes)))
         return LIO_ERR_INVALID_ARG;
+    enter(c);
     if ((size_t)n > c->temp_bytes / 16) return c->fail(LIO_ERR_CAPACITY, "lio_scan_undistort", "raw scan larger than the sort workspace");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -2005,7 +2092,7 @@ int lio_scan_upload_raw(lio_ctx* c, const float* raw_pts, int n, int stride_byte
     }
     HIPCHK(c, hipMemcpyAsync(c->d_raw, c->h_stage, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipEventRecord(c->ev_stage, s));
-    c->stage_busy = true;                                                      // waited for by the next writer of h_stage
+    c->stage_busy = true; c->stage_busy_slots = (size_t)n;                     // waited for by the next writer of h_stage
     return LIO_OK;
 }
 
@@ -2013,6 +2100,7 @@ int lio_scan_upload_raw(lio_ctx* c, const float* raw_pts, int n, int stride_byte
 // taken as it is.
 int lio_scan_compensate(lio_ctx* c, const lio_pose6d* imu_poses, int n_poses, const double end_state14[14]) {
     if (!c || n_poses < 0 || n_poses > 512 || (n_poses > 0 && (!imu_poses || !end_state14))) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (!c->raw_uploaded) return c->fail(LIO_ERR_NO_SCAN, "lio_scan_compensate", "no raw scan uploaded");
     if (n_poses > 0 && !c->raw_time_keyed) return LIO_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2028,11 +2116,15 @@ int lio_scan_compensate(lio_ctx* c, const lio_pose6d* imu_poses, int n_poses, co
     }
     // the poses go through the tail of the pinned staging buffer (bytes the point copy does not read)
     static_assert(sizeof(lio_pose6d) == 22 * sizeof(double), "Pose6D layout");
+    if (c->stage_busy && c->stage_busy_slots > c->h_stage_cap - POSE_STAGE_SLOTS) {   // (a copy in flight reads the tail too: not the raw upload's)
+        HIPCHK(c, hipEventSynchronize(c->ev_stage));
+        c->stage_busy = false;
+    }
     lio_pose6d* h_poses = reinterpret_cast<lio_pose6d*>(c->h_stage + (c->h_stage_cap - POSE_STAGE_SLOTS));
     std::memcpy(h_poses, imu_poses, (size_t)n_poses * sizeof(lio_pose6d));
     HIPCHK(c, hipMemcpyAsync(c->d_imu_poses, h_poses, (size_t)n_poses * sizeof(lio_pose6d), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipEventRecord(c->ev_stage, s));
-    c->stage_busy = true;
+    c->stage_busy = true; c->stage_busy_slots = c->h_stage_cap;
     // The compensation of a point depends on nothing but the point: it runs in input order.  The order
     // sort(pcl_out.points.begin(), pcl_out.points.end(), time_list) (:251) establishes is produced where it is
     // consumed -- as the minor key of the voxel filter's sort, or on demand by lio_scan_get_cloud (stable: ties keep
@@ -2072,6 +2164,7 @@ static int sort_undistorted_by_time(lio_ctx* c) {
 // become the current scan (as lio_scan_set would).
 int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
     if (!c || !(leaf_size > 0.0f)) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (n_out) *n_out = 0;
     if (!c->have_raw) return c->fail(LIO_ERR_NO_SCAN, "lio_scan_voxel_filter", "no raw scan (lio_scan_undistort first)");
     HIPCHK(c, hipSetDevice(c->device));
@@ -2156,6 +2249,7 @@ int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
 // which = 0: feats_undistort (time-sorted, compensated); 1: the current scan (feats_down_body)
 int lio_scan_get_cloud(lio_ctx* c, int which, float* out_xyz, int cap, int* n) {
     if (!c || (which != 0 && which != 1) || cap < 0 || (cap > 0 && !out_xyz)) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (which == 0 && c->have_raw) {
         HIPCHK(c, hipSetDevice(c->device));
         const int rc0 = sort_undistorted_by_time(c);
@@ -2295,17 +2389,36 @@ static int gate_arm(lio_ctx* c, bool do_search, bool ext) {
     return LIO_OK;
 }
 
+// The passes that follow the one just put on the stream, as the previous scan's update ran them (pattern_prev): enqueued now,
+// each behind a gate (gate_arm) -- during a search pass there is time to arm two, during a short one there is not.  Any caller
+// of lio_measure / lio_measure_begin gets this (the reference's callback included: h_share_model -> lio_measure); a prediction
+// that fails, or any other entry point that needs the stream, calls the armed passes off (enter()).
+static int arm_predicted(lio_ctx* c, bool searching, bool ext) {
+    const int arm_up_to = searching ? lio_ctx::GATE_AHEAD : 1;
+    for (size_t next = c->pattern_cur.size() + (size_t)c->gate_n; c->gate_n < arm_up_to && next < c->pattern_prev.size(); ++next) {
+        bool kind = c->pattern_prev[next] != 0;
+        if (c->dbg_gate_mispredict) kind = !kind;
+        const int before = c->gate_n;
+        const int rc = gate_arm(c, kind, ext);
+        if (rc != LIO_OK) return rc;
+        if (c->gate_n == before) break;                         // the context declined
+    }
+    return LIO_OK;
+}
+
 int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int extrinsic_est_en) {
     if (!c || !state14) return LIO_ERR_INVALID_ARG;
     c->stamp(do_search ? 'B' : 'b');
     if (c->pass_in_flight) return c->fail(LIO_ERR_INVALID_ARG, "lio_measure_begin", "the previous pass has not been collected (lio_measure_end)");
     if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "no scan set");
     if (!do_search && !c->have_search) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "first pass of a scan must search");
+    if (c->map_broken) return c->fail(LIO_ERR_NO_MAP, "lio_measure", "the map index is undefined after a failed update: Build / reconstruct it");
     HIPCHK(c, hipSetDevice(c->device));
     const int nq = c->nq;
     Pose14 pose;
     for (int i = 0; i < 14; ++i) pose.v[i] = state14[i];
     const bool ext = extrinsic_est_en != 0;
+    bool released = false;
     if (c->gate_n > 0) {
         const lio_ctx::ArmedPass ap = c->gate_q[0];
         if (ap.search == (do_search != 0) && ap.ext == ext && !c->want_rows && nq != 0) {
@@ -2314,28 +2427,24 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
             for (int i = 1; i < c->gate_n; ++i) c->gate_q[i - 1] = c->gate_q[i];
             --c->gate_n;
             ++c->n_gate_released;
-            c->last_pose = pose; c->last_ext = ext;
-            c->pass_in_flight = true; c->pass_empty = false;
-            c->pass_searched = do_search != 0;
-            if (do_search) { c->have_search = true; c->hint_valid = true; }
-            c->rows_staged = false;
             c->pass_seq = ap.pass_seq;
-            c->stamp('L');
-            return LIO_OK;
+            released = true;
+        } else {
+            gate_call_off(c);
         }
-        gate_call_off(c);
     }
     c->last_pose = pose; c->last_ext = ext;
-    c->pass_in_flight = true; c->pass_empty = nq == 0;
+    c->pass_in_flight = true; c->pass_empty = nq == 0; c->pass_gated = released;
     if (nq == 0) return LIO_OK;                               // "No Effective Points" laserMapping.cpp:1956
     hipStream_t s = c->stream;
     c->pass_searched = do_search != 0;
     c->rows_staged = false;
-    {
+    c->pattern_cur.push_back(do_search ? 1 : 0);
+    if (!released) {
         const int rc = enqueue_pass(c, pose, do_search != 0, ext, walk_in_its_own_launch(c), nullptr, &c->pass_seq);
         if (rc != LIO_OK) { c->pass_in_flight = false; return rc; }
-        if (do_search) { c->have_search = true; c->hint_valid = true; }
     }
+    if (do_search) { c->have_search = true; c->hint_valid = true; }
     c->stamp('L');
     if (c->want_rows) {
         // right behind the pass: the rows of the selected points, compacted in scan order, column-major (m read on the device)
@@ -2346,6 +2455,16 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
         const hipError_t ce = launch_rows_compact(rc, s);
         if (ce != hipSuccess) { lio_out dropped; (void)lio_measure_end(c, &dropped); return c->fail(LIO_ERR_HIP, "launch_rows_compact", hipGetErrorString(ce)); }
         c->rows_staged = true;
+    }
+    // the passes behind this one, as predicted: onto the stream now (their launch calls run beside the GPU's work)
+    {
+        const int rc = arm_predicted(c, do_search != 0, ext);
+        if (rc != LIO_OK) {                                   // the pass itself is fine: collect it, report
+            const std::string why = c->err;
+            lio_out dropped;
+            (void)lio_measure_end(c, &dropped);
+            return c->fail(rc, "lio_measure_begin (arming the next pass)", why.c_str());
+        }
     }
     // the next scan's upload, if one was handed over (lio_scan_upload_async): issued here, behind this pass's
     // launches, so that the runtime calls of the copy run while the GPU is busy with the pass
@@ -2361,6 +2480,7 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     return LIO_OK;
 }
 
+static int lio_measure_end_again(lio_ctx* c, lio_out* out) { c->pass_in_flight = true; return lio_measure_end(c, out); }
 int lio_measure_end(lio_ctx* c, lio_out* out) {
     if (!c || !out) return LIO_ERR_INVALID_ARG;
     if (!c->pass_in_flight) return c->fail(LIO_ERR_INVALID_ARG, "lio_measure_end", "no pass in flight (lio_measure_begin)");
@@ -2381,6 +2501,16 @@ int lio_measure_end(lio_ctx* c, lio_out* out) {
                 const hipError_t q = hipStreamQuery(s);
                 if (q == hipSuccess) {
                     if (__atomic_load_n(pseq, __ATOMIC_ACQUIRE) == seq) break;
+                    if (c->pass_gated) {
+                        // the pass sat behind a gate that gave up before the host's word came (a host stalled for seconds:
+                        // debugger, SIGSTOP, VM pause) and stood down: put it on the stream directly, once
+                        c->pass_gated = false;
+                        ++c->n_gate_reenqueued;
+                        gate_call_off(c);
+                        const int rc = enqueue_pass(c, c->last_pose, c->pass_searched, c->last_ext, walk_in_its_own_launch(c), nullptr, &c->pass_seq);
+                        if (rc != LIO_OK) return rc;
+                        return lio_measure_end_again(c, out);
+                    }
                     return c->fail(LIO_ERR_HIP, "lio_measure", "stream idle but result record not published");
                 }
                 if (q != hipErrorNotReady) return c->fail(LIO_ERR_HIP, "lio_measure", hipGetErrorString(q));
@@ -2414,6 +2544,7 @@ int lio_measure(lio_ctx* c, const double state14[14], int do_search, int extrins
 
 int lio_measure_want_rows(lio_ctx* c, int on) {
     if (!c) return LIO_ERR_INVALID_ARG;
+    enter(c);                                   // (an armed pass was built for the old setting)
     c->want_rows = on != 0;
     return LIO_OK;
 }
@@ -2430,8 +2561,19 @@ int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_m
     if (c->rows_staged) {
         // the pass left them compacted and column-major (lio_measure_want_rows): nothing is re-evaluated, nothing but the m
         // rows crosses PCIe -- written by the kernel itself (small scans) or moved by the copy engine (large ones)
-        if (!rows_direct(c, nq))
+        if (!rows_direct(c, nq)) {
+            // destinations the runtime knows as page-locked (the adaptor registers ekfom_data.h_x / .h, lio_host_register): the copy
+            // engine writes them where they are -- no pass through h_rows, no 9.6 MB host copy per pass at 100 k points
+            if (col_major && is_pinned_host(h_x) && is_pinned_host(reinterpret_cast<char*>(h_x) + (size_t)m * 12 * sizeof(double) - 1) &&
+                is_pinned_host(h) && is_pinned_host(reinterpret_cast<char*>(h) + (size_t)m * sizeof(double) - 1)) {
+                HIPCHK(c, hipMemcpyAsync(h_x, c->d_rows_c, (size_t)m * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipMemcpyAsync(h, c->d_rows_c + (size_t)12 * m, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+                HIPCHK(c, stream_wait(c));
+                ++c->n_rows_direct_dma;
+                return LIO_OK;
+            }
             HIPCHK(c, hipMemcpyAsync(c->h_rows, c->d_rows_c, (size_t)m * 13 * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
         HIPCHK(c, stream_wait(c));
         const double* src = c->h_rows;
         if (col_major) {
@@ -2477,6 +2619,7 @@ int lio_measure_rows(lio_ctx* c, double* h_x, double* h, int cap_rows, int col_m
 
 int lio_get_neighbors(lio_ctx* c, float* out_xyz, float* out_sqdist, int* out_count) {
     if (!c) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (!c->have_search) return c->fail(LIO_ERR_NO_SCAN, "lio_get_neighbors", "no search pass yet");
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->nq;
@@ -2498,6 +2641,7 @@ int lio_get_neighbors(lio_ctx* c, float* out_xyz, float* out_sqdist, int* out_co
 
 int lio_get_scan_state(lio_ctx* c, float* world_xyz, uint8_t* selected, float* normvec) {
     if (!c) return LIO_ERR_INVALID_ARG;
+    enter(c);
     if (!c->have_pass) return c->fail(LIO_ERR_NO_SCAN, "lio_get_scan_state", "no measurement pass yet");
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->nq;
@@ -2528,6 +2672,7 @@ int lio_get_scan_state(lio_ctx* c, float* world_xyz, uint8_t* selected, float* n
 // ---- profiling -----------------------------------------------------------------------------------
 int lio_profile_enable(lio_ctx* c, int on) {
     if (!c) return LIO_ERR_INVALID_ARG;
+    enter(c);
     HIPCHK(c, hipSetDevice(c->device));
     // (the recorded pairs are resolved by lio_profile_get / lio_profile_reset -- that takes a drained stream -- or when a pool
     // runs full; switching the timers on and off costs nothing, so a caller can time every n-th step of a loop)
@@ -2537,6 +2682,7 @@ int lio_profile_enable(lio_ctx* c, int on) {
 }
 int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (!c || !key) return LIO_ERR_INVALID_ARG;
+    enter(c);                                   // (switches change what a pass does: none stays armed across one)
     if (std::strcmp(key, "force_reduction_timeout") == 0) { c->dbg_force_timeout = value != 0; return LIO_OK; }
     if (std::strcmp(key, "separate_tree_walk") == 0) { c->dbg_separate_walk = value != 0; return LIO_OK; }
     if (std::strcmp(key, "library_sort") == 0) { c->dbg_library_sort = value != 0; return LIO_OK; }
@@ -2576,6 +2722,9 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "retired_budget") == 0) { *value = (long long)retired_slot_budget(c); return LIO_OK; }
     if (std::strcmp(key, "voxel_fast_runs") == 0) { *value = c->n_voxel_fast; return LIO_OK; }
     if (std::strcmp(key, "voxel_redone") == 0) { *value = c->n_voxel_redone; return LIO_OK; }
+    if (std::strcmp(key, "gate_reenqueued") == 0) { *value = c->n_gate_reenqueued; return LIO_OK; }
+    if (std::strcmp(key, "scan_pulled") == 0) { *value = c->n_scan_pulled; return LIO_OK; }
+    if (std::strcmp(key, "rows_direct_dma") == 0) { *value = c->n_rows_direct_dma; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_get", "unknown key");
 }
 int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {
@@ -2583,9 +2732,10 @@ int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {
     for (int i = 0; i < 8; ++i) out8[i] = c->h_out->dbg[i];
     return LIO_OK;
 }
-int lio_census_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; c->census = on != 0; return LIO_OK; }
+int lio_census_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; enter(c); c->census = on != 0; return LIO_OK; }
 int lio_profile_reset(lio_ctx* c) {
     if (!c) return LIO_ERR_INVALID_ARG;
+    enter(c);
     HIPCHK(c, hipSetDevice(c->device));
     prof_collect(c);
     for (int w = 0; w < LIO_PROF_COUNT; ++w) { c->prof_ms[w] = 0.0; c->prof_n[w] = 0; }
@@ -2593,6 +2743,7 @@ int lio_profile_reset(lio_ctx* c) {
 }
 int lio_profile_get(lio_ctx* c, int which, double* total_ms, long long* launches) {
     if (!c || which < 0 || which >= LIO_PROF_COUNT) return LIO_ERR_INVALID_ARG;
+    enter(c);
     prof_collect(c);
     if (total_ms) *total_ms = c->prof_ms[which];
     if (launches) *launches = c->prof_n[which];
@@ -2635,8 +2786,8 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
                                                 lio_update_log* log) {
     if (!kf || !ctx || !(R > 0.0)) return LIO_ERR_INVALID_ARG;
     int status = LIO_OK;
-    // (the converge flag of every call: the prediction of the NEXT update's passes, which are enqueued ahead of their pose)
-    ctx->pattern_cur.clear();
+    // (the converge flag of every call -- recorded by lio_measure_begin -- predicts the NEXT update's passes)
+    if (!ctx->pattern_cur.empty()) { ctx->pattern_prev.swap(ctx->pattern_cur); ctx->pattern_cur.clear(); }
     // the reference's h_share_model, bound to the GPU path (laserMapping.cpp:1876 <-> lio_measure), in two halves so
     // that the filter's result-independent algebra runs while the GPU works on the pass
     kf->kf.set_measurement_model_async(
@@ -2644,20 +2795,9 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
             if (status != LIO_OK) return;
             double pose[14];
             s.pose14(pose);
-            ctx->pattern_cur.push_back(d.converge ? 1 : 0);
+            // (lio_measure_begin also puts the passes after this one onto the stream, each behind a gate, as the previous update ran them)
             const int rc = lio_measure_begin(ctx, pose, d.converge ? 1 : 0, extrinsic_est_en);
             if (rc != LIO_OK) { status = rc; return; }
-            // the passes after this one, as the previous update ran them: onto the stream now, each behind a gate
-            // (lio_measure_begin) -- during a search pass there is time to arm two, during a short one there is not
-            const int arm_up_to = d.converge ? lio_ctx::GATE_AHEAD : 1;
-            for (size_t next = ctx->pattern_cur.size() + (size_t)ctx->gate_n; ctx->gate_n < arm_up_to && next < ctx->pattern_prev.size(); ++next) {
-                bool kind = ctx->pattern_prev[next] != 0;
-                if (ctx->dbg_gate_mispredict) kind = !kind;
-                const int before = ctx->gate_n;
-                const int rc2 = gate_arm(ctx, kind, extrinsic_est_en != 0);
-                if (rc2 != LIO_OK) { status = rc2; break; }
-                if (ctx->gate_n == before) break;              // the context declined
-            }
         },
         [&](lio::dyn_share_datastruct& d) {
             if (status != LIO_OK) { d.valid = false; d.m = 0; return; }
@@ -2680,6 +2820,7 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
     kf->kf.update_iterated_dyn_share_modified(R, solve_time);
     gate_call_off(ctx);                          // the update ended earlier than the previous one: nothing stays armed
     ctx->pattern_prev.swap(ctx->pattern_cur);
+    ctx->pattern_cur.clear();
     if (log) {
         const lio::update_stats& st = kf->kf.stats();
         log->n_calls = st.n_calls; log->n_search = st.n_search; log->converged = st.converged ? 1 : 0;
@@ -2692,6 +2833,7 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
 // h_x^T h_x / h_x^T h are formed here (esekfom.hpp:1790,1810) -- column blocks that stay in the L1 / L2 of one core
 int lio_eskf_update_iterated_dyn_share_callback(lio_eskf* kf, double R, lio_h_dyn_share_fn h, void* user, lio_update_log* log) {
     if (!kf || !h || !(R > 0.0)) return LIO_ERR_INVALID_ARG;
+    int status = LIO_OK;
     kf->kf.set_measurement_model([&](lio::state_ikfom& s, lio::dyn_share_datastruct& d) {
         double x26[26];
         s.to_array(x26);
@@ -2703,6 +2845,9 @@ int lio_eskf_update_iterated_dyn_share_callback(lio_eskf* kf, double R, lio_h_dy
         d.m = ds.m;
         d.res_mean = 0.0;
         if (!d.valid) return;
+        // what h_share_model guarantees (laserMapping.cpp:1956-1961: valid = false when effct_feat_num < 1) is checked, not trusted
+        if (ds.m < 1) { d.valid = false; d.m = 0; return; }
+        if (ds.h_x != nullptr && ds.h == nullptr) { status = LIO_ERR_INVALID_ARG; d.valid = false; d.m = 0; return; }
         if (ds.h_x == nullptr) {
             std::memcpy(d.HTH, ds.HTH, sizeof(d.HTH));
             std::memcpy(d.HTh, ds.HTh, sizeof(d.HTh));
@@ -2728,7 +2873,7 @@ int lio_eskf_update_iterated_dyn_share_callback(lio_eskf* kf, double R, lio_h_dy
         log->last_m = st.last_m; log->last_res_mean = st.last_res_mean;
         log->solve_seconds = st.solve_seconds; log->measure_seconds = st.measure_seconds;
     }
-    return LIO_OK;
+    return status;
 }
 int lio_eskf_scan_step_device(lio_eskf* kf, lio_ctx* ctx, const double x26[26], const double P[23 * 23],
                               const void* d_body_f4, int n, double R, int extrinsic_est_en, lio_update_log* log) {

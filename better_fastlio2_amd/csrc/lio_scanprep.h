@@ -26,6 +26,11 @@ struct VoxelGridDev {
 };
 constexpr uint32_t VOX_EMPTY = 1u, VOX_OVERFLOW = 2u;
 
+// feats_down_body straight out of the node's host cloud: one lane per record PULLS x, y, z (the first three floats of a record of
+// `stride_bytes`, e.g. pcl::PointXYZINormal's 48) over PCIe from page-locked host memory through its device alias and writes the
+// float4 scan buffer -- no host-side pack, no staging copy, no copy-engine latency (scripts/micro/upload_probe.hip: 8.6 k records
+// 16 us against 26 us for pack + copy; 100 k records 103-124 us against 90-200 us, with NO host time)
+hipError_t launch_scan_pull(const void* src_device_alias, int stride_bytes, int n, float4* dst, hipStream_t s);
 // key[i] = order-preserving image of pts[i].w (time offset), order[i] = i
 hipError_t launch_time_keys(const float4* pts, int n, uint64_t* keys, uint32_t* order, hipStream_t s);
 hipError_t launch_undistort(const float4* raw, int n, const double* poses, int n_poses, const Pose14& end, float4* out,

@@ -290,6 +290,29 @@ hipError_t launch_time_keys(const float4* pts, int n, uint64_t* keys, uint32_t* 
     hipLaunchKernelGGL(time_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, keys, order);
     return hipGetLastError();
 }
+// one lane per host record; records whose x, y, z, pad sit on a 16-byte boundary take one 16-byte read, others three 4-byte reads
+template <bool ALIGNED16>
+__global__ __launch_bounds__(256) void scan_pull_kernel(const char* __restrict__ src, int stride, int n, float4* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const char* rec = src + (size_t)i * (size_t)stride;
+    float4 v;
+    if (ALIGNED16) {
+        v = *reinterpret_cast<const float4*>(rec);
+    } else {
+        const float* p = reinterpret_cast<const float*>(rec);
+        v.x = p[0]; v.y = p[1]; v.z = p[2];
+    }
+    v.w = 0.0f;
+    dst[i] = v;
+}
+hipError_t launch_scan_pull(const void* src_device_alias, int stride_bytes, int n, float4* dst, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const bool aligned = stride_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(src_device_alias) & 15u) == 0u;
+    if (aligned) hipLaunchKernelGGL(scan_pull_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s, (const char*)src_device_alias, stride_bytes, n, dst);
+    else hipLaunchKernelGGL(scan_pull_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s, (const char*)src_device_alias, stride_bytes, n, dst);
+    return hipGetLastError();
+}
 hipError_t launch_undistort(const float4* raw, int n, const double* poses, int n_poses, const Pose14& end, float4* out,
                             hipStream_t s) {
     if (n <= 0) return hipSuccess;

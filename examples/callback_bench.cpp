@@ -6,7 +6,10 @@
 // bench.py and the tests drive through ctypes; the node-side types are the stand-ins of tests/csrc/adaptor_stubs (Eigen and
 // PCL are not in the image), laid out like the real ones (48-byte PointXYZINormal, column-major h_x).
 //   patched != 0: the "two-line patch" of INTEGRATION.md section 3 -- the callback hands over lio_measure's reduced form
-//                 (HTH / HTh) instead of rows; everything else (host-resident scan, synchronous passes) stays.
+//                 (HTH / HTh) instead of rows; everything else (host-resident scan, synchronous callback) stays.
+// What the adaptor does on its own in both forms: lio::scan_changed(ikdtree, G) starts the upload of the 48-byte records the
+// moment the node has them (a kernel pulls x, y, z out of the page-locked cloud), and lio_measure puts the passes it expects
+// next onto the stream ahead of their pose (the previous scan's converge pattern), so a callback mostly just mails a pose.
 #include "use-ikfom.hpp"            // stand-ins: state_ikfom, esekfom::dyn_share_datastruct
 #include <ikd-Tree/ikd_Tree.h>     // stand-ins: PointType, PointVector, StubCloud
 #include <memory>
@@ -33,6 +36,7 @@ std::unique_ptr<lio::NodeGlobals<PointType, CloudPtr, std::vector<PointVector>>>
 std::vector<CloudPtr> scans;                                            // what downSizeFilterSurf.filter left, one cloud per scan of the drive
 DynShare dyn;                                                           // the filter's dyn_share (esekfom.hpp:1636)
 bool patched_mode = false;
+bool legacy_scan_changed = false;
 double seconds_in_model = 0.0;                                           // inside the callback (library + adaptor), summed over the passes
 
 void h_share_model(state_ikfom& s, DynShare& ekfom_data) { lio::h_share_model(ikdtree, s, ekfom_data, *G); }   // :1876
@@ -52,23 +56,20 @@ struct ModelClock {
 void model(void*, const double x26[26], lio_dyn_share* d) {
     ModelClock clock;
     state_ikfom s = state_of(x26);
+    dyn.converge = d->converge != 0; dyn.valid = true;
     if (!patched_mode) {
-        dyn.converge = d->converge != 0; dyn.valid = true;
         h_share_model(s, dyn);
         d->valid = dyn.valid ? 1 : 0; d->m = effct_feat_num;
         d->h_x = dyn.h_x.data(); d->h = dyn.h.data();
         return;
     }
-    // two-line patch: same callback position, the reduced form instead of rows
-    lio_ctx* ctx = ikdtree.ctx();
-    if (ikdtree.scan_dirty) {
-        const auto& pts = feats_down_body->points;
-        if (lio_scan_set(ctx, pts.size() ? &pts[0].x : nullptr, feats_down_size, (int)sizeof(PointType)) != LIO_OK) { d->valid = 0; return; }
-        ikdtree.scan_dirty = false;
-    }
+    // two-line patch: same callback, same adaptor; the filter takes the reduced form (lio_out::HTH / ::HTh) instead of rows
     lio_out o;
-    if (lio_measure(ctx, x26, d->converge, extrinsic_est_en ? 1 : 0, &o) != LIO_OK) { d->valid = 0; return; }
-    d->valid = o.valid; d->m = o.m; d->h_x = nullptr; d->h = nullptr;
+    lio::h_share_model(ikdtree, s, dyn, *G, &o);
+    d->valid = dyn.valid ? 1 : 0; d->m = effct_feat_num;
+    if (!dyn.valid) return;
+    if (o.m < 23) { d->h_x = dyn.h_x.data(); d->h = dyn.h.data(); return; }   // the dense-gain branch works on rows (esekfom.hpp:1720-1750)
+    d->h_x = nullptr; d->h = nullptr;
     std::memcpy(d->HTH, o.HTH, sizeof(o.HTH)); std::memcpy(d->HTh, o.HTh, sizeof(o.HTh));
 }
 }  // namespace
@@ -76,6 +77,7 @@ void model(void*, const double x26[26], lio_dyn_share* d) {
 extern "C" {
 // the facade works on an existing context (the bench built the 5 M-point map in it)
 int cbb_setup(lio_ctx* ctx, int max_scan_points) {
+    ikdtree.pins.drop_all();                                            // (the clouds of a previous set-up are about to be freed; its context may be gone)
     ikdtree.adopt(ctx);
     res_last.assign((size_t)max_scan_points, 0.0f);
     point_selected_surf.reset(new bool[(size_t)max_scan_points]());
@@ -104,9 +106,11 @@ int cbb_step(lio_eskf* kf, int k, const double* x26, const double* P, double R, 
     try {
         feats_down_body = scans[(size_t)k];
         feats_down_size = (int)feats_down_body->points.size();
-        lio::scan_changed(ikdtree);
         extrinsic_est_en = ext != 0;
         patched_mode = patched != 0;
+        ikdtree.reset_status();
+        if (legacy_scan_changed) lio::scan_changed(ikdtree);        // round 3's form: the first callback uploads the cloud
+        else lio::scan_changed(ikdtree, *G);                         // :2325 -- the upload starts here, nobody waits for it
         int rc = lio_eskf_change_x(kf, x26);
         if (rc == LIO_OK) rc = lio_eskf_change_P(kf, P);
         if (rc == LIO_OK) rc = lio_eskf_update_iterated_dyn_share_callback(kf, R, model, nullptr, log);
@@ -117,6 +121,17 @@ int cbb_step(lio_eskf* kf, int k, const double* x26, const double* P, double R, 
     }
 }
 int cbb_last_m(void) { return effct_feat_num; }
+// status of the last library call the adaptor reported as failed during the last step (LIO_OK: none) -- in the default,
+// non-throwing mode a failure costs the pass (ekfom_data.valid = false), not the node
+int cbb_last_status(void) { return ikdtree.last_status; }
+// knobs: 0 = page-locking of the node's buffers off (staging copies), 1 = exceptions instead of valid = false,
+// 2 = the one-argument scan_changed (upload inside the first callback), 3 = size in bytes from which h_x / h are page-locked
+void cbb_option(int which, int value) {
+    if (which == 0) ikdtree.pin_host_buffers = value != 0;
+    if (which == 1) ikdtree.throw_on_error = value != 0;
+    if (which == 2) legacy_scan_changed = value != 0;
+    if (which == 3) ikdtree.pin_rows_min_bytes = (size_t)value;
+}
 // seconds spent inside the measurement-model callback since the last call (the rest of a step is the filter's own dense algebra)
 double cbb_take_model_seconds(void) { const double t = seconds_in_model; seconds_in_model = 0.0; return t; }
 }

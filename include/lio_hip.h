@@ -193,6 +193,18 @@ int  lio_map_nearest_search(lio_ctx* ctx, const float* q_xyz, int n, int stride_
  * point_selected_surf to all-true (laserMapping.cpp:2131).                                         */
 int  lio_scan_set(lio_ctx* ctx, const float* body_pts, int n, int stride_bytes);
 int  lio_scan_set_device(lio_ctx* ctx, const void* d_body_f4, int n);
+/* lio_scan_set without the wait: for the caller that hands feats_down_body over the moment its voxel filter has written it
+ * (lio::scan_changed, laserMapping.cpp:2322-2325) and goes on with its own work -- the passes that follow are ordered behind the
+ * upload on the stream.  Records in page-locked memory the HIP runtime knows (lio_host_alloc, lio_host_register) are PULLED by a
+ * kernel over PCIe where they lie -- no host-side pack, no staging copy, the call returns after one kernel launch -- and must then
+ * stay untouched until the first measurement pass of the scan has returned; any other memory is packed into the library's staging
+ * buffer before the call returns.  stride_bytes: a multiple of 4 (pcl::PointXYZINormal: 48).                                      */
+int  lio_scan_set_async(lio_ctx* ctx, const float* body_pts, int n, int stride_bytes);
+/* hipHostRegister / hipHostUnregister for callers that do not link the HIP runtime themselves (the adaptor header): page-locks
+ * [p, p + bytes) and maps it for the GPU, so that lio_scan_set_async can pull a cloud and lio_measure_rows can have the copy
+ * engine write h_x / h in place.  The range must stay allocated while it is registered.                                        */
+int  lio_host_register(void* p, size_t bytes);
+int  lio_host_unregister(void* p);
 /* Pipelined hand-over (the node receives scan k+1 while scan k is being processed): lio_scan_upload_async enqueues
  * the host-to-device copy of n float4 records (x, y, z, _) into the context's BACK scan buffer on a copy stream of
  * its own and returns at once (host_f4 should be pinned -- lio_host_alloc -- and must stay untouched until
@@ -298,7 +310,9 @@ results); "library_sort" sends every sort / compaction of map maintenance and sc
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
 /* counters for tests: "gate_released" / "gate_called_off" = pre-enqueued passes that ran / were called off; "voxel_fast_runs" /
  * "voxel_redone" = voxel-filter attempts on the compact-key path / sweeps filtered twice after a wrong prediction;
- * "retired_budget" = the retired-slot budget in force                                                                      */
+ * "retired_budget" = the retired-slot budget in force; "gate_reenqueued" = passes put on the stream again because their gate had
+ * given up (a host stalled for seconds); "scan_pulled" = scans a kernel pulled out of page-locked host records
+ * (lio_scan_set_async); "rows_direct_dma" = lio_measure_rows calls served by copies straight into page-locked h_x / h            */
 int  lio_debug_get(lio_ctx* ctx, const char* key, long long* value);
 /* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: [0] its start, [1] own partial
  * published, [2] group folded, [3] grid folded, [4] the listed queries' terms folded (search passes that list any),

@@ -27,7 +27,7 @@
 //            corr_normvect, Nearest_Points, point_selected_surf, res_last, feats_down_size, effct_feat_num, res_mean_last,
 //            extrinsic_est_en};
 //     void h_share_model(state_ikfom& s, esekfom::dyn_share_datastruct<double>& d) { lio::h_share_model(ikdtree, s, d, G); }
-//     ... lio::scan_changed(ikdtree);   after downSizeFilterSurf.filter(*feats_down_body)               (:2322-2325)
+//     ... lio::scan_changed(ikdtree, G); after downSizeFilterSurf.filter(*feats_down_body)              (:2322-2325)
 //     ... lio::sync_globals(ikdtree, G); at the top of map_incremental()                                (:1440)
 #ifndef LIO_HIP_ADAPTOR_HPP
 #define LIO_HIP_ADAPTOR_HPP
@@ -43,6 +43,41 @@
 #include "lio_hip.h"
 
 namespace lio {
+
+// Page-locked (hipHostRegister'ed) ranges of the node's memory: the cloud feats_down_body's points live in, ekfom_data.h_x,
+// ekfom_data.h.  ensure() registers [p, p + bytes) unless exactly that range already is -- the node's buffers keep their
+// address from scan to scan (PCL's VoxelGrid resizes the same vector, Eigen's resize() keeps an allocation whose size does not
+// change) -- and first drops every registered range it overlaps (the memory was re-allocated: a stale registration must never be
+// read through).  A few ranges are kept (a node that alternates between clouds), the oldest goes first.  Registration costs
+// tens of microseconds (78 us for 4.8 MB), so ranges below `min_bytes` are not worth it.  Contract: memory handed to ensure()
+// stays allocated until it is handed to ensure() again with another size, or drop_all() is called.  The destructor does NOT
+// unregister: it may run after the HIP runtime has gone.
+struct HostPin {
+    struct Range { char* p; size_t bytes; unsigned long long used; };
+    std::vector<Range> ranges;
+    unsigned long long clock = 0;
+    size_t max_ranges = 16;
+    bool ensure(void* q, size_t n, size_t min_bytes = 65536) {
+        if (q == nullptr || n < min_bytes) return false;
+        char* a = static_cast<char*>(q);
+        for (size_t i = 0; i < ranges.size();) {
+            Range& r = ranges[i];
+            if (r.p == a && r.bytes == n) { r.used = ++clock; return true; }
+            if (a < r.p + r.bytes && r.p < a + n) { (void)lio_host_unregister(r.p); ranges.erase(ranges.begin() + (long)i); continue; }
+            ++i;
+        }
+        if (ranges.size() >= max_ranges) {
+            size_t oldest = 0;
+            for (size_t i = 1; i < ranges.size(); ++i) if (ranges[i].used < ranges[oldest].used) oldest = i;
+            (void)lio_host_unregister(ranges[oldest].p);
+            ranges.erase(ranges.begin() + (long)oldest);
+        }
+        if (lio_host_register(q, n) != LIO_OK) return false;
+        ranges.push_back(Range{a, n, ++clock});
+        return true;
+    }
+    void drop_all() { for (const Range& r : ranges) (void)lio_host_unregister(r.p); ranges.clear(); }
+};
 
 // ikd_Tree.h:14 `enum delete_point_storage_set { NOT_RECORD, DELETE_POINTS_REC, MULTI_THREAD_REC }` -- the node passes
 // NOT_RECORD to flatten (:2364); the facade accepts whatever enum/int arrives there.
@@ -71,10 +106,16 @@ public:
     ~KdTreeFacade() { if (ctx_ && owns_) lio_destroy(ctx_); }
     // a process that created its context elsewhere (e.g. next to other users of the same GPU) hands it over; the facade
     // then neither creates nor destroys one
-    void adopt(lio_ctx* ctx) { if (ctx_ && owns_) lio_destroy(ctx_); ctx_ = ctx; owns_ = false; rows_requested = false; }
+    void adopt(lio_ctx* ctx) {
+        if (ctx_ && owns_) lio_destroy(ctx_);
+        ctx_ = ctx; owns_ = false;
+        if (ctx_) (void)lio_measure_want_rows(ctx_, 0);               // a known starting point whatever the previous owner asked for
+        rows_requested = false; scan_dirty = true; scan_failed = false; globals_stale = false;
+    }
     KdTreeFacade(const KdTreeFacade&) = delete;
     KdTreeFacade& operator=(const KdTreeFacade&) = delete;
 
+    // Without a GPU there is nothing to fall back to: a failed lio_create throws whatever throw_on_error says.
     lio_ctx* ctx() {
         if (!ctx_) {
             lio_config cfg{device_, box_length_, 0.0f, max_scan_, max_map_, 0};
@@ -83,6 +124,29 @@ public:
         }
         return ctx_;
     }
+    // Error behaviour.  The reference's measurement path reports trouble the way ROS nodes do: ekfom_data.valid = false + a
+    // warning (laserMapping.cpp:1956-1961) and the update skips the pass (esekfom.hpp:1641-1644); ikd-Tree printf()s.  Default
+    // here: the same -- a failed library call prints `lio_hip: <what>: <lio_last_error>` on stderr, h_share_model answers
+    // valid = false, map calls return 0 / leave their outputs empty, and the node stays alive.  throw_on_error = true turns
+    // every failure into a std::runtime_error instead (tests, nodes that prefer to die loudly).
+    bool throw_on_error = false;
+    int last_status = LIO_OK;     // status of the last failed call (LIO_OK: none since reset_status())
+    void reset_status() { last_status = LIO_OK; }
+    bool report(int rc, const char* what) const {
+        if (rc == LIO_OK) return true;
+        const_cast<KdTreeFacade*>(this)->last_status = rc;
+        const std::string msg = std::string(what) + ": " + (ctx_ ? lio_last_error(ctx_) : "no context");
+        if (throw_on_error) throw std::runtime_error(msg);
+        std::fprintf(stderr, "lio_hip: %s (status %d)\n", msg.c_str(), rc);
+        return false;
+    }
+    // page-lock the node's host buffers (the cloud the scan is pulled from, h_x / h the rows are copied into) with
+    // lio_host_register; false: every transfer goes through the library's own staging buffers
+    bool pin_host_buffers = true;
+    size_t pin_rows_min_bytes = (size_t)2 << 20;   // row blocks (m x 13 doubles) from this size on are copied straight into page-locked h_x / h
+    HostPin pins;
+    // forget every registration (before the node frees or re-allocates buffers it has handed over)
+    void unpin_all() { if (ctx_) (void)lio_synchronize(ctx_); pins.drop_all(); }
     lio_ctx* ctx() const { return const_cast<KdTreeFacade*>(this)->ctx(); }
 
     void set_downsample_param(float box_length) {                      // ikd_Tree.cpp:186-189; laserMapping.cpp:2332
@@ -149,7 +213,8 @@ public:
     }
 
     // ---- per-scan state of the adaptor (not part of the reference's class) ---------------------------------------
-    bool scan_dirty = true;       // feats_down_body changed since the last lio_scan_set
+    bool scan_dirty = true;       // feats_down_body changed since the last upload
+    bool scan_failed = false;     // ... and the library refused it (reported once; every pass of this scan answers valid = false)
     bool rows_requested = false;  // lio_measure_want_rows(ctx, 1) has been issued (the unmodified IKFoM reads h_x / h)
     bool globals_stale = false;   // a measurement pass ran since the last sync_globals
 
@@ -164,9 +229,7 @@ private:
             out.push_back(p);
         }
     }
-    void check(int rc, const char* what) const {
-        if (rc != LIO_OK) throw std::runtime_error(std::string(what) + ": " + lio_last_error(ctx_));
-    }
+    void check(int rc, const char* what) const { (void)report(rc, what); }
     lio_ctx* ctx_ = nullptr;
     bool owns_ = true;
     float box_length_;
@@ -192,32 +255,55 @@ struct NodeGlobals {
     bool& extrinsic_est_en;           // :44    in
 };
 
-// call after feats_down_body has been refilled (downSizeFilterSurf.filter, laserMapping.cpp:2322-2325)
-template <class PointT> inline void scan_changed(KdTreeFacade<PointT>& tree) { tree.scan_dirty = true; }
-
-// h_share_model (src/laserMapping.cpp:1876-2004)
-template <class PointT, class State, class DynShare, class G>
-inline void h_share_model(KdTreeFacade<PointT>& tree, State& s, DynShare& ekfom_data, G& g) {
+// feats_down_body -> the GPU, without waiting for it to arrive.  Page-locks the cloud's buffer once (its whole capacity, so that
+// a scan of another size inside the same allocation needs no new registration) and lets a kernel pull x, y, z out of the
+// 48-byte records where they lie; with pin_host_buffers off (or a registration that fails) the records are packed into the
+// library's staging buffer instead.  Returns false after reporting (KdTreeFacade::report) when the library refuses the scan.
+template <class PointT, class G>
+inline bool upload_scan(KdTreeFacade<PointT>& tree, G& g) {
     lio_ctx* ctx = tree.ctx();
-    if (!tree.rows_requested) {
+    auto& pts = g.feats_down_body->points;
+    const int n = g.feats_down_size;
+    if (tree.pin_host_buffers && n > 0) (void)tree.pins.ensure(&pts[0], pts.capacity() * sizeof(PointT));
+    const bool ok = tree.report(lio_scan_set_async(ctx, n > 0 ? &pts[0].x : nullptr, n, (int)sizeof(PointT)), "lio_scan_set_async");
+    tree.scan_dirty = !ok;
+    tree.scan_failed = !ok;
+    return ok;
+}
+// call after feats_down_body has been refilled (downSizeFilterSurf.filter, laserMapping.cpp:2322-2325).  With the globals at
+// hand the upload starts HERE, beside the node's own work between the voxel filter and the update (:2326-2379: validnum(),
+// size(), the resizes, the log line); the one-argument form only marks the scan and the first callback uploads it.
+template <class PointT> inline void scan_changed(KdTreeFacade<PointT>& tree) { tree.scan_dirty = true; tree.scan_failed = false; }
+template <class PointT, class G> inline void scan_changed(KdTreeFacade<PointT>& tree, G& g) {
+    tree.scan_dirty = true; tree.scan_failed = false;
+    (void)upload_scan(tree, g);
+}
+
+// h_share_model (src/laserMapping.cpp:1876-2004).  reduced != nullptr: the "two-line patch" of INTEGRATION.md section 3 -- the
+// caller's update_iterated_dyn_share_modified takes h_x^T h_x / h_x^T h from *reduced (lio_out::HTH, ::HTh) instead of forming
+// them from ekfom_data.h_x / .h, which then stay untouched (unless m < 23: the dense-gain branch needs the rows).
+template <class PointT, class State, class DynShare, class G>
+inline void h_share_model(KdTreeFacade<PointT>& tree, State& s, DynShare& ekfom_data, G& g, lio_out* reduced = nullptr) {
+    lio_ctx* ctx = tree.ctx();
+    // any failure below: what the reference does when it has no effective points (:1956-1961) -- the pass is invalid, the update
+    // skips it (esekfom.hpp:1641-1644), the node lives
+    auto invalid = [&]() { ekfom_data.valid = false; g.effct_feat_num = 0; };
+    const bool want_rows = reduced == nullptr;
+    if (tree.rows_requested != want_rows) {
         // the unmodified update_iterated_dyn_share_modified reads ekfom_data.h_x / .h: every pass stages them on the device,
         // compacted and column-major, so that lio_measure_rows below only moves m x 13 doubles
-        if (lio_measure_want_rows(ctx, 1) != LIO_OK) throw std::runtime_error("lio_measure_want_rows failed");
-        tree.rows_requested = true;
+        if (!tree.report(lio_measure_want_rows(ctx, want_rows ? 1 : 0), "lio_measure_want_rows")) { invalid(); return; }
+        tree.rows_requested = want_rows;
     }
-    if (tree.scan_dirty) {                                             // once per scan, before its first pass
-        const auto& pts = g.feats_down_body->points;
-        const int rc = lio_scan_set(ctx, pts.size() ? &pts[0].x : nullptr, g.feats_down_size, (int)sizeof(PointT));
-        if (rc != LIO_OK) throw std::runtime_error(std::string("lio_scan_set: ") + lio_last_error(ctx));
-        tree.scan_dirty = false;
-    }
+    if (tree.scan_failed) { invalid(); return; }                       // (reported when it happened)
+    if (tree.scan_dirty && !upload_scan(tree, g)) { invalid(); return; }   // once per scan, before its first pass
     const double st[14] = {s.pos[0], s.pos[1], s.pos[2],
                            s.rot.x(), s.rot.y(), s.rot.z(), s.rot.w(),
                            s.offset_R_L_I.x(), s.offset_R_L_I.y(), s.offset_R_L_I.z(), s.offset_R_L_I.w(),
                            s.offset_T_L_I[0], s.offset_T_L_I[1], s.offset_T_L_I[2]};
-    lio_out o;
-    const int rc = lio_measure(ctx, st, ekfom_data.converge ? 1 : 0, g.extrinsic_est_en ? 1 : 0, &o);
-    if (rc != LIO_OK) throw std::runtime_error(std::string("lio_measure: ") + lio_last_error(ctx));
+    lio_out local;
+    lio_out& o = reduced ? *reduced : local;
+    if (!tree.report(lio_measure(ctx, st, ekfom_data.converge ? 1 : 0, g.extrinsic_est_en ? 1 : 0, &o), "lio_measure")) { invalid(); return; }
     tree.globals_stale = true;
     g.effct_feat_num = o.m;                                            // :1942-1954
     if (!o.valid) {                                                    // :1956-1961
@@ -226,11 +312,17 @@ inline void h_share_model(KdTreeFacade<PointT>& tree, State& s, DynShare& ekfom_
         return;
     }
     g.res_mean_last = o.res_mean;                                      // :1963
+    if (reduced != nullptr && o.m >= 23) return;                      // the patched filter needs nothing else
     // the unmodified update_iterated_dyn_share_modified reads h_x (m x 12, Eigen column-major) and h (:1967-2002)
     ekfom_data.h_x.resize(o.m, 12);
     ekfom_data.h.resize(o.m);
-    const int rc2 = lio_measure_rows(ctx, ekfom_data.h_x.data(), ekfom_data.h.data(), o.m, /*col_major=*/1);
-    if (rc2 != LIO_OK) throw std::runtime_error(std::string("lio_measure_rows: ") + lio_last_error(ctx));
+    double* hx = ekfom_data.h_x.data();
+    double* hh = ekfom_data.h.data();
+    if (tree.pin_host_buffers) {
+        // large row blocks (100 k points: 9.6 MB per pass) are written by the copy engine straight into page-locked h_x / h
+        if ((size_t)o.m * 13 * sizeof(double) >= tree.pin_rows_min_bytes) { (void)tree.pins.ensure(hx, (size_t)o.m * 12 * sizeof(double)); (void)tree.pins.ensure(hh, (size_t)o.m * sizeof(double)); }
+    }
+    if (!tree.report(lio_measure_rows(ctx, hx, hh, o.m, /*col_major=*/1), "lio_measure_rows")) { invalid(); return; }
 }
 
 // Brings the reference's per-point globals up to date with the last measurement pass (no-op when they are).
@@ -242,9 +334,9 @@ inline void sync_globals(KdTreeFacade<PointT>& tree, G& g) {
     std::vector<float> world(3 * (size_t)n + 3), nv(4 * (size_t)n + 4), nbr(15 * (size_t)n + 15), nd(5 * (size_t)n + 5);
     std::vector<uint8_t> sel((size_t)n + 1);
     std::vector<int> cnt((size_t)n + 1);
-    if (lio_get_scan_state(ctx, world.data(), sel.data(), nv.data()) != LIO_OK ||
-        lio_get_neighbors(ctx, nbr.data(), nd.data(), cnt.data()) != LIO_OK)
-        throw std::runtime_error(std::string("lio::sync_globals: ") + lio_last_error(ctx));
+    if (!tree.report(lio_get_scan_state(ctx, world.data(), sel.data(), nv.data()), "lio::sync_globals (lio_get_scan_state)") ||
+        !tree.report(lio_get_neighbors(ctx, nbr.data(), nd.data(), cnt.data()), "lio::sync_globals (lio_get_neighbors)"))
+        return;                                                        // the globals keep the previous scan's values
     auto& body = g.feats_down_body->points;
     auto& wpts = g.feats_down_world->points;
     if ((int)wpts.size() < n) wpts.resize(n);

@@ -40,37 +40,135 @@ def test_staged_rows_equal_the_reevaluated_ones(gpu_capi, small_case, hap_case):
         ctx.close()
 
 
-@pytest.mark.parametrize("patched", [0, 1])
-def test_callback_chain_equals_the_library_update(gpu_capi, synth, small_case, patched):
+def _callback_case(gpu_capi, synth, small_case, n_scans=3):
+    w, sc = small_case["world"], small_case["scan"]
+    scans, priors = [], []
+    for k in range(n_scans):
+        s2 = sc if k == 0 else synth.make_scan(w, len(sc.body), seed=synth.SEED + 500 + k, pos=(0.5 * k, -0.2 * k, 0.0), rpy=(0.002, -0.003, 0.03 * k))
+        ps, rt = (small_case["pos"], small_case["rot"]) if k == 0 else synth.perturb_state(s2, seed=synth.SEED + 600 + k)
+        scans.append(s2)
+        priors.append(np.ascontiguousarray(gpu_capi.make_state26(ps, rt, s2.off_R, s2.off_T), np.float64))
+    return w, scans, priors
+
+
+# (patched, page-locked node buffers, one-argument scan_changed, rows through the copy engine)
+@pytest.mark.parametrize("patched,pin,legacy,rows_dma", [(0, 1, 0, 0), (1, 1, 0, 0), (0, 0, 0, 0), (1, 0, 1, 0), (0, 1, 0, 1), (0, 0, 1, 1)])
+def test_callback_chain_equals_the_library_update(gpu_capi, synth, small_case, patched, pin, legacy, rows_dma):
     """kf.update_iterated_dyn_share_modified -> h_share_model(state&, dyn_share&) through the adaptor header, rows back, H^T H
     formed by the filter on the host: same iterations, same posterior (to the summation order of H^T H) as the library's
-    own update; `patched` = the callback hands over the reduced form instead of rows."""
-    w, sc = small_case["world"], small_case["scan"]
+    own update; `patched` = the callback hands over the reduced form instead of rows.  Three scans in a row, so that the later
+    ones run on passes lio_measure enqueued ahead of their pose (the previous scan's converge pattern) and on a cloud a kernel
+    pulled out of the page-locked node buffer (`pin`) the moment lio::scan_changed(ikdtree, G) saw it; `legacy` = the
+    one-argument scan_changed (the first callback uploads); `rows_dma` = rows copied straight into page-locked h_x / h."""
+    w, scans, priors = _callback_case(gpu_capi, synth, small_case)
     B = gpu_capi.callback_bench()
-    ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+    n = len(scans[0].body)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=n, max_map_points=400_000)
     ctx.map_build(w.points)
-    x0 = gpu_capi.make_state26(small_case["pos"], small_case["rot"], sc.off_R, sc.off_T)
     P0 = np.ascontiguousarray(synth.init_cov(), np.float64)
-    kf = gpu_capi.Esekf(3)
-    kf.change_x(x0); kf.change_P(P0)
-    ctx.scan_set(sc.body)
-    log = kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
-    x_lib, P_lib = kf.get_x().copy(), kf.get_P().copy()
-    assert B.cbb_setup(ctx.h, len(sc.body)) == 0
-    body = np.ascontiguousarray(sc.body, np.float32)
-    k = B.cbb_add_scan(body.ctypes.data_as(C.c_void_p), len(body), 3)
-    kf2 = gpu_capi.Esekf(3)
-    ulog = gpu_capi.lio_update_log()
-    x0c = np.ascontiguousarray(x0, np.float64)
-    rc = B.cbb_step(kf2.h, k, x0c.ctypes.data_as(C.c_void_p), P0.ctypes.data_as(C.c_void_p), 0.001, 0, patched, C.byref(ulog))
-    assert rc == 0
-    assert ulog.n_calls == log["n_calls"] and ulog.n_search == log["n_search"] and B.cbb_last_m() == log["last_m"]
-    x_cb, P_cb = kf2.get_x(), kf2.get_P()
+    ref = []
+    for sc, x0 in zip(scans, priors):
+        kf = gpu_capi.Esekf(3)
+        kf.change_x(x0); kf.change_P(P0)
+        ctx.scan_set(sc.body)
+        log = kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+        ref.append((kf.get_x().copy(), kf.get_P().copy(), log))
+    assert B.cbb_setup(ctx.h, n) == 0
+    B.cbb_option(0, pin); B.cbb_option(1, 0); B.cbb_option(2, legacy); B.cbb_option(3, 4096 if rows_dma else (2 << 20))
+    if rows_dma:
+        ctx.debug_set("rows_direct", 0)            # rows through device memory + the copy engine, as for C2's 9.6 MB per pass
+    ids = []
+    for sc in scans:
+        body = np.ascontiguousarray(sc.body, np.float32)
+        ids.append(B.cbb_add_scan(body.ctypes.data_as(C.c_void_p), len(body), 3))
+    released0, pulled0, dma0 = ctx.debug_get("gate_released"), ctx.debug_get("scan_pulled"), ctx.debug_get("rows_direct_dma")
+    for k, (x_lib, P_lib, log) in enumerate(ref):
+        kf2 = gpu_capi.Esekf(3)
+        ulog = gpu_capi.lio_update_log()
+        rc = B.cbb_step(kf2.h, ids[k], priors[k].ctypes.data_as(C.c_void_p), P0.ctypes.data_as(C.c_void_p), 0.001, 0, patched, C.byref(ulog))
+        assert rc == 0 and B.cbb_last_status() == 0
+        assert ulog.n_calls == log["n_calls"] and ulog.n_search == log["n_search"] and B.cbb_last_m() == log["last_m"]
+        x_cb, P_cb = kf2.get_x(), kf2.get_P()
+        if patched:
+            assert np.array_equal(x_cb, x_lib) and np.array_equal(P_cb, P_lib)      # the very same numbers went in
+        else:
+            assert np.abs(x_cb - x_lib).max() < 1e-11 and np.abs(P_cb - P_lib).max() < 1e-12
     if patched:
-        assert np.array_equal(x_cb, x_lib) and np.array_equal(P_cb, P_lib)      # the very same numbers went in
-    else:
-        assert np.abs(x_cb - x_lib).max() < 1e-11 and np.abs(P_cb - P_lib).max() < 1e-12
+        assert ctx.debug_get("gate_released") - released0 >= 2      # scans 2 and 3: passes that were on the stream before their pose
+    assert (ctx.debug_get("scan_pulled") - pulled0 == len(scans)) == bool(pin)
+    if not patched:
+        assert (ctx.debug_get("rows_direct_dma") - dma0 > 0) == bool(pin and rows_dma)
+    ctx.debug_set("rows_direct", -1)
     ctx.measure_want_rows(False)
+    B.cbb_option(0, 1); B.cbb_option(2, 0); B.cbb_option(3, 2 << 20)
+    ctx.close()
+
+
+def test_a_failed_pass_costs_the_pass_not_the_node(gpu_capi, synth, small_case):
+    """The reference's callback has no error channel: trouble = ekfom_data.valid = false + a warning, and the update skips the
+    pass (laserMapping.cpp:1956-1961, esekfom.hpp:1641-1644).  The adaptor's default does the same with every LIO_ERR_* (here a
+    bounded wait of the reduction made to run out): the step returns, the state is the prior, the NEXT scan works; with
+    throw_on_error the same failure surfaces as an exception (callback_bench turns it into its status)."""
+    w, scans, priors = _callback_case(gpu_capi, synth, small_case, 2)
+    B = gpu_capi.callback_bench()
+    n = len(scans[0].body)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=n, max_map_points=400_000)
+    ctx.map_build(w.points)
+    P0 = np.ascontiguousarray(synth.init_cov(), np.float64)
+    assert B.cbb_setup(ctx.h, n) == 0
+    ids = [B.cbb_add_scan(np.ascontiguousarray(sc.body, np.float32).ctypes.data_as(C.c_void_p), n, 3) for sc in scans]
+    for patched in (0, 1):
+        for throwing in (0, 1):
+            B.cbb_option(1, throwing)
+            ctx.debug_set("force_reduction_timeout", 1)
+            kf = gpu_capi.Esekf(3)
+            ulog = gpu_capi.lio_update_log()
+            rc = B.cbb_step(kf.h, ids[0], priors[0].ctypes.data_as(C.c_void_p), P0.ctypes.data_as(C.c_void_p), 0.001, 0, patched, C.byref(ulog))
+            assert B.cbb_last_status() == gpu_capi.LIO_ERR_HIP
+            if throwing:
+                assert rc == gpu_capi.LIO_ERR_HIP
+            else:
+                assert rc == 0
+                assert np.array_equal(kf.get_x(), priors[0]) and np.array_equal(kf.get_P(), P0)     # every pass invalid: nothing moved
+            ctx.debug_set("force_reduction_timeout", 0)
+            B.cbb_option(1, 0)
+            rc = B.cbb_step(kf.h, ids[1], priors[1].ctypes.data_as(C.c_void_p), P0.ctypes.data_as(C.c_void_p), 0.001, 0, patched, C.byref(ulog))
+            assert rc == 0 and B.cbb_last_status() == 0 and B.cbb_last_m() > n // 2
+            assert np.linalg.norm(kf.get_x()[:3] - scans[1].pos) < 0.02
+    ctx.measure_want_rows(False)
+    ctx.close()
+
+
+@pytest.mark.parametrize("stride_floats", [3, 4, 12])
+def test_scan_set_async_equals_scan_set(gpu_capi, small_case, stride_floats):
+    """lio_scan_set_async: records pulled by a kernel out of page-locked memory (lio_host_register / lio_host_alloc), or packed
+    and copied without a wait from pageable memory -- the passes behind it see exactly the scan lio_scan_set would have
+    uploaded (strides of 12, 16 and pcl::PointXYZINormal's 48 bytes)."""
+    w, sc, st = small_case["world"], small_case["scan"], small_case["state14"]
+    n = len(sc.body)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=n, max_map_points=400_000)
+    ctx.map_build(w.points)
+    ctx.scan_set(sc.body)
+    g0 = ctx.measure(st, True, False)
+    nx0, nd0, nc0 = ctx.neighbors()
+    rec = np.full((n, stride_floats), 7.0, np.float32)
+    rec[:, :3] = sc.body
+    L = ctx.L
+    for pinned in (False, True):
+        buf = rec.copy()
+        if pinned:
+            assert L.lio_host_register(buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
+        before = ctx.debug_get("scan_pulled")
+        rc = L.lio_scan_set_async(ctx.h, buf.ctypes.data_as(C.c_void_p), n, 4 * stride_floats)
+        assert rc == 0, L.lio_last_error(ctx.h)
+        g = ctx.measure(st, True, False)
+        assert ctx.debug_get("scan_pulled") - before == (1 if pinned else 0)
+        nx, nd, nc = ctx.neighbors()
+        assert g["m"] == g0["m"] and np.array_equal(g["HTH"], g0["HTH"]) and np.array_equal(g["HTh"], g0["HTh"])
+        assert bits_equal(nx, nx0) and bits_equal(nd, nd0) and np.array_equal(nc, nc0)
+        if pinned:
+            ctx.synchronize()
+            assert L.lio_host_unregister(buf.ctypes.data_as(C.c_void_p)) == 0
     ctx.close()
 
 
