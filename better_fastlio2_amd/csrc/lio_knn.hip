@@ -107,6 +107,56 @@ __device__ __forceinline__ double candidate_key_f(float qx, float qy, float qz, 
     return key_make(db, idx);
 }
 
+// The second chance of a query whose 3x3x3 result stayed unproven, by the whole wavefront: the 98 shell cells of the 5x5x5 block
+// within the 5th distance `top` already holds (the best five of the inner block), two cells per lane one after the other, then
+// their buckets one after the other, 64 points per round trip -- the work of block5_search (lio_tree.h, phase A of the tree walk:
+// same cells, same candidates, same keys, same proof => the same result) written for FEW REGISTERS instead of few round trips:
+// inlined into knn27_kernel the batched form took the kernel from 56 to 88-92 VGPRs (8 -> 5 wavefronts per SIMD) for the sake
+// of ~45 of 100 000 queries.  Returns true when the result is proven inside the 5x5x5 block.
+__device__ __forceinline__ bool shell_second_chance(const KnnArgs& a, float qx, float qy, float qz, int lane, uint2* s_bk, WaveTop5& top) {
+    const float cell = a.grid.cell;
+    const int cx = cell_coord(qx, a.grid.inv_cell), cy = cell_coord(qy, a.grid.inv_cell), cz = cell_coord(qz, a.grid.inv_cell);
+    const bool inrange = cx >= 2 && cy >= 2 && cz >= 2 && (uint32_t)cx + 2u <= CELL_MAX && (uint32_t)cy + 2u <= CELL_MAX &&
+                         (uint32_t)cz + 2u <= CELL_MAX;
+    if (!inrange) return false;                    // (wave-uniform: one query)
+    int n_ne = 0;
+#pragma unroll 1
+    for (int sl = 0; sl < 2; ++sl) {
+        const int j = lane + 64 * sl;
+        const int ox = j / 25 - 2, oy = (j / 5) % 5 - 2, oz = j % 5 - 2;
+        const bool inner = ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1;
+        const bool want = j < 125 && !inner &&
+                          cell_box_sqdist(qx, qy, qz, (uint32_t)(cx + ox), (uint32_t)(cy + oy), (uint32_t)(cz + oz), 0, cell) <= top.tau();
+        uint32_t st = 0, ct = 0;
+        if (want) cell_find(a.l1table, a.l1mask, a.child, (uint32_t)(cx + ox), (uint32_t)(cy + oy), (uint32_t)(cz + oz), st, ct);
+        const bool ne = ct != 0;
+        const u64 b = __ballot(ne);
+        if (ne) s_bk[n_ne + __popcll(b & ((1ull << lane) - 1ull))] = make_uint2(st, ct);
+        n_ne += __popcll(b);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+    for (int b = 0; b < n_ne; ++b) {
+        const uint2 bk = s_bk[b];
+#pragma unroll 1
+        for (uint32_t base = 0; base < bk.y; base += 64u) {
+            const uint32_t i = base + (uint32_t)lane;
+            u64 key = KEY64_MAX;
+            if (i < bk.y) key = candidate_key(qx, qy, qz, a.map_pts[bk.x + i], bk.x + i);
+            top.merge(key);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if ((uint32_t)(top.g4 >> 32) >= INF_BITS) return false;
+    const float lox = (float)(cx - CELL_OFF - 2) * cell, hix = (float)(cx - CELL_OFF + 3) * cell;
+    const float loy = (float)(cy - CELL_OFF - 2) * cell, hiy = (float)(cy - CELL_OFF + 3) * cell;
+    const float loz = (float)(cz - CELL_OFF - 2) * cell, hiz = (float)(cz - CELL_OFF + 3) * cell;
+    const float gmin = fminf(fminf(qx - lox, hix - qx), fminf(fminf(qy - loy, hiy - qy), fminf(qz - loz, hiz - qz)));
+    return top.tau() < gmin * gmin;
+}
+
 // ---------------------------------------------------------------------------------------------
 // U = 0: the candidate walk of rounds 1-3 (list of {start, count}, one load in flight per lane) -- the form every throughput-bound
 //        launch uses (C2, C5: the kernel is VALU-bound there and extra loads in flight bought nothing).
@@ -436,6 +486,63 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         if (rd == K - 1) d5bits = key_dist_bits(m);
     }
 
+    // ---- proof: every point outside the searched block is farther than the 5th neighbour ------
+    bool proven = false;
+    if (active && r == 0) {
+        const float cell = a.grid.cell;
+        if (nvalid == K && cx >= 1 && cy >= 1 && cz >= 1 && (uint32_t)cx < CELL_MAX &&
+            (uint32_t)cy < CELL_MAX && (uint32_t)cz < CELL_MAX) {
+            // block faces (exact: integer * power of two)
+            const float lox = (float)(cx - CELL_OFF - 1) * cell, hix = (float)(cx - CELL_OFF + 2) * cell;
+            const float loy = (float)(cy - CELL_OFF - 1) * cell, hiy = (float)(cy - CELL_OFF + 2) * cell;
+            const float loz = (float)(cz - CELL_OFF - 1) * cell, hiz = (float)(cz - CELL_OFF + 2) * cell;
+            float gmin = fminf(fminf(qx - lox, hix - qx), fminf(fminf(qy - loy, hiy - qy), fminf(qz - loz, hiz - qz)));
+            // a point outside has |delta| >= gmin on one axis -> its computed sqdist >= fl(gmin*gmin)
+            proven = __uint_as_float(d5bits) < gmin * gmin;
+        }
+    }
+    // ---- second chance (round 4): the rare group whose result stayed unproven (41-55 of 100 000 queries at C2: sparse places,
+    // fewer than five points in the 27 cells) is finished HERE by the whole wavefront -- the 98 shell cells of the 5x5x5 block,
+    // pruned by the 5th distance the group already holds, two cells per lane, candidates as one flat list (block5_search, phase
+    // A of the tree walk) -- instead of being listed for the walker workgroups of the measurement kernel, whose chain (walk,
+    // one-wavefront plane fit, hand-off: ~10 us) outlasted the model it hid behind.  Every listed query of the BASELINE
+    // configs is settled inside 5x5x5; what is not goes on the list as before, seeded with the best five of the larger block.
+    // a.tune bit 1 switches it off (tests of the walk).
+    {
+        const u64 need = (a.tune & 2) ? 0ull : __ballot(active && r == 0 && !proven);
+        if (need != 0ull) {
+            __shared__ uint2 s_bk5[WPB][100];
+            for (u64 mm = need; mm != 0ull; mm &= mm - 1ull) {
+                const int gl = __ffsll((long long)mm) - 1;           // first lane of the unproven group
+                const float sx = __shfl(qx, gl, 64), sy = __shfl(qy, gl, 64), sz = __shfl(qz, gl, 64);
+                WaveTop5 t5;
+                {
+                    u64 kk[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const long long v = __shfl(__double_as_longlong(k < G ? mine0 : mine1), gl + (k % G), 64);
+                        kk[k] = (u64)v;
+                    }
+                    t5.g0 = kk[0]; t5.g1 = kk[1]; t5.g2 = kk[2]; t5.g3 = kk[3]; t5.g4 = kk[4];
+                }
+                const bool p2 = shell_second_chance(a, sx, sy, sz, lane, s_bk5[wave], t5);
+                const u64 res[K] = {t5.g0, t5.g1, t5.g2, t5.g3, t5.g4};
+                int nv2 = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) nv2 += ((uint32_t)(res[k] >> 32) < INF_BITS) ? 1 : 0;
+                // back to the group's lanes: lane gl + j keeps result j (and j + G when G < 5)
+                const int jj = lane - gl;
+                if (jj >= 0 && jj < G) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if (k % G == jj) { if (k < G) mine0 = __longlong_as_double((long long)res[k]); else mine1 = __longlong_as_double((long long)res[k]); }
+                    }
+                    if (jj == 0) { proven = p2; nvalid = nv2; }
+                }
+            }
+        }
+    }
+
     // ---- write Nearest_Points[q] ---------------------------------------------------------------
 #pragma unroll
     for (int half = 0; half < (G < K ? 2 : 1); ++half) {
@@ -455,21 +562,8 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         }
     }
 
-    // ---- proof: every point outside the searched block is farther than the 5th neighbour ------
     uint32_t slot = 0xffffffffu;                   // list entry of this query when it stays unproven (lane r == 0)
     if (active && r == 0) {
-        const float cell = a.grid.cell;
-        bool proven = false;
-        if (nvalid == K && cx >= 1 && cy >= 1 && cz >= 1 && (uint32_t)cx < CELL_MAX &&
-            (uint32_t)cy < CELL_MAX && (uint32_t)cz < CELL_MAX) {
-            // block faces (exact: integer * power of two)
-            const float lox = (float)(cx - CELL_OFF - 1) * cell, hix = (float)(cx - CELL_OFF + 2) * cell;
-            const float loy = (float)(cy - CELL_OFF - 1) * cell, hiy = (float)(cy - CELL_OFF + 2) * cell;
-            const float loz = (float)(cz - CELL_OFF - 1) * cell, hiz = (float)(cz - CELL_OFF + 2) * cell;
-            float gmin = fminf(fminf(qx - lox, hix - qx), fminf(fminf(qy - loy, hiy - qy), fminf(qz - loz, hiz - qz)));
-            // a point outside has |delta| >= gmin on one axis -> its computed sqdist >= fl(gmin*gmin)
-            proven = __uint_as_float(d5bits) < gmin * gmin;
-        }
         // unproven queries are redone by the exact tree walk (inside the measurement kernel of the pass, or
         // knn_tree_kernel); until then their count carries the mark the owner of the query looks for
         a.cnt[q] = (uint8_t)nvalid | (proven ? (uint8_t)0 : CNT_UNPROVEN);

@@ -149,6 +149,102 @@ __device__ __forceinline__ float4 load_walked_neighbor(const float4* nbr, size_t
                        __uint_as_float((uint32_t)(hi >> 32)));
 }
 
+// Phase A of the exact walk as a function of its own: the 5x5x5 cell block around q, looked up in the cell directory by the 64
+// lanes of a wavefront (two cells each), its candidates streamed as one flat list and merged into `top`.  seeded: `top` already
+// holds the best five of the inner 3x3x3 block (knn27_kernel's result) -- then only the 98 shell cells within their 5th distance
+// are looked at: a handful of cells and candidates instead of 125 cells and ~300.  Returns true when the result is PROVEN: the 5th
+// distance lies below the distance from q to the faces of the 5x5x5 block.  s_bk / s_pre: 128 entries of LDS each, private to the
+// wavefront; all 64 lanes call it together.  Used by tree_search_one below and by knn27_kernel (lio_knn.hip) as the SECOND
+// CHANCE of a query whose 3x3x3 result stayed unproven -- at C2 every such query is settled here.
+__device__ __forceinline__ bool block5_search(const float4* map_pts, const HashEntry* l1table, uint32_t l1mask, const uint2* child,
+                                          float cell, float inv_cell, float qx, float qy, float qz, int lane, uint2* s_bk,
+                                          uint32_t* s_pre, WaveTop5& top, bool seeded) {
+    const int cx = cell_coord(qx, inv_cell), cy = cell_coord(qy, inv_cell), cz = cell_coord(qz, inv_cell);
+    const bool inrange = cx >= 2 && cy >= 2 && cz >= 2 && (uint32_t)cx + 2u <= CELL_MAX &&
+                         (uint32_t)cy + 2u <= CELL_MAX && (uint32_t)cz + 2u <= CELL_MAX;
+    int n_ne = 0;
+    if (inrange) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int j = lane + 64 * sl;
+            uint32_t st = 0, ct = 0;
+            const int ox = j / 25 - 2, oy = (j / 5) % 5 - 2, oz = j % 5 - 2;
+            bool want = j < 125;
+            if (seeded) {
+                const bool inner = ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1;
+                want = want && !inner &&
+                       cell_box_sqdist(qx, qy, qz, (uint32_t)(cx + ox), (uint32_t)(cy + oy), (uint32_t)(cz + oz), 0, cell) <= top.tau();
+            }
+            if (want)
+                cell_find(l1table, l1mask, child, (uint32_t)(cx + ox),
+                          (uint32_t)(cy + oy), (uint32_t)(cz + oz), st, ct);
+            const bool ne = ct != 0;
+            const u64 b = __ballot(ne);
+            const int pos = n_ne + __popcll(b & ((1ull << lane) - 1ull));
+            if (ne) s_bk[pos] = make_uint2(st, ct);
+            n_ne += __popcll(b);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // exclusive prefix of the bucket counts (<= 125 buckets, two per lane)
+    uint32_t c0 = lane < n_ne ? s_bk[lane].y : 0u, c1 = lane + 64 < n_ne ? s_bk[lane + 64].y : 0u;
+    uint32_t i0 = c0, i1 = c1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u0 = __shfl_up(i0, o, 64), u1 = __shfl_up(i1, o, 64);
+        if (lane >= o) { i0 += u0; i1 += u1; }
+    }
+    const uint32_t tot0 = __shfl(i0, 63, 64), tot1 = __shfl(i1, 63, 64);
+    s_pre[lane] = i0 - c0;
+    s_pre[lane + 64] = tot0 + i1 - c1;
+    const uint32_t total = tot0 + tot1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // four 64-candidate chunks per round: their index searches and 16-byte gathers are all in
+    // flight before the first merge (one memory round trip instead of four)
+    for (uint32_t base = 0; base < total; base += 256) {
+        u64 key[4];
+        uint32_t idx[4];
+        float4 pt[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t f = base + 64u * c + (uint32_t)lane;
+            idx[c] = 0xffffffffu;
+            if (f < total) {
+                int lo = 0, hi = n_ne - 1;               // largest b with s_pre[b] <= f
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_pre[mid] <= f) lo = mid; else hi = mid - 1;
+                }
+                idx[c] = s_bk[lo].x + (f - s_pre[lo]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            pt[c] = make_float4(0.f, 0.f, 0.f, 1.f);
+            if (idx[c] != 0xffffffffu) pt[c] = map_pts[idx[c]];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            key[c] = idx[c] != 0xffffffffu ? candidate_key(qx, qy, qz, pt[c], idx[c]) : KEY64_MAX;
+            if (base + 64u * c < total) top.merge(key[c]);
+        }
+    }
+    bool proven = false;
+    if (inrange && (uint32_t)(top.g4 >> 32) < INF_BITS) {
+        const float lox = (float)(cx - CELL_OFF - 2) * cell, hix = (float)(cx - CELL_OFF + 3) * cell;
+        const float loy = (float)(cy - CELL_OFF - 2) * cell, hiy = (float)(cy - CELL_OFF + 3) * cell;
+        const float loz = (float)(cz - CELL_OFF - 2) * cell, hiz = (float)(cz - CELL_OFF + 3) * cell;
+        const float gmin = fminf(fminf(qx - lox, hix - qx), fminf(fminf(qy - loy, hiy - qy), fminf(qz - loz, hiz - qz)));
+        proven = top.tau() < gmin * gmin;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return proven;
+}
+
 // LDS of one walking wavefront
 struct TreeScratch {
     uint4 node[TREE_STACK];          // {start, count, level, bd bits}
@@ -186,89 +282,8 @@ __device__ __forceinline__ float4 tree_search_one(const TreeArgs& a, uint32_t q,
     // ---- phase A: the 5x5x5 cell block around the query (125 probes, 2 per lane).  Most queries
     // the 27-cell kernel could not prove are settled here in a handful of round trips.
     {
-        const int cx = cell_coord(qx, a.grid.inv_cell), cy = cell_coord(qy, a.grid.inv_cell), cz = cell_coord(qz, a.grid.inv_cell);
-        const bool inrange = cx >= 2 && cy >= 2 && cz >= 2 && (uint32_t)cx + 2u <= CELL_MAX &&
-                             (uint32_t)cy + 2u <= CELL_MAX && (uint32_t)cz + 2u <= CELL_MAX;
-        int n_ne = 0;
-        if (inrange) {
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
-                const int j = lane + 64 * sl;
-                uint32_t st = 0, ct = 0;
-                const int ox = j / 25 - 2, oy = (j / 5) % 5 - 2, oz = j % 5 - 2;
-                bool want = j < 125;
-                if (seeded) {
-                    const bool inner = ox >= -1 && ox <= 1 && oy >= -1 && oy <= 1 && oz >= -1 && oz <= 1;
-                    want = want && !inner &&
-                           cell_box_sqdist(qx, qy, qz, (uint32_t)(cx + ox), (uint32_t)(cy + oy), (uint32_t)(cz + oz), 0, cell) <= top.tau();
-                }
-                if (want)
-                    cell_find(a.ltable + a.levels.off[1], a.levels.mask[1], a.child, (uint32_t)(cx + ox),
-                              (uint32_t)(cy + oy), (uint32_t)(cz + oz), st, ct);
-                const bool ne = ct != 0;
-                const u64 b = __ballot(ne);
-                const int pos = n_ne + __popcll(b & ((1ull << lane) - 1ull));
-                if (ne) s_bk[pos] = make_uint2(st, ct);
-                n_ne += __popcll(b);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // exclusive prefix of the bucket counts (<= 125 buckets, two per lane)
-        uint32_t c0 = lane < n_ne ? s_bk[lane].y : 0u, c1 = lane + 64 < n_ne ? s_bk[lane + 64].y : 0u;
-        uint32_t i0 = c0, i1 = c1;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u0 = __shfl_up(i0, o, 64), u1 = __shfl_up(i1, o, 64);
-            if (lane >= o) { i0 += u0; i1 += u1; }
-        }
-        const uint32_t tot0 = __shfl(i0, 63, 64), tot1 = __shfl(i1, 63, 64);
-        s_pre[lane] = i0 - c0;
-        s_pre[lane + 64] = tot0 + i1 - c1;
-        const uint32_t total = tot0 + tot1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // four 64-candidate chunks per round: their index searches and 16-byte gathers are all in
-        // flight before the first merge (one memory round trip instead of four)
-        for (uint32_t base = 0; base < total; base += 256) {
-            u64 key[4];
-            uint32_t idx[4];
-            float4 pt[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t f = base + 64u * c + (uint32_t)lane;
-                idx[c] = 0xffffffffu;
-                if (f < total) {
-                    int lo = 0, hi = n_ne - 1;               // largest b with s_pre[b] <= f
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (s_pre[mid] <= f) lo = mid; else hi = mid - 1;
-                    }
-                    idx[c] = s_bk[lo].x + (f - s_pre[lo]);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                pt[c] = make_float4(0.f, 0.f, 0.f, 1.f);
-                if (idx[c] != 0xffffffffu) pt[c] = a.map_pts[idx[c]];
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                key[c] = idx[c] != 0xffffffffu ? candidate_key(qx, qy, qz, pt[c], idx[c]) : KEY64_MAX;
-                if (base + 64u * c < total) top.merge(key[c]);
-            }
-        }
-        bool proven = false;
-        if (inrange && (uint32_t)(top.g4 >> 32) < INF_BITS) {
-            const float lox = (float)(cx - CELL_OFF - 2) * cell, hix = (float)(cx - CELL_OFF + 3) * cell;
-            const float loy = (float)(cy - CELL_OFF - 2) * cell, hiy = (float)(cy - CELL_OFF + 3) * cell;
-            const float loz = (float)(cz - CELL_OFF - 2) * cell, hiz = (float)(cz - CELL_OFF + 3) * cell;
-            const float gmin = fminf(fminf(qx - lox, hix - qx), fminf(fminf(qy - loy, hiy - qy), fminf(qz - loz, hiz - qz)));
-            proven = top.tau() < gmin * gmin;
-        }
-        __builtin_amdgcn_wave_barrier();
+        const bool proven = block5_search(a.map_pts, a.ltable + a.levels.off[1], a.levels.mask[1], a.child, cell, a.grid.inv_cell, qx, qy, qz,
+                                          lane, s_bk, s_pre, top, seeded);
         if (proven) {
             if (changed) *changed = !unchanged();
             if (unchanged()) { __builtin_amdgcn_wave_barrier(); return make_float4(0.f, 0.f, 0.f, 0.f); }

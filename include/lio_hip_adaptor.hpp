@@ -36,6 +36,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -57,12 +58,15 @@ struct HostPin {
     std::vector<Range> ranges;
     unsigned long long clock = 0;
     size_t max_ranges = 16;
-    bool ensure(void* q, size_t n, size_t min_bytes = 65536) {
+    // contained_ok: a range that starts where a registered one starts and ends inside it counts as registered (a matrix that
+    // shrank inside its allocation).  ONLY for destinations whose arrival the caller verifies (h_share_model plants a marker
+    // the copy must overwrite): an allocator may have unmapped and re-mapped the pages behind an old registration.
+    bool ensure(void* q, size_t n, size_t min_bytes = 65536, bool contained_ok = false) {
         if (q == nullptr || n < min_bytes) return false;
         char* a = static_cast<char*>(q);
         for (size_t i = 0; i < ranges.size();) {
             Range& r = ranges[i];
-            if (r.p == a && r.bytes == n) { r.used = ++clock; return true; }
+            if (r.p == a && (r.bytes == n || (contained_ok && n < r.bytes))) { r.used = ++clock; return true; }
             if (a < r.p + r.bytes && r.p < a + n) { (void)lio_host_unregister(r.p); ranges.erase(ranges.begin() + (long)i); continue; }
             ++i;
         }
@@ -145,6 +149,7 @@ public:
     bool pin_host_buffers = true;
     size_t pin_rows_min_bytes = (size_t)2 << 20;   // row blocks (m x 13 doubles) from this size on are copied straight into page-locked h_x / h
     HostPin pins;
+    long n_stale_pins = 0;        // row blocks that did not arrive through a registration and were fetched again (see h_share_model)
     // forget every registration (before the node frees or re-allocates buffers it has handed over)
     void unpin_all() { if (ctx_) (void)lio_synchronize(ctx_); pins.drop_all(); }
     lio_ctx* ctx() const { return const_cast<KdTreeFacade*>(this)->ctx(); }
@@ -318,11 +323,24 @@ inline void h_share_model(KdTreeFacade<PointT>& tree, State& s, DynShare& ekfom_
     ekfom_data.h.resize(o.m);
     double* hx = ekfom_data.h_x.data();
     double* hh = ekfom_data.h.data();
-    if (tree.pin_host_buffers) {
-        // large row blocks (100 k points: 9.6 MB per pass) are written by the copy engine straight into page-locked h_x / h
-        if ((size_t)o.m * 13 * sizeof(double) >= tree.pin_rows_min_bytes) { (void)tree.pins.ensure(hx, (size_t)o.m * 12 * sizeof(double)); (void)tree.pins.ensure(hh, (size_t)o.m * sizeof(double)); }
-    }
+    // Large row blocks (100 k points: 9.6 MB per pass) are written by the copy engine straight into page-locked h_x / h.  m
+    // changes from pass to pass and Eigen re-allocates on every change of size, usually at the same address: a block that
+    // starts where a registered one starts and fits inside it is taken as registered (a registration costs ~150 us for 9.6
+    // MB) -- and because an allocator may have re-mapped those pages since, the arrival is VERIFIED: the last element of both
+    // blocks carries a marker no row can hold until the copy overwrites it; a marker that survives means the registration
+    // was stale: everything is unpinned and the rows come again through the library's own staging buffer.
+    bool pinned = false;
+    if (tree.pin_host_buffers && (size_t)o.m * 13 * sizeof(double) >= tree.pin_rows_min_bytes)
+        pinned = tree.pins.ensure(hx, (size_t)o.m * 12 * sizeof(double), 65536, true) && tree.pins.ensure(hh, (size_t)o.m * sizeof(double), 4096, true);
+    const unsigned long long MARK = 0x7ff8dead5ca1ab1eull;              // a quiet NaN with a payload of its own
+    auto bits_of = [](const double& v) { unsigned long long b; std::memcpy(&b, &v, 8); return b; };
+    if (pinned) { std::memcpy(&hx[(size_t)o.m * 12 - 1], &MARK, 8); std::memcpy(&hh[(size_t)o.m - 1], &MARK, 8); }
     if (!tree.report(lio_measure_rows(ctx, hx, hh, o.m, /*col_major=*/1), "lio_measure_rows")) { invalid(); return; }
+    if (pinned && (bits_of(hx[(size_t)o.m * 12 - 1]) == MARK || bits_of(hh[(size_t)o.m - 1]) == MARK)) {
+        ++tree.n_stale_pins;
+        tree.unpin_all();
+        if (!tree.report(lio_measure_rows(ctx, hx, hh, o.m, /*col_major=*/1), "lio_measure_rows")) { invalid(); return; }
+    }
 }
 
 // Brings the reference's per-point globals up to date with the last measurement pass (no-op when they are).

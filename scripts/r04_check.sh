@@ -3,7 +3,7 @@ tag=${1:-r04a}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R; export LIO_SYNTH_CACHE=/tmp/lio_synth
 T0=$(date +%s); stamp() { echo "== $1: $(( $(date +%s) - T0 )) s"; }
-timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -40 > $O/pytest_gpu_full.log; grep -a "passed\|failed\|error" $O/pytest_gpu_full.log | tail -3 > $O/pytest_gpu.log; tail -25 $O/pytest_gpu_full.log
+timeout 900 python -m pytest tests -m gpu -q -x ${PYTEST_ARGS:-} 2>&1 | grep -a -v "Rebuild thread\|Multi thread\|amdgpu.ids" > $O/pytest_gpu_full.log; grep -a "passed\|failed\|error" $O/pytest_gpu_full.log | tail -3 > $O/pytest_gpu.log; tail -${PYTEST_TAIL:-25} $O/pytest_gpu_full.log
 stamp pytest
 if [ "${2:-bench}" = "bench" ]; then
 timeout 500 python bench.py --gpus 1 --steps 100 --warmup 10 > $O/bench_c2.json 2> $O/bench_c2.err; tail -c 600 $O/bench_c2.err

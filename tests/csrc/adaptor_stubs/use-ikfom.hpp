@@ -12,7 +12,8 @@ struct state_ikfom { StubVec3 pos; StubQuat rot; StubQuat offset_R_L_I; StubVec3
 
 struct StubMatrix {
     std::vector<double> a; long r = 0, c = 0;
-    void resize(long rows, long cols) { r = rows; c = cols; a.assign((size_t)(rows * cols), 0.0); }
+    // Eigen's resize() does not initialise (and re-allocates when the size changes); the stand-in keeps its allocation
+    void resize(long rows, long cols) { r = rows; c = cols; a.resize((size_t)(rows * cols)); }
     void resize(long rows) { resize(rows, 1); }
     double* data() { return a.data(); }
     long rows() const { return r; }
