@@ -997,6 +997,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     { const char* e = std::getenv("LIO_TRACE_REBUILDS"); c->trace_rebuilds = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_TRACE_HOST"); c->trace_host = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_PRE_ENQUEUE"); if (e != nullptr && e[0] == '0') c->dbg_pre_enqueue = 0; }   // (A/B runs of scripts)
+    { const char* e = std::getenv("LIO_KNN_TUNE"); if (e != nullptr && e[0] >= '0' && e[0] <= '9') c->dbg_knn_tune = std::atoi(e); }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_KNN_WALK"); if (e != nullptr && (e[0] == '0' || e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0) c->dbg_knn_walk = e[0] - '0'; }
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, c->device));

@@ -501,15 +501,16 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             proven = __uint_as_float(d5bits) < gmin * gmin;
         }
     }
-    // ---- second chance (round 4): the rare group whose result stayed unproven (41-55 of 100 000 queries at C2: sparse places,
-    // fewer than five points in the 27 cells) is finished HERE by the whole wavefront -- the 98 shell cells of the 5x5x5 block,
-    // pruned by the 5th distance the group already holds, two cells per lane, candidates as one flat list (block5_search, phase
-    // A of the tree walk) -- instead of being listed for the walker workgroups of the measurement kernel, whose chain (walk,
-    // one-wavefront plane fit, hand-off: ~10 us) outlasted the model it hid behind.  Every listed query of the BASELINE
-    // configs is settled inside 5x5x5; what is not goes on the list as before, seeded with the best five of the larger block.
-    // a.tune bit 1 switches it off (tests of the walk).
+    // ---- second chance (round 4, OPT-IN: a.tune bit 1 -- measured and not adopted): the rare group whose
+    // result stayed unproven (41-55 of 100 000 queries at C2: sparse places, fewer than five points in the 27 cells) is finished
+    // HERE by the whole wavefront -- the 98 shell cells of the 5x5x5 block, pruned by the 5th distance the group already holds --
+    // instead of being listed for the walker workgroups of the measurement kernel.  Bit-identical results, an empty list at
+    // every BASELINE config, the search pass's measurement kernel 2.2 us shorter at C2 (1.0 at C3) -- and this kernel 25 us
+    // LONGER at C2 (6 at C3): a wavefront that takes the second chance runs a chain of dependent round trips (two per cell
+    // pair, one per shell bucket) while the launch is bound by its last wavefronts; the batched form that needs few round
+    // trips (block5_search) takes the kernel from 56 to 81-92 VGPRs.  The walk stays where it overlaps with the model.
     {
-        const u64 need = (a.tune & 2) ? 0ull : __ballot(active && r == 0 && !proven);
+        const u64 need = (a.tune & 2) ? __ballot(active && r == 0 && !proven) : 0ull;
         if (need != 0ull) {
             __shared__ uint2 s_bk5[WPB][100];
             for (u64 mm = need; mm != 0ull; mm &= mm - 1ull) {

@@ -99,12 +99,53 @@ def test_candidate_walk_variants_are_bit_identical(gpu_capi, oracle, small_case,
             assert bits_equal(r[k][0], z[k][0]) and bits_equal(r[k][1], z[k][1]) and np.array_equal(r[k][2], z[k][2])
 
 
-@pytest.mark.parametrize("ext", [False, True])
-def test_tree_walk_inside_the_measurement_kernel(gpu_capi, oracle, small_case, ext):
+@pytest.mark.parametrize("lanes", [4, 8, 16, 32, 64])
+def test_second_chance_inside_the_knn_kernel_is_bit_identical(gpu_capi, oracle, small_case, lanes):
+    """Round 4 (opt-in, knn_tune bit 1; measured and not adopted): a group of knn27_kernel whose 3x3x3 result stays unproven is finished by its wavefront inside the 5x5x5 block
+    (shell_second_chance, lio_knn.hip) instead of being listed for the tree walk.  Same cells, same candidates, same keys, same
+    proof as phase A of the walk: neighbours, distances and counts of the stand-alone search, of a search pass and of the bounded
+    re-search at a moved pose are the bits the kernel without the second chance + the walk produce -- and the
+    oracle's; the list shrinks to what lies beyond 5x5x5 cells; the sums agree to rounding (a settled query is summed by its
+    owner workgroup instead of by its walker)."""
+    q = _hard_queries(small_case, oracle)
+    om = oracle.OracleMap(0.2); om.build(small_case["world"].points)
+    ox, od, oc, _ = om.knn(q)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float64)
+    moved = ident.copy(); moved[:3] = [0.04, -0.03, 0.02]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=len(q), max_map_points=400_000, lanes_per_query=lanes)
+    ctx.map_build(small_case["world"].points)
+    res = {}
+    for tune in (0, 2):
+        ctx.debug_set("knn_tune", tune)
+        gx, gd, gc = ctx.nearest_search(q)
+        ctx.scan_set(q)
+        a = ctx.measure(ident, True, False)
+        n1 = ctx.neighbors()
+        b = ctx.measure(moved, True, False)
+        n2 = ctx.neighbors()
+        w, sel, nv = ctx.scan_state()
+        res[tune] = (gx, gd, gc, a, n1, b, n2, sel, nv)
+    ctx.close()
+    off, on = res[0], res[2]
+    assert np.array_equal(on[2], oc) and bits_equal(on[1], od)
+    assert bits_equal(on[0], off[0]) and bits_equal(on[1], off[1]) and np.array_equal(on[2], off[2])
+    for k in (4, 6):
+        assert bits_equal(on[k][0], off[k][0]) and bits_equal(on[k][1], off[k][1]) and np.array_equal(on[k][2], off[k][2])
+    assert np.array_equal(on[7], off[7]) and bits_equal(on[8], off[8])
+    for k in (3, 5):
+        assert on[k]["m"] == off[k]["m"] and 0 < on[k]["n_unresolved"] < off[k]["n_unresolved"]
+        assert np.abs(on[k]["HTH"] - off[k]["HTH"]).max() <= 1e-12 * np.abs(off[k]["HTH"]).max()
+        assert np.abs(on[k]["HTh"] - off[k]["HTh"]).max() <= 1e-12 * np.abs(off[k]["HTh"]).max()
+
+
+@pytest.mark.parametrize("ext,second_chance", [(False, 0), (True, 0), (False, 1), (True, 1)])
+def test_tree_walk_inside_the_measurement_kernel(gpu_capi, oracle, small_case, ext, second_chance):
     """A search pass walks the queries the 27-cell kernel could not prove INSIDE the measurement kernel (walker
     workgroups in front of the model workgroups; the owners of such queries wait for them).  With a scan that is
     mostly edge / far / above-the-map points (thousands of walks, clustered and scattered) the pass must equal the
-    same pass with the stand-alone walk kernel bit for bit, and the neighbours must equal the oracle's."""
+    same pass with the stand-alone walk kernel bit for bit, and the neighbours must equal the oracle's.  second_chance = 0:
+    knn27_kernel lists every unproven query (the default); 1 (knn_tune bit 1, opt-in): it settles what the 5x5x5 block settles
+    itself and lists only the rest -- far fewer walks, the same bits."""
     q = _hard_queries(small_case, oracle)
     ident = np.array([0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float64)      # world frame == body frame
     om = oracle.OracleMap(0.2); om.build(small_case["world"].points)
@@ -113,6 +154,7 @@ def test_tree_walk_inside_the_measurement_kernel(gpu_capi, oracle, small_case, e
     for separate in (0, 1):
         ctx = gpu_capi.LioContext(0.2, max_scan_points=len(q), max_map_points=400_000)
         ctx.map_build(small_case["world"].points)
+        ctx.debug_set("knn_tune", 2 if second_chance else 0)
         ctx.debug_set("separate_tree_walk", separate)
         ctx.scan_set(q)
         g = ctx.measure(ident, True, ext)
@@ -122,7 +164,7 @@ def test_tree_walk_inside_the_measurement_kernel(gpu_capi, oracle, small_case, e
         res[separate] = (g, g2, sel, nv, nx, nd, nc)
         ctx.close()
     a, b = res[0], res[1]
-    assert a[0]["n_unresolved"] == b[0]["n_unresolved"] > 1000
+    assert a[0]["n_unresolved"] == b[0]["n_unresolved"] > (300 if second_chance else 1000)
     for k in (0, 1):
         assert a[k]["m"] == b[k]["m"] and np.array_equal(a[k]["HTH"], b[k]["HTH"]) and np.array_equal(a[k]["HTh"], b[k]["HTh"])
     assert np.array_equal(a[0]["HTH"], a[1]["HTH"])
@@ -134,13 +176,15 @@ def test_tree_walk_inside_the_measurement_kernel(gpu_capi, oracle, small_case, e
     assert bits_equal(a[4][tie_free], ox[tie_free])
 
 
-@pytest.mark.parametrize("ext", [False, True])
-def test_walk_changes_a_result_with_few_listed_queries(gpu_capi, oracle, small_case, ext):
+@pytest.mark.parametrize("ext,second_chance", [(False, 0), (True, 0), (False, 1), (True, 1)])
+def test_walk_changes_a_result_with_few_listed_queries(gpu_capi, oracle, small_case, ext, second_chance):
     """Few listed queries (<= FIX_MAX): the walker workgroup of a listed query walks, evaluates the model on the exact
     neighbours and publishes the query's term of every sum; the last workgroup folds those terms in query order.  Queries
     0.8 m above the ground are such queries, and their walks DO change the result (the 3x3x3 block sees only the ground
     points with z >= 0).  Outputs, accept flags, rows and sums must be the oracle's on the exact neighbours
-    (laserMapping.cpp:1909-1938, ikd_Tree.cpp:367-397)."""
+    (laserMapping.cpp:1909-1938, ikd_Tree.cpp:367-397).  second_chance = 1 (knn_tune bit 1, opt-in): the same queries are finished
+    inside knn27_kernel by the 5x5x5 second chance of their wavefront -- nothing is listed, the owners evaluate them like any
+    other point, and every output is the same."""
     rng = np.random.default_rng(11)
     half = small_case["world"].ground_half
     wq = oracle.body_to_world(small_case["state14"], small_case["scan"].body)[:3000]
@@ -155,6 +199,7 @@ def test_walk_changes_a_result_with_few_listed_queries(gpu_capi, oracle, small_c
     for separate in (0, 1):
         ctx = gpu_capi.LioContext(0.2, max_scan_points=len(q), max_map_points=400_000)
         ctx.map_build(small_case["world"].points)
+        ctx.debug_set("knn_tune", 2 if second_chance else 0)
         ctx.debug_set("separate_tree_walk", separate)
         ctx.measure_want_rows(True)                     # the rows of THIS pass, staged by it (the walkers write their queries' rows)
         ctx.scan_set(q)
@@ -166,7 +211,10 @@ def test_walk_changes_a_result_with_few_listed_queries(gpu_capi, oracle, small_c
         ctx.close()
     g, sel, nv, nx, ghx, gh = res[0]
     lifted_idx = np.r_[1500:1560, 3060:3120]
-    assert 100 <= g["n_unresolved"] <= 256                            # few listed queries: the lifted ones (and a handful of the scan's)
+    if second_chance:
+        assert g["n_unresolved"] <= 2                                  # the lifted queries are settled inside knn27_kernel (5x5x5 block)
+    else:
+        assert 100 <= g["n_unresolved"] <= 256                        # few listed queries: the lifted ones (and a handful of the scan's)
     assert (nx[lifted_idx, :, 2] < 0).any(axis=1).sum() > 60           # ... whose exact neighbours lie outside the 3x3x3 block (z < 0)
     assert g["m"] == m and np.array_equal(sel, arr.selected)
     sb = sel.astype(bool)
