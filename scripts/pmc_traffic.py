@@ -21,9 +21,10 @@ import bench  # noqa: E402  (knn_source_hash)
 
 def main():
     root = sys.argv[1]
+    cfg = sys.argv[2] if len(sys.argv) > 2 else "c2"
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     shapes = collections.defaultdict(set)
-    for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+    for f in sorted(glob.glob(os.path.join(root, cfg, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "knn27_kernel" not in k:
@@ -45,7 +46,10 @@ def main():
             e["instructions_per_wavefront"] = {c: avg[c] / avg["SQ_WAVES"] for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if c in avg}
         out[variant] = e
     first = out.get("first_search", {})
-    doc = {"c2": {"kernel": " / ".join(sorted(shapes.get("first_search", []))) + " (first search of a scan, transform fused); bounded re-search: "
+    path = os.path.join(root, "knn_traffic.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    nm, nq, voxel, kind, _ = bench.CONFIGS[cfg]
+    doc[cfg] = {"kernel": " / ".join(sorted(shapes.get("first_search", []))) + " (first search of a scan, transform fused); bounded re-search: "
                             + " / ".join(sorted(shapes.get("hinted_search", []))),
                   "kernel_source_sha16": bench.knn_source_hash(), "date": datetime.date.today().isoformat(),
                   "launches_averaged": first.get("launches_averaged", 0),
@@ -53,11 +57,12 @@ def main():
                   "method": "scripts/pmc_knn.sh: separate rocprofv3 --pmc passes (--kernel-trace only) over scripts/knn_loop.py; "
                             "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half of a wide coalesced read, "
                             "MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated); Infinity-Cache hits are included in these "
-                            "memory-side counters, the 80 MB map is resident there after warm-up",
-                  "first_search": first, "hinted_search": out.get("hinted_search", {})}}
-    path = os.path.join(root, "knn_traffic.json")
+                            f"memory-side counters (the map of {nm} points x 16 B is resident there after warm-up when it fits its 256 MiB); "
+                            f"config {cfg}: {kind} scan of {nq} points",
+                  "first_search": first, "hinted_search": out.get("hinted_search", {})}
     json.dump(doc, open(path, "w"), indent=1)
-    print(json.dumps(doc["c2"], indent=1)[:1500])
+    print(cfg, json.dumps({k: doc[cfg][k] for k in ("kernel", "kernel_source_sha16", "hbm_bytes_per_launch")}, indent=1))
+    print(cfg, "instructions per wavefront", first.get("instructions_per_wavefront"))
 
 
 if __name__ == "__main__":

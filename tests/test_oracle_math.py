@@ -138,3 +138,60 @@ def test_eigen_summation_order_sensitivity(oracle, synth, small_case):
         assert v["accept_mask_flips"] <= 5
         assert v["max_abs_dpd2_m"] < 1e-3
         assert v["posterior_dpos_m"] < 1e-6 and v["posterior_drot_rad"] < 1e-7
+
+
+def _golden_plane_cases(n=4000):
+    """The 4 000 neighbourhoods of tests/golden/make_model_golden.py (the generator only: the module itself binds the product)."""
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_model_golden.py")).read()
+    ns = {"np": np}
+    exec(src[src.index("def plane_cases"):src.index("def main")], ns)
+    return ns["plane_cases"](np.random.default_rng(20240926), n)
+
+
+def test_esti_plane_against_the_exact_referee(oracle):
+    """"Parity unpinned" tightened as far as this image allows: the oracle's esti_plane restates Eigen's
+    ColPivHouseholderQR from a reading of Eigen; oracle/referee.py pins it on the mathematics Eigen implements instead.  For each
+    of the 4 000 golden neighbourhoods (noisy planes at map-like coordinates, near-collinear and near-coincident sets) the 5 x 3
+    least-squares problem of common_lib.h:511-520 is solved EXACTLY (rationals), and the oracle's (n^, d) must be
+      * the exact least-squares solution of a problem within 16 u32 ||A||_F of the given one (backward error after Walden, Karlson
+        and Sun -- what any backward-stable fp32 QR delivers, whatever its pivoting or summation order),
+      * hence within the first-order perturbation bound on the five signed distances the inlier test reads,
+      * with the SAME accept decision (common_lib.h:528-534) wherever every exact margin to the 0.1 m threshold exceeds that bound.
+    The referee has teeth: an fp32 solve of the normal equations (not backward stable at kappa ~ 1e3..1e4) fails it by orders of
+    magnitude, and so does a plane with the sign convention of d reversed."""
+    from oracle import referee
+    cases = _golden_plane_cases()
+    planes = np.zeros((len(cases), 4), np.float32)
+    oks = np.zeros(len(cases), bool)
+    worst_be, worst_pd, n_dec, n_und = 0.0, 0.0, 0, 0
+    for i, p in enumerate(cases):
+        oks[i], planes[i] = oracle.esti_plane(p, 0.1)
+        r = referee.referee_case(p, planes[i], oks[i], c_bound=16.0)
+        assert not r["singular"]
+        worst_be = max(worst_be, r["backward_error_over_u"])
+        worst_pd = max(worst_pd, r["pd_max_diff"] / r["pd_bound"])
+        if r["decision_equal"] is None:
+            n_und += 1
+        else:
+            n_dec += 1
+            assert r["decision_equal"], (i, r)
+    assert worst_be <= 16.0 and worst_pd <= 1.0
+    assert n_dec >= 0.95 * len(cases) and n_und < 0.05 * len(cases)
+    # the batched fp64 route bench.py uses on every plane of a scan gives the same verdicts on these cases
+    b = referee.referee_batch_fp64(cases, planes, oks, c_bound=16.0)
+    assert b["audited"] == len(cases) and abs(b["max_backward_error_over_u"] - worst_be) < 1e-3 * worst_be
+    assert b["decisions_equal"] and b["decidable"] == n_dec and b["pd_diff_over_bound_max"] <= 1.0
+    # teeth 1: normal equations in fp32
+    bad = np.zeros_like(planes)
+    for i, p in enumerate(cases[:400]):
+        A = p.astype(np.float32)
+        x = np.linalg.solve((A.T @ A).astype(np.float32), (-A.sum(0)).astype(np.float32)).astype(np.float32)
+        nrm = np.float32(np.linalg.norm(x))
+        bad[i] = np.concatenate([x / nrm, [np.float32(1) / nrm]])
+    bb = referee.referee_batch_fp64(cases[:400:5], bad[:400:5], oks[:400:5], c_bound=16.0)         # the well-conditioned kind
+    assert bb["max_backward_error_over_u"] > 100.0
+    # teeth 2: d with the other sign convention (n^.p - d)
+    flipped = planes.copy(); flipped[:, 3] *= -1
+    bf = referee.referee_batch_fp64(cases[:400], flipped[:400], oks[:400], c_bound=16.0)
+    assert bf["max_backward_error_over_u"] > 1e4
