@@ -154,6 +154,12 @@ struct lio_ctx {
     bool pass_gated = false;                   // ... and was released through a gate (re-enqueued directly once if its gate gave up)
     long long n_gate_reenqueued = 0;
     long long n_rows_direct_dma = 0;           // lio_measure_rows calls whose rows the copy engine wrote straight into the caller's page-locked buffers
+    // a scan handed over as page-locked host records (lio_scan_set_async) whose pull has not been issued yet: the first search
+    // pass of the scan pulls it inside knn27_kernel; anything else that needs d_body first launches the stand-alone pull
+    bool pull_pending = false;
+    const void* pull_alias = nullptr;          // device alias of the host records
+    int pull_stride = 0, pull_n = 0;
+    int dbg_fused_pull = 1;                    // lio_debug_set("fused_pull", 0): always the stand-alone pull kernel (A/B switch)
     long long n_scan_pulled = 0;               // scans a kernel pulled out of page-locked host records (lio_scan_set_async)
     // page-locked destinations the rows of the callback path are copied into directly (lio_measure_rows)
     int listed_last_search = 0;                // unproven queries of the most recent search pass: predicts the next one's
@@ -929,7 +935,8 @@ TreeArgs tree_args(lio_ctx* c, int nq, int stride, float4* nbr, uint8_t* cnt, fl
     return ta;
 }
 int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14& pose, int nq, int stride,
-            float4* nbr, uint8_t* cnt, float4* ulist, unsigned long long* useeds, bool use_hint, bool walk_now, const GateState* gate = nullptr) {
+            float4* nbr, uint8_t* cnt, float4* ulist, unsigned long long* useeds, bool use_hint, bool walk_now, const GateState* gate = nullptr,
+            bool pull_raw = false) {
     hipStream_t s = c->stream;
     // d_counters[0] / d_cand are zero here: zeroed at creation and re-zeroed by whoever consumes them
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
@@ -940,6 +947,10 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     if (body != nullptr && nq > FUSED_TRANSFORM_MAX_QUERIES) {       // (see transform_kernel, lio_knn.hip)
         HIPCHK(c, launch_transform(body, nq, pose, queries_world, s));
         ka.body = nullptr;
+    }
+    if (pull_raw && ka.body != nullptr) {
+        ka.body_raw = static_cast<const char*>(c->pull_alias); ka.body_raw_stride = c->pull_stride; ka.body_fill = c->d_body;
+        ka.body_raw_aligned = (c->pull_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(c->pull_alias) & 15u) == 0u) ? 1 : 0;
     }
     ka.nq = nq; ka.nq_stride = stride;
     ka.nbr = nbr; ka.cnt = cnt; ka.ulist = ulist; ka.useeds = useeds; ka.n_unres = c->d_counters; ka.cand_total = c->census ? c->d_cand : nullptr;
@@ -959,7 +970,19 @@ extern "C" {
 // Passes armed ahead of their pose (gate_arm) sit on the stream behind a gate kernel that waits for the host: whoever else wants
 // the stream -- every entry point that enqueues on it or waits for it -- calls them off first.
 static void gate_call_off(lio_ctx* c);
-static inline void enter(lio_ctx* c) { if (c->gate_n > 0) gate_call_off(c); }
+// ... and a scan whose pull out of the caller's host records is still owed (lio_scan_set_async) is pulled before anything but
+// its first search pass looks at the scan buffer.
+static void flush_pull(lio_ctx* c) {
+    c->pull_pending = false;
+    if (c->pull_n > 0 && hipSetDevice(c->device) == hipSuccess) {
+        const hipError_t e = launch_scan_pull(c->pull_alias, c->pull_stride, c->pull_n, c->d_body, c->stream);
+        if (e != hipSuccess) c->err = std::string("launch_scan_pull: ") + hipGetErrorString(e);
+    }
+}
+static inline void enter(lio_ctx* c) {
+    if (c->gate_n > 0) gate_call_off(c);
+    if (c->pull_pending) flush_pull(c);
+}
 
 const char* lio_version(void) { return "lio_hip 0.2 (gfx950)"; }
 int lio_device_count(void) {
@@ -1929,6 +1952,7 @@ static int scan_reset(lio_ctx* c, int n) {
 }
 int lio_scan_set(lio_ctx* c, const float* body_pts, int n, int stride_bytes) {
     if (!c || n < 0 || (n > 0 && !body_pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
+    c->pull_pending = false;
     enter(c);
     if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_set", "n exceeds max_scan_points");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1938,6 +1962,7 @@ int lio_scan_set(lio_ctx* c, const float* body_pts, int n, int stride_bytes) {
 }
 int lio_scan_set_device(lio_ctx* c, const void* d_body_f4, int n) {
     if (!c || n < 0 || (n > 0 && !d_body_f4)) return LIO_ERR_INVALID_ARG;
+    c->pull_pending = false;
     enter(c);
     if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_set_device", "n exceeds max_scan_points");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1958,13 +1983,20 @@ static bool is_pinned_host(const void* p) {
 int lio_scan_set_async(lio_ctx* c, const float* body_pts, int n, int stride_bytes) {
     if (!c || n < 0 || (n > 0 && !body_pts) || stride_bytes < 12 || (stride_bytes & 3) != 0) return LIO_ERR_INVALID_ARG;
     if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_set_async", "n exceeds max_scan_points");
+    c->pull_pending = false;                    // (a scan nobody looked at is simply replaced)
     enter(c);
     HIPCHK(c, hipSetDevice(c->device));
     if (n > 0 && is_pinned_host(body_pts) && is_pinned_host(reinterpret_cast<const char*>(body_pts) + (size_t)(n - 1) * (size_t)stride_bytes + 11)) {
         void* alias = nullptr;
         HIPCHK(c, hipHostGetDevicePointer(&alias, const_cast<float*>(body_pts), 0));
-        HIPCHK(c, launch_scan_pull(alias, stride_bytes, n, c->d_body, c->stream));
         ++c->n_scan_pulled;
+        if (c->dbg_fused_pull && n <= FUSED_TRANSFORM_MAX_QUERIES) {
+            // not yet: the first search pass of the scan pulls its queries itself (KnnArgs.body_raw), the search runs beside the
+            // transfer; whatever else wants the scan buffer first makes up for it (enter())
+            c->pull_pending = true; c->pull_alias = alias; c->pull_stride = stride_bytes; c->pull_n = n;
+        } else {
+            HIPCHK(c, launch_scan_pull(alias, stride_bytes, n, c->d_body, c->stream));
+        }
         return scan_reset(c, n);
     }
     const int rc = upload_points(c, body_pts, (size_t)n, stride_bytes, c->d_body);
@@ -2300,10 +2332,14 @@ static int enqueue_pass(lio_ctx* c, const Pose14& pose, bool do_search, bool ext
                         unsigned long long* seq_out) {
     hipStream_t s = c->stream;
     const int nq = c->nq;
+    // the scan is still in the caller's host records (lio_scan_set_async): its first search pulls it; anything else pulls first
+    const bool pull_here = c->pull_pending && do_search && gate == nullptr && nq == c->pull_n && nq <= FUSED_TRANSFORM_MAX_QUERIES;
+    if (c->pull_pending && !pull_here) flush_pull(c);
     if (do_search) {
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
-        const int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk, gate);
+        const int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk, gate, pull_here);
         if (rc != LIO_OK) return rc;
+        if (pull_here) c->pull_pending = false;
     }
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.gate = gate; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
@@ -2701,6 +2737,7 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
         return LIO_OK;
     }
     if (std::strcmp(key, "rows_direct") == 0) { c->dbg_rows_direct = (int)value; return LIO_OK; }
+    if (std::strcmp(key, "fused_pull") == 0) { c->dbg_fused_pull = value != 0; return LIO_OK; }
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
     if (std::strcmp(key, "pre_enqueue") == 0) { c->dbg_pre_enqueue = value != 0; return LIO_OK; }
     if (std::strcmp(key, "gate_mispredict") == 0) { c->dbg_gate_mispredict = value != 0; return LIO_OK; }

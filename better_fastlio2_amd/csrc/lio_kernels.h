@@ -18,6 +18,14 @@ struct KnnArgs {
     const float4*    world_in;      // queries in the world frame (body == nullptr)
     const float4*    body;          // or: feats_down_body -- the kernel transforms with `pose` itself (one wavefront per
     float4*          world_out;     //     workgroup, fp64 -> fp32, laserMapping.cpp:1894-1899) and writes feats_down_world
+    // the first search of a scan that was handed over as page-locked HOST records (lio_scan_set_async): the transforming wavefront
+    // pulls x, y, z of its queries over PCIe itself (device alias of the host records, `body_raw_stride` bytes apart) and leaves
+    // them in `body_fill` (= body) for every later reader -- the pull of the whole scan runs beside the search instead of in front
+    // of it (a stand-alone pull kernel: ~105 us for 100 k records of 48 bytes, then a 23 us search; fused: the longer of the two)
+    const char*      body_raw;      // nullptr: the scan is resident, read `body`
+    int              body_raw_stride;
+    int              body_raw_aligned;   // records start on 16-byte boundaries: one 16-byte read each
+    float4*          body_fill;
     Pose14           pose;
     const GateState* gate;          // non-null: the pose (and the order to skip the launch) come from there (lio_common.h)
     int              nq;

@@ -191,7 +191,21 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             if (!(a.tune & 1)) __builtin_amdgcn_s_setprio(3);
             const int qi = blockIdx.x * (WPB * GPW) + lane;
             if (qi < a.nq) {
-                const float4 b = a.body[qi];
+                float4 b;
+                if (a.body_raw != nullptr) {
+                    // (host memory through its device alias: one PCIe read per record, thousands of workgroups' worth in flight)
+                    const char* rec = a.body_raw + (size_t)qi * (size_t)a.body_raw_stride;
+                    if (a.body_raw_aligned) {
+                        b = *reinterpret_cast<const float4*>(rec);
+                    } else {
+                        const float* p = reinterpret_cast<const float*>(rec);
+                        b.x = p[0]; b.y = p[1]; b.z = p[2];
+                    }
+                    b.w = 0.0f;
+                    a.body_fill[qi] = b;
+                } else {
+                    b = a.body[qi];
+                }
                 const PoseQ s = pose_unpack(a.gate != nullptr ? a.gate->pose : a.pose);
                 float wx, wy, wz;
                 body_to_world(s, b.x, b.y, b.z, wx, wy, wz);

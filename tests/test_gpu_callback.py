@@ -154,7 +154,8 @@ def test_scan_set_async_equals_scan_set(gpu_capi, small_case, stride_floats):
     rec = np.full((n, stride_floats), 7.0, np.float32)
     rec[:, :3] = sc.body
     L = ctx.L
-    for pinned in (False, True):
+    for pinned, fused in ((False, 1), (True, 1), (True, 0)):
+        ctx.debug_set("fused_pull", fused)          # 1: the first search pulls its own queries; 0: a pull kernel in front of it
         buf = rec.copy()
         if pinned:
             assert L.lio_host_register(buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
@@ -166,6 +167,12 @@ def test_scan_set_async_equals_scan_set(gpu_capi, small_case, stride_floats):
         nx, nd, nc = ctx.neighbors()
         assert g["m"] == g0["m"] and np.array_equal(g["HTH"], g0["HTH"]) and np.array_equal(g["HTh"], g0["HTh"])
         assert bits_equal(nx, nx0) and bits_equal(nd, nd0) and np.array_equal(nc, nc0)
+        assert bits_equal(ctx.scan_cloud(1), np.ascontiguousarray(sc.body, np.float32))     # the scan buffer every later reader sees
+        # a scan handed over and never searched is pulled by whoever asks for it first
+        buf[:, :3] += 1.0
+        assert L.lio_scan_set_async(ctx.h, buf.ctypes.data_as(C.c_void_p), n, 4 * stride_floats) == 0
+        assert bits_equal(ctx.scan_cloud(1), np.ascontiguousarray(sc.body + 1.0, np.float32))
+        buf[:, :3] -= 1.0
         if pinned:
             ctx.synchronize()
             assert L.lio_host_unregister(buf.ctypes.data_as(C.c_void_p)) == 0
