@@ -115,7 +115,10 @@ def latency_summary(lat_s):
         return None
     v = np.sort(np.asarray(lat_s, np.float64)) * 1e3
     q = lambda f: float(v[min(len(v) - 1, int(np.ceil(f * len(v))) - 1)])
-    return {"unit": "ms", "steps": int(len(v)), "p50": q(0.50), "p90": q(0.90), "p99": q(0.99), "max": float(v[-1])}
+    out = {"unit": "ms", "steps": int(len(v)), "p50": q(0.50), "p90": q(0.90), "p99": q(0.99), "max": float(v[-1])}
+    if len(v) >= 1000:
+        out["p99.9"] = q(0.999)
+    return out
 
 
 def timed_steps(step_fn, steps: int, warmup: int, dist, device, lat=None):
@@ -501,7 +504,11 @@ def main():
         if rank != 0:
             world = synth.World(points=None, voxel=voxel, ground_half=meta[0], walls=meta[1], seed=meta[2])
     # room for the inserts of the node loop: every replica applies the lists of ALL ranks (~0.1 nq points per rank and step)
-    ctx = capi.LioContext(voxel, max_scan_points=nq, max_map_points=nm + 2_000_000 * max(1, world_size), device=local, lanes_per_query=a.lanes)
+    # (+ the long node-loop window of N = 1; + the gathered lists of the emulated world: W x ~0.15 nq points per step)
+    room = 2_000_000 * max(1, world_size)
+    if world_size == 1 and not a.no_extras:
+        room += 4_000_000 + (int(0.2 * nq) * a.emulate_world * 40 if a.emulate_world > 1 else 0)
+    ctx = capi.LioContext(voxel, max_scan_points=nq, max_map_points=nm + room, device=local, lanes_per_query=a.lanes)
     if dist is not None:
         torch.cuda.synchronize(device)
         ctx.map_build_device(pts4.data_ptr(), nm)
@@ -731,6 +738,24 @@ def main():
             except capi.LioError as e:
                 # (C5: eight ranks' inserts of 1 M-point scans outgrow the map capacity this bench allocates)
                 extras["node_loop_emulated_world%d" % a.emulate_world] = {"skipped": str(e)}
+        if dist is None:
+            # the tail of the real loop: a window long enough to hold the full index rebuilds the retired-slot budget triggers by itself
+            # (the 48-step window above sees none; `sustained` prices one in).  Per-step wall times, p99.9 and max included.
+            n_long = int(os.environ.get("LIO_BENCH_LONG_STEPS", "2400" if a.config != "c5" else "0"))
+            if n_long > 0 and a.steps >= 20:
+                info_l0 = ctx.map_info()
+                lat_long = []
+                try:
+                    t_long = timed_steps(step_node, n_long, 0, None, device, lat_long)
+                    info_l1 = ctx.map_info()
+                    ll = latency_summary(lat_long)
+                    ll.update({"value": n_long / t_long, "unit_value": "scans/s", "full_index_rebuilds_in_window": info_l1["n_full_rebuilds"] - info_l0["n_full_rebuilds"],
+                               "incremental_index_updates_in_window": info_l1["n_incremental_updates"] - info_l0["n_incremental_updates"],
+                               "live_points_after": info_l1["n_live"],
+                               "slowest_steps_ms": [float(x) * 1e3 for x in sorted(lat_long)[-5:]]})
+                    extras["node_loop"]["latency_long_window"] = ll
+                except capi.LioError as e:
+                    extras["node_loop"]["latency_long_window"] = {"skipped": str(e), "steps_done": len(lat_long)}
     else:
         cold_ms = None
         post_ms = None
