@@ -357,13 +357,15 @@ def sustained_figure(ctx, per_step_s, info0, info1, one_more_step):
     rebuilds_in_window = info1["n_full_rebuilds"] - info0["n_full_rebuilds"]
     retired_per_step = max(info1["n_retired"] - info0["n_retired"], 0) / upd if rebuilds_in_window == 0 else None
     ctx.debug_set("retired_budget", 1)
-    ctx.synchronize()
+    one_more_step()                                            # (untimed: under the deferred exchange schedule this step only holds its batch back;
+    ctx.synchronize()                                          #  the NEXT one lets it into the map -- and meets the budget)
     t0 = time.perf_counter()
     one_more_step()
     ctx.synchronize()
     forced_ms = (time.perf_counter() - t0) * 1e3
     ctx.debug_set("retired_budget", 0)
     info2 = ctx.map_info()
+    info1 = dict(info1, n_full_rebuilds=info2["n_full_rebuilds"] - 1) if info2["n_full_rebuilds"] - info1["n_full_rebuilds"] == 2 else info1   # (the untimed step rebuilt too)
     rebuild_ms = max(forced_ms - per_step_s * 1e3, 0.0)
     budget = ctx.debug_get("retired_budget")                 # retired slots that trigger a rebuild (a multiple of the live points)
     # the forced rebuild compacts the few retired slots of this window; the one at the budget also streams `budget` dead
@@ -381,7 +383,7 @@ def sustained_figure(ctx, per_step_s, info0, info1, one_more_step):
 
 
 def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, P0_p, ulog_ref, k_steps, n_rot, step_own, tick,
-                        device, node_loop_1):
+                        device, node_loop_1, deferred=False):
     """What ONE rank of a W-GPU job does per scan, measured on one GPU ("the only serial term is
     applying W x the inserts per replica"): its own scan step, then lio_replicate_step with the lists of all W ranks --
     the library's loop-back mode packs W - 1 PARKED ranks' messages into the gathered buffer where ncclAllGather would
@@ -408,6 +410,10 @@ def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, 
         v_scans.append(ds); v_priors.append(xs)
     ctx.debug_set("replicate_loopback", 1)
     ctx.replicate_init(b"", W - 1, W)
+    # deferred: the gathered lists of exchange k enter the map at the start of exchange k + 1, the read-only half of their
+    # Add_Points runs on a side stream beside this rank's scan step k + 1 (lio_replicate_defer)
+    ctx.replicate_defer(deferred)
+    side0 = ctx.debug_get("plans_on_side_stream")
     kfv = capi.Esekf(kf.maximum_iter)
     acc = {"own": 0.0, "exchange": 0.0, "n_add": 0, "n_nodown": 0, "steps": 0}
     lat = []
@@ -420,11 +426,11 @@ def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, 
     def one(timed):
         k = tick[0] % n_rot
         for v in range(W - 1):                                  # untimed: the other ranks' scan steps, lists parked
+            ctx.debug_set("replicate_loopback_rank", v)
             rc = L.lio_eskf_scan_step_device(kfv.h, ctx.h, v_priors[v][k].ctypes.data_as(C.c_void_p), P0_p,
                                              C.c_void_p(v_scans[v][k].data_ptr()), nq, 0.001, ext_i, ulog_ref)
             if rc != 0:
                 raise capi.LioError("virtual rank scan step failed: " + L.lio_last_error(ctx.h).decode())
-            ctx.debug_set("replicate_loopback_rank", v)
             ctx.replicate_step(kfv.get_x()[:14], voxel, True)
         ctx.debug_set("replicate_loopback_rank", W - 1)
         ctx.synchronize()
@@ -458,6 +464,9 @@ def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, 
            "vs_node_loop_world1": (1.0 / per_step) / node_loop_1["value"],
            "latency": latency_summary(lat),
            "sustained": sustained_figure(ctx, per_step, info0, info, lambda: one(False)),
+           "schedule": "deferred (lio_replicate_defer): lists of exchange k enter the map at the start of exchange k + 1, their read-only half "
+                       "planned on a side stream beside scan step k + 1" if deferred else "immediate: every exchange ends with its lists in the map",
+           "plans_on_the_side_stream": ctx.debug_get("plans_on_side_stream") - side0,
            "how": f"one GPU, lio_debug_set replicate_loopback: {W - 1} virtual ranks park their lists (untimed), the timed rank "
                   "runs its scan step + lio_replicate_step over all lists; no wire time"}
     if "value" in out["sustained"] and "value" in node_loop_1.get("sustained", {}):
@@ -685,6 +694,7 @@ def main():
             uid = [capi.replicate_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             ctx.replicate_init(uid[0], rank, world_size)
+            ctx.replicate_defer(True)                          # (every rank alike: the gathered lists of a step enter the map at the start of the next exchange)
         k_node = max(8, min(a.steps, 48))
         ctx.profile_enable(False)
         ctx.profile_reset()
@@ -706,7 +716,7 @@ def main():
         extras["node_loop"] = {"value": world_size * k_node / t_node, "unit": "scans/s", "ms_per_step": t_node / k_node * 1e3,
                                "steps": k_node, "map_update_ms_per_step": maint["seconds"] / max(maint["steps"], 1) * 1e3,
                                "inserted_per_step": (maint["n_add"] + maint["n_nodown"]) / max(maint["steps"], 1),
-                               "exchange": "lio_replicate_step: one ncclAllGather (RCCL over xGMI) on the library's stream" if dist is not None else "none (1 rank)",
+                               "exchange": "lio_replicate_step: one ncclAllGather (RCCL over xGMI) on the library's stream, deferred schedule (lio_replicate_defer)" if dist is not None else "none (1 rank)",
                                "incremental_index_updates": info["n_incremental_updates"], "full_index_rebuilds": info["n_full_rebuilds"],
                                "boundary_points_replayed_per_step": info["n_boundary_points"] / max(info["n_incremental_updates"], 1),
                                "latency": latency_summary(lat_node)}
@@ -731,13 +741,19 @@ def main():
         post_ms = prof_post["knn27"]["total_ms"] / max(prof_post["knn27"]["launches"], 1)
         cand_post_mean = float(np.mean(cand_post))
         if dist is None and a.emulate_world > 1:
+            key = "node_loop_emulated_world%d" % a.emulate_world
             try:
-                extras["node_loop_emulated_world%d" % a.emulate_world] = emulated_world_loop(
-                    a.emulate_world, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, P0_p, ulog_ref, max(8, min(a.steps, 24)),
-                    n_rot, step_resident, tick, device, extras["node_loop"])
+                # (both schedules start from the SAME map: the world as generated -- the loops above and each other's inserts would
+                # otherwise leave the second run fewer points to add)
+                ctx.map_build(world.points)
+                imm = emulated_world_loop(a.emulate_world, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, P0_p, ulog_ref, max(8, min(a.steps, 24)),
+                                          n_rot, step_resident, tick, device, extras["node_loop"], deferred=False)
+                ctx.map_build(world.points)
+                extras[key] = emulated_world_loop(a.emulate_world, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, P0_p, ulog_ref,
+                                                  max(8, min(a.steps, 24)), n_rot, step_resident, tick, device, extras["node_loop"], deferred=True)
+                extras[key]["immediate_schedule"] = imm
             except capi.LioError as e:
-                # (C5: eight ranks' inserts of 1 M-point scans outgrow the map capacity this bench allocates)
-                extras["node_loop_emulated_world%d" % a.emulate_world] = {"skipped": str(e)}
+                extras[key] = {"skipped": str(e)}
         if dist is None:
             # the tail of the real loop: a window long enough to hold the full index rebuilds the retired-slot budget triggers by itself
             # (the 48-step window above sees none; `sustained` prices one in).  Per-step wall times, p99.9 and max included.

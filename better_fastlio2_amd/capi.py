@@ -64,7 +64,7 @@ class lio_imu_info(C.Structure):
 # every symbol include/lio_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_device_count", "lio_stream", "lio_synchronize",
-    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_replicate_unique_id", "lio_replicate_init", "lio_replicate_finalize", "lio_replicate_queue_boxes", "lio_replicate_step", "lio_fov_segment", "lio_map_reconstruct",
+    "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_replicate_unique_id", "lio_replicate_init", "lio_replicate_finalize", "lio_replicate_queue_boxes", "lio_replicate_step", "lio_replicate_defer", "lio_fov_segment", "lio_map_reconstruct",
     "lio_map_set_downsample_param", "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_acquire_removed_points", "lio_map_get_info", "lio_map_nearest_search",
     "lio_scan_set", "lio_scan_set_device", "lio_scan_set_async", "lio_host_register", "lio_host_unregister", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_measure_want_rows", "lio_eskf_update_iterated_dyn_share_callback", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get", "lio_debug_set", "lio_debug_get", "lio_debug_stamps",
@@ -122,6 +122,7 @@ def load(build_if_missing: bool = True):
     L.lio_replicate_unique_id.argtypes = [_vp]
     L.lio_replicate_init.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int]
     L.lio_replicate_finalize.argtypes = [_vp]
+    L.lio_replicate_defer.argtypes = [_vp, C.c_int]
     L.lio_replicate_finalize.restype = None
     L.lio_replicate_queue_boxes.argtypes = [_vp, _vp, C.c_int]
     L.lio_replicate_step.argtypes = [_vp, _vp, C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -365,6 +366,11 @@ class LioContext:
         """lio_replicate_init: unique_id = the 128 bytes of replicate_unique_id() made by rank 0 (ignored for world 1)."""
         buf = (C.c_char * 128).from_buffer_copy(unique_id.ljust(128, b"\0")[:128]) if unique_id else None
         self._chk(self.L.lio_replicate_init(self.h, buf, rank, world, list_capacity), "lio_replicate_init")
+
+    def replicate_defer(self, on: bool = True):
+        """lio_replicate_defer: the gathered lists of exchange k enter the map at the start of exchange k + 1; the read-only half
+        of their Add_Points runs on a side stream beside scan step k + 1."""
+        self._chk(self.L.lio_replicate_defer(self.h, int(on)), "lio_replicate_defer")
 
     def replicate_queue_boxes(self, boxes):
         b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)

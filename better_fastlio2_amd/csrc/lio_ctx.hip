@@ -243,6 +243,32 @@ struct lio_ctx {
     float4 *d_rep_send = nullptr, *d_rep_recv = nullptr;
     float rep_boxes[6 * REP_MAX_BOXES]{};      // delete boxes queued for the next exchange
     int rep_n_boxes = 0;
+    // ---- the DEFERRED schedule of the exchange (lio_replicate_defer): the gathered lists of exchange k enter the map at the
+    // START of exchange k + 1 -- after scan step k + 1 has searched the map without them -- so that the read-only half of their
+    // Add_Points (voxel keys, the grouping sort, the speculative fold: fold_batch_plan) runs on a SIDE stream beside scan step
+    // k + 1 and only the half that writes the map (fold_commit, the index update) stays between two scan steps.
+    bool rep_defer = false;
+    struct DeferredBatch {
+        bool pending = false;                  // a gathered batch waits to enter the map
+        bool plan_owed = false;                // its plan may run on the side stream: the next scan step launches it (lio_measure_begin)
+        bool planned = false;                  // ... and has been launched there (ev_side says when it is done)
+        uint32_t n_add = 0, n_plain = 0, n_boxes = 0;
+        HostBox box;
+        FoldArgs fa{};
+        BoundaryArgs ba{};
+    } def;
+    float4* d_def_add[2] = {nullptr, nullptr};     // gathered PointToAdd lists: [def_cur] = the deferred batch, [def_cur ^ 1] = the next gather
+    float4* d_def_plain[2] = {nullptr, nullptr};   // gathered PointNoNeedDownsample lists
+    float* d_def_boxes[2] = {nullptr, nullptr};    // gathered delete boxes
+    size_t cap_def = 0;
+    int def_cur = 0;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_side = nullptr;
+    void* h_small2 = nullptr;                  // a second host-mapped mail box (the totals of an exchange, read after the settle's own wait)
+    uint32_t* d_small2 = nullptr;
+    uint32_t small2_seq = 0;
+    long long n_plans_on_side_stream = 0, n_settled = 0;
+    int def_last_counter = 0, def_last_deleted = 0;   // tmp_counter / deleted points of the batch the last exchange let into the map
     // loop-back test mode (lio_debug_set "replicate_loopback", then lio_replicate_init without an id): rep_world VIRTUAL
     // ranks on this one GPU.  lio_replicate_step as virtual rank r < world - 1 ("replicate_loopback_rank") parks that
     // rank's lists, counts and boxes; as rank world - 1 it packs every parked rank's message into its slot of the gathered
@@ -677,10 +703,15 @@ int collect_box_deleted(lio_ctx* c) {
 
 // ---- Add_Points machinery (ikd_Tree.cpp:414-489) --------------------------------------------------
 int apply_pending(lio_ctx* c);
+static int deferred_settle_fwd(lio_ctx* c);
 static int ensure_add_buffers(lio_ctx* c, size_t n) {
     if (n <= c->cap_add) return LIO_OK;
     // (grown by half at least: two dozen re-allocations are a millisecond, not something a growing batch should pay step by step)
     if (c->cap_add != 0 && n < c->cap_add + c->cap_add / 2) n = c->cap_add + c->cap_add / 2;
+    if (c->def.pending) {                      // (its plan points into the buffers about to be replaced)
+        const int rc = deferred_settle_fwd(c);
+        if (rc != LIO_OK) return rc;
+    }
     if (c->fold_n != 0 || c->plain_n != 0) {   // left behind by a call that failed half-way: index them first
         const int rc = apply_pending(c);
         if (rc != LIO_OK) return rc;
@@ -984,6 +1015,16 @@ static inline void enter(lio_ctx* c) {
     if (c->gate_n > 0) gate_call_off(c);
     if (c->pull_pending) flush_pull(c);
 }
+// ... and whoever reads or changes the MAP (everything but the measurement passes and the scan hand-over) first lets a gathered
+// batch the deferred exchange schedule still holds back enter it (lio_replicate_defer): outside lio_replicate_step the map is
+// always the map with every exchanged list applied.
+static int deferred_settle(lio_ctx* c, int* add_counter, int* n_deleted);
+namespace { int deferred_settle_fwd(lio_ctx* c) { return deferred_settle(c, nullptr, nullptr); } }
+static inline int enter_map(lio_ctx* c) {
+    enter(c);
+    if (c->def.pending) return deferred_settle(c, nullptr, nullptr);
+    return LIO_OK;
+}
 
 const char* lio_version(void) { return "lio_hip 0.2 (gfx950)"; }
 int lio_device_count(void) {
@@ -1164,6 +1205,14 @@ void lio_destroy(lio_ctx* c) {
     for (int w = 0; w < LIO_PROF_COUNT; ++w)
         for (hipEvent_t e : c->ev_pool[w]) (void)hipEventDestroy(e);
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
+    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+    if (c->h_small2) (void)hipHostFree(c->h_small2);
+    for (int i = 0; i < 2; ++i) {
+        if (c->d_def_add[i]) (void)hipFree(c->d_def_add[i]);
+        if (c->d_def_plain[i]) (void)hipFree(c->d_def_plain[i]);
+        if (c->d_def_boxes[i]) (void)hipFree(c->d_def_boxes[i]);
+    }
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -1180,13 +1229,14 @@ int lio_synchronize(lio_ctx* c) {
     enter(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, stream_wait(c));
+    if (c->def.planned) HIPCHK(c, hipStreamSynchronize(c->side_stream));       // (the plan of a deferred batch, beside the scan step)
     return LIO_OK;
 }
 
 // ---- map ---------------------------------------------------------------------------------------
 int lio_map_build(lio_ctx* c, const float* pts, long long n, int stride_bytes) {
     if (!c || n < 0 || (n > 0 && !pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     if ((size_t)n > c->cap_map) return c->fail(LIO_ERR_CAPACITY, "lio_map_build", "n exceeds max_map_points");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = upload_points(c, pts, (size_t)n, stride_bytes, c->d_pts_tmp);
@@ -1200,7 +1250,7 @@ int lio_map_build(lio_ctx* c, const float* pts, long long n, int stride_bytes) {
 }
 int lio_map_build_device(lio_ctx* c, const void* d_pts_f4, long long n) {
     if (!c || n < 0 || (n > 0 && !d_pts_f4)) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     if ((size_t)n > c->cap_map) return c->fail(LIO_ERR_CAPACITY, "lio_map_build_device", "n exceeds max_map_points");
     HIPCHK(c, hipSetDevice(c->device));
     if (n > 0)
@@ -1220,17 +1270,12 @@ int lio_map_reconstruct(lio_ctx* c, const float* pts, long long n, int stride_by
 // index: the batch is grouped by down-sample voxel, every group folds against the indexed points (tomb-stoning what it
 // replaces) and leaves its survivor in d_add_out; the counts stay on the device until the index update's read-back.
 // At most one down-sampled batch per index update (pending points are not in the index yet).
-static int fold_batch_device(lio_ctx* c, const float4* batch, uint32_t n, const HostBox& box) {
+// First half: everything that only READS the map -- voxel keys, the grouping sort, boundary classification, the speculative
+// fold (fold_plan_kernel), the list of dirty groups -- on the context's current stream (`c->stream`: the deferred schedule of
+// the replica exchange points it at the side stream for the duration of this call).  fa / ba: what the second half needs.
+static int fold_batch_plan(lio_ctx* c, const float4* batch, uint32_t n, const HostBox& box, FoldArgs& fa, BoundaryArgs& ba) {
     hipStream_t s = c->stream;
-    if (n == 0) return LIO_OK;
-    if (c->fold_n != 0) {
-        const int rc = apply_pending(c);
-        if (rc != LIO_OK) return rc;
-    }
-    if ((size_t)c->n_live + (size_t)c->plain_n + (size_t)n > c->cap_map)
-        return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
     if ((size_t)n > c->cap_add) return c->fail(LIO_ERR_CAPACITY, "Add_Points", "batch buffers too small");
-    c->last_add_counter = 0;
     const float ds = c->cfg.filter_size_map_min;
     const KeyFrame vf = voxel_frame(box, ds);
     const int kb = frame_bits(vf);
@@ -1251,22 +1296,42 @@ static int fold_batch_device(lio_ctx* c, const float4* batch, uint32_t n, const 
     view.skey = c->d_add_keys2; view.sord = c->d_add_order2; view.n_dev = nullptr; view.n_add = 0; view.n = n; view.shift = 0;
     // boundary points (outside their own fp32 box / inside a neighbour's): their groups leave the parallel fold
     // and are replayed point by point
-    BoundaryArgs ba{};
+    ba = BoundaryArgs{};
     ba.map_pts = c->d_pts; ba.l1table = c->d_ltable + c->levels.off[1]; ba.l1mask = c->levels.mask[1]; ba.child = c->d_child;
     ba.grid = c->grid; ba.ds = ds; ba.new_pts = batch; ba.view = view; ba.frame = vf;
     ba.dirty = c->d_add_dirty; ba.dirty_pt = c->d_add_dirty_pt; ba.dlist = c->d_add_dlist; ba.n_dirty = c->d_apply + 10;
     ba.seq_out = c->d_add_out + n; ba.n_added = c->d_apply + 5; ba.n_replaced = c->d_apply + 4;
-    FoldArgs fa{};
+    fa = FoldArgs{};
     fa.map_pts = c->d_pts; fa.l1table = ba.l1table; fa.l1mask = ba.l1mask; fa.child = c->d_child;
     fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch; fa.view = view;
     fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
     fa.plan = c->d_add_plan; fa.ranges = c->d_add_ranges; fa.count_parts = c->d_add_parts;
     HIPCHK(c, launch_fold_plan(fa, ba, s));
     HIPCHK(c, launch_compact_dirty(ba, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
-    HIPCHK(c, launch_fold_commit(fa, ba, s));
+    return LIO_OK;
+}
+// Second half: the plans of the clean groups are carried out, the dirty groups replayed (tomb-stones in the map, survivors in
+// d_add_out); the batch is then pending for the index update.  The map must not have changed since the plan.
+static int fold_batch_commit(lio_ctx* c, const FoldArgs& fa, const BoundaryArgs& ba, uint32_t n, const HostBox& box) {
+    HIPCHK(c, launch_fold_commit(fa, ba, c->stream));
     c->fold_n = n;
     c->batch_box.merge(box);
     return LIO_OK;
+}
+static int fold_batch_device(lio_ctx* c, const float4* batch, uint32_t n, const HostBox& box) {
+    if (n == 0) return LIO_OK;
+    if (c->fold_n != 0) {
+        const int rc = apply_pending(c);
+        if (rc != LIO_OK) return rc;
+    }
+    if ((size_t)c->n_live + (size_t)c->plain_n + (size_t)n > c->cap_map)
+        return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
+    c->last_add_counter = 0;
+    FoldArgs fa{};
+    BoundaryArgs ba{};
+    const int rc = fold_batch_plan(c, batch, n, box, fa, ba);
+    if (rc != LIO_OK) return rc;
+    return fold_batch_commit(c, fa, ba, n, box);
 }
 // One Add_Points(.., false) call: the points are simply pending (they must stay where they are until the index update)
 static int plain_batch_device(lio_ctx* c, const float4* batch, uint32_t n, const HostBox& box) {
@@ -1295,7 +1360,7 @@ static int rebuild_from_stored(lio_ctx* c, int* add_counter = nullptr) {
 // of down-sampled inserts that changed the tree (tmp_counter), 0 when downsample_on is false.
 int lio_map_add(lio_ctx* c, const float* pts, int n, int stride_bytes, int downsample_on, int* n_added) {
     if (!c || n < 0 || (n > 0 && !pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     if (n_added) *n_added = 0;
     if (n == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1319,7 +1384,7 @@ int lio_map_add_pair(lio_ctx* c, const float* add_pts, int n_add, const float* n
                      int stride_bytes, int* add_counter) {
     if (!c || n_add < 0 || n_nodown < 0 || (n_add > 0 && !add_pts) || (n_nodown > 0 && !nodown_pts) || stride_bytes < 12)
         return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     if (add_counter) *add_counter = 0;
     if (n_add + n_nodown == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1407,7 +1472,7 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
                         int apply, float* out_add_xyz, int* n_add, float* out_nodown_xyz, int* n_nodown,
                         int* add_counter) {
     if (!c || !state14 || !(filter_size_map_min > 0.0)) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     if (n_add) *n_add = 0;
     if (n_nodown) *n_nodown = 0;
     if (add_counter) *add_counter = 0;
@@ -1447,7 +1512,7 @@ int lio_map_incremental_device(lio_ctx* c, const double state14[14], double filt
                                void** d_add_f4, int* n_add, void** d_nodown_f4, int* n_nodown) {
     if (!c || !state14 || !(filter_size_map_min > 0.0) || !d_add_f4 || !n_add || !d_nodown_f4 || !n_nodown)
         return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     ListWords w;
     int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, &w);
     if (rc != LIO_OK) return rc;
@@ -1459,7 +1524,7 @@ int lio_map_incremental_device(lio_ctx* c, const double state14[14], double filt
 int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const void* d_nodown_f4, int n_nodown,
                             int* add_counter) {
     if (!c || n_add < 0 || n_nodown < 0 || (n_add > 0 && !d_add_f4) || (n_nodown > 0 && !d_nodown_f4)) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     if (add_counter) *add_counter = 0;
     if (n_add + n_nodown == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1504,7 +1569,7 @@ int lio_map_add_pair_device(lio_ctx* c, const void* d_add_f4, int n_add, const v
 }
 
 // ---- replica exchange behind the C ABI ------------------------------------------------
-static int delete_boxes_resident(lio_ctx* c, int nbb, int* total);
+static int delete_boxes_resident(lio_ctx* c, int nbb, int* total, const float* d_boxes = nullptr);
 static void account_deleted(lio_ctx* c, int total);
 // RCCL is loaded at run time (dlopen): a single-GPU user of this library needs no librccl.  `backend "nccl" IS RCCL on
 // ROCm`: a process that already carries one (PyTorch bundles its own librccl.so) shares it through the SONAME.
@@ -1600,7 +1665,7 @@ int lio_replicate_init(lio_ctx* c, const void* id128, int rank, int world, int l
 
 void lio_replicate_finalize(lio_ctx* c) {
     if (!c) return;
-    enter(c);
+    (void)enter_map(c);
     if (c->rep_comm) {
         RcclApi* r = rccl_api(nullptr);
         if (r) (void)r->CommDestroy(c->rep_comm);
@@ -1614,6 +1679,12 @@ void lio_replicate_finalize(lio_ctx* c) {
     c->rep_world = 0; c->rep_n_boxes = 0; c->rep_loopback = false; c->rep_staged = 0;
 }
 
+int lio_replicate_defer(lio_ctx* c, int on) {
+    if (!c) return LIO_ERR_INVALID_ARG;
+    { const int rc = enter_map(c); if (rc != LIO_OK) return rc; }      // (a batch held back under the old setting enters the map first)
+    c->rep_defer = on != 0;
+    return LIO_OK;
+}
 int lio_replicate_queue_boxes(lio_ctx* c, const float* minmax6, int nb) {
     if (!c || nb < 0 || (nb > 0 && !minmax6)) return LIO_ERR_INVALID_ARG;
     if (c->rep_world == 0) return c->fail(LIO_ERR_INVALID_ARG, "lio_replicate_queue_boxes", "lio_replicate_init has not been called");
@@ -1637,7 +1708,104 @@ static int pack_parked_rank(lio_ctx* c, int r, uint32_t cap) {
     HIPCHK(c, launch_replicate_pack(pr, c->stream));
     return LIO_OK;
 }
-static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4], HostBox& box) {
+// the side stream, its event, the second mail box and the two sets of gathered-list buffers of the deferred schedule
+static int ensure_deferred(lio_ctx* c) {
+    if (!c->side_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    if (!c->ev_side) HIPCHK(c, hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    if (!c->h_small2) {
+        HIPCHK(c, hipHostMalloc(&c->h_small2, 256, hipHostMallocMapped));
+        std::memset(c->h_small2, 0, 256);
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_small2, c->h_small2, 0));
+    }
+    if (c->cap_def < c->cap_add) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->d_def_add[i]) (void)hipFree(c->d_def_add[i]);
+            if (c->d_def_plain[i]) (void)hipFree(c->d_def_plain[i]);
+            c->d_def_add[i] = c->d_def_plain[i] = nullptr;
+        }
+        c->cap_def = 0;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(c, hipMalloc((void**)&c->d_def_add[i], c->cap_add * sizeof(float4)));
+            HIPCHK(c, hipMalloc((void**)&c->d_def_plain[i], c->cap_add * sizeof(float4)));
+            if (!c->d_def_boxes[i]) HIPCHK(c, hipMalloc((void**)&c->d_def_boxes[i], 6 * REP_MAX_BOXES_TOTAL * sizeof(float)));
+        }
+        c->cap_def = c->cap_add;
+    }
+    return LIO_OK;
+}
+// the plan of the deferred batch on the SIDE stream (called from the first measurement pass of the next scan step, behind its
+// launches): nothing on the main stream waits for it until the next exchange
+static int deferred_launch_plan(lio_ctx* c) {
+    lio_ctx::DeferredBatch& d = c->def;
+    d.plan_owed = false;
+    if (!d.pending || d.planned || d.n_add == 0) return LIO_OK;
+    hipStream_t main_stream = c->stream;
+    c->stream = c->side_stream;                 // (every launch helper of the fold takes the context's stream)
+    const int rc = fold_batch_plan(c, c->d_def_add[c->def_cur], d.n_add, d.box, d.fa, d.ba);
+    c->stream = main_stream;
+    if (rc != LIO_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_side, c->side_stream));
+    d.planned = true;
+    ++c->n_plans_on_side_stream;
+    return LIO_OK;
+}
+// main stream <- side stream: nothing that follows on the main stream starts before the plan is done (usually it finished
+// during the scan step: then the host has seen it complete and no dependency is enqueued at all)
+static int deferred_join_side(lio_ctx* c) {
+    if (!c->def.planned) return LIO_OK;
+    const hipError_t q = hipEventQuery(c->ev_side);
+    if (q == hipErrorNotReady) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_side, 0));
+    else if (q != hipSuccess) return c->fail(LIO_ERR_HIP, "deferred exchange: side stream", hipGetErrorString(q));
+    return LIO_OK;
+}
+// The deferred batch enters the map: Delete_Point_Boxes(all boxes), Add_Points(all PointToAdd, true),
+// Add_Points(all PointNoNeedDownsample, false), rank order inside each -- exactly what the immediate schedule runs, one
+// exchange later.  A batch whose plan has not run (no scan step came in between, or it carries delete boxes: their points must
+// be gone before the fold looks at the voxels) is planned here, on the main stream.
+static int deferred_settle(lio_ctx* c, int* add_counter, int* n_deleted) {
+    lio_ctx::DeferredBatch& d = c->def;
+    if (add_counter) *add_counter = 0;
+    if (n_deleted) *n_deleted = 0;
+    if (!d.pending) return LIO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = deferred_join_side(c);
+    if (rc != LIO_OK) return rc;
+    const uint32_t n_add = d.n_add, n_plain = d.n_plain, n_boxes = d.n_boxes;
+    const HostBox box = d.box;
+    const bool planned = d.planned;
+    const int cur = c->def_cur;
+    d.pending = false; d.plan_owed = false; d.planned = false;      // (whatever happens below, the batch is not applied twice)
+    ++c->n_settled;
+    int deleted = 0;
+    if (n_boxes > 0 && c->n_points > 0) {
+        c->hint_valid = false;
+        rc = delete_boxes_resident(c, (int)n_boxes, &deleted, c->d_def_boxes[cur]);
+        if (rc != LIO_OK) return rc;
+        account_deleted(c, deleted);
+    }
+    c->last_add_counter = 0;
+    if (n_add > 0) {
+        if (c->fold_n != 0) {                   // (left behind by a call that failed half-way)
+            rc = apply_pending(c);
+            if (rc != LIO_OK) return rc;
+        }
+        if ((size_t)c->n_live + (size_t)c->plain_n + (size_t)n_add > c->cap_map)
+            return c->fail(LIO_ERR_CAPACITY, "lio_replicate_step", "live points + gathered lists exceed max_map_points");
+        if (!planned) {
+            rc = fold_batch_plan(c, c->d_def_add[cur], n_add, box, d.fa, d.ba);
+            if (rc != LIO_OK) return rc;
+        }
+        rc = fold_batch_commit(c, d.fa, d.ba, n_add, box);
+        if (rc != LIO_OK) return rc;
+    }
+    rc = plain_batch_device(c, c->d_def_plain[cur], n_plain, box);
+    if (rc != LIO_OK) return rc;
+    rc = rebuild_from_stored(c, add_counter);
+    if (n_deleted) *n_deleted = deleted;
+    return rc;
+}
+
+static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4], HostBox& box, bool defer = false) {
     hipStream_t s = c->stream;
     const size_t msg_f4 = (size_t)REP_HEADER_F4 + 2 * (size_t)cap;
     RepPackArgs pa{};
@@ -1663,9 +1831,28 @@ static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4], H
     RepCompactArgs ca{};
     ca.gathered = c->d_rep_recv; ca.world = c->rep_world; ca.cap = cap; ca.add_out = c->d_add_pts; ca.nodown_out = c->d_add_pts2;
     ca.boxes_out = c->d_boxes; ca.totals = c->d_counters + 8; ca.bbox = c->d_counters + 24;
+    if (defer) {                                // the gathered lists wait in buffers of their own until the next exchange
+        const int g = c->def_cur ^ 1;
+        ca.add_out = c->d_def_add[g]; ca.nodown_out = c->d_def_plain[g]; ca.boxes_out = c->d_def_boxes[g];
+    }
     HIPCHK(c, launch_replicate_compact(ca, s));
     uint32_t w[22] = {};                                        // d_counters[8 .. 29]: the four totals, the list kernel's error word, ... the bounding box
-    HIPCHK(c, read_back(c, w, c->d_counters + 8, sizeof(w)));
+    if (defer && c->def.pending) {
+        // The totals go into the second mail box WITHOUT a wait; the previous batch enters the map behind them on the stream, and
+        // its own read-back (the statistics of the index update) is the one host wait of this exchange: by then the totals are there.
+        const uint32_t seq2 = ++c->small2_seq;
+        HIPCHK(c, launch_publish_words(c->d_counters + 8, 22, c->d_small2, seq2, s));
+        const int rc = deferred_settle(c, &c->def_last_counter, &c->def_last_deleted);
+        if (rc != LIO_OK) return rc;
+        volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(c->h_small2) + 32;
+        for (uint64_t spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq2; ++spins) {
+            if (spins > (1ull << 28)) { HIPCHK(c, hipStreamSynchronize(s)); break; }
+        }
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq2) return c->fail(LIO_ERR_HIP, "lio_replicate_step", "the totals of the exchange never arrived");
+        std::memcpy(w, c->h_small2, sizeof(w));
+    } else {
+        HIPCHK(c, read_back(c, w, c->d_counters + 8, sizeof(w)));
+    }
     if (w[4] != 0u) return list_kernel_failed(c);
     std::memcpy(tot, w, 4 * sizeof(uint32_t));
     box_from_images(w + 16, box);
@@ -1682,8 +1869,10 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
     if (n_deleted) *n_deleted = 0;
     if (add_counter) *add_counter = 0;
     HIPCHK(c, hipSetDevice(c->device));
+    int rc = deferred_join_side(c);
+    if (rc != LIO_OK) return rc;
     // map_incremental's two lists of this rank stay on the device, and so do their counts
-    int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, nullptr);
+    rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, nullptr);
     if (rc != LIO_OK) return rc;
     if (c->rep_loopback && c->rep_rank + 1 < c->rep_world) {
         // loop-back: this call speaks for a virtual rank other than the last one -- park what it would have sent
@@ -1699,7 +1888,13 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
     }
     uint32_t tot[4] = {0, 0, 0, 0};
     HostBox box;
-    rc = replicate_exchange_apply(c, c->rep_cap, tot, box);
+    const bool defer = c->rep_defer;
+    if (defer) {
+        rc = ensure_deferred(c);
+        if (rc != LIO_OK) return rc;
+        c->def_last_counter = 0; c->def_last_deleted = 0;
+    }
+    rc = replicate_exchange_apply(c, c->rep_cap, tot, box, defer);
     if (rc != LIO_OK) return rc;
     if ((tot[3] & REP_FLAG_OVERFLOW) != 0 && c->rep_cap < (uint32_t)c->cap_q) {
         // some rank had more points than a message holds: every rank sees the flag, every rank repeats the exchange at
@@ -1707,11 +1902,29 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
         // if ... the first round's outputs are overwritten by the second)
         rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, nullptr);
         if (rc != LIO_OK) return rc;
-        rc = replicate_exchange_apply(c, (uint32_t)c->cap_q, tot, box);
+        rc = replicate_exchange_apply(c, (uint32_t)c->cap_q, tot, box, defer);
         if (rc != LIO_OK) return rc;
     }
     c->rep_n_boxes = 0;
     c->rep_staged = 0;
+    if (defer) {
+        // (a first exchange finds nothing to settle: its read-back was the plain one)
+        if ((size_t)c->n_live + (size_t)tot[0] + (size_t)tot[1] > c->cap_map)
+            return c->fail(LIO_ERR_CAPACITY, "lio_replicate_step", "live points + gathered lists exceed max_map_points");
+        lio_ctx::DeferredBatch& d = c->def;
+        c->def_cur ^= 1;                        // what was gathered is now the deferred batch
+        d.pending = tot[0] + tot[1] + tot[2] > 0;
+        d.planned = false;
+        d.n_add = tot[0]; d.n_plain = tot[1]; d.n_boxes = tot[2]; d.box = box;
+        // its plan may run beside the next scan step unless delete boxes have to go first (or nothing is down-sampled at all)
+        d.plan_owed = d.pending && tot[0] > 0 && tot[2] == 0;
+        if (!d.plan_owed) HIPCHK(c, reset_list_box(c));   // (no voxel_keys_kernel will do it before the next lists are made)
+        if (n_add_total) *n_add_total = (int)tot[0];
+        if (n_nodown_total) *n_nodown_total = (int)tot[1];
+        if (n_deleted) *n_deleted = c->def_last_deleted;
+        if (add_counter) *add_counter = c->def_last_counter;
+        return LIO_OK;
+    }
     if ((size_t)c->n_live + (size_t)tot[0] + (size_t)tot[1] > c->cap_map)
         return c->fail(LIO_ERR_CAPACITY, "lio_replicate_step", "live points + gathered lists exceed max_map_points");
     // every replica: the boxes of all ranks (rank order), then the insert lists of all ranks (rank order)
@@ -1751,21 +1964,22 @@ int lio_map_set_downsample_param(lio_ctx* c, float downsample_size) {
 // indexed first, so that the numbers are exact)
 long long lio_map_size(lio_ctx* c) {
     if (!c) return 0;
-    enter(c);
+    (void)enter_map(c);
     if ((c->fold_n != 0 || c->plain_n != 0) && hipSetDevice(c->device) == hipSuccess) (void)apply_pending(c);
     return (long long)c->n_points - (long long)c->n_retired;
 }
 long long lio_map_validnum(lio_ctx* c) {
     if (!c) return 0;
-    enter(c);
+    (void)enter_map(c);
     if ((c->fold_n != 0 || c->plain_n != 0) && hipSetDevice(c->device) == hipSuccess) (void)apply_pending(c);
     return (long long)c->n_live;
 }
 
 // Delete_by_range over the boxes already sitting in c->d_boxes (<= 64)
-static int delete_boxes_resident(lio_ctx* c, int nbb, int* total) {
+static int delete_boxes_resident(lio_ctx* c, int nbb, int* total, const float* d_boxes) {
+    if (d_boxes == nullptr) d_boxes = c->d_boxes;
     HIPCHK(c, hipMemsetAsync(c->d_counters + 2, 0, sizeof(uint32_t), c->stream));
-    HIPCHK(c, launch_delete_boxes(c->d_pts, c->n_points, c->d_boxes, nbb, c->d_counters + 2, c->stream));
+    HIPCHK(c, launch_delete_boxes(c->d_pts, c->n_points, d_boxes, nbb, c->d_counters + 2, c->stream));
     uint32_t cnt = 0;
     HIPCHK(c, read_back(c, &cnt, c->d_counters + 2, sizeof(uint32_t)));
     *total += (int)cnt;
@@ -1778,7 +1992,7 @@ static void account_deleted(lio_ctx* c, int total) {
 }
 int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_deleted) {
     if (!c || nb < 0 || (nb > 0 && !minmax6)) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     if (n_deleted) *n_deleted = 0;
     if (nb == 0 || c->n_points == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1807,7 +2021,7 @@ int lio_map_delete_boxes(lio_ctx* c, const float* minmax6, int nb, int* n_delete
 int lio_fov_segment(lio_ctx* c, const double pos_lid[3], double cube_len, float det_range, float* boxes_out,
                     int* n_boxes, int* n_deleted) {
     if (!c || !pos_lid) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     if (n_boxes) *n_boxes = 0;
     if (n_deleted) *n_deleted = 0;
     const float MOV_THRESHOLD = 1.5f;                                        // :53
@@ -1859,7 +2073,7 @@ int lio_fov_segment(lio_ctx* c, const double pos_lid[3], double cube_len, float 
 
 int lio_map_flatten(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
     if (!c || cap < 0 || (cap > 0 && !out_xyz)) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     HIPCHK(c, hipSetDevice(c->device));
     if (n) *n = (long long)c->n_live;
     if (c->n_points == 0 || cap == 0) return LIO_OK;
@@ -1881,7 +2095,7 @@ int lio_map_flatten(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
 
 int lio_map_acquire_removed_points(lio_ctx* c, float* out_xyz, long long cap, long long* n) {
     if (!c || !n || cap < 0) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     HIPCHK(c, hipSetDevice(c->device));
     {
         const int rc0 = collect_box_deleted(c);
@@ -1905,6 +2119,7 @@ int lio_map_acquire_removed_points(lio_ctx* c, float* out_xyz, long long cap, lo
 
 int lio_map_get_info(lio_ctx* c, lio_map_info* info) {
     if (!c || !info) return LIO_ERR_INVALID_ARG;
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     info->n_points = c->n_points; info->n_live = c->n_live; info->n_cells = c->n_cells;
     info->table_slots = (long long)c->levels.mask[1] + 1;
     info->cell_size = c->grid.cell; info->downsample_size = c->cfg.filter_size_map_min;
@@ -1918,7 +2133,7 @@ int lio_map_get_info(lio_ctx* c, lio_map_info* info) {
 int lio_map_nearest_search(lio_ctx* c, const float* q_xyz, int n, int stride_bytes, float* out_xyz,
                            float* out_sqdist, int* out_count) {
     if (!c || n < 0 || (n > 0 && !q_xyz) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    { const int rc_settle = enter_map(c); if (rc_settle != LIO_OK) return rc_settle; }
     if (n == 0) return LIO_OK;
     HIPCHK(c, hipSetDevice(c->device));
     if (n > c->cap_qs) {
@@ -2523,6 +2738,17 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
             return c->fail(rc, "lio_measure_begin (arming the next pass)", why.c_str());
         }
     }
+    // the plan of a gathered batch the deferred exchange holds back: onto the side stream now, beside this scan step (loop-back:
+    // beside the scan step of the LAST virtual rank -- the one a real rank's would run beside)
+    if (c->def.plan_owed && !c->want_rows && (!c->rep_loopback || c->rep_rank + 1 == c->rep_world)) {
+        const int rc = deferred_launch_plan(c);
+        if (rc != LIO_OK) {
+            const std::string why = c->err;
+            lio_out dropped;
+            (void)lio_measure_end(c, &dropped);
+            return c->fail(rc, "lio_measure_begin (planning the deferred batch)", why.c_str());
+        }
+    }
     // the next scan's upload, if one was handed over (lio_scan_upload_async): issued here, behind this pass's
     // launches, so that the runtime calls of the copy run while the GPU is busy with the pass
     if (c->upload_pending) {
@@ -2781,6 +3007,8 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "voxel_fast_runs") == 0) { *value = c->n_voxel_fast; return LIO_OK; }
     if (std::strcmp(key, "voxel_redone") == 0) { *value = c->n_voxel_redone; return LIO_OK; }
     if (std::strcmp(key, "gate_mail_in_vram") == 0) { *value = c->gate_mail_in_vram ? 1 : 0; return LIO_OK; }
+    if (std::strcmp(key, "plans_on_side_stream") == 0) { *value = c->n_plans_on_side_stream; return LIO_OK; }
+    if (std::strcmp(key, "deferred_settled") == 0) { *value = c->n_settled; return LIO_OK; }
     if (std::strcmp(key, "gate_reenqueued") == 0) { *value = c->n_gate_reenqueued; return LIO_OK; }
     if (std::strcmp(key, "scan_pulled") == 0) { *value = c->n_scan_pulled; return LIO_OK; }
     if (std::strcmp(key, "rows_direct_dma") == 0) { *value = c->n_rows_direct_dma; return LIO_OK; }

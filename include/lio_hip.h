@@ -158,6 +158,15 @@ int  lio_replicate_queue_boxes(lio_ctx* ctx, const float* minmax6, int nb);
  * false), rank order inside each.  Totals over all ranks are returned; *add_counter as Add_Points' return value.   */
 int  lio_replicate_step(lio_ctx* ctx, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
                         int* n_add_total, int* n_nodown_total, int* n_deleted, int* add_counter);
+/* The DEFERRED schedule of the exchange (off by default; every rank of a job must choose the same).  on != 0: the lists and
+ * boxes gathered by exchange k enter every replica at the START of exchange k + 1 instead of at the end of exchange k -- scan
+ * step k + 1 searches the map without them (all replicas alike: they stay bit-identical, and the sequence of Delete_Point_Boxes /
+ * Add_Points calls a replica sees is unchanged), and the half of their Add_Points that only READS the map (voxel keys, grouping
+ * sort, the speculative fold) runs on a second stream beside scan step k + 1; only the half that writes stays between two scan
+ * steps.  lio_replicate_step then returns the totals of the exchange it ran and *n_deleted / *add_counter of the batch that
+ * entered the map during the call (the previous exchange's).  Any other map call (lio_map_*, lio_fov_segment, ...) lets a batch
+ * that is held back enter first, so outside lio_replicate_step the map always holds every exchanged list.                     */
+int  lio_replicate_defer(lio_ctx* ctx, int on);
 /* KD_TREE::Delete_Point_Boxes (ikd_Tree.cpp:536-556): boxes = nb x {min xyz, max xyz}, half-open.  */
 int  lio_map_delete_boxes(lio_ctx* ctx, const float* minmax6, int nb, int* n_deleted);
 /* lasermap_fov_segment (src/laserMapping.cpp:1136-1200): the local-map cube (edge cube_len) follows the
@@ -310,7 +319,8 @@ results); "library_sort" sends every sort / compaction of map maintenance and sc
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
 /* counters for tests: "gate_released" / "gate_called_off" = pre-enqueued passes that ran / were called off; "voxel_fast_runs" /
  * "voxel_redone" = voxel-filter attempts on the compact-key path / sweeps filtered twice after a wrong prediction;
- * "retired_budget" = the retired-slot budget in force; "gate_reenqueued" = passes put on the stream again because their gate had
+ * "retired_budget" = the retired-slot budget in force; "plans_on_side_stream" / "deferred_settled" = batches of the deferred exchange schedule whose plan ran beside a scan
+ * step / that entered the map; "gate_reenqueued" = passes put on the stream again because their gate had
  * given up (a host stalled for seconds); "scan_pulled" = scans a kernel pulled out of page-locked host records
  * (lio_scan_set_async); "rows_direct_dma" = lio_measure_rows calls served by copies straight into page-locked h_x / h            */
 int  lio_debug_get(lio_ctx* ctx, const char* key, long long* value);

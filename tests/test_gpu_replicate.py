@@ -151,6 +151,96 @@ def test_loopback_world(gpu_capi, oracle, synth, small_case, W):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("W", [2, 8])
+def test_deferred_schedule_in_a_loopback_world(gpu_capi, oracle, synth, small_case, W):
+    """lio_replicate_defer: the lists and boxes gathered by exchange k enter the map at the START of exchange k + 1; scan step
+    k + 1 searches the map without them while the read-only half of their Add_Points (keys, sort, the speculative fold) runs on
+    a side stream, and only the half that writes stays between two scan steps.  Held against a twin context driven by plain
+    calls on the SAME schedule -- every rank's scan step, then the previous round's Delete_Point_Boxes + Add_Points pair -- so
+    the posterior of every scan step (it depends on every neighbour the search found) says the two maps were the same map
+    when they were searched; the flattened maps are compared at the end (any map call lets a batch that is held back enter
+    first) with each other and with the reference ikd-Tree fed the same sequence of calls (ikd_Tree.cpp:414-489, 536-556).  A
+    delete box travels in round 1 (its batch is planned after the deletion, on the main stream), one rank overflows its
+    message in round 0; the other batches must have been planned on the side stream."""
+    w = small_case["world"]
+    thin = np.ascontiguousarray(w.points[::2])
+    nq_small, nq_big = 1500, 6000
+    big_rank = W // 2
+    box_rank = max(0, W // 2 - 1) if W > 2 else 1
+    a = gpu_capi.LioContext(0.2, max_scan_points=nq_big, max_map_points=400_000)     # loop-back exchange, deferred schedule
+    b = gpu_capi.LioContext(0.2, max_scan_points=nq_big, max_map_points=400_000)     # twin: plain calls on the same schedule
+    a.map_build(thin); b.map_build(thin)
+    ref = oracle.RefIkdTree(0.2) if oracle.ref_available() else None
+    if ref is not None:
+        ref.build(thin)
+    a.debug_set("replicate_loopback", 1)
+    kfa, kfb = gpu_capi.Esekf(3), gpu_capi.Esekf(3)
+    held = None                                              # the twin's batch of the previous round: (boxes, add, nodown)
+    rounds = 4
+
+    def apply_held():
+        boxes, add, nodown = held
+        nd = b.map_delete_boxes(boxes) if len(boxes) else 0
+        cnt = b.map_add_pair(add, nodown)
+        if ref is not None:
+            if len(boxes):
+                assert ref.delete_boxes(boxes) == nd
+            assert ref.add(add, True) == cnt
+            ref.add(nodown, False)
+        return nd, cnt
+
+    for k in range(rounds):
+        posts, lists, boxes_all = [], [], []
+        for r in range(W):                                   # the twin: every rank's scan step on the map WITHOUT the held batch
+            n = nq_big if r == big_rank else nq_small
+            sc = synth.make_scan(w, n, seed=synth.SEED + 31 + 17 * k + 1000 * r, pos=(2.0 + 0.9 * k + 5.0 * r, -1.5 + 0.4 * k - 3.0 * r, 0.0),
+                                 rpy=(0.004, -0.006, 0.3 + 0.05 * k + 0.7 * r))
+            ps, rt = synth.perturb_state(sc, dpos=0.05, drot_deg=0.3, seed=synth.SEED + 5 + k + r)
+            x0 = gpu_capi.make_state26(ps, rt, sc.off_R, sc.off_T)
+            kfb.change_x(x0); kfb.change_P(synth.init_cov())
+            b.scan_set(sc.body)
+            kfb.update_iterated_dyn_share_modified(b, 0.001, False)
+            post = kfb.get_x()[:14].copy()
+            posts.append((sc, x0, post))
+            lists.append(b.map_incremental(post, 0.2, True, apply=False, want_lists=True))
+        if k == 0:
+            sizes = sorted(max(l["n_add"], l["n_nodown"]) for l in lists)
+            a.replicate_init(b"", W - 1, W, (sizes[-1] + sizes[-2]) // 2)
+            a.replicate_defer(True)
+        for r in range(W):
+            sc, x0, post = posts[r]
+            a.debug_set("replicate_loopback_rank", r)       # (before the scan step: the LAST rank's step is the one the plan runs beside)
+            kfa.change_x(x0); kfa.change_P(synth.init_cov())
+            a.scan_set(sc.body)
+            kfa.update_iterated_dyn_share_modified(a, 0.001, False)
+            assert np.array_equal(kfa.get_x()[:14], post), (k, r)      # searched the same map
+            if r == box_rank and k == 1:
+                bx = np.array([[-30.0 + 2 * k, -30.0, -1.0, -27.0 + 2 * k, 30.0, 5.0]], np.float32)
+                a.replicate_queue_boxes(bx)
+                boxes_all.append(bx)
+            ra = a.replicate_step(post, 0.2, True)
+        add = np.concatenate([l["add"] for l in lists]); nodown = np.concatenate([l["nodown"] for l in lists])
+        assert (ra["n_add"], ra["n_nodown"]) == (len(add), len(nodown))
+        if held is not None:                                 # the previous round's batch entered both maps during this exchange
+            nd_b, cnt_b = apply_held()
+            assert (ra["n_deleted"], ra["add_counter"]) == (nd_b, cnt_b)
+        else:
+            assert (ra["n_deleted"], ra["add_counter"]) == (0, 0)
+        held = (np.concatenate(boxes_all) if boxes_all else np.zeros((0, 6), np.float32), add, nodown)
+    assert a.debug_get("deferred_settled") == rounds - 1
+    assert a.debug_get("plans_on_side_stream") == rounds - 2    # every settled batch but the one with the delete box
+    # any map call lets the last batch in
+    apply_held()
+    assert a.map_validnum() == b.map_validnum()
+    assert a.debug_get("deferred_settled") == rounds
+    assert bits_equal(_key(a.map_flatten()), _key(b.map_flatten()))
+    if ref is not None:
+        assert ref.validnum() == a.map_validnum()
+        ref.quiesce(50)
+        assert bits_equal(_key(a.map_flatten()), _key(ref.flatten()))
+    a.close(); b.close()
+
+
 _WORKER = r"""
 import os, sys, numpy as np
 sys.path.insert(0, sys.argv[1])
