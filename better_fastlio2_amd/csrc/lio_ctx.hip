@@ -1710,7 +1710,14 @@ static int pack_parked_rank(lio_ctx* c, int r, uint32_t cap) {
 }
 // the side stream, its event, the second mail box and the two sets of gathered-list buffers of the deferred schedule
 static int ensure_deferred(lio_ctx* c) {
-    if (!c->side_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    if (!c->side_stream) {
+        // the LOWEST priority the device offers: what runs there is meant to fill the gaps of the scan step (measured: no
+        // difference to the default priority on this part, scan step 144.6-148.3 vs 146.1 us; LIO_SIDE_PRIORITY=0 switches back)
+        int least = 0, greatest = 0;
+        const char* e = std::getenv("LIO_SIDE_PRIORITY");
+        if ((e != nullptr && e[0] == '0') || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+        HIPCHK(c, hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
+    }
     if (!c->ev_side) HIPCHK(c, hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
     if (!c->h_small2) {
         HIPCHK(c, hipHostMalloc(&c->h_small2, 256, hipHostMallocMapped));
@@ -2597,7 +2604,10 @@ static int enqueue_pass(lio_ctx* c, const Pose14& pose, bool do_search, bool ext
         ra.rows = c->d_rows; ra.m_dev = reinterpret_cast<int*>(c->d_counters + 18);
     }
     if (do_search && !separate_walk) {
-        ra.n_walkers = residual_walkers(nq); ra.walk_done = c->d_counters + 16;
+        // (walker workgroups sized by the previous pass's list instead of the scan -- 64-128 instead of 390 at C2 -- changed nothing:
+        // A/B on one box, three alternations, median step 115.8-116.7 vs 115.3-117.1 us; idle workgroups are not what the ramp costs)
+        ra.n_walkers = residual_walkers(nq);
+        ra.walk_done = c->d_counters + 16;
         ra.tree = tree_args(c, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds);
         ra.lunits = c->d_lunits;
     }
