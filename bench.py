@@ -694,7 +694,10 @@ def main():
             uid = [capi.replicate_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             ctx.replicate_init(uid[0], rank, world_size)
-            ctx.replicate_defer(True)                          # (every rank alike: the gathered lists of a step enter the map at the start of the next exchange)
+            # every rank alike: the gathered lists of a step enter the map at the start of the next exchange, their read-only half
+            # planned beside the next scan step -- where a scan step leaves room beside it (C2 / C3: latency-bound passes; C5's
+            # 1 M-point passes fill the GPU, the plan beside them costs more than it hides: 0.31 vs 0.41 of N = 1 emulated)
+            ctx.replicate_defer(nq <= 262144)
         k_node = max(8, min(a.steps, 48))
         ctx.profile_enable(False)
         ctx.profile_reset()
@@ -716,7 +719,7 @@ def main():
         extras["node_loop"] = {"value": world_size * k_node / t_node, "unit": "scans/s", "ms_per_step": t_node / k_node * 1e3,
                                "steps": k_node, "map_update_ms_per_step": maint["seconds"] / max(maint["steps"], 1) * 1e3,
                                "inserted_per_step": (maint["n_add"] + maint["n_nodown"]) / max(maint["steps"], 1),
-                               "exchange": "lio_replicate_step: one ncclAllGather (RCCL over xGMI) on the library's stream, deferred schedule (lio_replicate_defer)" if dist is not None else "none (1 rank)",
+                               "exchange": ("lio_replicate_step: one ncclAllGather (RCCL over xGMI) on the library's stream, " + ("deferred" if nq <= 262144 else "immediate") + " schedule") if dist is not None else "none (1 rank)",
                                "incremental_index_updates": info["n_incremental_updates"], "full_index_rebuilds": info["n_full_rebuilds"],
                                "boundary_points_replayed_per_step": info["n_boundary_points"] / max(info["n_incremental_updates"], 1),
                                "latency": latency_summary(lat_node)}
@@ -752,6 +755,7 @@ def main():
                 extras[key] = emulated_world_loop(a.emulate_world, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, P0_p, ulog_ref,
                                                   max(8, min(a.steps, 24)), n_rot, step_resident, tick, device, extras["node_loop"], deferred=True)
                 extras[key]["immediate_schedule"] = imm
+                extras[key]["schedule_bench_uses_for_n_gt_1"] = "deferred" if nq <= 262144 else "immediate"
             except capi.LioError as e:
                 extras[key] = {"skipped": str(e)}
         if dist is None:

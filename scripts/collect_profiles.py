@@ -15,6 +15,9 @@ for name, out in (("bench_c2.json", f"{tag}_bench_c2.json"), ("bench_c3.json", f
                   ("bench_c2_driver.json", f"{tag}_bench_c2_driver_cmdline.json"), ("emulated_timeline.txt", f"{tag}_emulated_world8_timeline.txt"),
                   ("node_loop_timeline.txt", f"{tag}_node_loop_timeline.txt"), ("rebuild_timeline.txt", f"{tag}_rebuild_timeline.txt"),
                   ("kernel_stats.txt", f"{tag}_bench_c2_extras_kernel_totals.txt"), ("host_trace.log", f"{tag}_host_trace.log"),
+                  # round 4 (scripts/end_of_round_r04.sh, scripts/r04_timeline.sh)
+                  ("emulated_timeline_deferred.txt", f"{tag}_emulated_world8_timeline_deferred.txt"),
+                  ("emulated_timeline_immediate.txt", f"{tag}_emulated_world8_timeline_immediate.txt"),
                   (os.path.join("prof_loop", "kernel_stats_trim.csv"), f"{tag}_loopbody_kernel_stats.csv")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 0:
@@ -24,8 +27,16 @@ ks = os.path.join(src, "prof", "kernel_stats.csv")
 if os.path.exists(ks):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "trim_kernel_stats.py"), ks,
                            os.path.join(dst, f"{tag}_bench_c2_kernel_stats.csv"),
-                           "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline (scripts/rocprof_bench.sh)"])
+                           "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras (the CONTRACT LOOP only: the drive + its untimed event-stamped repeat; scripts/rocprof_bench.sh)"])
     print("copied", f"{tag}_bench_c2_kernel_stats.csv")
+
+for sub, name, out, cmd in (("prof", "kernel_stats_all.csv", f"{tag}_bench_c2_kernel_stats_all_extras.csv", "python bench.py --steps 100 --warmup 10 --no-cpu-baseline (EVERY extra: averages mix the drive, the node loop's denser map, the emulated world and the 2 400-step window)"),
+                            ("prof_c3", "kernel_stats.csv", f"{tag}_bench_c3_kernel_stats.csv", "python bench.py --config c3 --steps 100 --warmup 10 --no-cpu-baseline --no-extras (the contract loop only)")):
+    ks2 = os.path.join(src, sub, name)
+    if os.path.exists(ks2):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "trim_kernel_stats.py"), ks2, os.path.join(dst, out),
+                               "rocprofv3 --kernel-trace --stats --output-format csv -- " + cmd + " (scripts/rocprof_bench.sh)"])
+        print("copied", out)
 
 # the fuzzers' verdict lines
 fz = [f for f in ("fuzz_map.log", "fuzz_loop.log", "fuzz_measure.log", "fuzz_scanprep.log") if os.path.exists(os.path.join(src, f))]

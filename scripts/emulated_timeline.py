@@ -1,14 +1,17 @@
 """Kernel time line of ONE timed segment of bench.py's emulated world (the last one of the run) out of a rocprofv3 kernel trace:
 from the end of the last virtual rank's parking (replicate_stage_kernel) to the end of the timed rank's exchange.  With the
 deferred schedule the plan of the held batch runs on a second queue beside the scan step: the queue of every kernel is printed.
-    python scripts/emulated_timeline.py <dir with *kernel_trace.csv> <out.txt>"""
+    python scripts/emulated_timeline.py <dir with *kernel_trace.csv> <out.txt> [which exchange, counted from the end: default 5]
+(bench.py --steps 8 runs 12 exchanges under the immediate schedule, then 12 under the deferred one; the last two of each are the
+forced-rebuild steps of `sustained`)"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 qcol = 'Queue_Id' if 'Queue_Id' in rows[0] else None
-last_compact = max(i for i, n in enumerate(names) if 'replicate_compact_kernel' in n)
+compacts = [i for i, n in enumerate(names) if 'replicate_compact_kernel' in n]
+last_compact = compacts[-int(sys.argv[3]) if len(sys.argv) > 3 else -5]
 a = last_compact
 while a > 0 and 'replicate_stage_kernel' not in names[a]:
     a -= 1
