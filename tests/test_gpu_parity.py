@@ -318,6 +318,33 @@ def test_passes_enqueued_ahead_of_their_pose(gpu_capi, synth, small_case):
     assert out["wrong"][2] >= 3                                       # (a flipped prediction is right where this update differs from the last)
 
 
+def test_a_pass_whose_gate_gave_up_is_put_on_the_stream_again(gpu_capi, small_case):
+    """A pass armed ahead of its pose sits behind a gate kernel that gives up after two seconds (a queue must never hang on a host
+    that does not come back).  A host that DOES come back late -- a debugger, SIGSTOP, a VM pause -- finds its pass stood down:
+    lio_measure_end then sees an idle stream without a record and enqueues the pass directly, once ("gate_reenqueued"), instead
+    of failing the iterated update.  Same numbers as the pass that was never armed."""
+    import time
+    w, sc, st = small_case["world"], small_case["scan"], small_case["state14"]
+    st2 = st.copy(); st2[:3] += [0.01, -0.02, 0.005]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+    ctx.map_build(w.points)
+    ctx.debug_set("pre_enqueue", 0)
+    ctx.scan_set(sc.body)
+    ref = [ctx.measure(st, True, False), ctx.measure(st2, False, False)]
+    ctx.debug_set("pre_enqueue", 1)
+    ctx.scan_set(sc.body)                                 # the pattern of the scan above (search, re-use) predicts this one's
+    a = ctx.measure(st, True, False)                      # ... arms the re-use pass behind a gate
+    assert ctx.debug_get("gate_reenqueued") == 0
+    time.sleep(2.4)                                       # the gate gives up
+    b = ctx.measure(st2, False, False)
+    assert ctx.debug_get("gate_reenqueued") == 1
+    for got, want in ((a, ref[0]), (b, ref[1])):
+        assert got["m"] == want["m"] and np.array_equal(got["HTH"], want["HTH"]) and np.array_equal(got["HTh"], want["HTh"])
+    c = ctx.measure(st2, True, False)                     # and the context goes on as if nothing had happened
+    assert c["m"] > 1000
+    ctx.close()
+
+
 @pytest.mark.parametrize("ext", [False, True])
 def test_reduction_across_workgroup_counts(gpu_capi, oracle, small_case, ext):
     """The cross-workgroup reduction (groups of 16 workgroups folded by designated reducers, then the group sums)
