@@ -151,6 +151,55 @@ def test_loopback_world(gpu_capi, oracle, synth, small_case, W):
     a.close(); b.close()
 
 
+def test_deferred_schedule_through_rccl(gpu_capi, oracle, synth, small_case):
+    """The deferred schedule with the REAL collective on the library's stream (one rank: ncclCommInitRank with world 1, the
+    all-gather really runs -- what `bench.py --gpus N` does on every rank): scan step k + 1 searches the map without the lists of
+    exchange k, which enter at the start of exchange k + 1 with their plan made on the side stream.  Twin context on the same
+    schedule through plain calls; posteriors equal at every step, maps equal at the end (and equal to the reference tree)."""
+    w = small_case["world"]
+    thin = np.ascontiguousarray(w.points[::2])
+    nq = 8000
+    a = gpu_capi.LioContext(0.2, max_scan_points=nq, max_map_points=400_000)
+    b = gpu_capi.LioContext(0.2, max_scan_points=nq, max_map_points=400_000)
+    a.map_build(thin); b.map_build(thin)
+    ref = oracle.RefIkdTree(0.2) if oracle.ref_available() else None
+    if ref is not None:
+        ref.build(thin)
+    a.replicate_init(gpu_capi.replicate_unique_id(), 0, 1, 0)
+    a.replicate_defer(True)
+    kfa, kfb = gpu_capi.Esekf(3), gpu_capi.Esekf(3)
+    held = None
+    for k in range(4):
+        sc, ps, rt = _drive(synth, w, nq, k)
+        x0 = gpu_capi.make_state26(ps, rt, sc.off_R, sc.off_T)
+        for ctx, kf in ((a, kfa), (b, kfb)):
+            kf.change_x(x0); kf.change_P(synth.init_cov())
+            ctx.scan_set(sc.body)
+            kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+        assert np.array_equal(kfa.get_x(), kfb.get_x()), k            # both searched the map without the previous exchange's lists
+        post = kfa.get_x()[:14]
+        ra = a.replicate_step(post, 0.2, True)
+        mine = b.map_incremental(post, 0.2, True, apply=False, want_lists=True)
+        assert (ra["n_add"], ra["n_nodown"]) == (mine["n_add"], mine["n_nodown"])
+        if held is not None:
+            cnt = b.map_add_pair(held["add"], held["nodown"])
+            assert ra["add_counter"] == cnt
+            if ref is not None:
+                assert ref.add(held["add"], True) == cnt
+                ref.add(held["nodown"], False)
+        held = mine
+    assert a.debug_get("plans_on_side_stream") == 3 and a.debug_get("deferred_settled") == 3
+    cnt = b.map_add_pair(held["add"], held["nodown"])
+    if ref is not None:
+        ref.add(held["add"], True); ref.add(held["nodown"], False)
+    assert a.map_validnum() == b.map_validnum()                        # (any map call lets the held batch in)
+    assert bits_equal(_key(a.map_flatten()), _key(b.map_flatten()))
+    if ref is not None:
+        ref.quiesce(50)
+        assert bits_equal(_key(a.map_flatten()), _key(ref.flatten()))
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("W", [2, 8])
 def test_deferred_schedule_in_a_loopback_world(gpu_capi, oracle, synth, small_case, W):
     """lio_replicate_defer: the lists and boxes gathered by exchange k enter the map at the START of exchange k + 1; scan step
