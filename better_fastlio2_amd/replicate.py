@@ -97,3 +97,41 @@ def apply_in_rank_order(map_like, insert_lists, downsample_on: bool = True) -> i
         if len(pts):
             total += map_like.map_add(pts, downsample_on)
     return total
+
+
+class DeferredExchange:
+    """The DEFERRED schedule of the exchange (lio_replicate_defer) as a protocol twin: the lists and boxes
+    gathered by exchange k enter every replica at the START of exchange k + 1 -- scan step k + 1 searches the map without them, on
+    every rank alike -- in the order every replica shares: Delete_Point_Boxes(all boxes), Add_Points(all PointToAdd, true),
+    Add_Points(all PointNoNeedDownsample, false), rank order inside each.  (In liblio_hip.so the read-only half of the held batch's
+    Add_Points runs on a side stream beside scan step k + 1; here only the ORDER is modelled -- which is what keeps the replicas
+    bit-identical.)  map_like: anything with map_add(points, downsample_on) and, when boxes are used, map_delete_boxes(boxes)."""
+
+    def __init__(self, capacity: int, device: "torch.device | str" = "cpu", group=None):
+        self.capacity, self.device, self.group = capacity, device, group
+        self.held = None                       # (boxes [nb, 6], add lists per rank, nodown lists per rank)
+
+    def _apply(self, map_like) -> int:
+        if self.held is None:
+            return 0
+        boxes, adds, nodowns = self.held
+        self.held = None
+        if len(boxes):
+            map_like.map_delete_boxes(boxes)
+        counter = apply_in_rank_order(map_like, adds, True)
+        apply_in_rank_order(map_like, nodowns, False)
+        return counter
+
+    def step(self, map_like, add_pts, nodown_pts, boxes=None) -> int:
+        """One exchange: gather this step's lists, let the PREVIOUS step's batch into the map, hold the new one.
+        Returns Add_Points' counter of the batch that entered."""
+        adds = exchange_inserts(add_pts, self.capacity, self.device, self.group)
+        nodowns = exchange_inserts(nodown_pts, self.capacity, self.device, self.group)
+        bx = exchange_boxes(np.zeros((0, 6), np.float32) if boxes is None else boxes, device=self.device, group=self.group)
+        counter = self._apply(map_like)
+        self.held = (bx, adds, nodowns)
+        return counter
+
+    def flush(self, map_like) -> int:
+        """Any other use of the map lets a held batch in first (lio_hip.h)."""
+        return self._apply(map_like)
