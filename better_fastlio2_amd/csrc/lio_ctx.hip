@@ -154,6 +154,10 @@ struct lio_ctx {
     bool pass_searched = false;                // the pass in flight is a search pass
     bool pass_gated = false;                   // ... and was released through a gate (re-enqueued directly once if its gate gave up)
     long long n_gate_reenqueued = 0;
+    int gate_in_kernel = 3;                    // bit 0: passes that re-use neighbours, bit 1: search passes -- wait for the host's word inside
+                                               // their first kernel instead of behind a gate kernel (mail slots in device memory only;
+                                               // LIO_GATE_IN_KERNEL / lio_debug_set("gate_in_kernel"))
+    long long n_gate_in_kernel = 0;
     long long n_rows_direct_dma = 0;           // lio_measure_rows calls whose rows the copy engine wrote straight into the caller's page-locked buffers
     // a scan handed over as page-locked host records (lio_scan_set_async) whose pull has not been issued yet: the first search
     // pass of the scan pulls it inside knn27_kernel; anything else that needs d_body first launches the stand-alone pull
@@ -968,7 +972,7 @@ TreeArgs tree_args(lio_ctx* c, int nq, int stride, float4* nbr, uint8_t* cnt, fl
 }
 int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14& pose, int nq, int stride,
             float4* nbr, uint8_t* cnt, float4* ulist, unsigned long long* useeds, bool use_hint, bool walk_now, const GateState* gate = nullptr,
-            bool pull_raw = false) {
+            bool pull_raw = false, const GateMail* mail = nullptr, unsigned long long expect = 0ull) {
     hipStream_t s = c->stream;
     // d_counters[0] / d_cand are zero here: zeroed at creation and re-zeroed by whoever consumes them
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
@@ -989,6 +993,9 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.use_hint = use_hint ? 1 : 0;
     ka.tune = c->dbg_knn_tune;
     ka.gate = gate;
+    if (mail != nullptr && ka.body != nullptr) {                      // (no gate kernel in front: the launch reads the host's word itself)
+        ka.mail = mail; ka.expect = expect; ka.gate_out = const_cast<GateState*>(gate); ka.gate = nullptr;
+    }
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
     ka.walk = (lanes == 4 || lanes == 8 || lanes == 16) ? (c->dbg_knn_walk >= 0 ? c->dbg_knn_walk : auto_walk(nq, lanes)) : 0;
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
@@ -1063,6 +1070,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     { const char* e = std::getenv("LIO_TRACE_HOST"); c->trace_host = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_PRE_ENQUEUE"); if (e != nullptr && e[0] == '0') c->dbg_pre_enqueue = 0; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_KNN_TUNE"); if (e != nullptr && e[0] >= '0' && e[0] <= '9') c->dbg_knn_tune = std::atoi(e); }   // (A/B runs of scripts)
+    { const char* e = std::getenv("LIO_GATE_IN_KERNEL"); if (e != nullptr && e[0] >= '0' && e[0] <= '3' && e[1] == 0) c->gate_in_kernel = e[0] - '0'; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_KNN_WALK"); if (e != nullptr && (e[0] == '0' || e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0) c->dbg_knn_walk = e[0] - '0'; }
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, c->device));
@@ -2569,7 +2577,7 @@ static bool rows_direct(const lio_ctx* c, int nq) {
 // yet -- the kernels take it from there (and stand down if told to).  Nothing of the context's pass state changes here
 // except the sequence number the pass consumes (*seq_out).
 static int enqueue_pass(lio_ctx* c, const Pose14& pose, bool do_search, bool ext, bool separate_walk, const GateState* gate,
-                        unsigned long long* seq_out) {
+                        unsigned long long* seq_out, const GateMail* mail = nullptr, unsigned long long expect = 0ull) {
     hipStream_t s = c->stream;
     const int nq = c->nq;
     // the scan is still in the caller's host records (lio_scan_set_async): its first search pulls it; anything else pulls first
@@ -2577,12 +2585,13 @@ static int enqueue_pass(lio_ctx* c, const Pose14& pose, bool do_search, bool ext
     if (c->pull_pending && !pull_here) flush_pull(c);
     if (do_search) {
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
-        const int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk, gate, pull_here);
+        const int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk, gate, pull_here, mail, expect);
         if (rc != LIO_OK) return rc;
         if (pull_here) c->pull_pending = false;
     }
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.gate = gate; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
+    if (mail != nullptr && !do_search) { ra.mail = mail; ra.expect = expect; ra.gate = nullptr; }   // (the first kernel of the pass reads the host's word)
     ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.rows = nullptr; ra.units = c->d_units; ra.gunits = c->d_gunits;
     if ((uint32_t)(c->seq + 1ull) == 0u) {
         // The partial sums carry the low 32 bits of the sequence number as their stamp (lio_measure.hip): when those go round, a
@@ -2660,12 +2669,21 @@ static int gate_arm(lio_ctx* c, bool do_search, bool ext) {
     for (int w = 0; c->prof != 0u && w < LIO_PROF_COUNT; ++w) if (c->ev_next[w] + 16 > 8192) return LIO_OK;
     const unsigned long long mail_seq = ++c->gate_mail_seq;
     GateState* st = c->d_gate + (mail_seq % lio_ctx::GATE_SLOTS);
-    const hipError_t ge = launch_gate(c->d_gate_mail + (mail_seq % lio_ctx::GATE_SLOTS), mail_seq, st, c->stream);
-    if (ge != hipSuccess) return c->fail(LIO_ERR_HIP, "launch_gate", hipGetErrorString(ge));
+    const GateMail* slot = c->d_gate_mail + (mail_seq % lio_ctx::GATE_SLOTS);
+    // Mail slots in device memory: the first kernel of the pass waits for the host's word itself (gate_poll, lio_device.h) --
+    // one dependent dispatch less between the host's word and the pass.  Slots in host memory (no large BAR): a one-wavefront
+    // gate kernel in front does the waiting (hundreds of workgroups polling over PCIe starve each other).
+    const bool in_kernel = c->gate_mail_in_vram && (c->gate_in_kernel & (do_search ? 2 : 1)) != 0;
+    if (!in_kernel) {
+        const hipError_t ge = launch_gate(slot, mail_seq, st, c->stream);
+        if (ge != hipSuccess) return c->fail(LIO_ERR_HIP, "launch_gate", hipGetErrorString(ge));
+    } else {
+        ++c->n_gate_in_kernel;
+    }
     lio_ctx::ArmedPass& ap = c->gate_q[c->gate_n++];
     ap.search = do_search; ap.ext = ext; ap.mail_seq = mail_seq; ap.pass_seq = 0;
     Pose14 none{};
-    const int rc = enqueue_pass(c, none, do_search, ext, false, st, &ap.pass_seq);
+    const int rc = enqueue_pass(c, none, do_search, ext, false, st, &ap.pass_seq, in_kernel ? slot : nullptr, mail_seq);
     if (rc != LIO_OK) { gate_call_off(c); return rc; }
     c->stamp('G');
     return LIO_OK;
@@ -2997,6 +3015,7 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
     if (std::strcmp(key, "pre_enqueue") == 0) { c->dbg_pre_enqueue = value != 0; return LIO_OK; }
     if (std::strcmp(key, "gate_mispredict") == 0) { c->dbg_gate_mispredict = value != 0; return LIO_OK; }
+    if (std::strcmp(key, "gate_in_kernel") == 0) { enter(c); c->gate_in_kernel = (int)(value & 3); return LIO_OK; }
     if (std::strcmp(key, "sequence_numbers") == 0) {           // test hook: the next pass / compaction launch take these numbers + 1 (stamp wrap-around)
         c->seq = (unsigned long long)value; c->compact_seq = (uint32_t)value; c->gsort_seq = (uint32_t)value;
         return LIO_OK;
@@ -3020,6 +3039,7 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "plans_on_side_stream") == 0) { *value = c->n_plans_on_side_stream; return LIO_OK; }
     if (std::strcmp(key, "deferred_settled") == 0) { *value = c->n_settled; return LIO_OK; }
     if (std::strcmp(key, "gate_reenqueued") == 0) { *value = c->n_gate_reenqueued; return LIO_OK; }
+    if (std::strcmp(key, "gate_in_kernel") == 0) { *value = c->n_gate_in_kernel; return LIO_OK; }
     if (std::strcmp(key, "scan_pulled") == 0) { *value = c->n_scan_pulled; return LIO_OK; }
     if (std::strcmp(key, "rows_direct_dma") == 0) { *value = c->n_rows_direct_dma; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_get", "unknown key");

@@ -42,4 +42,42 @@ __device__ __forceinline__ void cell_find(const HashEntry* l1table, uint32_t l1m
     if (index != nullptr) *index = ci;
 }
 
+// ---- the host's word to a pass that sits on the stream ahead of its pose, read by the FIRST KERNEL OF THE PASS itself ---------
+// (lio_ctx.hip gate_arm; the stand-alone gate_kernel of lio_knn.hip is the form for mail slots in host memory.)  One whole
+// wavefront calls gate_poll: lanes 0..16 fetch one word of the slot each -- fine-grained device memory the CPU writes through
+// the BAR, so a poll is a round trip to local memory -- until the sequence number the launch was made for is there with a
+// matching check word.  Returns the lane's word; `go` (wave-uniform) is false when the host called the pass off or nobody
+// answered for two seconds.  The wait is over before most of the launch's workgroups have been dispatched: the host writes the
+// word ~3 us after the previous pass's record, the dispatch of a dependent launch takes about as long.
+__device__ __forceinline__ unsigned long long mail_word(unsigned long long w, int i) {   // word i of the mail as a wave-uniform value
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, i);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), i);
+    return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+__device__ __forceinline__ unsigned long long gate_poll(const GateMail* mail, unsigned long long expect, bool& go) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long w = 0ull;
+    bool ok = false;
+    for (;;) {
+        if (lane < 17) w = __hip_atomic_load(&mail->w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (mail_word(w, 0) == expect) {
+            unsigned long long all[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) all[i] = mail_word(w, i);
+            if (gate_check(all) == mail_word(w, 16)) { ok = true; break; }
+        }
+        if (wall_clock64() - t0 > 200000000ull) break;             // 100 MHz: 2 s
+        __builtin_amdgcn_s_sleep(2);
+    }
+    go = ok && mail_word(w, 1) == GATE_GO;
+    return w;
+}
+__device__ __forceinline__ Pose14 gate_pose(unsigned long long w) {                       // words 2..15, wave-uniform
+    Pose14 p;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) p.v[i] = __longlong_as_double((long long)mail_word(w, 2 + i));
+    return p;
+}
+
 }  // namespace lio

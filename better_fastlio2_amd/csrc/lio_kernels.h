@@ -28,6 +28,12 @@ struct KnnArgs {
     float4*          body_fill;
     Pose14           pose;
     const GateState* gate;          // non-null: the pose (and the order to skip the launch) come from there (lio_common.h)
+    // non-null: this launch is the first kernel of a pass enqueued ahead of its pose and there is NO gate kernel in front of it --
+    // the transforming wavefront of every workgroup waits for the host's word itself (gate_poll, lio_device.h); workgroup 0
+    // leaves {skip, pose} in gate_out for the measurement kernel behind this launch
+    const GateMail*  mail;
+    unsigned long long expect;
+    GateState*       gate_out;
     int              nq;
     int              nq_stride;     // leading dimension of nbr
     float4*          nbr;           // [5][nq_stride]: x, y, z, sqdist of the k-th neighbour
@@ -79,6 +85,8 @@ struct ResidualArgs {
     int            nq_stride;
     Pose14         pose;
     const GateState* gate;          // non-null: the pose (and the order to skip the launch) come from there (lio_common.h)
+    const GateMail*  mail;          // non-null (passes that re-use neighbours only): no gate kernel in front -- the first wavefront of
+    unsigned long long expect;      //           every workgroup waits for the host's word itself (gate_poll, lio_device.h)
     const float4*  nbr;             // Nearest_Points
     const uint8_t* cnt;
     uint8_t*       sel;             // point_selected_surf (in: previous pass, out: this pass)

@@ -185,12 +185,27 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         // this workgroup, by its first wavefront: the fp64 transform is issued once per workgroup instead of once per
         // G-lane group (a separate 3 us launch before; every lane repeating it cost 2.6 us of this kernel's VALU time)
         __shared__ float s_q[WPB * GPW][3];
-        if (wave == 0 && lane < WPB * GPW) {
+        __shared__ uint32_t s_called_off;
+        if (wave == 0) {
             // everyone else in the workgroup waits for this wavefront: ahead of the other workgroups' wavefronts on its SIMD
             // (A/B on one box, scripts/dbg/knn_ab.py: -0.3 ... -1.0 us per launch)
             if (!(a.tune & 1)) __builtin_amdgcn_s_setprio(3);
+            Pose14 pose_w = a.pose;
+            bool go = true;
+            if (a.mail != nullptr) {
+                // a pass enqueued ahead of its pose, no gate kernel in front: the host's word is read here
+                const unsigned long long w = gate_poll(a.mail, a.expect, go);
+                pose_w = gate_pose(w);
+                if (blockIdx.x == 0) {                     // ... and left for the measurement kernel behind this launch
+                    if (lane >= 2 && lane < 16) a.gate_out->pose.v[lane - 2] = go ? __longlong_as_double((long long)w) : 0.0;
+                    if (lane == 0) a.gate_out->skip = go ? 0u : 1u;
+                }
+                if (lane == 0) s_called_off = go ? 0u : 1u;
+            } else if (a.gate != nullptr) {
+                pose_w = a.gate->pose;
+            }
             const int qi = blockIdx.x * (WPB * GPW) + lane;
-            if (qi < a.nq) {
+            if (go && lane < WPB * GPW && qi < a.nq) {
                 float4 b;
                 if (a.body_raw != nullptr) {
                     // (host memory through its device alias: one PCIe read per record, thousands of workgroups' worth in flight)
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
                 } else {
                     b = a.body[qi];
                 }
-                const PoseQ s = pose_unpack(a.gate != nullptr ? a.gate->pose : a.pose);
+                const PoseQ s = pose_unpack(pose_w);
                 float wx, wy, wz;
                 body_to_world(s, b.x, b.y, b.z, wx, wy, wz);
                 a.world_out[qi] = make_float4(wx, wy, wz, b.w);
@@ -215,6 +230,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             if (!(a.tune & 1)) __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
+        if (a.mail != nullptr && s_called_off != 0u) return;   // the host called the pass off (or never answered): nothing is published
         if (active) { qx = s_q[wave * GPW + g][0]; qy = s_q[wave * GPW + g][1]; qz = s_q[wave * GPW + g][2]; }
     } else if (active) {
         const float4 w = a.world_in[q];            // world-frame query (the caller's)

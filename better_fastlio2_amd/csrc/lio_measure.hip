@@ -74,6 +74,29 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     __shared__ uint32_t s_failed;                  // a bounded wait ran out (reported, never silent)
     if (a.gate != nullptr && a.gate->skip != 0u) return;      // a pre-enqueued pass the host called off (nothing is published)
     const int tid = threadIdx.x;
+    // A pass that re-uses neighbours, enqueued ahead of its pose with no gate kernel in front: the first wavefront of every
+    // workgroup waits for the host's word (gate_poll, lio_device.h) and hands it to the others through LDS.
+    Pose14 pose_in{};                             // (search passes read their pose where they use it: no 28 live scalar registers)
+    if (!SEARCH) pose_in = a.pose;
+    if (!SEARCH && a.mail != nullptr) {
+        __shared__ unsigned long long s_mail[17];
+        if (tid < 64) {
+            bool go;
+            unsigned long long w = gate_poll(a.mail, a.expect, go);
+            if (tid == 1 && !go) w = GATE_SKIP;               // (a timed-out wait reads as an order to stand down)
+            if (tid < 17) s_mail[tid] = w;
+        }
+        __syncthreads();
+        const unsigned long long w = s_mail[(tid & 63) < 17 ? (tid & 63) : 0];
+        if (mail_word(w, 1) != GATE_GO) return;
+        pose_in = gate_pose(w);
+    } else if (!SEARCH && a.gate != nullptr) {
+        pose_in = a.gate->pose;
+    }
+    auto pose_now = [&]() -> Pose14 {
+        if (SEARCH) return a.gate != nullptr ? a.gate->pose : a.pose;
+        return pose_in;
+    };
     // bounded waits: seconds, not microseconds -- a pathological search (every query inside a slab of deleted points:
     // ~1 ms per walk) must still finish; the bound only turns a hang into a reported error
     constexpr unsigned SPIN_LIMIT = 1u << 22;
@@ -145,7 +168,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
         for (int k = 0; k < K; ++k) { px[k] = __shfl(own.x, k, 64); py[k] = __shfl(own.y, k, 64); pz[k] = __shfl(own.z, k, 64); }
         const float d4 = __shfl(own.w, 4, 64);
         // every lane evaluates the same query (uniform; lane 0 stores)
-        const PoseQ sw = pose_unpack(a.gate != nullptr ? a.gate->pose : a.pose);
+        const PoseQ sw = pose_unpack(pose_now());
         const float4 fb = a.body[qi];
         bool fsel = false;
         float fnx = 0.f, fny = 0.f, fnz = 0.f, fpd = 0.f, fpd2 = 0.f;
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
     // is the one stored here (16 bytes instead of 80, no QR).
     const bool in = i < a.nq;
     bool walked_elsewhere = false;                 // a listed query in fix mode: its walker evaluates it and writes its outputs
-    const PoseQ s = pose_unpack(a.gate != nullptr ? a.gate->pose : a.pose);
+    const PoseQ s = pose_unpack(pose_now());
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     float wx = 0.f, wy = 0.f, wz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f, plane_d = 0.f;
     if (SEARCH) {

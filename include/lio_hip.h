@@ -311,7 +311,9 @@ results); "library_sort" sends every sort / compaction of map maintenance and sc
  * in rank order, overflow repeat, Delete_Point_Boxes + the Add_Points pair); "pre_enqueue" = 0 stops
  * lio_eskf_update_iterated_dyn_share_modified from putting the next pass on the stream ahead of its pose (identical results),
  * "gate_mispredict" = 1 makes it predict the wrong kind of pass every time (every pre-enqueued pass is called off; identical
- * results); "knn_walk" = 0 / 1 / 2 / 4 forces the candidate walk of the k-NN kernel (plain list / prefix-form list with that
+ * results), "gate_in_kernel" (bit 0: passes that re-use neighbours, bit 1: search passes; default 3) chooses where such a pass
+ * waits for its pose: inside its own first kernel (mail slots in device memory, i.e. a large-BAR GPU) or, 0, behind a
+ * one-wavefront gate kernel (always the form when the slots are host memory; identical results); "knn_walk" = 0 / 1 / 2 / 4 forces the candidate walk of the k-NN kernel (plain list / prefix-form list with that
  * many candidates per lane in flight; -1 = by scan size again) and "lanes_per_query" = 4 ... 64 its lanes per query (0 = by
  * scan size) -- identical results, A/B switches; "voxel_fast_path" = 0 keeps lio_scan_voxel_filter on the general sort even
  * for sweeps in time order (identical results); "retired_budget" overrides the number of retired slots that triggers a full
@@ -321,7 +323,7 @@ int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
  * "voxel_redone" = voxel-filter attempts on the compact-key path / sweeps filtered twice after a wrong prediction;
  * "retired_budget" = the retired-slot budget in force; "plans_on_side_stream" / "deferred_settled" = batches of the deferred exchange schedule whose plan ran beside a scan
  * step / that entered the map; "gate_reenqueued" = passes put on the stream again because their gate had
- * given up (a host stalled for seconds); "scan_pulled" = scans a kernel pulled out of page-locked host records
+ * given up (a host stalled for seconds); "gate_in_kernel" = passes armed without a gate kernel; "scan_pulled" = scans a kernel pulled out of page-locked host records
  * (lio_scan_set_async); "rows_direct_dma" = lio_measure_rows calls served by copies straight into page-locked h_x / h            */
 int  lio_debug_get(lio_ctx* ctx, const char* key, long long* value);
 /* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: [0] its start, [1] own partial

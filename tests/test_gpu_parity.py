@@ -293,13 +293,21 @@ def test_passes_enqueued_ahead_of_their_pose(gpu_capi, synth, small_case):
         ps, rt = synth.perturb_state(s2, seed=synth.SEED + 400 + k)
         scans.append(s2); priors.append(gpu_capi.make_state26(ps, rt, s2.off_R, s2.off_T))
     out = {}
-    for mode in ("plain", "ahead", "wrong"):
+    # (the wait for the host's word: inside the first kernel of the armed pass where the mail slots are device memory -- the default
+    # on a large-BAR box -- or in a gate kernel in front of it; "gate_in_kernel" 0 forces the latter, 1 / 2 = re-use / search passes only)
+    for mode in ("plain", "ahead", "wrong", "ahead_gate_kernel", "wrong_gate_kernel", "ahead_in_kernel_reuse_only", "ahead_in_kernel_search_only"):
         ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
         ctx.map_build(w.points)
         if mode == "plain":
             ctx.debug_set("pre_enqueue", 0)
-        if mode == "wrong":
+        if mode.startswith("wrong"):
             ctx.debug_set("gate_mispredict", 1)
+        if mode.endswith("gate_kernel"):
+            ctx.debug_set("gate_in_kernel", 0)
+        if mode.endswith("reuse_only"):
+            ctx.debug_set("gate_in_kernel", 1)
+        if mode.endswith("search_only"):
+            ctx.debug_set("gate_in_kernel", 2)
         res = []
         for k, iters in enumerate((3, 3, 1, 3)):               # the third update is shorter than the one before it
             kf = gpu_capi.Esekf(iters)
@@ -308,17 +316,23 @@ def test_passes_enqueued_ahead_of_their_pose(gpu_capi, synth, small_case):
             res.append((kf.get_x(), kf.get_P(), (log["n_calls"], log["n_search"], log["last_m"], log["converged"])))
             mi = ctx.map_incremental(kf.get_x()[:14], 0.2, True)          # the stream is free: nothing waits behind a gate
             res.append((np.array([mi["n_add"], mi["n_nodown"]]), np.array([ctx.map_validnum()]), ()))
-        out[mode] = (res, ctx.debug_get("gate_released"), ctx.debug_get("gate_called_off"))
+        out[mode] = (res, ctx.debug_get("gate_released"), ctx.debug_get("gate_called_off"), ctx.debug_get("gate_in_kernel"), ctx.debug_get("gate_mail_in_vram"))
         ctx.close()
-    for mode in ("ahead", "wrong"):
+    for mode in out:
         for a, b in zip(out["plain"][0], out[mode][0]):
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], mode
+        if mode.startswith("ahead"):
+            assert out[mode][1] == out["ahead"][1] and out[mode][2] == out["ahead"][2], mode
+    assert out["ahead_gate_kernel"][3] == 0 and out["wrong_gate_kernel"][3] == 0
+    if out["ahead"][4]:
+        assert out["ahead"][3] >= out["ahead"][1] and 0 < out["ahead_in_kernel_reuse_only"][3] < out["ahead"][3] and 0 < out["ahead_in_kernel_search_only"][3] < out["ahead"][3]
     assert out["plain"][1] == 0 and out["plain"][2] == 0
     assert out["ahead"][1] >= 3 and out["ahead"][2] >= 1          # passes that ran on a pre-enqueued launch; the one left armed by the short update
     assert out["wrong"][2] >= 3                                       # (a flipped prediction is right where this update differs from the last)
 
 
-def test_a_pass_whose_gate_gave_up_is_put_on_the_stream_again(gpu_capi, small_case):
+@pytest.mark.parametrize("in_kernel", [3, 0])
+def test_a_pass_whose_gate_gave_up_is_put_on_the_stream_again(gpu_capi, small_case, in_kernel):
     """A pass armed ahead of its pose sits behind a gate kernel that gives up after two seconds (a queue must never hang on a host
     that does not come back).  A host that DOES come back late -- a debugger, SIGSTOP, a VM pause -- finds its pass stood down:
     lio_measure_end then sees an idle stream without a record and enqueues the pass directly, once ("gate_reenqueued"), instead
@@ -332,6 +346,7 @@ def test_a_pass_whose_gate_gave_up_is_put_on_the_stream_again(gpu_capi, small_ca
     ctx.scan_set(sc.body)
     ref = [ctx.measure(st, True, False), ctx.measure(st2, False, False)]
     ctx.debug_set("pre_enqueue", 1)
+    ctx.debug_set("gate_in_kernel", in_kernel)            # (3: the armed pass waits inside its own first kernel; 0: behind a gate kernel)
     ctx.scan_set(sc.body)                                 # the pattern of the scan above (search, re-use) predicts this one's
     a = ctx.measure(st, True, False)                      # ... arms the re-use pass behind a gate
     assert ctx.debug_get("gate_reenqueued") == 0
