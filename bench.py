@@ -121,12 +121,17 @@ def latency_summary(lat_s):
     return out
 
 
-def timed_steps(step_fn, steps: int, warmup: int, dist, device, lat=None):
+def timed_steps(step_fn, steps: int, warmup: int, dist, device, lat=None, quiesce=None):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks.  lat (a list) receives
-    the wall time of every timed step (a step returns when its result is on the host: two clock reads per step)."""
+    the wall time of every timed step (a step returns when its result is on the host: two clock reads per step).
+    quiesce: called behind the last step of each loop, INSIDE the timed region -- the pipelined scan step leaves the first
+    search of the next scan on the stream waiting for its pose (lio_hip.h); lio_synchronize calls it off, so that the
+    device-wide synchronisation below waits for the K steps and not for a pass nobody will release."""
     import torch
     for _ in range(warmup):
         step_fn()
+    if quiesce is not None:
+        quiesce()
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
@@ -142,6 +147,8 @@ def timed_steps(step_fn, steps: int, warmup: int, dist, device, lat=None):
             tn = time.perf_counter()
             lat.append(tn - tp)
             tp = tn
+    if quiesce is not None:
+        quiesce()
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
@@ -640,13 +647,16 @@ def main():
     if rc != 0:
         fail("first upload", rc)
     lat_value = []
-    elapsed = timed_steps(step_pipelined, a.steps, a.warmup, dist, device, lat_value)
+    elapsed = timed_steps(step_pipelined, a.steps, a.warmup, dist, device, lat_value, quiesce=lambda: L.lio_synchronize(ctx.h))
+    if os.environ.get("LIO_TRACE_HOST") == "1":
+        ctx.debug_set("dump_host_trace", 90)                   # (the host side of the last timed steps, to stderr)
     ctx.profile_reset()
     n_sampled_steps = max(3 * n_rot, min(a.steps, 96))
     run_sampled = sampled(step_pipelined)
     for _ in range(n_sampled_steps):
         run_sampled()
     L.lio_scan_swap(ctx.h)                                     # consume the upload left in flight by the last step
+    L.lio_synchronize(ctx.h)                                   # (... and call off the first search the last step armed for it)
     prof = ctx.profile()
     ctx.profile_enable(False)
     knn_ms = prof["knn27"]["total_ms"] / max(prof["knn27"]["launches"], 1)

@@ -707,6 +707,21 @@ def scan_step_device(kf: "Esekf", ctx: "LioContext", x26, P, d_body_ptr: int, n:
     return {k: getattr(log, k) for k, _ in lio_update_log._fields_}
 
 
+def scan_step_pipelined(kf: "Esekf", ctx: "LioContext", x26, P, next_pinned_f4, R: float = 0.001, extrinsic_est_en: bool = False) -> dict:
+    """lio_eskf_scan_step_pipelined: the scan uploaded during the previous call becomes current, the copy of `next_pinned_f4`
+    ([n, 4] float32 from pinned_points, or None) travels during this one.  The caller keeps `next_pinned_f4` alive until the
+    call after the next has returned."""
+    x = None if x26 is None else np.ascontiguousarray(x26, np.float64)
+    p = None if P is None else np.ascontiguousarray(P, np.float64)
+    log = lio_update_log()
+    rc = kf.L.lio_eskf_scan_step_pipelined(kf.h, ctx.h, None if x is None else _ptr(x), None if p is None else _ptr(p),
+                                           None if next_pinned_f4 is None else _ptr(next_pinned_f4),
+                                           0 if next_pinned_f4 is None else len(next_pinned_f4), R, int(extrinsic_est_en), C.byref(log))
+    if rc != LIO_OK:
+        raise LioError(f"lio_eskf_scan_step_pipelined: {ERRORS.get(rc, rc)}: {ctx.L.lio_last_error(ctx.h).decode()}")
+    return {k: getattr(log, k) for k, _ in lio_update_log._fields_}
+
+
 def make_state26(pos, rot, off_R, off_T, vel=(0, 0, 0), bg=(0, 0, 0), ba=(0, 0, 0), grav=(0, 0, -9.809)) -> np.ndarray:
     """x26 = pos3, rot xyzw, offR xyzw, offT3, vel3, bg3, ba3, grav3 (use-ikfom.hpp:21-30)."""
     return np.concatenate([pos, rot, off_R, off_T, vel, bg, ba, grav]).astype(np.float64)

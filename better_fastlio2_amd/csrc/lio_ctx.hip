@@ -79,7 +79,8 @@ struct lio_ctx {
     struct HostStamp { char tag; long long ns; unsigned polls; };
     std::vector<HostStamp> host_trace;
     void stamp(char tag, unsigned polls = 0) {
-        if (!trace_host || host_trace.size() >= 4096) return;
+        if (!trace_host) return;
+        if (host_trace.size() >= 4096) host_trace.erase(host_trace.begin(), host_trace.begin() + 2048);   // (keeps the most recent stamps)
         host_trace.push_back({tag, (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(), polls});
     }
     bool trace_rebuilds = false;               // LIO_TRACE_REBUILDS=1 in the environment: one stderr line per budget-triggered rebuild
@@ -143,7 +144,12 @@ struct lio_ctx {
     GateMail* d_gate_mail = nullptr;           // their device address
     bool gate_mail_in_vram = false;            // the slots are fine-grained device memory the CPU writes through the BAR (lio_create)
     GateState* d_gate = nullptr;               // [GATE_SLOTS] device: what a gate leaves for the kernels behind it
-    struct ArmedPass { bool search, ext; unsigned long long mail_seq, pass_seq; };
+    struct ArmedPass {
+        bool search, ext; unsigned long long mail_seq, pass_seq;
+        bool across = false;                   // armed across a scan boundary (stays set; next_scan is cleared by lio_scan_swap)
+        bool next_scan = false;                // the FIRST pass of the scan in the back buffer (gate_arm_next_scan): survives the end of
+        const float4* body = nullptr; int nq = 0;   // the update and lio_scan_swap (which checks that it swaps in this buffer, this many points)
+    };
     ArmedPass gate_q[GATE_AHEAD];              // gates + passes that sit on the stream waiting for the host, in stream order
     int gate_n = 0;
     unsigned long long gate_mail_seq = 0;      // sequence number of the gate armed last (its slot: seq % GATE_SLOTS)
@@ -154,10 +160,14 @@ struct lio_ctx {
     bool pass_searched = false;                // the pass in flight is a search pass
     bool pass_gated = false;                   // ... and was released through a gate (re-enqueued directly once if its gate gave up)
     long long n_gate_reenqueued = 0;
-    int gate_in_kernel = 3;                    // bit 0: passes that re-use neighbours, bit 1: search passes -- wait for the host's word inside
+    int gate_in_kernel = 3;                    // bit 0: passes that re-use neighbours, bit 1: search passes (bit 2: also the one armed across a scan boundary) -- wait for the host's word inside
                                                // their first kernel instead of behind a gate kernel (mail slots in device memory only;
                                                // LIO_GATE_IN_KERNEL / lio_debug_set("gate_in_kernel"))
     long long n_gate_in_kernel = 0;
+    bool arm_across_scans = false;             // lio_eskf_scan_step_pipelined: the first search of the NEXT scan (already uploaded) goes onto the
+    int dbg_arm_next_scan = 1;                 // stream behind the last pass of this one; lio_debug_set("arm_next_scan", 0) / LIO_ARM_NEXT_SCAN=0: never
+    long long n_next_scan_armed = 0, n_next_scan_released = 0;
+    bool across_off_this_scan = false;         // this scan's update already ran past an end the previous one predicted: no second guess
     long long n_rows_direct_dma = 0;           // lio_measure_rows calls whose rows the copy engine wrote straight into the caller's page-locked buffers
     // a scan handed over as page-locked host records (lio_scan_set_async) whose pull has not been issued yet: the first search
     // pass of the scan pulls it inside knn27_kernel; anything else that needs d_body first launches the stand-alone pull
@@ -1009,6 +1019,7 @@ extern "C" {
 // Passes armed ahead of their pose (gate_arm) sit on the stream behind a gate kernel that waits for the host: whoever else wants
 // the stream -- every entry point that enqueues on it or waits for it -- calls them off first.
 static void gate_call_off(lio_ctx* c);
+static int gate_arm_next_scan(lio_ctx* c, bool ext);
 // ... and a scan whose pull out of the caller's host records is still owed (lio_scan_set_async) is pulled before anything but
 // its first search pass looks at the scan buffer.
 static void flush_pull(lio_ctx* c) {
@@ -1070,7 +1081,8 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     { const char* e = std::getenv("LIO_TRACE_HOST"); c->trace_host = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_PRE_ENQUEUE"); if (e != nullptr && e[0] == '0') c->dbg_pre_enqueue = 0; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_KNN_TUNE"); if (e != nullptr && e[0] >= '0' && e[0] <= '9') c->dbg_knn_tune = std::atoi(e); }   // (A/B runs of scripts)
-    { const char* e = std::getenv("LIO_GATE_IN_KERNEL"); if (e != nullptr && e[0] >= '0' && e[0] <= '3' && e[1] == 0) c->gate_in_kernel = e[0] - '0'; }   // (A/B runs of scripts)
+    { const char* e = std::getenv("LIO_ARM_NEXT_SCAN"); if (e != nullptr && e[0] == '0') c->dbg_arm_next_scan = 0; }   // (A/B runs of scripts)
+    { const char* e = std::getenv("LIO_GATE_IN_KERNEL"); if (e != nullptr && e[0] >= '0' && e[0] <= '7' && e[1] == 0) c->gate_in_kernel = e[0] - '0'; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_KNN_WALK"); if (e != nullptr && (e[0] == '0' || e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0) c->dbg_knn_walk = e[0] - '0'; }
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, c->device));
@@ -1184,17 +1196,21 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     return LIO_OK;
 }
 
+// LIO_TRACE_HOST=1: the last `last` stamps of the host side (tag, microseconds since the previous one) to stderr; the trace starts over
+static void dump_host_trace(lio_ctx* c, size_t last) {
+    const size_t n = c->host_trace.size(), from = n > last ? n - last : 0;
+    for (size_t i = from; i < n && n > 1; ++i)
+        std::fprintf(stderr, "lio host trace %c %+9.2f us%s\n", c->host_trace[i].tag,
+                     i > from ? (double)(c->host_trace[i].ns - c->host_trace[i - 1].ns) * 1e-3 : 0.0,
+                     c->host_trace[i].tag == 'S' ? (c->host_trace[i].polls == 0 ? "  (no poll: the record was there)" : "  (polled)") : "");
+    c->host_trace.clear();
+}
 void lio_destroy(lio_ctx* c) {
-    if (c && c->trace_host && c->host_trace.size() > 1) {
-        const size_t n = c->host_trace.size(), from = n > 80 ? n - 80 : 0;
-        for (size_t i = from; i < n; ++i)
-            std::fprintf(stderr, "lio host trace %c %+9.2f us%s\n", c->host_trace[i].tag,
-                         i > from ? (double)(c->host_trace[i].ns - c->host_trace[i - 1].ns) * 1e-3 : 0.0,
-                         c->host_trace[i].tag == 'S' ? (c->host_trace[i].polls == 0 ? "  (no poll: the record was there)" : "  (polled)") : "");
-    }
+    if (c && c->trace_host) dump_host_trace(c, 80);
     if (!c) return;
     (void)hipSetDevice(c->device);
     lio_replicate_finalize(c);
+    if (c->gate_n > 0) gate_call_off(c);                       // (a pass armed across a scan boundary may still wait for its pose)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_gs_part, c->d_gs_part2, c->d_porder, c->d_porder2, c->d_pnewoff, c->d_plan, c->d_ghist, c->d_gagg, c->d_apply, c->d_temp, c->d_counters, c->d_cagg, c->d_cand, c->d_boxes,
@@ -2193,6 +2209,7 @@ static int scan_reset(lio_ctx* c, int n) {
     if (!c->pattern_cur.empty()) { c->pattern_prev.swap(c->pattern_cur); c->pattern_cur.clear(); }
     c->nq = n;
     c->have_scan = true; c->have_search = false; c->have_pass = false; c->last_m = 0; c->hint_valid = false;
+    c->across_off_this_scan = false;
     // point_selected_surf starts all-true (laserMapping.cpp:2131), but nothing reads it before the first pass of
     // the scan has written it: that pass must search (lio_measure enforces it) and a search pass decides from the
     // neighbours alone (:1911) -- so there is no fill launch here
@@ -2276,6 +2293,7 @@ static int issue_pending_upload(lio_ctx* c) {
 int lio_scan_upload_async(lio_ctx* c, const void* host_f4, int n) {
     if (!c || n < 0 || (n > 0 && !host_f4)) return LIO_ERR_INVALID_ARG;
     if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_upload_async", "n exceeds max_scan_points");
+    for (int i = 0; i < c->gate_n; ++i) if (c->gate_q[i].next_scan) { gate_call_off(c); break; }   // (armed on the buffer this upload replaces)
     // The copy is issued by the next measurement pass right behind its kernel launches (the runtime calls then run
     // beside the GPU's work), or by lio_scan_swap if no pass comes first.
     c->upload_pending = true; c->upload_src = host_f4; c->upload_n = n;
@@ -2283,7 +2301,10 @@ int lio_scan_upload_async(lio_ctx* c, const void* host_f4, int n) {
 }
 int lio_scan_swap(lio_ctx* c) {
     if (!c) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    // the first pass of the scan that is swapped in may already sit on the stream (gate_arm_next_scan): it stays
+    const bool armed_for_it = c->gate_n == 1 && c->gate_q[0].next_scan && !c->upload_pending && !c->pull_pending &&
+                              c->gate_q[0].body == c->d_body_back && c->gate_q[0].nq == c->nq_back;
+    if (!armed_for_it) enter(c);
     HIPCHK(c, hipSetDevice(c->device));
     if (c->upload_pending) {
         const int rc = issue_pending_upload(c);
@@ -2292,12 +2313,15 @@ int lio_scan_swap(lio_ctx* c) {
     if (c->nq_back < 0) return c->fail(LIO_ERR_NO_SCAN, "lio_scan_swap", "no scan was uploaded with lio_scan_upload_async");
     // usually the copy finished long ago (it ran beside the previous scan step): then the host has seen it complete
     // and everything launched from here on is ordered behind it; otherwise the compute stream waits for the event
-    const hipError_t q = hipEventQuery(c->ev_copy);
-    if (q == hipErrorNotReady) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
-    else if (q != hipSuccess) return c->fail(LIO_ERR_HIP, "lio_scan_swap", hipGetErrorString(q));
+    if (!armed_for_it) {                                       // (an armed pass already sits behind the copy)
+        const hipError_t q = hipEventQuery(c->ev_copy);
+        if (q == hipErrorNotReady) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+        else if (q != hipSuccess) return c->fail(LIO_ERR_HIP, "lio_scan_swap", hipGetErrorString(q));
+    }
     float4* t = c->d_body; c->d_body = c->d_body_back; c->d_body_back = t;
     const int n = c->nq_back;
     c->nq_back = -1;
+    if (armed_for_it) c->gate_q[0].next_scan = false;         // from here on: the first pass of the CURRENT scan
     return scan_reset(c, n);
 }
 void* lio_host_alloc(size_t bytes) {
@@ -2661,6 +2685,16 @@ static void gate_call_off(lio_ctx* c) {
     }
     c->gate_n = 0;
 }
+// the update of the current scan is over: what was armed for IT stands down; the first pass of the next scan stays
+static void gate_call_off_this_scan(lio_ctx* c) {
+    int kept = 0;
+    for (int i = 0; i < c->gate_n; ++i) {
+        if (c->gate_q[i].next_scan) { c->gate_q[kept++] = c->gate_q[i]; continue; }
+        gate_write(c, c->gate_q[i].mail_seq, GATE_SKIP, nullptr);
+        ++c->n_gate_called_off;
+    }
+    c->gate_n = kept;
+}
 // enqueue [gate][pass of the given kind] behind whatever is on the stream; LIO_OK also when the context declines (nothing armed)
 static int gate_arm(lio_ctx* c, bool do_search, bool ext) {
     if (c->gate_n >= lio_ctx::GATE_AHEAD || !c->dbg_pre_enqueue || c->want_rows || c->nq == 0 || !c->have_search) return LIO_OK;
@@ -2681,11 +2715,53 @@ static int gate_arm(lio_ctx* c, bool do_search, bool ext) {
         ++c->n_gate_in_kernel;
     }
     lio_ctx::ArmedPass& ap = c->gate_q[c->gate_n++];
+    ap = lio_ctx::ArmedPass{};
     ap.search = do_search; ap.ext = ext; ap.mail_seq = mail_seq; ap.pass_seq = 0;
     Pose14 none{};
     const int rc = enqueue_pass(c, none, do_search, ext, false, st, &ap.pass_seq, in_kernel ? slot : nullptr, mail_seq);
     if (rc != LIO_OK) { gate_call_off(c); return rc; }
     c->stamp('G');
+    return LIO_OK;
+}
+
+static int gate_arm_next_scan(lio_ctx* c, bool ext) {
+    for (int i = 0; i < c->gate_n; ++i) if (c->gate_q[i].next_scan) return LIO_OK;          // (once)
+    if (c->gate_n >= lio_ctx::GATE_AHEAD || !c->dbg_pre_enqueue || c->want_rows || c->upload_pending || c->nq_back <= 0 || c->pull_pending) return LIO_OK;
+    if (c->dbg_separate_walk != 0 || c->listed_last_search > INLINE_WALK_MAX_LISTED || c->nq_back > FUSED_TRANSFORM_MAX_QUERIES) return LIO_OK;
+    if (c->prof != 0u) return LIO_OK;          // (kernel timing on: an event pair around a pass that may be called off would count as a launch)
+    // the copy of that scan: usually long finished (it ran beside this scan's first pass); otherwise the stream waits for it here
+    const hipError_t q = hipEventQuery(c->ev_copy);
+    if (q == hipErrorNotReady) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+    else if (q != hipSuccess) return c->fail(LIO_ERR_HIP, "gate_arm_next_scan", hipGetErrorString(q));
+    c->stamp(q == hipErrorNotReady ? '!' : '1');
+    const unsigned long long mail_seq = ++c->gate_mail_seq;
+    GateState* st = c->d_gate + (mail_seq % lio_ctx::GATE_SLOTS);
+    const GateMail* slot = c->d_gate_mail + (mail_seq % lio_ctx::GATE_SLOTS);
+    // This wait is as long as the host takes from one scan to the next (~10 us in a replay loop, the scan period in a live node):
+    // by default it is a gate kernel's -- one wavefront -- so that the search kernel's own duration stays its work (what rocprofv3
+    // and the event stamps report for it) and the GPU is not full of polling workgroups in between; bit 2 of "gate_in_kernel"
+    // moves it into the search kernel like the waits inside a scan (one dependent dispatch less, A/B switch).
+    const bool in_kernel = c->gate_mail_in_vram && (c->gate_in_kernel & 4) != 0;
+    if (!in_kernel) {
+        const hipError_t ge = launch_gate(slot, mail_seq, st, c->stream);
+        if (ge != hipSuccess) return c->fail(LIO_ERR_HIP, "launch_gate", hipGetErrorString(ge));
+    } else {
+        ++c->n_gate_in_kernel;
+    }
+    c->stamp('2');
+    lio_ctx::ArmedPass& ap = c->gate_q[c->gate_n++];
+    ap = lio_ctx::ArmedPass{};
+    ap.search = true; ap.ext = ext; ap.mail_seq = mail_seq; ap.pass_seq = 0;
+    ap.next_scan = true; ap.across = true; ap.body = c->d_body_back; ap.nq = c->nq_back;
+    // the pass is enqueued as the first pass of THAT scan: its points, its count, no neighbours of an earlier search to bound it
+    float4* const body_now = c->d_body; const int nq_now = c->nq; const bool hint_now = c->hint_valid;
+    c->d_body = c->d_body_back; c->nq = c->nq_back; c->hint_valid = false;
+    Pose14 none{};
+    const int rc = enqueue_pass(c, none, true, ext, false, st, &ap.pass_seq, in_kernel ? slot : nullptr, mail_seq);
+    c->d_body = body_now; c->nq = nq_now; c->hint_valid = hint_now;
+    if (rc != LIO_OK) { gate_call_off(c); return rc; }
+    ++c->n_next_scan_armed;
+    c->stamp('N');
     return LIO_OK;
 }
 
@@ -2701,8 +2777,16 @@ static int arm_predicted(lio_ctx* c, bool searching, bool ext) {
         const int before = c->gate_n;
         const int rc = gate_arm(c, kind, ext);
         if (rc != LIO_OK) return rc;
-        if (c->gate_n == before) break;                         // the context declined
+        if (c->gate_n == before) return LIO_OK;                 // the context declined
     }
+    // Everything the previous update predicts for THIS scan is running or armed: the scan that waits in the back buffer comes next,
+    // and its first pass always searches -- onto the stream behind them (lio_eskf_scan_step_pipelined only: between two of its calls
+    // nothing else uses the stream).  The launch calls and the dispatch of that search then lie beside this scan's last passes
+    // instead of between the scans (scripts/step_timeline.py: 12-16 us of an idle GPU per scan boundary before).  lio_scan_swap
+    // keeps the pass armed; the first lio_measure_begin of the scan hands it its pose; anything else calls it off.
+    if (c->arm_across_scans && c->dbg_arm_next_scan && !c->across_off_this_scan && c->gate_n < arm_up_to &&
+        c->pattern_cur.size() + (size_t)c->gate_n >= c->pattern_prev.size() && !c->pattern_prev.empty())
+        return gate_arm_next_scan(c, ext);
     return LIO_OK;
 }
 
@@ -2721,18 +2805,21 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     bool released = false;
     if (c->gate_n > 0) {
         const lio_ctx::ArmedPass ap = c->gate_q[0];
-        if (ap.search == (do_search != 0) && ap.ext == ext && !c->want_rows && nq != 0) {
+        if (ap.search == (do_search != 0) && ap.ext == ext && !c->want_rows && nq != 0 && !ap.next_scan) {
             // the pass is already on the stream: hand it its pose
             gate_write(c, ap.mail_seq, GATE_GO, &pose);
             for (int i = 1; i < c->gate_n; ++i) c->gate_q[i - 1] = c->gate_q[i];
             --c->gate_n;
             ++c->n_gate_released;
+            if (ap.across) ++c->n_next_scan_released;
             c->pass_seq = ap.pass_seq;
             released = true;
         } else {
+            if (ap.next_scan) c->across_off_this_scan = true;   // (the update runs longer than the previous one did)
             gate_call_off(c);
         }
     }
+    if (released) c->stamp('r');
     c->last_pose = pose; c->last_ext = ext;
     c->pass_in_flight = true; c->pass_empty = nq == 0; c->pass_gated = released;
     if (nq == 0) return LIO_OK;                               // "No Effective Points" laserMapping.cpp:1956
@@ -3015,7 +3102,9 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
     if (std::strcmp(key, "pre_enqueue") == 0) { c->dbg_pre_enqueue = value != 0; return LIO_OK; }
     if (std::strcmp(key, "gate_mispredict") == 0) { c->dbg_gate_mispredict = value != 0; return LIO_OK; }
-    if (std::strcmp(key, "gate_in_kernel") == 0) { enter(c); c->gate_in_kernel = (int)(value & 3); return LIO_OK; }
+    if (std::strcmp(key, "gate_in_kernel") == 0) { enter(c); c->gate_in_kernel = (int)(value & 7); return LIO_OK; }
+    if (std::strcmp(key, "dump_host_trace") == 0) { if (c->trace_host) dump_host_trace(c, (size_t)(value > 0 ? value : 80)); return LIO_OK; }
+    if (std::strcmp(key, "arm_next_scan") == 0) { enter(c); c->dbg_arm_next_scan = value != 0; return LIO_OK; }
     if (std::strcmp(key, "sequence_numbers") == 0) {           // test hook: the next pass / compaction launch take these numbers + 1 (stamp wrap-around)
         c->seq = (unsigned long long)value; c->compact_seq = (uint32_t)value; c->gsort_seq = (uint32_t)value;
         return LIO_OK;
@@ -3040,6 +3129,8 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "deferred_settled") == 0) { *value = c->n_settled; return LIO_OK; }
     if (std::strcmp(key, "gate_reenqueued") == 0) { *value = c->n_gate_reenqueued; return LIO_OK; }
     if (std::strcmp(key, "gate_in_kernel") == 0) { *value = c->n_gate_in_kernel; return LIO_OK; }
+    if (std::strcmp(key, "next_scan_armed") == 0) { *value = c->n_next_scan_armed; return LIO_OK; }
+    if (std::strcmp(key, "next_scan_released") == 0) { *value = c->n_next_scan_released; return LIO_OK; }
     if (std::strcmp(key, "scan_pulled") == 0) { *value = c->n_scan_pulled; return LIO_OK; }
     if (std::strcmp(key, "rows_direct_dma") == 0) { *value = c->n_rows_direct_dma; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_get", "unknown key");
@@ -3135,7 +3226,7 @@ int lio_eskf_update_iterated_dyn_share_modified(lio_eskf* kf, lio_ctx* ctx, doub
         });
     double solve_time = 0.0;
     kf->kf.update_iterated_dyn_share_modified(R, solve_time);
-    gate_call_off(ctx);                          // the update ended earlier than the previous one: nothing stays armed
+    gate_call_off_this_scan(ctx);                // the update ended earlier than the previous one: nothing of THIS scan stays armed
     ctx->pattern_prev.swap(ctx->pattern_cur);
     ctx->pattern_cur.clear();
     if (log) {
@@ -3205,11 +3296,19 @@ int lio_eskf_scan_step_device(lio_eskf* kf, lio_ctx* ctx, const double x26[26], 
 int lio_eskf_scan_step_pipelined(lio_eskf* kf, lio_ctx* ctx, const double x26[26], const double P[23 * 23],
                                  const void* next_host_f4, int n_next, double R, int extrinsic_est_en, lio_update_log* log) {
     if (!kf || !ctx) return LIO_ERR_INVALID_ARG;
+    ctx->stamp('P');
     int rc = lio_scan_swap(ctx);                                   // the scan uploaded during the previous step
+    ctx->stamp('w');
     if (rc == LIO_OK && next_host_f4 != nullptr) rc = lio_scan_upload_async(ctx, next_host_f4, n_next);   // travels during this one
     if (rc == LIO_OK && x26 != nullptr) rc = lio_eskf_change_x(kf, x26);
     if (rc == LIO_OK && P != nullptr) rc = lio_eskf_change_P(kf, P);
+    // (the next call of this function is what follows on the stream: the first search of the scan just handed over may be put
+    // there behind this scan's last passes -- arm_predicted)
+    ctx->arm_across_scans = next_host_f4 != nullptr && n_next > 0;
     if (rc == LIO_OK) rc = lio_eskf_update_iterated_dyn_share_modified(kf, ctx, R, extrinsic_est_en, log);
+    ctx->arm_across_scans = false;
+    if (rc != LIO_OK) enter(ctx);
+    ctx->stamp('U');
     return rc;
 }
 int lio_state_boxplus(double x26[26], const double dx23[23]) {

@@ -313,7 +313,9 @@ results); "library_sort" sends every sort / compaction of map maintenance and sc
  * "gate_mispredict" = 1 makes it predict the wrong kind of pass every time (every pre-enqueued pass is called off; identical
  * results), "gate_in_kernel" (bit 0: passes that re-use neighbours, bit 1: search passes; default 3) chooses where such a pass
  * waits for its pose: inside its own first kernel (mail slots in device memory, i.e. a large-BAR GPU) or, 0, behind a
- * one-wavefront gate kernel (always the form when the slots are host memory; identical results); "knn_walk" = 0 / 1 / 2 / 4 forces the candidate walk of the k-NN kernel (plain list / prefix-form list with that
+ * one-wavefront gate kernel (always the form when the slots are host memory; identical results; bit 2: also the search
+ * lio_eskf_scan_step_pipelined arms across a scan boundary, which waits behind a gate kernel by default), "arm_next_scan" = 0
+ * keeps lio_eskf_scan_step_pipelined from arming it; "knn_walk" = 0 / 1 / 2 / 4 forces the candidate walk of the k-NN kernel (plain list / prefix-form list with that
  * many candidates per lane in flight; -1 = by scan size again) and "lanes_per_query" = 4 ... 64 its lanes per query (0 = by
  * scan size) -- identical results, A/B switches; "voxel_fast_path" = 0 keeps lio_scan_voxel_filter on the general sort even
  * for sweeps in time order (identical results); "retired_budget" overrides the number of retired slots that triggers a full
@@ -323,7 +325,8 @@ int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
  * "voxel_redone" = voxel-filter attempts on the compact-key path / sweeps filtered twice after a wrong prediction;
  * "retired_budget" = the retired-slot budget in force; "plans_on_side_stream" / "deferred_settled" = batches of the deferred exchange schedule whose plan ran beside a scan
  * step / that entered the map; "gate_reenqueued" = passes put on the stream again because their gate had
- * given up (a host stalled for seconds); "gate_in_kernel" = passes armed without a gate kernel; "scan_pulled" = scans a kernel pulled out of page-locked host records
+ * given up (a host stalled for seconds); "gate_in_kernel" = passes armed without a gate kernel; "next_scan_armed" / "next_scan_released" = first searches
+ * armed across a scan boundary / of those, the ones that ran; "scan_pulled" = scans a kernel pulled out of page-locked host records
  * (lio_scan_set_async); "rows_direct_dma" = lio_measure_rows calls served by copies straight into page-locked h_x / h            */
 int  lio_debug_get(lio_ctx* ctx, const char* key, long long* value);
 /* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: [0] its start, [1] own partial
@@ -387,7 +390,14 @@ int  lio_eskf_scan_step_device(lio_eskf* kf, lio_ctx* ctx, const double x26[26],
 /* The same for a node that receives scan k+1 while scan k is being processed: the scan handed over with
  * lio_scan_upload_async during the previous step becomes the current one (lio_scan_swap), the copy of the next scan
  * (next_host_f4, n_next float4 records in pinned host memory; NULL = none) is started behind this step's first
- * kernels, then the update runs.  Before the first step: lio_scan_upload_async(ctx, first_scan, n).            */
+ * kernels, then the update runs.  Before the first step: lio_scan_upload_async(ctx, first_scan, n).
+ * With a next scan handed over, the call also leaves that scan's FIRST SEARCH on the stream, behind this scan's last passes,
+ * waiting for its pose (a one-wavefront gate kernel in front of it): the next call of this function hands the pose over instead
+ * of launching -- the launch calls and the dispatch lie beside this scan's work, not between the scans.  Every other lio_* call
+ * on the context (lio_synchronize included) calls that search off first -- it is then launched when its scan's update begins,
+ * same results -- and an unanswered wait ends by itself after 2 s.  A caller that synchronises the DEVICE by other means
+ * (hipDeviceSynchronize, a collective on another stream that needs the whole GPU) calls lio_synchronize(ctx) first.
+ * lio_debug_set("arm_next_scan", 0) switches it off.                                                                    */
 int  lio_eskf_scan_step_pipelined(lio_eskf* kf, lio_ctx* ctx, const double x26[26], const double P[23 * 23],
                                   const void* next_host_f4, int n_next, double R, int extrinsic_est_en, lio_update_log* log);
 /* esekf::predict(dt, Q, i_in) (esekfom.hpp:280-383) with the process model f / df_dx / df_dw of

@@ -1327,3 +1327,60 @@ def test_contexts_release_their_memory(gpu_capi, small_case):
         cycle()
     after = free_bytes()
     assert before - after < (8 << 20), (before, after)      # nothing of the ~100 MB per context stays behind
+
+
+@pytest.mark.parametrize("variant", ["armed", "armed_wait_in_kernel", "not_armed", "map_update_between_scans"])
+def test_first_search_of_the_next_scan_is_armed_across_the_scan_boundary(gpu_capi, synth, small_case, variant):
+    """lio_eskf_scan_step_pipelined puts the first search of the NEXT scan (already uploaded) onto the stream behind the last
+    passes of the current one (gate_arm_next_scan, lio_ctx.hip): lio_scan_swap keeps it armed, the scan's first lio_measure_begin
+    hands it its pose.  Bit-identical to the plain sequence -- also when the previous update mispredicts where this one ends (the
+    third update is shorter, the fourth longer than the one before), when anything else uses the stream between two scans (the
+    armed search is called off and launched directly) and with the switch off."""
+    w, sc = small_case["world"], small_case["scan"]
+    P0 = synth.init_cov()
+    scans, priors = [], []
+    for k in range(6):
+        s2 = synth.make_scan(w, len(sc.body), seed=synth.SEED + 700 + k, pos=(0.5 * k, 0.2 * k, 0.0), rpy=(0.001, -0.002, 0.03 * k))
+        ps, rt = synth.perturb_state(s2, seed=synth.SEED + 800 + k)
+        scans.append(s2); priors.append(gpu_capi.make_state26(ps, rt, s2.off_R, s2.off_T))
+    iters = (3, 3, 1, 3, 3, 3)
+    between = variant == "map_update_between_scans"
+
+    def run(pipelined):
+        ctx = gpu_capi.LioContext(0.2, max_scan_points=len(sc.body), max_map_points=400_000)
+        ctx.map_build(w.points)
+        if variant == "not_armed":
+            ctx.debug_set("arm_next_scan", 0)
+        if variant == "armed_wait_in_kernel":
+            ctx.debug_set("gate_in_kernel", 7)
+        pinned = [gpu_capi.pinned_points(s.body) for s in scans]
+        res = []
+        if pipelined:
+            ctx.scan_upload_async(pinned[0])
+        for k in range(len(scans)):
+            kf = gpu_capi.Esekf(iters[k])
+            if pipelined:
+                log = gpu_capi.scan_step_pipelined(kf, ctx, priors[k], P0, pinned[k + 1] if k + 1 < len(scans) else None, 0.001, False)
+            else:
+                buf = gpu_capi.scan_to_device(scans[k].body)
+                log = gpu_capi.scan_step_device(kf, ctx, priors[k], P0, buf.ptr, len(scans[k].body), 0.001, False)
+            res.append((kf.get_x(), kf.get_P(), (log["n_calls"], log["n_search"], log["last_m"], log["converged"])))
+            if between:
+                mi = ctx.map_incremental(kf.get_x()[:14], 0.2, True)
+                res.append((np.array([mi["n_add"], mi["n_nodown"]]), np.array([ctx.map_validnum()]), ()))
+        counters = (ctx.debug_get("next_scan_armed"), ctx.debug_get("next_scan_released"), ctx.debug_get("gate_called_off"))
+        ctx.synchronize()                                   # (nothing left waiting: returns at once)
+        ctx.close()
+        return res, counters
+
+    plain, c0 = run(False)
+    piped, c1 = run(True)
+    assert c0[0] == 0 and c0[1] == 0
+    for a, b in zip(plain, piped):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    if variant == "not_armed":
+        assert c1[0] == 0 and c1[1] == 0
+    elif between:
+        assert c1[0] >= 3 and c1[1] == 0                    # armed, called off by map_incremental every time
+    else:
+        assert c1[0] >= 3 and 2 <= c1[1] <= c1[0], c1        # (a mispredicted boundary: armed too early, called off, launched directly)
