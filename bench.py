@@ -632,11 +632,17 @@ def main():
     SAMPLE = int(os.environ.get("LIO_BENCH_EVENT_EVERY", "3"))
 
     def sampled(step_fn):
+        # Two steps in a row with the timers on, then SAMPLE - 2 without: while they are on the library does not arm the next scan's
+        # first search across the scan boundary (an event pair around a pass that may stand down would count as a launch), so the
+        # SECOND step's first search is a direct, stamped launch; the first step contributes its bounded search.  Switching the
+        # timers calls nothing off (lio_profile_enable), so the loop below contains no launch that stands down.
+        state = [False]
+
         def f():
-            if SAMPLE > 0 and tick[0] % SAMPLE == 0:
-                ctx.profile_enable(only=[capi.PROF_KNN, capi.PROF_KNN_HINT])
-            elif SAMPLE <= 0 or tick[0] % SAMPLE == 1:
-                ctx.profile_enable(False)
+            on = SAMPLE > 0 and (SAMPLE < 3 or tick[0] % SAMPLE in (0, 1))
+            if on != state[0]:
+                ctx.profile_enable(only=[capi.PROF_KNN, capi.PROF_KNN_HINT]) if on else ctx.profile_enable(False)
+                state[0] = on
             step_fn()
         return f
 

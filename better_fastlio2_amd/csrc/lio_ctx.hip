@@ -3070,7 +3070,8 @@ int lio_get_scan_state(lio_ctx* c, float* world_xyz, uint8_t* selected, float* n
 // ---- profiling -----------------------------------------------------------------------------------
 int lio_profile_enable(lio_ctx* c, int on) {
     if (!c) return LIO_ERR_INVALID_ARG;
-    enter(c);
+    // (no enter(): what is armed stays armed, with or without its event pair -- gate_arm / gate_arm_next_scan look at the pools and
+    // at `prof` when THEY launch, and a direct launch never happens with anything armed)
     HIPCHK(c, hipSetDevice(c->device));
     // (the recorded pairs are resolved by lio_profile_get / lio_profile_reset -- that takes a drained stream -- or when a pool
     // runs full; switching the timers on and off costs nothing, so a caller can time every n-th step of a loop)

@@ -14,7 +14,7 @@ for name, out in (("bench_c2.json", f"{tag}_bench_c2.json"), ("bench_c3.json", f
                   # round 3 (scripts/end_of_round_r03.sh)
                   ("bench_c2_driver.json", f"{tag}_bench_c2_driver_cmdline.json"), ("emulated_timeline.txt", f"{tag}_emulated_world8_timeline.txt"),
                   ("node_loop_timeline.txt", f"{tag}_node_loop_timeline.txt"), ("rebuild_timeline.txt", f"{tag}_rebuild_timeline.txt"),
-                  ("kernel_stats.txt", f"{tag}_bench_c2_extras_kernel_totals.txt"), ("host_trace.log", f"{tag}_host_trace.log"),
+                  ("kernel_stats.txt", f"{tag}_bench_c2_extras_kernel_totals.txt"), ("host_trace.log", f"{tag}_host_trace.log"), ("step_timeline.txt", f"{tag}_step_timeline.txt"),
                   # round 4 (scripts/end_of_round_r04.sh, scripts/r04_timeline.sh)
                   ("emulated_timeline_deferred.txt", f"{tag}_emulated_world8_timeline_deferred.txt"),
                   ("emulated_timeline_immediate.txt", f"{tag}_emulated_world8_timeline_immediate.txt"),
@@ -27,7 +27,7 @@ ks = os.path.join(src, "prof", "kernel_stats.csv")
 if os.path.exists(ks):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "trim_kernel_stats.py"), ks,
                            os.path.join(dst, f"{tag}_bench_c2_kernel_stats.csv"),
-                           "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras (the CONTRACT LOOP only: the drive + its untimed event-stamped repeat; scripts/rocprof_bench.sh)"])
+                           "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras (the CONTRACT LOOP only: the drive + its untimed event-stamped repeat; three of the first-search launches are passes armed across a scan boundary that lio_synchronize called off -- they stand down in ~5 us; scripts/rocprof_bench.sh)"])
     print("copied", f"{tag}_bench_c2_kernel_stats.csv")
 
 for sub, name, out, cmd in (("prof", "kernel_stats_all.csv", f"{tag}_bench_c2_kernel_stats_all_extras.csv", "python bench.py --steps 100 --warmup 10 --no-cpu-baseline (EVERY extra: averages mix the drive, the node loop's denser map, the emulated world and the 2 400-step window)"),

@@ -29,5 +29,8 @@ timeout 200 python tests/fuzz/fuzz_loop.py 80 9000 > $O/fuzz_loop.log 2>&1; echo
 timeout 200 python tests/fuzz/fuzz_measure.py 150 12000 > $O/fuzz_measure.log 2>&1; echo "fuzz_measure rc=$?"
 timeout 200 python tests/fuzz/fuzz_scanprep.py 200 40000 > $O/fuzz_scanprep.log 2>&1; echo "fuzz_scanprep rc=$?"
 stamp fuzz
+bash scripts/r04_step_timeline.sh $tag > $O/step_timeline.out 2>&1; tail -3 $O/step_timeline.txt
+LIO_TRACE_HOST=1 timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extras 2>&1 >/dev/null | grep -a "host trace" | head -90 | tail -48 > $O/host_trace.log
+stamp "step time line + host trace"
 timeout 1300 python bench.py --config c5 --steps 40 --warmup 5 > $O/bench_c5.json 2> $O/bench_c5.err; tail -1 $O/bench_c5.json | cut -c1-200
 stamp "bench c5"
