@@ -3141,51 +3141,6 @@ int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {
     for (int i = 0; i < 8; ++i) out8[i] = c->h_out->dbg[i];
     return LIO_OK;
 }
-// Probe (not part of the ABI, scripts/dbg/overlap_pair_probe.py): how long does a search pass take when its measurement kernel is
-// on the stream NEXT to its k-NN kernel instead of behind it?  Upper bound of what a pass gains if model workgroups waited for
-// "their" k-NN workgroups instead of for the launch: out[0] k-NN alone, [1] measurement kernel (no walk) alone, [2] both on one
-// stream, [3] both at once on two streams -- host time per iteration (launches + waits, the same in every form), microseconds.
-// The concurrent form reads neighbours while they are rewritten with the same values (same pose): its results are not used.
-int lio_debug_overlap_pair_probe(lio_ctx* c, const double* state14, int ext, int iters, double* out4) {
-    if (!c || !state14 || !out4 || iters <= 0) return LIO_ERR_INVALID_ARG;
-    enter(c);
-    if (!c->have_map || !c->have_scan) return c->fail(LIO_ERR_INVALID_ARG, "overlap probe", "needs a map and a scan");
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = ensure_deferred(c);
-    if (rc != LIO_OK) return rc;
-    Pose14 pose;
-    std::memcpy(pose.v, state14, sizeof(pose.v));
-    const int nq = c->nq;
-    hipStream_t main_s = c->stream, side_s = c->side_stream;
-    auto knn = [&]() { return run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, false, false); };
-    auto model = [&](hipStream_t s) {
-        ResidualArgs ra{};
-        ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
-        ra.sel = c->d_sel; ra.world = c->d_world; ra.normvec = c->d_normvec; ra.plane = c->d_plane; ra.units = c->d_units; ra.gunits = c->d_gunits;
-        ra.n_unresolved = c->d_counters; ra.cand_total = c->d_cand; ra.out = c->d_out; ra.seq = ++c->seq;
-        return launch_residual(ra, true, ext != 0, s) == hipSuccess ? LIO_OK : LIO_ERR_HIP;
-    };
-    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    for (int form = 0; form < 4; ++form) {
-        double t = 0.0;
-        for (int it = -8; it < iters; ++it) {
-            const double t0 = now();
-            if (form == 0 || form == 2 || form == 3) { rc = knn(); if (rc != LIO_OK) return rc; }
-            if (form == 1 || form == 2) { rc = model(main_s); if (rc != LIO_OK) return rc; }
-            if (form == 3) { rc = model(side_s); if (rc != LIO_OK) return rc; }
-            HIPCHK(c, hipStreamSynchronize(main_s));
-            HIPCHK(c, hipStreamSynchronize(side_s));
-            if (it >= 0) t += now() - t0;
-        }
-        out4[form] = t / iters;
-    }
-    // leave the pass state as a fresh scan would find it: counters consumed, no neighbours promised
-    rc = knn(); if (rc != LIO_OK) return rc;
-    rc = model(main_s); if (rc != LIO_OK) return rc;
-    HIPCHK(c, hipStreamSynchronize(main_s));
-    c->have_search = false; c->have_pass = false; c->hint_valid = false;
-    return LIO_OK;
-}
 int lio_census_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; enter(c); c->census = on != 0; return LIO_OK; }
 int lio_profile_reset(lio_ctx* c) {
     if (!c) return LIO_ERR_INVALID_ARG;
