@@ -526,6 +526,23 @@ def test_scan_preparation_fuzz_seeds(gpu_capi, oracle):
     ctx.close()
 
 
+def test_pass_control_fuzz_seeds(gpu_capi):
+    """Eight cases of tests/fuzz/fuzz_pipeline.py: the pipelined scan step with everything armed (passes ahead of their pose,
+    the next scan's first search across the scan boundary) against the plain sequence on a twin context -- scans of changing
+    sizes, updates of 1..4 iterations, calls between two scans, switches of the armed forms, forced mispredictions: equal bits
+    after every scan, equal maps at the end."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz", "fuzz_pipeline.py")
+    spec = importlib.util.spec_from_file_location("fuzz_pipeline", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    tot = np.zeros(4, np.int64)
+    for seed in range(62000, 62008):
+        tot += np.array(fz.run_case(seed), np.int64)
+    assert tot[0] > 0 and tot[1] > 0 and tot[2] > 0 and tot[3] > 0      # armed, released, released by word, called off: all exercised
+
+
 def test_map_mutation_parity(gpu_capi, oracle, small_case):
     """Add_Points (down-sampled: one point per voxel, nearest the centre; plain), Delete_Point_Boxes,
     validnum/size/flatten: same return values and live set as the oracle, k-NN parity afterwards."""
