@@ -3,8 +3,10 @@
 // (capacities from lio_config) so that a scan step performs no allocation.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <chrono>
+#include <immintrin.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -174,6 +176,19 @@ struct lio_ctx {
     bool pull_pending = false;
     const void* pull_alias = nullptr;          // device alias of the host records
     int pull_stride = 0, pull_n = 0;
+    // assisted pull (enqueue_pass): while the first search of a scan pulls the back of the host cloud as raw records, this thread
+    // packs the front into 16-byte records the search reads instead -- a third of the PCIe bytes for every record packed in time
+    const char* pull_host = nullptr;           // the host address behind pull_alias
+    float4* h_pack = nullptr;                  // [cap_q] page-locked, coherent staging of the packed front
+    const float4* d_pack = nullptr;            // its device alias
+    unsigned long long* h_pack_progress = nullptr;   // stamp << 32 | records packed: the word behind the gates' mail slots
+    const unsigned long long* d_pack_progress = nullptr;
+    uint32_t pack_stamp = 0;
+    double pack_ns_per_record = 1.0;           // this host's packing speed (running estimate: warm caches ~0.45, cold ~1.6)
+    int dbg_assist_pull = 1;                   // lio_debug_set("assist_pull"): 0 = off, 1 = share by the running estimate, 2..90 = that share of the scan in per cent
+    long long n_assisted_pulls = 0, last_pack_front = 0;
+    int dbg_assist_stall_us = 0;               // test hook: this thread sleeps that long before it packs (the search falls back to raw records)
+    double last_pack_us = 0.0;
     int dbg_fused_pull = 1;                    // lio_debug_set("fused_pull", 0): always the stand-alone pull kernel (A/B switch)
     long long n_scan_pulled = 0;               // scans a kernel pulled out of page-locked host records (lio_scan_set_async)
     // page-locked destinations the rows of the callback path are copied into directly (lio_measure_rows)
@@ -982,7 +997,7 @@ TreeArgs tree_args(lio_ctx* c, int nq, int stride, float4* nbr, uint8_t* cnt, fl
 }
 int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14& pose, int nq, int stride,
             float4* nbr, uint8_t* cnt, float4* ulist, unsigned long long* useeds, bool use_hint, bool walk_now, const GateState* gate = nullptr,
-            bool pull_raw = false, const GateMail* mail = nullptr, unsigned long long expect = 0ull) {
+            bool pull_raw = false, const GateMail* mail = nullptr, unsigned long long expect = 0ull, int pack_front = 0) {
     hipStream_t s = c->stream;
     // d_counters[0] / d_cand are zero here: zeroed at creation and re-zeroed by whoever consumes them
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
@@ -1008,6 +1023,10 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     }
     const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
     ka.walk = (lanes == 4 || lanes == 8 || lanes == 16) ? (c->dbg_knn_walk >= 0 ? c->dbg_knn_walk : auto_walk(nq, lanes)) : 0;
+    if (pack_front > 0 && ka.body_raw != nullptr) {                   // (assisted pull: the front comes packed from the host, enqueue_pass)
+        ka.pack_src = c->d_pack; ka.pack_progress = c->d_pack_progress; ka.pack_stamp = c->pack_stamp; ka.pack_front = pack_front;
+        ka.pack_rot = pack_front / (4 * (64 / lanes));
+    }
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
     if (walk_now) HIPCHK(c, launch_knn_tree(tree_args(c, nq, stride, nbr, cnt, ulist, useeds), s, prof_timer(c, LIO_PROF_FALLBACK)));
     return LIO_OK;
@@ -1083,6 +1102,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     { const char* e = std::getenv("LIO_KNN_TUNE"); if (e != nullptr && e[0] >= '0' && e[0] <= '9') c->dbg_knn_tune = std::atoi(e); }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_ARM_NEXT_SCAN"); if (e != nullptr && e[0] == '0') c->dbg_arm_next_scan = 0; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_GATE_IN_KERNEL"); if (e != nullptr && e[0] >= '0' && e[0] <= '7' && e[1] == 0) c->gate_in_kernel = e[0] - '0'; }   // (A/B runs of scripts)
+    { const char* e = std::getenv("LIO_ASSIST_PULL"); if (e != nullptr && e[0] >= '0' && e[0] <= '9') c->dbg_assist_pull = std::atoi(e); }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_KNN_WALK"); if (e != nullptr && (e[0] == '0' || e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0) c->dbg_knn_walk = e[0] - '0'; }
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, c->device));
@@ -1102,16 +1122,19 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
         if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) != hipSuccess) { (void)hipGetLastError(); large_bar = 0; }
         if (e != nullptr && e[0] == '0') large_bar = 0;
         void* vram = nullptr;
-        if (large_bar && hipExtMallocWithFlags(&vram, lio_ctx::GATE_SLOTS * sizeof(GateMail), hipDeviceMallocFinegrained) == hipSuccess && vram != nullptr) {
+        if (large_bar && hipExtMallocWithFlags(&vram, (lio_ctx::GATE_SLOTS + 1) * sizeof(GateMail), hipDeviceMallocFinegrained) == hipSuccess && vram != nullptr) {
             c->h_gate_mail = static_cast<GateMail*>(vram); c->d_gate_mail = c->h_gate_mail; c->gate_mail_in_vram = true;
-            CREATE_CHK(hipMemset(vram, 0, lio_ctx::GATE_SLOTS * sizeof(GateMail)));
+            CREATE_CHK(hipMemset(vram, 0, (lio_ctx::GATE_SLOTS + 1) * sizeof(GateMail)));
         } else {
             (void)hipGetLastError();
-            CREATE_CHK(hipHostMalloc((void**)&c->h_gate_mail, lio_ctx::GATE_SLOTS * sizeof(GateMail), hipHostMallocMapped | hipHostMallocCoherent));
-            std::memset(c->h_gate_mail, 0, lio_ctx::GATE_SLOTS * sizeof(GateMail));
+            CREATE_CHK(hipHostMalloc((void**)&c->h_gate_mail, (lio_ctx::GATE_SLOTS + 1) * sizeof(GateMail), hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(c->h_gate_mail, 0, (lio_ctx::GATE_SLOTS + 1) * sizeof(GateMail));
             CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_gate_mail, c->h_gate_mail, 0));
         }
     }
+    // (one slot more than the gates use: its first word is the progress word of the assisted pull)
+    c->h_pack_progress = &c->h_gate_mail[lio_ctx::GATE_SLOTS].w[0];
+    c->d_pack_progress = &c->d_gate_mail[lio_ctx::GATE_SLOTS].w[0];
     CREATE_CHK(hipMalloc((void**)&c->d_gate, lio_ctx::GATE_SLOTS * sizeof(GateState)));
     CREATE_CHK(hipMemset(c->d_gate, 0, lio_ctx::GATE_SLOTS * sizeof(GateState)));
 
@@ -1240,6 +1263,7 @@ void lio_destroy(lio_ctx* c) {
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->h_pack) (void)hipHostFree(c->h_pack);
     if (c->h_gate_mail) { if (c->gate_mail_in_vram) (void)hipFree(c->h_gate_mail); else (void)hipHostFree(c->h_gate_mail); }
     if (c->d_gate) (void)hipFree(c->d_gate);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2258,7 +2282,7 @@ int lio_scan_set_async(lio_ctx* c, const float* body_pts, int n, int stride_byte
         if (c->dbg_fused_pull && n <= FUSED_TRANSFORM_MAX_QUERIES) {
             // not yet: the first search pass of the scan pulls its queries itself (KnnArgs.body_raw), the search runs beside the
             // transfer; whatever else wants the scan buffer first makes up for it (enter())
-            c->pull_pending = true; c->pull_alias = alias; c->pull_stride = stride_bytes; c->pull_n = n;
+            c->pull_pending = true; c->pull_alias = alias; c->pull_stride = stride_bytes; c->pull_n = n; c->pull_host = reinterpret_cast<const char*>(body_pts);
         } else {
             HIPCHK(c, launch_scan_pull(alias, stride_bytes, n, c->d_body, c->stream));
         }
@@ -2597,6 +2621,64 @@ static bool rows_direct(const lio_ctx* c, int nq) {
 // One pass = lio_measure_begin (enqueue the kernels, return at once) + lio_measure_end (wait for the result record).
 // The host work of the caller that does not depend on the result -- in the iterated update: x [-] x_prop, the
 // Jacobian-corrected P and its first inversion (esekfom.hpp:1655-1703, :1788) -- runs between the two, beside the GPU.
+// ---- assisted pull ---------------------------------------------------------------------------------------------------------
+// The first search of a scan handed over as page-locked host records pulls them over PCIe itself; 100 k records of 48 bytes are
+// 4.8 MB = 85 us at 57 GB/s, behind which a 23 us search waits.  The host thread that launched the pass would only wait for it:
+// instead it packs the FRONT of the cloud into 16-byte records (page-locked staging) and announces its progress in a word the
+// search polls; workgroups of the back -- dispatched first -- pull raw records meanwhile.  Share of the front: where packing
+// (pack_ns_per_record, measured on every scan: the node's cloud may be warm in L3 or not) and the PCIe bytes of both parts take
+// equally long.  Same values by either route: nothing about a result depends on who got to a record first.
+constexpr double PCIE_BYTES_PER_NS = 57.0;               // GPU-initiated reads of page-locked host memory (profiles/r04a_upload_probe.log)
+constexpr int ASSIST_CHUNK = 2048;                        // records per progress announcement (a multiple of 64)
+static int assist_share(lio_ctx* c, int nq) {
+    if (c->dbg_assist_pull == 0 || !c->gate_mail_in_vram || c->pull_host == nullptr || c->pull_stride < 32) return 0;
+    const double raw_ns = (double)nq * c->pull_stride / PCIE_BYTES_PER_NS;
+    if (raw_ns < 15000.0) return 0;                       // (a pull a search hides anyway)
+    double share;
+    if (c->dbg_assist_pull >= 2) share = std::min(c->dbg_assist_pull, 90) / 100.0;
+    else share = std::min(0.9, (double)c->pull_stride / (PCIE_BYTES_PER_NS * c->pack_ns_per_record + c->pull_stride - 16.0));
+    int front = (int)(share * nq) / ASSIST_CHUNK * ASSIST_CHUNK;
+    if (front < 2 * ASSIST_CHUNK) {
+        // (an estimate that says "not worth it" is only ever corrected by a measurement: let it drift back until one is taken)
+        if (c->dbg_assist_pull == 1) c->pack_ns_per_record *= 0.9;
+        return 0;
+    }
+    if (!c->h_pack) {
+        if (hipHostMalloc((void**)&c->h_pack, (size_t)c->cap_q * sizeof(float4), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&c->d_pack, c->h_pack, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->h_pack) { (void)hipHostFree(c->h_pack); c->h_pack = nullptr; }
+            c->dbg_assist_pull = 0;                           // (no staging: every scan is pulled raw)
+            return 0;
+        }
+    }
+    if (++c->pack_stamp == 0u) ++c->pack_stamp;
+    return front;
+}
+static void assist_pack(lio_ctx* c, int front) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const char* src = c->pull_host;
+    const size_t stride = (size_t)c->pull_stride;
+    float* dst = reinterpret_cast<float*>(c->h_pack);
+    const __m128 keep_xyz = _mm_castsi128_ps(_mm_set_epi32(0, -1, -1, -1));
+    volatile unsigned long long* word = c->h_pack_progress;
+    if (c->dbg_assist_stall_us > 0) ::usleep((useconds_t)c->dbg_assist_stall_us);
+    for (int done = 0; done < front;) {
+        const int end = std::min(front, done + ASSIST_CHUNK);
+        for (int i = done; i < end; ++i)
+            _mm_store_ps(dst + 4 * (size_t)i, _mm_and_ps(_mm_loadu_ps(reinterpret_cast<const float*>(src + (size_t)i * stride)), keep_xyz));
+        done = end;
+        __builtin_ia32_sfence();                            // the records before the word that announces them
+        *word = ((unsigned long long)c->pack_stamp << 32) | (unsigned long long)(uint32_t)done;
+        __builtin_ia32_sfence();                            // (write-combined BAR mapping: nothing lingers)
+    }
+    const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+    // (one pre-empted scan must not talk the estimate out of helping: a cloud read from DRAM packs at ~1.6 ns per record)
+    c->pack_ns_per_record = 0.7 * c->pack_ns_per_record + 0.3 * std::min(ns / front, 4.0);
+    c->last_pack_us = ns * 1e-3; c->last_pack_front = front;
+    ++c->n_assisted_pulls;
+}
+
 // The kernels of one pass on the stream: [k-NN (search passes)] [measurement kernel].  gate != nullptr: the pose is not known
 // yet -- the kernels take it from there (and stand down if told to).  Nothing of the context's pass state changes here
 // except the sequence number the pass consumes (*seq_out).
@@ -2607,9 +2689,10 @@ static int enqueue_pass(lio_ctx* c, const Pose14& pose, bool do_search, bool ext
     // the scan is still in the caller's host records (lio_scan_set_async): its first search pulls it; anything else pulls first
     const bool pull_here = c->pull_pending && do_search && gate == nullptr && nq == c->pull_n && nq <= FUSED_TRANSFORM_MAX_QUERIES;
     if (c->pull_pending && !pull_here) flush_pull(c);
+    const int pack_front = pull_here ? assist_share(c, nq) : 0;
     if (do_search) {
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
-        const int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk, gate, pull_here, mail, expect);
+        const int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk, gate, pull_here, mail, expect, pack_front);
         if (rc != LIO_OK) return rc;
         if (pull_here) c->pull_pending = false;
     }
@@ -2645,6 +2728,7 @@ static int enqueue_pass(lio_ctx* c, const Pose14& pose, bool do_search, bool ext
         ra.lunits = c->d_lunits;
     }
     const hipError_t le = launch_residual(ra, do_search, ext, s, prof_timer(c, LIO_PROF_RESIDUAL));
+    if (pack_front > 0) assist_pack(c, pack_front);             // (whatever the launch said: the search is waiting for these records)
     if (le != hipSuccess) return c->fail(LIO_ERR_HIP, "launch_residual", hipGetErrorString(le));
     return LIO_OK;
 }
@@ -3099,6 +3183,8 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
         return LIO_OK;
     }
     if (std::strcmp(key, "rows_direct") == 0) { c->dbg_rows_direct = (int)value; return LIO_OK; }
+    if (std::strcmp(key, "assist_pull") == 0) { c->dbg_assist_pull = (int)value; return LIO_OK; }
+    if (std::strcmp(key, "assist_pull_stall_us") == 0) { c->dbg_assist_stall_us = (int)value; return LIO_OK; }
     if (std::strcmp(key, "fused_pull") == 0) { c->dbg_fused_pull = value != 0; return LIO_OK; }
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
     if (std::strcmp(key, "pre_enqueue") == 0) { c->dbg_pre_enqueue = value != 0; return LIO_OK; }
@@ -3132,6 +3218,9 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "gate_in_kernel") == 0) { *value = c->n_gate_in_kernel; return LIO_OK; }
     if (std::strcmp(key, "next_scan_armed") == 0) { *value = c->n_next_scan_armed; return LIO_OK; }
     if (std::strcmp(key, "next_scan_released") == 0) { *value = c->n_next_scan_released; return LIO_OK; }
+    if (std::strcmp(key, "assisted_pulls") == 0) { *value = c->n_assisted_pulls; return LIO_OK; }
+    if (std::strcmp(key, "last_pack_front") == 0) { *value = c->last_pack_front; return LIO_OK; }
+    if (std::strcmp(key, "last_pack_ns") == 0) { *value = (long long)(c->last_pack_us * 1e3); return LIO_OK; }
     if (std::strcmp(key, "scan_pulled") == 0) { *value = c->n_scan_pulled; return LIO_OK; }
     if (std::strcmp(key, "rows_direct_dma") == 0) { *value = c->n_rows_direct_dma; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_get", "unknown key");

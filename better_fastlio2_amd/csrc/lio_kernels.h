@@ -26,6 +26,16 @@ struct KnnArgs {
     int              body_raw_stride;
     int              body_raw_aligned;   // records start on 16-byte boundaries: one 16-byte read each
     float4*          body_fill;
+    // ... and the host helps (lio_ctx.hip, assisted pull): while the workgroups dispatched first pull the BACK of the scan as raw
+    // records, the host thread that would otherwise only wait for the pass packs the FRONT [0, pack_front) into 16-byte records
+    // (`pack_src`: device alias of its page-locked staging buffer) and publishes how far it has come in `pack_progress`
+    // (stamp << 32 | records done; fine-grained device memory where the BAR maps it).  A third of the bytes cross PCIe for every
+    // record the host gets to first.  A workgroup whose records are not there in time reads them raw: same values either way.
+    const float4*    pack_src;      // nullptr: everything raw
+    const unsigned long long* pack_progress;
+    uint32_t         pack_stamp;
+    int              pack_front;    // a multiple of 64 records (whole workgroups whatever the lanes per query)
+    int              pack_rot;      // workgroup b takes query block (b + pack_rot) mod blocks: the raw part is dispatched first
     Pose14           pose;
     const GateState* gate;          // non-null: the pose (and the order to skip the launch) come from there (lio_common.h)
     // non-null: this launch is the first kernel of a pass enqueued ahead of its pose and there is NO gate kernel in front of it --

@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     if (a.gate != nullptr && a.gate->skip != 0u) return;      // a pre-enqueued pass the host called off
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / G, r = lane % G;
-    const int q = (blockIdx.x * WPB + wave) * GPW + g;
+    // (assisted pull: the query blocks are handed out rotated -- the part pulled raw goes first, then the front in the host's order)
+    int qb = (int)blockIdx.x + a.pack_rot;
+    if (qb >= (int)gridDim.x) qb -= (int)gridDim.x;
+    const int q = (qb * WPB + wave) * GPW + g;
     const bool active = q < a.nq;
 
     float qx = 0.0f, qy = 0.0f, qz = 0.0f;
@@ -204,10 +207,26 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             } else if (a.gate != nullptr) {
                 pose_w = a.gate->pose;
             }
-            const int qi = blockIdx.x * (WPB * GPW) + lane;
+            const int qi = qb * (WPB * GPW) + lane;
+            // assisted pull: a workgroup of the front waits (bounded) until the host has packed its records; out of time -> raw
+            bool packed_by_host = false;
+            if (go && a.body_raw != nullptr && a.pack_src != nullptr && qb * (WPB * GPW) < a.pack_front) {
+                const uint32_t need = (uint32_t)min((qb + 1) * (WPB * GPW), a.pack_front);
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    const unsigned long long w = __hip_atomic_load(a.pack_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((uint32_t)(w >> 32) == a.pack_stamp && (uint32_t)w >= need) { packed_by_host = true; break; }
+                    if (wall_clock64() - t0 > 30000ull) break;           // 100 MHz: 300 us -- a host that was pre-empted
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                // (the records were written before the word that announces them: x86 store order + sfence, lio_ctx.hip)
+            }
             if (go && lane < WPB * GPW && qi < a.nq) {
                 float4 b;
-                if (a.body_raw != nullptr) {
+                if (a.body_raw != nullptr && packed_by_host) {
+                    b = a.pack_src[qi];                                  // (16 bytes instead of the whole record; w = 0 already)
+                    a.body_fill[qi] = b;
+                } else if (a.body_raw != nullptr) {
                     // (host memory through its device alias: one PCIe read per record, thousands of workgroups' worth in flight)
                     const char* rec = a.body_raw + (size_t)qi * (size_t)a.body_raw_stride;
                     if (a.body_raw_aligned) {

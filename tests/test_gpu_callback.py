@@ -179,6 +179,52 @@ def test_scan_set_async_equals_scan_set(gpu_capi, small_case, stride_floats):
     ctx.close()
 
 
+@pytest.mark.parametrize("stride_floats", [8, 12])
+def test_assisted_pull_equals_scan_set(gpu_capi, synth, small_case, stride_floats):
+    """The first search of a scan handed over as page-locked host records, with the host packing the FRONT of the cloud beside
+    it (assisted pull, lio_ctx.hip): workgroups of the back pull raw records, workgroups of the front wait for the host's
+    progress word and read 16-byte records -- or give up on a stalled host and read raw.  Every share (off, by the running
+    estimate, 25 / 50 / 90 per cent) and a host that sleeps 2 ms before it packs leave exactly the scan, the neighbours and the
+    sums of lio_scan_set."""
+    w = small_case["world"]
+    n = 60_000
+    sc = synth.make_scan(w, n, seed=synth.SEED + 4242)
+    ps, rt = synth.perturb_state(sc, seed=synth.SEED + 4243)
+    st = gpu_capi.make_state26(ps, rt, sc.off_R, sc.off_T)[:14]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=n, max_map_points=400_000)
+    if not ctx.debug_get("gate_mail_in_vram"):
+        ctx.close(); pytest.skip("no large BAR: the progress word would be polled over PCIe (assisted pull stays off)")
+    ctx.map_build(w.points)
+    ctx.scan_set(sc.body)
+    g0 = ctx.measure(st, True, False)
+    nx0, nd0, nc0 = ctx.neighbors()
+    rec = np.full((n, stride_floats), 7.0, np.float32)
+    rec[:, :3] = sc.body
+    L = ctx.L
+    buf = rec.copy()
+    assert L.lio_host_register(buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
+    for lanes in (0, 16):
+        ctx.debug_set("lanes_per_query", lanes)
+        for share, stall in ((0, 0), (1, 0), (25, 0), (50, 0), (90, 0), (50, 2000), (1, 0)):
+            ctx.debug_set("assist_pull", share); ctx.debug_set("assist_pull_stall_us", stall)
+            before = ctx.debug_get("assisted_pulls")
+            assert L.lio_scan_set_async(ctx.h, buf.ctypes.data_as(C.c_void_p), n, 4 * stride_floats) == 0, L.lio_last_error(ctx.h)
+            g = ctx.measure(st, True, False)
+            assert ctx.debug_get("assisted_pulls") - before == (0 if share == 0 else 1)      # (also right behind the stalled scan: one slow scan does not end the help)
+            if share >= 2:
+                assert ctx.debug_get("last_pack_front") == (share * n // 100) // 2048 * 2048
+            nx, nd, nc = ctx.neighbors()
+            assert g["m"] == g0["m"] and np.array_equal(g["HTH"], g0["HTH"]) and np.array_equal(g["HTh"], g0["HTh"])
+            assert bits_equal(nx, nx0) and bits_equal(nd, nd0) and np.array_equal(nc, nc0)
+            assert bits_equal(ctx.scan_cloud(1), np.ascontiguousarray(sc.body, np.float32))
+            g = ctx.measure(st, False, False)                       # (a pass on the scan buffer the search left)
+            assert g["m"] > n // 2
+    ctx.debug_set("assist_pull_stall_us", 0)
+    ctx.synchronize()
+    assert L.lio_host_unregister(buf.ctypes.data_as(C.c_void_p)) == 0
+    ctx.close()
+
+
 def test_kitti_bin_step_script():
     """scripts/kitti_bin_step.py on a sweep in KITTI's .bin format (a synthetic one: no data set ships here): read, no-pose
     lio_scan_undistort, lio_scan_voxel_filter(0.5), the scan step; neighbours against the reference tree."""
