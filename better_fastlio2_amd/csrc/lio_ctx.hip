@@ -184,9 +184,16 @@ struct lio_ctx {
     unsigned long long* h_pack_progress = nullptr;   // stamp << 32 | records packed: the word behind the gates' mail slots
     const unsigned long long* d_pack_progress = nullptr;
     uint32_t pack_stamp = 0;
-    double pack_ns_per_record = 1.0;           // this host's packing speed (running estimate: warm caches ~0.45, cold ~1.6)
+    double assist_frac = 0.78;                 // share of a scan the host packs: steered by the measured time of the scans' first passes (assist_share)
+    int assist_side = -1, assist_next_side = 0; // this scan's share: a little below (0) / above (1) assist_frac; -1 = not steered
+    double assist_acc[2] = {0.0, 0.0};         // ns per record from the launch of an assisted first pass to its record, per side
+    int assist_cnt[2] = {0, 0};
+    double assist_t0_ns = 0.0;                 // launch of the assisted pass in flight (0 = none)
+    double pack_ns_per_record = 1.0;           // this host's packing speed (reported; warm caches ~0.45, from DRAM ~1.0)
     int dbg_assist_pull = 1;                   // lio_debug_set("assist_pull"): 0 = off, 1 = share by the running estimate, 2..90 = that share of the scan in per cent
     long long n_assisted_pulls = 0, last_pack_front = 0;
+    int dbg_assist_chunk = 0;                  // (0 = by scan size) lio_debug_set("assist_pull_chunk"): records per progress announcement (a multiple of 64)
+    double last_publish_us = 0.0;              // of last_pack_us: spent announcing progress (fences + the word through the BAR)
     int dbg_assist_stall_us = 0;               // test hook: this thread sleeps that long before it packs (the search falls back to raw records)
     double last_pack_us = 0.0;
     int dbg_fused_pull = 1;                    // lio_debug_set("fused_pull", 0): always the stand-alone pull kernel (A/B switch)
@@ -1026,6 +1033,7 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     if (pack_front > 0 && ka.body_raw != nullptr) {                   // (assisted pull: the front comes packed from the host, enqueue_pass)
         ka.pack_src = c->d_pack; ka.pack_progress = c->d_pack_progress; ka.pack_stamp = c->pack_stamp; ka.pack_front = pack_front;
         ka.pack_rot = pack_front / (4 * (64 / lanes));
+        ka.pack_wait_out = reinterpret_cast<unsigned long long*>(c->d_small + 48);     // (bytes 192..199 of the host-mapped words)
     }
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
     if (walk_now) HIPCHK(c, launch_knn_tree(tree_args(c, nq, stride, nbr, cnt, ulist, useeds), s, prof_timer(c, LIO_PROF_FALLBACK)));
@@ -2629,20 +2637,32 @@ static bool rows_direct(const lio_ctx* c, int nq) {
 // (pack_ns_per_record, measured on every scan: the node's cloud may be warm in L3 or not) and the PCIe bytes of both parts take
 // equally long.  Same values by either route: nothing about a result depends on who got to a record first.
 constexpr double PCIE_BYTES_PER_NS = 57.0;               // GPU-initiated reads of page-locked host memory (profiles/r04a_upload_probe.log)
-constexpr int ASSIST_CHUNK = 2048;                        // records per progress announcement (a multiple of 64)
+
 static int assist_share(lio_ctx* c, int nq) {
     if (c->dbg_assist_pull == 0 || !c->gate_mail_in_vram || c->pull_host == nullptr || c->pull_stride < 32) return 0;
     const double raw_ns = (double)nq * c->pull_stride / PCIE_BYTES_PER_NS;
     if (raw_ns < 15000.0) return 0;                       // (a pull a search hides anyway)
+    // The share is steered by what it is meant to shorten: the time from the launch of the scan's first pass to its record
+    // (per record of the scan), taken on every assisted scan.  Scans alternate between a share a little above and a little below the
+    // current one; every few pairs the share moves towards the faster side.  (A model -- the host's packing speed against the PCIe
+    // rate -- does not hold: the speed depends on the share itself, both sides read the same cloud, and on what the caches hold;
+    // neither does "host and raw pull finish together": the best share has the host finish later, the search still has the
+    // packed front to read and to search.)  A workgroup that gave up on the host (stalled: pre-empted, stopped) cuts the share at once.
     double share;
-    if (c->dbg_assist_pull >= 2) share = std::min(c->dbg_assist_pull, 90) / 100.0;
-    else share = std::min(0.9, (double)c->pull_stride / (PCIE_BYTES_PER_NS * c->pack_ns_per_record + c->pull_stride - 16.0));
-    int front = (int)(share * nq) / ASSIST_CHUNK * ASSIST_CHUNK;
-    if (front < 2 * ASSIST_CHUNK) {
-        // (an estimate that says "not worth it" is only ever corrected by a measurement: let it drift back until one is taken)
-        if (c->dbg_assist_pull == 1) c->pack_ns_per_record *= 0.9;
-        return 0;
+    if (c->dbg_assist_pull >= 2) {
+        share = std::min(c->dbg_assist_pull, 92) / 100.0;
+        c->assist_side = -1;
+    } else {
+        const unsigned long long w = __atomic_load_n(reinterpret_cast<volatile unsigned long long*>(reinterpret_cast<char*>(c->h_small) + 192), __ATOMIC_ACQUIRE);
+        if (c->pack_stamp != 0u && (uint32_t)(w >> 32) == c->pack_stamp && (uint32_t)w == 0xffffffffu) {     // (the previous assisted scan's word)
+            c->assist_frac = std::max(0.25, c->assist_frac * 0.7);
+            c->assist_acc[0] = c->assist_acc[1] = 0.0; c->assist_cnt[0] = c->assist_cnt[1] = 0;
+        }
+        c->assist_side = c->assist_next_side; c->assist_next_side ^= 1;
+        share = std::max(0.2, std::min(0.94, c->assist_frac + (c->assist_side ? 0.03 : -0.03)));
     }
+    int front = (int)(share * nq) / 64 * 64;
+    if (front < 4096) return 0;
     if (!c->h_pack) {
         if (hipHostMalloc((void**)&c->h_pack, (size_t)c->cap_q * sizeof(float4), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostGetDevicePointer((void**)&c->d_pack, c->h_pack, 0) != hipSuccess) {
@@ -2662,20 +2682,39 @@ static void assist_pack(lio_ctx* c, int front) {
     float* dst = reinterpret_cast<float*>(c->h_pack);
     const __m128 keep_xyz = _mm_castsi128_ps(_mm_set_epi32(0, -1, -1, -1));
     volatile unsigned long long* word = c->h_pack_progress;
+    // records per announcement: a twelfth of the scan, 1024 ... 8192 (announcing costs ~0.1 us, but with 2048-record chunks the
+    // packing itself ran at 0.75 instead of 0.43 ns per record beside the search's reads of what was just announced --
+    // profiles/r04y_assisted_pull.log; finer than that only delays nothing: a workgroup waits for at most one chunk = ~3.5 us)
+    int chunk = c->dbg_assist_chunk;
+    if (chunk <= 0) { chunk = (c->pull_n / 12 + 63) / 64 * 64; chunk = std::max(1024, std::min(8192, chunk)); }
+    unsigned long long publish_ticks = 0;
+    const unsigned long long tsc0 = __rdtsc();
     if (c->dbg_assist_stall_us > 0) ::usleep((useconds_t)c->dbg_assist_stall_us);
     for (int done = 0; done < front;) {
-        const int end = std::min(front, done + ASSIST_CHUNK);
-        for (int i = done; i < end; ++i)
-            _mm_store_ps(dst + 4 * (size_t)i, _mm_and_ps(_mm_loadu_ps(reinterpret_cast<const float*>(src + (size_t)i * stride)), keep_xyz));
+        const int end = std::min(front, done + chunk);
+        // four records per round, streaming stores (whole 64-byte lines leave through the write-combining buffers: no read for
+        // ownership of the staging buffer, nothing of it displaces the cloud in the caches -- scripts/micro/pack_probe.cpp on the
+        // bench's host: 0.48 -> 0.40 ns per record warm, 1.29 -> 0.94 from DRAM)
+        for (int i = done; i < end; i += 4) {                 // (chunk and `front` are multiples of 64)
+            const __m128 r0 = _mm_loadu_ps(reinterpret_cast<const float*>(src + (size_t)i * stride));
+            const __m128 r1 = _mm_loadu_ps(reinterpret_cast<const float*>(src + (size_t)(i + 1) * stride));
+            const __m128 r2 = _mm_loadu_ps(reinterpret_cast<const float*>(src + (size_t)(i + 2) * stride));
+            const __m128 r3 = _mm_loadu_ps(reinterpret_cast<const float*>(src + (size_t)(i + 3) * stride));
+            _mm_stream_ps(dst + 4 * (size_t)i, _mm_and_ps(r0, keep_xyz)); _mm_stream_ps(dst + 4 * (size_t)i + 4, _mm_and_ps(r1, keep_xyz));
+            _mm_stream_ps(dst + 4 * (size_t)i + 8, _mm_and_ps(r2, keep_xyz)); _mm_stream_ps(dst + 4 * (size_t)i + 12, _mm_and_ps(r3, keep_xyz));
+        }
         done = end;
+        const unsigned long long tp = __rdtsc();
         __builtin_ia32_sfence();                            // the records before the word that announces them
         *word = ((unsigned long long)c->pack_stamp << 32) | (unsigned long long)(uint32_t)done;
         __builtin_ia32_sfence();                            // (write-combined BAR mapping: nothing lingers)
+        publish_ticks += __rdtsc() - tp;
     }
     const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
     // (one pre-empted scan must not talk the estimate out of helping: a cloud read from DRAM packs at ~1.6 ns per record)
     c->pack_ns_per_record = 0.7 * c->pack_ns_per_record + 0.3 * std::min(ns / front, 4.0);
     c->last_pack_us = ns * 1e-3; c->last_pack_front = front;
+    { const unsigned long long all = __rdtsc() - tsc0; c->last_publish_us = all ? c->last_pack_us * (double)publish_ticks / (double)all : 0.0; }
     ++c->n_assisted_pulls;
 }
 
@@ -2690,6 +2729,7 @@ static int enqueue_pass(lio_ctx* c, const Pose14& pose, bool do_search, bool ext
     const bool pull_here = c->pull_pending && do_search && gate == nullptr && nq == c->pull_n && nq <= FUSED_TRANSFORM_MAX_QUERIES;
     if (c->pull_pending && !pull_here) flush_pull(c);
     const int pack_front = pull_here ? assist_share(c, nq) : 0;
+    if (pack_front > 0) c->assist_t0_ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now().time_since_epoch()).count();   // (passes armed behind this one come through here too)
     if (do_search) {
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
         const int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk, gate, pull_here, mail, expect, pack_front);
@@ -3001,6 +3041,22 @@ int lio_measure_end(lio_ctx* c, lio_out* out) {
         }
         c->stamp('S', spins);
     }
+    if (c->assist_t0_ns > 0.0) {                             // the first pass of an assisted pull: its time steers the share (assist_share)
+        const double t = (std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now().time_since_epoch()).count() - c->assist_t0_ns) / std::max(1, c->nq);
+        c->assist_t0_ns = 0.0;
+        if (c->assist_side >= 0) {
+            c->assist_acc[c->assist_side] += t; ++c->assist_cnt[c->assist_side];
+            if (c->assist_cnt[0] >= 3 && c->assist_cnt[1] >= 3) {
+                const double below = c->assist_acc[0] / c->assist_cnt[0], above = c->assist_acc[1] / c->assist_cnt[1];
+                // (1.5 %: at C2 six points of share are worth ~6 % of a first pass; where they are worth less -- C3 -- the share stays put)
+                // Steering stays within 55 ... 90 %: every host and cloud measured has its best share there (cold DRAM 70, warm L3 90);
+                // below that only a workgroup that gave up takes it (assist_share), and steering brings it back up.
+                if (above < below * 0.985) c->assist_frac = std::min(0.9, c->assist_frac + 0.03);
+                else if (below < above * 0.985) c->assist_frac = std::max(std::min(c->assist_frac, 0.55), c->assist_frac - 0.03);
+                c->assist_acc[0] = c->assist_acc[1] = 0.0; c->assist_cnt[0] = c->assist_cnt[1] = 0;
+            }
+        }
+    }
 
     const DeviceOut& d = *c->h_out;
     if (d.n_unresolved < 0) return c->fail(LIO_ERR_HIP, "lio_measure", "tree walk exceeded its stack bound");
@@ -3184,6 +3240,10 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     }
     if (std::strcmp(key, "rows_direct") == 0) { c->dbg_rows_direct = (int)value; return LIO_OK; }
     if (std::strcmp(key, "assist_pull") == 0) { c->dbg_assist_pull = (int)value; return LIO_OK; }
+    if (std::strcmp(key, "assist_pull_chunk") == 0) {
+        if (value < 0 || value % 64 != 0 || value > 65536) return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "assist_pull_chunk: 0 (by scan size) or a multiple of 64 up to 65536");
+        c->dbg_assist_chunk = (int)value; return LIO_OK;
+    }
     if (std::strcmp(key, "assist_pull_stall_us") == 0) { c->dbg_assist_stall_us = (int)value; return LIO_OK; }
     if (std::strcmp(key, "fused_pull") == 0) { c->dbg_fused_pull = value != 0; return LIO_OK; }
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
@@ -3219,7 +3279,9 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "next_scan_armed") == 0) { *value = c->n_next_scan_armed; return LIO_OK; }
     if (std::strcmp(key, "next_scan_released") == 0) { *value = c->n_next_scan_released; return LIO_OK; }
     if (std::strcmp(key, "assisted_pulls") == 0) { *value = c->n_assisted_pulls; return LIO_OK; }
+    if (std::strcmp(key, "assist_share_permille") == 0) { *value = (long long)(c->assist_frac * 1000.0 + 0.5); return LIO_OK; }
     if (std::strcmp(key, "last_pack_front") == 0) { *value = c->last_pack_front; return LIO_OK; }
+    if (std::strcmp(key, "last_publish_ns") == 0) { *value = (long long)(c->last_publish_us * 1e3); return LIO_OK; }
     if (std::strcmp(key, "last_pack_ns") == 0) { *value = (long long)(c->last_pack_us * 1e3); return LIO_OK; }
     if (std::strcmp(key, "scan_pulled") == 0) { *value = c->n_scan_pulled; return LIO_OK; }
     if (std::strcmp(key, "rows_direct_dma") == 0) { *value = c->n_rows_direct_dma; return LIO_OK; }

@@ -36,6 +36,8 @@ struct KnnArgs {
     uint32_t         pack_stamp;
     int              pack_front;    // a multiple of 64 records (whole workgroups whatever the lanes per query)
     int              pack_rot;      // workgroup b takes query block (b + pack_rot) mod blocks: the raw part is dispatched first
+    unsigned long long* pack_wait_out;   // host-mapped: stamp << 32 | ticks (100 MHz) the LAST workgroup of the front waited for the host's
+                                    // word, 0xffffffff = it gave up and read raw records (the host then takes a smaller share, assist_share)
     Pose14           pose;
     const GateState* gate;          // non-null: the pose (and the order to skip the launch) come from there (lio_common.h)
     // non-null: this launch is the first kernel of a pass enqueued ahead of its pose and there is NO gate kernel in front of it --

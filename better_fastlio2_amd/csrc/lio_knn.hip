@@ -219,6 +219,12 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
                     if (wall_clock64() - t0 > 30000ull) break;           // 100 MHz: 300 us -- a host that was pre-empted
                     __builtin_amdgcn_s_sleep(8);
                 }
+                if (need == (uint32_t)a.pack_front && lane == 0 && a.pack_wait_out != nullptr) {
+                    // the last workgroup of the front (the last of the launch): how long did it wait for the host -- or did it give up?
+                    unsigned long long dt = wall_clock64() - t0;
+                    if (dt > 0xfffffffeull) dt = 0xfffffffeull;
+                    __hip_atomic_store(a.pack_wait_out, ((unsigned long long)a.pack_stamp << 32) | (packed_by_host ? dt : 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 // (the records were written before the word that announces them: x86 store order + sfence, lio_ctx.hip)
             }
             if (go && lane < WPB * GPW && qi < a.nq) {

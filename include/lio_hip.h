@@ -207,7 +207,12 @@ int  lio_scan_set_device(lio_ctx* ctx, const void* d_body_f4, int n);
  * upload on the stream.  Records in page-locked memory the HIP runtime knows (lio_host_alloc, lio_host_register) are PULLED by a
  * kernel over PCIe where they lie -- no host-side pack, no staging copy, the call returns after one kernel launch -- and must then
  * stay untouched until the first measurement pass of the scan has returned; any other memory is packed into the library's staging
- * buffer before the call returns.  stride_bytes: a multiple of 4 (pcl::PointXYZINormal: 48).                                      */
+ * buffer before the call returns.  stride_bytes: a multiple of 4 (pcl::PointXYZINormal: 48).
+ * Large clouds of fat records (>= 32 bytes apart, >= 15 us of PCIe time) are pulled WITH THE CALLER'S HELP: inside the scan's first
+ * lio_measure[_begin] the calling thread -- which would only wait for the pass -- packs the front of the cloud into 16-byte records
+ * the search reads instead of the raw ones, while the search pulls the back as it is (a third of the PCIe bytes for every record
+ * packed in time; the share is steered by the measured time of the scans' first passes; lio_debug_set "assist_pull" = 0 switches
+ * it off).  Results do not depend on who got to a record first.                                                                  */
 int  lio_scan_set_async(lio_ctx* ctx, const float* body_pts, int n, int stride_bytes);
 /* hipHostRegister / hipHostUnregister for callers that do not link the HIP runtime themselves (the adaptor header): page-locks
  * [p, p + bytes) and maps it for the GPU, so that lio_scan_set_async can pull a cloud and lio_measure_rows can have the copy
@@ -319,7 +324,9 @@ results); "library_sort" sends every sort / compaction of map maintenance and sc
  * many candidates per lane in flight; -1 = by scan size again) and "lanes_per_query" = 4 ... 64 its lanes per query (0 = by
  * scan size) -- identical results, A/B switches; "voxel_fast_path" = 0 keeps lio_scan_voxel_filter on the general sort even
  * for sweeps in time order (identical results); "retired_budget" overrides the number of retired slots that triggers a full
- * index rebuild (0 = the default, four times the live points).  Unknown key: LIO_ERR_INVALID_ARG.       */
+ * index rebuild (0 = the default, four times the live points); "assist_pull" = 0 / 1 / 2..92: the host's share of an assisted
+ * pull off / steered / fixed in per cent, "assist_pull_chunk" = records per progress announcement (0 = by scan size),
+ * "assist_pull_stall_us" = test hook: the host sleeps that long before it packs.  Unknown key: LIO_ERR_INVALID_ARG.       */
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
 /* counters for tests: "gate_released" / "gate_called_off" = pre-enqueued passes that ran / were called off; "voxel_fast_runs" /
  * "voxel_redone" = voxel-filter attempts on the compact-key path / sweeps filtered twice after a wrong prediction;
@@ -327,7 +334,9 @@ int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
  * step / that entered the map; "gate_reenqueued" = passes put on the stream again because their gate had
  * given up (a host stalled for seconds); "gate_in_kernel" = passes armed without a gate kernel; "next_scan_armed" / "next_scan_released" = first searches
  * armed across a scan boundary / of those, the ones that ran; "scan_pulled" = scans a kernel pulled out of page-locked host records
- * (lio_scan_set_async); "rows_direct_dma" = lio_measure_rows calls served by copies straight into page-locked h_x / h            */
+ * (lio_scan_set_async); "rows_direct_dma" = lio_measure_rows calls served by copies straight into page-locked h_x / h;
+ * "assisted_pulls" = scans whose first search had the host pack the front of the cloud beside it, "last_pack_front" / "last_pack_ns" /
+ * "assist_share_permille" = records packed, time it took, and the share in force                                                  */
 int  lio_debug_get(lio_ctx* ctx, const char* key, long long* value);
 /* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: [0] its start, [1] own partial
  * published, [2] group folded, [3] grid folded, [4] the listed queries' terms folded (search passes that list any),

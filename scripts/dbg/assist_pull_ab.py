@@ -39,6 +39,8 @@ def step():
     rc = B.cbb_step(kf.h, ids[k], priors[k].ctypes.data_as(C.c_void_p), P0.ctypes.data_as(C.c_void_p), 0.001, ext, 1, C.byref(ulog))
     assert rc == 0, ctx.L.lio_last_error(ctx.h)
 
+chunk = int(os.environ.get("CHUNK", "0"))
+ctx.debug_set("assist_pull_chunk", chunk)
 ref = None
 res = {v: [] for v in shares}
 for r in range(reps):
@@ -54,7 +56,7 @@ for r in range(reps):
         for _ in range(steps):
             step()
         ctx.synchronize(); dt = time.perf_counter() - t0
-        res[v].append((dt / steps * 1e6, ctx.debug_get("last_pack_front"), ctx.debug_get("last_pack_ns") / 1e3))
+        res[v].append((dt / steps * 1e6, ctx.debug_get("last_pack_front"), ctx.debug_get("last_pack_ns") / 1e3, ctx.debug_get("last_publish_ns") / 1e3, ctx.debug_get("assist_share_permille") / 10.0))
 for v in shares:
-    print("%s rotate %d assist_pull %2d: step us %s | scans/s (best) %.0f | last front %d records packed in %.1f us" % (
-        cfg, n_rot, v, " ".join("%.1f" % m[0] for m in res[v]), 1e6 / min(m[0] for m in res[v]), res[v][-1][1], res[v][-1][2]), flush=True)
+    print("%s rotate %d chunk %d assist_pull %2d: step us %s | scans/s (best) %.0f | last front %d records packed in %.1f us (of which %.1f us announcing); steered share %.0f %%" % (
+        cfg, n_rot, chunk, v, " ".join("%.1f" % m[0] for m in res[v]), 1e6 / min(m[0] for m in res[v]), res[v][-1][1], res[v][-1][2], res[v][-1][3], res[v][-1][4]), flush=True)

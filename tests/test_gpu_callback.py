@@ -212,7 +212,7 @@ def test_assisted_pull_equals_scan_set(gpu_capi, synth, small_case, stride_float
             g = ctx.measure(st, True, False)
             assert ctx.debug_get("assisted_pulls") - before == (0 if share == 0 else 1)      # (also right behind the stalled scan: one slow scan does not end the help)
             if share >= 2:
-                assert ctx.debug_get("last_pack_front") == (share * n // 100) // 2048 * 2048
+                assert ctx.debug_get("last_pack_front") == (share * n // 100) // 64 * 64
             nx, nd, nc = ctx.neighbors()
             assert g["m"] == g0["m"] and np.array_equal(g["HTH"], g0["HTH"]) and np.array_equal(g["HTh"], g0["HTh"])
             assert bits_equal(nx, nx0) and bits_equal(nd, nd0) and np.array_equal(nc, nc0)
