@@ -2640,6 +2640,11 @@ constexpr double PCIE_BYTES_PER_NS = 57.0;               // GPU-initiated reads 
 
 static int assist_share(lio_ctx* c, int nq) {
     if (c->dbg_assist_pull == 0 || !c->gate_mail_in_vram || c->pull_host == nullptr || c->pull_stride < 32) return 0;
+    {   // (the search kernel has the assisted form where it walks the prefix-form list: 4, 8 or 16 lanes per query, no census)
+        const int lanes = c->cfg.lanes_per_query > 0 ? c->cfg.lanes_per_query : auto_lanes(nq);
+        const int walk = (lanes == 4 || lanes == 8 || lanes == 16) ? (c->dbg_knn_walk >= 0 ? c->dbg_knn_walk : auto_walk(nq, lanes)) : 0;
+        if (c->census || (walk != 1 && walk != 2 && walk != 4)) return 0;
+    }
     const double raw_ns = (double)nq * c->pull_stride / PCIE_BYTES_PER_NS;
     if (raw_ns < 15000.0) return 0;                       // (a pull a search hides anyway)
     // The share is steered by what it is meant to shorten: the time from the launch of the scan's first pass to its record

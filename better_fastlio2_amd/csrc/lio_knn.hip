@@ -166,7 +166,9 @@ __device__ __forceinline__ bool shell_second_chance(const KnnArgs& a, float qx, 
 //        node's ~9 k-point scans) are a chain of dependent round trips, one per candidate of a lane; this makes it one per U.
 //        Same candidates, same keys, same ladder: bit-identical results (the order in which a lane offers its candidates to its
 //        sorted list does not change the list).
-template <int G, bool CENSUS, bool HINT, int U = 0>
+// PACK: the first search of an assisted pull (KnnArgs.pack_*) -- an instantiation of its own: compiled into every launch, the few
+// live values it adds took the kernel from eight to seven wavefronts per SIMD (+2 us per launch at C2, measured).
+template <int G, bool CENSUS, bool HINT, int U = 0, bool PACK = false>
 __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     constexpr int WPB = 4;
     constexpr int GPW = 64 / G;                    // queries per wavefront
@@ -177,8 +179,11 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / G, r = lane % G;
     // (assisted pull: the query blocks are handed out rotated -- the part pulled raw goes first, then the front in the host's order)
-    int qb = (int)blockIdx.x + a.pack_rot;
-    if (qb >= (int)gridDim.x) qb -= (int)gridDim.x;
+    int qb = (int)blockIdx.x;
+    if constexpr (PACK) {
+        qb += a.pack_rot;
+        if (qb >= (int)gridDim.x) qb -= (int)gridDim.x;
+    }
     const int q = (qb * WPB + wave) * GPW + g;
     const bool active = q < a.nq;
 
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             const int qi = qb * (WPB * GPW) + lane;
             // assisted pull: a workgroup of the front waits (bounded) until the host has packed its records; out of time -> raw
             bool packed_by_host = false;
-            if (go && a.body_raw != nullptr && a.pack_src != nullptr && qb * (WPB * GPW) < a.pack_front) {
+            if (PACK && go && a.body_raw != nullptr && a.pack_src != nullptr && qb * (WPB * GPW) < a.pack_front) {
                 const uint32_t need = (uint32_t)min((qb + 1) * (WPB * GPW), a.pack_front);
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             }
             if (go && lane < WPB * GPW && qi < a.nq) {
                 float4 b;
-                if (a.body_raw != nullptr && packed_by_host) {
+                if (PACK && a.body_raw != nullptr && packed_by_host) {
                     b = a.pack_src[qi];                                  // (16 bytes instead of the whole record; w = 0 already)
                     a.body_fill[qi] = b;
                 } else if (a.body_raw != nullptr) {
@@ -653,12 +658,14 @@ static void launch_knn27_gu(const KnnArgs& a, hipStream_t s, KernelTimer t) {
     const int qpb = 4 * (64 / G);                  // queries per 256-thread workgroup
     const dim3 grid((a.nq + qpb - 1) / qpb), block(256);
     if (t.start != nullptr) {
-        if (a.use_hint) hipExtLaunchKernelGGL((knn27_kernel<G, false, true, U>), grid, block, 0, s, t.start, t.stop, 0, a);
-        else            hipExtLaunchKernelGGL((knn27_kernel<G, false, false, U>), grid, block, 0, s, t.start, t.stop, 0, a);
+        if (a.use_hint)               hipExtLaunchKernelGGL((knn27_kernel<G, false, true, U>), grid, block, 0, s, t.start, t.stop, 0, a);
+        else if (a.pack_src != nullptr) hipExtLaunchKernelGGL((knn27_kernel<G, false, false, U, true>), grid, block, 0, s, t.start, t.stop, 0, a);
+        else                          hipExtLaunchKernelGGL((knn27_kernel<G, false, false, U>), grid, block, 0, s, t.start, t.stop, 0, a);
         return;
     }
-    if (a.use_hint) hipLaunchKernelGGL((knn27_kernel<G, false, true, U>), grid, block, 0, s, a);
-    else            hipLaunchKernelGGL((knn27_kernel<G, false, false, U>), grid, block, 0, s, a);
+    if (a.use_hint)               hipLaunchKernelGGL((knn27_kernel<G, false, true, U>), grid, block, 0, s, a);
+    else if (a.pack_src != nullptr) hipLaunchKernelGGL((knn27_kernel<G, false, false, U, true>), grid, block, 0, s, a);
+    else                          hipLaunchKernelGGL((knn27_kernel<G, false, false, U>), grid, block, 0, s, a);
 }
 template <int G>
 static void launch_knn27_g(const KnnArgs& a, hipStream_t s, KernelTimer t) {
@@ -678,7 +685,7 @@ static void launch_knn27_g(const KnnArgs& a, hipStream_t s, KernelTimer t) {
     }
     if (a.cand_total != nullptr) hipLaunchKernelGGL((knn27_kernel<G, true, false>), grid, block, 0, s, a);
     else if (a.use_hint)         hipLaunchKernelGGL((knn27_kernel<G, false, true>), grid, block, 0, s, a);
-    else                         hipLaunchKernelGGL((knn27_kernel<G, false, false>), grid, block, 0, s, a);
+    else                         hipLaunchKernelGGL((knn27_kernel<G, false, false>), grid, block, 0, s, a);   // (never with pack_src: launch_knn27)
 }
 // feats_down_world = pose (x) feats_down_body (laserMapping.cpp:1894-1899) as its own launch, one lane per point: for scans
 // far beyond the 100 k of the node (C5: 1 M queries against a map that does not fit the Infinity Cache) the transform
