@@ -43,6 +43,8 @@ fz = [f for f in ("fuzz_map.log", "fuzz_loop.log", "fuzz_measure.log", "fuzz_sca
 if fz:
     with open(os.path.join(dst, f"{tag}_fuzz.log"), "w") as out:
         for f in fz:
-            lines = [l for l in open(os.path.join(src, f), errors="replace").read().splitlines() if "thread" not in l.lower() and "amdgpu.ids" not in l]
-            out.write(f"== {f}\n" + "\n".join(lines[-3:]) + "\n")
+            # (the reference tree's rebuild thread prints into the same stream, without line ends: take the verdict itself)
+            import re
+            verdicts = re.findall(r"FUZZ[^\r\n]*", open(os.path.join(src, f), errors="replace").read())
+            out.write(f"== {f}: " + (verdicts[-1] if verdicts else "no verdict line") + "\n")
     print("copied", f"{tag}_fuzz.log")
