@@ -321,6 +321,11 @@ def callback_figures(ctx, capi, synth, world, scans, scan_poses, priors, P0_p, u
         ids.append(B.cbb_add_scan(b.ctypes.data_as(C.c_void_p), len(b), 3))
     out["value_callback"] = run("value_callback", ids, x_p, 0, k_steps)
     out["value_callback_patched"] = run("value_callback_patched", ids, x_p, 1, k_steps)
+    # opt-in (lio::KdTreeFacade::set_pack_threads(2) / lio_scan_pack_threads): a second packing thread inside the library for the
+    # assisted pull of the host cloud -- off by default, a library that starts threads should be asked to
+    B.cbb_option(4, 2)
+    out["value_callback_patched_two_pack_threads"] = run("value_callback_patched_two_pack_threads", ids, x_p, 1, k_steps)
+    B.cbb_option(4, 1)
     # the node's real scan size: the same drive, sweeps down-sampled to ~8.6 k points
     n_small = 8600
     small, small_x, small_ids = [], [], []

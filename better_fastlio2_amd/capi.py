@@ -66,7 +66,7 @@ EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_device_count", "lio_stream", "lio_synchronize",
     "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_replicate_unique_id", "lio_replicate_init", "lio_replicate_finalize", "lio_replicate_queue_boxes", "lio_replicate_step", "lio_replicate_defer", "lio_fov_segment", "lio_map_reconstruct",
     "lio_map_set_downsample_param", "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_acquire_removed_points", "lio_map_get_info", "lio_map_nearest_search",
-    "lio_scan_set", "lio_scan_set_device", "lio_scan_set_async", "lio_host_register", "lio_host_unregister", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_measure_want_rows", "lio_eskf_update_iterated_dyn_share_callback", "lio_get_neighbors",
+    "lio_scan_set", "lio_scan_set_device", "lio_scan_set_async", "lio_scan_pack_threads", "lio_host_register", "lio_host_unregister", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_measure_want_rows", "lio_eskf_update_iterated_dyn_share_callback", "lio_get_neighbors",
     "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get", "lio_debug_set", "lio_debug_get", "lio_debug_stamps",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
     "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_eskf_scan_step_device", "lio_eskf_scan_step_pipelined", "lio_state_boxplus",
@@ -144,6 +144,7 @@ def load(build_if_missing: bool = True):
     L.lio_scan_set.argtypes = [_vp, _vp, C.c_int, C.c_int]
     L.lio_scan_set_device.argtypes = [_vp, _vp, C.c_int]
     L.lio_scan_set_async.argtypes = [_vp, _vp, C.c_int, C.c_int]
+    L.lio_scan_pack_threads.argtypes = [_vp, C.c_int]
     L.lio_host_register.argtypes = [_vp, C.c_size_t]
     L.lio_host_unregister.argtypes = [_vp]
     L.lio_scan_upload_async.argtypes = [_vp, _vp, C.c_int]
@@ -448,6 +449,10 @@ class LioContext:
         b = _points(body)
         self._chk(self.L.lio_scan_set_async(self.h, _ptr(b), len(b), _stride(b)), "lio_scan_set_async")
         self._scan_keep = b
+
+    def scan_pack_threads(self, n: int):
+        """lio_scan_pack_threads: 2 = a second packing thread inside the library for the assisted pull, 1 = none (default)."""
+        self._chk(self.L.lio_scan_pack_threads(self.h, int(n)), "lio_scan_pack_threads")
 
     def scan_undistort(self, raw_xyzt, imu_poses=None, end_state14=None):
         """UndistortPcl's point side: raw_xyzt [n, 4] = x, y, z, time offset in ms; imu_poses [K, 22]

@@ -11,7 +11,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lio_hip.h"
@@ -39,6 +43,78 @@ struct HostBox {
         if (!o.any) return;
         add(o.lo[0], o.lo[1], o.lo[2]);
         add(o.hi[0], o.hi[1], o.hi[2]);
+    }
+};
+
+// The optional second packing thread of the assisted pull (lio_scan_pack_threads(ctx, 2); none by default: a library that starts
+// threads should be asked to).  It sleeps on a condition variable; lio_scan_set_async wakes it when a cloud worth the help has been
+// handed over, it then spins (<= 400 us) for the job the scan's first pass posts and packs the SECOND half of the host's share
+// while the calling thread packs the first.  Whoever gets there first claims that half: a helper that wakes up late finds it taken.
+constexpr double PCIE_BYTES_PER_NS = 57.0;               // GPU-initiated reads of page-locked host memory (profiles/r04a_upload_probe.log)
+struct PackJob {
+    const char* src = nullptr; size_t stride = 0; float* dst = nullptr;
+    int lo = 0, hi = 0, chunk = 0; uint32_t stamp = 0; volatile unsigned long long* word = nullptr;
+};
+static void pack_records(const PackJob& j) {
+    const __m128 keep_xyz = _mm_castsi128_ps(_mm_set_epi32(0, -1, -1, -1));
+    for (int done = j.lo; done < j.hi;) {
+        const int end = std::min(j.hi, done + j.chunk);
+        // four records per round, streaming stores (whole 64-byte lines leave through the write-combining buffers: no read for
+        // ownership of the staging buffer, nothing of it displaces the cloud in the caches -- scripts/micro/pack_probe.cpp on the
+        // bench's host: 0.48 -> 0.40 ns per record warm, 1.29 -> 0.94 from DRAM)
+        for (int i = done; i < end; i += 4) {                 // (chunks and ranges are multiples of 64)
+            const __m128 r0 = _mm_loadu_ps(reinterpret_cast<const float*>(j.src + (size_t)i * j.stride));
+            const __m128 r1 = _mm_loadu_ps(reinterpret_cast<const float*>(j.src + (size_t)(i + 1) * j.stride));
+            const __m128 r2 = _mm_loadu_ps(reinterpret_cast<const float*>(j.src + (size_t)(i + 2) * j.stride));
+            const __m128 r3 = _mm_loadu_ps(reinterpret_cast<const float*>(j.src + (size_t)(i + 3) * j.stride));
+            _mm_stream_ps(j.dst + 4 * (size_t)i, _mm_and_ps(r0, keep_xyz)); _mm_stream_ps(j.dst + 4 * (size_t)i + 4, _mm_and_ps(r1, keep_xyz));
+            _mm_stream_ps(j.dst + 4 * (size_t)i + 8, _mm_and_ps(r2, keep_xyz)); _mm_stream_ps(j.dst + 4 * (size_t)i + 12, _mm_and_ps(r3, keep_xyz));
+        }
+        done = end;
+        __builtin_ia32_sfence();                            // the records before the word that announces them
+        *j.word = ((unsigned long long)j.stamp << 32) | (unsigned long long)(uint32_t)done;
+        __builtin_ia32_sfence();                            // (write-combined BAR mapping: nothing lingers)
+    }
+}
+struct PackHelper {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    unsigned wake_seq = 0;                               // (under mu) bumped by lio_scan_set_async
+    bool quit = false;                                   // (under mu)
+    std::atomic<unsigned long long> job_seq{0};          // a job with this number is posted (`job` is complete)
+    std::atomic<unsigned long long> claimed{0};          // number of the last job whose second half somebody took
+    std::atomic<unsigned long long> helper_busy{0};      // number of the job the helper is packing (0: none)
+    PackJob job;
+    bool claim(unsigned long long id) {
+        unsigned long long cur = claimed.load(std::memory_order_relaxed);
+        while (cur < id) if (claimed.compare_exchange_weak(cur, id, std::memory_order_acq_rel)) return true;
+        return false;
+    }
+    void run() {
+        unsigned seen_wake = 0;
+        unsigned long long seen_job = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return quit || wake_seq != seen_wake; });
+                if (quit) return;
+                seen_wake = wake_seq;
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(400)) {
+                const unsigned long long id = job_seq.load(std::memory_order_acquire);
+                if (id != seen_job) {
+                    seen_job = id;
+                    helper_busy.store(id, std::memory_order_release);
+                    const bool mine = claim(id);            // (a job the calling thread finished itself long ago: keep looking for this scan's)
+                    if (mine) pack_records(job);            // (`job` does not change while helper_busy names it: assist_share waits)
+                    helper_busy.store(0, std::memory_order_release);
+                    if (mine) break;
+                }
+                __builtin_ia32_pause();
+            }
+        }
     }
 };
 
@@ -193,7 +269,10 @@ struct lio_ctx {
     int dbg_assist_pull = 1;                   // lio_debug_set("assist_pull"): 0 = off, 1 = share by the running estimate, 2..90 = that share of the scan in per cent
     long long n_assisted_pulls = 0, last_pack_front = 0;
     int dbg_assist_chunk = 0;                  // (0 = by scan size) lio_debug_set("assist_pull_chunk"): records per progress announcement (a multiple of 64)
-    double last_publish_us = 0.0;              // of last_pack_us: spent announcing progress (fences + the word through the BAR)
+    long long n_helper_late = 0;               // scans whose second half the calling thread packed itself (the helper had not come)
+    int assist_threads = 1;                    // lio_scan_pack_threads: 1 = the calling thread alone, 2 = + the helper
+    PackHelper* pack_helper = nullptr;
+    unsigned long long pack_job_id = 0;
     int dbg_assist_stall_us = 0;               // test hook: this thread sleeps that long before it packs (the search falls back to raw records)
     double last_pack_us = 0.0;
     int dbg_fused_pull = 1;                    // lio_debug_set("fused_pull", 0): always the stand-alone pull kernel (A/B switch)
@@ -1004,7 +1083,7 @@ TreeArgs tree_args(lio_ctx* c, int nq, int stride, float4* nbr, uint8_t* cnt, fl
 }
 int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14& pose, int nq, int stride,
             float4* nbr, uint8_t* cnt, float4* ulist, unsigned long long* useeds, bool use_hint, bool walk_now, const GateState* gate = nullptr,
-            bool pull_raw = false, const GateMail* mail = nullptr, unsigned long long expect = 0ull, int pack_front = 0) {
+            bool pull_raw = false, const GateMail* mail = nullptr, unsigned long long expect = 0ull, int pack_front = 0, int pack_mid = 0) {
     hipStream_t s = c->stream;
     // d_counters[0] / d_cand are zero here: zeroed at creation and re-zeroed by whoever consumes them
     // (the residual kernel's last workgroup after a measurement pass, lio_map_nearest_search explicitly)
@@ -1032,7 +1111,7 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
     ka.walk = (lanes == 4 || lanes == 8 || lanes == 16) ? (c->dbg_knn_walk >= 0 ? c->dbg_knn_walk : auto_walk(nq, lanes)) : 0;
     if (pack_front > 0 && ka.body_raw != nullptr) {                   // (assisted pull: the front comes packed from the host, enqueue_pass)
         ka.pack_src = c->d_pack; ka.pack_progress = c->d_pack_progress; ka.pack_stamp = c->pack_stamp; ka.pack_front = pack_front;
-        ka.pack_rot = pack_front / (4 * (64 / lanes));
+        ka.pack_rot = pack_front / (4 * (64 / lanes)); ka.pack_mid = pack_mid;
         ka.pack_wait_out = reinterpret_cast<unsigned long long*>(c->d_small + 48);     // (bytes 192..199 of the host-mapped words)
     }
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
@@ -1236,6 +1315,27 @@ static void dump_host_trace(lio_ctx* c, size_t last) {
                      c->host_trace[i].tag == 'S' ? (c->host_trace[i].polls == 0 ? "  (no poll: the record was there)" : "  (polled)") : "");
     c->host_trace.clear();
 }
+static void pack_helper_stop(lio_ctx* c) {
+    PackHelper* h = c->pack_helper;
+    if (h == nullptr) return;
+    { std::lock_guard<std::mutex> lk(h->mu); h->quit = true; }
+    h->cv.notify_one();
+    if (h->th.joinable()) h->th.join();
+    delete h;
+    c->pack_helper = nullptr;
+}
+int lio_scan_pack_threads(lio_ctx* c, int n) {
+    if (!c || n < 1) return LIO_ERR_INVALID_ARG;
+    if (n == 1) { pack_helper_stop(c); c->assist_threads = 1; return LIO_OK; }
+    if (c->pack_helper == nullptr) {
+        PackHelper* h = new PackHelper();
+        try { h->th = std::thread([h] { h->run(); }); }
+        catch (const std::exception& e) { delete h; return c->fail(LIO_ERR_HIP, "lio_scan_pack_threads", e.what()); }
+        c->pack_helper = h;
+    }
+    c->assist_threads = 2;                                 // (more than one helper: the calling thread's half would have to shrink below what the launches take)
+    return LIO_OK;
+}
 void lio_destroy(lio_ctx* c) {
     if (c && c->trace_host) dump_host_trace(c, 80);
     if (!c) return;
@@ -1271,6 +1371,7 @@ void lio_destroy(lio_ctx* c) {
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->h_small) (void)hipHostFree(c->h_small);
+    pack_helper_stop(c);
     if (c->h_pack) (void)hipHostFree(c->h_pack);
     if (c->h_gate_mail) { if (c->gate_mail_in_vram) (void)hipFree(c->h_gate_mail); else (void)hipHostFree(c->h_gate_mail); }
     if (c->d_gate) (void)hipFree(c->d_gate);
@@ -2291,6 +2392,11 @@ int lio_scan_set_async(lio_ctx* c, const float* body_pts, int n, int stride_byte
             // not yet: the first search pass of the scan pulls its queries itself (KnnArgs.body_raw), the search runs beside the
             // transfer; whatever else wants the scan buffer first makes up for it (enter())
             c->pull_pending = true; c->pull_alias = alias; c->pull_stride = stride_bytes; c->pull_n = n; c->pull_host = reinterpret_cast<const char*>(body_pts);
+            if (c->pack_helper != nullptr && stride_bytes >= 32 && (double)n * stride_bytes / PCIE_BYTES_PER_NS >= 15000.0) {
+                // the second packing thread: awake and looking for its job by the time the scan's first pass posts it
+                { std::lock_guard<std::mutex> lk(c->pack_helper->mu); ++c->pack_helper->wake_seq; }
+                c->pack_helper->cv.notify_one();
+            }
         } else {
             HIPCHK(c, launch_scan_pull(alias, stride_bytes, n, c->d_body, c->stream));
         }
@@ -2636,7 +2742,6 @@ static bool rows_direct(const lio_ctx* c, int nq) {
 // search polls; workgroups of the back -- dispatched first -- pull raw records meanwhile.  Share of the front: where packing
 // (pack_ns_per_record, measured on every scan: the node's cloud may be warm in L3 or not) and the PCIe bytes of both parts take
 // equally long.  Same values by either route: nothing about a result depends on who got to a record first.
-constexpr double PCIE_BYTES_PER_NS = 57.0;               // GPU-initiated reads of page-locked host memory (profiles/r04a_upload_probe.log)
 
 static int assist_share(lio_ctx* c, int nq) {
     if (c->dbg_assist_pull == 0 || !c->gate_mail_in_vram || c->pull_host == nullptr || c->pull_stride < 32) return 0;
@@ -2677,49 +2782,52 @@ static int assist_share(lio_ctx* c, int nq) {
             return 0;
         }
     }
+    if (c->pack_helper != nullptr) {
+        // (a helper still packing the previous cloud -- it was pre-empted for longer than a scan -- writes into the staging buffer:
+        // this scan goes without help)
+        const auto t0 = std::chrono::steady_clock::now();
+        while (c->pack_helper->helper_busy.load(std::memory_order_acquire) != 0) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) return 0;
+            __builtin_ia32_pause();
+        }
+    }
     if (++c->pack_stamp == 0u) ++c->pack_stamp;
     return front;
 }
-static void assist_pack(lio_ctx* c, int front) {
-    const auto t0 = std::chrono::steady_clock::now();
-    const char* src = c->pull_host;
-    const size_t stride = (size_t)c->pull_stride;
-    float* dst = reinterpret_cast<float*>(c->h_pack);
-    const __m128 keep_xyz = _mm_castsi128_ps(_mm_set_epi32(0, -1, -1, -1));
-    volatile unsigned long long* word = c->h_pack_progress;
+static int assist_chunk(const lio_ctx* c) {
     // records per announcement: a twelfth of the scan, 1024 ... 8192 (announcing costs ~0.1 us, but with 2048-record chunks the
     // packing itself ran at 0.75 instead of 0.43 ns per record beside the search's reads of what was just announced --
     // profiles/r04y_assisted_pull.log; finer than that only delays nothing: a workgroup waits for at most one chunk = ~3.5 us)
     int chunk = c->dbg_assist_chunk;
     if (chunk <= 0) { chunk = (c->pull_n / 12 + 63) / 64 * 64; chunk = std::max(1024, std::min(8192, chunk)); }
-    unsigned long long publish_ticks = 0;
-    const unsigned long long tsc0 = __rdtsc();
+    return chunk;
+}
+// before the launches of the pass: where the calling thread's part ends (0 = it packs everything), the helper's job posted
+static int assist_post(lio_ctx* c, int front) {
+    PackHelper* h = c->pack_helper;
+    if (h == nullptr || front < 16384) return 0;
+    // the calling thread still has the launches of the pass in front of it (~6 us): its part is the smaller one
+    const int mid = (int)(0.45 * front) / 64 * 64;
+    h->job.src = c->pull_host; h->job.stride = (size_t)c->pull_stride; h->job.dst = reinterpret_cast<float*>(c->h_pack);
+    h->job.lo = mid; h->job.hi = front; h->job.chunk = assist_chunk(c); h->job.stamp = c->pack_stamp; h->job.word = c->h_pack_progress + 1;
+    h->job_seq.store(++c->pack_job_id, std::memory_order_release);
+    return mid;
+}
+static void assist_pack(lio_ctx* c, int front, int mid) {
+    const auto t0 = std::chrono::steady_clock::now();
     if (c->dbg_assist_stall_us > 0) ::usleep((useconds_t)c->dbg_assist_stall_us);
-    for (int done = 0; done < front;) {
-        const int end = std::min(front, done + chunk);
-        // four records per round, streaming stores (whole 64-byte lines leave through the write-combining buffers: no read for
-        // ownership of the staging buffer, nothing of it displaces the cloud in the caches -- scripts/micro/pack_probe.cpp on the
-        // bench's host: 0.48 -> 0.40 ns per record warm, 1.29 -> 0.94 from DRAM)
-        for (int i = done; i < end; i += 4) {                 // (chunk and `front` are multiples of 64)
-            const __m128 r0 = _mm_loadu_ps(reinterpret_cast<const float*>(src + (size_t)i * stride));
-            const __m128 r1 = _mm_loadu_ps(reinterpret_cast<const float*>(src + (size_t)(i + 1) * stride));
-            const __m128 r2 = _mm_loadu_ps(reinterpret_cast<const float*>(src + (size_t)(i + 2) * stride));
-            const __m128 r3 = _mm_loadu_ps(reinterpret_cast<const float*>(src + (size_t)(i + 3) * stride));
-            _mm_stream_ps(dst + 4 * (size_t)i, _mm_and_ps(r0, keep_xyz)); _mm_stream_ps(dst + 4 * (size_t)i + 4, _mm_and_ps(r1, keep_xyz));
-            _mm_stream_ps(dst + 4 * (size_t)i + 8, _mm_and_ps(r2, keep_xyz)); _mm_stream_ps(dst + 4 * (size_t)i + 12, _mm_and_ps(r3, keep_xyz));
-        }
-        done = end;
-        const unsigned long long tp = __rdtsc();
-        __builtin_ia32_sfence();                            // the records before the word that announces them
-        *word = ((unsigned long long)c->pack_stamp << 32) | (unsigned long long)(uint32_t)done;
-        __builtin_ia32_sfence();                            // (write-combined BAR mapping: nothing lingers)
-        publish_ticks += __rdtsc() - tp;
+    PackJob mine;
+    mine.src = c->pull_host; mine.stride = (size_t)c->pull_stride; mine.dst = reinterpret_cast<float*>(c->h_pack);
+    mine.lo = 0; mine.hi = mid > 0 ? mid : front; mine.chunk = assist_chunk(c); mine.stamp = c->pack_stamp; mine.word = c->h_pack_progress;
+    pack_records(mine);
+    if (mid > 0 && c->pack_helper->claim(c->pack_job_id)) {      // the helper has not come for its half (woke up late, or not at all)
+        mine.lo = mid; mine.hi = front; mine.word = c->h_pack_progress + 1;
+        pack_records(mine);
+        ++c->n_helper_late;
     }
     const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
-    // (one pre-empted scan must not talk the estimate out of helping: a cloud read from DRAM packs at ~1.6 ns per record)
-    c->pack_ns_per_record = 0.7 * c->pack_ns_per_record + 0.3 * std::min(ns / front, 4.0);
+    c->pack_ns_per_record = 0.7 * c->pack_ns_per_record + 0.3 * std::min(ns / std::max(1, mine.hi - mine.lo), 4.0);
     c->last_pack_us = ns * 1e-3; c->last_pack_front = front;
-    { const unsigned long long all = __rdtsc() - tsc0; c->last_publish_us = all ? c->last_pack_us * (double)publish_ticks / (double)all : 0.0; }
     ++c->n_assisted_pulls;
 }
 
@@ -2734,10 +2842,11 @@ static int enqueue_pass(lio_ctx* c, const Pose14& pose, bool do_search, bool ext
     const bool pull_here = c->pull_pending && do_search && gate == nullptr && nq == c->pull_n && nq <= FUSED_TRANSFORM_MAX_QUERIES;
     if (c->pull_pending && !pull_here) flush_pull(c);
     const int pack_front = pull_here ? assist_share(c, nq) : 0;
+    const int pack_mid = pack_front > 0 ? assist_post(c, pack_front) : 0;
     if (pack_front > 0) c->assist_t0_ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now().time_since_epoch()).count();   // (passes armed behind this one come through here too)
     if (do_search) {
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
-        const int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk, gate, pull_here, mail, expect, pack_front);
+        const int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk, gate, pull_here, mail, expect, pack_front, pack_mid);
         if (rc != LIO_OK) return rc;
         if (pull_here) c->pull_pending = false;
     }
@@ -2773,7 +2882,7 @@ static int enqueue_pass(lio_ctx* c, const Pose14& pose, bool do_search, bool ext
         ra.lunits = c->d_lunits;
     }
     const hipError_t le = launch_residual(ra, do_search, ext, s, prof_timer(c, LIO_PROF_RESIDUAL));
-    if (pack_front > 0) assist_pack(c, pack_front);             // (whatever the launch said: the search is waiting for these records)
+    if (pack_front > 0) assist_pack(c, pack_front, pack_mid);   // (whatever the launch said: the search is waiting for these records)
     if (le != hipSuccess) return c->fail(LIO_ERR_HIP, "launch_residual", hipGetErrorString(le));
     return LIO_OK;
 }
@@ -3249,6 +3358,7 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
         if (value < 0 || value % 64 != 0 || value > 65536) return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "assist_pull_chunk: 0 (by scan size) or a multiple of 64 up to 65536");
         c->dbg_assist_chunk = (int)value; return LIO_OK;
     }
+    if (std::strcmp(key, "assist_pull_threads") == 0) return lio_scan_pack_threads(c, (int)value);
     if (std::strcmp(key, "assist_pull_stall_us") == 0) { c->dbg_assist_stall_us = (int)value; return LIO_OK; }
     if (std::strcmp(key, "fused_pull") == 0) { c->dbg_fused_pull = value != 0; return LIO_OK; }
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
@@ -3286,7 +3396,7 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "assisted_pulls") == 0) { *value = c->n_assisted_pulls; return LIO_OK; }
     if (std::strcmp(key, "assist_share_permille") == 0) { *value = (long long)(c->assist_frac * 1000.0 + 0.5); return LIO_OK; }
     if (std::strcmp(key, "last_pack_front") == 0) { *value = c->last_pack_front; return LIO_OK; }
-    if (std::strcmp(key, "last_publish_ns") == 0) { *value = (long long)(c->last_publish_us * 1e3); return LIO_OK; }
+    if (std::strcmp(key, "pack_helper_late") == 0) { *value = c->n_helper_late; return LIO_OK; }
     if (std::strcmp(key, "last_pack_ns") == 0) { *value = (long long)(c->last_pack_us * 1e3); return LIO_OK; }
     if (std::strcmp(key, "scan_pulled") == 0) { *value = c->n_scan_pulled; return LIO_OK; }
     if (std::strcmp(key, "rows_direct_dma") == 0) { *value = c->n_rows_direct_dma; return LIO_OK; }

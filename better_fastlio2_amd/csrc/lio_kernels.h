@@ -35,6 +35,8 @@ struct KnnArgs {
     const unsigned long long* pack_progress;
     uint32_t         pack_stamp;
     int              pack_front;    // a multiple of 64 records (whole workgroups whatever the lanes per query)
+    int              pack_mid;      // > 0: a second host thread packs [pack_mid, pack_front) and announces it in pack_progress[1]
+                                    // (the absolute record number it has reached); [0, pack_mid) belongs to pack_progress[0]
     int              pack_rot;      // workgroup b takes query block (b + pack_rot) mod blocks: the raw part is dispatched first
     unsigned long long* pack_wait_out;   // host-mapped: stamp << 32 | ticks (100 MHz) the LAST workgroup of the front waited for the host's
                                     // word, 0xffffffff = it gave up and read raw records (the host then takes a smaller share, assist_share)

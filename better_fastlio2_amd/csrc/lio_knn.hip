@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
                 const uint32_t need = (uint32_t)min((qb + 1) * (WPB * GPW), a.pack_front);
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
-                    const unsigned long long w = __hip_atomic_load(a.pack_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // (workgroups of [pack_mid, pack_front) listen to the second packing thread's word, lio_ctx.hip)
+                    const unsigned long long w = __hip_atomic_load(a.pack_progress + (a.pack_mid > 0 && qb * (WPB * GPW) >= a.pack_mid ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if ((uint32_t)(w >> 32) == a.pack_stamp && (uint32_t)w >= need) { packed_by_host = true; break; }
                     if (wall_clock64() - t0 > 30000ull) break;           // 100 MHz: 300 us -- a host that was pre-empted
                     __builtin_amdgcn_s_sleep(8);

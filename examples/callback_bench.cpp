@@ -8,8 +8,9 @@
 //   patched != 0: the "two-line patch" of INTEGRATION.md section 3 -- the callback hands over lio_measure's reduced form
 //                 (HTH / HTh) instead of rows; everything else (host-resident scan, synchronous callback) stays.
 // What the adaptor does on its own in both forms: lio::scan_changed(ikdtree, G) starts the upload of the 48-byte records the
-// moment the node has them (a kernel pulls x, y, z out of the page-locked cloud), and lio_measure puts the passes it expects
-// next onto the stream ahead of their pose (the previous scan's converge pattern), so a callback mostly just mails a pose.
+// moment the node has them (the first search pulls x, y, z out of the page-locked cloud, the calling thread packs the front of a
+// large cloud beside it), and lio_measure puts the passes it expects next onto the stream ahead of their pose (the previous scan's
+// converge pattern), so a callback mostly just mails a pose.
 #include "use-ikfom.hpp"            // stand-ins: state_ikfom, esekfom::dyn_share_datastruct
 #include <ikd-Tree/ikd_Tree.h>     // stand-ins: PointType, PointVector, StubCloud
 #include <memory>
@@ -125,12 +126,14 @@ int cbb_last_m(void) { return effct_feat_num; }
 // non-throwing mode a failure costs the pass (ekfom_data.valid = false), not the node
 int cbb_last_status(void) { return ikdtree.last_status; }
 // knobs: 0 = page-locking of the node's buffers off (staging copies), 1 = exceptions instead of valid = false,
-// 2 = the one-argument scan_changed (upload inside the first callback), 3 = size in bytes from which h_x / h are page-locked
+// 2 = the one-argument scan_changed (upload inside the first callback), 3 = size in bytes from which h_x / h are page-locked,
+// 4 = packing threads of the assisted pull (1 = the calling thread alone)
 void cbb_option(int which, int value) {
     if (which == 0) ikdtree.pin_host_buffers = value != 0;
     if (which == 1) ikdtree.throw_on_error = value != 0;
     if (which == 2) legacy_scan_changed = value != 0;
     if (which == 3) ikdtree.pin_rows_min_bytes = (size_t)value;
+    if (which == 4) (void)ikdtree.set_pack_threads(value);
 }
 // seconds spent inside the measurement-model callback since the last call (the rest of a step is the filter's own dense algebra)
 double cbb_take_model_seconds(void) { const double t = seconds_in_model; seconds_in_model = 0.0; return t; }

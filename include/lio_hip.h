@@ -214,6 +214,11 @@ int  lio_scan_set_device(lio_ctx* ctx, const void* d_body_f4, int n);
  * packed in time; the share is steered by the measured time of the scans' first passes; lio_debug_set "assist_pull" = 0 switches
  * it off).  Results do not depend on who got to a record first.                                                                  */
 int  lio_scan_set_async(lio_ctx* ctx, const float* body_pts, int n, int stride_bytes);
+/* The assisted pull with a SECOND packing thread inside the library (n = 2; n = 1, the default: the calling thread alone, no thread
+ * is ever started): it sleeps until lio_scan_set_async hands over a cloud worth the help, then packs the second half of the host's
+ * share while the calling thread packs the first.  For nodes that push un-down-sampled sweeps (~100 k points) through the callback:
+ * 166 -> ~150 us per scan at C2; nothing below ~50 k points.  Joined by lio_destroy / n = 1.                */
+int  lio_scan_pack_threads(lio_ctx* ctx, int n);
 /* hipHostRegister / hipHostUnregister for callers that do not link the HIP runtime themselves (the adaptor header): page-locks
  * [p, p + bytes) and maps it for the GPU, so that lio_scan_set_async can pull a cloud and lio_measure_rows can have the copy
  * engine write h_x / h in place.  The range must stay allocated while it is registered.                                        */

@@ -147,6 +147,10 @@ public:
     // page-lock the node's host buffers (the cloud the scan is pulled from, h_x / h the rows are copied into) with
     // lio_host_register; false: every transfer goes through the library's own staging buffers
     bool pin_host_buffers = true;
+    // Nodes that push un-down-sampled sweeps (~100 k points) through the callback: a second packing thread inside the library for
+    // the assisted pull of the cloud (lio_scan_pack_threads; the reference's own h_share_model keeps MP_PROC_NUM OpenMP threads
+    // busy at this point, laserMapping.cpp:1888).  1 = none (default).
+    bool set_pack_threads(int n) { return report(lio_scan_pack_threads(ctx(), n), "lio_scan_pack_threads"); }
     size_t pin_rows_min_bytes = (size_t)2 << 20;   // row blocks (m x 13 doubles) from this size on are copied straight into page-locked h_x / h
     HostPin pins;
     long n_stale_pins = 0;        // row blocks that did not arrive through a registration and were fetched again (see h_share_model)

@@ -40,6 +40,7 @@ def step():
     assert rc == 0, ctx.L.lio_last_error(ctx.h)
 
 chunk = int(os.environ.get("CHUNK", "0"))
+ctx.scan_pack_threads(int(os.environ.get("THREADS", "1")))
 ctx.debug_set("assist_pull_chunk", chunk)
 ref = None
 res = {v: [] for v in shares}
@@ -56,7 +57,7 @@ for r in range(reps):
         for _ in range(steps):
             step()
         ctx.synchronize(); dt = time.perf_counter() - t0
-        res[v].append((dt / steps * 1e6, ctx.debug_get("last_pack_front"), ctx.debug_get("last_pack_ns") / 1e3, ctx.debug_get("last_publish_ns") / 1e3, ctx.debug_get("assist_share_permille") / 10.0))
+        res[v].append((dt / steps * 1e6, ctx.debug_get("last_pack_front"), ctx.debug_get("last_pack_ns") / 1e3, ctx.debug_get("pack_helper_late"), ctx.debug_get("assist_share_permille") / 10.0))
 for v in shares:
-    print("%s rotate %d chunk %d assist_pull %2d: step us %s | scans/s (best) %.0f | last front %d records packed in %.1f us (of which %.1f us announcing); steered share %.0f %%" % (
-        cfg, n_rot, chunk, v, " ".join("%.1f" % m[0] for m in res[v]), 1e6 / min(m[0] for m in res[v]), res[v][-1][1], res[v][-1][2], res[v][-1][3], res[v][-1][4]), flush=True)
+    print("%s rotate %d chunk %d threads %s assist_pull %2d: step us %s | scans/s (best) %.0f | last front %d records packed in %.1f us (helper late on %d scans so far); steered share %.0f %%" % (
+        cfg, n_rot, chunk, os.environ.get('THREADS', '1'), v, " ".join("%.1f" % m[0] for m in res[v]), 1e6 / min(m[0] for m in res[v]), res[v][-1][1], res[v][-1][2], res[v][-1][3], res[v][-1][4]), flush=True)

@@ -182,7 +182,7 @@ def test_scan_set_async_equals_scan_set(gpu_capi, small_case, stride_floats):
 @pytest.mark.parametrize("stride_floats", [8, 12])
 def test_assisted_pull_equals_scan_set(gpu_capi, synth, small_case, stride_floats):
     """The first search of a scan handed over as page-locked host records, with the host packing the FRONT of the cloud beside
-    it (assisted pull, lio_ctx.hip): workgroups of the back pull raw records, workgroups of the front wait for the host's
+    it (assisted pull, lio_ctx.hip; alone or with the library's optional second packing thread): workgroups of the back pull raw records, workgroups of the front wait for the host's
     progress word and read 16-byte records -- or give up on a stalled host and read raw.  Every share (off, by the running
     estimate, 25 / 50 / 90 per cent) and a host that sleeps 2 ms before it packs leave exactly the scan, the neighbours and the
     sums of lio_scan_set."""
@@ -203,8 +203,9 @@ def test_assisted_pull_equals_scan_set(gpu_capi, synth, small_case, stride_float
     L = ctx.L
     buf = rec.copy()
     assert L.lio_host_register(buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
-    for lanes in (0, 16):
+    for lanes, threads in ((0, 1), (16, 1), (0, 2), (0, 1)):
         ctx.debug_set("lanes_per_query", lanes)
+        ctx.scan_pack_threads(threads)                  # 2: a second packing thread inside the library takes the second half of the front
         for share, stall in ((0, 0), (1, 0), (25, 0), (50, 0), (90, 0), (50, 2000), (1, 0)):
             ctx.debug_set("assist_pull", share); ctx.debug_set("assist_pull_stall_us", stall)
             before = ctx.debug_get("assisted_pulls")
