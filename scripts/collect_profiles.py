@@ -39,7 +39,7 @@ for sub, name, out, cmd in (("prof", "kernel_stats_all.csv", f"{tag}_bench_c2_ke
         print("copied", out)
 
 # the fuzzers' verdict lines
-fz = [f for f in ("fuzz_map.log", "fuzz_loop.log", "fuzz_measure.log", "fuzz_scanprep.log", "fuzz_pipeline.log") if os.path.exists(os.path.join(src, f))]
+fz = [f for f in ("fuzz_map.log", "fuzz_loop.log", "fuzz_measure.log", "fuzz_scanprep.log", "fuzz_pipeline.log", "fuzz_assist.log") if os.path.exists(os.path.join(src, f))]
 if fz:
     with open(os.path.join(dst, f"{tag}_fuzz.log"), "w") as out:
         for f in fz:

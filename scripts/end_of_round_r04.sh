@@ -29,6 +29,7 @@ timeout 200 python tests/fuzz/fuzz_loop.py 80 9000 > $O/fuzz_loop.log 2>&1; echo
 timeout 200 python tests/fuzz/fuzz_measure.py 150 12000 > $O/fuzz_measure.log 2>&1; echo "fuzz_measure rc=$?"
 timeout 200 python tests/fuzz/fuzz_scanprep.py 200 40000 > $O/fuzz_scanprep.log 2>&1; echo "fuzz_scanprep rc=$?"
 timeout 200 python tests/fuzz/fuzz_pipeline.py 100 64000 > $O/fuzz_pipeline.log 2>&1; echo "fuzz_pipeline rc=$?"
+timeout 200 python tests/fuzz/fuzz_assist.py 400 74000 > $O/fuzz_assist.log 2>&1; echo "fuzz_assist rc=$?"
 stamp fuzz
 bash scripts/r04_step_timeline.sh $tag > $O/step_timeline.out 2>&1; tail -3 $O/step_timeline.txt
 LIO_TRACE_HOST=1 timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extras 2>&1 >/dev/null | grep -a "host trace" | head -90 | tail -48 > $O/host_trace.log

@@ -226,6 +226,18 @@ def test_assisted_pull_equals_scan_set(gpu_capi, synth, small_case, stride_float
     ctx.close()
 
 
+def test_assisted_pull_fuzz_seed():
+    """150 scans of tests/fuzz/fuzz_assist.py: clouds of random sizes and strides, share steered / fixed / off, one or two packing
+    threads switched at random, a host that stalls -- every scan's first pass equal to lio_scan_set's on a twin context, to the bit."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz", "fuzz_assist.py")
+    spec = importlib.util.spec_from_file_location("fuzz_assist", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    fz.main(150, 71500)
+
+
 def test_kitti_bin_step_script():
     """scripts/kitti_bin_step.py on a sweep in KITTI's .bin format (a synthetic one: no data set ships here): read, no-pose
     lio_scan_undistort, lio_scan_voxel_filter(0.5), the scan step; neighbours against the reference tree."""
