@@ -290,6 +290,10 @@ def callback_figures(ctx, capi, synth, world, scans, scan_poses, priors, P0_p, u
     out = {}
     kf = capi.Esekf(max_iter)
     n_rot = len(scans)
+    # a node page-locks its ONE cloud once, when it starts; this drive has n_rot of them: every cloud has been handed over twice
+    # before the clock starts (and the share of the assisted pull has had ~2 n_rot scans to settle), whatever --warmup says
+    w_steps = max(w_steps, 2 * n_rot)
+    k_steps = max(k_steps, 40)
 
     def run(name, scan_ids, x_ptrs, patched, k_steps):
         def f():
