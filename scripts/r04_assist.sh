@@ -1,3 +1,4 @@
+# round 4: assisted pull -- the callback tests, then the in-process A/B on the callback chain (8 clouds in turn / one cloud; one and two packing threads)
 tag=${1:-r04yb}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R; export LIO_SYNTH_CACHE=/tmp/lio_synth
