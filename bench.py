@@ -225,18 +225,37 @@ def cpu_baseline(world_pts, scan, x0, P0, max_iter: int, ext: bool, sample_every
     if use_ref:
         rx6, rd6, rc6, secs6 = tree.knn(wq, 6)
         _, _, _, secs = tree.knn(wq)
-        if sample_every == 1 and gpu_side.get("nbr_xyz") is not None:
-            gx, gd, gc = gpu_side["nbr_xyz"], gpu_side["nbr_d"], gpu_side["nbr_cnt"]
+        if gpu_side.get("nbr_xyz") is not None:
+            # sample_every > 1 (C5): the GPU neighbours of exactly the sampled rows against the reference tree's -- the queries
+            # are the same fp32 world points (the transform is bit-equal to the oracle's, checked below), the map the same 50 M points
+            sl = slice(None, None, sample_every)
+            gx, gd, gc = (np.ascontiguousarray(gpu_side[k][sl]) for k in ("nbr_xyz", "nbr_d", "nbr_cnt"))
+            gw = np.ascontiguousarray(gpu_side["world"][sl])
             rd, rx = np.ascontiguousarray(rd6[:, :5]), np.ascontiguousarray(rx6[:, :5])
             tie_free = (np.diff(rd6, axis=1) > 0).all(1)
             parity_nbr = {
                 "queries": int(len(wq)),
+                "world_point_mismatches": int((gw.view(np.uint32) != wq.view(np.uint32)).any(axis=1).sum()),
                 "count_mismatches": int((gc != np.minimum(rc6, 5)).sum()),
                 "sqdist_mismatches": int((gd.view(np.uint32) != rd.view(np.uint32)).any(axis=1).sum()),
                 "point_mismatches": int((gx[tie_free].view(np.uint32) != rx[tie_free].view(np.uint32)).any(axis=(1, 2)).sum()),
                 "rows_with_a_tie_in_ranks_1_6": int((~tie_free).sum()),
                 "rank56_ties": int((rd6[:, 4] == rd6[:, 5]).sum()),
-                "against": "reference ikd-Tree (oracle/_ref), Nearest_Search k=6, all queries, bitwise"}
+                "against": "reference ikd-Tree (oracle/_ref), Nearest_Search k=6, " +
+                           ("all queries" if sample_every == 1 else f"every {sample_every}th query of the scan") + ", bitwise"}
+            # the bounded (HINT) re-search of the same rows at the moved pose, when the GPU side carries it
+            if gpu_side.get("hint_world") is not None:
+                hw = np.ascontiguousarray(gpu_side["hint_world"][sl])
+                hx, hd, hc = (np.ascontiguousarray(gpu_side[k][sl]) for k in ("hint_xyz", "hint_d", "hint_cnt"))
+                qx6, qd6, qc6, _ = tree.knn(hw, 6)
+                tf2 = (np.diff(qd6, axis=1) > 0).all(1)
+                parity_nbr["bounded_re_search"] = {
+                    "queries": int(len(hw)),
+                    "count_mismatches": int((hc != np.minimum(qc6, 5)).sum()),
+                    "sqdist_mismatches": int((hd.view(np.uint32) != np.ascontiguousarray(qd6[:, :5]).view(np.uint32)).any(axis=1).sum()),
+                    "point_mismatches": int((hx[tf2].view(np.uint32) != np.ascontiguousarray(qx6[:, :5])[tf2].view(np.uint32)).any(axis=(1, 2)).sum()),
+                    "rows_with_a_tie_in_ranks_1_6": int((~tf2).sum())}
+        if sample_every == 1 and gpu_side.get("nbr_xyz") is not None:
             mp, ms = po.decision_margins(gx, gd, gc, gpu_side["world"], scan.body)
             parity_nbr["decision_flip_audit"] = {
                 "plane_inlier_0.1m_margin_lt_1e-5": int((mp < 1e-5).sum()), "s_gt_0.9_margin_lt_1e-5": int((ms < 1e-5).sum()),
@@ -490,6 +509,128 @@ def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, 
     return out
 
 
+def other_config_block(cfg: str, capi, synth, device, k_steps: int, with_parity: bool):
+    """A second BASELINE config inside the default line (the driver runs only `python bench.py`): its own context, its own
+    world, the same pipelined drive / entry point as `value`, the dominant kernel event-stamped the same way, and the two parity
+    gates (every neighbour of scan 0 against the reference tree; the posterior against the CPU path) -- compact keys only."""
+    import ctypes as C
+    nm, nq, voxel, kind, max_iter = CONFIGS[cfg]
+    world = synth.make_world(nm, voxel)
+    ctx = capi.LioContext(voxel, max_scan_points=nq, max_map_points=nm + 100_000, device=device.index)
+    ctx.map_build(world.points)
+    L = ctx.L
+    P0 = synth.init_cov()
+    P0_c = np.ascontiguousarray(P0, np.float64)
+    P0_p = P0_c.ctypes.data_as(C.c_void_p)
+    n_rot = 8
+    px, py, yaw = 3.1, -2.2, 0.52
+    scans, priors, h_scans = [], [], []
+    for k in range(n_rot):
+        sc = synth.make_scan(world, nq, kind=kind, seed=synth.SEED + 1 + 17 * k, pos=(px + 0.9 * k, py + 0.4 * k, 0.0), rpy=(0.004, -0.006, yaw + 0.05 * k))
+        ps, rt = synth.perturb_state(sc, seed=synth.SEED + 2 + 7 * k)
+        scans.append(sc)
+        priors.append(np.ascontiguousarray(capi.make_state26(ps, rt, sc.off_R, sc.off_T), np.float64))
+        h_scans.append(capi.pinned_points(sc.body))
+    ext = scans[0].extrinsic_est_en
+    x_p = [x.ctypes.data_as(C.c_void_p) for x in priors]
+    h_p = [C.c_void_p(h.ctypes.data) for h in h_scans]
+    kf = capi.Esekf(max_iter)
+    ulog = capi.lio_update_log()
+    tick = [0]
+
+    def step():
+        k = tick[0] % n_rot
+        tick[0] += 1
+        rc = L.lio_eskf_scan_step_pipelined(kf.h, ctx.h, x_p[k], P0_p, h_p[(k + 1) % n_rot], nq, 0.001, int(ext), C.byref(ulog))
+        if rc != 0:
+            raise capi.LioError(f"{cfg}: pipelined scan step failed ({rc}): " + L.lio_last_error(ctx.h).decode())
+
+    # untimed: candidate census (byte model), GPU side of the parity gates
+    ctx.census_enable(True)
+    cand = []
+    gpu_side = {}
+    for k in range(n_rot):
+        ctx.scan_set(scans[k].body)
+        cand.append(int(ctx.measure(priors[k][:14], True, ext)["n_candidates"]))
+        if k == 0:
+            wpts, _, _ = ctx.scan_state()
+            nx, nd, nc = ctx.neighbors()
+            gpu_side = {"world": wpts, "nbr_xyz": nx, "nbr_d": nd, "nbr_cnt": nc}
+    ctx.census_enable(False)
+    ctx.scan_set(scans[0].body)
+    kf.change_x(priors[0]); kf.change_P(P0)
+    kf.update_iterated_dyn_share_modified(ctx, 0.001, ext)
+    x_gpu = kf.get_x().copy()
+    # timed: the contract loop of this config
+    rc = L.lio_scan_upload_async(ctx.h, h_p[0], nq)
+    if rc != 0:
+        raise capi.LioError(f"{cfg}: first upload failed")
+    lat = []
+    t = timed_steps(step, k_steps, 16, None, device, lat, quiesce=lambda: L.lio_synchronize(ctx.h))
+    # untimed, right behind it: the first searches of the same drive, event-stamped (two steps in three)
+    ctx.profile_reset()
+    for i in range(96):
+        on = i % 3 in (0, 1)
+        ctx.profile_enable(only=[capi.PROF_KNN, capi.PROF_KNN_HINT]) if on else ctx.profile_enable(False)
+        step()
+    L.lio_scan_swap(ctx.h)
+    L.lio_synchronize(ctx.h)
+    prof = ctx.profile()
+    ctx.profile_enable(False)
+    knn_ms = prof["knn27"]["total_ms"] / max(prof["knn27"]["launches"], 1)
+    bytes_knn = knn_algorithmic_bytes(nq, float(np.mean(cand)))
+    out = {"workload": f"{cfg}: {kind} scan N_q={nq} vs map N_m={nm} (voxel {voxel} m), k=5, NUM_MAX_ITERATIONS={max_iter}, extrinsic_est_en={ext}",
+           "value": k_steps / t, "unit": "scans/s", "ms_per_step": t / k_steps * 1e3, "steps": k_steps, "latency": latency_summary(lat),
+           "knn_us_per_point": knn_ms * 1e3 / nq,
+           "roofline": {"kernel": "knn27_kernel", "avg_launch_us": knn_ms * 1e3, "algorithmic_bytes_per_launch": bytes_knn, "C_mean": float(np.mean(cand)) / nq,
+                        "achieved": bytes_knn / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bytes_knn / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if knn_ms > 0 else 0.0,
+                        "launches_stamped": int(prof["knn27"]["launches"])}}
+    ctx.close()
+    if with_parity:
+        from oracle import pyoracle as po
+        if po.ref_available():
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)                                      # (the reference tree printf()s from its re-balancing thread)
+            try:
+                tree = po.RefIkdTree(voxel)
+                tree.build(world.points)
+                wq = po.body_to_world(priors[0][:14], scans[0].body)
+                rx6, rd6, rc6, _ = tree.knn(wq, 6)
+                tie_free = (np.diff(rd6, axis=1) > 0).all(1)
+                gx, gd, gc = gpu_side["nbr_xyz"], gpu_side["nbr_d"], gpu_side["nbr_cnt"]
+                rd, rx = np.ascontiguousarray(rd6[:, :5]), np.ascontiguousarray(rx6[:, :5])
+                out["neighbors_bit_exact"] = {
+                    "queries": int(len(wq)),
+                    "world_point_mismatches": int((gpu_side["world"].view(np.uint32) != wq.view(np.uint32)).any(axis=1).sum()),
+                    "count_mismatches": int((gc != np.minimum(rc6, 5)).sum()),
+                    "sqdist_mismatches": int((gd.view(np.uint32) != rd.view(np.uint32)).any(axis=1).sum()),
+                    "point_mismatches": int((gx[tie_free].view(np.uint32) != rx[tie_free].view(np.uint32)).any(axis=(1, 2)).sum()),
+                    "rows_with_a_tie_in_ranks_1_6": int((~tie_free).sum()),
+                    "against": "reference ikd-Tree (oracle/_ref), Nearest_Search k=6, all queries, bitwise"}
+                po.use_reference_knn(tree)
+                try:
+                    om = po.OracleMap(voxel)
+                    xo, _, _, olog = po.update_iterated(om, priors[0], P0, scans[0].body, 0.001, max_iter, None, ext, knn_method=2)
+                finally:
+                    po.use_reference_knn(None)
+                q1, q2 = x_gpu[3:7], xo[3:7]
+                out["posterior"] = {"pos_diff_m": float(np.linalg.norm(x_gpu[:3] - xo[:3])),
+                                    "rot_diff_rad": float(4.0 * np.arcsin(min(1.0, 0.5 * min(np.linalg.norm(q1 - q2), np.linalg.norm(q1 + q2))))),
+                                    "state_max_abs_diff": float(np.max(np.abs(x_gpu - xo))), "passes": int(len(olog)),
+                                    "against": "oracle h_share_model + IKFoM update on the reference ikd-Tree, same prior, same scan"}
+                del tree
+                import gc
+                gc.collect()
+            finally:
+                sys.stdout.flush()
+                C.CDLL(None).fflush(None)
+                os.dup2(saved, 1)
+                os.close(saved)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -501,6 +642,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the contract loop (no resident / replay / node-loop figures)")
     ap.add_argument("--map-update", action="store_true", help="(kept for compatibility: the node loop is always reported)")
+    ap.add_argument("--long-steps", type=int, default=5000, help="steps of value_long_window (the contract loop over a window a clock transient cannot flatter; 0 = off)")
+    ap.add_argument("--other-configs", default="c3", help="comma-separated configs reported as compact blocks inside the default (c2) line; '' = none")
     ap.add_argument("--emulate-world", type=int, default=8,
                     help="N = 1 only: also time this rank's node loop with the insert lists of W replicas applied (loop-back exchange; 0 = off)")
     a = ap.parse_args()
@@ -620,6 +763,27 @@ def main():
             gpu_side = {"world": wpts, "nbr_xyz": nx, "nbr_d": nd, "nbr_cnt": nc}
     ctx.census_enable(False)
     cand_mean_per_scan = float(np.mean(cand))
+    sample_every = 1 if nq <= 200_000 else 8                  # (the CPU leg's sample: the whole scan when a CPU scan step stays around a second)
+    x_gpu_sample = None
+    if rank == 0 and not a.no_cpu_baseline and world_size == 1:
+        # GPU side of the second parity gate: the bounded (HINT) re-search of scan 0 at the pose the first update moves to
+        ctx.scan_set_device(d_scans[0].data_ptr(), nq)
+        kf0 = capi.Esekf(0)                                    # maximum_iter = 0: one pass, one update
+        kf0.change_x(x0); kf0.change_P(P0)
+        kf0.update_iterated_dyn_share_modified(ctx, 0.001, ext)
+        st2 = kf0.get_x()[:14].copy()
+        ctx.measure(st2, True, ext)                            # bounded by the neighbours of the search above
+        hw, _, _ = ctx.scan_state()
+        hx, hd, hc = ctx.neighbors()
+        gpu_side.update({"hint_world": hw, "hint_xyz": hx, "hint_d": hd, "hint_cnt": hc})
+        if sample_every > 1:
+            # the CPU leg runs the scan step on every `sample_every`-th point: the GPU's step on exactly that sub-scan, same prior
+            body_s = np.ascontiguousarray(scan.body[::sample_every])
+            ctx.scan_set(body_s)
+            kfs = capi.Esekf(max_iter)
+            kfs.change_x(x0); kfs.change_P(P0)
+            kfs.update_iterated_dyn_share_modified(ctx, 0.001, ext)
+            x_gpu_sample = kfs.get_x().copy()
     step_replay()
     log = {k: getattr(ulog, k) for k, _ in capi.lio_update_log._fields_}
     x_gpu = kf.get_x().copy()                                  # posterior of scan 0's step (parity gate below)
@@ -674,6 +838,22 @@ def main():
     L.lio_synchronize(ctx.h)                                   # (... and call off the first search the last step armed for it)
     prof = ctx.profile()
     ctx.profile_enable(False)
+    # the headline again over a LONG window (the driver's --steps 20 is 2.2 ms of wall clock): the same loop, the same entry point,
+    # per-step wall times; p50 / p99 / p99.9 / max say whether `value` is what a node would see over half a second
+    long_window = None
+    if a.long_steps > 0 and not a.no_extras:
+        tick[0] = 0
+        rc = L.lio_scan_upload_async(ctx.h, h_p[0], nq)
+        if rc != 0:
+            fail("upload before the long window", rc)
+        lat_long_value = []
+        n_lw = a.long_steps if nq <= 262144 else max(200, a.long_steps // 10)
+        t_lw = timed_steps(step_pipelined, n_lw, n_rot, dist, device, lat_long_value, quiesce=lambda: L.lio_synchronize(ctx.h))
+        L.lio_scan_swap(ctx.h)
+        L.lio_synchronize(ctx.h)
+        long_window = latency_summary(lat_long_value)
+        long_window.update({"value": world_size * n_lw / t_lw, "unit_value": "scans/s", "ms_per_step": t_lw / n_lw * 1e3,
+                            "how": "the contract loop (`value`'s step function) over a window of this many steps, per-step wall times"})
     knn_ms = prof["knn27"]["total_ms"] / max(prof["knn27"]["launches"], 1)
     hint_ms = prof["knn27_hint"]["total_ms"] / max(prof["knn27_hint"]["launches"], 1) if prof["knn27_hint"]["launches"] else None
     knn_launches_sampled = int(prof["knn27"]["launches"])
@@ -901,7 +1081,17 @@ def main():
                                  "launches of the timed drive repeated untimed right behind the timed region (no instrumentation inside `value`)"},
         "roofline_detail": detail,
     }
+    if long_window is not None:
+        out["value_long_window"] = long_window
     out.update(extras)
+    if world_size == 1 and not a.no_extras and a.config == "c2" and a.other_configs:
+        L.lio_synchronize(ctx.h)                                # (nothing of the headline context may sit armed on the GPU beside the other config)
+        out["other_configs"] = {}
+        for oc in [c for c in a.other_configs.split(",") if c in CONFIGS and c != a.config]:
+            try:
+                out["other_configs"][oc] = other_config_block(oc, capi, synth, device, max(200, min(a.steps * 10, 1000)), not a.no_cpu_baseline)
+            except Exception as e:                             # noqa: BLE001  (a second config must never cost the headline line)
+                out["other_configs"][oc] = {"skipped": repr(e)}
     if world_size == 1 and not a.no_cpu_baseline:
         # the reference's ikd-Tree printf()s from its re-balancing thread: keep stdout to the ONE JSON line
         sys.stdout.flush()
@@ -909,7 +1099,7 @@ def main():
         os.dup2(2, 1)
         try:
             # the whole scan when a CPU scan step stays around a second (C2: 0.4 s), a sample of it otherwise
-            cb = cpu_baseline(world.points, scan, x0, P0, max_iter, ext, 1 if nq <= 200_000 else 8, gpu_side)
+            cb = cpu_baseline(world.points, scan, x0, P0, max_iter, ext, sample_every, gpu_side)
             import gc
             gc.collect()                                       # ~RefIkdTree joins the thread (prints again)
         finally:
@@ -924,12 +1114,15 @@ def main():
         nbr = cb.pop("neighbors")
         sens = cb.pop("eigen_order_sensitivity")
         referee_out = cb.pop("exact_referee")
-        if cb["sample"].startswith("the whole scan"):
-            q1, q2 = x_gpu[3:7], x_cpu[3:7]
-            out["parity"] = {"pos_diff_m": float(np.linalg.norm(x_gpu[:3] - x_cpu[:3])),
+        whole = cb["sample"].startswith("the whole scan")
+        x_cmp = x_gpu if whole else x_gpu_sample
+        if x_cmp is not None:
+            q1, q2 = x_cmp[3:7], x_cpu[3:7]
+            out["parity"] = {"pos_diff_m": float(np.linalg.norm(x_cmp[:3] - x_cpu[:3])),
                              "rot_diff_rad": float(4.0 * np.arcsin(min(1.0, 0.5 * min(np.linalg.norm(q1 - q2), np.linalg.norm(q1 + q2))))),
-                             "state_max_abs_diff": float(np.max(np.abs(x_gpu - x_cpu))),
-                             "against": "oracle h_share_model + IKFoM update on the reference ikd-Tree, same prior, same scan",
+                             "state_max_abs_diff": float(np.max(np.abs(x_cmp - x_cpu))),
+                             "against": "oracle h_share_model + IKFoM update on the reference ikd-Tree, same prior, " +
+                                        ("same scan" if whole else f"the sub-scan of every {sample_every}th point (GPU and CPU alike)"),
                              "neighbors_bit_exact": nbr,
                              # the model half is pinned on a restatement of Eigen (no Eigen in this image): how far the
                              # reference's own build could be from it -- every reduction of esti_plane's QR re-ordered

@@ -239,6 +239,7 @@ def callback_bench():
         B.cbb_step.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp]
         B.cbb_last_m.restype = C.c_int
         B.cbb_last_status.restype = C.c_int
+        B.cbb_last_validnum.restype = C.c_int
         B.cbb_option.argtypes = [C.c_int, C.c_int]
         B.cbb_option.restype = None
         B.cbb_take_model_seconds.restype = C.c_double

@@ -224,6 +224,7 @@ struct lio_ctx {
     GateState* d_gate = nullptr;               // [GATE_SLOTS] device: what a gate leaves for the kernels behind it
     struct ArmedPass {
         bool search, ext; unsigned long long mail_seq, pass_seq;
+        bool hint = false;                     // the bound its search was enqueued with (hint_valid at that moment)
         bool across = false;                   // armed across a scan boundary (stays set; next_scan is cleared by lio_scan_swap)
         bool next_scan = false;                // the FIRST pass of the scan in the back buffer (gate_arm_next_scan): survives the end of
         const float4* body = nullptr; int nq = 0;   // the update and lio_scan_swap (which checks that it swaps in this buffer, this many points)
@@ -237,6 +238,7 @@ struct lio_ctx {
     std::vector<signed char> pattern_prev, pattern_cur;   // converge flag per call of the previous / the running iterated update
     bool pass_searched = false;                // the pass in flight is a search pass
     bool pass_gated = false;                   // ... and was released through a gate (re-enqueued directly once if its gate gave up)
+    bool pass_hint = false;                    // the bound the pass in flight was armed / launched with: what a re-enqueue must use again
     long long n_gate_reenqueued = 0;
     int gate_in_kernel = 3;                    // bit 0: passes that re-use neighbours, bit 1: search passes (bit 2: also the one armed across a scan boundary) -- wait for the host's word inside
                                                // their first kernel instead of behind a gate kernel (mail slots in device memory only;
@@ -367,6 +369,7 @@ struct lio_ctx {
         bool pending = false;                  // a gathered batch waits to enter the map
         bool plan_owed = false;                // its plan may run on the side stream: the next scan step launches it (lio_measure_begin)
         bool planned = false;                  // ... and has been launched there (ev_side says when it is done)
+        bool joined = false;                   // ... and the main stream has been ordered behind it (enter / the settle)
         uint32_t n_add = 0, n_plain = 0, n_boxes = 0;
         HostBox box;
         FoldArgs fa{};
@@ -1135,9 +1138,14 @@ static void flush_pull(lio_ctx* c) {
         if (e != hipSuccess) c->err = std::string("launch_scan_pull: ") + hipGetErrorString(e);
     }
 }
+static int deferred_join_side(lio_ctx* c);
 static inline void enter(lio_ctx* c) {
     if (c->gate_n > 0) gate_call_off(c);
     if (c->pull_pending) flush_pull(c);
+    // the plan of a deferred batch on the side stream (deferred_launch_plan) uses the context-wide stamped scratch of the sorts and
+    // compactions (d_cagg / d_gagg / d_ghist / d_temp / d_apply): whatever an entry point puts on the main stream from here on is
+    // ordered behind it (usually the plan finished long ago: one event query, no dependency enqueued)
+    if (c->def.planned) (void)deferred_join_side(c);
 }
 // ... and whoever reads or changes the MAP (everything but the measurement passes and the scan hand-over) first lets a gathered
 // batch the deferred exchange schedule still holds back enter it (lio_replicate_defer): outside lio_replicate_step the map is
@@ -1909,17 +1917,18 @@ static int deferred_launch_plan(lio_ctx* c) {
     c->stream = main_stream;
     if (rc != LIO_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev_side, c->side_stream));
-    d.planned = true;
+    d.planned = true; d.joined = false;
     ++c->n_plans_on_side_stream;
     return LIO_OK;
 }
 // main stream <- side stream: nothing that follows on the main stream starts before the plan is done (usually it finished
 // during the scan step: then the host has seen it complete and no dependency is enqueued at all)
 static int deferred_join_side(lio_ctx* c) {
-    if (!c->def.planned) return LIO_OK;
+    if (!c->def.planned || c->def.joined) return LIO_OK;
     const hipError_t q = hipEventQuery(c->ev_side);
     if (q == hipErrorNotReady) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_side, 0));
     else if (q != hipSuccess) return c->fail(LIO_ERR_HIP, "deferred exchange: side stream", hipGetErrorString(q));
+    c->def.joined = true;                       // (the main stream is ordered behind this plan: nothing to do until the next one)
     return LIO_OK;
 }
 // The deferred batch enters the map: Delete_Point_Boxes(all boxes), Add_Points(all PointToAdd, true),
@@ -1938,7 +1947,7 @@ static int deferred_settle(lio_ctx* c, int* add_counter, int* n_deleted) {
     const HostBox box = d.box;
     const bool planned = d.planned;
     const int cur = c->def_cur;
-    d.pending = false; d.plan_owed = false; d.planned = false;      // (whatever happens below, the batch is not applied twice)
+    d.pending = false; d.plan_owed = false; d.planned = false; d.joined = false;      // (whatever happens below, the batch is not applied twice)
     ++c->n_settled;
     int deleted = 0;
     if (n_boxes > 0 && c->n_points > 0) {
@@ -2064,8 +2073,15 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
         // some rank had more points than a message holds: every rank sees the flag, every rank repeats the exchange at
         // the full scan capacity (the lists and counters of this rank are still in place: compact wrote elsewhere only
         // if ... the first round's outputs are overwritten by the second)
-        rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, nullptr);
-        if (rc != LIO_OK) return rc;
+        // Immediate schedule: the first round's compaction wrote the gathered lists over this rank's own (d_add_pts / d_add_pts2):
+        // they are made again, on the same map, with the same result.  Deferred schedule: the gathered lists went to buffers of their
+        // own and the first round has already let the HELD batch into the map (deferred_settle) -- lists made now would see batch
+        // k - 1, which the documented schedule (and every rank's twin) does not: this rank's lists and counts of the first round are
+        // still in place (nothing of the settle touches d_add_pts / d_add_pts2 / d_counters[5..6]) and are packed again as they are.
+        if (!defer) {
+            rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, nullptr);
+            if (rc != LIO_OK) return rc;
+        }
         rc = replicate_exchange_apply(c, (uint32_t)c->cap_q, tot, box, defer);
         if (rc != LIO_OK) return rc;
     }
@@ -2078,7 +2094,7 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
         lio_ctx::DeferredBatch& d = c->def;
         c->def_cur ^= 1;                        // what was gathered is now the deferred batch
         d.pending = tot[0] + tot[1] + tot[2] > 0;
-        d.planned = false;
+        d.planned = false; d.joined = false;
         d.n_add = tot[0]; d.n_plain = tot[1]; d.n_boxes = tot[2]; d.box = box;
         // its plan may run beside the next scan step unless delete boxes have to go first (or nothing is down-sampled at all)
         d.plan_owed = d.pending && tot[0] > 0 && tot[2] == 0;
@@ -2126,16 +2142,23 @@ int lio_map_set_downsample_param(lio_ctx* c, float downsample_size) {
 }
 // (a call that failed between an Add_Points and its index update leaves the batch pending, its counts on the device: it is
 // indexed first, so that the numbers are exact)
-long long lio_map_size(lio_ctx* c) {
-    if (!c) return 0;
+// Both read HOST counters: they touch the stream only when a batch is really owed to the map (a deferred exchange, a call that
+// failed half-way).  In particular they do NOT call armed passes off and do NOT flush a pending scan pull: the node calls them
+// between lio::scan_changed and the update (laserMapping.cpp:2343-2344), and the fused / assisted pull of the scan's first search
+// must survive that (round 4's enter_map() here made the assisted pull dead code in the node's own call order).
+static void settle_owed_batches(lio_ctx* c) {
+    if (!c->def.pending && c->fold_n == 0 && c->plain_n == 0) return;
     (void)enter_map(c);
     if ((c->fold_n != 0 || c->plain_n != 0) && hipSetDevice(c->device) == hipSuccess) (void)apply_pending(c);
+}
+long long lio_map_size(lio_ctx* c) {
+    if (!c) return 0;
+    settle_owed_batches(c);
     return (long long)c->n_points - (long long)c->n_retired;
 }
 long long lio_map_validnum(lio_ctx* c) {
     if (!c) return 0;
-    (void)enter_map(c);
-    if ((c->fold_n != 0 || c->plain_n != 0) && hipSetDevice(c->device) == hipSuccess) (void)apply_pending(c);
+    settle_owed_batches(c);
     return (long long)c->n_live;
 }
 
@@ -2954,7 +2977,7 @@ static int gate_arm(lio_ctx* c, bool do_search, bool ext) {
     }
     lio_ctx::ArmedPass& ap = c->gate_q[c->gate_n++];
     ap = lio_ctx::ArmedPass{};
-    ap.search = do_search; ap.ext = ext; ap.mail_seq = mail_seq; ap.pass_seq = 0;
+    ap.search = do_search; ap.ext = ext; ap.mail_seq = mail_seq; ap.pass_seq = 0; ap.hint = c->hint_valid;
     Pose14 none{};
     const int rc = enqueue_pass(c, none, do_search, ext, false, st, &ap.pass_seq, in_kernel ? slot : nullptr, mail_seq);
     if (rc != LIO_OK) { gate_call_off(c); return rc; }
@@ -2990,7 +3013,7 @@ static int gate_arm_next_scan(lio_ctx* c, bool ext) {
     lio_ctx::ArmedPass& ap = c->gate_q[c->gate_n++];
     ap = lio_ctx::ArmedPass{};
     ap.search = true; ap.ext = ext; ap.mail_seq = mail_seq; ap.pass_seq = 0;
-    ap.next_scan = true; ap.across = true; ap.body = c->d_body_back; ap.nq = c->nq_back;
+    ap.next_scan = true; ap.across = true; ap.body = c->d_body_back; ap.nq = c->nq_back; ap.hint = false;
     // the pass is enqueued as the first pass of THAT scan: its points, its count, no neighbours of an earlier search to bound it
     float4* const body_now = c->d_body; const int nq_now = c->nq; const bool hint_now = c->hint_valid;
     c->d_body = c->d_body_back; c->nq = c->nq_back; c->hint_valid = false;
@@ -3051,6 +3074,7 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
             ++c->n_gate_released;
             if (ap.across) ++c->n_next_scan_released;
             c->pass_seq = ap.pass_seq;
+            c->pass_hint = ap.hint;
             released = true;
         } else {
             if (ap.next_scan) c->across_off_this_scan = true;   // (the update runs longer than the previous one did)
@@ -3066,6 +3090,7 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     c->rows_staged = false;
     c->pattern_cur.push_back(do_search ? 1 : 0);
     if (!released) {
+        c->pass_hint = c->hint_valid;
         const int rc = enqueue_pass(c, pose, do_search != 0, ext, walk_in_its_own_launch(c), nullptr, &c->pass_seq);
         if (rc != LIO_OK) { c->pass_in_flight = false; return rc; }
     }
@@ -3143,7 +3168,12 @@ int lio_measure_end(lio_ctx* c, lio_out* out) {
                         c->pass_gated = false;
                         ++c->n_gate_reenqueued;
                         gate_call_off(c);
+                        // with the bound it was ARMED with: lio_measure_begin has since set hint_valid for every search pass, and the
+                        // first search of a scan armed across the scan boundary must not bound on the previous scan's neighbours
+                        const bool hint_now = c->hint_valid;
+                        c->hint_valid = c->pass_hint;
                         const int rc = enqueue_pass(c, c->last_pose, c->pass_searched, c->last_ext, walk_in_its_own_launch(c), nullptr, &c->pass_seq);
+                        c->hint_valid = hint_now;
                         if (rc != LIO_OK) return rc;
                         return lio_measure_end_again(c, out);
                     }

@@ -38,6 +38,7 @@ std::vector<CloudPtr> scans;                                            // what 
 DynShare dyn;                                                           // the filter's dyn_share (esekfom.hpp:1636)
 bool patched_mode = false;
 bool legacy_scan_changed = false;
+int node_valid_num = 0, node_tree_size = 0;                              // featsFromMapNum / kdtree_size_st (:2343-2344)
 double seconds_in_model = 0.0;                                           // inside the callback (library + adaptor), summed over the passes
 
 void h_share_model(state_ikfom& s, DynShare& ekfom_data) { lio::h_share_model(ikdtree, s, ekfom_data, *G); }   // :1876
@@ -112,6 +113,10 @@ int cbb_step(lio_eskf* kf, int k, const double* x26, const double* P, double R, 
         ikdtree.reset_status();
         if (legacy_scan_changed) lio::scan_changed(ikdtree);        // round 3's form: the first callback uploads the cloud
         else lio::scan_changed(ikdtree, *G);                         // :2325 -- the upload starts here, nobody waits for it
+        // what the node does between the voxel filter and the update (laserMapping.cpp:2343-2344): `int featsFromMapNum =
+        // ikdtree.validnum(); kdtree_size_st = ikdtree.size();` -- both read host counters and must leave the pending pull alone
+        node_valid_num = ikdtree.validnum();
+        node_tree_size = ikdtree.size();
         int rc = lio_eskf_change_x(kf, x26);
         if (rc == LIO_OK) rc = lio_eskf_change_P(kf, P);
         if (rc == LIO_OK) rc = lio_eskf_update_iterated_dyn_share_callback(kf, R, model, nullptr, log);
@@ -122,6 +127,7 @@ int cbb_step(lio_eskf* kf, int k, const double* x26, const double* P, double R, 
     }
 }
 int cbb_last_m(void) { return effct_feat_num; }
+int cbb_last_validnum(void) { return node_valid_num; }
 // status of the last library call the adaptor reported as failed during the last step (LIO_OK: none) -- in the default,
 // non-throwing mode a failure costs the pass (ekfom_data.valid = false), not the node
 int cbb_last_status(void) { return ikdtree.last_status; }

@@ -226,6 +226,51 @@ def test_assisted_pull_equals_scan_set(gpu_capi, synth, small_case, stride_float
     ctx.close()
 
 
+def test_assisted_pull_survives_the_nodes_call_order(gpu_capi, synth):
+    """The node calls ikdtree.validnum() and ikdtree.size() between lio::scan_changed and the update (laserMapping.cpp:2343-2344).
+    Both read host counters: the scan pull still owed by scan_changed must stay owed -- the scan's first search pulls it, with the
+    calling thread packing the front (assisted pull) -- and passes armed across calls must stay armed.  (Round 4's lio_map_size /
+    lio_map_validnum went through enter_map() and flushed the pull with a stand-alone kernel: the assisted pull never ran in the
+    node's own order.)  callback_bench's cbb_step issues the two calls where the node does."""
+    import ctypes as C
+    nq = 60_000                                   # 48-byte records: 2.9 MB, 50 us of PCIe time -- a cloud worth the help
+    w = synth.make_world(400_000, 0.2)
+    B = gpu_capi.callback_bench()
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=nq, max_map_points=600_000)
+    if not ctx.debug_get("gate_mail_in_vram"):
+        ctx.close(); pytest.skip("no large BAR: the assisted pull stays off")
+    ctx.map_build(w.points)
+    P0 = np.ascontiguousarray(synth.init_cov(), np.float64)
+    scans, priors = [], []
+    for k in range(3):
+        s2 = synth.make_scan(w, nq, seed=synth.SEED + 900 + k, pos=(0.6 * k, 0.2 * k, 0.0), rpy=(0.002, -0.003, 0.04 * k))
+        ps, rt = synth.perturb_state(s2, seed=synth.SEED + 950 + k)
+        scans.append(s2); priors.append(np.ascontiguousarray(gpu_capi.make_state26(ps, rt, s2.off_R, s2.off_T), np.float64))
+    ref = []
+    for sc, x0 in zip(scans, priors):
+        kf = gpu_capi.Esekf(3)
+        kf.change_x(x0); kf.change_P(P0)
+        ctx.scan_set(sc.body)
+        log = kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+        ref.append((kf.get_x().copy(), kf.get_P().copy(), log))
+    assert B.cbb_setup(ctx.h, nq) == 0
+    B.cbb_option(0, 1); B.cbb_option(1, 0); B.cbb_option(2, 0)
+    ids = [B.cbb_add_scan(np.ascontiguousarray(sc.body, np.float32).ctypes.data_as(C.c_void_p), nq, 3) for sc in scans]
+    assisted0, pulled0 = ctx.debug_get("assisted_pulls"), ctx.debug_get("scan_pulled")
+    for rep in range(2):
+        for k, (x_lib, P_lib, log) in enumerate(ref):
+            kf2 = gpu_capi.Esekf(3)
+            ulog = gpu_capi.lio_update_log()
+            rc = B.cbb_step(kf2.h, ids[k], priors[k].ctypes.data_as(C.c_void_p), P0.ctypes.data_as(C.c_void_p), 0.001, 0, 1, C.byref(ulog))
+            assert rc == 0 and B.cbb_last_status() == 0 and B.cbb_last_validnum() == len(w.points)
+            assert ulog.n_calls == log["n_calls"] and B.cbb_last_m() == log["last_m"]
+            assert np.array_equal(kf2.get_x(), x_lib) and np.array_equal(kf2.get_P(), P_lib)
+    assert ctx.debug_get("scan_pulled") - pulled0 == 6
+    assert ctx.debug_get("assisted_pulls") - assisted0 == 6           # every scan's first search pulled its own cloud, host packing beside it
+    ctx.measure_want_rows(False)
+    ctx.close()
+
+
 def test_assisted_pull_fuzz_seed():
     """150 scans of tests/fuzz/fuzz_assist.py: clouds of random sizes and strides, share steered / fixed / off, one or two packing
     threads switched at random, a host that stalls -- every scan's first pass equal to lio_scan_set's on a twin context, to the bit."""

@@ -5,7 +5,8 @@ compiled verbatim from include/ikd-Tree/ikd_Tree.cpp by oracle/Makefile) -- not 
                                                       first search and the bounded (hinted) second search at the moved pose
   C3  24 000-point HAP scan vs 2 M-point map          the same, plus the whole measurement pass against the oracle's
                                                       h_share_model (extrinsic_est_en = true, config/hap_livox.yaml:45,49)
-  C5  1 M-point scan vs 50 M-point map                no CPU tree of that size fits a test run (8.8 GB, minutes): the
+  C5  1 M-point scan vs 50 M-point map                every 8th query (125 000) against the reference tree built from the
+                                                      same 50 M points (8.8 GB, ~20 s), first / bounded / fresh search; the
                                                       size-independent properties + brute force over all 50 M points
 plus KD_TREE::reconstruct (ikd_Tree.cpp:1394-1405) after adds, box deletes and a moved local-map cube, and the error
 path of a timed-out cross-workgroup reduction.
@@ -169,15 +170,63 @@ def test_c3_full_size_hap_vs_reference_tree(gpu_capi, oracle, synth):
     ctx.close()
 
 
-def test_c5_properties_1m_scan_50m_map(gpu_capi, synth):
-    """BASELINE config 5 (cube_len 1000, filter_size_map_min 0.1): five neighbours per point, every reported sqdist is
-    the fp32 distance of the reported point and ascending, brute force over all 50 M points for 32 queries, run-to-run
-    identical bits, an O(batch) insert is found by the next search, the update converges to the true pose."""
+@pytest.fixture(scope="module")
+def c5(synth):
     nm, nq, voxel = 50_000_000, 1_000_000, 0.1
     world = synth.make_world(nm, voxel)
     scan = synth.make_scan(world, nq, kind="wide")
     pos, rot = synth.perturb_state(scan)
-    st = synth.state_vector(pos, rot, scan.off_R, scan.off_T)
+    return {"world": world, "scan": scan, "pos": pos, "rot": rot, "nm": nm, "nq": nq, "voxel": voxel,
+            "state14": synth.state_vector(pos, rot, scan.off_R, scan.off_T)}
+
+
+def test_c5_sampled_neighbours_equal_the_reference_tree(gpu_capi, oracle, synth, c5):
+    """BASELINE config 5 against the reference itself: KD_TREE::Nearest_Search (ikd_Tree.cpp:367-397, unbounded: max_dist =
+    INFINITY, ikd_Tree.h:236) of the verbatim reference tree built from the same 50 M points (8.8 GB, ~20 s) on every 8th query
+    of the 1 M-point scan (125 000 queries, k = 6 so that rank-5/6 ties would show): counts, squared-distance bits and -- on
+    tie-free rows -- the neighbour points of the GPU's first search, of its bounded (HINT) re-search at the pose the first
+    update moves to, and of a fresh search there."""
+    _need_ref(oracle)
+    w, sc, st, nq, voxel = c5["world"], c5["scan"], c5["state14"], c5["nq"], c5["voxel"]
+    ctx = gpu_capi.LioContext(voxel, max_scan_points=nq, max_map_points=c5["nm"] + 100_000)
+    ctx.map_build(w.points)
+    ctx.scan_set(sc.body)
+    ctx.measure(st, True, False)
+    wq, _, _ = ctx.scan_state()
+    gx, gd, gc = ctx.neighbors()
+    kf = gpu_capi.Esekf(0)                        # maximum_iter = 0: one pass, one update
+    kf.change_x(gpu_capi.make_state26(c5["pos"], c5["rot"], sc.off_R, sc.off_T)); kf.change_P(synth.init_cov())
+    kf.update_iterated_dyn_share_modified(ctx, 0.001, False)
+    st2 = kf.get_x()[:14].copy()
+    assert 0.02 < np.linalg.norm(st2[:3] - st[:3]) < 0.3
+    ctx.measure(st2, True, False)                  # bounded by the neighbours of the search above
+    wq2, _, _ = ctx.scan_state()
+    hx, hd, hc = ctx.neighbors()
+    ctx.scan_set(sc.body)                          # forgets the bound: an unbounded search at the same pose
+    ctx.measure(st2, True, False)
+    fx, fd, fc = ctx.neighbors()
+    assert bits_equal(fx, hx) and bits_equal(fd, hd) and np.array_equal(fc, hc)       # all 1 M rows: bounded == fresh
+    ctx.close()
+    assert bits_equal(wq, oracle.body_to_world(st, sc.body))
+    ref = oracle.RefIkdTree(voxel)
+    ref.build(w.points)
+    assert ref.validnum() == len(w.points)
+    sl = slice(3, None, 8)
+    c = np.ascontiguousarray
+    n, d_bad, p_bad, ties, r56 = _compare_all_neighbours(ref, c(wq[sl]), c(gx[sl]), c(gd[sl]), c(gc[sl]))
+    assert n >= 100_000 and (d_bad, p_bad) == (0, 0), (n, d_bad, p_bad, ties, r56)
+    n2, d_bad2, p_bad2, ties2, _ = _compare_all_neighbours(ref, c(wq2[sl]), c(hx[sl]), c(hd[sl]), c(hc[sl]))
+    assert (n2, d_bad2, p_bad2) == (n, 0, 0), (n2, d_bad2, p_bad2, ties2)
+    assert ties + ties2 <= n // 1000               # the synthetic generator is tie-free up to fp32 coincidences at 50 M points
+    del ref
+
+
+def test_c5_properties_1m_scan_50m_map(gpu_capi, synth, c5):
+    """BASELINE config 5 (cube_len 1000, filter_size_map_min 0.1): five neighbours per point, every reported sqdist is
+    the fp32 distance of the reported point and ascending, brute force over all 50 M points for 32 queries, run-to-run
+    identical bits, an O(batch) insert is found by the next search, the update converges to the true pose."""
+    nm, nq, voxel = c5["nm"], c5["nq"], c5["voxel"]
+    world, scan, pos, rot, st = c5["world"], c5["scan"], c5["pos"], c5["rot"], c5["state14"]
     ctx = gpu_capi.LioContext(voxel, max_scan_points=nq, max_map_points=nm + 100_000)
     ctx.map_build(world.points)
     ctx.scan_set(scan.body)

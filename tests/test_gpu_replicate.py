@@ -200,8 +200,8 @@ def test_deferred_schedule_through_rccl(gpu_capi, oracle, synth, small_case):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("W", [2, 8])
-def test_deferred_schedule_in_a_loopback_world(gpu_capi, oracle, synth, small_case, W):
+@pytest.mark.parametrize("W,tiny_messages", [(2, False), (8, False), (4, True)])
+def test_deferred_schedule_in_a_loopback_world(gpu_capi, oracle, synth, small_case, W, tiny_messages):
     """lio_replicate_defer: the lists and boxes gathered by exchange k enter the map at the START of exchange k + 1; scan step
     k + 1 searches the map without them while the read-only half of their Add_Points (keys, sort, the speculative fold) runs on
     a side stream, and only the half that writes stays between two scan steps.  Held against a twin context driven by plain
@@ -210,7 +210,9 @@ def test_deferred_schedule_in_a_loopback_world(gpu_capi, oracle, synth, small_ca
     when they were searched; the flattened maps are compared at the end (any map call lets a batch that is held back enter
     first) with each other and with the reference ikd-Tree fed the same sequence of calls (ikd_Tree.cpp:414-489, 536-556).  A
     delete box travels in round 1 (its batch is planned after the deletion, on the main stream), one rank overflows its
-    message in round 0; the other batches must have been planned on the side stream."""
+    message in round 0; the other batches must have been planned on the side stream.  tiny_messages: a message holds 64 points,
+    so EVERY round overflows and repeats its exchange at full capacity -- in rounds >= 1 behind a first round that has already let
+    the held batch into the map: the repeat must pack the lists this rank made BEFORE that (the documented schedule, the twin's)."""
     w = small_case["world"]
     thin = np.ascontiguousarray(w.points[::2])
     nq_small, nq_big = 1500, 6000
@@ -254,8 +256,10 @@ def test_deferred_schedule_in_a_loopback_world(gpu_capi, oracle, synth, small_ca
             lists.append(b.map_incremental(post, 0.2, True, apply=False, want_lists=True))
         if k == 0:
             sizes = sorted(max(l["n_add"], l["n_nodown"]) for l in lists)
-            a.replicate_init(b"", W - 1, W, (sizes[-1] + sizes[-2]) // 2)
+            a.replicate_init(b"", W - 1, W, 64 if tiny_messages else (sizes[-1] + sizes[-2]) // 2)
             a.replicate_defer(True)
+        if tiny_messages:
+            assert max(max(l["n_add"], l["n_nodown"]) for l in lists) > 64, k       # this round overflows
         for r in range(W):
             sc, x0, post = posts[r]
             a.debug_set("replicate_loopback_rank", r)       # (before the scan step: the LAST rank's step is the one the plan runs beside)
