@@ -74,7 +74,7 @@ struct TreeLevels {
 // pos3, rot xyzw, offR xyzw, offT3 -- passed to kernels by value (112 bytes of kernarg)
 struct Pose14 { double v[14]; };
 
-// A pass enqueued BEFORE its pose is known (the iterated update, lio_ctx.hip): a one-wavefront gate kernel in front of the pass's
+// A pass enqueued BEFORE its pose is known (the iterated update, lio_pass.hip): a one-wavefront gate kernel in front of the pass's
 // kernels waits for the host's word in GateMail (host-mapped, coherent) and leaves the pose -- or the order to skip the pass -- in
 // GateState (device memory), which the kernels behind it read instead of their by-value pose.
 struct GateState { uint32_t skip; uint32_t pad[3]; Pose14 pose; };

@@ -43,7 +43,7 @@ __device__ __forceinline__ void cell_find(const HashEntry* l1table, uint32_t l1m
 }
 
 // ---- the host's word to a pass that sits on the stream ahead of its pose, read by the FIRST KERNEL OF THE PASS itself ---------
-// (lio_ctx.hip gate_arm; the stand-alone gate_kernel of lio_knn.hip is the form for mail slots in host memory.)  One whole
+// (lio_pass.hip gate_arm; the stand-alone gate_kernel of lio_knn.hip is the form for mail slots in host memory.)  One whole
 // wavefront calls gate_poll: lanes 0..16 fetch one word of the slot each -- fine-grained device memory the CPU writes through
 // the BAR, so a poll is a round trip to local memory -- until the sequence number the launch was made for is there with a
 // matching check word.  Returns the lane's word; `go` (wave-uniform) is false when the host called the pass off or nobody

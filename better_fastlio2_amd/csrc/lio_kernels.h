@@ -1,4 +1,4 @@
-// lio_kernels.h -- launch interface between the host side of liblio_hip.so (lio_ctx.hip) and the
+// lio_kernels.h -- launch interface between the host side of liblio_hip.so (lio_ctx.hip, lio_update.hip, lio_scan.hip, lio_pull.hip, lio_pass.hip) and the
 // gfx950 kernels (lio_knn.hip, lio_measure.hip, lio_map.hip).  Internal; the public boundary is
 // include/lio_hip.h.
 #pragma once
@@ -26,7 +26,7 @@ struct KnnArgs {
     int              body_raw_stride;
     int              body_raw_aligned;   // records start on 16-byte boundaries: one 16-byte read each
     float4*          body_fill;
-    // ... and the host helps (lio_ctx.hip, assisted pull): while the workgroups dispatched first pull the BACK of the scan as raw
+    // ... and the host helps (lio_pull.hip, assisted pull): while the workgroups dispatched first pull the BACK of the scan as raw
     // records, the host thread that would otherwise only wait for the pass packs the FRONT [0, pack_front) into 16-byte records
     // (`pack_src`: device alias of its page-locked staging buffer) and publishes how far it has come in `pack_progress`
     // (stamp << 32 | records done; fine-grained device memory where the BAR maps it).  A third of the bytes cross PCIe for every

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
                 const uint32_t need = (uint32_t)min((qb + 1) * (WPB * GPW), a.pack_front);
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
-                    // (workgroups of [pack_mid, pack_front) listen to the second packing thread's word, lio_ctx.hip)
+                    // (workgroups of [pack_mid, pack_front) listen to the second packing thread's word, lio_pull.hip)
                     const unsigned long long w = __hip_atomic_load(a.pack_progress + (a.pack_mid > 0 && qb * (WPB * GPW) >= a.pack_mid ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     if ((uint32_t)(w >> 32) == a.pack_stamp && (uint32_t)w >= need) { packed_by_host = true; break; }
                     if (wall_clock64() - t0 > 30000ull) break;           // 100 MHz: 300 us -- a host that was pre-empted
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
                     if (dt > 0xfffffffeull) dt = 0xfffffffeull;
                     __hip_atomic_store(a.pack_wait_out, ((unsigned long long)a.pack_stamp << 32) | (packed_by_host ? dt : 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
-                // (the records were written before the word that announces them: x86 store order + sfence, lio_ctx.hip)
+                // (the records were written before the word that announces them: x86 store order + sfence, lio_pull.hip)
             }
             if (go && lane < WPB * GPW && qi < a.nq) {
                 float4 b;

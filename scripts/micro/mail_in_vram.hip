@@ -1,4 +1,4 @@
-// Micro-benchmark: where should the host's word to an armed gate kernel live?  Today (lio_ctx.hip, gate_write) the mail slot is in
+// Micro-benchmark: where should the host's word to an armed gate kernel live?  Today (lio_pass.hip, gate_write) the mail slot is in
 // host-mapped memory and the one-wavefront gate polls it over PCIe (a read round trip per poll).  Alternative: the slot in
 // FINE-GRAINED DEVICE memory that the CPU writes through the PCIe BAR -- the gate then polls local memory and the word travels once.
 //   1  can the CPU store into hipExtMallocWithFlags(hipDeviceMallocFinegrained) memory at all on this box?  (forked: a fault kills

@@ -1,5 +1,5 @@
 // Micro-probe (host only): how fast can ONE host thread turn the front of a 48-byte-stride cloud into 16-byte records?
-// (assist_pack, lio_ctx.hip: the faster it is, the larger the share of a scan that crosses PCIe as 16 instead of 48 bytes.)
+// (assist_pack, lio_pull.hip: the faster it is, the larger the share of a scan that crosses PCIe as 16 instead of 48 bytes.)
 // Variants: plain 16-byte load/mask/store; + software prefetch; unrolled x4; 32-byte stores of two records; streaming stores;
 // two threads.  Warm = the same cloud again and again (a node's voxel filter has just written it); cold = 8 clouds in turn behind
 // a 512 MB sweep.   g++ -O2 -mavx2 -pthread scripts/micro/pack_probe.cpp -o scripts/micro/pack_probe && scripts/micro/pack_probe

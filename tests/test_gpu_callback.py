@@ -182,7 +182,7 @@ def test_scan_set_async_equals_scan_set(gpu_capi, small_case, stride_floats):
 @pytest.mark.parametrize("stride_floats", [8, 12])
 def test_assisted_pull_equals_scan_set(gpu_capi, synth, small_case, stride_floats):
     """The first search of a scan handed over as page-locked host records, with the host packing the FRONT of the cloud beside
-    it (assisted pull, lio_ctx.hip; alone or with the library's optional second packing thread): workgroups of the back pull raw records, workgroups of the front wait for the host's
+    it (assisted pull, lio_pull.hip; alone or with the library's optional second packing thread): workgroups of the back pull raw records, workgroups of the front wait for the host's
     progress word and read 16-byte records -- or give up on a stalled host and read raw.  Every share (off, by the running
     estimate, 25 / 50 / 90 per cent) and a host that sleeps 2 ms before it packs leave exactly the scan, the neighbours and the
     sums of lio_scan_set."""

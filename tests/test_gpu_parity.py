@@ -281,7 +281,7 @@ def test_scan_step_call_equals_the_four_calls(gpu_capi, synth, small_case):
 
 def test_passes_enqueued_ahead_of_their_pose(gpu_capi, synth, small_case):
     """Inside the iterated update the next pass goes onto the stream while the GPU works on the current one, behind a gate
-    kernel that waits for the pose (lio_ctx.hip, gate_arm): the posterior, the covariance and the call log must be what the
+    kernel that waits for the pose (lio_pass.hip, gate_arm): the posterior, the covariance and the call log must be what the
     plain sequence gives, bit for bit -- when every prediction holds, when every prediction is wrong (each armed pass is called
     off, its kernels stand down), when the update runs fewer passes than the previous one (a pass stays armed at the end and is
     called off), and the stream must be free for map maintenance right after (esekfom.hpp:1636-1938, laserMapping.cpp:2380)."""
@@ -1349,7 +1349,7 @@ def test_contexts_release_their_memory(gpu_capi, small_case):
 @pytest.mark.parametrize("variant", ["armed", "armed_wait_in_kernel", "not_armed", "map_update_between_scans"])
 def test_first_search_of_the_next_scan_is_armed_across_the_scan_boundary(gpu_capi, synth, small_case, variant):
     """lio_eskf_scan_step_pipelined puts the first search of the NEXT scan (already uploaded) onto the stream behind the last
-    passes of the current one (gate_arm_next_scan, lio_ctx.hip): lio_scan_swap keeps it armed, the scan's first lio_measure_begin
+    passes of the current one (gate_arm_next_scan, lio_pass.hip): lio_scan_swap keeps it armed, the scan's first lio_measure_begin
     hands it its pose.  Bit-identical to the plain sequence -- also when the previous update mispredicts where this one ends (the
     third update is shorter, the fourth longer than the one before), when anything else uses the stream between two scans (the
     armed search is called off and launched directly) and with the switch off."""
