@@ -66,8 +66,8 @@ EXPORTS = [
     "lio_create", "lio_destroy", "lio_last_error", "lio_version", "lio_device_count", "lio_stream", "lio_synchronize",
     "lio_map_build", "lio_map_build_device", "lio_map_add", "lio_map_add_pair", "lio_map_add_pair_device", "lio_map_incremental", "lio_map_incremental_device", "lio_map_delete_boxes", "lio_replicate_unique_id", "lio_replicate_init", "lio_replicate_finalize", "lio_replicate_queue_boxes", "lio_replicate_step", "lio_replicate_defer", "lio_fov_segment", "lio_map_reconstruct",
     "lio_map_set_downsample_param", "lio_map_size", "lio_map_validnum", "lio_map_flatten", "lio_map_acquire_removed_points", "lio_map_get_info", "lio_map_nearest_search",
-    "lio_scan_set", "lio_scan_set_device", "lio_scan_set_async", "lio_scan_pack_threads", "lio_host_register", "lio_host_unregister", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_measure_want_rows", "lio_eskf_update_iterated_dyn_share_callback", "lio_get_neighbors",
-    "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get", "lio_debug_set", "lio_debug_get", "lio_debug_stamps",
+    "lio_scan_set", "lio_scan_set_device", "lio_scan_set_async", "lio_scan_pack_threads", "lio_host_register", "lio_host_unregister", "lio_scan_upload_async", "lio_scan_swap", "lio_host_alloc", "lio_host_free", "lio_scan_undistort", "lio_scan_upload_raw", "lio_scan_compensate", "lio_scan_voxel_filter", "lio_scan_prefetch_raw", "lio_scan_prep_begin", "lio_scan_prep_end", "lio_scan_get_cloud", "lio_measure", "lio_measure_begin", "lio_measure_end", "lio_measure_rows", "lio_measure_want_rows", "lio_eskf_update_iterated_dyn_share_callback", "lio_get_neighbors",
+    "lio_get_scan_state", "lio_scan_size", "lio_profile_enable", "lio_census_enable", "lio_profile_reset", "lio_profile_get", "lio_debug_set", "lio_debug_get", "lio_debug_stamps", "lio_debug_knn_stamps",
     "lio_eskf_create", "lio_eskf_destroy", "lio_eskf_init_dyn_share", "lio_eskf_change_x", "lio_eskf_change_P",
     "lio_eskf_get_x", "lio_eskf_get_P", "lio_eskf_update_iterated_dyn_share_modified", "lio_eskf_scan_step_device", "lio_eskf_scan_step_pipelined", "lio_state_boxplus",
     "lio_state_boxminus", "lio_eskf_predict", "lio_process_noise_cov",
@@ -158,6 +158,9 @@ def load(build_if_missing: bool = True):
     L.lio_scan_upload_raw.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int]
     L.lio_scan_compensate.argtypes = [_vp, _vp, C.c_int, _vp]
     L.lio_scan_voxel_filter.argtypes = [_vp, C.c_float, C.POINTER(C.c_int)]
+    L.lio_scan_prefetch_raw.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int]
+    L.lio_scan_prep_begin.argtypes = [_vp]
+    L.lio_scan_prep_end.argtypes = [_vp, C.POINTER(C.c_int)]
     L.lio_scan_get_cloud.argtypes = [_vp, C.c_int, _vp, C.c_int, C.POINTER(C.c_int)]
     L.lio_measure.argtypes = [_vp, _vp, C.c_int, C.c_int, C.POINTER(lio_out)]
     L.lio_measure_rows.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int]
@@ -172,6 +175,7 @@ def load(build_if_missing: bool = True):
     L.lio_debug_set.argtypes = [_vp, C.c_char_p, C.c_longlong]
     L.lio_debug_get.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_longlong)]
     L.lio_debug_stamps.argtypes = [_vp, _vp]
+    L.lio_debug_knn_stamps.argtypes = [_vp, _vp, C.c_longlong, _vp]
     L.lio_profile_get.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.lio_eskf_create.restype = _vp
     L.lio_eskf_destroy.argtypes = [_vp]
@@ -474,6 +478,23 @@ class LioContext:
     def scan_voxel_filter(self, leaf_size: float) -> int:
         n = C.c_int(0)
         self._chk(self.L.lio_scan_voxel_filter(self.h, float(leaf_size), C.byref(n)), "lio_scan_voxel_filter")
+        return n.value
+
+    def scan_prefetch_raw(self, pinned_xyzt: np.ndarray):
+        """A sweep of x, y, z, t records in page-locked memory (pinned_points) starts its way to the GPU on the copy stream; the
+        scan_undistort / ImuProcess.process call that names the same array takes it where it is.  Keep the array alive until then."""
+        assert pinned_xyzt.dtype == np.float32 and pinned_xyzt.ndim == 2 and pinned_xyzt.shape[1] == 4 and pinned_xyzt.flags.c_contiguous
+        self._chk(self.L.lio_scan_prefetch_raw(self.h, _ptr(pinned_xyzt), len(pinned_xyzt), 16, 12), "lio_scan_prefetch_raw")
+        self._prefetch_keep = pinned_xyzt
+
+    def scan_prep_begin(self):
+        """From here to scan_prep_end the raw-scan calls (scan_undistort, ImuProcess.process, scan_voxel_filter) only enqueue, on a
+        stream of their own; map calls of the current scan go on meanwhile."""
+        self._chk(self.L.lio_scan_prep_begin(self.h), "lio_scan_prep_begin")
+
+    def scan_prep_end(self) -> int:
+        n = C.c_int(0)
+        self._chk(self.L.lio_scan_prep_end(self.h, C.byref(n)), "lio_scan_prep_end")
         return n.value
 
     def scan_cloud(self, which: int) -> np.ndarray:

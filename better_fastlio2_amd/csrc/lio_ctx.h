@@ -125,6 +125,16 @@ struct PackHelper {
     }
 };
 
+// one attempt of the voxel filter (lio_scan.hip): what was predicted, which record it filled
+struct VoxelRun {
+    int n = 0;
+    float leaf = 0.0f;
+    bool time_minor = false, may_compact = false, compact = false;
+    int passes = 0;
+    uint32_t max_leaves = 0;
+    VoxelGridDev* vox = nullptr;               // the record this attempt filled (its summary is what the host reads)
+};
+
 struct lio_ctx {
     lio_config cfg{};
     int device = 0;
@@ -348,6 +358,22 @@ struct lio_ctx {
     int vox_passes_guess = 3;                  // 8-bit splits the previous sweep's leaf index needed (22-24 bits at 0.5 m leaves)
     long long n_voxel_redone = 0;              // sweeps filtered twice (a wrong prediction)
 
+    // asynchronous scan preparation (lio_scan_prefetch_raw / lio_scan_prep_begin / _end, lio_scan.hip)
+    float4* d_raw_back = nullptr;              // destination of a prefetched sweep (copy stream)
+    const void* raw_prefetch_src = nullptr;
+    int raw_prefetch_n = 0;
+    bool raw_prefetched = false;
+    hipEvent_t ev_raw = nullptr;
+    hipStream_t prep_stream = nullptr;
+    bool prep_active = false, prep_filtered = false, prep_enqueued = false;
+    VoxelRun prep_run;                         // the filter enqueued there: what lio_scan_prep_end judges
+    unsigned long long *d_cagg_prep = nullptr, *d_gagg_prep = nullptr;   // the preparation stream's own stamped scratch
+    uint32_t compact_seq_prep = 0, gsort_seq_prep = 0;
+    void* h_small3 = nullptr;                  // its mail box (the filter's summary)
+    uint32_t* d_small3 = nullptr;
+    uint32_t small3_seq = 0;
+    long long n_raw_prefetch_hits = 0, n_prep_overlapped = 0;
+
     // batch buffers of lio_map_add
     size_t cap_add = 0;
     float4 *d_add_pts = nullptr, *d_add_pts2 = nullptr, *d_add_out = nullptr;
@@ -418,6 +444,9 @@ struct lio_ctx {
     int dbg_knn_walk = -1;                     // lio_debug_set("knn_walk") / LIO_KNN_WALK: -1 = by scan size (auto_walk), 0 / 1 / 2 / 4 = KnnArgs.walk
     int dbg_library_sort = 0;                  // lio_debug_set("library_sort"): rocPRIM for every sort / compaction (A/B switch)
     int dbg_stamps = 0;                        // lio_debug_set("stamps"): the last workgroup takes wall_clock64 stamps (lio_debug_stamps)
+    int dbg_knn_stamps = 0;                    // lio_debug_set("knn_stamps"): searches run the stamped instantiation of knn27_kernel (lio_debug_knn_stamps)
+    unsigned long long* d_knn_stamps = nullptr;   // [workgroups][KNN_STAMP_WORDS]
+    int knn_stamps_wgs = 0;                    // workgroups of the last stamped launch
     int dbg_separate_walk = 0;                 // lio_debug_set("separate_tree_walk"): the stand-alone knn_tree_kernel per search pass
     std::vector<hipEvent_t> ev_pool[LIO_PROF_COUNT];   // start, stop, start, stop, ...
     size_t ev_next[LIO_PROF_COUNT]{};          // events of the pool in use

@@ -249,6 +249,14 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     { const char* e = std::getenv("LIO_TRACE_REBUILDS"); c->trace_rebuilds = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_TRACE_HOST"); c->trace_host = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_PRE_ENQUEUE"); if (e != nullptr && e[0] == '0') c->dbg_pre_enqueue = 0; }   // (A/B runs of scripts)
+    // Environments in which a launch call returns only when its kernel has ended (HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL: debugging
+    // aids of the runtime): a pass put on the stream AHEAD of its pose would wait for a word the host can only write after the launch
+    // call has returned -- it could only time out.  Nothing is armed there; every pass is launched when its pose is known.
+    {
+        const char* b = std::getenv("HIP_LAUNCH_BLOCKING");
+        const char* k = std::getenv("AMD_SERIALIZE_KERNEL");
+        if ((b != nullptr && b[0] != 0 && b[0] != '0') || (k != nullptr && k[0] != 0 && k[0] != '0')) { c->dbg_pre_enqueue = 0; c->dbg_arm_next_scan = 0; }
+    }
     { const char* e = std::getenv("LIO_KNN_TUNE"); if (e != nullptr && e[0] >= '0' && e[0] <= '9') c->dbg_knn_tune = std::atoi(e); }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_ARM_NEXT_SCAN"); if (e != nullptr && e[0] == '0') c->dbg_arm_next_scan = 0; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_GATE_IN_KERNEL"); if (e != nullptr && e[0] >= '0' && e[0] <= '7' && e[1] == 0) c->gate_in_kernel = e[0] - '0'; }   // (A/B runs of scripts)
@@ -388,8 +396,8 @@ void lio_destroy(lio_ctx* c) {
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
                    c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_gs_part, c->d_gs_part2, c->d_porder, c->d_porder2, c->d_pnewoff, c->d_plan, c->d_ghist, c->d_gagg, c->d_apply, c->d_temp, c->d_counters, c->d_cagg, c->d_cand, c->d_boxes,
                    c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_useeds, c->d_lunits, c->d_rows, c->d_rows_c,
-                   c->d_units, c->d_gunits, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, c->d_qs_useeds,
-                   c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
+                   c->d_units, c->d_gunits, c->d_knn_stamps, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, c->d_qs_useeds,
+                   c->d_raw, c->d_raw_back, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2,
                    c->d_add_order, c->d_add_order2, c->d_add_dirty, c->d_add_dirty_pt, c->d_add_dlist, c->d_add_plan, c->d_add_ranges, c->d_add_parts,
@@ -410,6 +418,11 @@ void lio_destroy(lio_ctx* c) {
         if (c->d_def_plain[i]) (void)hipFree(c->d_def_plain[i]);
         if (c->d_def_boxes[i]) (void)hipFree(c->d_def_boxes[i]);
     }
+    if (c->prep_stream) { (void)hipStreamSynchronize(c->prep_stream); (void)hipStreamDestroy(c->prep_stream); }
+    if (c->ev_raw) (void)hipEventDestroy(c->ev_raw);
+    if (c->h_small3) (void)hipHostFree(c->h_small3);
+    if (c->d_cagg_prep) (void)hipFree(c->d_cagg_prep);
+    if (c->d_gagg_prep) (void)hipFree(c->d_gagg_prep);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -475,6 +488,7 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "separate_tree_walk") == 0) { c->dbg_separate_walk = value != 0; return LIO_OK; }
     if (std::strcmp(key, "library_sort") == 0) { c->dbg_library_sort = value != 0; return LIO_OK; }
     if (std::strcmp(key, "stamps") == 0) { c->dbg_stamps = value != 0; return LIO_OK; }
+    if (std::strcmp(key, "knn_stamps") == 0) { c->dbg_knn_stamps = value != 0; return LIO_OK; }
     if (std::strcmp(key, "knn_tune") == 0) { c->dbg_knn_tune = (int)value; return LIO_OK; }
     if (std::strcmp(key, "voxel_fast_path") == 0) { c->dbg_voxel_fast = value != 0; return LIO_OK; }
     if (std::strcmp(key, "knn_walk") == 0) {
@@ -534,12 +548,26 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "pack_helper_late") == 0) { *value = c->n_helper_late; return LIO_OK; }
     if (std::strcmp(key, "last_pack_ns") == 0) { *value = (long long)(c->last_pack_us * 1e3); return LIO_OK; }
     if (std::strcmp(key, "scan_pulled") == 0) { *value = c->n_scan_pulled; return LIO_OK; }
+    if (std::strcmp(key, "raw_prefetch_hits") == 0) { *value = c->n_raw_prefetch_hits; return LIO_OK; }
+    if (std::strcmp(key, "prep_overlapped") == 0) { *value = c->n_prep_overlapped; return LIO_OK; }
     if (std::strcmp(key, "rows_direct_dma") == 0) { *value = c->n_rows_direct_dma; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_get", "unknown key");
 }
 int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {
     if (!c || !out8) return LIO_ERR_INVALID_ARG;
     for (int i = 0; i < 8; ++i) out8[i] = c->h_out->dbg[i];
+    return LIO_OK;
+}
+int lio_debug_knn_stamps(lio_ctx* c, unsigned long long* out, long long cap_words, int* n_workgroups) {
+    if (!c || !n_workgroups || cap_words < 0 || (cap_words > 0 && !out)) return LIO_ERR_INVALID_ARG;
+    enter(c);
+    *n_workgroups = c->d_knn_stamps ? c->knn_stamps_wgs : 0;
+    const size_t words = (size_t)*n_workgroups * KNN_STAMP_WORDS;
+    if (words == 0 || cap_words == 0) return LIO_OK;
+    if ((size_t)cap_words < words) return c->fail(LIO_ERR_CAPACITY, "lio_debug_knn_stamps", "cap_words < workgroups * 8");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, stream_wait(c));
+    HIPCHK(c, hipMemcpy(out, c->d_knn_stamps, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return LIO_OK;
 }
 int lio_census_enable(lio_ctx* c, int on) { if (!c) return LIO_ERR_INVALID_ARG; enter(c); c->census = on != 0; return LIO_OK; }

@@ -47,13 +47,14 @@ __device__ __forceinline__ void cell_find(const HashEntry* l1table, uint32_t l1m
 // wavefront calls gate_poll: lanes 0..16 fetch one word of the slot each -- fine-grained device memory the CPU writes through
 // the BAR, so a poll is a round trip to local memory -- until the sequence number the launch was made for is there with a
 // matching check word.  Returns the lane's word; `go` (wave-uniform) is false when the host called the pass off or nobody
-// answered for two seconds.  The wait is over before most of the launch's workgroups have been dispatched: the host writes the
+// answered for ten milliseconds.  The wait is over before most of the launch's workgroups have been dispatched: the host writes the
 // word ~3 us after the previous pass's record, the dispatch of a dependent launch takes about as long.
 __device__ __forceinline__ unsigned long long mail_word(unsigned long long w, int i) {   // word i of the mail as a wave-uniform value
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, i);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), i);
     return ((unsigned long long)hi << 32) | (unsigned long long)lo;
 }
+constexpr unsigned long long GATE_IN_KERNEL_WAIT_TICKS = 1000000ull;     // 100 MHz: 10 ms
 __device__ __forceinline__ unsigned long long gate_poll(const GateMail* mail, unsigned long long expect, bool& go) {
     const int lane = (int)(threadIdx.x & 63u);
     const unsigned long long t0 = wall_clock64();
@@ -67,7 +68,13 @@ __device__ __forceinline__ unsigned long long gate_poll(const GateMail* mail, un
             for (int i = 0; i < 16; ++i) all[i] = mail_word(w, i);
             if (gate_check(all) == mail_word(w, 16)) { ok = true; break; }
         }
-        if (wall_clock64() - t0 > 200000000ull) break;             // 100 MHz: 2 s
+        // 10 ms.  The host answers ~3 us after the previous pass's record; a host that has not answered after 10 ms is not
+        // polling (pre-empted for scheduler quanta, stopped, in a debugger).  Every workgroup of the launch waits HERE -- a search of 100 k queries is a
+        // resident grid that fills the GPU -- so the wait must be short: the launch stands down, the GPU is free for whoever else
+        // uses it (tests/test_gpu_robustness.py: another process keeps stepping through a 3 s SIGSTOP), and the host, when it
+        // comes back, finds an idle stream without a record and puts the pass on the stream directly (lio_measure_end,
+        // "gate_reenqueued": ~25 us once).  The one-wavefront gate_kernel (lio_knn.hip) keeps its 2 s: it parks nothing.
+        if (wall_clock64() - t0 > GATE_IN_KERNEL_WAIT_TICKS) break;
         __builtin_amdgcn_s_sleep(2);
     }
     go = ok && mail_word(w, 1) == GATE_GO;

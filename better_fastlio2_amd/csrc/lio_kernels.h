@@ -60,7 +60,13 @@ struct KnnArgs {
     int              tune;          // experiment switches (lio_debug_set "knn_tune"): bit 0 = do NOT raise the transforming wavefront's priority
     int              walk;          // candidate walk: 0 = list of {start, count}, one load in flight per lane; 1 / 2 / 4 = prefix-form
                                     // list with that many candidates per lane in flight (4, 8 or 16 lanes per query; lio_knn.hip)
+    // diagnostics (lio_debug_set "knn_stamps"; 8 lanes per query, walk 4 only): non-null = the STAMPED instantiation of the kernel --
+    // wavefront 0 of every workgroup leaves eight wall_clock64 stamps (100 MHz) at [workgroup][8]: entry, query known (transform +
+    // barrier), directory records arrived, bucket list in prefix form, candidates walked, merged + proven, results stored, spare.
+    // The launch ramp and the rungs of the kernel's dependent chain, per workgroup (scripts/knn_stamps.py).
+    unsigned long long* stamps;
 };
+constexpr int KNN_STAMP_WORDS = 8;
 // feats_down_world = pose (x) feats_down_body as a launch of its own (large scans only; otherwise inside knn27_kernel)
 hipError_t launch_transform(const float4* body, int n, const Pose14& pose, float4* world, hipStream_t s);
 // lanes_per_query in {4, 8, 16, 32, 64}

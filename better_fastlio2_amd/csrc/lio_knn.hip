@@ -168,9 +168,19 @@ __device__ __forceinline__ bool shell_second_chance(const KnnArgs& a, float qx, 
 //        sorted list does not change the list).
 // PACK: the first search of an assisted pull (KnnArgs.pack_*) -- an instantiation of its own: compiled into every launch, the few
 // live values it adds took the kernel from eight to seven wavefronts per SIMD (+2 us per launch at C2, measured).
-template <int G, bool CENSUS, bool HINT, int U = 0, bool PACK = false>
+// STAMP: the diagnostic instantiation (KnnArgs.stamps): same code, seven wall-clock stamps per workgroup, a full wait for memory in
+// front of the stamps that close a memory phase -- never launched unless asked for (lio_debug_set "knn_stamps").
+template <int G, bool CENSUS, bool HINT, int U = 0, bool PACK = false, bool STAMP = false>
 __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     constexpr int WPB = 4;
+    unsigned long long tst[KNN_STAMP_WORDS] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    auto stamp = [&](int i, bool drain) {
+        if constexpr (STAMP) {
+            if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            tst[i] = wall_clock64();
+        }
+    };
+    stamp(0, false);
     constexpr int GPW = 64 / G;                    // queries per wavefront
     static_assert(U == 0 || ((G == 4 || G == 8 || G == 16) && !CENSUS), "prefix-form walk: 4, 8 or 16 lanes per query, no census");
     __shared__ uint2 s_bucket[WPB][GPW][U > 0 ? 32 : 28];   // LDS-staged non-empty buckets {start, count}
@@ -267,6 +277,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         const float4 w = a.world_in[q];            // world-frame query (the caller's)
         qx = w.x; qy = w.y; qz = w.z;
     }
+    stamp(1, true);
     const float inv_cell = a.grid.inv_cell;
     // cell_coord (lio_common.h) with the clamp as one v_med3_f32: the same cell for every finite coordinate and for +-inf;
     // a NaN lands in SOME valid cell instead of the middle one, which is all it needs (none of its distances is a number:
@@ -433,6 +444,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         }
     }
 
+    stamp(2, true);
     // ---- compact the non-empty buckets of each group into LDS ---------------------------------
     int n_ne = 0;
 #pragma unroll
@@ -504,6 +516,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- the walk: candidate t of the query lies in the first bucket whose cumulative count exceeds t, at map index
         // (start - candidates before) + t; lane r takes t = r, r + G, ...; U of them are fetched together
+        stamp(3, true);
         uint32_t t = (uint32_t)r;
         const uint2* cur = lst;
         uint2 bk = *cur;                                                 // (total == 0: never used)
@@ -532,6 +545,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         }
     }
 
+    stamp(4, true);
     // ---- merge the G sorted lists: five rounds of group-min + pop ------------------------------
     // lane r keeps result r (and result r + G when G < 5)
     double mine0 = Top5::none(), mine1 = Top5::none();
@@ -605,6 +619,7 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         }
     }
 
+    stamp(5, false);
     // ---- write Nearest_Points[q] ---------------------------------------------------------------
 #pragma unroll
     for (int half = 0; half < (G < K ? 2 : 1); ++half) {
@@ -645,6 +660,13 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
             if (G < K && r + G < K) dst[r + G] = (unsigned long long)__double_as_longlong(mine1);
         }
     }
+    stamp(6, true);
+    if constexpr (STAMP) {
+        if (a.stamps != nullptr && threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < KNN_STAMP_WORDS; ++i) a.stamps[(size_t)blockIdx.x * KNN_STAMP_WORDS + i] = tst[i];
+        }
+    }
     // candidate census for the byte model (opt-in: one atomic per wavefront)
     if (CENSUS) {
         uint32_t c = (active && r == 0) ? csum : 0u;
@@ -658,6 +680,13 @@ template <int G, int U>
 static void launch_knn27_gu(const KnnArgs& a, hipStream_t s, KernelTimer t) {
     const int qpb = 4 * (64 / G);                  // queries per 256-thread workgroup
     const dim3 grid((a.nq + qpb - 1) / qpb), block(256);
+    if constexpr (G == 8 && U == 4) {
+        if (a.stamps != nullptr && a.pack_src == nullptr) {      // diagnostics: the stamped instantiation
+            if (a.use_hint) hipLaunchKernelGGL((knn27_kernel<G, false, true, U, false, true>), grid, block, 0, s, a);
+            else            hipLaunchKernelGGL((knn27_kernel<G, false, false, U, false, true>), grid, block, 0, s, a);
+            return;
+        }
+    }
     if (t.start != nullptr) {
         if (a.use_hint)               hipExtLaunchKernelGGL((knn27_kernel<G, false, true, U>), grid, block, 0, s, t.start, t.stop, 0, a);
         else if (a.pack_src != nullptr) hipExtLaunchKernelGGL((knn27_kernel<G, false, false, U, true>), grid, block, 0, s, t.start, t.stop, 0, a);

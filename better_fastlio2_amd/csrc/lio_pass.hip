@@ -48,6 +48,12 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
         ka.pack_rot = pack_front / (4 * (64 / lanes)); ka.pack_mid = pack_mid;
         ka.pack_wait_out = reinterpret_cast<unsigned long long*>(c->d_small + 48);     // (bytes 192..199 of the host-mapped words)
     }
+    ka.stamps = nullptr;
+    if (c->dbg_knn_stamps && lanes == 8 && ka.walk == 4 && !c->census && ka.pack_src == nullptr) {   // diagnostics: the stamped instantiation
+        if (!c->d_knn_stamps) HIPCHK(c, hipMalloc((void**)&c->d_knn_stamps, ((size_t)c->cap_q / 32 + 1) * KNN_STAMP_WORDS * sizeof(unsigned long long)));
+        ka.stamps = c->d_knn_stamps;
+        c->knn_stamps_wgs = (nq + 31) / 32;
+    }
     HIPCHK(c, launch_knn27(ka, lanes, s, prof_timer(c, use_hint ? LIO_PROF_KNN_HINT : LIO_PROF_KNN)));
     if (walk_now) HIPCHK(c, launch_knn_tree(tree_args(c, nq, stride, nbr, cnt, ulist, useeds), s, prof_timer(c, LIO_PROF_FALLBACK)));
     return LIO_OK;
@@ -149,7 +155,8 @@ static bool walk_in_its_own_launch(const lio_ctx* c) {
 // the current one, behind a gate kernel; when the pose is known the host only writes it, with a sequence number, into the
 // gate's mail.  A wrong prediction (or the end of the update) calls the pass off: its kernels see GateState.skip and return.
 // lio_measure_begin arms the passes it expects next (arm_predicted); every other entry point that needs the stream calls them
-// off first (enter()), and a gate nobody answers gives up by itself after two seconds.
+// off first (enter()), and a wait nobody answers gives up by itself: after 10 ms inside a pass's own first kernel (every workgroup
+// of the launch waits there: it must not park the GPU), after two seconds in the one-wavefront gate kernel.
 static void gate_write(lio_ctx* c, unsigned long long mail_seq, unsigned long long cmd, const Pose14* pose) {
     unsigned long long w[16];
     w[0] = mail_seq; w[1] = cmd;

@@ -51,6 +51,7 @@ int issue_pending_upload(lio_ctx* c) {
 int lio_scan_upload_async(lio_ctx* c, const void* host_f4, int n) {
     if (!c || n < 0 || (n > 0 && !host_f4)) return LIO_ERR_INVALID_ARG;
     if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_upload_async", "n exceeds max_scan_points");
+    if (c->prep_active) return c->fail(LIO_ERR_INVALID_ARG, "lio_scan_upload_async", "the back scan buffer belongs to a running preparation (lio_scan_prep_end first)");
     for (int i = 0; i < c->gate_n; ++i) if (c->gate_q[i].next_scan) { gate_call_off(c); break; }   // (armed on the buffer this upload replaces)
     // The copy is issued by the next measurement pass right behind its kernel launches (the runtime calls then run
     // beside the GPU's work), or by lio_scan_swap if no pass comes first.
@@ -87,12 +88,14 @@ static int ensure_raw_buffers(lio_ctx* c, size_t n) {
     if (!c->d_imu_poses) HIPCHK(c, hipMalloc((void**)&c->d_imu_poses, 512 * 22 * sizeof(double)));
     if (!c->d_vox) HIPCHK(c, hipMalloc((void**)&c->d_vox, 2 * sizeof(VoxelGridDev)));
     if (n <= c->cap_raw) return LIO_OK;
-    void* old[] = {c->d_raw, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
+    void* old[] = {c->d_raw, c->d_raw_back, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
                    c->d_raw_order2, c->d_leaf_count, c->d_leaf_start};
-    for (void* p : old) if (p) (void)hipFree(p);
-    c->d_raw = c->d_undist = c->d_leafpts = nullptr; c->d_raw_keys = c->d_raw_keys2 = c->d_leaf_keys = nullptr;
+    for (void* p : old) if (p) (void)hipFree(p);           // (hipFree waits for the device: nothing in flight reads them)
+    c->raw_prefetched = false;
+    c->d_raw = c->d_raw_back = c->d_undist = c->d_leafpts = nullptr; c->d_raw_keys = c->d_raw_keys2 = c->d_leaf_keys = nullptr;
     c->d_raw_order = c->d_raw_order2 = c->d_leaf_count = c->d_leaf_start = nullptr; c->cap_raw = 0;
     HIPCHK(c, hipMalloc((void**)&c->d_raw, n * sizeof(float4)));
+    HIPCHK(c, hipMalloc((void**)&c->d_raw_back, n * sizeof(float4)));     // destination of lio_scan_prefetch_raw
     HIPCHK(c, hipMalloc((void**)&c->d_undist, n * sizeof(float4)));
     HIPCHK(c, hipMalloc((void**)&c->d_leafpts, n * sizeof(float4)));
     HIPCHK(c, hipMalloc((void**)&c->d_raw_keys, n * sizeof(uint64_t)));
@@ -119,12 +122,25 @@ int lio_scan_upload_raw(lio_ctx* c, const float* raw_pts, int n, int stride_byte
     enter(c);
     if ((size_t)n > c->temp_bytes / 16) return c->fail(LIO_ERR_CAPACITY, "lio_scan_undistort", "raw scan larger than the sort workspace");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
+    hipStream_t s = c->prep_active ? c->prep_stream : c->stream;      // (lio_scan_prep_begin: the preparation runs on a stream of its own)
     int rc = ensure_raw_buffers(c, (size_t)(n > 0 ? n : 1));
     if (rc != LIO_OK) return rc;
     c->n_raw = n; c->have_raw = false; c->raw_uploaded = true;
     c->raw_time_keyed = time_offset_bytes >= 0;
     if (n == 0) return LIO_OK;
+    if (c->raw_prefetched) {
+        // the sweep is already on its way (lio_scan_prefetch_raw, copy stream): take the buffer it went to
+        const bool hit = c->raw_prefetch_src == raw_pts && c->raw_prefetch_n == n && time_offset_bytes == 12 && stride_bytes == 16;
+        c->raw_prefetched = false;
+        if (hit) {
+            const hipError_t q = hipEventQuery(c->ev_raw);
+            if (q == hipErrorNotReady) HIPCHK(c, hipStreamWaitEvent(s, c->ev_raw, 0));
+            else if (q != hipSuccess) return c->fail(LIO_ERR_HIP, "lio_scan_upload_raw (prefetched sweep)", hipGetErrorString(q));
+            float4* t = c->d_raw; c->d_raw = c->d_raw_back; c->d_raw_back = t;
+            ++c->n_raw_prefetch_hits;
+            return LIO_OK;
+        }
+    }
     rc = ensure_stage(c, (size_t)n + POSE_STAGE_SLOTS);                        // the IMU poses travel behind the points
     if (rc != LIO_OK) return rc;
     const char* src = reinterpret_cast<const char*>(raw_pts);
@@ -159,7 +175,7 @@ int lio_scan_compensate(lio_ctx* c, const lio_pose6d* imu_poses, int n_poses, co
     if (!c->raw_uploaded) return c->fail(LIO_ERR_NO_SCAN, "lio_scan_compensate", "no raw scan uploaded");
     if (n_poses > 0 && !c->raw_time_keyed) return LIO_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
+    hipStream_t s = c->prep_active ? c->prep_stream : c->stream;
     const int n = c->n_raw;
     c->have_raw = true;
     if (n == 0) return LIO_OK;
@@ -217,94 +233,258 @@ static int sort_undistorted_by_time(lio_ctx* c) {
 // downSizeFilterSurf.setInputCloud(feats_undistort); downSizeFilterSurf.filter(*feats_down_body)
 // (src/laserMapping.cpp:2322-2323): pcl::VoxelGrid on the cloud left by lio_scan_undistort; the centroids
 // become the current scan (as lio_scan_set would).
+//
+// One pass over the stream, one read-back at the end: getMinMax3D, min_b_/divb_mul_, the leaf index of every
+// point, a stable sort by leaf, the run heads and the centroids all stay on the device (VoxelGridDev).
+// A sweep between the single-launch sort's range and the group sort's (16 k ... 256 k points: every real one) whose points
+// already come in time order -- most drivers deliver them so -- needs no time key: a STABLE sort by the leaf index alone is
+// the sort by (leaf, time, input order).  That key has ~22 bits instead of 64: three stable 8-bit splits (lio_gsort.hip, LSD
+// form) instead of the library's ten merge launches.  Whether THIS sweep is in order, and how wide its leaf index is, only
+// the device knows (minmax_kernel checks the order while it reads the points): the host PREDICTS both from the previous sweep,
+// enqueues the whole filter without waiting, and finds the verdict in the read-back at the end; a wrong prediction (the first
+// out-of-order sweep of a driver, a sweep whose extent needs another digit) is followed by the filter on the general path.
+static void voxel_plan(lio_ctx* c, VoxelRun& r, float leaf_size) {
+    r.n = c->n_raw; r.leaf = leaf_size;
+    r.time_minor = c->raw_time_keyed && !c->undist_sorted;     // the cloud is not KNOWN to be in time order
+    r.may_compact = !c->dbg_library_sort && c->dbg_voxel_fast && (size_t)r.n > SORT_MAX_ITEMS && (uint32_t)r.n <= GSORT_MAX;
+    r.compact = r.may_compact && !(r.time_minor && c->vox_saw_unsorted);
+    r.max_leaves = (uint32_t)r.n < (uint32_t)c->cap_q + 1u ? (uint32_t)r.n : (uint32_t)c->cap_q + 1u;
+}
+// the stamped scratch of the single-launch scans / the LSD sort: the context's own, or the preparation stream's (lio_scan_prep_begin:
+// the map update may run its own stamped launches on the main stream at the same time)
+static uint32_t voxel_compact_stamp(lio_ctx* c, bool prep, hipStream_t s, unsigned long long** agg) {
+    if (!prep) { *agg = c->d_cagg; return next_compact_stamp(c); }
+    *agg = c->d_cagg_prep;
+    if (++c->compact_seq_prep == 0u) {
+        (void)hipMemsetAsync(c->d_cagg_prep, 0, COMPACT_AGG_WORDS * sizeof(unsigned long long), s);
+        ++c->compact_seq_prep;
+    }
+    return c->compact_seq_prep;
+}
+// one attempt of the filter on stream s, centroids into out_body; nothing waits
+static int voxel_enqueue(lio_ctx* c, VoxelRun& r, hipStream_t s, bool prep, float4* out_body) {
+    const int n = r.n;
+    VoxelGridDev* vox = c->d_vox + c->vox_cur;
+    VoxelGridDev* vox_next = c->d_vox + (c->vox_cur ^ 1);
+    r.vox = vox;
+    if (!c->vox_clean[c->vox_cur]) HIPCHK(c, hipMemsetAsync(vox, 0, sizeof(VoxelGridDev), s));
+    c->vox_clean[c->vox_cur] = false;
+    c->vox_clean[c->vox_cur ^ 1] = false;                           // (until the centroid launch below is known to be enqueued)
+    // inverse_leaf_size_ = 1 / leaf_size_; the order of the points is checked whenever it matters for the next prediction
+    HIPCHK(c, launch_minmax_params(c->d_undist, n, vox, 1.0f / r.leaf, r.may_compact && r.time_minor, s));
+    unsigned long long* agg = nullptr;
+    if (r.compact) {
+        r.passes = c->vox_passes_guess;
+        ++c->n_voxel_fast;
+        unsigned long long* gagg = prep ? c->d_gagg_prep : c->d_gagg;
+        uint32_t& gseq = prep ? c->gsort_seq_prep : c->gsort_seq;
+        if (gseq + (uint32_t)r.passes < gseq || gseq + (uint32_t)r.passes == 0xffffffffu) {   // (stamp wrap-around: as run_sort)
+            HIPCHK(c, hipMemsetAsync(gagg, 0, GSORT_AGG_WORDS * sizeof(unsigned long long), s));
+            gseq = 0u;
+        }
+        HIPCHK(c, launch_voxel_index_compact(c->d_undist, n, vox, c->d_raw_keys, s));
+        GsortLsdArgs g{};
+        g.keys = c->d_raw_keys; g.n = (uint32_t)n; g.kb = 8 * r.passes; g.passes = r.passes; g.keys_out = c->d_raw_keys2; g.vals_out = c->d_raw_order2;
+        g.part = c->d_leaf_keys; g.part2 = reinterpret_cast<uint64_t*>(c->d_leafpts);  // (scratch of this call: 8 and 16 bytes per point)
+        g.hist = &vox->hist[0][0]; g.agg = gagg; g.stamp0 = gseq + 1u; g.err = &vox->summary[3];
+        gseq += (uint32_t)r.passes;
+        HIPCHK(c, launch_gsort_lsd(g, s));
+        const uint32_t stamp = voxel_compact_stamp(c, prep, s, &agg);
+        HIPCHK(c, launch_run_heads(c->d_raw_keys2, (uint32_t)n, 0, c->d_leaf_start, &vox->n_leaves, agg, stamp, &vox->summary[3], s));
+    } else {
+        HIPCHK(c, launch_voxel_index(c->d_undist, n, vox, r.time_minor, c->d_raw_keys, c->d_raw_order, s));
+        HIPCHK(c, sort_pairs_any(c, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s, &vox->summary[3]));
+        if (compact_small(c, (size_t)n)) {
+            const uint32_t stamp = voxel_compact_stamp(c, prep, s, &agg);
+            HIPCHK(c, launch_run_heads(c->d_raw_keys2, (uint32_t)n, 32, c->d_leaf_start, &vox->n_leaves, agg, stamp, &vox->summary[3], s));
+        } else {
+            HIPCHK(c, select_run_heads_u64(c->d_temp, c->temp_bytes, c->d_raw_keys2, (size_t)n, c->d_leaf_start, &vox->n_leaves, s));
+        }
+    }
+    HIPCHK(c, launch_centroids(c->d_undist, c->d_raw_order2, c->d_raw_keys2, c->d_leaf_start, vox, (uint32_t)n, r.max_leaves,
+                               (uint32_t)c->cap_q, out_body, s, r.compact, vox_next));
+    c->vox_clean[c->vox_cur ^ 1] = true;                            // (cleared by the centroid kernel)
+    c->vox_cur ^= 1;
+    static_assert(offsetof(VoxelGridDev, probe) == offsetof(VoxelGridDev, summary) + 4 * sizeof(uint32_t), "summary and probe are read together");
+    return LIO_OK;
+}
+// the verdict of an attempt: *redo = the prediction was wrong, r is set up for the next attempt
+static int voxel_judge(lio_ctx* c, VoxelRun& r, const uint32_t summary[6], int attempt, bool* redo) {
+    *redo = false;
+    if (summary[3] != 0u) return c->fail(LIO_ERR_HIP, "lio_scan_voxel_filter", "a bounded wait of a sort / compaction kernel ran out");
+    if (r.may_compact && r.time_minor) c->vox_saw_unsorted = summary[4] != 0u;            // what the next sweep is taken for
+    if (!r.compact || summary[2] != 0u) return LIO_OK;             // (an empty / overflowing grid: nothing was sorted, nothing to redo)
+    const int need = ((int)summary[5] + 7) / 8;
+    const bool wrong = (r.time_minor && summary[4] != 0u) || need > r.passes;
+    if (need >= 1 && need <= 4) c->vox_passes_guess = need;
+    if (!wrong) return LIO_OK;
+    ++c->n_voxel_redone;
+    if (attempt >= 2) return c->fail(LIO_ERR_HIP, "lio_scan_voxel_filter", "the sort prediction failed three times on one sweep");
+    r.compact = !(r.time_minor && summary[4] != 0u);               // out of order: the general path; too few digits: again with `need`
+    *redo = true;
+    return LIO_OK;
+}
+// the filtered cloud in `out_body` (== c->d_body, or the back buffer that is then swapped in) becomes the current scan
+static int voxel_adopt(lio_ctx* c, const uint32_t summary[6], float4* out_body, int* n_out) {
+    if (summary[2] & VOX_OVERFLOW)
+        return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "leaf size too small for the extent of the scan (index overflow, as in PCL)");
+    if (out_body != c->d_body) { float4* t = c->d_body; c->d_body = c->d_body_back; c->d_body_back = t; }
+    if (summary[2] & VOX_EMPTY) return scan_reset(c, 0);            // no finite point
+    const uint32_t n_real = summary[0] - summary[1];                 // the run of dropped (non-finite) points is last
+    if ((int)n_real > c->cap_q) {
+        c->have_scan = false;                                        // the scan buffer holds a truncated result
+        return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "down-sampled scan exceeds max_scan_points");
+    }
+    if (n_out) *n_out = (int)n_real;
+    return scan_reset(c, (int)n_real);
+}
+// the whole filter on the main stream, attempts and all (out_body: c->d_body, or c->d_body_back at the end of an asynchronous preparation)
+static int voxel_filter_sync(lio_ctx* c, VoxelRun& r, float4* out_body, int first_attempt, int* n_out) {
+    uint32_t summary[6] = {0, 0, 0, 0, 0, 0};
+    for (int attempt = first_attempt; ; ++attempt) {
+        int rc = voxel_enqueue(c, r, c->stream, false, out_body);
+        if (rc != LIO_OK) return rc;
+        HIPCHK(c, read_back(c, summary, r.vox->summary, sizeof(summary)));
+        bool redo = false;
+        rc = voxel_judge(c, r, summary, attempt, &redo);
+        if (rc != LIO_OK) return rc;
+        if (!redo) break;
+    }
+    return voxel_adopt(c, summary, out_body, n_out);
+}
+
 int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
     if (!c || !(leaf_size > 0.0f)) return LIO_ERR_INVALID_ARG;
     enter(c);
     if (n_out) *n_out = 0;
     if (!c->have_raw) return c->fail(LIO_ERR_NO_SCAN, "lio_scan_voxel_filter", "no raw scan (lio_scan_undistort first)");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
     const int n = c->n_raw;
+    if (c->prep_active) {
+        // asynchronous preparation: the filter is enqueued on the preparation stream (its summary goes to a mail box of its own,
+        // its centroids to the back scan buffer) and the call returns; lio_scan_prep_end reads the verdict and swaps the scan in.
+        // The general path (tiny sweeps, sweeps out of time order) may use the library's workspace, which the map update on the main
+        // stream uses too: such a sweep is filtered by lio_scan_prep_end instead.
+        if (c->prep_filtered) return c->fail(LIO_ERR_INVALID_ARG, "lio_scan_voxel_filter", "one filter per lio_scan_prep_begin");
+        c->prep_filtered = true; c->prep_enqueued = false;
+        voxel_plan(c, c->prep_run, leaf_size);
+        if (n_out) *n_out = -1;                                     // (known at lio_scan_prep_end)
+        if (n == 0 || !c->prep_run.compact) return LIO_OK;
+        const int rc = voxel_enqueue(c, c->prep_run, c->prep_stream, true, c->d_body_back);
+        if (rc != LIO_OK) return rc;
+        HIPCHK(c, launch_publish_words(c->prep_run.vox->summary, 6, c->d_small3, ++c->small3_seq, c->prep_stream));
+        c->prep_enqueued = true;
+        return LIO_OK;
+    }
     if (n == 0) return scan_reset(c, 0);
-    // One pass over the stream, one read-back at the end: getMinMax3D, min_b_/divb_mul_, the leaf index of every
-    // point, a stable sort by leaf, the run heads and the centroids all stay on the device (VoxelGridDev).
-    const bool time_minor = c->raw_time_keyed && !c->undist_sorted;     // the cloud is not KNOWN to be in time order
-    // A sweep between the single-launch sort's range and the group sort's (16 k ... 256 k points: every real one) whose points
-    // already come in time order -- most drivers deliver them so -- needs no time key: a STABLE sort by the leaf index alone is
-    // the sort by (leaf, time, input order).  That key has ~22 bits instead of 64: three stable 8-bit splits (lio_gsort.hip, LSD
-    // form) instead of the library's ten merge launches.  Whether THIS sweep is in order, and how wide its leaf index is, only
-    // the device knows (minmax_kernel checks the order while it reads the points): the host PREDICTS both from the previous sweep,
-    // enqueues the whole filter without waiting, and finds the verdict in the read-back at the end; a wrong prediction (the first
-    // out-of-order sweep of a driver, a sweep whose extent needs another digit) is followed by the filter on the general path.
-    const bool may_compact = !c->dbg_library_sort && c->dbg_voxel_fast && (size_t)n > SORT_MAX_ITEMS && (uint32_t)n <= GSORT_MAX;
-    bool compact = may_compact && !(time_minor && c->vox_saw_unsorted);
-    const uint32_t max_leaves = (uint32_t)n < (uint32_t)c->cap_q + 1u ? (uint32_t)n : (uint32_t)c->cap_q + 1u;
-    uint32_t summary[6] = {0, 0, 0, 0, 0, 0};
-    for (int attempt = 0; ; ++attempt) {
-        VoxelGridDev* vox = c->d_vox + c->vox_cur;
-        VoxelGridDev* vox_next = c->d_vox + (c->vox_cur ^ 1);
-        if (!c->vox_clean[c->vox_cur]) HIPCHK(c, hipMemsetAsync(vox, 0, sizeof(VoxelGridDev), s));
-        c->vox_clean[c->vox_cur] = false;
-        c->vox_clean[c->vox_cur ^ 1] = false;                           // (until the centroid launch below is known to be enqueued)
-        // inverse_leaf_size_ = 1 / leaf_size_; the order of the points is checked whenever it matters for the next prediction
-        HIPCHK(c, launch_minmax_params(c->d_undist, n, vox, 1.0f / leaf_size, may_compact && time_minor, s));
-        int passes = 0;
-        if (compact) {
-            passes = c->vox_passes_guess;
-            ++c->n_voxel_fast;
-            if (c->gsort_seq + (uint32_t)passes < c->gsort_seq || c->gsort_seq + (uint32_t)passes == 0xffffffffu) {   // (stamp wrap-around: as run_sort)
-                HIPCHK(c, hipMemsetAsync(c->d_gagg, 0, GSORT_AGG_WORDS * sizeof(unsigned long long), s));
-                c->gsort_seq = 0u;
+    VoxelRun r;
+    voxel_plan(c, r, leaf_size);
+    return voxel_filter_sync(c, r, c->d_body, 0, n_out);
+}
+
+// ---- asynchronous scan preparation: scan k + 1 is compensated and filtered BESIDE the map update of scan k -----------------------
+// (the node's loop body, laserMapping.cpp:2256-2401: Process -> voxel filter -> update -> map_incremental -> lasermap_fov_segment;
+// the last two of scan k and the first two of scan k + 1 depend on nothing of each other but the posterior of scan k.)
+//   lio_scan_prefetch_raw(ctx, sweep)      the moment the driver has the sweep: copy engine -> a second raw buffer (copy stream)
+//   lio_scan_prep_begin(ctx)               from here on lio_scan_upload_raw / _compensate / _voxel_filter (through lio_imu_process or
+//                                          directly) only ENQUEUE, on a stream of their own with their own stamped scratch
+//   ... lio_map_incremental / lio_fov_segment of scan k on the main stream, as ever (they read scan k: untouched) ...
+//   lio_scan_prep_end(ctx, &n)             the filter's verdict (already there), the filtered cloud becomes the current scan
+// Same kernels, same order per stream, same values: the preparation writes the back scan buffer, the map update reads the front one.
+static int ensure_prep(lio_ctx* c) {
+    if (!c->prep_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking));
+    if (!c->ev_raw) HIPCHK(c, hipEventCreateWithFlags(&c->ev_raw, hipEventDisableTiming));
+    if (!c->h_small3) {
+        HIPCHK(c, hipHostMalloc(&c->h_small3, 256, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(c->h_small3, 0, 256);
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_small3, c->h_small3, 0));
+    }
+    if (!c->d_cagg_prep) {
+        HIPCHK(c, hipMalloc((void**)&c->d_cagg_prep, COMPACT_AGG_WORDS * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemset(c->d_cagg_prep, 0, COMPACT_AGG_WORDS * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc((void**)&c->d_gagg_prep, GSORT_AGG_WORDS * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemset(c->d_gagg_prep, 0, GSORT_AGG_WORDS * sizeof(unsigned long long)));
+    }
+    return LIO_OK;
+}
+int lio_scan_prefetch_raw(lio_ctx* c, const float* raw_pts, int n, int stride_bytes, int time_offset_bytes) {
+    if (!c || n < 0 || (n > 0 && !raw_pts)) return LIO_ERR_INVALID_ARG;
+    // a hint: only x, y, z, t records in page-locked memory can be read in place by the copy engine; anything else is uploaded
+    // by lio_scan_upload_raw as before
+    if (n == 0 || stride_bytes != 16 || time_offset_bytes != 12 || (size_t)n > c->temp_bytes / 16 || c->prep_active || !is_pinned_host(raw_pts)) return LIO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_prep(c);
+    if (rc != LIO_OK) return rc;
+    if ((size_t)n > c->cap_raw) {
+        enter(c);                               // (the buffers are re-allocated: nothing may be armed on them)
+        rc = ensure_raw_buffers(c, (size_t)n);
+        if (rc != LIO_OK) return rc;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_raw_back, raw_pts, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(c, hipEventRecord(c->ev_raw, c->copy_stream));
+    c->raw_prefetched = true; c->raw_prefetch_src = raw_pts; c->raw_prefetch_n = n;
+    return LIO_OK;
+}
+int lio_scan_prep_begin(lio_ctx* c) {
+    if (!c) return LIO_ERR_INVALID_ARG;
+    enter(c);
+    if (c->prep_active) return c->fail(LIO_ERR_INVALID_ARG, "lio_scan_prep_begin", "a preparation is already running (lio_scan_prep_end)");
+    if (c->upload_pending || c->nq_back >= 0)
+        return c->fail(LIO_ERR_INVALID_ARG, "lio_scan_prep_begin", "the back scan buffer holds a scan handed over with lio_scan_upload_async");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = ensure_prep(c);
+    if (rc != LIO_OK) return rc;
+    c->prep_active = true; c->prep_filtered = false; c->prep_enqueued = false;
+    return LIO_OK;
+}
+int lio_scan_prep_end(lio_ctx* c, int* n_out) {
+    if (!c) return LIO_ERR_INVALID_ARG;
+    if (n_out) *n_out = 0;
+    if (!c->prep_active) return c->fail(LIO_ERR_INVALID_ARG, "lio_scan_prep_end", "no preparation is running (lio_scan_prep_begin)");
+    enter(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    c->prep_active = false;
+    if (!c->prep_filtered) {                    // (only the upload / the compensation ran there)
+        HIPCHK(c, hipStreamSynchronize(c->prep_stream));
+        return LIO_OK;
+    }
+    c->prep_filtered = false;
+    if (!c->have_raw) return c->fail(LIO_ERR_NO_SCAN, "lio_scan_prep_end", "no raw scan (lio_scan_undistort first)");
+    VoxelRun& r = c->prep_run;
+    if (r.n == 0) { HIPCHK(c, hipStreamSynchronize(c->prep_stream)); return scan_reset(c, 0); }
+    if (!c->prep_enqueued) {
+        // the general path was predicted: the filter runs here, on the main stream, behind everything of the preparation stream
+        HIPCHK(c, hipStreamSynchronize(c->prep_stream));
+        return voxel_filter_sync(c, r, c->d_body_back, 0, n_out);
+    }
+    // the summary of the filter is the last thing the preparation stream does: when its word is there, everything before it is done
+    {
+        const uint32_t seq = c->small3_seq;
+        volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(c->h_small3) + 32;
+        for (uint64_t spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spins) {
+            if ((spins & 0xfffffu) == 0xfffffu) {
+                const hipError_t q = hipStreamQuery(c->prep_stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return c->fail(LIO_ERR_HIP, "lio_scan_prep_end", hipGetErrorString(q));
+                if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return c->fail(LIO_ERR_HIP, "lio_scan_prep_end", "the preparation stream is idle but its summary never arrived");
             }
-            HIPCHK(c, launch_voxel_index_compact(c->d_undist, n, vox, c->d_raw_keys, s));
-            GsortLsdArgs g{};
-            g.keys = c->d_raw_keys; g.n = (uint32_t)n; g.kb = 8 * passes; g.passes = passes; g.keys_out = c->d_raw_keys2; g.vals_out = c->d_raw_order2;
-            g.part = c->d_leaf_keys; g.part2 = reinterpret_cast<uint64_t*>(c->d_leafpts);  // (scratch of this call: 8 and 16 bytes per point)
-            g.hist = &vox->hist[0][0]; g.agg = c->d_gagg; g.stamp0 = c->gsort_seq + 1u; g.err = &vox->summary[3];
-            c->gsort_seq += (uint32_t)passes;
-            HIPCHK(c, launch_gsort_lsd(g, s));
-            HIPCHK(c, launch_run_heads(c->d_raw_keys2, (uint32_t)n, 0, c->d_leaf_start, &vox->n_leaves, c->d_cagg, next_compact_stamp(c), &vox->summary[3], s));
-        } else {
-            HIPCHK(c, launch_voxel_index(c->d_undist, n, vox, time_minor, c->d_raw_keys, c->d_raw_order, s));
-            HIPCHK(c, sort_pairs_any(c, c->d_raw_keys, c->d_raw_keys2, c->d_raw_order, c->d_raw_order2, (size_t)n, s, &vox->summary[3]));
-            if (compact_small(c, (size_t)n))
-                HIPCHK(c, launch_run_heads(c->d_raw_keys2, (uint32_t)n, 32, c->d_leaf_start, &vox->n_leaves, c->d_cagg, next_compact_stamp(c), &vox->summary[3], s));
-            else
-                HIPCHK(c, select_run_heads_u64(c->d_temp, c->temp_bytes, c->d_raw_keys2, (size_t)n, c->d_leaf_start, &vox->n_leaves, s));
+            __builtin_ia32_pause();
         }
-        HIPCHK(c, launch_centroids(c->d_undist, c->d_raw_order2, c->d_raw_keys2, c->d_leaf_start, vox, (uint32_t)n, max_leaves,
-                                   (uint32_t)c->cap_q, c->d_body, s, compact, vox_next));
-        c->vox_clean[c->vox_cur ^ 1] = true;                            // (cleared by the centroid kernel)
-        c->vox_cur ^= 1;
-        static_assert(offsetof(VoxelGridDev, probe) == offsetof(VoxelGridDev, summary) + 4 * sizeof(uint32_t), "summary and probe are read together");
-        HIPCHK(c, read_back(c, summary, vox->summary, sizeof(summary)));
-        if (summary[3] != 0u) return c->fail(LIO_ERR_HIP, "lio_scan_voxel_filter", "a bounded wait of a sort / compaction kernel ran out");
-        if (may_compact && time_minor) c->vox_saw_unsorted = summary[4] != 0u;            // what the next sweep is taken for
-        if (!compact || summary[2] != 0u) break;                        // (an empty / overflowing grid: nothing was sorted, nothing to redo)
-        const int need = ((int)summary[5] + 7) / 8;
-        const bool wrong = (time_minor && summary[4] != 0u) || need > passes;
-        if (need >= 1 && need <= 4) c->vox_passes_guess = need;
-        if (!wrong) break;
-        ++c->n_voxel_redone;
-        if (attempt >= 2) return c->fail(LIO_ERR_HIP, "lio_scan_voxel_filter", "the sort prediction failed three times on one sweep");
-        compact = !(time_minor && summary[4] != 0u);                    // out of order: the general path; too few digits: again with `need`
     }
-    if (summary[2] & VOX_OVERFLOW)
-        return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "leaf size too small for the extent of the scan (index overflow, as in PCL)");
-    if (summary[2] & VOX_EMPTY) return scan_reset(c, 0);                // no finite point
-    const uint32_t n_real = summary[0] - summary[1];                     // the run of dropped (non-finite) points is last
-    if ((int)n_real > c->cap_q) {
-        c->have_scan = false;                                            // the scan buffer holds a truncated result
-        return c->fail(LIO_ERR_CAPACITY, "lio_scan_voxel_filter", "down-sampled scan exceeds max_scan_points");
-    }
-    if (n_out) *n_out = (int)n_real;
-    return scan_reset(c, (int)n_real);
+    uint32_t summary[6];
+    std::memcpy(summary, c->h_small3, sizeof(summary));
+    bool redo = false;
+    int rc = voxel_judge(c, r, summary, 0, &redo);
+    if (rc != LIO_OK) return rc;
+    if (redo) return voxel_filter_sync(c, r, c->d_body_back, 1, n_out);   // (a wrong prediction: once more, here)
+    ++c->n_prep_overlapped;
+    return voxel_adopt(c, summary, c->d_body_back, n_out);
 }
 
 // which = 0: feats_undistort (time-sorted, compensated); 1: the current scan (feats_down_body)
 int lio_scan_get_cloud(lio_ctx* c, int which, float* out_xyz, int cap, int* n) {
     if (!c || (which != 0 && which != 1) || cap < 0 || (cap > 0 && !out_xyz)) return LIO_ERR_INVALID_ARG;
     enter(c);
+    if (which == 0 && c->prep_active) return c->fail(LIO_ERR_INVALID_ARG, "lio_scan_get_cloud", "feats_undistort is being prepared (lio_scan_prep_end first)");
     if (which == 0 && c->have_raw) {
         HIPCHK(c, hipSetDevice(c->device));
         const int rc0 = sort_undistorted_by_time(c);

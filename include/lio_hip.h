@@ -264,6 +264,21 @@ int  lio_scan_compensate(lio_ctx* ctx, const lio_pose6d* imu_poses, int n_poses,
  * of every occupied leaf, ascending leaf index; the result becomes the current scan (feats_down_body),
  * exactly as if it had been passed to lio_scan_set.  *n_out = feats_down_size.                             */
 int  lio_scan_voxel_filter(lio_ctx* ctx, float leaf_size, int* n_out);
+/* The node's loop body overlapped (laserMapping.cpp:2256-2401): Process + voxel filter of scan k + 1 depend on nothing of
+ * map_incremental / lasermap_fov_segment of scan k but the posterior both start from.
+ *   lio_scan_prefetch_raw   a hint, the moment the driver has the sweep: x, y, z, t records (stride 16, time at byte 12) in page-locked
+ *                           memory start their way to the GPU on the copy stream; the lio_scan_upload_raw / lio_imu_process call that
+ *                           names the same records then takes them where they are.  Anything else: LIO_OK, nothing happens.
+ *   lio_scan_prep_begin     from here to lio_scan_prep_end, lio_scan_upload_raw / lio_scan_compensate / lio_scan_undistort /
+ *                           lio_imu_process / lio_scan_voxel_filter only ENQUEUE -- on a stream of their own, into the back scan buffer;
+ *                           lio_scan_voxel_filter answers *n_out = -1.  Map calls (lio_map_incremental, lio_fov_segment, ...) and
+ *                           read-outs of the CURRENT scan go on as ever on the main stream meanwhile.  Not together with
+ *                           lio_scan_upload_async / lio_eskf_scan_step_pipelined (they use the same back buffer).
+ *   lio_scan_prep_end       waits for the preparation (usually done), the filtered cloud becomes the current scan (as the synchronous
+ *                           lio_scan_voxel_filter leaves it), *n_out = its points.  Same values as the synchronous calls.               */
+int  lio_scan_prefetch_raw(lio_ctx* ctx, const float* raw_pts, int n, int stride_bytes, int time_offset_bytes);
+int  lio_scan_prep_begin(lio_ctx* ctx);
+int  lio_scan_prep_end(lio_ctx* ctx, int* n_out);
 /* which = 0: feats_undistort, 1: the current scan; xyz packed, *n = number of points available.            */
 int  lio_scan_get_cloud(lio_ctx* ctx, int which, float* out_xyz, int cap, int* n);
 
@@ -347,6 +362,11 @@ int  lio_debug_get(lio_ctx* ctx, const char* key, long long* value);
  * published, [2] group folded, [3] grid folded, [4] the listed queries' terms folded (search passes that list any),
  * [5] unused, [6] sums final, [7] record written (diagnostics)                                                          */
 int  lio_debug_stamps(lio_ctx* ctx, unsigned long long out8[8]);
+/* lio_debug_set("knn_stamps", 1): searches of 8 lanes per query run a STAMPED instantiation of the k-NN kernel (diagnostics only: it
+ * drains memory in front of every stamp).  Returns the stamps of the last such launch, eight wall_clock64 words (100 MHz) per
+ * workgroup: [0] entry, [1] query known (transform + barrier), [2] directory records arrived, [3] bucket list in prefix form,
+ * [4] candidates walked, [5] merged + proven, [6] results stored, [7] unused.  out == NULL / cap_words == 0: the count only.   */
+int  lio_debug_knn_stamps(lio_ctx* ctx, unsigned long long* out, long long cap_words, int* n_workgroups);
 /* accumulated milliseconds and launch count of one kernel family since the last reset             */
 int  lio_profile_get(lio_ctx* ctx, int which, double* total_ms, long long* launches);
 

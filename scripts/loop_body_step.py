@@ -63,6 +63,92 @@ for it in range(n_scans + 4):
         nq_list.append(nq)
         assert ready
 print("raw %d pts -> feats_down %d pts (voxel 0.5 m); map %d -> %d points" % (n_raw, int(np.median(nq_list)), nm, ctx.map_validnum()))
+print("SERIAL loop, a synchronisation behind every stage (stage attribution):")
 for k, v in stages.items():
     print("  %-16s median %8.1f us   (p90 %8.1f)" % (k, np.median(v), np.percentile(v, 90)))
 print("LOOP BODY: %.0f scans/s on one GPU (median of %d scans)" % (1e6 / np.median(stages["total"]), len(nq_list)))
+
+# ---- the same loop body as a node that keeps going would run it: no synchronisation between the stages, arguments converted once
+# (the reference's host is C++), first in the reference's own order, then OVERLAPPED: sweep k + 1 is prefetched by the copy engine
+# while scan k is processed (lio_scan_prefetch_raw: the moment a driver has the sweep) and compensated + voxel-filtered on a stream
+# of its own beside map_incremental / lasermap_fov_segment of scan k (lio_scan_prep_begin / _end) -------------------------------------
+import ctypes as C
+L = ctx.L
+na, nb, cnt, nbx, ndl, und, nout = (C.c_int(0) for _ in range(7))
+boxes = np.zeros((3, 6), np.float32)
+x26 = np.zeros(26)
+x26_p = x26.ctypes.data_as(C.c_void_p)
+ulog = capi.lio_update_log()
+P0 = np.ascontiguousarray(synth.init_cov(), np.float64)
+priors = []
+for it in range(len(scans)):
+    pos, rot = synth.perturb_state(scans[it][0], seed=100 + it)
+    priors.append((np.asarray(pos, np.float64), np.asarray(rot, np.float64)))
+smp_all = [np.ascontiguousarray(samples(0.1 * (it + 1), 0.1 * (it + 1) + 0.1), np.float64) for it in range(n_scans + 8)]
+voxel_d, leaf = C.c_double(0.2), C.c_float(0.5)
+pos3 = np.zeros(3)
+
+
+def imu_process(it):
+    sc, raw = scans[it % len(scans)]
+    beg = 0.1 * (it + 1)
+    smp = smp_all[it]
+    rc = imu.L.lio_imu_process(imu.h, kf.h, ctx.h, beg, beg + 0.099, raw.ctypes.data_as(C.c_void_p), len(raw), 16, 12,
+                               smp.ctypes.data_as(C.c_void_p), len(smp), C.byref(und))
+    assert rc == 0 and und.value, (rc, L.lio_last_error(ctx.h))
+
+
+def put_prior(it):
+    # the stationary IMU stream moved nothing: the prior back at the scan's pose (the scans are independent poses)
+    L.lio_eskf_get_x(kf.h, x26_p)
+    x26[0:3], x26[3:7] = priors[it % len(scans)]
+    x26[14:17] = 0.0
+    L.lio_eskf_change_x(kf.h, x26_p)
+    L.lio_eskf_change_P(kf.h, P0.ctypes.data_as(C.c_void_p))
+
+
+def update_and_map(it, overlapped):
+    rc = L.lio_eskf_update_iterated_dyn_share_modified(kf.h, ctx.h, C.c_double(0.001), 0, C.byref(ulog))
+    assert rc == 0, L.lio_last_error(ctx.h)
+    L.lio_eskf_get_x(kf.h, x26_p)
+    post = x26.copy()
+    if overlapped and it + 1 < n_total:
+        # scan k + 1's preparation goes onto its own stream now (its sweep was prefetched during scan k's update) ...
+        rc = L.lio_scan_prep_begin(ctx.h); assert rc == 0, L.lio_last_error(ctx.h)
+        imu_process(it + 1)
+        rc = L.lio_scan_voxel_filter(ctx.h, leaf, C.byref(nout)); assert rc == 0, L.lio_last_error(ctx.h)
+    # ... and scan k's map maintenance runs beside it
+    rc = L.lio_map_incremental(ctx.h, post.ctypes.data_as(C.c_void_p), voxel_d, 1, 1, None, C.byref(na), None, C.byref(nb), C.byref(cnt))
+    assert rc == 0, L.lio_last_error(ctx.h)
+    pos3[:] = post[0:3]
+    rc = L.lio_fov_segment(ctx.h, pos3.ctypes.data_as(C.c_void_p), C.c_double(1000.0), C.c_float(100.0), boxes.ctypes.data_as(C.c_void_p), C.byref(nbx), C.byref(ndl))
+    assert rc == 0, L.lio_last_error(ctx.h)
+
+
+for overlapped in (False, True):
+    n_total = n_scans + 4
+    lat = []
+    ctx.synchronize()
+    if overlapped:
+        L.lio_scan_prefetch_raw(ctx.h, scans[0][1].ctypes.data_as(C.c_void_p), n_raw, 16, 12)
+        L.lio_scan_prep_begin(ctx.h); imu_process(0); L.lio_scan_voxel_filter(ctx.h, leaf, C.byref(nout))
+    hits0, ov0 = ctx.debug_get("raw_prefetch_hits"), ctx.debug_get("prep_overlapped")
+    t_prev = time.perf_counter()
+    for it in range(n_total):
+        if overlapped:
+            rc = L.lio_scan_prep_end(ctx.h, C.byref(nout)); assert rc == 0, L.lio_last_error(ctx.h)
+            if it + 1 < n_total:
+                nxt = scans[(it + 1) % len(scans)][1]
+                L.lio_scan_prefetch_raw(ctx.h, nxt.ctypes.data_as(C.c_void_p), n_raw, 16, 12)    # sweep k + 1 "arrives" while scan k is processed
+        else:
+            imu_process(it)
+            rc = L.lio_scan_voxel_filter(ctx.h, leaf, C.byref(nout)); assert rc == 0, L.lio_last_error(ctx.h)
+        put_prior(it)
+        update_and_map(it, overlapped)
+        t = time.perf_counter()
+        lat.append(t - t_prev); t_prev = t
+    ctx.synchronize()
+    v = np.asarray(lat[4:]) * 1e6
+    extra = "  (prefetched sweeps %d, preparations filtered beside the map update %d)" % (ctx.debug_get("raw_prefetch_hits") - hits0, ctx.debug_get("prep_overlapped") - ov0) if overlapped else ""
+    print("%s loop, no synchronisation between the stages: median %.1f us per scan (p90 %.1f) = %.0f scans/s, feats_down %d%s"
+          % ("OVERLAPPED" if overlapped else "SERIAL    ", np.median(v), np.percentile(v, 90), 1e6 / np.median(v), nout.value, extra))

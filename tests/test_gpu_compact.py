@@ -85,3 +85,84 @@ def test_time_ordered_sweeps_take_the_compact_key_sort(gpu_capi, synth, small_ca
     c, fc = _drive(gpu_capi, synth, small_case["world"], n_raw, "library_sort", 5, sorted_times=True, leaf=0.1)
     d, fd = _drive(gpu_capi, synth, small_case["world"], n_raw, None, 5, sorted_times=True, leaf=0.1)
     _same(d, fd, c, fc)                                              # a finer grid: more bits in the leaf index (more passes)
+
+
+@pytest.mark.parametrize("n_raw", [9000, 40000, 131072])
+def test_overlapped_scan_preparation_equals_the_serial_loop(gpu_capi, synth, small_case, n_raw):
+    """lio_scan_prefetch_raw + lio_scan_prep_begin / _end: sweep k + 1 travels on the copy stream, is compensated and voxel-filtered on
+    a stream of its own (own stamped scratch, own mail box, centroids into the back scan buffer) WHILE map_incremental of scan k runs
+    on the main stream -- the same filtered clouds, measurement passes, insert counts and final map, bit for bit, as the serial loop
+    (laserMapping.cpp:2256-2401 in its own order).  Sweeps in time order (compact-key LSD sort on the preparation stream), one with a
+    swapped pair (the prediction fails: the filter is redone by lio_scan_prep_end), tiny sweeps (general path: filtered at the end)."""
+    world = small_case["world"]
+    half = world.ground_half
+    rng = np.random.default_rng(77)
+    poses = np.zeros((12, 22))
+    poses[:, 0] = np.arange(12) * 0.01
+    poses[:, 7] = 1.0
+    poses[:, 10] = poses[:, 0] * 1.0
+    poses[:, 13] = poses[:, 17] = poses[:, 21] = 1.0
+    end = synth.state_vector(poses[-1, 10:13], [0, 0, 0, 1], [0, 0, 0, 1.0], np.zeros(3))
+    sweeps = []
+    for k in range(5):
+        xyz = (rng.uniform(-0.6 * half, 0.6 * half, (n_raw, 3)) * [1, 1, 0.02]).astype(np.float32)
+        t = np.sort(np.floor(rng.uniform(0, 100.0, n_raw) * 4).astype(np.float32) / 4)
+        if k == 3:
+            t[n_raw // 2], t[n_raw // 2 + 1] = t[n_raw // 2 + 1] + 1, t[n_raw // 2]      # one out-of-order pair
+        sweeps.append(gpu_capi.pinned_points(np.concatenate([xyz, t[:, None]], 1).astype(np.float32)) if k != 2
+                      else np.concatenate([xyz, t[:, None]], 1).astype(np.float32))            # (one sweep in pageable memory: no prefetch)
+    leaf = 0.5 if n_raw > 20000 else 0.1
+    states = [synth.state_vector([0.05 * k, 0.02, 0.0], [0, 0, 0, 1], np.array([0, 0, 0, 1.0]), np.zeros(3)) for k in range(5)]
+
+    def serial():
+        ctx = gpu_capi.LioContext(0.2, max_scan_points=131072, max_map_points=600_000)
+        ctx.map_build(world.points)
+        out = []
+        for k in range(5):
+            ctx.scan_undistort(sweeps[k], poses, end)
+            m = ctx.scan_voxel_filter(leaf)
+            down = ctx.scan_cloud(1).copy()
+            g = ctx.measure(states[k], True, False)
+            r = ctx.map_incremental(states[k], 0.2, True, apply=True)
+            out.append((m, down, g["m"], g["HTH"].copy(), r["n_add"], r["n_nodown"], r["add_counter"], ctx.map_validnum()))
+        flat = ctx.map_flatten().copy()
+        ctx.close()
+        return out, flat
+
+    def overlapped():
+        ctx = gpu_capi.LioContext(0.2, max_scan_points=131072, max_map_points=600_000)
+        ctx.map_build(world.points)
+        out = []
+        ctx.scan_prefetch_raw(sweeps[0])
+        ctx.scan_prep_begin()
+        ctx.scan_undistort(sweeps[0], poses, end)
+        assert ctx.scan_voxel_filter(leaf) == -1
+        m = ctx.scan_prep_end()
+        for k in range(5):
+            down = ctx.scan_cloud(1).copy()
+            g = ctx.measure(states[k], True, False)
+            if k + 1 < 5:
+                ctx.scan_prefetch_raw(sweeps[k + 1])                            # (sweep 2 lives in pageable memory: the hint does nothing)
+                ctx.scan_prep_begin()
+                ctx.scan_undistort(sweeps[k + 1], poses, end)
+                assert ctx.scan_voxel_filter(leaf) == -1
+            r = ctx.map_incremental(states[k], 0.2, True, apply=True)          # ... beside the preparation of the next sweep
+            out.append((m, down, g["m"], g["HTH"].copy(), r["n_add"], r["n_nodown"], r["add_counter"], ctx.map_validnum()))
+            if k + 1 < 5:
+                m = ctx.scan_prep_end()
+        flat = ctx.map_flatten().copy()
+        stats = (ctx.debug_get("raw_prefetch_hits"), ctx.debug_get("prep_overlapped"), ctx.debug_get("voxel_redone"))
+        ctx.close()
+        return out, flat, stats
+
+    a, fa = serial()
+    b, fb, stats = overlapped()
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert x[0] == y[0] and x[2] == y[2] and x[4:] == y[4:], k
+        assert bits_equal(x[1], y[1]) and np.array_equal(x[3], y[3]), k
+    assert fa.shape == fb.shape and bits_equal(fa, fb)
+    assert stats[0] == 4                                             # every page-locked sweep was taken from the prefetch buffer
+    if n_raw > 16384:
+        assert stats[1] >= 3 and stats[2] >= 1                       # filtered beside the map update; the swapped pair was redone at the end
+    else:
+        assert stats[1] == 0                                         # tiny sweeps: the general path, filtered by lio_scan_prep_end
