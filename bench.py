@@ -854,6 +854,30 @@ def main():
         long_window = latency_summary(lat_long_value)
         long_window.update({"value": world_size * n_lw / t_lw, "unit_value": "scans/s", "ms_per_step": t_lw / n_lw * 1e3,
                             "how": "the contract loop (`value`'s step function) over a window of this many steps, per-step wall times"})
+    # the floor of a scan step: the same entry point on 256-point scans (every 390th point of the drive's scans: the same passes --
+    # launches, mail round trips, records over PCIe, the filter's algebra -- with nothing to search or to fit).  What `value` would
+    # be if every kernel took no time; the plateau small scans sit on (C3, a node's ~9 k-point scans).
+    step_floor = None
+    if not a.no_extras and dist is None and nq >= 4096:
+        n_tiny = 256
+        tiny = [capi.pinned_points(np.ascontiguousarray(sc.body[::max(1, nq // n_tiny)][:n_tiny])) for sc in scans]
+        tiny_p = [C.c_void_p(t.ctypes.data) for t in tiny]
+
+        def step_tiny():
+            k = tick[0] % n_rot
+            tick[0] += 1
+            rc = L.lio_eskf_scan_step_pipelined(kf.h, ctx.h, x_p[k], P0_p, tiny_p[(k + 1) % n_rot], n_tiny, 0.001, ext_i, ulog_ref)
+            if rc != 0:
+                fail("tiny scan step", rc)
+        tick[0] = 0
+        rc = L.lio_scan_upload_async(ctx.h, tiny_p[0], n_tiny)
+        if rc != 0:
+            fail("upload before the floor loop", rc)
+        t_fl = timed_steps(step_tiny, 400, 2 * n_rot, None, device, None, quiesce=lambda: L.lio_synchronize(ctx.h))
+        L.lio_scan_swap(ctx.h)
+        L.lio_synchronize(ctx.h)
+        step_floor = {"us_per_step": t_fl / 400 * 1e6, "scan_points": n_tiny, "passes_per_step": int(ulog.n_calls), "search_passes_per_step": int(ulog.n_search),
+                      "steps": 400, "how": "lio_eskf_scan_step_pipelined on 256-point scans: the launches, mail round trips and host algebra of a step without its work"}
     knn_ms = prof["knn27"]["total_ms"] / max(prof["knn27"]["launches"], 1)
     hint_ms = prof["knn27_hint"]["total_ms"] / max(prof["knn27_hint"]["launches"], 1) if prof["knn27_hint"]["launches"] else None
     knn_launches_sampled = int(prof["knn27"]["launches"])
@@ -1083,6 +1107,8 @@ def main():
     }
     if long_window is not None:
         out["value_long_window"] = long_window
+    if step_floor is not None:
+        out["step_floor"] = step_floor
     out.update(extras)
     if world_size == 1 and not a.no_extras and a.config == "c2" and a.other_configs:
         L.lio_synchronize(ctx.h)                                # (nothing of the headline context may sit armed on the GPU beside the other config)

@@ -100,7 +100,8 @@ def load(build_if_missing: bool = True):
                 C.CDLL(cand, mode=C.RTLD_GLOBAL)
         except Exception:
             pass
-    path = library_path()
+    # LIO_HIP_LIBRARY: another build of the library (A/B of two builds on ONE box: the only comparison that holds, profiles/README.md)
+    path = os.environ.get("LIO_HIP_LIBRARY") or library_path()
     if not os.path.exists(path):
         if not build_if_missing:
             raise LioError(f"{path} is missing: run `python -m better_fastlio2_amd.build` (no CPU fallback exists)")

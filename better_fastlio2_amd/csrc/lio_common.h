@@ -103,6 +103,8 @@ struct DeviceOut {                            // written by the final reduction 
     int      n_unresolved;
     unsigned long long seq;                   // written LAST (system-scope release): the host polls it
     unsigned long long dbg[8];                // wall_clock64 stamps of the last workgroup (100 MHz; diagnostics only)
+    float    probe[8];                        // feats_down_body[0] and [nq - 1] as the measurement kernel read them: the host's check of a scan
+                                              // a kernel pulled out of the caller's page-locked records (a stale registration reads other pages)
 };
 
 // ---- cell / key arithmetic (host + device) ----------------------------------------------------

@@ -295,6 +295,16 @@ struct lio_ctx {
     int dbg_assist_stall_us = 0;               // test hook: this thread sleeps that long before it packs (the search falls back to raw records)
     double last_pack_us = 0.0;
     int dbg_fused_pull = 1;                    // lio_debug_set("fused_pull", 0): always the stand-alone pull kernel (A/B switch)
+    // the pass in flight pulled its scan out of the caller's records: its record carries the first and the last point the GPU saw
+    // (DeviceOut::probe) and lio_measure_end compares them with the host's copy -- a registration that went stale (the node freed and
+    // re-allocated its cloud at the same address: the old pages stay pinned, the GPU reads THEM) is caught, the scan uploaded again
+    // through the staging buffer and the pass repeated ("stale_pulls")
+    bool scan_pull_failed = false;             // the stand-alone pull of a scan could not be launched: the scan is gone (the next pass says so)
+    bool pull_check = false;
+    const char* pull_check_host = nullptr;
+    int pull_check_stride = 0, pull_check_n = 0;
+    long long n_stale_pulls = 0;
+    int dbg_pull_alias_shift = 0;              // test hook: the fused pull reads this many records further on (what a stale registration looks like)
     long long n_scan_pulled = 0;               // scans a kernel pulled out of page-locked host records (lio_scan_set_async)
     // page-locked destinations the rows of the callback path are copied into directly (lio_measure_rows)
     int listed_last_search = 0;                // unproven queries of the most recent search pass: predicts the next one's

@@ -510,6 +510,7 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "assist_pull_threads") == 0) return lio_scan_pack_threads(c, (int)value);
     if (std::strcmp(key, "assist_pull_stall_us") == 0) { c->dbg_assist_stall_us = (int)value; return LIO_OK; }
     if (std::strcmp(key, "fused_pull") == 0) { c->dbg_fused_pull = value != 0; return LIO_OK; }
+    if (std::strcmp(key, "pull_alias_shift") == 0) { c->dbg_pull_alias_shift = (int)value; return LIO_OK; }
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
     if (std::strcmp(key, "pre_enqueue") == 0) { c->dbg_pre_enqueue = value != 0; return LIO_OK; }
     if (std::strcmp(key, "gate_mispredict") == 0) { c->dbg_gate_mispredict = value != 0; return LIO_OK; }
@@ -548,6 +549,7 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "pack_helper_late") == 0) { *value = c->n_helper_late; return LIO_OK; }
     if (std::strcmp(key, "last_pack_ns") == 0) { *value = (long long)(c->last_pack_us * 1e3); return LIO_OK; }
     if (std::strcmp(key, "scan_pulled") == 0) { *value = c->n_scan_pulled; return LIO_OK; }
+    if (std::strcmp(key, "stale_pulls") == 0) { *value = c->n_stale_pulls; return LIO_OK; }
     if (std::strcmp(key, "raw_prefetch_hits") == 0) { *value = c->n_raw_prefetch_hits; return LIO_OK; }
     if (std::strcmp(key, "prep_overlapped") == 0) { *value = c->n_prep_overlapped; return LIO_OK; }
     if (std::strcmp(key, "rows_direct_dma") == 0) { *value = c->n_rows_direct_dma; return LIO_OK; }

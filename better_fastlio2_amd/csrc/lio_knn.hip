@@ -291,18 +291,35 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
     // re-measured from the new query, bound the new 5th distance from above: tau = max_k d(q, nbr_k).
     // Every point that can enter the result then lies in a cell whose box distance is <= tau, so the
     // other cells are neither probed nor streamed (exactness: see DESIGN.md section 3.1).
+    // Round 5: the loads of the previous neighbours are ISSUED here and looked at behind the level-1 probes of the directory
+    // below -- one memory round trip for both instead of two in a row (the stamped ladder, scripts/knn_stamps.py: the directory
+    // rung of a bounded search took 1.84 us against 1.04 us in a first search at 24 k queries).
     uint32_t tau_bits = INF_BITS;
     float glo[3] = {0.f, 0.f, 0.f}, ghi[3] = {0.f, 0.f, 0.f};
+    constexpr int HK = (K + G - 1) / G;            // previous neighbours per lane (G < K: lane 0 measures two)
+    float4 hint_p[HK];
+    uint8_t hint_cnt = 0;
     if (HINT) {
-        uint32_t db = 0u;
-        bool have = false;
+#pragma unroll
+        for (int j = 0; j < HK; ++j) hint_p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) {
-            have = (a.cnt[q] & ~CNT_UNPROVEN) >= K;
-            for (int k = r; k < K; k += G) {           // G < K (4 lanes per query): lane 0 measures two
-                const float4 p = a.nbr[(size_t)k * a.nq_stride + q];
-                const float d = sqdist3(qx, qy, qz, p.x, p.y, p.z);
-                const uint32_t b = d == d ? __float_as_uint(d) : INF_BITS;
-                db = b > db ? b : db;
+            hint_cnt = a.cnt[q];
+#pragma unroll
+            for (int j = 0; j < HK; ++j)
+                if (r + j * G < K) hint_p[j] = a.nbr[(size_t)(r + j * G) * a.nq_stride + q];
+        }
+    }
+    auto hint_bound = [&]() {
+        uint32_t db = 0u;
+        const bool have = active && (hint_cnt & ~CNT_UNPROVEN) >= K;
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < HK; ++j) {
+                if (r + j * G < K) {
+                    const float d = sqdist3(qx, qy, qz, hint_p[j].x, hint_p[j].y, hint_p[j].z);
+                    const uint32_t b = d == d ? __float_as_uint(d) : INF_BITS;
+                    db = b > db ? b : db;
+                }
             }
         }
         db = group_max_u32<G>(db);
@@ -312,8 +329,8 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
         const float lox = (float)(cx - CELL_OFF) * cell, loy = (float)(cy - CELL_OFF) * cell, loz = (float)(cz - CELL_OFF) * cell;
         glo[0] = qx - lox; glo[1] = qy - loy; glo[2] = qz - loz;
         ghi[0] = (lox + cell) - qx; ghi[1] = (loy + cell) - qy; ghi[2] = (loz + cell) - qz;
-    }
-    const float tau = __uint_as_float(tau_bits);
+    };
+    float tau = __uint_as_float(INF_BITS);
 
     // ---- cell directory look-up.  The 3x3x3 block touches at most 2x2x2 level-1 cells (a level-1 cell = 4x4x4
     // grid cells): lanes 0..7 of the group hash-probe those (the only hashing, the only collisions), every level-1
@@ -349,6 +366,13 @@ __global__ __launch_bounds__(256) void knn27_kernel(KnnArgs a) {
                 k1[s1] = pack_key(x1, y1, z1);
                 sl1[s1] = hash_cell(x1, y1, z1) & l1mask;
                 e1[s1] = l1[want ? sl1[s1] : 0u];                   // unconditional load, discarded when not wanted
+            }
+            if (HINT) { hint_bound(); tau = __uint_as_float(tau_bits); }     // (the probes are in flight: the previous neighbours arrive beside them)
+#pragma unroll
+            for (int s1 = 0; s1 < L1SLOTS; ++s1) {
+                const int li = r + s1 * G;
+                const uint32_t x1 = b0x + (uint32_t)((li >> 2) & 1), y1 = b0y + (uint32_t)((li >> 1) & 1), z1 = b0z + (uint32_t)(li & 1);
+                const bool want = active && li < 8 && x1 <= h1x && y1 <= h1y && z1 <= h1z;
                 if (!want) e1[s1] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
             }
 #pragma unroll

@@ -473,6 +473,11 @@ __global__ __launch_bounds__(BS) void residual_kernel(ResidualArgs a) {
             out->HTH[i] = v;
         }
         if (tid < 12) out->HTh[tid] = tid < S::NC ? s_fin[S::NP + tid] : 0.0;
+        if (tid == 62 || tid == 63) {               // the first and the last scan point as this launch sees them (DeviceOut::probe)
+            const float4 p = a.body[tid == 62 ? 0 : a.nq - 1];
+            float* dst = out->probe + (tid == 62 ? 0 : 4);
+            dst[0] = p.x; dst[1] = p.y; dst[2] = p.z; dst[3] = p.w;
+        }
         if (tid == 0) {
             out->res_sum = s_fin[S::NP + S::NC];
             out->m = failed ? -1 : (int)(s_fin[S::NP + S::NC + 1] + 0.5);

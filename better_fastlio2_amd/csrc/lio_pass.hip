@@ -30,7 +30,7 @@ int run_knn(lio_ctx* c, const float4* body, float4* queries_world, const Pose14&
         ka.body = nullptr;
     }
     if (pull_raw && ka.body != nullptr) {
-        ka.body_raw = static_cast<const char*>(c->pull_alias); ka.body_raw_stride = c->pull_stride; ka.body_fill = c->d_body;
+        ka.body_raw = static_cast<const char*>(c->pull_alias) + (size_t)c->dbg_pull_alias_shift * (size_t)c->pull_stride; ka.body_raw_stride = c->pull_stride; ka.body_fill = c->d_body;
         ka.body_raw_aligned = (c->pull_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(c->pull_alias) & 15u) == 0u) ? 1 : 0;
     }
     ka.nq = nq; ka.nq_stride = stride;
@@ -101,7 +101,10 @@ static int enqueue_pass(lio_ctx* c, const Pose14& pose, bool do_search, bool ext
         // a later search of the same scan re-uses the neighbours of the previous one as a bound
         const int rc = run_knn(c, c->d_body, c->d_world, pose, nq, c->cap_q, c->d_nbr, c->d_cnt, c->d_ulist, c->d_useeds, c->hint_valid, separate_walk, gate, pull_here, mail, expect, pack_front, pack_mid);
         if (rc != LIO_OK) return rc;
-        if (pull_here) c->pull_pending = false;
+        if (pull_here) {
+            c->pull_pending = false;
+            c->pull_check = c->pull_host != nullptr; c->pull_check_host = c->pull_host; c->pull_check_stride = c->pull_stride; c->pull_check_n = nq;
+        }
     }
     ResidualArgs ra{};
     ra.body = c->d_body; ra.nq = nq; ra.nq_stride = c->cap_q; ra.pose = pose; ra.gate = gate; ra.nbr = c->d_nbr; ra.cnt = c->d_cnt;
@@ -286,6 +289,7 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     if (!c || !state14) return LIO_ERR_INVALID_ARG;
     c->stamp(do_search ? 'B' : 'b');
     if (c->pass_in_flight) return c->fail(LIO_ERR_INVALID_ARG, "lio_measure_begin", "the previous pass has not been collected (lio_measure_end)");
+    if (!c->have_scan && c->scan_pull_failed) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", ("the pull of the scan out of the caller's records failed: " + c->err).c_str());
     if (!c->have_scan) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "no scan set");
     if (!do_search && !c->have_search) return c->fail(LIO_ERR_NO_SCAN, "lio_measure", "first pass of a scan must search");
     if (c->map_broken) return c->fail(LIO_ERR_NO_MAP, "lio_measure", "the map index is undefined after a failed update: Build / reconstruct it");
@@ -434,6 +438,25 @@ int lio_measure_end(lio_ctx* c, lio_out* out) {
     }
 
     const DeviceOut& d = *c->h_out;
+    if (c->pull_check) {
+        // this pass pulled its scan out of the caller's page-locked records: are the points the GPU saw the points that are there?
+        c->pull_check = false;
+        const float* first = reinterpret_cast<const float*>(c->pull_check_host);
+        const float* last = reinterpret_cast<const float*>(c->pull_check_host + (size_t)(c->pull_check_n - 1) * (size_t)c->pull_check_stride);
+        const bool same = std::memcmp(first, d.probe, 12) == 0 && std::memcmp(last, d.probe + 4, 12) == 0;
+        if (!same && c->pull_check_n == c->nq) {
+            ++c->n_stale_pulls;
+            gate_call_off(c);                           // (passes armed behind this one read the same scan buffer)
+            const int rcu = upload_points(c, first, (size_t)c->pull_check_n, c->pull_check_stride, c->d_body);   // the CPU reads the real cloud
+            if (rcu != LIO_OK) return rcu;
+            const bool hint_now = c->hint_valid;
+            c->hint_valid = c->pass_hint;
+            const int rc = enqueue_pass(c, c->last_pose, c->pass_searched, c->last_ext, walk_in_its_own_launch(c), nullptr, &c->pass_seq);
+            c->hint_valid = hint_now;
+            if (rc != LIO_OK) return rc;
+            return lio_measure_end_again(c, out);
+        }
+    }
     if (d.n_unresolved < 0) return c->fail(LIO_ERR_HIP, "lio_measure", "tree walk exceeded its stack bound");
     if (d.m < 0) return c->fail(LIO_ERR_HIP, "lio_measure", "a bounded wait inside the measurement kernel ran out (sums incomplete)");
     out->m = d.m;

@@ -11,7 +11,13 @@ void flush_pull(lio_ctx* c) {
     c->pull_pending = false;
     if (c->pull_n > 0 && hipSetDevice(c->device) == hipSuccess) {
         const hipError_t e = launch_scan_pull(c->pull_alias, c->pull_stride, c->pull_n, c->d_body, c->stream);
-        if (e != hipSuccess) c->err = std::string("launch_scan_pull: ") + hipGetErrorString(e);
+        if (e != hipSuccess) {
+            // nobody reads enter()'s status: the scan is declared missing, so that the next pass fails loudly (LIO_ERR_NO_SCAN)
+            // instead of measuring whatever the scan buffer holds
+            c->err = std::string("launch_scan_pull: ") + hipGetErrorString(e);
+            c->have_scan = false;
+            c->scan_pull_failed = true;
+        }
     }
 }
 void pack_helper_stop(lio_ctx* c) {

@@ -10,6 +10,7 @@ int scan_reset(lio_ctx* c, int n) {
     // lio_measure_begin arms ahead of its pose (gate_arm)
     if (!c->pattern_cur.empty()) { c->pattern_prev.swap(c->pattern_cur); c->pattern_cur.clear(); }
     c->nq = n;
+    c->scan_pull_failed = false;
     c->have_scan = true; c->have_search = false; c->have_pass = false; c->last_m = 0; c->hint_valid = false;
     c->across_off_this_scan = false;
     // point_selected_surf starts all-true (laserMapping.cpp:2131), but nothing reads it before the first pass of

@@ -49,7 +49,9 @@ namespace lio {
 // ekfom_data.h.  ensure() registers [p, p + bytes) unless exactly that range already is -- the node's buffers keep their
 // address from scan to scan (PCL's VoxelGrid resizes the same vector, Eigen's resize() keeps an allocation whose size does not
 // change) -- and first drops every registered range it overlaps (the memory was re-allocated: a stale registration must never be
-// read through).  A few ranges are kept (a node that alternates between clouds), the oldest goes first.  Registration costs
+// read through).  What an exact (address, size) match cannot see -- the node freed the buffer and got the same address back for a new
+// one: the old PAGES stay registered -- is caught behind the transfer: rows by a marker (h_share_model), the cloud by the library's
+// comparison of the first and the last point the GPU saw with the host's records (lio_measure, "stale_pulls").  A few ranges are kept (a node that alternates between clouds), the oldest goes first.  Registration costs
 // tens of microseconds (78 us for 4.8 MB), so ranges below `min_bytes` are not worth it.  Contract: memory handed to ensure()
 // stays allocated until it is handed to ensure() again with another size, or drop_all() is called.  The destructor does NOT
 // unregister: it may run after the HIP runtime has gone.
@@ -154,6 +156,9 @@ public:
     size_t pin_rows_min_bytes = (size_t)2 << 20;   // row blocks (m x 13 doubles) from this size on are copied straight into page-locked h_x / h
     HostPin pins;
     long n_stale_pins = 0;        // row blocks that did not arrive through a registration and were fetched again (see h_share_model)
+    long long n_stale_scan_pulls = 0;   // scans the library found to differ from the host's cloud after a pull through a registration (it
+                                  // uploaded them again through its staging buffer: "stale_pulls"); every registration is dropped then
+    bool check_pull = false;      // the scan was handed over through a registration: look at "stale_pulls" behind its first pass
     // forget every registration (before the node frees or re-allocates buffers it has handed over)
     void unpin_all() { if (ctx_) (void)lio_synchronize(ctx_); pins.drop_all(); }
     lio_ctx* ctx() const { return const_cast<KdTreeFacade*>(this)->ctx(); }
@@ -273,7 +278,8 @@ inline bool upload_scan(KdTreeFacade<PointT>& tree, G& g) {
     lio_ctx* ctx = tree.ctx();
     auto& pts = g.feats_down_body->points;
     const int n = g.feats_down_size;
-    if (tree.pin_host_buffers && n > 0) (void)tree.pins.ensure(&pts[0], pts.capacity() * sizeof(PointT));
+    tree.check_pull = false;
+    if (tree.pin_host_buffers && n > 0) tree.check_pull = tree.pins.ensure(&pts[0], pts.capacity() * sizeof(PointT));
     const bool ok = tree.report(lio_scan_set_async(ctx, n > 0 ? &pts[0].x : nullptr, n, (int)sizeof(PointT)), "lio_scan_set_async");
     tree.scan_dirty = !ok;
     tree.scan_failed = !ok;
@@ -314,6 +320,15 @@ inline void h_share_model(KdTreeFacade<PointT>& tree, State& s, DynShare& ekfom_
     lio_out& o = reduced ? *reduced : local;
     if (!tree.report(lio_measure(ctx, st, ekfom_data.converge ? 1 : 0, g.extrinsic_est_en ? 1 : 0, &o), "lio_measure")) { invalid(); return; }
     tree.globals_stale = true;
+    if (tree.check_pull) {
+        // The first pass of a scan that a kernel pulled out of the registered cloud: the library compares the first and the last point
+        // the GPU saw with the host's records (a buffer freed and re-allocated at the same address keeps its OLD pages registered) and,
+        // on a difference, uploads the scan again through its staging buffer and repeats the pass -- the results above are right either
+        // way; here the stale registrations go, so that the next scan is registered afresh.
+        tree.check_pull = false;
+        long long stale = 0;
+        if (lio_debug_get(ctx, "stale_pulls", &stale) == LIO_OK && stale != tree.n_stale_scan_pulls) { tree.n_stale_scan_pulls = stale; tree.unpin_all(); }
+    }
     g.effct_feat_num = o.m;                                            // :1942-1954
     if (!o.valid) {                                                    // :1956-1961
         ekfom_data.valid = false;

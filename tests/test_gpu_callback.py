@@ -179,6 +179,42 @@ def test_scan_set_async_equals_scan_set(gpu_capi, small_case, stride_floats):
     ctx.close()
 
 
+@pytest.mark.parametrize("assist", [0, 60])
+def test_a_stale_registration_is_caught_behind_the_pull(gpu_capi, small_case, assist):
+    """a cloud freed and re-allocated at the same address keeps its OLD pages registered -- the GPU's pull then reads
+    them, not the scan.  The record of the pass that pulled carries the first and the last point the GPU saw (DeviceOut::probe);
+    lio_measure_end compares them with the host's records, uploads the scan again through the staging buffer on a difference and
+    repeats the pass ("stale_pulls").  Emulated with the test hook "pull_alias_shift": the kernel reads three records further on."""
+    w, sc, st = small_case["world"], small_case["scan"], small_case["state14"]
+    n = len(sc.body) - 8
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=n + 8, max_map_points=400_000)
+    ctx.map_build(w.points)
+    ctx.scan_set(sc.body[:n])
+    g0 = ctx.measure(st, True, False)
+    nx0, nd0, nc0 = ctx.neighbors()
+    rec = np.full((n + 8, 12), 7.0, np.float32)
+    rec[:, :3] = sc.body
+    L = ctx.L
+    assert L.lio_host_register(rec.ctypes.data_as(C.c_void_p), rec.nbytes) == 0
+    ctx.debug_set("assist_pull", assist)
+    for shift, stale in ((0, 0), (3, 1), (0, 0)):
+        ctx.debug_set("pull_alias_shift", shift)
+        before = ctx.debug_get("stale_pulls")
+        assert L.lio_scan_set_async(ctx.h, rec.ctypes.data_as(C.c_void_p), n, 48) == 0
+        g = ctx.measure(st, True, False)                  # the pull, the check, (the repeat)
+        assert ctx.debug_get("stale_pulls") - before == stale
+        nx, nd, nc = ctx.neighbors()
+        assert g["m"] == g0["m"] and np.array_equal(g["HTH"], g0["HTH"]) and np.array_equal(g["HTh"], g0["HTh"])
+        assert bits_equal(nx, nx0) and bits_equal(nd, nd0) and np.array_equal(nc, nc0)
+        assert bits_equal(ctx.scan_cloud(1), np.ascontiguousarray(sc.body[:n], np.float32))
+        g2 = ctx.measure(st, False, False)                # and the scan goes on as usual
+        assert g2["m"] == g0["m"]
+    ctx.debug_set("pull_alias_shift", 0); ctx.debug_set("assist_pull", 1)
+    ctx.synchronize()
+    assert L.lio_host_unregister(rec.ctypes.data_as(C.c_void_p)) == 0
+    ctx.close()
+
+
 @pytest.mark.parametrize("stride_floats", [8, 12])
 def test_assisted_pull_equals_scan_set(gpu_capi, synth, small_case, stride_floats):
     """The first search of a scan handed over as page-locked host records, with the host packing the FRONT of the cloud beside
