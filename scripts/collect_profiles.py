@@ -10,7 +10,7 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 for name, out in (("bench_c2.json", f"{tag}_bench_c2.json"), ("bench_c3.json", f"{tag}_bench_c3.json"), ("bench_c5.json", f"{tag}_bench_c5.json"),
                   ("loopbody.log", f"{tag}_loopbody.log"), ("pytest_gpu.log", f"{tag}_pytest_gpu.log"), ("stamps.log", f"{tag}_stamps.log"),
-                  ("knn_traffic.json", "knn_traffic.json"),
+                  ("knn_traffic.json", "knn_traffic.json"), ("knn_stamps.log", f"{tag}_knn_stamps.log"),
                   # round 3 (scripts/end_of_round_r03.sh)
                   ("bench_c2_driver.json", f"{tag}_bench_c2_driver_cmdline.json"), ("emulated_timeline.txt", f"{tag}_emulated_world8_timeline.txt"),
                   ("node_loop_timeline.txt", f"{tag}_node_loop_timeline.txt"), ("rebuild_timeline.txt", f"{tag}_rebuild_timeline.txt"),
