@@ -129,6 +129,8 @@ int lio_scan_upload_raw(lio_ctx* c, const float* raw_pts, int n, int stride_byte
     c->n_raw = n; c->have_raw = false; c->raw_uploaded = true;
     c->raw_time_keyed = time_offset_bytes >= 0;
     if (n == 0) return LIO_OK;
+    rc = ensure_stage(c, (size_t)n + POSE_STAGE_SLOTS);                        // the IMU poses travel behind the points (lio_scan_compensate)
+    if (rc != LIO_OK) return rc;
     if (c->raw_prefetched) {
         // the sweep is already on its way (lio_scan_prefetch_raw, copy stream): take the buffer it went to
         const bool hit = c->raw_prefetch_src == raw_pts && c->raw_prefetch_n == n && time_offset_bytes == 12 && stride_bytes == 16;
@@ -142,8 +144,6 @@ int lio_scan_upload_raw(lio_ctx* c, const float* raw_pts, int n, int stride_byte
             return LIO_OK;
         }
     }
-    rc = ensure_stage(c, (size_t)n + POSE_STAGE_SLOTS);                        // the IMU poses travel behind the points
-    if (rc != LIO_OK) return rc;
     const char* src = reinterpret_cast<const char*>(raw_pts);
     if (time_offset_bytes == 12 && stride_bytes == 16 && is_pinned_host(raw_pts)) {
         // x, y, z, t records in page-locked memory (lio_host_alloc): the copy engine reads them where they are -- no
