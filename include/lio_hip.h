@@ -346,7 +346,10 @@ results); "library_sort" sends every sort / compaction of map maintenance and sc
  * for sweeps in time order (identical results); "retired_budget" overrides the number of retired slots that triggers a full
  * index rebuild (0 = the default, four times the live points); "assist_pull" = 0 / 1 / 2..92: the host's share of an assisted
  * pull off / steered / fixed in per cent, "assist_pull_chunk" = records per progress announcement (0 = by scan size),
- * "assist_pull_stall_us" = test hook: the host sleeps that long before it packs.  Unknown key: LIO_ERR_INVALID_ARG.       */
+ * "assist_pull_stall_us" = test hook: the host sleeps that long before it packs; "knn_stamps" = 1: searches of 8 lanes per query run
+ * the stamped instantiation of the k-NN kernel (lio_debug_knn_stamps); "pull_alias_shift" = n: test hook, the fused pull of a host
+ * cloud reads n records further on (what a stale registration looks like: the check behind the pull must catch it).
+ * Unknown key: LIO_ERR_INVALID_ARG.                                                                                        */
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
 /* counters for tests: "gate_released" / "gate_called_off" = pre-enqueued passes that ran / were called off; "voxel_fast_runs" /
  * "voxel_redone" = voxel-filter attempts on the compact-key path / sweeps filtered twice after a wrong prediction;
@@ -356,7 +359,10 @@ int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
  * armed across a scan boundary / of those, the ones that ran; "scan_pulled" = scans a kernel pulled out of page-locked host records
  * (lio_scan_set_async); "rows_direct_dma" = lio_measure_rows calls served by copies straight into page-locked h_x / h;
  * "assisted_pulls" = scans whose first search had the host pack the front of the cloud beside it, "last_pack_front" / "last_pack_ns" /
- * "assist_share_permille" = records packed, time it took, and the share in force                                                  */
+ * "assist_share_permille" = records packed, time it took, and the share in force; "stale_pulls" = scans whose first and last point,
+ * as the GPU saw them through a registration, differed from the host's records -- uploaded again through the staging buffer, the pass
+ * repeated (a caller drops its registrations then: the adaptor does); "raw_prefetch_hits" = sweeps lio_scan_upload_raw took from the
+ * prefetch buffer, "prep_overlapped" = preparations whose filter ran on the preparation stream (lio_scan_prep_begin / _end)        */
 int  lio_debug_get(lio_ctx* ctx, const char* key, long long* value);
 /* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: [0] its start, [1] own partial
  * published, [2] group folded, [3] grid folded, [4] the listed queries' terms folded (search passes that list any),

@@ -15,7 +15,7 @@ for name, out in (("bench_c2.json", f"{tag}_bench_c2.json"), ("bench_c3.json", f
                   ("bench_c2_driver.json", f"{tag}_bench_c2_driver_cmdline.json"), ("emulated_timeline.txt", f"{tag}_emulated_world8_timeline.txt"),
                   ("node_loop_timeline.txt", f"{tag}_node_loop_timeline.txt"), ("rebuild_timeline.txt", f"{tag}_rebuild_timeline.txt"),
                   ("kernel_stats.txt", f"{tag}_bench_c2_extras_kernel_totals.txt"), ("host_trace.log", f"{tag}_host_trace.log"), ("step_timeline.txt", f"{tag}_step_timeline.txt"),
-                  # round 4 (scripts/end_of_round_r04.sh, scripts/r04_timeline.sh)
+                  # round 4 (scripts/end_of_round_r04.sh, scripts/lab/r04_timeline.sh)
                   ("emulated_timeline_deferred.txt", f"{tag}_emulated_world8_timeline_deferred.txt"),
                   ("emulated_timeline_immediate.txt", f"{tag}_emulated_world8_timeline_immediate.txt"),
                   (os.path.join("prof_loop", "kernel_stats_trim.csv"), f"{tag}_loopbody_kernel_stats.csv")):

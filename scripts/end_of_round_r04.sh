@@ -31,7 +31,7 @@ timeout 200 python tests/fuzz/fuzz_scanprep.py 200 40000 > $O/fuzz_scanprep.log 
 timeout 200 python tests/fuzz/fuzz_pipeline.py 100 64000 > $O/fuzz_pipeline.log 2>&1; echo "fuzz_pipeline rc=$?"
 timeout 200 python tests/fuzz/fuzz_assist.py 400 74000 > $O/fuzz_assist.log 2>&1; echo "fuzz_assist rc=$?"
 stamp fuzz
-bash scripts/r04_step_timeline.sh $tag > $O/step_timeline.out 2>&1; tail -3 $O/step_timeline.txt
+bash scripts/lab/r04_step_timeline.sh $tag > $O/step_timeline.out 2>&1; tail -3 $O/step_timeline.txt
 LIO_TRACE_HOST=1 timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extras 2>&1 >/dev/null | grep -a "host trace" | head -90 | tail -48 > $O/host_trace.log
 stamp "step time line + host trace"
 timeout 1300 python bench.py --config c5 --steps 40 --warmup 5 > $O/bench_c5.json 2> $O/bench_c5.err; tail -1 $O/bench_c5.json | cut -c1-200

@@ -166,3 +166,49 @@ def test_overlapped_scan_preparation_equals_the_serial_loop(gpu_capi, synth, sma
         assert stats[1] >= 3 and stats[2] >= 1                       # filtered beside the map update; the swapped pair was redone at the end
     else:
         assert stats[1] == 0                                         # tiny sweeps: the general path, filtered by lio_scan_prep_end
+
+
+def test_scan_preparation_calls_out_of_order(gpu_capi, synth, small_case):
+    """lio_scan_prep_begin / _end out of order, the back scan buffer already promised to lio_scan_upload_async, a preparation that only
+    uploads, a first sweep taken from the prefetch buffer on a context that has never staged anything: errors are reported, nothing hangs,
+    the context goes on."""
+    world = small_case["world"]
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=65536, max_map_points=400_000)
+    dev = gpu_capi.scan_to_device(world.points[:100_000])
+    ctx.map_build_device(dev.ptr, 100_000)                             # (no host upload: the staging buffer does not exist yet)
+    rng = np.random.default_rng(3)
+    xyz = (rng.uniform(-20, 20, (30_000, 3)) * [1, 1, 0.02]).astype(np.float32)
+    t = np.sort(rng.uniform(0, 100.0, 30_000)).astype(np.float32)
+    sweep = gpu_capi.pinned_points(np.concatenate([xyz, t[:, None]], 1))
+    poses = np.zeros((12, 22))
+    poses[:, 0] = np.arange(12) * 0.01
+    poses[:, 7] = 1.0
+    poses[:, 10] = poses[:, 0] * 1.0
+    poses[:, 13] = poses[:, 17] = poses[:, 21] = 1.0
+    end = synth.state_vector(poses[-1, 10:13], [0, 0, 0, 1], [0, 0, 0, 1.0], np.zeros(3))
+    with pytest.raises(gpu_capi.LioError, match="no preparation is running"):
+        ctx.scan_prep_end()
+    ctx.scan_prefetch_raw(sweep)
+    ctx.scan_prep_begin()
+    with pytest.raises(gpu_capi.LioError, match="already running"):
+        ctx.scan_prep_begin()
+    with pytest.raises(gpu_capi.LioError, match="running preparation"):
+        ctx.scan_upload_async(gpu_capi.pinned_points(xyz[:100]))
+    ctx.scan_undistort(sweep, poses, end)                              # from the prefetch buffer
+    assert ctx.scan_voxel_filter(0.5) == -1
+    with pytest.raises(gpu_capi.LioError, match="one filter per"):
+        ctx.scan_voxel_filter(0.5)
+    n = ctx.scan_prep_end()
+    assert ctx.debug_get("raw_prefetch_hits") == 1 and 1000 < n < 30_000
+    down = ctx.scan_cloud(1).copy()
+    ctx.scan_undistort(sweep, poses, end)                              # the same sweep, serial calls
+    assert ctx.scan_voxel_filter(0.5) == n and bits_equal(ctx.scan_cloud(1), down)
+    ctx.scan_prep_begin()                                              # a preparation without a filter: only the upload + compensation run there
+    ctx.scan_undistort(sweep, poses, end)
+    assert ctx.scan_prep_end() == 0
+    assert ctx.scan_voxel_filter(0.5) == n and bits_equal(ctx.scan_cloud(1), down)
+    ctx.scan_upload_async(gpu_capi.pinned_points(xyz[:100]))
+    with pytest.raises(gpu_capi.LioError, match="lio_scan_upload_async"):
+        ctx.scan_prep_begin()
+    ctx.scan_swap()
+    ctx.close()
