@@ -429,6 +429,19 @@ struct lio_ctx {
     uint32_t* d_small2 = nullptr;
     uint32_t small2_seq = 0;
     long long n_plans_on_side_stream = 0, n_settled = 0;
+    // Round 5: the COMMIT half of the deferred batch (fold_commit ... cell_apply) on the side stream too -- right behind its plan --
+    // beside the part of the NEXT exchange that does not touch the map: this rank's list kernel, the message, the all-gather (its wire
+    // time on real hardware), the compaction of the gathered lists.  lio_replicate_step starts it, reads its statistics from a mail
+    // box of their own where the blocking settle used to sit, and only then lets anything else onto the main stream.
+    bool settle_side = false;                  // the chain is on the side stream, its 32 statistics words on their way to mail box 4
+    uint32_t settle_seq = 0;
+    void* h_small4 = nullptr;
+    uint32_t* d_small4 = nullptr;
+    uint32_t small4_seq = 0;
+    unsigned long long* d_cagg_lists = nullptr;   // stamped scratch of the list kernel while the commit's scans use d_cagg
+    uint32_t compact_seq_lists = 0;
+    long long n_settled_beside_exchange = 0;
+    int dbg_settle_beside = 1;                 // lio_debug_set("settle_beside_exchange", 0): the blocking settle of round 4 (A/B switch)
     int def_last_counter = 0, def_last_deleted = 0;   // tmp_counter / deleted points of the batch the last exchange let into the map
     // loop-back test mode (lio_debug_set "replicate_loopback", then lio_replicate_init without an id): rep_world VIRTUAL
     // ranks on this one GPU.  lio_replicate_step as virtual rank r < world - 1 ("replicate_loopback_rank") parks that

@@ -257,6 +257,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
         const char* k = std::getenv("AMD_SERIALIZE_KERNEL");
         if ((b != nullptr && b[0] != 0 && b[0] != '0') || (k != nullptr && k[0] != 0 && k[0] != '0')) { c->dbg_pre_enqueue = 0; c->dbg_arm_next_scan = 0; }
     }
+    { const char* e = std::getenv("LIO_SETTLE_BESIDE"); if (e != nullptr && e[0] == '0') c->dbg_settle_beside = 0; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_KNN_TUNE"); if (e != nullptr && e[0] >= '0' && e[0] <= '9') c->dbg_knn_tune = std::atoi(e); }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_ARM_NEXT_SCAN"); if (e != nullptr && e[0] == '0') c->dbg_arm_next_scan = 0; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_GATE_IN_KERNEL"); if (e != nullptr && e[0] >= '0' && e[0] <= '7' && e[1] == 0) c->gate_in_kernel = e[0] - '0'; }   // (A/B runs of scripts)
@@ -413,6 +414,8 @@ void lio_destroy(lio_ctx* c) {
     if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     if (c->h_small2) (void)hipHostFree(c->h_small2);
+    if (c->h_small4) (void)hipHostFree(c->h_small4);
+    if (c->d_cagg_lists) (void)hipFree(c->d_cagg_lists);
     for (int i = 0; i < 2; ++i) {
         if (c->d_def_add[i]) (void)hipFree(c->d_def_add[i]);
         if (c->d_def_plain[i]) (void)hipFree(c->d_def_plain[i]);
@@ -510,6 +513,7 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
     if (std::strcmp(key, "assist_pull_threads") == 0) return lio_scan_pack_threads(c, (int)value);
     if (std::strcmp(key, "assist_pull_stall_us") == 0) { c->dbg_assist_stall_us = (int)value; return LIO_OK; }
     if (std::strcmp(key, "fused_pull") == 0) { c->dbg_fused_pull = value != 0; return LIO_OK; }
+    if (std::strcmp(key, "settle_beside_exchange") == 0) { c->dbg_settle_beside = value != 0; return LIO_OK; }
     if (std::strcmp(key, "pull_alias_shift") == 0) { c->dbg_pull_alias_shift = (int)value; return LIO_OK; }
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
     if (std::strcmp(key, "pre_enqueue") == 0) { c->dbg_pre_enqueue = value != 0; return LIO_OK; }
@@ -539,6 +543,7 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "gate_mail_in_vram") == 0) { *value = c->gate_mail_in_vram ? 1 : 0; return LIO_OK; }
     if (std::strcmp(key, "plans_on_side_stream") == 0) { *value = c->n_plans_on_side_stream; return LIO_OK; }
     if (std::strcmp(key, "deferred_settled") == 0) { *value = c->n_settled; return LIO_OK; }
+    if (std::strcmp(key, "settled_beside_exchange") == 0) { *value = c->n_settled_beside_exchange; return LIO_OK; }
     if (std::strcmp(key, "gate_reenqueued") == 0) { *value = c->n_gate_reenqueued; return LIO_OK; }
     if (std::strcmp(key, "gate_in_kernel") == 0) { *value = c->n_gate_in_kernel; return LIO_OK; }
     if (std::strcmp(key, "next_scan_armed") == 0) { *value = c->n_next_scan_armed; return LIO_OK; }

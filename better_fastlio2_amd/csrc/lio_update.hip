@@ -339,8 +339,10 @@ namespace {
 // The pending points enter the index: O(batch), the rest of the map is not touched (lio_mapadd.hip).
 // Launches: pend_build, the sort by (cell, list) (1 or 2), cell_plan (with the scan of the new bucket sizes), cell_apply,
 // and ONE read-back that brings the statistics of this update together with the counts the fold left on the device.
-int apply_pending(lio_ctx* c) {
+// First half: the launches (on c->stream).  *launched = false: there was nothing to do, or the full rebuild did it.
+static int apply_pending_enqueue(lio_ctx* c, bool* launched) {
     hipStream_t s = c->stream;
+    *launched = false;
     if (c->map_broken) return c->fail(LIO_ERR_NO_MAP, "Add_Points", "the map index is undefined after a failed update: Build / reconstruct it");
     if (c->fold_n == 0 && c->plain_n == 0) return LIO_OK;
     c->hint_valid = false;
@@ -366,8 +368,12 @@ int apply_pending(lio_ctx* c) {
     a.agg = c->d_cagg; a.stamp = next_compact_stamp(c); a.err = c->d_apply + 15;
     HIPCHK(c, launch_cell_plan(a, s));
     HIPCHK(c, launch_cell_apply(a, s));
-    uint32_t st[32] = {};
-    rc = fetch_batch_counts(c, st);
+    *launched = true;
+    return LIO_OK;
+}
+// Second half: the 32 statistics words of the update (st; rc = how reading them went) -> the host's view of the map, the budgets,
+// a full rebuild when one is due.
+static int apply_pending_finish(lio_ctx* c, const uint32_t st[32], int rc) {
     if (rc != LIO_OK) {
         // cell_apply may already have re-written buckets at the tail and retired their old slots: the counts that say how far
         // it got are what could not be read.  The batch is dropped and the index declared undefined -- loudly, for every call
@@ -411,6 +417,14 @@ int apply_pending(lio_ctx* c) {
         return rebuild_full(c);
     }
     return LIO_OK;
+}
+int apply_pending(lio_ctx* c) {
+    bool launched = false;
+    int rc = apply_pending_enqueue(c, &launched);
+    if (rc != LIO_OK || !launched) return rc;
+    uint32_t st[32] = {};
+    rc = fetch_batch_counts(c, st);
+    return apply_pending_finish(c, st, rc);
 }
 
 }  // namespace
@@ -638,8 +652,20 @@ static int map_incremental_lists(lio_ctx* c, const double state14[14], double fi
     if (compact_small(c, (size_t)nq)) {
         // classification + both lists + their counts + their bounding box in ONE launch
         // (its error word is d_counters[12]: it travels with every read-back of the two counts, here and in the exchange)
-        HIPCHK(c, launch_map_incremental_lists(ia, c->d_add_pts, c->d_add_pts2, c->d_counters + 5, c->d_counters + 24, c->d_cagg,
-                                               next_compact_stamp(c), c->d_counters + 12, s));
+        unsigned long long* agg = c->d_cagg;
+        uint32_t stamp;
+        if (c->settle_side) {                       // (the commit on the side stream runs its scans on d_cagg right now)
+            agg = c->d_cagg_lists;
+            if (++c->compact_seq_lists == 0u) {
+                HIPCHK(c, hipMemsetAsync(c->d_cagg_lists, 0, COMPACT_AGG_WORDS * sizeof(unsigned long long), s));
+                ++c->compact_seq_lists;
+            }
+            stamp = c->compact_seq_lists;
+        } else {
+            stamp = next_compact_stamp(c);
+        }
+        HIPCHK(c, launch_map_incremental_lists(ia, c->d_add_pts, c->d_add_pts2, c->d_counters + 5, c->d_counters + 24, agg,
+                                               stamp, c->d_counters + 12, s));
     } else {
         HIPCHK(c, launch_map_incremental(ia, s));
         HIPCHK(c, select_points_by_class(c->d_temp, c->temp_bytes, c->d_world, c->d_add_cls, 1, c->d_add_pts, c->d_counters + 5, (size_t)nq, s));
@@ -907,6 +933,15 @@ static int ensure_deferred(lio_ctx* c) {
         std::memset(c->h_small2, 0, 256);
         HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_small2, c->h_small2, 0));
     }
+    if (!c->h_small4) {
+        HIPCHK(c, hipHostMalloc(&c->h_small4, 256, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(c->h_small4, 0, 256);
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_small4, c->h_small4, 0));
+    }
+    if (!c->d_cagg_lists) {
+        HIPCHK(c, hipMalloc((void**)&c->d_cagg_lists, COMPACT_AGG_WORDS * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemset(c->d_cagg_lists, 0, COMPACT_AGG_WORDS * sizeof(unsigned long long)));
+    }
     if (c->cap_def < c->cap_add) {
         for (int i = 0; i < 2; ++i) {
             if (c->d_def_add[i]) (void)hipFree(c->d_def_add[i]);
@@ -996,6 +1031,74 @@ int deferred_settle(lio_ctx* c, int* add_counter, int* n_deleted) {
     return rc;
 }
 
+// The commit half of the deferred batch on the SIDE stream (behind its plan, which ran there beside the scan step): enqueued, not
+// waited for -- lio_replicate_step then runs everything of the next exchange that does not touch the map on the main stream beside
+// it and collects the statistics with deferred_settle_side_end.  Only the plain case: planned, no delete boxes, an index that takes
+// incremental updates, every sort / scan on the single-launch kernels (the library's workspace is shared).  Returns LIO_OK with
+// c->settle_side == false when the case is another one (the caller then settles the blocking way).
+static int deferred_settle_side_begin(lio_ctx* c) {
+    lio_ctx::DeferredBatch& d = c->def;
+    if (!c->dbg_settle_beside || !d.pending || !d.planned || d.n_boxes != 0 || d.n_add == 0 || c->fold_n != 0 || c->plain_n != 0 ||
+        c->map_broken || !c->have_map || c->n_live == 0 || c->n_points == 0 || c->dbg_library_sort || !compact_small(c, (size_t)c->nq) ||
+        (size_t)d.n_add + (size_t)d.n_plain > (size_t)GSORT_MAX || c->prep_active ||
+        (size_t)c->n_live + (size_t)d.n_add + (size_t)d.n_plain > c->cap_map)
+        return LIO_OK;
+    const uint32_t n_add = d.n_add, n_plain = d.n_plain;
+    const HostBox box = d.box;
+    const int cur = c->def_cur;
+    d.pending = false; d.plan_owed = false; d.planned = false; d.joined = false;      // (whatever happens below, the batch is not applied twice)
+    ++c->n_settled;
+    c->last_add_counter = 0;
+    hipStream_t main_stream = c->stream;
+    c->stream = c->side_stream;                 // (every launch helper of the update takes the context's stream)
+    bool launched = false;
+    int rc = fold_batch_commit(c, d.fa, d.ba, n_add, box);
+    if (rc == LIO_OK) rc = plain_batch_device(c, c->d_def_plain[cur], n_plain, box);
+    if (rc == LIO_OK) rc = apply_pending_enqueue(c, &launched);
+    if (rc == LIO_OK && launched) {
+        c->settle_seq = ++c->small4_seq;
+        const hipError_t e = launch_publish_words(c->d_apply, 32, c->d_small4, c->settle_seq, c->side_stream);
+        if (e != hipSuccess) rc = c->fail(LIO_ERR_HIP, "deferred exchange: publishing the statistics", hipGetErrorString(e));
+    }
+    c->stream = main_stream;
+    if (rc != LIO_OK) return rc;
+    c->settle_side = launched;                  // (not launched: a full rebuild took the batch in, synchronously)
+    if (launched) ++c->n_settled_beside_exchange;
+    return LIO_OK;
+}
+static int deferred_settle_side_end(lio_ctx* c, int* add_counter) {
+    if (add_counter) *add_counter = 0;
+    if (!c->settle_side) return LIO_OK;
+    c->settle_side = false;
+    volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(c->h_small4) + 32;
+    int rc = LIO_OK;
+    for (uint64_t spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->settle_seq; ++spins) {
+        if ((spins & 0xfffffu) == 0xfffffu) {
+            const hipError_t q = hipStreamQuery(c->side_stream);
+            if (q != hipErrorNotReady) {          // idle (or broken) without the word: the chain never got there
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->settle_seq) break;
+                rc = c->fail(LIO_ERR_HIP, "deferred exchange: the commit on the side stream", q == hipSuccess ? "stream idle but its statistics never arrived" : hipGetErrorString(q));
+                break;
+            }
+        }
+        __builtin_ia32_pause();
+    }
+    uint32_t st[32] = {};
+    if (rc == LIO_OK) {
+        std::memcpy(st, c->h_small4, sizeof(st));
+        if (st[14] != 0u) {
+            (void)hipMemsetAsync(c->d_apply + 14, 0, sizeof(uint32_t), c->stream);
+            rc = c->fail(LIO_ERR_HIP, "Add_Points", "a batch point lies outside the key frame derived from the batch's bounding box");
+        } else {
+            rc = check_compact_error(c, st[15]);
+        }
+    }
+    // (the side stream is idle: whatever the second half launches -- a full rebuild -- runs on the main stream behind nothing of it)
+    rc = apply_pending_finish(c, st, rc);
+    if (rc == LIO_OK && add_counter) *add_counter = c->last_add_counter;
+    return rc;
+}
+
 static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4], HostBox& box, bool defer = false) {
     hipStream_t s = c->stream;
     const size_t msg_f4 = (size_t)REP_HEADER_F4 + 2 * (size_t)cap;
@@ -1028,12 +1131,16 @@ static int replicate_exchange_apply(lio_ctx* c, uint32_t cap, uint32_t tot[4], H
     }
     HIPCHK(c, launch_replicate_compact(ca, s));
     uint32_t w[22] = {};                                        // d_counters[8 .. 29]: the four totals, the list kernel's error word, ... the bounding box
-    if (defer && c->def.pending) {
+    if (defer && (c->def.pending || c->settle_side)) {
         // The totals go into the second mail box WITHOUT a wait; the previous batch enters the map behind them on the stream, and
         // its own read-back (the statistics of the index update) is the one host wait of this exchange: by then the totals are there.
+        // (Round 5: in the plain case that batch's commit has been running on the side stream since this exchange began -- here its
+        // statistics are collected.)
         const uint32_t seq2 = ++c->small2_seq;
         HIPCHK(c, launch_publish_words(c->d_counters + 8, 22, c->d_small2, seq2, s));
-        const int rc = deferred_settle(c, &c->def_last_counter, &c->def_last_deleted);
+        int rc;
+        if (c->settle_side) { c->def_last_deleted = 0; rc = deferred_settle_side_end(c, &c->def_last_counter); }
+        else rc = deferred_settle(c, &c->def_last_counter, &c->def_last_deleted);
         if (rc != LIO_OK) return rc;
         volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(c->h_small2) + 32;
         for (uint64_t spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq2; ++spins) {
@@ -1062,6 +1169,18 @@ int lio_replicate_step(lio_ctx* c, const double state14[14], double filter_size_
     HIPCHK(c, hipSetDevice(c->device));
     int rc = deferred_join_side(c);
     if (rc != LIO_OK) return rc;
+    // the deferred schedule, plain case: the commit of the batch held back starts NOW on the side stream, beside this rank's list
+    // kernel, the message, the all-gather and the compaction below (none of them reads the map).  A virtual rank that only parks
+    // its lists (loop-back) leaves the batch where it is: the exchange proper is the last rank's call.
+    if (c->rep_defer && c->def.pending && !(c->rep_loopback && c->rep_rank + 1 < c->rep_world)) {
+        rc = ensure_deferred(c);
+        if (rc == LIO_OK) rc = deferred_settle_side_begin(c);
+        if (rc != LIO_OK) return rc;
+    }
+    struct SettleGuard {                        // an error return below must not leave the commit's statistics uncollected
+        lio_ctx* c;
+        ~SettleGuard() { if (c->settle_side) (void)deferred_settle_side_end(c, nullptr); }
+    } settle_guard{c};
     // map_incremental's two lists of this rank stay on the device, and so do their counts
     rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, nullptr);
     if (rc != LIO_OK) return rc;

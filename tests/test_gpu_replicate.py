@@ -189,6 +189,7 @@ def test_deferred_schedule_through_rccl(gpu_capi, oracle, synth, small_case):
                 ref.add(held["nodown"], False)
         held = mine
     assert a.debug_get("plans_on_side_stream") == 3 and a.debug_get("deferred_settled") == 3
+    assert a.debug_get("settled_beside_exchange") == 3                 # (round 5: every planned batch was committed on the side stream, beside the next exchange)
     cnt = b.map_add_pair(held["add"], held["nodown"])
     if ref is not None:
         ref.add(held["add"], True); ref.add(held["nodown"], False)
@@ -282,6 +283,7 @@ def test_deferred_schedule_in_a_loopback_world(gpu_capi, oracle, synth, small_ca
         held = (np.concatenate(boxes_all) if boxes_all else np.zeros((0, 6), np.float32), add, nodown)
     assert a.debug_get("deferred_settled") == rounds - 1
     assert a.debug_get("plans_on_side_stream") == rounds - 2    # every settled batch but the one with the delete box
+    assert a.debug_get("settled_beside_exchange") == rounds - 2  # ... and those were committed on the side stream, beside the exchange that followed
     # any map call lets the last batch in
     apply_held()
     assert a.map_validnum() == b.map_validnum()
