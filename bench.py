@@ -644,6 +644,7 @@ def main():
     ap.add_argument("--map-update", action="store_true", help="(kept for compatibility: the node loop is always reported)")
     ap.add_argument("--long-steps", type=int, default=5000, help="steps of value_long_window (the contract loop over a window a clock transient cannot flatter; 0 = off)")
     ap.add_argument("--other-configs", default="c3", help="comma-separated configs reported as compact blocks inside the default (c2) line; '' = none")
+    ap.add_argument("--no-loop-body", action="store_true", help="skip the `loop_body` block (the node's whole loop body on raw sweeps)")
     ap.add_argument("--emulate-world", type=int, default=8,
                     help="N = 1 only: also time this rank's node loop with the insert lists of W replicas applied (loop-back exchange; 0 = off)")
     a = ap.parse_args()
@@ -1012,6 +1013,21 @@ def main():
                     extras["node_loop"]["latency_long_window"] = ll
                 except capi.LioError as e:
                     extras["node_loop"]["latency_long_window"] = {"skipped": str(e), "steps_done": len(lat_long)}
+            # The loop a NODE runs per scan (laserMapping.cpp:2256-2401), on the same context and a fresh copy of
+            # the map: Process (IMU propagation on the host, compensation on the GPU) -> voxel filter -> update -> map_incremental ->
+            # lasermap_fov_segment on raw 120 k-point sweeps -- stage by stage, run through, and with the next sweep prefetched and
+            # prepared beside the map update (scripts/loop_body_step.py; not the contract metric)
+            if a.config == "c2" and not a.no_loop_body and a.steps >= 20:
+                try:
+                    import importlib.util
+                    spec = importlib.util.spec_from_file_location("loop_body_step", os.path.join(ROOT, "scripts", "loop_body_step.py"))
+                    lb = importlib.util.module_from_spec(spec)
+                    spec.loader.exec_module(lb)
+                    ctx.map_build(world.points)
+                    extras["loop_body"] = lb.run(ctx, capi, synth, world, n_scans=24)
+                    extras["loop_body"]["how"] = "scripts/loop_body_step.py: 120 k-point raw sweeps (x, y, z, t in page-locked memory), 0.5 m voxel filter, 3 ESKF iterations, the C2 map"
+                except Exception as e:                         # noqa: BLE001  (never at the cost of the headline line)
+                    extras["loop_body"] = {"skipped": repr(e)}
     else:
         cold_ms = None
         post_ms = None
@@ -1105,6 +1121,9 @@ def main():
                                  "launches of the timed drive repeated untimed right behind the timed region (no instrumentation inside `value`)"},
         "roofline_detail": detail,
     }
+    # what the pass control did over the whole run (lio_debug_get): passes that ran on launches armed ahead of their pose, called off,
+    # put on the stream again because a wait gave up (a host that stalled: must stay 0 on a quiet box), next-scan searches armed / released
+    out["pass_control"] = {k: int(ctx.debug_get(k)) for k in ("gate_released", "gate_called_off", "gate_reenqueued", "gate_in_kernel", "next_scan_armed", "next_scan_released")}
     if long_window is not None:
         out["value_long_window"] = long_window
     if step_floor is not None:
