@@ -374,7 +374,7 @@ struct lio_ctx {
     int raw_prefetch_n = 0;
     bool raw_prefetched = false;
     hipEvent_t ev_raw = nullptr;
-    hipStream_t prep_stream = nullptr;
+    hipStream_t prep_stream = nullptr;         // = copy_stream (ensure_prep, lio_scan.hip)
     bool prep_active = false, prep_filtered = false, prep_enqueued = false;
     VoxelRun prep_run;                         // the filter enqueued there: what lio_scan_prep_end judges
     unsigned long long *d_cagg_prep = nullptr, *d_gagg_prep = nullptr;   // the preparation stream's own stamped scratch

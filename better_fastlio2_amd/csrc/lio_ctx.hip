@@ -421,7 +421,7 @@ void lio_destroy(lio_ctx* c) {
         if (c->d_def_plain[i]) (void)hipFree(c->d_def_plain[i]);
         if (c->d_def_boxes[i]) (void)hipFree(c->d_def_boxes[i]);
     }
-    if (c->prep_stream) { (void)hipStreamSynchronize(c->prep_stream); (void)hipStreamDestroy(c->prep_stream); }
+    // (prep_stream is the copy stream: destroyed below)
     if (c->ev_raw) (void)hipEventDestroy(c->ev_raw);
     if (c->h_small3) (void)hipHostFree(c->h_small3);
     if (c->d_cagg_prep) (void)hipFree(c->d_cagg_prep);

@@ -393,7 +393,11 @@ int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
 //   lio_scan_prep_end(ctx, &n)             the filter's verdict (already there), the filtered cloud becomes the current scan
 // Same kernels, same order per stream, same values: the preparation writes the back scan buffer, the map update reads the front one.
 static int ensure_prep(lio_ctx* c) {
-    if (!c->prep_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking));
+    // The preparation runs on the context's COPY stream, behind the prefetch of its own sweep: a stream of its own may end up sharing
+    // a hardware queue with the main stream (the runtime hands queues out round-robin over ALL streams of the process -- inside
+    // bench.py, with the side stream and torch's streams alive, the overlapped loop body ran at 312 us instead of 215 us: nothing
+    // overlapped), and the copy stream has nothing else to do between lio_scan_prep_begin and _end (lio_scan_upload_async is excluded).
+    if (!c->prep_stream) c->prep_stream = c->copy_stream;
     if (!c->ev_raw) HIPCHK(c, hipEventCreateWithFlags(&c->ev_raw, hipEventDisableTiming));
     if (!c->h_small3) {
         HIPCHK(c, hipHostMalloc(&c->h_small3, 256, hipHostMallocMapped | hipHostMallocCoherent));

@@ -270,7 +270,7 @@ int  lio_scan_voxel_filter(lio_ctx* ctx, float leaf_size, int* n_out);
  *                           memory start their way to the GPU on the copy stream; the lio_scan_upload_raw / lio_imu_process call that
  *                           names the same records then takes them where they are.  Anything else: LIO_OK, nothing happens.
  *   lio_scan_prep_begin     from here to lio_scan_prep_end, lio_scan_upload_raw / lio_scan_compensate / lio_scan_undistort /
- *                           lio_imu_process / lio_scan_voxel_filter only ENQUEUE -- on a stream of their own, into the back scan buffer;
+ *                           lio_imu_process / lio_scan_voxel_filter only ENQUEUE -- on the context's copy stream, into the back scan buffer;
  *                           lio_scan_voxel_filter answers *n_out = -1.  Map calls (lio_map_incremental, lio_fov_segment, ...) and
  *                           read-outs of the CURRENT scan go on as ever on the main stream meanwhile.  Not together with
  *                           lio_scan_upload_async / lio_eskf_scan_step_pipelined (they use the same back buffer).
