@@ -1,6 +1,7 @@
 """Differential fuzzing of the scan preparation (lio_scan_undistort / lio_scan_voxel_filter / lio_scan_get_cloud)
 against the oracle restatements: random cloud sizes and extents, leaf sizes, time stamps with ties, non-finite
-points, pose lists of random length, both call orders (cloud read before / after the filter).
+points, pose lists of random length, both call orders (cloud read before / after the filter); half of the cases prepared
+between lio_scan_prep_begin / _end (prefetched sweep, own stream) beside an insert batch on the main stream.
 
     python tests/fuzz/fuzz_scanprep.py [n_cases] [first_seed]
 """
@@ -31,6 +32,7 @@ def poses_for(rng, n_poses, dt):
 
 
 def run_case(seed, ctx):
+    global n_overlapped
     rng = np.random.default_rng(seed)
     n = int(rng.choice([1, 2, 15, 16, 17, 255, 1000, 4096, 20_000, 60_000]))
     extent = float(rng.choice([2.0, 20.0, 80.0]))
@@ -59,11 +61,27 @@ def run_case(seed, ctx):
     end = np.concatenate([poses[-1, 10:13] + rng.normal(0, 0.01, 3), q, qo, rng.normal(0, 0.1, 3)])
     leaf = float(rng.choice([0.1, 0.2, 0.5, 1.0, 3.0]))
     read_first = bool(rng.integers(0, 2))
-    ctx.scan_undistort(raw, poses, end)
+    # round 5: half of the cases take the OVERLAPPED route -- the sweep prefetched by the copy engine (when it lies in page-locked
+    # memory), compensated and filtered between lio_scan_prep_begin / _end while an insert batch runs its own stamped scans and sorts
+    # on the main stream -- and must come out exactly like the serial calls
+    overlapped = rng.random() < 0.5
     und_o, ts = po.undistort(raw, poses, end)
-    und_g = ctx.scan_cloud(0) if read_first else None
+    und_g = None
     try:
-        m = ctx.scan_voxel_filter(leaf)
+        if overlapped:
+            src = capi.pinned_points(raw) if rng.random() < 0.7 else raw
+            ctx.scan_prefetch_raw(src) if src is not raw else None
+            ctx.scan_prep_begin()
+            ctx.scan_undistort(src, poses, end)
+            assert ctx.scan_voxel_filter(leaf) == -1, seed
+            batch = (rng.uniform(-40, 40, (int(rng.integers(1, 6000)), 3)) * [1, 1, 0.05]).astype(np.float32)
+            ctx.map_add(batch, bool(rng.integers(0, 2)))
+            n_overlapped += 1
+            m = ctx.scan_prep_end()
+        else:
+            ctx.scan_undistort(raw, poses, end)
+            und_g = ctx.scan_cloud(0) if read_first else None
+            m = ctx.scan_voxel_filter(leaf)
     except capi.LioError as e:
         # PCL's index overflow check, or more leaves than the scan buffer holds: the oracle must agree on the reason
         assert "LIO_ERR_CAPACITY" in str(e), (seed, str(e))
@@ -88,12 +106,15 @@ def run_case(seed, ctx):
 
 
 ctx_cap = 70_000
+n_overlapped = 0                                 # cases that went through lio_scan_prep_begin / _end
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 30000
-    ctx = capi.LioContext(0.2, max_scan_points=ctx_cap, max_map_points=100_000)
+    ctx = capi.LioContext(0.2, max_scan_points=ctx_cap, max_map_points=2_000_000)
+    ctx.map_build((np.random.default_rng(1).uniform(-40, 40, (40_000, 3)) * [1, 1, 0.05]).astype(np.float32))   # (the overlapped cases insert into it)
     res = {}
     for seed in range(s0, s0 + n):
         r = run_case(seed, ctx)
         res[r] = res.get(r, 0) + 1
-    print("FUZZ SCANPREP OK: %d cases %s; compact-key attempts %d, redone %d" % (n, res, ctx.debug_get("voxel_fast_runs"), ctx.debug_get("voxel_redone")), flush=True)
+    print("FUZZ SCANPREP OK: %d cases %s; compact-key attempts %d, redone %d; %d cases through lio_scan_prep_begin / _end (%d sweeps from the prefetch buffer, %d filtered beside the insert batch)"
+          % (n, res, ctx.debug_get("voxel_fast_runs"), ctx.debug_get("voxel_redone"), n_overlapped, ctx.debug_get("raw_prefetch_hits"), ctx.debug_get("prep_overlapped")), flush=True)

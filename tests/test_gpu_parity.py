@@ -511,18 +511,21 @@ def test_node_loop_fuzz_seeds(gpu_capi, oracle):
 def test_scan_preparation_fuzz_seeds(gpu_capi, oracle):
     """Forty cases of tests/fuzz/fuzz_scanprep.py: raw clouds from 1 to 60 k points with time ties, clumps (leaves with
     hundreds of points), non-finite points, pose lists of 2..25 entries, leaf sizes from 0.1 to 3 m, the cloud read
-    before or after the filter -- compensation vs the restatement, voxel grid bit-exact, PCL's overflow refusal."""
+    before or after the filter -- compensation vs the restatement, voxel grid bit-exact, PCL's overflow refusal; half of the cases
+    prepared between lio_scan_prep_begin / _end beside an insert batch on the main stream (round 5)."""
     import importlib.util
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz", "fuzz_scanprep.py")
     spec = importlib.util.spec_from_file_location("fuzz_scanprep", path)
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    ctx = gpu_capi.LioContext(0.2, max_scan_points=fz.ctx_cap, max_map_points=100_000)
+    ctx = gpu_capi.LioContext(0.2, max_scan_points=fz.ctx_cap, max_map_points=2_000_000)
+    ctx.map_build((np.random.default_rng(1).uniform(-40, 40, (40_000, 3)) * [1, 1, 0.05]).astype(np.float32))   # (the overlapped cases insert into it)
     seen = set()
     for seed in range(30000, 30040):
         seen.add(fz.run_case(seed, ctx))
     assert "ok" in seen
+    assert fz.n_overlapped >= 10 and ctx.debug_get("prep_overlapped") >= 1      # (round 5: half of the cases go through lio_scan_prep_begin / _end)
     ctx.close()
 
 
