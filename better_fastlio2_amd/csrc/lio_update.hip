@@ -1061,7 +1061,11 @@ static int deferred_settle_side_begin(lio_ctx* c) {
         if (e != hipSuccess) rc = c->fail(LIO_ERR_HIP, "deferred exchange: publishing the statistics", hipGetErrorString(e));
     }
     c->stream = main_stream;
-    if (rc != LIO_OK) return rc;
+    if (rc != LIO_OK) {
+        // part of the chain may be on the side stream: nothing of the error handling on the main stream may run beside it
+        (void)hipStreamSynchronize(c->side_stream);
+        return rc;
+    }
     c->settle_side = launched;                  // (not launched: a full rebuild took the batch in, synchronously)
     if (launched) ++c->n_settled_beside_exchange;
     return LIO_OK;
