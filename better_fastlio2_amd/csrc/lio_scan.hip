@@ -362,7 +362,7 @@ int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
     HIPCHK(c, hipSetDevice(c->device));
     const int n = c->n_raw;
     if (c->prep_active) {
-        // asynchronous preparation: the filter is enqueued on the preparation stream (its summary goes to a mail box of its own,
+        // asynchronous preparation: the filter is enqueued on the preparation (= copy) stream (its summary goes to a mail box of its own,
         // its centroids to the back scan buffer) and the call returns; lio_scan_prep_end reads the verdict and swaps the scan in.
         // The general path (tiny sweeps, sweeps out of time order) may use the library's workspace, which the map update on the main
         // stream uses too: such a sweep is filtered by lio_scan_prep_end instead.
@@ -388,7 +388,7 @@ int lio_scan_voxel_filter(lio_ctx* c, float leaf_size, int* n_out) {
 // the last two of scan k and the first two of scan k + 1 depend on nothing of each other but the posterior of scan k.)
 //   lio_scan_prefetch_raw(ctx, sweep)      the moment the driver has the sweep: copy engine -> a second raw buffer (copy stream)
 //   lio_scan_prep_begin(ctx)               from here on lio_scan_upload_raw / _compensate / _voxel_filter (through lio_imu_process or
-//                                          directly) only ENQUEUE, on a stream of their own with their own stamped scratch
+//                                          directly) only ENQUEUE, on the copy stream, with their own stamped scratch
 //   ... lio_map_incremental / lio_fov_segment of scan k on the main stream, as ever (they read scan k: untouched) ...
 //   lio_scan_prep_end(ctx, &n)             the filter's verdict (already there), the filtered cloud becomes the current scan
 // Same kernels, same order per stream, same values: the preparation writes the back scan buffer, the map update reads the front one.
