@@ -505,8 +505,9 @@ int residual_walkers(int nq) {
     return w;
 }
 
-// 256 lanes per workgroup: 512 measured the same and 1024 slower on MI355X (the kernel is a chain of
-// dependent round trips, not throughput-bound)
+// 256 lanes per workgroup: 512 measured the same and 1024 slower on MI355X (the kernel is a chain of dependent round trips, not
+// throughput-bound); 128 (round 6, A/B on one box, profiles/r06a_residual_128_lanes_ab.log): search pass 14.0-14.3 vs 12.7-13.0 us
+// at C2, equal at C3
 template <bool EXT, bool SEARCH, bool WALK>
 static void launch_residual_v(const ResidualArgs& a, hipStream_t s, KernelTimer t) {
     const dim3 grid(residual_blocks(a.nq) + (WALK ? a.n_walkers : 0)), block(256);

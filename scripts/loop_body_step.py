@@ -159,10 +159,12 @@ def run(ctx, capi, synth, world, n_scans=24, n_raw=120_000, staged=True):
         ctx.synchronize()
         v = np.asarray(lat[4:]) * 1e6
         key = "overlapped" if overlapped else "serial"
+        worst = np.argsort(v)[-4:][::-1]
         out[key] = {"median_us": float(np.median(v)), "p90_us": float(np.percentile(v, 90)), "scans_per_s": float(1e6 / np.median(v)), "scans": int(len(v)),
-                    "feats_down": int(nout.value)}
+                    "feats_down": int(nout.value), "slowest_scans": [{"scan": int(i) + 4, "us": float(v[i])} for i in worst]}
         if overlapped:
             out[key].update({"prefetched_sweeps": int(ctx.debug_get("raw_prefetch_hits") - hits0),
+                             "prefetch_hits_per_scan": float(ctx.debug_get("raw_prefetch_hits") - hits0) / n_total,
                              "preparations_filtered_beside_the_map_update": int(ctx.debug_get("prep_overlapped") - ov0)})
     out["map_points_after"] = int(ctx.map_validnum())
     return out
