@@ -219,7 +219,13 @@ int lio_imu_process(lio_imu* imu, lio_eskf* kf, lio_ctx* ctx, double lidar_beg_t
         meas.imu[i].stamp = samples[i].stamp;
         for (int k = 0; k < 3; ++k) { meas.imu[i].acc[k] = samples[i].acc[k]; meas.imu[i].gyr[k] = samples[i].gyr[k]; }
     }
-    return imu->p.Process(meas, kf->kf, ctx, undistorted);
+    int und = 0;
+    const int rc = imu->p.Process(meas, kf->kf, ctx, &und);
+    if (undistorted) *undistorted = und;
+    // a sweep prefetched for this call (lio_scan_prefetch_raw) that Process did not upload -- it returns before UndistortPcl while the
+    // IMU initialises -- must not answer for a later sweep in the same driver buffer
+    if (ctx && !und) ctx->raw_prefetched = false;
+    return rc;
 }
 int lio_imu_get_poses(lio_imu* imu, lio_pose6d* out, int cap, int* n) {
     if (!imu || !n) return LIO_ERR_INVALID_ARG;

@@ -90,10 +90,22 @@ hipError_t launch_bbox(const float4* pts, uint32_t n, uint32_t* bbox, hipStream_
 }
 
 // ---- map_incremental's classification (laserMapping.cpp:1448-1489) AND its two order-preserving lists, one launch --
+// A tile publishes EIGHT stamped words: its two list counts and the six faces of the bounding box of its list points (order
+// images).  Every tile sums the counts of the tiles before it (its write positions); the LAST tile also folds the boxes and
+// leaves the totals where the host / the exchange expect them (counts[0..1], bbox[0..5]) and -- round 6 -- as a BatchDesc with
+// both key frames for a map update that follows with no host round trip in between.  (Until round 5 every tile added its box
+// with six atomicMin / atomicMax on the same cache line: 391 tiles x 6 same-line atomics at ~7 ns each were most of the
+// kernel's 16 us at 100 k points.)
 __global__ __launch_bounds__(256) void map_incremental_lists_kernel(IncrArgs a, float4* add_out, float4* nodown_out, uint32_t* counts,
-                                                                    uint32_t* bbox, u64* agg, uint32_t stamp, uint32_t* err) {
+                                                                    uint32_t* bbox, u64* agg, uint32_t stamp, uint32_t* err,
+                                                                    BatchDesc* desc, float ds, float inv_cell, int kb_max) {
     __shared__ uint32_t s_w1[4], s_w2[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint32_t s_bb[4][6];
+    __shared__ uint32_t s_sum[2][4];
+    __shared__ uint32_t s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (int)blockIdx.x;
+    const int i = b * 256 + tid;
     uint8_t cls = 0;
     float4 wp = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < a.nq) {
@@ -101,26 +113,141 @@ __global__ __launch_bounds__(256) void map_incremental_lists_kernel(IncrArgs a, 
         a.world[i] = wp;
         a.cls[i] = cls;
     }
-    block_bbox(wp, cls != 0, bbox);                              // of both lists: the frames of the batch's keys (lio_mapadd.h)
+    if (tid == 0) s_bad = 0u;
+    // the tile's box (of both lists: the frames of the batch's keys, lio_mapadd.h); a non-finite coordinate counts as 0 (lio_bbox.h)
+    {
+        const float c3[3] = {wp.x, wp.y, wp.z};
+        uint32_t lo[3], hi[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const float v = (__float_as_uint(c3[ax]) & 0x7f800000u) != 0x7f800000u ? c3[ax] : 0.0f;
+            lo[ax] = cls != 0 ? float_order_image(v) : BBOX_MIN_INIT;
+            hi[ax] = cls != 0 ? float_order_image(v) : BBOX_MAX_INIT;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t x = (uint32_t)__shfl_xor((int)lo[ax], o, 64), y = (uint32_t)__shfl_xor((int)hi[ax], o, 64);
+                lo[ax] = x < lo[ax] ? x : lo[ax];
+                hi[ax] = y > hi[ax] ? y : hi[ax];
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { s_bb[wave][ax] = lo[ax]; s_bb[wave][3 + ax] = hi[ax]; }
+        }
+    }
     uint32_t tot1, tot2;
-    const uint32_t r1 = tile_rank(cls == 1, tot1, s_w1);
+    const uint32_t r1 = tile_rank(cls == 1, tot1, s_w1);        // (its barrier also completes s_bb and s_bad)
     const uint32_t r2 = tile_rank(cls == 2, tot2, s_w2);
-    const uint32_t mine[2] = {tot1, tot2};
-    uint32_t before[2];
-    const bool ok = tile_exclusive_prefix<2>(mine, agg, stamp, before);
-    if (ok && cls == 1) add_out[before[0] + r1] = wp;
-    if (ok && cls == 2) nodown_out[before[1] + r2] = wp;
+    // publish: words 0..1 the counts, 2..7 the box
+    if (tid < 8) {
+        uint32_t v;
+        if (tid == 0) v = tot1;
+        else if (tid == 1) v = tot2;
+        else {
+            const int f = tid - 2;
+            v = s_bb[0][f];
+            for (int w = 1; w < 4; ++w) v = f < 3 ? (s_bb[w][f] < v ? s_bb[w][f] : v) : (s_bb[w][f] > v ? s_bb[w][f] : v);
+        }
+        __hip_atomic_store(agg + (size_t)b * 8 + tid, (u64)v | ((u64)stamp << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the counts of the tiles before this one
+    uint32_t acc1 = 0u, acc2 = 0u;
+    bool bad = false;
+    for (int p = tid; p < b; p += 256) {
+        u64 v1, v2;
+        unsigned spins = 0;
+        do {
+            v1 = __hip_atomic_load(agg + (size_t)p * 8 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v2 = __hip_atomic_load(agg + (size_t)p * 8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (((uint32_t)(v1 >> 32) != stamp || (uint32_t)(v2 >> 32) != stamp) && ++spins < COMPACT_SPIN_LIMIT);
+        bad = bad || (uint32_t)(v1 >> 32) != stamp || (uint32_t)(v2 >> 32) != stamp;
+        acc1 += (uint32_t)v1; acc2 += (uint32_t)v2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { acc1 += (uint32_t)__shfl_xor((int)acc1, o, 64); acc2 += (uint32_t)__shfl_xor((int)acc2, o, 64); }
+    if (lane == 0) { s_sum[0][wave] = acc1; s_sum[1][wave] = acc2; }
+    if (bad) s_bad = 1u;
+    __syncthreads();
+    const uint32_t before1 = s_sum[0][0] + s_sum[0][1] + s_sum[0][2] + s_sum[0][3];
+    const uint32_t before2 = s_sum[1][0] + s_sum[1][1] + s_sum[1][2] + s_sum[1][3];
+    bool ok = s_bad == 0u;
+    if (ok && cls == 1) add_out[before1 + r1] = wp;
+    if (ok && cls == 2) nodown_out[before2 + r2] = wp;
     // a tile whose wait ran out has skipped its writes: EVERY such tile reports (the last tile's own wait may well succeed)
-    if (!ok && threadIdx.x == 0) atomicOr(err, 1u);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        counts[0] = ok ? before[0] + tot1 : 0u;
-        counts[1] = ok ? before[1] + tot2 : 0u;
+    if (!ok && tid == 0) atomicOr(err, 1u);
+    if (b != (int)gridDim.x - 1) return;
+    // ---- the last tile: the box of all tiles (their words were published before the counts this tile has just seen were -- but
+    // by other lanes: every word carries its own stamp and is polled for it)
+    __syncthreads();                                              // (s_bb / s_sum are reused)
+    uint32_t bb[6] = {BBOX_MIN_INIT, BBOX_MIN_INIT, BBOX_MIN_INIT, BBOX_MAX_INIT, BBOX_MAX_INIT, BBOX_MAX_INIT};
+    for (int p = tid; p <= b; p += 256) {
+        u64 v[6];
+        unsigned spins = 0;
+        bool got;
+        do {
+            got = true;
+#pragma unroll
+            for (int f = 0; f < 6; ++f) {
+                v[f] = __hip_atomic_load(agg + (size_t)p * 8 + 2 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                got = got && (uint32_t)(v[f] >> 32) == stamp;
+            }
+        } while (!got && ++spins < COMPACT_SPIN_LIMIT);
+        if (!got) { s_bad = 1u; continue; }
+#pragma unroll
+        for (int f = 0; f < 3; ++f) { bb[f] = (uint32_t)v[f] < bb[f] ? (uint32_t)v[f] : bb[f]; bb[3 + f] = (uint32_t)v[3 + f] > bb[3 + f] ? (uint32_t)v[3 + f] : bb[3 + f]; }
+    }
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t x = (uint32_t)__shfl_xor((int)bb[f], o, 64), y = (uint32_t)__shfl_xor((int)bb[3 + f], o, 64);
+            bb[f] = x < bb[f] ? x : bb[f];
+            bb[3 + f] = y > bb[3 + f] ? y : bb[3 + f];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) s_bb[wave][f] = bb[f];
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    ok = s_bad == 0u;
+    if (!ok) atomicOr(err, 1u);
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        uint32_t v = s_bb[0][f];
+        for (int w = 1; w < 4; ++w) v = f < 3 ? (s_bb[w][f] < v ? s_bb[w][f] : v) : (s_bb[w][f] > v ? s_bb[w][f] : v);
+        bb[f] = v;
+    }
+    const uint32_t n1 = ok ? before1 + tot1 : 0u, n2 = ok ? before2 + tot2 : 0u;
+    counts[0] = n1;
+    counts[1] = n2;
+    // (the accumulators may hold the box of lists made earlier and never consumed: a wider box is harmless, lio_mapadd.h)
+#pragma unroll
+    for (int f = 0; f < 3; ++f) { if (bb[f] < bbox[f]) bbox[f] = bb[f]; if (bb[3 + f] > bbox[3 + f]) bbox[3 + f] = bb[3 + f]; }
+    if (desc != nullptr) {
+        BatchDesc d{};
+        d.flags = ok ? 0u : 1u;
+        if (ok && n1 + n2 != 0u) {
+            float blo[3], bhi[3];
+#pragma unroll
+            for (int f = 0; f < 3; ++f) { blo[f] = float_from_order_image(bbox[f]); bhi[f] = float_from_order_image(bbox[3 + f]); }
+            d.vf = voxel_frame_of(blo, bhi, ds);
+            d.cf = cell_frame_of(blo, bhi, ds, inv_cell);
+            d.kb_v = (uint32_t)frame_bits(d.vf); d.kb_c = (uint32_t)frame_bits(d.cf) + 1u;
+            if ((int)d.kb_v > kb_max || (int)d.kb_c > kb_max) d.flags |= 2u;
+        }
+        d.n_add = d.flags == 0u ? n1 : 0u;
+        d.n_plain = d.flags == 0u ? n2 : 0u;
+        *desc = d;
     }
 }
 hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, float4* nodown_out, uint32_t* counts, uint32_t* bbox, u64* agg,
-                                        uint32_t stamp, uint32_t* err, hipStream_t s) {
+                                        uint32_t stamp, uint32_t* err, hipStream_t s, BatchDesc* desc, float ds, float inv_cell, int kb_max) {
     if (a.nq <= 0) return hipSuccess;
-    hipLaunchKernelGGL(map_incremental_lists_kernel, dim3((a.nq + 255) / 256), dim3(256), 0, s, a, add_out, nodown_out, counts, bbox, agg, stamp, err);
+    if ((size_t)((a.nq + 255) / 256) * 8u > COMPACT_AGG_WORDS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(map_incremental_lists_kernel, dim3((a.nq + 255) / 256), dim3(256), 0, s, a, add_out, nodown_out, counts, bbox, agg, stamp, err,
+                       desc, ds, inv_cell, kb_max);
     return hipGetLastError();
 }
 
@@ -180,7 +307,8 @@ hipError_t launch_run_heads(const uint64_t* keys, uint32_t n, int shift, uint32_
 __global__ __launch_bounds__(256) void compact_dirty_kernel(BoundaryArgs a, u64* agg, uint32_t stamp, uint32_t* err) {
     __shared__ uint32_t s_w[4];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool live = i < a.view.n && a.dirty_pt[i] != 0;
+    const uint32_t n = a.view.n_dev != nullptr ? min(a.view.n, *a.view.n_dev + a.view.n_add) : a.view.n;   // (beyond it the marks are not initialised)
+    const bool live = i < n && a.dirty_pt[i] != 0;
     uint32_t tot;
     const uint32_t r = tile_rank(live, tot, s_w);
     const uint32_t mine[1] = {tot};
@@ -203,7 +331,10 @@ __global__ __launch_bounds__(256) void pend_build_kernel(PendBuildArgs a) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_hist[256];
     const int tid = threadIdx.x;
-    const uint32_t tp = (a.n_plain + 255u) / 256u;
+    const uint32_t tp = (a.n_plain + 255u) / 256u;              // tiles of the plain list (by the launch bound with desc)
+    // (round 6) the counts and the cell frame may still be on the device: n_plain / n_surv_slots are then launch bounds
+    uint32_t n_plain = a.n_plain, half = a.n_surv_slots, n_half = a.n_surv_slots;
+    if (a.desc != nullptr) { n_plain = min(a.n_plain, a.desc->n_plain); half = a.n_surv_slots / 2u; n_half = min(half, a.desc->n_add); a.frame = a.desc->cf; }
     const int kb = frame_bits(a.frame) + 1;
     if (a.count_parts != nullptr && blockIdx.x == gridDim.x - 1) {
         // the extra workgroup: the fold's counters, one pair per workgroup of fold_commit_kernel, added up (fixed order)
@@ -215,6 +346,7 @@ __global__ __launch_bounds__(256) void pend_build_kernel(PendBuildArgs a) {
         if ((tid & 63) == 0) { s_rc[tid >> 6][0] = r; s_rc[tid >> 6][1] = c; }
         __syncthreads();
         if (tid < 2) a.fold_counts[tid] = s_rc[0][tid] + s_rc[1][tid] + s_rc[2][tid] + s_rc[3][tid];
+        if (a.desc != nullptr && tid == 2) { a.desc_copy[0] = a.desc->n_add; a.desc_copy[1] = a.desc->n_plain; a.desc_copy[2] = a.desc->flags; }
         return;
     }
     const uint32_t n_tiles = gridDim.x - (a.count_parts != nullptr ? 1u : 0u);     // tiles of the list proper
@@ -234,22 +366,27 @@ __global__ __launch_bounds__(256) void pend_build_kernel(PendBuildArgs a) {
     };
     if (blockIdx.x < tp) {
         const uint32_t i = blockIdx.x * 256u + (uint32_t)tid;
-        if (i < a.n_plain) emit(i, a.plain[i], 1u);
-        if (a.n_surv_slots == 0u && blockIdx.x == 0 && tid == 0) *a.n_surv = 0u;
+        if (i < n_plain) emit(i, a.plain[i], 1u);
+        if (a.n_surv_slots == 0u && blockIdx.x == 0 && tid == 0) { *a.n_surv = 0u; if (a.n_pend != nullptr) *a.n_pend = n_plain; }
     } else {
         const uint32_t b = blockIdx.x - tp;
         const uint32_t i = b * 256u + (uint32_t)tid;
         float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
-        if (i < a.n_surv_slots) p = a.surv[i];
-        const bool live = i < a.n_surv_slots && p.w == 0.0f;
+        // (with desc: two halves of `half` slots, the first n_half of each are real -- the others were never initialised)
+        const bool real = i < a.n_surv_slots && (i < half ? i : i - half) < n_half;
+        if (real) p = a.surv[i];
+        const bool live = real && p.w == 0.0f;
         uint32_t tot;
         const uint32_t r = tile_rank(live, tot, s_w);
         const uint32_t mine[1] = {tot};
         uint32_t before[1];
         const bool ok = tile_exclusive_prefix<1>(mine, a.agg, a.stamp, before, (int)b);
-        if (ok && live) emit(a.n_plain + before[0] + r, p, 0u);
+        if (ok && live) emit(n_plain + before[0] + r, p, 0u);
         if (!ok && tid == 0) atomicOr(a.err, 1u);
-        if (blockIdx.x == n_tiles - 1 && tid == 0) *a.n_surv = ok ? before[0] + tot : 0u;
+        if (blockIdx.x == n_tiles - 1 && tid == 0) {
+            *a.n_surv = ok ? before[0] + tot : 0u;
+            if (a.n_pend != nullptr) *a.n_pend = ok ? n_plain + before[0] + tot : 0u;
+        }
     }
     if (a.hist != nullptr) {
         __syncthreads();

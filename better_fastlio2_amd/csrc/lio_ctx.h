@@ -197,7 +197,11 @@ struct lio_ctx {
     uint32_t *d_porder = nullptr, *d_porder2 = nullptr, *d_pnewoff = nullptr;
     CellPlan* d_plan = nullptr;
     uint32_t* d_apply = nullptr;               // [0..2] apply stats, [3] new slots, [4] fold: replaced, [5] fold: tmp_counter,
-                                               // [6] survivors, [10] boundary points, [14] key-frame violations, [15] compaction time-outs
+                                               // [6] survivors, [7] pending points, [10] boundary points, [11..13] n_add / n_plain / flags of the
+                                               // BatchDesc, [14] key-frame violations, [15] compaction time-outs; [32..47] the BatchDesc itself
+    bool dbg_fast_update = true;               // LIO_FAST_UPDATE=0: lio_map_incremental takes the host round trip between its lists and their
+                                               // Add_Points again (A/B runs of scripts)
+    long long n_fast_updates = 0;              // map updates that ran without it
     uint32_t* d_ghist = nullptr;               // two partition histograms of the group sort (lio_gsort.hip), used alternately
     int ghist_cur = 0;
     bool ghist_dirty = false;                  // a key kernel filled a histogram whose sort never ran
@@ -337,6 +341,7 @@ struct lio_ctx {
     uint32_t* d_small = nullptr;               // device alias of h_small
     uint32_t small_seq = 0;
     bool stage_busy = false;
+    hipStream_t stage_stream = nullptr;        // the stream ev_stage was last recorded on (one event covers the buffer: lio_scan_compensate)
     size_t stage_busy_slots = 0;               // float4 slots at the head of h_stage the copy in flight still reads
     bool undist_sorted = true;                 // d_undist is in time order (else: input order, sorted on demand)
     bool raw_time_keyed = false;               // the raw scan came with per-point times
@@ -425,6 +430,7 @@ struct lio_ctx {
     int def_cur = 0;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_side = nullptr;
+    hipEvent_t ev_main = nullptr;              // main stream -> side stream: the commit of a deferred batch starts behind whatever the main stream holds
     void* h_small2 = nullptr;                  // a second host-mapped mail box (the totals of an exchange, read after the settle's own wait)
     uint32_t* d_small2 = nullptr;
     uint32_t small2_seq = 0;
@@ -540,7 +546,7 @@ LIO_INTERNAL int check_compact_error(lio_ctx* c, uint32_t flag_word);
 LIO_INTERNAL SortKind sort_kind(const lio_ctx* c, size_t n_bound, int kb);
 LIO_INTERNAL int sort_hist(lio_ctx* c, SortKind k, uint32_t** hist);
 LIO_INTERNAL int run_sort(lio_ctx* c, SortKind k, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
-                          size_t n_bound, const uint32_t* n_dev, uint32_t n_dev_add, int kb);
+                          size_t n_bound, const uint32_t* n_dev, uint32_t n_dev_add, int kb, const uint32_t* kb_dev = nullptr);
 LIO_INTERNAL hipError_t compact_live_any(lio_ctx* c, const float4* src, uint32_t n, float4* dst, uint32_t* n_out);
 LIO_INTERNAL bool is_pinned_host(const void* p);
 LIO_INTERNAL void prof_collect(lio_ctx* c);

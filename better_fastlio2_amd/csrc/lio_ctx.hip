@@ -93,7 +93,7 @@ int upload_points(lio_ctx* c, const float* pts, size_t n, int stride_bytes, floa
     pack_points(pts, n, stride_bytes, c->h_stage);
     HIPCHK(c, hipMemcpyAsync(d_dst, c->h_stage, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_stage, c->stream));
-    c->stage_busy = true; c->stage_busy_slots = n;
+    c->stage_busy = true; c->stage_busy_slots = n; c->stage_stream = c->stream;
     return LIO_OK;
 }
 
@@ -146,14 +146,14 @@ int sort_hist(lio_ctx* c, SortKind k, uint32_t** hist) {
 // stable sort by key of n_bound records of which *n_dev + n_dev_add are real (n_dev == nullptr: all); with SORT_LIBRARY the
 // unused slots must hold keys that sort last.  Result in keys_out / vals_out.
 int run_sort(lio_ctx* c, SortKind k, const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
-                    size_t n_bound, const uint32_t* n_dev, uint32_t n_dev_add, int kb) {
+                    size_t n_bound, const uint32_t* n_dev, uint32_t n_dev_add, int kb, const uint32_t* kb_dev) {
     hipStream_t s = c->stream;
     if (n_bound == 0) return LIO_OK;
     if (k == SORT_RANK) {
         HIPCHK(c, launch_sort_pairs_small(keys_in, vals_in, (uint32_t)n_bound, keys_out, vals_out, s, n_dev, n_dev_add));
     } else if (k == SORT_LARGE) {
         GsortArgs g{};
-        g.keys = keys_in; g.vals = vals_in; g.n = (uint32_t)n_bound; g.n_dev = n_dev; g.n_dev_add = n_dev_add; g.kb = kb;
+        g.keys = keys_in; g.vals = vals_in; g.n = (uint32_t)n_bound; g.n_dev = n_dev; g.n_dev_add = n_dev_add; g.kb = kb; g.kb_dev = kb_dev;
         g.keys_out = keys_out; g.vals_out = vals_out; g.part = c->d_gs_part; g.part2 = c->d_gs_part2;
         g.hist = c->d_ghist + 256 * c->ghist_cur; g.hist_other = c->d_ghist + 256 * (c->ghist_cur ^ 1);
         if (++c->gsort_seq == 0u) {                        // (stamp wrap-around: as next_compact_stamp)
@@ -262,6 +262,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     { const char* e = std::getenv("LIO_ARM_NEXT_SCAN"); if (e != nullptr && e[0] == '0') c->dbg_arm_next_scan = 0; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_GATE_IN_KERNEL"); if (e != nullptr && e[0] >= '0' && e[0] <= '7' && e[1] == 0) c->gate_in_kernel = e[0] - '0'; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_ASSIST_PULL"); if (e != nullptr && e[0] >= '0' && e[0] <= '9') c->dbg_assist_pull = std::atoi(e); }   // (A/B runs of scripts)
+    { const char* e = std::getenv("LIO_FAST_UPDATE"); if (e != nullptr && e[0] == '0') c->dbg_fast_update = false; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_KNN_WALK"); if (e != nullptr && (e[0] == '0' || e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0) c->dbg_knn_walk = e[0] - '0'; }
     hipDeviceProp_t prop;
     CREATE_CHK(hipGetDeviceProperties(&prop, c->device));
@@ -309,8 +310,8 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     if (c->slots_cap > 0xfffffff0ull) c->slots_cap = 0xfffffff0ull;
     CREATE_CHK(hipMalloc((void**)&c->d_pts, c->slots_cap * sizeof(float4)));
     CREATE_CHK(hipMalloc((void**)&c->d_pts_tmp, c->slots_cap * sizeof(float4)));
-    CREATE_CHK(hipMalloc((void**)&c->d_apply, 32 * sizeof(uint32_t)));
-    CREATE_CHK(hipMemset(c->d_apply, 0, 32 * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_apply, 64 * sizeof(uint32_t)));     // (words 32..: the BatchDesc of the insert lists, lio_mapadd.h)
+    CREATE_CHK(hipMemset(c->d_apply, 0, 64 * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_mkeys, nm * sizeof(uint64_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_mkeys_tmp, nm * sizeof(uint64_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_vals, nm * sizeof(uint32_t)));
@@ -423,6 +424,7 @@ void lio_destroy(lio_ctx* c) {
     }
     // (prep_stream is the copy stream: destroyed below)
     if (c->ev_raw) (void)hipEventDestroy(c->ev_raw);
+    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
     if (c->h_small3) (void)hipHostFree(c->h_small3);
     if (c->d_cagg_prep) (void)hipFree(c->d_cagg_prep);
     if (c->d_gagg_prep) (void)hipFree(c->d_gagg_prep);
@@ -510,10 +512,9 @@ int lio_debug_set(lio_ctx* c, const char* key, long long value) {
         if (value < 0 || value % 64 != 0 || value > 65536) return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_set", "assist_pull_chunk: 0 (by scan size) or a multiple of 64 up to 65536");
         c->dbg_assist_chunk = (int)value; return LIO_OK;
     }
-    if (std::strcmp(key, "assist_pull_threads") == 0) return lio_scan_pack_threads(c, (int)value);
     if (std::strcmp(key, "assist_pull_stall_us") == 0) { c->dbg_assist_stall_us = (int)value; return LIO_OK; }
     if (std::strcmp(key, "fused_pull") == 0) { c->dbg_fused_pull = value != 0; return LIO_OK; }
-    if (std::strcmp(key, "settle_beside_exchange") == 0) { c->dbg_settle_beside = value != 0; return LIO_OK; }
+    if (std::strcmp(key, "fast_update") == 0) { c->dbg_fast_update = value != 0; return LIO_OK; }   // (round 6; replaces the unused keys "settle_beside_exchange": LIO_SETTLE_BESIDE, and "assist_pull_threads": lio_scan_pack_threads)
     if (std::strcmp(key, "pull_alias_shift") == 0) { c->dbg_pull_alias_shift = (int)value; return LIO_OK; }
     if (std::strcmp(key, "retired_budget") == 0) { c->dbg_retired_budget = value; return LIO_OK; }
     if (std::strcmp(key, "pre_enqueue") == 0) { c->dbg_pre_enqueue = value != 0; return LIO_OK; }
@@ -558,6 +559,7 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "raw_prefetch_hits") == 0) { *value = c->n_raw_prefetch_hits; return LIO_OK; }
     if (std::strcmp(key, "prep_overlapped") == 0) { *value = c->n_prep_overlapped; return LIO_OK; }
     if (std::strcmp(key, "rows_direct_dma") == 0) { *value = c->n_rows_direct_dma; return LIO_OK; }
+    if (std::strcmp(key, "fast_updates") == 0) { *value = c->n_fast_updates; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_get", "unknown key");
 }
 int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {

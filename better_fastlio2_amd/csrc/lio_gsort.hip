@@ -78,7 +78,8 @@ __global__ __launch_bounds__(512) void gsort_partition_kernel(GsortArgs a) {
     for (int x = tid; x < 8 * 256; x += 512) (&s_wcnt[0][0])[x] = 0u;
     if (tid == 0) s_bad = 0u;
     __syncthreads();
-    const int msd_shift = a.kb > 8 ? a.kb - 8 : 0;
+    const int kb = a.kb_dev != nullptr ? (int)*a.kb_dev : a.kb;
+    const int msd_shift = kb > 8 ? kb - 8 : 0;
     const uint32_t i0 = blockIdx.x * GS_TILE + (uint32_t)wave * 256u;
     u64 rec[4];
     uint32_t off[4], dg[4];
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(1024) void gsort_bucket_kernel(GsortArgs a) {
     const uint32_t base = s_range[0], cnt = s_range[1];
     if (cnt == 0u) return;
     // what the partition left to sort: the key bits below its digit, 8 bits or fewer per pass
-    const int rem = a.kb > 8 ? a.kb - 8 : 0;
+    const int kb = a.kb_dev != nullptr ? (int)*a.kb_dev : a.kb;
+    const int rem = kb > 8 ? kb - 8 : 0;
     const int passes = (rem + 7) / 8;
     const int w = passes > 0 ? (rem + passes - 1) / passes : 0;
     const u64* fin;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(1024) void gsort_bucket_kernel(GsortArgs a) {
 
 hipError_t launch_gsort_large(const GsortArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    if (a.n > GSORT_MAX || a.kb + GS_IB > 64) return hipErrorInvalidValue;
+    if (a.n > GSORT_MAX || (a.kb_dev == nullptr && a.kb + GS_IB > 64)) return hipErrorInvalidValue;   // (device-resident key bits: BATCH_KB_MAX)
     hipLaunchKernelGGL(gsort_partition_kernel, dim3((a.n + GS_TILE - 1u) / GS_TILE), dim3(512), 0, s, a);
     hipLaunchKernelGGL(gsort_bucket_kernel, dim3(256), dim3(1024), 0, s, a);
     return hipGetLastError();

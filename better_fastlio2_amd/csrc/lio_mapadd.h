@@ -37,6 +37,53 @@ LIO_HD int voxel_coord(float v, float ds) {
     return (int)f;
 }
 
+// frame of the integer coordinates lo .. hi (inclusive) of a batch: one spare coordinate per axis above hi, so that the
+// all-ones key is never a point's (the group of the non-finite points, lio_mapadd.hip)
+LIO_HD KeyFrame frame_of(const int lo[3], const int hi[3]) {
+    KeyFrame f{};
+    f.ox = lo[0]; f.oy = lo[1]; f.oz = lo[2];
+    int bits[3];
+    for (int i = 0; i < 3; ++i) {
+        const long long extent = (long long)hi[i] - (long long)lo[i] + 2;
+        int b = 1;
+        while (b < 40 && (1ll << b) < extent) ++b;
+        bits[i] = b;
+    }
+    f.bx = bits[0]; f.by = bits[1]; f.bz = bits[2];
+    return f;
+}
+// of the down-sample voxel keys of a batch inside the box blo .. bhi
+LIO_HD KeyFrame voxel_frame_of(const float blo[3], const float bhi[3], float ds) {
+    int lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) { lo[i] = voxel_coord(blo[i], ds); hi[i] = voxel_coord(bhi[i], ds); }   // floor(v / ds) is monotone in v
+    return frame_of(lo, hi);
+}
+// of the grid cells the pending points of a batch can fall into: survivors are batch points or map points inside the
+// down-sample boxes of batch points, i.e. within one box edge of the batch's bounding box
+LIO_HD KeyFrame cell_frame_of(const float blo[3], const float bhi[3], float ds, float inv_cell) {
+    int lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) {
+        lo[i] = cell_coord(blo[i] - 2.0f * ds, inv_cell) - 1;
+        hi[i] = cell_coord(bhi[i] + 2.0f * ds, inv_cell) + 1;
+    }
+    return frame_of(lo, hi);
+}
+
+// What the kernel that makes map_incremental's two insert lists leaves ON THE DEVICE for the kernels of the map update behind
+// it (round 6: no host round trip between the lists and their Add_Points -- the host used to read the two counts and the
+// bounding box back, derive the frames and only then launch): the list lengths and both key frames, derived by the last tile
+// of that kernel with the very functions the host uses (frame_of above: same integers either way).
+struct BatchDesc {
+    uint32_t n_add, n_plain;        // PointToAdd / PointNoNeedDownsample as the update is to see them (0 / 0 when flags != 0)
+    uint32_t flags;                 // 1: a bounded wait of the list kernel ran out; 2: a frame too wide for the group sort (the host's
+                                    // own path takes the lists -- they are intact, their counts and box where they always were)
+    uint32_t kb_v, kb_c;            // key bits of the two sorts: frame_bits(vf), frame_bits(cf) + 1
+    uint32_t pad[3];
+    KeyFrame vf;                    // of the down-sample voxel keys
+    KeyFrame cf;                    // of the grid-cell keys
+};
+constexpr int BATCH_KB_MAX = 46;    // 64 - GSORT_INDEX_BITS (lio_gsort.hip: the record is key << 18 | input position)
+
 // ---- a batch grouped by key: what lio_gsort.hip leaves --------------------------------------------------------------
 // Sorted keys + the batch index of the record at every sorted position.  Equal keys are contiguous and in batch order;
 // a GROUP is named by the position of its first record (its HEAD): position s is a head iff s == 0 or the keys at s-1 and s differ.
@@ -111,6 +158,7 @@ struct ApplyArgs {
     GroupView        view;          // pending points grouped by (grid cell, list): key = cell key * 2 + (1 for the plain list), so
                                     // that inside a cell the survivors of Add_Points(.., true) precede the plain inserts (:1492-1493)
     KeyFrame         frame;         // of the cell keys
+    const KeyFrame*  frame_dev;     // nullptr, or where the frame is on the device (BatchDesc: it replaces `frame`)
     CellPlan*        plan;          // [position] (heads)
     uint32_t*        new_size;      // [position] live old points + new points of a head, 0 elsewhere
     uint32_t*        new_off;       // [position] exclusive scan of new_size (written by the plan kernel)
@@ -144,6 +192,7 @@ struct BoundaryArgs {
     const float4*    new_pts;       // the batch, caller's order
     GroupView        view;          // grouped by voxel
     KeyFrame         frame;         // of the voxel keys
+    const KeyFrame*  frame_dev;     // nullptr, or where the frame is on the device (BatchDesc: it replaces `frame`)
     uint8_t*         dirty;         // [n] per head position
     uint8_t*         dirty_pt;      // [n] per batch index: the point belongs to a dirty group
     uint32_t*        dlist;         // [n] batch indices of the points of dirty groups, ascending (compact_dirty)
@@ -166,7 +215,8 @@ hipError_t launch_map_incremental(const IncrArgs& a, hipStream_t s);
 // (counters, dirty marks, "nothing" in every survivor slot, the bounding box accumulators for the next batch)
 struct VoxelKeyArgs {
     const float4* pts;
-    uint32_t      n;
+    uint32_t      n;                // points, or (desc != nullptr) the launch bound
+    const BatchDesc* desc;          // nullptr, or the device-resident count (n_add) and frame (vf) that replace `n` / `frame`
     float         ds;
     KeyFrame      frame;
     uint64_t*     keys;
@@ -175,7 +225,7 @@ struct VoxelKeyArgs {
     uint32_t*     zero_counters;    // [0..1] fold counters, [6] number of boundary points  (d_apply + 4)
     uint8_t*      dirty;
     uint8_t*      dirty_pt;
-    float4*       out2n;            // [2n] survivor slots of the fold and of the replay
+    float4*       out2n;            // [2n] survivor slots of the fold and of the replay (n = the launch bound with desc)
     uint32_t*     bbox;             // [6] reset to "empty"
     uint32_t*     flags;            // |= 1 when a point lies outside the frame (must not happen: reported)
 };
@@ -189,6 +239,11 @@ struct PendBuildArgs {
     uint32_t      n_surv_slots;
     const float4* plain;            // PointNoNeedDownsample (may be nullptr)
     uint32_t      n_plain;
+    const BatchDesc* desc;          // nullptr, or the device-resident counts and cell frame: n_plain is then the launch bound of the
+                                    // plain list, the survivor slots are two halves of n_surv_slots / 2 of which the first n_add
+                                    // each are real, and `frame` is replaced by desc->cf
+    uint32_t*     n_pend;           // (with desc) out: n_plain + survivors, the length of the pending list
+    uint32_t*     desc_copy;        // (with desc) out: [0] n_add, [1] n_plain, [2] flags -- where the statistics read-back finds them
     float4*       pend;             // out: [n_plain][survivors]
     Grid          grid;
     KeyFrame      frame;            // cell frame
@@ -210,10 +265,12 @@ hipError_t launch_pend_build(const PendBuildArgs& a, hipStream_t s);
 // 8-byte words of scratch shared by all of them, stamp = a number no earlier launch on this buffer used, *err |= 1 on a
 // timed-out wait
 constexpr uint32_t COMPACT_MAX_ITEMS = 262144;    // 1024 tiles of 256: all resident at once
-constexpr size_t COMPACT_AGG_WORDS = 2 * 1024;
+constexpr size_t COMPACT_AGG_WORDS = 8 * 1024;   // (the list kernel publishes eight words per tile: two counts, the six faces of its bounding box)
 // map_incremental's classification + PointToAdd / PointNoNeedDownsample in scan order + their counts + their bounding box, one launch
+// desc (optional): the BatchDesc of the two lists for a map update that follows without a host round trip (ds / inv_cell: what its frames are derived with)
 hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, float4* nodown_out, uint32_t* counts, uint32_t* bbox,
-                                        unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s);
+                                        unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s,
+                                        BatchDesc* desc = nullptr, float ds = 0.0f, float inv_cell = 0.0f, int kb_max = BATCH_KB_MAX);
 // live points (w == 0) to the front of dst, order kept
 hipError_t launch_compact_live(const float4* src, uint32_t n, float4* dst, uint32_t* n_out, unsigned long long* agg, uint32_t stamp,
                                uint32_t* err, hipStream_t s);
@@ -246,6 +303,7 @@ struct GsortArgs {
     const uint32_t* n_dev;          // optional device-resident count: *n_dev + n_dev_add records are real
     uint32_t        n_dev_add;
     int             kb;
+    const uint32_t* kb_dev;         // optional: the key bits are still on the device (BatchDesc), `kb` is ignored
     uint64_t*       keys_out;
     uint32_t*       vals_out;
     uint64_t*       part;           // [n] scratch

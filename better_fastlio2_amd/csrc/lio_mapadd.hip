@@ -45,16 +45,22 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(VoxelKeyArgs a) {
     // (fold counters, number of boundary points, the bounding box of the NEXT batch) and marks every output slot "nothing"
     if (blockIdx.x == 0 && threadIdx.x < 2) a.zero_counters[threadIdx.x] = 0u;
     if (blockIdx.x == 0 && threadIdx.x == 2) a.zero_counters[6] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 14) a.bbox[threadIdx.x - 8] = threadIdx.x < 11 ? BBOX_MIN_INIT : BBOX_MAX_INIT;
+    // (a BatchDesc that sends the lists back to the host's own path -- flags -- leaves their box where that path reads it)
+    const bool keep_box = a.desc != nullptr && a.desc->flags != 0u;
+    if (blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 14 && !keep_box) a.bbox[threadIdx.x - 8] = threadIdx.x < 11 ? BBOX_MIN_INIT : BBOX_MAX_INIT;
     s_hist[threadIdx.x] = 0u;
     __syncthreads();
+    // (round 6) count and frame may still be on the device: a.n is then the launch bound, the survivor slots are laid out by it
+    const uint32_t n_slots = a.n;
+    uint32_t n = a.n;
+    if (a.desc != nullptr) { n = min(a.n, a.desc->n_add); a.frame = a.desc->vf; }
     const int kb = frame_bits(a.frame);
     const uint64_t junk = kb >= 64 ? ~0ull : (1ull << kb) - 1ull;      // a key no point of the frame has (lio_mapadd.h)
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         a.dirty[i] = 0;
         a.dirty_pt[i] = 0;
         a.out2n[i] = make_float4(0.f, 0.f, 0.f, 1.0f);
-        a.out2n[a.n + i] = make_float4(0.f, 0.f, 0.f, 1.0f);
+        a.out2n[n_slots + i] = make_float4(0.f, 0.f, 0.f, 1.0f);
         const float4 p = a.pts[i];
         const int ix = voxel_coord(p.x, a.ds), iy = voxel_coord(p.y, a.ds), iz = voxel_coord(p.z, a.ds);
         // a point with a non-finite coordinate never enters the map through Add_Points(.., true) (its box holds nothing and
@@ -322,6 +328,7 @@ __device__ __forceinline__ void for_each_live_point(const float4* map_pts, uint3
 // every dirty mark of the batch is known.  The replay only touches the voxels of dirty groups, and a map point inside two
 // boxes makes both groups dirty, so nothing a clean group's plan was computed from changes before it is carried out.
 __global__ __launch_bounds__(64) void fold_plan_kernel(FoldArgs a, BoundaryArgs ba) {
+    if (ba.frame_dev != nullptr) ba.frame = *ba.frame_dev;      // (round 6: the frame may still be on the device, BatchDesc)
     const uint32_t n = view_count(a.view);
     const float ds = a.ds;
     const int lane = threadIdx.x, t = lane & 7;
@@ -562,6 +569,7 @@ __device__ __forceinline__ bool plan_tile_prefix(uint32_t mine, uint32_t b, unsi
 __global__ __launch_bounds__(256) void cell_plan_kernel(ApplyArgs a) {
     __shared__ uint32_t s_w[4];
     __shared__ uint8_t s_head[256];
+    if (a.frame_dev != nullptr) a.frame = *a.frame_dev;         // (round 6: the frame may still be on the device, BatchDesc)
     const uint32_t n = view_count(a.view);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the statistics the apply kernel accumulates start from zero (nothing reads them before it)
@@ -625,6 +633,7 @@ __device__ __forceinline__ uint32_t table_claim(HashEntry* table, uint32_t mask,
 
 __global__ __launch_bounds__(256) void cell_apply_kernel(ApplyArgs a) {
     __shared__ uint32_t s_stat[4][2];
+    if (a.frame_dev != nullptr) a.frame = *a.frame_dev;
     const uint32_t n = view_count(a.view);
     // room check on the device (every lane sees the same total): either the whole batch is applied or nothing is
     const uint32_t total = a.stats[3];

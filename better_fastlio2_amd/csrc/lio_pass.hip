@@ -327,7 +327,7 @@ int lio_measure_begin(lio_ctx* c, const double state14[14], int do_search, int e
     if (!released) {
         c->pass_hint = c->hint_valid;
         const int rc = enqueue_pass(c, pose, do_search != 0, ext, walk_in_its_own_launch(c), nullptr, &c->pass_seq);
-        if (rc != LIO_OK) { c->pass_in_flight = false; return rc; }
+        if (rc != LIO_OK) { c->pass_in_flight = false; c->pull_check = false; return rc; }
     }
     if (do_search) { c->have_search = true; c->hint_valid = true; }
     c->stamp('L');
@@ -441,10 +441,12 @@ int lio_measure_end(lio_ctx* c, lio_out* out) {
     if (c->pull_check) {
         // this pass pulled its scan out of the caller's page-locked records: are the points the GPU saw the points that are there?
         c->pull_check = false;
+        // (only the scan this pass ran on: scan_reset drops the check with the scan, and a count that differs is never dereferenced)
+        const bool mine = c->pull_check_n == c->nq && c->pull_check_n > 0 && c->pull_check_host == c->pull_host;
         const float* first = reinterpret_cast<const float*>(c->pull_check_host);
-        const float* last = reinterpret_cast<const float*>(c->pull_check_host + (size_t)(c->pull_check_n - 1) * (size_t)c->pull_check_stride);
-        const bool same = std::memcmp(first, d.probe, 12) == 0 && std::memcmp(last, d.probe + 4, 12) == 0;
-        if (!same && c->pull_check_n == c->nq) {
+        const float* last = mine ? reinterpret_cast<const float*>(c->pull_check_host + (size_t)(c->pull_check_n - 1) * (size_t)c->pull_check_stride) : nullptr;
+        const bool same = !mine || (std::memcmp(first, d.probe, 12) == 0 && std::memcmp(last, d.probe + 4, 12) == 0);
+        if (!same) {
             ++c->n_stale_pulls;
             gate_call_off(c);                           // (passes armed behind this one read the same scan buffer)
             const int rcu = upload_points(c, first, (size_t)c->pull_check_n, c->pull_check_stride, c->d_body);   // the CPU reads the real cloud

@@ -50,6 +50,7 @@ int lio_scan_set_async(lio_ctx* c, const float* body_pts, int n, int stride_byte
     if (!c || n < 0 || (n > 0 && !body_pts) || stride_bytes < 12 || (stride_bytes & 3) != 0) return LIO_ERR_INVALID_ARG;
     if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_set_async", "n exceeds max_scan_points");
     c->pull_pending = false;                    // (a scan nobody looked at is simply replaced)
+    c->raw_prefetched = false;
     enter(c);
     HIPCHK(c, hipSetDevice(c->device));
     if (n > 0 && is_pinned_host(body_pts) && is_pinned_host(reinterpret_cast<const char*>(body_pts) + (size_t)(n - 1) * (size_t)stride_bytes + 11)) {

@@ -11,6 +11,7 @@ int scan_reset(lio_ctx* c, int n) {
     if (!c->pattern_cur.empty()) { c->pattern_prev.swap(c->pattern_cur); c->pattern_cur.clear(); }
     c->nq = n;
     c->scan_pull_failed = false;
+    c->pull_check = false;                      // (the check of a pass that pulled the PREVIOUS scan: its records may be gone by now)
     c->have_scan = true; c->have_search = false; c->have_pass = false; c->last_m = 0; c->hint_valid = false;
     c->across_off_this_scan = false;
     // point_selected_surf starts all-true (laserMapping.cpp:2131), but nothing reads it before the first pass of
@@ -21,6 +22,7 @@ int scan_reset(lio_ctx* c, int n) {
 int lio_scan_set(lio_ctx* c, const float* body_pts, int n, int stride_bytes) {
     if (!c || n < 0 || (n > 0 && !body_pts) || stride_bytes < 12) return LIO_ERR_INVALID_ARG;
     c->pull_pending = false;
+    c->raw_prefetched = false;
     enter(c);
     if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_set", "n exceeds max_scan_points");
     HIPCHK(c, hipSetDevice(c->device));
@@ -31,6 +33,7 @@ int lio_scan_set(lio_ctx* c, const float* body_pts, int n, int stride_bytes) {
 int lio_scan_set_device(lio_ctx* c, const void* d_body_f4, int n) {
     if (!c || n < 0 || (n > 0 && !d_body_f4)) return LIO_ERR_INVALID_ARG;
     c->pull_pending = false;
+    c->raw_prefetched = false;
     enter(c);
     if (n > c->cap_q) return c->fail(LIO_ERR_CAPACITY, "lio_scan_set_device", "n exceeds max_scan_points");
     HIPCHK(c, hipSetDevice(c->device));
@@ -164,7 +167,7 @@ int lio_scan_upload_raw(lio_ctx* c, const float* raw_pts, int n, int stride_byte
     }
     HIPCHK(c, hipMemcpyAsync(c->d_raw, c->h_stage, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipEventRecord(c->ev_stage, s));
-    c->stage_busy = true; c->stage_busy_slots = (size_t)n;                     // waited for by the next writer of h_stage
+    c->stage_busy = true; c->stage_busy_slots = (size_t)n; c->stage_stream = s;   // waited for by the next writer of h_stage
     return LIO_OK;
 }
 
@@ -188,7 +191,9 @@ int lio_scan_compensate(lio_ctx* c, const lio_pose6d* imu_poses, int n_poses, co
     }
     // the poses go through the tail of the pinned staging buffer (bytes the point copy does not read)
     static_assert(sizeof(lio_pose6d) == 22 * sizeof(double), "Pose6D layout");
-    if (c->stage_busy && c->stage_busy_slots > c->h_stage_cap - POSE_STAGE_SLOTS) {   // (a copy in flight reads the tail too: not the raw upload's)
+    // (a copy in flight reads the tail too: not the raw upload's.  ONE event covers the buffer: a copy recorded on the other stream
+    // -- the main stream's upload of host points beside a preparation -- would no longer be covered once the event is re-recorded here)
+    if (c->stage_busy && (c->stage_busy_slots > c->h_stage_cap - POSE_STAGE_SLOTS || c->stage_stream != s)) {
         HIPCHK(c, hipEventSynchronize(c->ev_stage));
         c->stage_busy = false;
     }
@@ -196,7 +201,7 @@ int lio_scan_compensate(lio_ctx* c, const lio_pose6d* imu_poses, int n_poses, co
     std::memcpy(h_poses, imu_poses, (size_t)n_poses * sizeof(lio_pose6d));
     HIPCHK(c, hipMemcpyAsync(c->d_imu_poses, h_poses, (size_t)n_poses * sizeof(lio_pose6d), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipEventRecord(c->ev_stage, s));
-    c->stage_busy = true; c->stage_busy_slots = c->h_stage_cap;
+    c->stage_busy = true; c->stage_busy_slots = c->h_stage_cap; c->stage_stream = s;
     // The compensation of a point depends on nothing but the point: it runs in input order.  The order
     // sort(pcl_out.points.begin(), pcl_out.points.end(), time_list) (:251) establishes is produced where it is
     // consumed -- as the minor key of the voxel filter's sort, or on demand by lio_scan_get_cloud (stable: ties keep
@@ -414,6 +419,12 @@ static int ensure_prep(lio_ctx* c) {
 }
 int lio_scan_prefetch_raw(lio_ctx* c, const float* raw_pts, int n, int stride_bytes, int time_offset_bytes) {
     if (!c || n < 0 || (n > 0 && !raw_pts)) return LIO_ERR_INVALID_ARG;
+    // A prefetched sweep is recognised by (records, count) alone, and a driver re-uses one buffer for sweeps of one size: a prefetch
+    // nobody consumed (lio_imu_process returns before UndistortPcl while the IMU initialises) must not answer for a LATER sweep.  Every
+    // call here -- also one that does nothing -- drops what was prefetched before, and so do lio_imu_process when it returns without
+    // having uploaded its sweep and lio_scan_set / _set_device / _set_async (a scan that did not come from a raw sweep).  A caller
+    // prefetches every sweep or none; a prefetch nobody consumed is simply issued again.
+    if (!c->prep_active) c->raw_prefetched = false;
     // a hint: only x, y, z, t records in page-locked memory can be read in place by the copy engine; anything else is uploaded
     // by lio_scan_upload_raw as before
     if (n == 0 || stride_bytes != 16 || time_offset_bytes != 12 || (size_t)n > c->temp_bytes / 16 || c->prep_active || !is_pinned_host(raw_pts)) return LIO_OK;
@@ -442,13 +453,7 @@ int lio_scan_prep_begin(lio_ctx* c) {
     c->prep_active = true; c->prep_filtered = false; c->prep_enqueued = false;
     return LIO_OK;
 }
-int lio_scan_prep_end(lio_ctx* c, int* n_out) {
-    if (!c) return LIO_ERR_INVALID_ARG;
-    if (n_out) *n_out = 0;
-    if (!c->prep_active) return c->fail(LIO_ERR_INVALID_ARG, "lio_scan_prep_end", "no preparation is running (lio_scan_prep_begin)");
-    enter(c);
-    HIPCHK(c, hipSetDevice(c->device));
-    c->prep_active = false;
+static int scan_prep_end_body(lio_ctx* c, int* n_out) {
     if (!c->prep_filtered) {                    // (only the upload / the compensation ran there)
         HIPCHK(c, hipStreamSynchronize(c->prep_stream));
         return LIO_OK;
@@ -483,6 +488,19 @@ int lio_scan_prep_end(lio_ctx* c, int* n_out) {
     if (redo) return voxel_filter_sync(c, r, c->d_body_back, 1, n_out);   // (a wrong prediction: once more, here)
     ++c->n_prep_overlapped;
     return voxel_adopt(c, summary, c->d_body_back, n_out);
+}
+int lio_scan_prep_end(lio_ctx* c, int* n_out) {
+    if (!c) return LIO_ERR_INVALID_ARG;
+    if (n_out) *n_out = 0;
+    if (!c->prep_active) return c->fail(LIO_ERR_INVALID_ARG, "lio_scan_prep_end", "no preparation is running (lio_scan_prep_begin)");
+    enter(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    c->prep_active = false;
+    const int rc = scan_prep_end_body(c, n_out);
+    // an aborted preparation may still be writing the raw / key / back-scan buffers on its stream: the caller's next (synchronous)
+    // upload or filter re-uses them on the main stream -- nothing of the preparation outlives a failed lio_scan_prep_end
+    if (rc != LIO_OK && c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
+    return rc;
 }
 
 // which = 0: feats_undistort (time-sorted, compensated); 1: the current scan (feats_down_body)

@@ -6,35 +6,9 @@
 #include "lio_ctx.h"
 
 namespace {
-// frame of the integer coordinates lo .. hi (inclusive) of a batch: one spare coordinate per axis above hi, so that the
-// all-ones key is never a point's (the group of the non-finite points, lio_mapadd.hip)
-static KeyFrame frame_of(const int lo[3], const int hi[3]) {
-    KeyFrame f{};
-    f.ox = lo[0]; f.oy = lo[1]; f.oz = lo[2];
-    int* b[3] = {&f.bx, &f.by, &f.bz};
-    for (int i = 0; i < 3; ++i) {
-        const long long extent = (long long)hi[i] - (long long)lo[i] + 2;
-        int bits = 1;
-        while ((1ll << bits) < extent) ++bits;
-        *b[i] = bits;
-    }
-    return f;
-}
-static KeyFrame voxel_frame(const HostBox& box, float ds) {
-    int lo[3], hi[3];
-    for (int i = 0; i < 3; ++i) { lo[i] = voxel_coord(box.lo[i], ds); hi[i] = voxel_coord(box.hi[i], ds); }   // floor(v / ds) is monotone in v
-    return frame_of(lo, hi);
-}
-// the grid cells the pending points of a batch can fall into: survivors are batch points or map points inside the
-// down-sample boxes of batch points, i.e. within one box edge of the batch's bounding box
-static KeyFrame cell_frame(const HostBox& box, float ds, float inv_cell) {
-    int lo[3], hi[3];
-    for (int i = 0; i < 3; ++i) {
-        lo[i] = cell_coord(box.lo[i] - 2.0f * ds, inv_cell) - 1;
-        hi[i] = cell_coord(box.hi[i] + 2.0f * ds, inv_cell) + 1;
-    }
-    return frame_of(lo, hi);
-}
+// the frames of a batch's compressed keys from its bounding box (lio_mapadd.h: the same functions the list kernel runs on the device)
+static KeyFrame voxel_frame(const HostBox& box, float ds) { return voxel_frame_of(box.lo, box.hi, ds); }
+static KeyFrame cell_frame(const HostBox& box, float ds, float inv_cell) { return cell_frame_of(box.lo, box.hi, ds, inv_cell); }
 // the bounding-box accumulators of the insert lists (d_counters[24..29]) back to "empty": by the host when no kernel that
 // consumes the lists (voxel_keys_kernel resets them itself) is going to run
 hipError_t reset_list_box(lio_ctx* c) {
@@ -676,6 +650,118 @@ static int map_incremental_lists(lio_ctx* c, const double state14[14], double fi
     return LIO_OK;
 }
 
+// ---- round 6: map_incremental + both Add_Points + the index update with NO host round trip in between ----------------------
+// The list kernel leaves the list lengths and both key frames on the device (BatchDesc, d_apply[32..]); every kernel behind it is
+// launched with the SCAN size as its bound and takes its real size and its frame from there; the one read-back at the end brings
+// the statistics of the index update together with the two list lengths.  Same kernels, same values, same order as the path with
+// the read-back in the middle (fold_batch_device / apply_pending): the frames are derived by the same functions from the same box.
+static bool fast_update_possible(const lio_ctx* c) {
+    const size_t nq = (size_t)c->nq;
+    return c->dbg_fast_update && c->have_scan && nq > 0 && compact_small(c, nq) && !c->map_broken && c->have_map && c->n_live != 0 && c->n_points != 0 &&
+           c->fold_n == 0 && c->plain_n == 0 && !c->def.pending && !c->settle_side && sort_kind(c, nq, 0) != SORT_LIBRARY &&
+           (size_t)c->n_live + nq <= c->cap_map;
+}
+static int map_incremental_fast(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
+                                int* n_add_out, int* n_nodown_out, int* add_counter, bool* done) {
+    *done = false;
+    const uint32_t nq = (uint32_t)c->nq;
+    hipStream_t s = c->stream;
+    int rc = ensure_add_buffers(c, (size_t)nq);
+    if (rc != LIO_OK) return rc;
+    if (2u * (size_t)nq > c->cap_pend) return LIO_OK;             // (cannot happen: cap_pend = 2 cap_add + 2)
+    BatchDesc* desc = reinterpret_cast<BatchDesc*>(c->d_apply + 32);
+    const float ds = c->cfg.filter_size_map_min;
+    if (!c->have_search) HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, (size_t)nq, s));   // no neighbour lists at all (first scans): every point is a PointToAdd (:1487)
+    IncrArgs ia{};
+    ia.body = c->d_body; ia.nq = (int)nq; ia.nq_stride = c->cap_q;
+    for (int i = 0; i < 14; ++i) ia.pose.v[i] = state14[i];
+    ia.nbr = c->d_nbr; ia.cnt = c->d_cnt; ia.filter_size_map_min = filter_size_map_min;
+    ia.flg_EKF_inited = flg_EKF_inited; ia.world = c->d_world; ia.cls = c->d_add_cls;
+    HIPCHK(c, launch_map_incremental_lists(ia, c->d_add_pts, c->d_add_pts2, c->d_counters + 5, c->d_counters + 24, c->d_cagg, next_compact_stamp(c),
+                                           c->d_counters + 12, s, desc, ds, c->grid.inv_cell, BATCH_KB_MAX));
+    c->hint_valid = false;
+    c->last_add_counter = 0;
+    // ---- Add_Points(PointToAdd, true): plan + commit (fold_batch_plan / fold_batch_commit with device-resident n and frame)
+    const SortKind kind_v = sort_kind(c, nq, 0);
+    VoxelKeyArgs vk{};
+    vk.pts = c->d_add_pts; vk.n = nq; vk.desc = desc; vk.ds = ds; vk.keys = c->d_add_keys; vk.order = c->d_add_order;
+    rc = sort_hist(c, kind_v, &vk.hist);
+    if (rc != LIO_OK) return rc;
+    vk.zero_counters = c->d_apply + 4; vk.dirty = c->d_add_dirty; vk.dirty_pt = c->d_add_dirty_pt; vk.out2n = c->d_add_out;
+    vk.bbox = c->d_counters + 24; vk.flags = c->d_apply + 14;
+    HIPCHK(c, launch_voxel_keys(vk, s));
+    rc = run_sort(c, kind_v, c->d_add_keys, c->d_add_order, c->d_add_keys2, c->d_add_order2, nq, &desc->n_add, 0, 0, &desc->kb_v);
+    if (rc != LIO_OK) return rc;
+    GroupView view{};
+    view.skey = c->d_add_keys2; view.sord = c->d_add_order2; view.n_dev = &desc->n_add; view.n_add = 0; view.n = nq; view.shift = 0;
+    BoundaryArgs ba{};
+    ba.map_pts = c->d_pts; ba.l1table = c->d_ltable + c->levels.off[1]; ba.l1mask = c->levels.mask[1]; ba.child = c->d_child;
+    ba.grid = c->grid; ba.ds = ds; ba.new_pts = c->d_add_pts; ba.view = view; ba.frame_dev = &desc->vf;
+    ba.dirty = c->d_add_dirty; ba.dirty_pt = c->d_add_dirty_pt; ba.dlist = c->d_add_dlist; ba.n_dirty = c->d_apply + 10;
+    ba.seq_out = c->d_add_out + nq; ba.n_added = c->d_apply + 5; ba.n_replaced = c->d_apply + 4;
+    FoldArgs fa{};
+    fa.map_pts = c->d_pts; fa.l1table = ba.l1table; fa.l1mask = ba.l1mask; fa.child = c->d_child;
+    fa.grid = c->grid; fa.ds = ds; fa.new_pts = c->d_add_pts; fa.view = view;
+    fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
+    fa.plan = c->d_add_plan; fa.ranges = c->d_add_ranges; fa.count_parts = c->d_add_parts;
+    HIPCHK(c, launch_fold_plan(fa, ba, s));
+    HIPCHK(c, launch_compact_dirty(ba, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+    HIPCHK(c, launch_fold_commit(fa, ba, s));
+    // ---- the index update (build_pending / apply_pending_enqueue with device-resident sizes and frame)
+    const SortKind kind_c = kind_v;
+    PendBuildArgs pb{};
+    pb.surv = c->d_add_out; pb.n_surv_slots = 2u * nq; pb.plain = c->d_add_pts2; pb.n_plain = nq; pb.desc = desc;
+    pb.pend = c->d_pend; pb.grid = c->grid; pb.keys = c->d_pkeys; pb.order = c->d_porder;
+    rc = sort_hist(c, kind_c, &pb.hist);
+    if (rc != LIO_OK) return rc;
+    pb.count_parts = c->d_add_parts; pb.n_count_parts = fold_commit_workgroups(nq);
+    pb.fold_counts = c->d_apply + 4;
+    pb.n_surv = c->d_apply + 6; pb.n_pend = c->d_apply + 7; pb.desc_copy = c->d_apply + 11;
+    pb.flags = c->d_apply + 14; pb.agg = c->d_cagg; pb.stamp = next_compact_stamp(c); pb.err = c->d_apply + 15;
+    HIPCHK(c, launch_pend_build(pb, s));
+    rc = run_sort(c, kind_c, c->d_pkeys, c->d_porder, c->d_pkeys2, c->d_porder2, nq, c->d_apply + 7, 0, 0, &desc->kb_c);
+    if (rc != LIO_OK) return rc;
+    ApplyArgs a{};
+    a.map_pts = c->d_pts; a.grid = c->grid; a.ltable = c->d_ltable;
+    a.child = c->d_child; a.block_bump = c->d_apply + 9; a.blocks_cap = (uint32_t)c->child_blocks_cap;
+    a.levels = c->levels;
+    a.pend = c->d_pend;
+    a.view.skey = c->d_pkeys2; a.view.sord = c->d_porder2; a.view.n_dev = c->d_apply + 7; a.view.n_add = 0; a.view.n = nq; a.view.shift = 1;
+    a.frame_dev = &desc->cf; a.plan = c->d_plan; a.new_off = c->d_pnewoff; a.tail = c->n_points; a.stats = c->d_apply;
+    a.slots_cap = (uint32_t)c->slots_cap;
+    a.agg = c->d_cagg; a.stamp = next_compact_stamp(c); a.err = c->d_apply + 15;
+    HIPCHK(c, launch_cell_plan(a, s));
+    HIPCHK(c, launch_cell_apply(a, s));
+    // ---- the ONE read-back: statistics of the index update, counts of the fold, lengths of the two lists
+    uint32_t st[32] = {};
+    const hipError_t he = read_back(c, st, c->d_apply, 32 * sizeof(uint32_t));
+    if (he != hipSuccess) {
+        // cell_apply may have re-written buckets: the index is undefined (as apply_pending_finish says of its own failed read-back)
+        c->map_broken = true; c->have_map = false; c->hint_valid = false;
+        return c->fail(LIO_ERR_HIP, "lio_map_incremental", hipGetErrorString(he));
+    }
+    if (st[13] & 1u) return list_kernel_failed(c);               // (lists with holes, counts zero: every kernel behind it ran on nothing)
+    if (st[13] & 2u) return LIO_OK;                               // frames too wide for the group sort: nothing ran; *done stays false
+    *done = true;
+    ++c->n_fast_updates;
+    const uint32_t n_add = st[11], n_plain = st[12];
+    if (n_add_out) *n_add_out = (int)n_add;
+    if (n_nodown_out) *n_nodown_out = (int)n_plain;
+    if (n_add + n_plain == 0u) return LIO_OK;                     // (an update of nothing: the map is as it was)
+    rc = LIO_OK;
+    if (st[14] != 0u) {
+        (void)hipMemsetAsync(c->d_apply + 14, 0, sizeof(uint32_t), s);
+        rc = c->fail(LIO_ERR_HIP, "Add_Points", "a batch point lies outside the key frame derived from the batch's bounding box");
+    } else {
+        rc = check_compact_error(c, st[15]);
+    }
+    // the host's view of what has just happened: a down-sampled batch of n_add points and a plain one of n_plain, pending list built
+    c->fold_n = n_add; c->plain_n = n_plain; c->plain_ptr = c->d_add_pts2; c->pend_built = true;
+    rc = apply_pending_finish(c, st, rc);
+    if (rc == LIO_OK && add_counter) *add_counter = c->last_add_counter;
+    return rc;
+}
+
 // map_incremental (src/laserMapping.cpp:1440-1496) on the scan of the last measurement passes.
 int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
                         int apply, float* out_add_xyz, int* n_add, float* out_nodown_xyz, int* n_nodown,
@@ -687,8 +773,22 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
     if (add_counter) *add_counter = 0;
     HIPCHK(c, hipSetDevice(c->device));
     ListWords w;
-    int rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, &w);
-    if (rc != LIO_OK) return rc;
+    int rc;
+    bool lists_made = false;
+    if (apply && !out_add_xyz && !out_nodown_xyz && fast_update_possible(c)) {
+        // the node's own call (laserMapping.cpp:2401): nobody wants the lists on the host -- no round trip in the middle
+        bool done = false;
+        rc = map_incremental_fast(c, state14, filter_size_map_min, flg_EKF_inited, n_add, n_nodown, add_counter, &done);
+        if (rc != LIO_OK || done) return rc;
+        // (frames too wide for the group sort: nothing but the list kernel ran -- its lists, their counts and their box are in place)
+        rc = fetch_list_words(c, w);
+        if (rc != LIO_OK) return rc;
+        lists_made = true;
+    }
+    if (!lists_made) {
+        rc = map_incremental_lists(c, state14, filter_size_map_min, flg_EKF_inited, &w);
+        if (rc != LIO_OK) return rc;
+    }
     hipStream_t s = c->stream;
     if (n_add) *n_add = (int)w.n_add;
     if (n_nodown) *n_nodown = (int)w.n_plain;
@@ -1050,6 +1150,13 @@ static int deferred_settle_side_begin(lio_ctx* c) {
     ++c->n_settled;
     c->last_add_counter = 0;
     hipStream_t main_stream = c->stream;
+    // The commit writes the map (tomb-stones, directory records) and shares d_apply / the sort scratch with the main stream: it is
+    // ordered behind everything the main stream holds at this moment.  By the call graph that is nothing that reads the map (every
+    // reader was collected by the host before lio_replicate_step, armed passes were called off by enter()) -- the event is usually
+    // complete when it is recorded; it is there so that a future main-stream launch in front of this point cannot race silently.
+    if (!c->ev_main) HIPCHK(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_main, main_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_main, 0));
     c->stream = c->side_stream;                 // (every launch helper of the update takes the context's stream)
     bool launched = false;
     int rc = fold_batch_commit(c, d.fa, d.ba, n_add, box);

@@ -269,6 +269,10 @@ int  lio_scan_voxel_filter(lio_ctx* ctx, float leaf_size, int* n_out);
  *   lio_scan_prefetch_raw   a hint, the moment the driver has the sweep: x, y, z, t records (stride 16, time at byte 12) in page-locked
  *                           memory start their way to the GPU on the copy stream; the lio_scan_upload_raw / lio_imu_process call that
  *                           names the same records then takes them where they are.  Anything else: LIO_OK, nothing happens.
+ *                           A prefetched sweep is recognised by (records, count) and answers for the NEXT upload only: every call of
+ *                           lio_scan_prefetch_raw drops an earlier prefetch nobody consumed, and so do lio_imu_process when it returns
+ *                           without undistorting (IMU initialisation) and lio_scan_set / _set_device / _set_async.  Prefetch every
+ *                           sweep or none.
  *   lio_scan_prep_begin     from here to lio_scan_prep_end, lio_scan_upload_raw / lio_scan_compensate / lio_scan_undistort /
  *                           lio_imu_process / lio_scan_voxel_filter only ENQUEUE -- on the context's copy stream, into the back scan buffer;
  *                           lio_scan_voxel_filter answers *n_out = -1.  Map calls (lio_map_incremental, lio_fov_segment, ...) and
@@ -348,7 +352,9 @@ results); "library_sort" sends every sort / compaction of map maintenance and sc
  * pull off / steered / fixed in per cent, "assist_pull_chunk" = records per progress announcement (0 = by scan size),
  * "assist_pull_stall_us" = test hook: the host sleeps that long before it packs; "knn_stamps" = 1: searches of 8 lanes per query run
  * the stamped instantiation of the k-NN kernel (lio_debug_knn_stamps); "pull_alias_shift" = n: test hook, the fused pull of a host
- * cloud reads n records further on (what a stale registration looks like: the check behind the pull must catch it).
+ * cloud reads n records further on (what a stale registration looks like: the check behind the pull must catch it);
+ * "fast_update" = 0: lio_map_incremental(apply = 1, no lists wanted) reads its list lengths back before it launches their
+ * Add_Points, as until round 5 (identical results; environment: LIO_FAST_UPDATE=0).
  * Unknown key: LIO_ERR_INVALID_ARG.                                                                                        */
 int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
 /* counters for tests: "gate_released" / "gate_called_off" = pre-enqueued passes that ran / were called off; "voxel_fast_runs" /
@@ -362,7 +368,8 @@ int  lio_debug_set(lio_ctx* ctx, const char* key, long long value);
  * "assist_share_permille" = records packed, time it took, and the share in force; "stale_pulls" = scans whose first and last point,
  * as the GPU saw them through a registration, differed from the host's records -- uploaded again through the staging buffer, the pass
  * repeated (a caller drops its registrations then: the adaptor does); "raw_prefetch_hits" = sweeps lio_scan_upload_raw took from the
- * prefetch buffer, "prep_overlapped" = preparations whose filter ran on the preparation stream (lio_scan_prep_begin / _end)        */
+ * prefetch buffer, "prep_overlapped" = preparations whose filter ran on the preparation stream (lio_scan_prep_begin / _end);
+ * "fast_updates" = lio_map_incremental calls whose whole map update ran with no host round trip in the middle               */
 int  lio_debug_get(lio_ctx* ctx, const char* key, long long* value);
 /* wall_clock64 stamps (100 MHz) the last workgroup of the last measurement kernel took: [0] its start, [1] own partial
  * published, [2] group folded, [3] grid folded, [4] the listed queries' terms folded (search passes that list any),

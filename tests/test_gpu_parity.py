@@ -1404,3 +1404,41 @@ def test_first_search_of_the_next_scan_is_armed_across_the_scan_boundary(gpu_cap
         assert c1[0] >= 3 and c1[1] == 0                    # armed, called off by map_incremental every time
     else:
         assert c1[0] >= 3 and 2 <= c1[1] <= c1[0], c1        # (a mispredicted boundary: armed too early, called off, launched directly)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq", [6_000, 20_000])
+def test_map_update_without_the_host_round_trip_equals_the_one_with_it(gpu_capi, synth, small_case, nq):
+    """Round 6: lio_map_incremental(apply = 1, no lists wanted) launches the whole map update -- lists, both Add_Points, the index
+    update -- without reading the list lengths and the bounding box back in the middle (list lengths and key frames stay on the
+    device, BatchDesc).  Twin contexts, one with lio_debug_set("fast_update", 0): same counts, same map (flattened, in order, bitwise),
+    same statistics after every scan of a short drive (the twin's path is the one test_map_incremental_sequence and the fuzz seeds
+    hold against the reference tree: laserMapping.cpp:1440-1496, ikd_Tree.cpp:414-489).  6 000 points: the one-launch rank sort;
+    20 000: the group sort, whose key bits now come from the device too."""
+    w = small_case["world"]
+    ctxs = [gpu_capi.LioContext(0.2, max_scan_points=nq, max_map_points=500_000) for _ in range(2)]
+    ctxs[1].debug_set("fast_update", 0)
+    for c in ctxs:
+        c.map_build(w.points)
+    for k in range(5):
+        sc = synth.make_scan(w, nq, seed=synth.SEED + 300 + k, pos=(1.0 + 0.7 * k, -0.5 + 0.3 * k, 0.0), rpy=(0.002, -0.003, 0.3 + 0.04 * k))
+        st = synth.state_vector(sc.pos, sc.rot, sc.off_R, sc.off_T)
+        res = []
+        for c in ctxs:
+            c.scan_set(sc.body)
+            c.measure(st, True, False)
+            res.append(c.map_incremental(st, 0.2, True, apply=True, want_lists=False))
+        assert res[0] == res[1], (k, res)
+        assert res[0]["n_add"] + res[0]["n_nodown"] > 0
+        f0, f1 = ctxs[0].map_flatten(), ctxs[1].map_flatten()
+        assert bits_equal(f0, f1), k
+        i0, i1 = ctxs[0].map_info(), ctxs[1].map_info()
+        for key in ("n_points", "n_live", "n_cells", "n_retired", "n_incremental_updates", "n_full_rebuilds", "n_boundary_points"):
+            assert i0[key] == i1[key], (k, key, i0[key], i1[key])
+    assert ctxs[0].debug_get("fast_updates") == 5 and ctxs[1].debug_get("fast_updates") == 0
+    # the same scan again, no search in between (its neighbours are the old ones: most voxels are taken now)
+    res = [c.map_incremental(st, 0.2, True, apply=True, want_lists=False) for c in ctxs]
+    assert res[0] == res[1]
+    assert bits_equal(ctxs[0].map_flatten(), ctxs[1].map_flatten())
+    for c in ctxs:
+        c.close()
