@@ -98,7 +98,8 @@ hipError_t launch_bbox(const float4* pts, uint32_t n, uint32_t* bbox, hipStream_
 // kernel's 16 us at 100 k points.)
 __global__ __launch_bounds__(256) void map_incremental_lists_kernel(IncrArgs a, float4* add_out, float4* nodown_out, uint32_t* counts,
                                                                     uint32_t* bbox, u64* agg, uint32_t stamp, uint32_t* err,
-                                                                    BatchDesc* desc, float ds, float inv_cell, int kb_max) {
+                                                                    BatchDesc* desc, float ds, float inv_cell, int kb_max,
+                                                                    uint32_t bound_add, uint32_t bound_plain) {
     __shared__ uint32_t s_w1[4], s_w2[4];
     __shared__ uint32_t s_bb[4][6];
     __shared__ uint32_t s_sum[2][4];
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(256) void map_incremental_lists_kernel(IncrArgs a, 
             d.cf = cell_frame_of(blo, bhi, ds, inv_cell);
             d.kb_v = (uint32_t)frame_bits(d.vf); d.kb_c = (uint32_t)frame_bits(d.cf) + 1u;
             if ((int)d.kb_v > kb_max || (int)d.kb_c > kb_max) d.flags |= 2u;
+            if (n1 > bound_add || n2 > bound_plain) d.flags |= 4u;    // longer than the launches behind this one were sized for
         }
         d.n_add = d.flags == 0u ? n1 : 0u;
         d.n_plain = d.flags == 0u ? n2 : 0u;
@@ -243,11 +245,12 @@ __global__ __launch_bounds__(256) void map_incremental_lists_kernel(IncrArgs a, 
     }
 }
 hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, float4* nodown_out, uint32_t* counts, uint32_t* bbox, u64* agg,
-                                        uint32_t stamp, uint32_t* err, hipStream_t s, BatchDesc* desc, float ds, float inv_cell, int kb_max) {
+                                        uint32_t stamp, uint32_t* err, hipStream_t s, BatchDesc* desc, float ds, float inv_cell, int kb_max,
+                                        uint32_t bound_add, uint32_t bound_plain) {
     if (a.nq <= 0) return hipSuccess;
     if ((size_t)((a.nq + 255) / 256) * 8u > COMPACT_AGG_WORDS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(map_incremental_lists_kernel, dim3((a.nq + 255) / 256), dim3(256), 0, s, a, add_out, nodown_out, counts, bbox, agg, stamp, err,
-                       desc, ds, inv_cell, kb_max);
+                       desc, ds, inv_cell, kb_max, bound_add, bound_plain);
     return hipGetLastError();
 }
 

@@ -202,6 +202,9 @@ struct lio_ctx {
     bool dbg_fast_update = true;               // LIO_FAST_UPDATE=0: lio_map_incremental takes the host round trip between its lists and their
                                                // Add_Points again (A/B runs of scripts)
     long long n_fast_updates = 0;              // map updates that ran without it
+    long long n_fast_update_overflows = 0;     // ... that found a list longer than their launches were sized for (redone with the round trip)
+    uint32_t pred_n_add = 0, pred_n_plain = 0; // lengths of the previous lio_map_incremental's lists: what the next one's launches are sized by
+    bool pred_lists_valid = false;
     uint32_t* d_ghist = nullptr;               // two partition histograms of the group sort (lio_gsort.hip), used alternately
     int ghist_cur = 0;
     bool ghist_dirty = false;                  // a key kernel filled a histogram whose sort never ran
@@ -534,6 +537,7 @@ extern "C" {
 // lio_ctx.hip
 LIO_INTERNAL hipError_t publish_and_wait(lio_ctx* c, const uint32_t* d_src, int n_words);
 LIO_INTERNAL hipError_t stream_wait(lio_ctx* c);
+LIO_INTERNAL hipError_t wait_published(lio_ctx* c, uint32_t seq);
 LIO_INTERNAL hipError_t read_back(lio_ctx* c, void* host_dst, const void* d_src, size_t bytes);
 LIO_INTERNAL int ensure_stage(lio_ctx* c, size_t n);
 LIO_INTERNAL int ensure_scratch(lio_ctx* c, size_t bytes);

@@ -37,6 +37,21 @@ hipError_t publish_and_wait(lio_ctx* c, const uint32_t* d_src, int n_words) {
     return hipStreamSynchronize(c->stream);
 }
 hipError_t stream_wait(lio_ctx* c) { return publish_and_wait(c, nullptr, 0); }
+// the polling half alone: a kernel already on the stream publishes `seq` itself (cell_apply_kernel's last workgroup)
+hipError_t wait_published(lio_ctx* c, uint32_t seq) {
+    volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(c->h_small) + 32;
+    for (uint64_t spins = 0; spins < (1ull << 28); ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return hipSuccess;
+        if ((spins & 0xfffffu) == 0xfffffu) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipErrorNotReady) {                              // idle (or broken): the word is there by now, or it never will be
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return hipSuccess;
+                return q == hipSuccess ? hipErrorUnknown : q;
+            }
+        }
+    }
+    return hipErrorUnknown;
+}
 // A few counters from the device (bytes: a multiple of 4, at most 128)
 hipError_t read_back(lio_ctx* c, void* host_dst, const void* d_src, size_t bytes) {
     const hipError_t e = publish_and_wait(c, reinterpret_cast<const uint32_t*>(d_src), (int)(bytes / 4));
@@ -560,6 +575,7 @@ int lio_debug_get(lio_ctx* c, const char* key, long long* value) {
     if (std::strcmp(key, "prep_overlapped") == 0) { *value = c->n_prep_overlapped; return LIO_OK; }
     if (std::strcmp(key, "rows_direct_dma") == 0) { *value = c->n_rows_direct_dma; return LIO_OK; }
     if (std::strcmp(key, "fast_updates") == 0) { *value = c->n_fast_updates; return LIO_OK; }
+    if (std::strcmp(key, "fast_update_overflows") == 0) { *value = c->n_fast_update_overflows; return LIO_OK; }
     return c->fail(LIO_ERR_INVALID_ARG, "lio_debug_get", "unknown key");
 }
 int lio_debug_stamps(lio_ctx* c, unsigned long long out8[8]) {

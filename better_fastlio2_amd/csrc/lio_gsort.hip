@@ -34,6 +34,7 @@ constexpr int GS_IB = GSORT_INDEX_BITS;
 constexpr u64 GS_IMASK = (1ull << GS_IB) - 1ull;
 constexpr uint32_t GS_TILE = 2048;               // records per partition tile: 8 wavefronts x 4 rounds x 64 lanes
 constexpr uint32_t GS_LDS_CAP = 8192;            // records of a bucket that is sorted inside LDS
+constexpr uint32_t GS_RANK_CAP = 256;            // ... that is ranked by counting there (no passes)
 
 // lanes of this wavefront (among the valid ones) that hold the same digit
 __device__ __forceinline__ u64 gs_match(uint32_t d, bool valid, int bits) {
@@ -211,6 +212,20 @@ __global__ __launch_bounds__(1024) void gsort_bucket_kernel(GsortArgs a) {
     const int passes = (rem + 7) / 8;
     const int w = passes > 0 ? (rem + passes - 1) / passes : 0;
     const u64* fin;
+    if (cnt <= GS_RANK_CAP) {
+        // a small bucket (the usual one of a single scan's batch: a few dozen records): rank by counting inside LDS -- the record
+        // key << 18 | input position is unique, its order IS the stable key order -- instead of up to three LSD passes of a
+        // 1024-lane workgroup with four barriers per chunk
+        if (tid < (int)cnt) s_buf[0][tid] = (u64)a.part[base + tid];
+        __syncthreads();
+        if (tid >= (int)cnt) return;
+        const u64 r = s_buf[0][tid];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < cnt; ++j) rank += s_buf[0][j] < r ? 1u : 0u;      // (every lane reads the same word: a broadcast)
+        a.keys_out[base + rank] = r >> GS_IB;
+        a.vals_out[base + rank] = a.vals[(uint32_t)(r & GS_IMASK)];
+        return;
+    }
     if (cnt <= GS_LDS_CAP) {
         for (uint32_t i = tid; i < cnt; i += 1024u) s_buf[0][i] = (u64)a.part[base + i];
         __syncthreads();

@@ -23,16 +23,20 @@ __device__ __forceinline__ uint8_t map_incremental_classify_point(const IncrArgs
         const float my = (float)(floor((double)wy / fs) * fs + 0.5 * fs);
         const float mz = (float)(floor((double)wz / fs) * fs + 0.5 * fs);
         const float dist = sqdist3(wx, wy, wz, mx, my, mz);     // :1462
-        const float4 n0 = a.nbr[i];
+        // (all five neighbours are asked for together: one memory round trip instead of the chain of dependent loads the
+        // early exit of :1476-1480 would make -- the decision is the same, "any of the five nearer than the point")
+        float4 nb[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) nb[k] = a.nbr[(size_t)k * a.nq_stride + i];
+        const float4 n0 = nb[0];
         if ((double)fabsf(n0.x - mx) > 0.5 * fs && (double)fabsf(n0.y - my) > 0.5 * fs && (double)fabsf(n0.z - mz) > 0.5 * fs) {
             cls = 2;                                            // :1465-1469
         } else {
             bool need_add = true;
             if (cnt >= K) {                                     // :1474-1475
-                for (int k = 0; k < K; ++k) {
-                    const float4 p = a.nbr[(size_t)k * a.nq_stride + i];
-                    if (sqdist3(p.x, p.y, p.z, mx, my, mz) < dist) { need_add = false; break; }   // :1476-1480
-                }
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (sqdist3(nb[k].x, nb[k].y, nb[k].z, mx, my, mz) < dist) need_add = false;   // :1476-1480
             }
             cls = need_add ? 1 : 0;
         }

@@ -75,8 +75,9 @@ LIO_HD KeyFrame cell_frame_of(const float blo[3], const float bhi[3], float ds, 
 // of that kernel with the very functions the host uses (frame_of above: same integers either way).
 struct BatchDesc {
     uint32_t n_add, n_plain;        // PointToAdd / PointNoNeedDownsample as the update is to see them (0 / 0 when flags != 0)
-    uint32_t flags;                 // 1: a bounded wait of the list kernel ran out; 2: a frame too wide for the group sort (the host's
-                                    // own path takes the lists -- they are intact, their counts and box where they always were)
+    uint32_t flags;                 // 1: a bounded wait of the list kernel ran out; 2: a frame too wide for the group sort; 4: a list longer
+                                    // than the launches behind were sized for (2, 4: the host's own path takes the lists -- they are
+                                    // intact, their counts and box where they always were)
     uint32_t kb_v, kb_c;            // key bits of the two sorts: frame_bits(vf), frame_bits(cf) + 1
     uint32_t pad[3];
     KeyFrame vf;                    // of the down-sample voxel keys
@@ -169,6 +170,11 @@ struct ApplyArgs {
     unsigned long long* agg;        // stamped tile sums of the plan kernel's scan (lio_compact.hip)
     uint32_t         stamp;
     uint32_t*        err;
+    // (round 6) the statistics leave with the apply kernel: its last workgroup to finish copies stats[0..32) into host-mapped memory
+    // and publishes `publish_seq` there (what a publish_words launch behind it did until round 5); nullptr: nobody is waiting
+    uint32_t*        publish_dst;
+    uint32_t         publish_seq;
+    uint32_t*        ticket;        // arrival counter of the workgroups (zero on entry, zero again on exit)
 };
 constexpr int APPLY_LEVEL_NEW = 16;                // stats[16 + L]: entries hashed level L gained since the last full rebuild
 constexpr uint32_t APPLY_FLAG_OUTSIDE_TOP = 1u;   // a new cell lies outside the root node of the tree
@@ -197,6 +203,8 @@ struct BoundaryArgs {
     uint8_t*         dirty_pt;      // [n] per batch index: the point belongs to a dirty group
     uint32_t*        dlist;         // [n] batch indices of the points of dirty groups, ascending (compact_dirty)
     uint32_t*        n_dirty;
+    bool             list_here;     // the replaying wavefront of fold_commit_kernel makes dlist / n_dirty itself (small batches: one
+                                    // launch less; launch_compact_dirty is then not called)
     float4*          seq_out;       // [n] points appended by the sequential pass (w == 0 live)
     uint32_t*        n_added;
     uint32_t*        n_replaced;
@@ -264,13 +272,15 @@ hipError_t launch_pend_build(const PendBuildArgs& a, hipStream_t s);
 // ---- single-launch compaction primitives (lio_compact.hip) for inputs up to COMPACT_MAX_ITEMS; agg = COMPACT_AGG_WORDS
 // 8-byte words of scratch shared by all of them, stamp = a number no earlier launch on this buffer used, *err |= 1 on a
 // timed-out wait
+constexpr uint32_t DIRTY_LIST_HERE_MAX = 16384;  // batches up to here: fold_commit_kernel lists the dirty points itself
 constexpr uint32_t COMPACT_MAX_ITEMS = 262144;    // 1024 tiles of 256: all resident at once
 constexpr size_t COMPACT_AGG_WORDS = 8 * 1024;   // (the list kernel publishes eight words per tile: two counts, the six faces of its bounding box)
 // map_incremental's classification + PointToAdd / PointNoNeedDownsample in scan order + their counts + their bounding box, one launch
 // desc (optional): the BatchDesc of the two lists for a map update that follows without a host round trip (ds / inv_cell: what its frames are derived with)
 hipError_t launch_map_incremental_lists(const IncrArgs& a, float4* add_out, float4* nodown_out, uint32_t* counts, uint32_t* bbox,
                                         unsigned long long* agg, uint32_t stamp, uint32_t* err, hipStream_t s,
-                                        BatchDesc* desc = nullptr, float ds = 0.0f, float inv_cell = 0.0f, int kb_max = BATCH_KB_MAX);
+                                        BatchDesc* desc = nullptr, float ds = 0.0f, float inv_cell = 0.0f, int kb_max = BATCH_KB_MAX,
+                                        uint32_t bound_add = 0xffffffffu, uint32_t bound_plain = 0xffffffffu);
 // live points (w == 0) to the front of dst, order kept
 hipError_t launch_compact_live(const float4* src, uint32_t n, float4* dst, uint32_t* n_out, unsigned long long* agg, uint32_t stamp,
                                uint32_t* err, hipStream_t s);

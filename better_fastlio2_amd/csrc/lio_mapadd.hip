@@ -188,8 +188,47 @@ __device__ __forceinline__ uint32_t find_voxel_group(const BoundaryArgs& a, uint
 // starts with an agent-scope acquire (the L1 forgets its lines) and ends with a release (its stores are in L2), so the
 // reads in between are plain 16-byte loads, four in flight -- round 2 read every coordinate with an agent-scope atomic
 // of its own, 17 us per replayed point (measured: seven points were most of the fold's 120 us).
+// the replay list of a small batch made by the replaying wavefront itself (what compact_dirty_kernel makes for large ones): the
+// batch indices whose dirty_pt mark is set, ascending.  4096 marks per round (four 16-byte loads per lane in flight); marked
+// points are a handful per batch, so the slow part -- one lane's sixteen marks at a time -- hardly ever runs.
+__device__ __forceinline__ uint32_t list_dirty_points(const BoundaryArgs& a, int lane) {
+    const uint32_t n = view_count(a.view);
+    const uint4* marks = reinterpret_cast<const uint4*>(a.dirty_pt);
+    uint32_t cnt = 0;
+    for (uint32_t base = 0; base < n; base += 4096u) {
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t i0 = base + u * 1024u + (uint32_t)lane * 16u;
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (i0 < n) v[u] = marks[i0 >> 4];                  // (the buffer is a whole number of 16-byte words: hipMalloc)
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t i0 = base + u * 1024u + (uint32_t)lane * 16u;
+            for (unsigned long long m = __ballot((v[u].x | v[u].y | v[u].z | v[u].w) != 0u); m != 0ull; m &= m - 1ull) {
+                const int l = __builtin_ctzll(m);
+                const uint32_t w[4] = {(uint32_t)__shfl((int)v[u].x, l, 64), (uint32_t)__shfl((int)v[u].y, l, 64),
+                                       (uint32_t)__shfl((int)v[u].z, l, 64), (uint32_t)__shfl((int)v[u].w, l, 64)};
+                const uint32_t j0 = (uint32_t)__shfl((int)i0, l, 64);
+#pragma unroll
+                for (uint32_t j = 0; j < 16u; ++j) {
+                    const bool set = ((w[j >> 2] >> (8u * (j & 3u))) & 0xffu) != 0u && j0 + j < n;   // (marks beyond n were never initialised)
+                    if (set) { if (lane == 0) a.dlist[cnt] = j0 + j; ++cnt; }
+                }
+            }
+        }
+    }
+    if (lane == 0) *a.n_dirty = cnt;
+    // (the list is read back by this very wavefront: stores drained, L1 lines dropped)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return cnt;
+}
+
 __device__ __forceinline__ void fold_sequential(const BoundaryArgs& a, int lane, uint2* count_parts) {
-    const uint32_t n_dirty = *a.n_dirty;
+    const uint32_t n_dirty = a.list_here ? list_dirty_points(a, lane) : *a.n_dirty;
     if (n_dirty == 0u) { if (lane == 0) count_parts[0] = make_uint2(0u, 0u); return; }
     uint32_t n_seq = 0, counter = 0, replaced = 0;
     // What one point of the replay writes (tomb-stones, the list of points added so far) is read by THIS wavefront at the
@@ -633,16 +672,15 @@ __device__ __forceinline__ uint32_t table_claim(HashEntry* table, uint32_t mask,
 
 __global__ __launch_bounds__(256) void cell_apply_kernel(ApplyArgs a) {
     __shared__ uint32_t s_stat[4][2];
+    __shared__ uint32_t s_last;
     if (a.frame_dev != nullptr) a.frame = *a.frame_dev;
     const uint32_t n = view_count(a.view);
     // room check on the device (every lane sees the same total): either the whole batch is applied or nothing is
     const uint32_t total = a.stats[3];
-    if ((uint64_t)a.tail + (uint64_t)total > (uint64_t)a.slots_cap) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.stats + 2, APPLY_FLAG_NO_ROOM);
-        return;
-    }
+    const bool room = (uint64_t)a.tail + (uint64_t)total <= (uint64_t)a.slots_cap;
+    if (!room && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.stats + 2, APPLY_FLAG_NO_ROOM);
     uint32_t retired_sum = 0, new_cells = 0;                   // summed over the wavefront at the end: one atomic each, not one per cell
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; room && s < n; s += gridDim.x * blockDim.x) {
         // every pending point goes to its own slot (cell_plan_kernel's prefix): behind the cell's live old points, survivors
         // first, then plain inserts, batch order -- the order of the sort
         const bool head = view_is_head(a.view, s);
@@ -718,6 +756,22 @@ __global__ __launch_bounds__(256) void cell_apply_kernel(ApplyArgs a) {
         const uint32_t v = s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x] + s_stat[2][threadIdx.x] + s_stat[3][threadIdx.x];
         if (v != 0) atomicAdd(a.stats + threadIdx.x, v);
     }
+    if (a.publish_dst == nullptr) return;
+    // ---- the statistics leave with this kernel: the workgroup that finishes LAST copies them into host-mapped memory and publishes
+    // the sequence number the host polls.  Every statistic is accumulated by device-scope atomics (performed at the memory side);
+    // a workgroup takes its ticket only when its own have been acknowledged (vmcnt), so the last one reads them complete.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_last == 0u) return;
+    if (threadIdx.x < 32) a.publish_dst[threadIdx.x] = __hip_atomic_load(a.stats + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.publish_dst + 32, a.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // map_incremental's per-point decision (src/laserMapping.cpp:1448-1489): lio_incr.h; this kernel is the classification
@@ -762,8 +816,9 @@ hipError_t launch_cell_plan(const ApplyArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_cell_apply(const ApplyArgs& a, hipStream_t s) {
-    if (a.view.n == 0) return hipSuccess;
+    if (a.view.n == 0 && a.publish_dst == nullptr) return hipSuccess;
     uint32_t b = (a.view.n + 255u) / 256u; if (b > 512u) b = 512u;
+    if (b == 0u) b = 1u;                         // (somebody waits for the statistics this kernel publishes)
     hipLaunchKernelGGL(cell_apply_kernel, dim3(b), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -314,7 +314,7 @@ namespace {
 // Launches: pend_build, the sort by (cell, list) (1 or 2), cell_plan (with the scan of the new bucket sizes), cell_apply,
 // and ONE read-back that brings the statistics of this update together with the counts the fold left on the device.
 // First half: the launches (on c->stream).  *launched = false: there was nothing to do, or the full rebuild did it.
-static int apply_pending_enqueue(lio_ctx* c, bool* launched) {
+static int apply_pending_enqueue(lio_ctx* c, bool* launched, uint32_t* publish_dst = nullptr, uint32_t publish_seq = 0u) {
     hipStream_t s = c->stream;
     *launched = false;
     if (c->map_broken) return c->fail(LIO_ERR_NO_MAP, "Add_Points", "the map index is undefined after a failed update: Build / reconstruct it");
@@ -340,10 +340,21 @@ static int apply_pending_enqueue(lio_ctx* c, bool* launched) {
     a.frame = cf; a.plan = c->d_plan; a.new_off = c->d_pnewoff; a.tail = c->n_points; a.stats = c->d_apply;
     a.slots_cap = (uint32_t)c->slots_cap;
     a.agg = c->d_cagg; a.stamp = next_compact_stamp(c); a.err = c->d_apply + 15;
+    a.publish_dst = publish_dst; a.publish_seq = publish_seq; a.ticket = c->d_apply + 8;   // (the statistics leave with the apply kernel)
     HIPCHK(c, launch_cell_plan(a, s));
     HIPCHK(c, launch_cell_apply(a, s));
     *launched = true;
     return LIO_OK;
+}
+// the 32 statistics words the apply kernel published under `seq` (+ the flags of the kernels in front of it)
+static int collect_batch_counts(lio_ctx* c, uint32_t seq, uint32_t st[32]) {
+    HIPCHK(c, wait_published(c, seq));
+    std::memcpy(st, c->h_small, 32 * sizeof(uint32_t));
+    if (st[14] != 0u) {
+        (void)hipMemsetAsync(c->d_apply + 14, 0, sizeof(uint32_t), c->stream);
+        return c->fail(LIO_ERR_HIP, "Add_Points", "a batch point lies outside the key frame derived from the batch's bounding box");
+    }
+    return check_compact_error(c, st[15]);
 }
 // Second half: the 32 statistics words of the update (st; rc = how reading them went) -> the host's view of the map, the budgets,
 // a full rebuild when one is due.
@@ -394,10 +405,11 @@ static int apply_pending_finish(lio_ctx* c, const uint32_t st[32], int rc) {
 }
 int apply_pending(lio_ctx* c) {
     bool launched = false;
-    int rc = apply_pending_enqueue(c, &launched);
+    const uint32_t seq = ++c->small_seq;
+    int rc = apply_pending_enqueue(c, &launched, c->d_small, seq);
     if (rc != LIO_OK || !launched) return rc;
     uint32_t st[32] = {};
-    rc = fetch_batch_counts(c, st);
+    rc = collect_batch_counts(c, seq, st);
     return apply_pending_finish(c, st, rc);
 }
 
@@ -477,8 +489,9 @@ static int fold_batch_plan(lio_ctx* c, const float4* batch, uint32_t n, const Ho
     fa.grid = c->grid; fa.ds = ds; fa.new_pts = batch; fa.view = view;
     fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
     fa.plan = c->d_add_plan; fa.ranges = c->d_add_ranges; fa.count_parts = c->d_add_parts;
+    ba.list_here = n <= DIRTY_LIST_HERE_MAX;  // (small batches: the replaying wavefront of fold_commit_kernel lists the dirty points itself)
     HIPCHK(c, launch_fold_plan(fa, ba, s));
-    HIPCHK(c, launch_compact_dirty(ba, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+    if (!ba.list_here) HIPCHK(c, launch_compact_dirty(ba, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
     return LIO_OK;
 }
 // Second half: the plans of the clean groups are carried out, the dirty groups replayed (tomb-stones in the map, survivors in
@@ -651,15 +664,25 @@ static int map_incremental_lists(lio_ctx* c, const double state14[14], double fi
 }
 
 // ---- round 6: map_incremental + both Add_Points + the index update with NO host round trip in between ----------------------
-// The list kernel leaves the list lengths and both key frames on the device (BatchDesc, d_apply[32..]); every kernel behind it is
-// launched with the SCAN size as its bound and takes its real size and its frame from there; the one read-back at the end brings
-// the statistics of the index update together with the two list lengths.  Same kernels, same values, same order as the path with
-// the read-back in the middle (fold_batch_device / apply_pending): the frames are derived by the same functions from the same box.
+// The list kernel leaves the list lengths and both key frames on the device (BatchDesc, d_apply[32..]); every kernel behind it takes
+// its real size and its frame from there; the one read-back at the end brings the statistics of the index update together with the
+// two list lengths.  Same kernels, same values, same order as the path with the read-back in the middle (fold_batch_device /
+// apply_pending): the frames are derived by the same functions from the same box.
+// What the host cannot know is how LARGE to launch.  The scan size is a bound, but a scan inserts a twelfth of its points and a
+// launch pays for the workgroups it does not need (measured, profiles/r06b_*: with every kernel sized for the 100 k points of the
+// scan the update was 18 us slower than with the round trip it saved).  So the launches are sized by the PREVIOUS update's lists
+// (+ 25 % + 256: consecutive scans of a drive insert alike); the list kernel itself checks the lists against these bounds and, if
+// one is longer, leaves a descriptor that makes every kernel behind it a no-op -- the host then finds the lists intact and takes
+// its own path with them (one wasted chain of empty launches; `fast_update_overflows`).
 static bool fast_update_possible(const lio_ctx* c) {
     const size_t nq = (size_t)c->nq;
     return c->dbg_fast_update && c->have_scan && nq > 0 && compact_small(c, nq) && !c->map_broken && c->have_map && c->n_live != 0 && c->n_points != 0 &&
-           c->fold_n == 0 && c->plain_n == 0 && !c->def.pending && !c->settle_side && sort_kind(c, nq, 0) != SORT_LIBRARY &&
+           c->fold_n == 0 && c->plain_n == 0 && !c->def.pending && !c->settle_side && c->pred_lists_valid &&
            (size_t)c->n_live + nq <= c->cap_map;
+}
+static uint32_t list_bound(uint32_t last, uint32_t nq) {
+    const uint64_t b = ((uint64_t)last + (uint64_t)last / 4u + 256u + 255u) / 256u * 256u;
+    return (uint32_t)(b < (uint64_t)nq ? b : (uint64_t)nq);
 }
 static int map_incremental_fast(lio_ctx* c, const double state14[14], double filter_size_map_min, int flg_EKF_inited,
                                 int* n_add_out, int* n_nodown_out, int* add_counter, bool* done) {
@@ -668,7 +691,11 @@ static int map_incremental_fast(lio_ctx* c, const double state14[14], double fil
     hipStream_t s = c->stream;
     int rc = ensure_add_buffers(c, (size_t)nq);
     if (rc != LIO_OK) return rc;
-    if (2u * (size_t)nq > c->cap_pend) return LIO_OK;             // (cannot happen: cap_pend = 2 cap_add + 2)
+    const uint32_t b_add = list_bound(c->pred_n_add, nq), b_plain = list_bound(c->pred_n_plain, nq);
+    const uint32_t b_pend = b_add + b_plain;                      // (every survivor is one of the b_add points)
+    if ((size_t)b_pend > c->cap_pend) return LIO_OK;
+    const SortKind kind_v = sort_kind(c, b_add, 0), kind_c = sort_kind(c, b_pend, 0);
+    if (kind_v == SORT_LIBRARY || kind_c == SORT_LIBRARY) return LIO_OK;
     BatchDesc* desc = reinterpret_cast<BatchDesc*>(c->d_apply + 32);
     const float ds = c->cfg.filter_size_map_min;
     if (!c->have_search) HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, (size_t)nq, s));   // no neighbour lists at all (first scans): every point is a PointToAdd (:1487)
@@ -678,76 +705,83 @@ static int map_incremental_fast(lio_ctx* c, const double state14[14], double fil
     ia.nbr = c->d_nbr; ia.cnt = c->d_cnt; ia.filter_size_map_min = filter_size_map_min;
     ia.flg_EKF_inited = flg_EKF_inited; ia.world = c->d_world; ia.cls = c->d_add_cls;
     HIPCHK(c, launch_map_incremental_lists(ia, c->d_add_pts, c->d_add_pts2, c->d_counters + 5, c->d_counters + 24, c->d_cagg, next_compact_stamp(c),
-                                           c->d_counters + 12, s, desc, ds, c->grid.inv_cell, BATCH_KB_MAX));
-    c->hint_valid = false;
+                                           c->d_counters + 12, s, desc, ds, c->grid.inv_cell, BATCH_KB_MAX, b_add, b_plain));
     c->last_add_counter = 0;
     // ---- Add_Points(PointToAdd, true): plan + commit (fold_batch_plan / fold_batch_commit with device-resident n and frame)
-    const SortKind kind_v = sort_kind(c, nq, 0);
     VoxelKeyArgs vk{};
-    vk.pts = c->d_add_pts; vk.n = nq; vk.desc = desc; vk.ds = ds; vk.keys = c->d_add_keys; vk.order = c->d_add_order;
+    vk.pts = c->d_add_pts; vk.n = b_add; vk.desc = desc; vk.ds = ds; vk.keys = c->d_add_keys; vk.order = c->d_add_order;
     rc = sort_hist(c, kind_v, &vk.hist);
     if (rc != LIO_OK) return rc;
     vk.zero_counters = c->d_apply + 4; vk.dirty = c->d_add_dirty; vk.dirty_pt = c->d_add_dirty_pt; vk.out2n = c->d_add_out;
     vk.bbox = c->d_counters + 24; vk.flags = c->d_apply + 14;
     HIPCHK(c, launch_voxel_keys(vk, s));
-    rc = run_sort(c, kind_v, c->d_add_keys, c->d_add_order, c->d_add_keys2, c->d_add_order2, nq, &desc->n_add, 0, 0, &desc->kb_v);
+    rc = run_sort(c, kind_v, c->d_add_keys, c->d_add_order, c->d_add_keys2, c->d_add_order2, b_add, &desc->n_add, 0, 0, &desc->kb_v);
     if (rc != LIO_OK) return rc;
     GroupView view{};
-    view.skey = c->d_add_keys2; view.sord = c->d_add_order2; view.n_dev = &desc->n_add; view.n_add = 0; view.n = nq; view.shift = 0;
+    view.skey = c->d_add_keys2; view.sord = c->d_add_order2; view.n_dev = &desc->n_add; view.n_add = 0; view.n = b_add; view.shift = 0;
     BoundaryArgs ba{};
     ba.map_pts = c->d_pts; ba.l1table = c->d_ltable + c->levels.off[1]; ba.l1mask = c->levels.mask[1]; ba.child = c->d_child;
     ba.grid = c->grid; ba.ds = ds; ba.new_pts = c->d_add_pts; ba.view = view; ba.frame_dev = &desc->vf;
     ba.dirty = c->d_add_dirty; ba.dirty_pt = c->d_add_dirty_pt; ba.dlist = c->d_add_dlist; ba.n_dirty = c->d_apply + 10;
-    ba.seq_out = c->d_add_out + nq; ba.n_added = c->d_apply + 5; ba.n_replaced = c->d_apply + 4;
+    ba.seq_out = c->d_add_out + b_add; ba.n_added = c->d_apply + 5; ba.n_replaced = c->d_apply + 4;
     FoldArgs fa{};
     fa.map_pts = c->d_pts; fa.l1table = ba.l1table; fa.l1mask = ba.l1mask; fa.child = c->d_child;
     fa.grid = c->grid; fa.ds = ds; fa.new_pts = c->d_add_pts; fa.view = view;
     fa.out_pts = c->d_add_out; fa.n_added = c->d_apply + 5; fa.n_replaced = c->d_apply + 4; fa.dirty = c->d_add_dirty;
     fa.plan = c->d_add_plan; fa.ranges = c->d_add_ranges; fa.count_parts = c->d_add_parts;
+    ba.list_here = b_add <= DIRTY_LIST_HERE_MAX;
     HIPCHK(c, launch_fold_plan(fa, ba, s));
-    HIPCHK(c, launch_compact_dirty(ba, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+    if (!ba.list_here) HIPCHK(c, launch_compact_dirty(ba, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
     HIPCHK(c, launch_fold_commit(fa, ba, s));
     // ---- the index update (build_pending / apply_pending_enqueue with device-resident sizes and frame)
-    const SortKind kind_c = kind_v;
     PendBuildArgs pb{};
-    pb.surv = c->d_add_out; pb.n_surv_slots = 2u * nq; pb.plain = c->d_add_pts2; pb.n_plain = nq; pb.desc = desc;
+    pb.surv = c->d_add_out; pb.n_surv_slots = 2u * b_add; pb.plain = c->d_add_pts2; pb.n_plain = b_plain; pb.desc = desc;
     pb.pend = c->d_pend; pb.grid = c->grid; pb.keys = c->d_pkeys; pb.order = c->d_porder;
     rc = sort_hist(c, kind_c, &pb.hist);
     if (rc != LIO_OK) return rc;
-    pb.count_parts = c->d_add_parts; pb.n_count_parts = fold_commit_workgroups(nq);
+    pb.count_parts = c->d_add_parts; pb.n_count_parts = fold_commit_workgroups(b_add);
     pb.fold_counts = c->d_apply + 4;
     pb.n_surv = c->d_apply + 6; pb.n_pend = c->d_apply + 7; pb.desc_copy = c->d_apply + 11;
     pb.flags = c->d_apply + 14; pb.agg = c->d_cagg; pb.stamp = next_compact_stamp(c); pb.err = c->d_apply + 15;
     HIPCHK(c, launch_pend_build(pb, s));
-    rc = run_sort(c, kind_c, c->d_pkeys, c->d_porder, c->d_pkeys2, c->d_porder2, nq, c->d_apply + 7, 0, 0, &desc->kb_c);
+    rc = run_sort(c, kind_c, c->d_pkeys, c->d_porder, c->d_pkeys2, c->d_porder2, b_pend, c->d_apply + 7, 0, 0, &desc->kb_c);
     if (rc != LIO_OK) return rc;
     ApplyArgs a{};
     a.map_pts = c->d_pts; a.grid = c->grid; a.ltable = c->d_ltable;
     a.child = c->d_child; a.block_bump = c->d_apply + 9; a.blocks_cap = (uint32_t)c->child_blocks_cap;
     a.levels = c->levels;
     a.pend = c->d_pend;
-    a.view.skey = c->d_pkeys2; a.view.sord = c->d_porder2; a.view.n_dev = c->d_apply + 7; a.view.n_add = 0; a.view.n = nq; a.view.shift = 1;
+    a.view.skey = c->d_pkeys2; a.view.sord = c->d_porder2; a.view.n_dev = c->d_apply + 7; a.view.n_add = 0; a.view.n = b_pend; a.view.shift = 1;
     a.frame_dev = &desc->cf; a.plan = c->d_plan; a.new_off = c->d_pnewoff; a.tail = c->n_points; a.stats = c->d_apply;
     a.slots_cap = (uint32_t)c->slots_cap;
     a.agg = c->d_cagg; a.stamp = next_compact_stamp(c); a.err = c->d_apply + 15;
+    const uint32_t seq = ++c->small_seq;
+    a.publish_dst = c->d_small; a.publish_seq = seq; a.ticket = c->d_apply + 8;
     HIPCHK(c, launch_cell_plan(a, s));
     HIPCHK(c, launch_cell_apply(a, s));
-    // ---- the ONE read-back: statistics of the index update, counts of the fold, lengths of the two lists
+    // ---- the ONE wait: statistics of the index update, counts of the fold, lengths of the two lists -- published by the apply
+    // kernel's last workgroup, no launch behind it
     uint32_t st[32] = {};
-    const hipError_t he = read_back(c, st, c->d_apply, 32 * sizeof(uint32_t));
+    const hipError_t he = wait_published(c, seq);
+    std::memcpy(st, c->h_small, sizeof(st));
     if (he != hipSuccess) {
         // cell_apply may have re-written buckets: the index is undefined (as apply_pending_finish says of its own failed read-back)
         c->map_broken = true; c->have_map = false; c->hint_valid = false;
         return c->fail(LIO_ERR_HIP, "lio_map_incremental", hipGetErrorString(he));
     }
     if (st[13] & 1u) return list_kernel_failed(c);               // (lists with holes, counts zero: every kernel behind it ran on nothing)
-    if (st[13] & 2u) return LIO_OK;                               // frames too wide for the group sort: nothing ran; *done stays false
+    if (st[13] & 6u) {                                            // a frame too wide for the group sort, or a list longer than its bound:
+        if (st[13] & 4u) ++c->n_fast_update_overflows;            // nothing ran; *done stays false, the lists wait on the device
+        return LIO_OK;
+    }
     *done = true;
     ++c->n_fast_updates;
     const uint32_t n_add = st[11], n_plain = st[12];
+    c->pred_n_add = n_add; c->pred_n_plain = n_plain;
     if (n_add_out) *n_add_out = (int)n_add;
     if (n_nodown_out) *n_nodown_out = (int)n_plain;
     if (n_add + n_plain == 0u) return LIO_OK;                     // (an update of nothing: the map is as it was)
+    c->hint_valid = false;
     rc = LIO_OK;
     if (st[14] != 0u) {
         (void)hipMemsetAsync(c->d_apply + 14, 0, sizeof(uint32_t), s);
@@ -780,7 +814,8 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
         bool done = false;
         rc = map_incremental_fast(c, state14, filter_size_map_min, flg_EKF_inited, n_add, n_nodown, add_counter, &done);
         if (rc != LIO_OK || done) return rc;
-        // (frames too wide for the group sort: nothing but the list kernel ran -- its lists, their counts and their box are in place)
+        // (frames too wide for the group sort, or a list longer than predicted: nothing but the list kernel ran -- its lists, their
+        // counts and their box are in place)
         rc = fetch_list_words(c, w);
         if (rc != LIO_OK) return rc;
         lists_made = true;
@@ -790,6 +825,7 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
         if (rc != LIO_OK) return rc;
     }
     hipStream_t s = c->stream;
+    c->pred_n_add = w.n_add; c->pred_n_plain = w.n_plain; c->pred_lists_valid = true;   // (what the next update's launches are sized by)
     if (n_add) *n_add = (int)w.n_add;
     if (n_nodown) *n_nodown = (int)w.n_plain;
     // the lists, for the caller that replicates them to other GPUs
@@ -1161,12 +1197,8 @@ static int deferred_settle_side_begin(lio_ctx* c) {
     bool launched = false;
     int rc = fold_batch_commit(c, d.fa, d.ba, n_add, box);
     if (rc == LIO_OK) rc = plain_batch_device(c, c->d_def_plain[cur], n_plain, box);
-    if (rc == LIO_OK) rc = apply_pending_enqueue(c, &launched);
-    if (rc == LIO_OK && launched) {
-        c->settle_seq = ++c->small4_seq;
-        const hipError_t e = launch_publish_words(c->d_apply, 32, c->d_small4, c->settle_seq, c->side_stream);
-        if (e != hipSuccess) rc = c->fail(LIO_ERR_HIP, "deferred exchange: publishing the statistics", hipGetErrorString(e));
-    }
+    c->settle_seq = ++c->small4_seq;            // (published by the apply kernel itself, into the mail box of the side stream)
+    if (rc == LIO_OK) rc = apply_pending_enqueue(c, &launched, c->d_small4, c->settle_seq);
     c->stream = main_stream;
     if (rc != LIO_OK) {
         // part of the chain may be on the side stream: nothing of the error handling on the main stream may run beside it

@@ -29,7 +29,5 @@ stamp "fast update A/B"
 for v in 0 1 0 1; do echo "LIO_FAST_UPDATE=$v"; LIO_FAST_UPDATE=$v timeout 300 python scripts/loop_body_step.py 40 2>&1 | grep -a "map_incremental\|SERIAL \|OVERLAPPED"; done > $O/loopbody_ab.log 2>&1
 cat $O/loopbody_ab.log
 stamp "loop body A/B"
-( cd /tmp && export TMPDIR=/tmp && LIO_BENCH_LONG_STEPS=0 timeout 500 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python $R/bench.py --steps 16 --warmup 2 --no-cpu-baseline --long-steps 0 --other-configs "" --no-loop-body --emulate-world 0 > $O/trace_bench.log 2> $O/trace_bench.err )
-python scripts/node_loop_timeline.py $O/trace $O/node_loop_timeline.txt
-find $O/trace -name "*kernel_trace.csv" -delete
+for fu in 1 0; do ( cd /tmp && export TMPDIR=/tmp && LIO_FAST_UPDATE=$fu LIO_BENCH_LONG_STEPS=0 timeout 500 rocprofv3 --kernel-trace --output-format csv -d $O/trace$fu -- python $R/bench.py --steps 16 --warmup 2 --no-cpu-baseline --long-steps 0 --other-configs "" --no-loop-body --emulate-world 0 > $O/trace_bench$fu.log 2> $O/trace_bench$fu.err ); python scripts/node_loop_timeline.py $O/trace$fu $O/node_loop_timeline_fast$fu.txt; find $O/trace$fu -name "*kernel_trace.csv" -delete; done
 stamp "node loop time line"

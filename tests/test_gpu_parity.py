@@ -1435,10 +1435,29 @@ def test_map_update_without_the_host_round_trip_equals_the_one_with_it(gpu_capi,
         i0, i1 = ctxs[0].map_info(), ctxs[1].map_info()
         for key in ("n_points", "n_live", "n_cells", "n_retired", "n_incremental_updates", "n_full_rebuilds", "n_boundary_points"):
             assert i0[key] == i1[key], (k, key, i0[key], i1[key])
-    assert ctxs[0].debug_get("fast_updates") == 5 and ctxs[1].debug_get("fast_updates") == 0
-    # the same scan again, no search in between (its neighbours are the old ones: most voxels are taken now)
+    # (the first update of a context has no previous lists to size its launches by: it takes the round trip)
+    assert ctxs[0].debug_get("fast_updates") + ctxs[0].debug_get("fast_update_overflows") == 4 and ctxs[0].debug_get("fast_updates") >= 2
+    assert ctxs[1].debug_get("fast_updates") == 0
+    # the same scan again, no search in between (its neighbours are the old ones: most voxels are taken now) ...
     res = [c.map_incremental(st, 0.2, True, apply=True, want_lists=False) for c in ctxs]
     assert res[0] == res[1]
     assert bits_equal(ctxs[0].map_flatten(), ctxs[1].map_flatten())
+    # ... and then a scan from a place the drive has not been to: far more inserts than the launches were sized for -- the list
+    # kernel says so on the device, every kernel behind it does nothing, the lists go through the round trip
+    small = res[0]["n_add"] + res[0]["n_nodown"]
+    ov0 = ctxs[0].debug_get("fast_update_overflows")
+    sc = synth.make_scan(w, nq, seed=synth.SEED + 399, pos=(-9.0, 7.0, 0.0), rpy=(0.0, 0.0, -2.0))
+    st = synth.state_vector(sc.pos, sc.rot, sc.off_R, sc.off_T)
+    res = []
+    for c in ctxs:
+        c.scan_set(sc.body)
+        c.measure(st, True, False)
+        res.append(c.map_incremental(st, 0.2, True, apply=True, want_lists=False))
+    assert res[0] == res[1]
+    assert res[0]["n_add"] + res[0]["n_nodown"] > 2 * small + 512, (small, res[0])
+    assert ctxs[0].debug_get("fast_update_overflows") == ov0 + 1
+    assert bits_equal(ctxs[0].map_flatten(), ctxs[1].map_flatten())
+    i0, i1 = ctxs[0].map_info(), ctxs[1].map_info()
+    assert i0["n_live"] == i1["n_live"] and i0["n_points"] == i1["n_points"] and i0["n_incremental_updates"] == i1["n_incremental_updates"]
     for c in ctxs:
         c.close()
