@@ -497,7 +497,7 @@ def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, 
            "full_index_rebuilds": info["n_full_rebuilds"] - info0["n_full_rebuilds"],
            "boundary_points_replayed_per_step": (info["n_boundary_points"] - info0["n_boundary_points"]) / max(info["n_incremental_updates"] - info0["n_incremental_updates"], 1),
            "vs_node_loop_world1": (1.0 / per_step) / node_loop_1["value"],
-           "latency": latency_summary(lat),
+           "latency": latency_summary(lat), "slowest_steps_ms": [round(float(x) * 1e3, 3) for x in sorted(lat)[-3:]],
            "sustained": sustained_figure(ctx, per_step, info0, info, lambda: one(False)),
            "schedule": "deferred (lio_replicate_defer): lists of exchange k enter the map at the start of exchange k + 1, their read-only half "
                        "planned on a side stream beside scan step k + 1" if deferred else "immediate: every exchange ends with its lists in the map",
@@ -995,7 +995,10 @@ def main():
         tick[0] = 0
         lat_node = []
         info_n0 = ctx.map_info()
-        t_node = timed_steps(step_node, k_node, 4, dist, device, lat_node)
+        for _ in range(4):                                     # warm-up (the first update allocates its batch buffers: not a per-step cost)
+            step_node()
+        maint.update({"n_add": 0, "n_nodown": 0, "seconds": 0.0, "steps": 0})
+        t_node = timed_steps(step_node, k_node, 0, dist, device, lat_node)
         info = ctx.map_info()
         maint_timed = dict(maint)
         # (the first search behind a map update, event-stamped: the same loop, untimed, right behind the timed window)
@@ -1013,6 +1016,7 @@ def main():
                                "exchange": ("lio_replicate_step: one ncclAllGather (RCCL over xGMI) on the library's stream, " + ("deferred" if nq <= 262144 else "immediate") + " schedule") if dist is not None else "none (1 rank)",
                                "incremental_index_updates": info["n_incremental_updates"], "full_index_rebuilds": info["n_full_rebuilds"],
                                "boundary_points_replayed_per_step": info["n_boundary_points"] / max(info["n_incremental_updates"], 1),
+                               "updates_without_a_host_round_trip": int(ctx.debug_get("fast_updates")), "updates_redone_with_the_round_trip_after_a_list_outgrew_its_launches": int(ctx.debug_get("fast_update_overflows")),
                                "latency": latency_summary(lat_node)}
         if dist is None:
             extras["node_loop"]["sustained"] = sustained_figure(ctx, t_node / k_node, info_n0, info, step_node)

@@ -532,37 +532,48 @@ hipError_t launch_exclusive_scan(const uint32_t* in, uint32_t n, uint32_t* out, 
 // SORT_MAX_ITEMS.  (Tried first and dropped: bitonic tiles in LDS + a multi-way rank search behind a stamped hand-off;
 // a 1024-record tile alone took ~30 us -- two wavefronts issuing ~220 instructions per round of the network.)
 constexpr uint32_t RANK_WAVES = 16;
-__global__ __launch_bounds__(1024) void rank_sort_pairs_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t n,
-                                                               uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                               const uint32_t* __restrict__ n_dev, uint32_t n_dev_add) {
-    __shared__ uint32_t s_cnt[RANK_WAVES][64];
-    if (n_dev != nullptr) n = min(n, *n_dev + n_dev_add);          // the count is still on the device: n was the launch bound
-    if (blockIdx.x * 64u >= n) return;
-    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t i0 = blockIdx.x * 64u, i = i0 + lane;
-    const bool in = i < n;
-    const uint64_t ki = in ? keys_in[i] : ~0ull;
-    const uint32_t per = (n + RANK_WAVES - 1u) / RANK_WAVES;
-    const uint32_t j0 = min(n, wave * per), j1 = min(n, j0 + per);
+// the count of one wavefront's share [j0, j1) for the record (ki, i) of workgroup rows [i0, i0 + 64); T = uint32_t when every key
+// of the batch fits 32 bits (compressed keys, lio_mapadd.h: the usual case) -- a 32-bit compare issues at full rate, a 64-bit one
+// does not -- the loads stay 8 bytes apart
+template <class T>
+__device__ __forceinline__ uint32_t rank_count(const uint64_t* __restrict__ keys_in, T ki, uint32_t i, uint32_t i0, uint32_t j0, uint32_t j1) {
+    auto key = [&](uint32_t j) -> T { return sizeof(T) == 4 ? (T)reinterpret_cast<const uint32_t*>(keys_in)[2u * j] : (T)keys_in[j]; };
     uint32_t cnt = 0;
     // records before the workgroup's own 64: "not after" = key <=; after them: key <; the 64 themselves: by position
     {
         const uint32_t e = min(j1, i0);
 #pragma unroll 16
-        for (uint32_t j = j0; j < e; ++j) cnt += keys_in[j] <= ki ? 1u : 0u;
+        for (uint32_t j = j0; j < e; ++j) cnt += key(j) <= ki ? 1u : 0u;
     }
     {
         const uint32_t sj = max(j0, i0), e = min(j1, i0 + 64u);
         for (uint32_t j = sj; j < e; ++j) {
-            const uint64_t kj = keys_in[j];
+            const T kj = key(j);
             cnt += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
         }
     }
     {
         const uint32_t sj = max(j0, i0 + 64u);
 #pragma unroll 16
-        for (uint32_t j = sj; j < j1; ++j) cnt += keys_in[j] < ki ? 1u : 0u;
+        for (uint32_t j = sj; j < j1; ++j) cnt += key(j) < ki ? 1u : 0u;
     }
+    return cnt;
+}
+__global__ __launch_bounds__(1024) void rank_sort_pairs_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t n,
+                                                               uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                               const uint32_t* __restrict__ n_dev, uint32_t n_dev_add, int kb, const uint32_t* __restrict__ kb_dev) {
+    __shared__ uint32_t s_cnt[RANK_WAVES][64];
+    if (n_dev != nullptr) n = min(n, *n_dev + n_dev_add);          // the count is still on the device: n was the launch bound
+    if (blockIdx.x * 64u >= n) return;
+    if (kb_dev != nullptr) kb = (int)*kb_dev;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t i0 = blockIdx.x * 64u, i = i0 + lane;
+    const bool in = i < n;
+    const uint64_t ki = in ? keys_in[i] : ~0ull;
+    const uint32_t per = (n + RANK_WAVES - 1u) / RANK_WAVES;
+    const uint32_t j0 = min(n, wave * per), j1 = min(n, j0 + per);
+    // (a lane beyond n holds the all-ones key in either width: it counts everything and stores nothing)
+    const uint32_t cnt = kb <= 32 ? rank_count<uint32_t>(keys_in, in ? (uint32_t)ki : 0xffffffffu, i, i0, j0, j1) : rank_count<uint64_t>(keys_in, ki, i, i0, j0, j1);
     s_cnt[wave][lane] = cnt;
     __syncthreads();
     if (wave == 0u && in) {
@@ -574,10 +585,10 @@ __global__ __launch_bounds__(1024) void rank_sort_pairs_kernel(const uint64_t* _
     }
 }
 hipError_t launch_sort_pairs_small(const uint64_t* keys_in, const uint32_t* vals_in, uint32_t n, uint64_t* keys_out, uint32_t* vals_out,
-                                   hipStream_t s, const uint32_t* n_dev, uint32_t n_dev_add) {
+                                   hipStream_t s, const uint32_t* n_dev, uint32_t n_dev_add, int kb, const uint32_t* kb_dev) {
     if (n == 0) return hipSuccess;
     if (n > SORT_MAX_ITEMS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rank_sort_pairs_kernel, dim3((n + 63u) / 64u), dim3(64 * RANK_WAVES), 0, s, keys_in, vals_in, n, keys_out, vals_out, n_dev, n_dev_add);
+    hipLaunchKernelGGL(rank_sort_pairs_kernel, dim3((n + 63u) / 64u), dim3(64 * RANK_WAVES), 0, s, keys_in, vals_in, n, keys_out, vals_out, n_dev, n_dev_add, kb, kb_dev);
     return hipGetLastError();
 }
 

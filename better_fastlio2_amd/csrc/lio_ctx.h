@@ -203,8 +203,16 @@ struct lio_ctx {
                                                // Add_Points again (A/B runs of scripts)
     long long n_fast_updates = 0;              // map updates that ran without it
     long long n_fast_update_overflows = 0;     // ... that found a list longer than their launches were sized for (redone with the round trip)
-    uint32_t pred_n_add = 0, pred_n_plain = 0; // lengths of the previous lio_map_incremental's lists: what the next one's launches are sized by
+    // list lengths of the last eight lio_map_incremental calls: the next one's launches are sized by their maxima (a drive that
+    // alternates between places -- bench.py's rotation of eight scans -- predicts badly from the previous scan alone)
+    uint32_t pred_add_ring[8] = {}, pred_plain_ring[8] = {};
+    int pred_ring_pos = 0;
     bool pred_lists_valid = false;
+    void pred_record(uint32_t n_add, uint32_t n_plain) {
+        pred_add_ring[pred_ring_pos] = n_add; pred_plain_ring[pred_ring_pos] = n_plain;
+        pred_ring_pos = (pred_ring_pos + 1) & 7; pred_lists_valid = true;
+    }
+    uint32_t pred_max(const uint32_t (&r)[8]) const { uint32_t m = 0; for (uint32_t v : r) m = v > m ? v : m; return m; }
     uint32_t* d_ghist = nullptr;               // two partition histograms of the group sort (lio_gsort.hip), used alternately
     int ghist_cur = 0;
     bool ghist_dirty = false;                  // a key kernel filled a histogram whose sort never ran

@@ -165,7 +165,7 @@ int run_sort(lio_ctx* c, SortKind k, const uint64_t* keys_in, const uint32_t* va
     hipStream_t s = c->stream;
     if (n_bound == 0) return LIO_OK;
     if (k == SORT_RANK) {
-        HIPCHK(c, launch_sort_pairs_small(keys_in, vals_in, (uint32_t)n_bound, keys_out, vals_out, s, n_dev, n_dev_add));
+        HIPCHK(c, launch_sort_pairs_small(keys_in, vals_in, (uint32_t)n_bound, keys_out, vals_out, s, n_dev, n_dev_add, kb_dev != nullptr ? 64 : (kb > 0 ? kb : 64), kb_dev));
     } else if (k == SORT_LARGE) {
         GsortArgs g{};
         g.keys = keys_in; g.vals = vals_in; g.n = (uint32_t)n_bound; g.n_dev = n_dev; g.n_dev_add = n_dev_add; g.kb = kb; g.kb_dev = kb_dev;

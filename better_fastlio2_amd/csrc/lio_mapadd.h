@@ -21,13 +21,37 @@ LIO_HD bool frame_holds(const KeyFrame& f, int x, int y, int z) {
     const long long dx = (long long)x - f.ox, dy = (long long)y - f.oy, dz = (long long)z - f.oz;
     return dx >= 0 && dx < (1ll << f.bx) && dy >= 0 && dy < (1ll << f.by) && dz >= 0 && dz < (1ll << f.bz);
 }
+// The key of a coordinate triple inside its frame.  NOT x | y | z from the top: the group sort (lio_gsort.hip) splits a batch by the
+// top eight key bits first, and with the high coordinate bits on top those are slabs of space -- a scan's inserts crowd around
+// the sensor, eight ranks' lists put thousands of records into a few of the 256 buckets and one workgroup sorts each (61 us of a
+// 76 k-point batch, profiles/r05z_emulated_world8_timeline.txt).  The LOW bits of the three coordinates lead instead (3 + 3 + 2,
+// fewer where an axis has fewer): neighbouring voxels fall into different buckets, every bucket gets its share whatever the
+// shape of the cloud.  Nothing needs the order of the keys to mean anything -- groups are runs of equal keys, look-ups are binary
+// searches for an exact key, the decode below is the inverse -- only that every party uses the same one.
+struct KeyLayout { int lx, ly, lz, hx, hy, hz; };
+LIO_HD KeyLayout frame_layout(const KeyFrame& f) {
+    KeyLayout l;
+    l.lx = f.bx < 3 ? f.bx : 3; l.ly = f.by < 3 ? f.by : 3; l.lz = f.bz < 2 ? f.bz : 2;
+    l.hx = f.bx - l.lx; l.hy = f.by - l.ly; l.hz = f.bz - l.lz;
+    return l;
+}
 LIO_HD uint64_t frame_key(const KeyFrame& f, int x, int y, int z) {
-    return ((uint64_t)(uint32_t)(x - f.ox) << (f.by + f.bz)) | ((uint64_t)(uint32_t)(y - f.oy) << f.bz) | (uint64_t)(uint32_t)(z - f.oz);
+    const KeyLayout l = frame_layout(f);
+    const uint32_t ux = (uint32_t)(x - f.ox), uy = (uint32_t)(y - f.oy), uz = (uint32_t)(z - f.oz);
+    const uint32_t lo = ((ux & ((1u << l.lx) - 1u)) << (l.ly + l.lz)) | ((uy & ((1u << l.ly) - 1u)) << l.lz) | (uz & ((1u << l.lz) - 1u));
+    const uint64_t hi = ((uint64_t)(ux >> l.lx) << (l.hy + l.hz)) | ((uint64_t)(uy >> l.ly) << l.hz) | (uint64_t)(uz >> l.lz);
+    return ((uint64_t)lo << (l.hx + l.hy + l.hz)) | hi;
 }
 LIO_HD void frame_decode(const KeyFrame& f, uint64_t key, int& x, int& y, int& z) {
-    z = f.oz + (int)(key & ((1ull << f.bz) - 1ull));
-    y = f.oy + (int)((key >> f.bz) & ((1ull << f.by) - 1ull));
-    x = f.ox + (int)(key >> (f.by + f.bz));
+    const KeyLayout l = frame_layout(f);
+    const int hbits = l.hx + l.hy + l.hz;
+    const uint32_t lo = (uint32_t)(key >> hbits);
+    const uint64_t hi = key & ((1ull << hbits) - 1ull);
+    const uint32_t xl = (lo >> (l.ly + l.lz)) & ((1u << l.lx) - 1u), yl = (lo >> l.lz) & ((1u << l.ly) - 1u), zl = lo & ((1u << l.lz) - 1u);
+    const uint32_t xh = (uint32_t)(hi >> (l.hy + l.hz)), yh = (uint32_t)((hi >> l.hz) & ((1ull << l.hy) - 1ull)), zh = (uint32_t)(hi & ((1ull << l.hz) - 1ull));
+    x = f.ox + (int)((xh << l.lx) | xl);
+    y = f.oy + (int)((yh << l.ly) | yl);
+    z = f.oz + (int)((zh << l.lz) | zl);
 }
 // integer down-sample voxel of a coordinate: floor(v / ds) (ikd_Tree.cpp:424), clamped like the grid cells
 LIO_HD int voxel_coord(float v, float ds) {
@@ -39,15 +63,18 @@ LIO_HD int voxel_coord(float v, float ds) {
 
 // frame of the integer coordinates lo .. hi (inclusive) of a batch: one spare coordinate per axis above hi, so that the
 // all-ones key is never a point's (the group of the non-finite points, lio_mapadd.hip)
+// The origin is rounded down to a multiple of eight: the low three bits of a coordinate inside the frame are then the low bits
+// of the coordinate itself, and the ORDER of the keys (frame_key below: low bits lead) does not depend on which box the frame was
+// derived from -- the list kernel's box of the list points and the library path's box of the whole scan sort a batch alike.
 LIO_HD KeyFrame frame_of(const int lo[3], const int hi[3]) {
     KeyFrame f{};
-    f.ox = lo[0]; f.oy = lo[1]; f.oz = lo[2];
+    const int o[3] = {lo[0] & ~7, lo[1] & ~7, lo[2] & ~7};
+    f.ox = o[0]; f.oy = o[1]; f.oz = o[2];
     int bits[3];
     for (int i = 0; i < 3; ++i) {
-        const long long extent = (long long)hi[i] - (long long)lo[i] + 2;
-        int b = 1;
-        while (b < 40 && (1ll << b) < extent) ++b;
-        bits[i] = b;
+        const long long extent = (long long)hi[i] - (long long)o[i] + 2;
+        // smallest b >= 1 with 2^b >= extent (no loop: the list kernel's last lane runs this at the tail of its launch)
+        bits[i] = extent <= 2 ? 1 : 64 - __builtin_clzll((unsigned long long)(extent - 1));
     }
     f.bx = bits[0]; f.by = bits[1]; f.bz = bits[2];
     return f;
@@ -287,7 +314,8 @@ hipError_t launch_compact_live(const float4* src, uint32_t n, float4* dst, uint3
 // stable sort of (u64 key, u32 value) pairs, one launch, no workspace (rank by counting: O(n^2))
 constexpr uint32_t SORT_MAX_ITEMS = 16384;
 hipError_t launch_sort_pairs_small(const uint64_t* keys_in, const uint32_t* vals_in, uint32_t n, uint64_t* keys_out, uint32_t* vals_out,
-                                   hipStream_t s, const uint32_t* n_dev = nullptr, uint32_t n_dev_add = 0);
+                                   hipStream_t s, const uint32_t* n_dev = nullptr, uint32_t n_dev_add = 0, int kb = 64, const uint32_t* kb_dev = nullptr);
+// (kb / kb_dev: every key is below 2^kb -- from 32 bits down the kernel compares 32-bit words)
 // run starts only, runs of equal keys >> shift (the voxel filter's leaves: the leaf index is the upper half of the key)
 hipError_t launch_run_heads(const uint64_t* keys, uint32_t n, int shift, uint32_t* starts_out, uint32_t* n_runs_out, unsigned long long* agg,
                             uint32_t stamp, uint32_t* err, hipStream_t s);

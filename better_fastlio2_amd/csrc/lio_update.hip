@@ -670,8 +670,8 @@ static int map_incremental_lists(lio_ctx* c, const double state14[14], double fi
 // apply_pending): the frames are derived by the same functions from the same box.
 // What the host cannot know is how LARGE to launch.  The scan size is a bound, but a scan inserts a twelfth of its points and a
 // launch pays for the workgroups it does not need (measured, profiles/r06b_*: with every kernel sized for the 100 k points of the
-// scan the update was 18 us slower than with the round trip it saved).  So the launches are sized by the PREVIOUS update's lists
-// (+ 25 % + 256: consecutive scans of a drive insert alike); the list kernel itself checks the lists against these bounds and, if
+// scan the update was 18 us slower than with the round trip it saved).  So the launches are sized by the lists of the last eight
+// updates (their maximum + 25 % + 256: consecutive scans of a drive insert alike); the list kernel itself checks the lists against these bounds and, if
 // one is longer, leaves a descriptor that makes every kernel behind it a no-op -- the host then finds the lists intact and takes
 // its own path with them (one wasted chain of empty launches; `fast_update_overflows`).
 static bool fast_update_possible(const lio_ctx* c) {
@@ -691,7 +691,7 @@ static int map_incremental_fast(lio_ctx* c, const double state14[14], double fil
     hipStream_t s = c->stream;
     int rc = ensure_add_buffers(c, (size_t)nq);
     if (rc != LIO_OK) return rc;
-    const uint32_t b_add = list_bound(c->pred_n_add, nq), b_plain = list_bound(c->pred_n_plain, nq);
+    const uint32_t b_add = list_bound(c->pred_max(c->pred_add_ring), nq), b_plain = list_bound(c->pred_max(c->pred_plain_ring), nq);
     const uint32_t b_pend = b_add + b_plain;                      // (every survivor is one of the b_add points)
     if ((size_t)b_pend > c->cap_pend) return LIO_OK;
     const SortKind kind_v = sort_kind(c, b_add, 0), kind_c = sort_kind(c, b_pend, 0);
@@ -777,7 +777,7 @@ static int map_incremental_fast(lio_ctx* c, const double state14[14], double fil
     *done = true;
     ++c->n_fast_updates;
     const uint32_t n_add = st[11], n_plain = st[12];
-    c->pred_n_add = n_add; c->pred_n_plain = n_plain;
+    c->pred_record(n_add, n_plain);
     if (n_add_out) *n_add_out = (int)n_add;
     if (n_nodown_out) *n_nodown_out = (int)n_plain;
     if (n_add + n_plain == 0u) return LIO_OK;                     // (an update of nothing: the map is as it was)
@@ -825,7 +825,7 @@ int lio_map_incremental(lio_ctx* c, const double state14[14], double filter_size
         if (rc != LIO_OK) return rc;
     }
     hipStream_t s = c->stream;
-    c->pred_n_add = w.n_add; c->pred_n_plain = w.n_plain; c->pred_lists_valid = true;   // (what the next update's launches are sized by)
+    c->pred_record(w.n_add, w.n_plain);         // (what the next updates' launches are sized by)
     if (n_add) *n_add = (int)w.n_add;
     if (n_nodown) *n_nodown = (int)w.n_plain;
     // the lists, for the caller that replicates them to other GPUs

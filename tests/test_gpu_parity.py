@@ -1442,21 +1442,27 @@ def test_map_update_without_the_host_round_trip_equals_the_one_with_it(gpu_capi,
     res = [c.map_incremental(st, 0.2, True, apply=True, want_lists=False) for c in ctxs]
     assert res[0] == res[1]
     assert bits_equal(ctxs[0].map_flatten(), ctxs[1].map_flatten())
-    # ... and then a scan from a place the drive has not been to: far more inserts than the launches were sized for -- the list
-    # kernel says so on the device, every kernel behind it does nothing, the lists go through the round trip
-    small = res[0]["n_add"] + res[0]["n_nodown"]
-    ov0 = ctxs[0].debug_get("fast_update_overflows")
+    for c in ctxs:
+        c.close()
+    # A list longer than the launches were sized for: fresh twins, a scan of 150 points first (its lists are what the next update is
+    # sized by), then a full scan from elsewhere -- the list kernel says so on the device, every kernel behind it does nothing, the
+    # lists go through the round trip
+    ctxs = [gpu_capi.LioContext(0.2, max_scan_points=nq, max_map_points=500_000) for _ in range(2)]
+    ctxs[1].debug_set("fast_update", 0)
     sc = synth.make_scan(w, nq, seed=synth.SEED + 399, pos=(-9.0, 7.0, 0.0), rpy=(0.0, 0.0, -2.0))
     st = synth.state_vector(sc.pos, sc.rot, sc.off_R, sc.off_T)
-    res = []
     for c in ctxs:
-        c.scan_set(sc.body)
-        c.measure(st, True, False)
-        res.append(c.map_incremental(st, 0.2, True, apply=True, want_lists=False))
-    assert res[0] == res[1]
-    assert res[0]["n_add"] + res[0]["n_nodown"] > 2 * small + 512, (small, res[0])
-    assert ctxs[0].debug_get("fast_update_overflows") == ov0 + 1
-    assert bits_equal(ctxs[0].map_flatten(), ctxs[1].map_flatten())
+        c.map_build(w.points)
+    for body in (np.ascontiguousarray(sc.body[:150]), sc.body):
+        res = []
+        for c in ctxs:
+            c.scan_set(body)
+            c.measure(st, True, False)
+            res.append(c.map_incremental(st, 0.2, True, apply=True, want_lists=False))
+        assert res[0] == res[1]
+        assert bits_equal(ctxs[0].map_flatten(), ctxs[1].map_flatten())
+    assert res[0]["n_add"] + res[0]["n_nodown"] > 1024, res[0]
+    assert ctxs[0].debug_get("fast_update_overflows") == 1 and ctxs[0].debug_get("fast_updates") == 0
     i0, i1 = ctxs[0].map_info(), ctxs[1].map_info()
     assert i0["n_live"] == i1["n_live"] and i0["n_points"] == i1["n_points"] and i0["n_incremental_updates"] == i1["n_incremental_updates"]
     for c in ctxs:
