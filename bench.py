@@ -718,6 +718,12 @@ def main():
     ext_i = int(ext)
     tick = [0]
 
+    def dbg_counter(key):
+        try:
+            return int(ctx.debug_get(key))
+        except capi.LioError:                                  # (an older build of the library: A/B runs through LIO_HIP_LIBRARY)
+            return None
+
     def fail(what, rc):
         raise capi.LioError(f"{what} failed: {capi.ERRORS.get(rc, rc)}: {L.lio_last_error(ctx.h).decode()}")
 
@@ -953,7 +959,7 @@ def main():
             tick[0] = 0
             t = timed_steps(fn, k_extra, w_extra, dist, device)
             extras[name] = {"value": world_size * k_extra / t, "unit": "scans/s", "ms_per_step": t / k_extra * 1e3, "steps": k_extra}
-        if dist is None:
+        if dist is None and os.environ.get("LIO_BENCH_NO_CALLBACK") != "1":   # (A/B runs of another build through LIO_HIP_LIBRARY: libcallback_bench.so is linked against the tree's library)
             extras.update(callback_figures(ctx, capi, synth, world, scans, scan_poses, priors, P0_p, ulog_ref, ext_i, nq, kind, max_iter, k_extra, w_extra,
                                            step_resident, tick, device))
         # node loop: scan step + map_incremental (+ exchange) -- mutates the map, so it runs last
@@ -1016,7 +1022,7 @@ def main():
                                "exchange": ("lio_replicate_step: one ncclAllGather (RCCL over xGMI) on the library's stream, " + ("deferred" if nq <= 262144 else "immediate") + " schedule") if dist is not None else "none (1 rank)",
                                "incremental_index_updates": info["n_incremental_updates"], "full_index_rebuilds": info["n_full_rebuilds"],
                                "boundary_points_replayed_per_step": info["n_boundary_points"] / max(info["n_incremental_updates"], 1),
-                               "updates_without_a_host_round_trip": int(ctx.debug_get("fast_updates")), "updates_redone_with_the_round_trip_after_a_list_outgrew_its_launches": int(ctx.debug_get("fast_update_overflows")),
+                               "updates_without_a_host_round_trip": dbg_counter("fast_updates"), "updates_redone_with_the_round_trip_after_a_list_outgrew_its_launches": dbg_counter("fast_update_overflows"),
                                "latency": latency_summary(lat_node)}
         if dist is None:
             extras["node_loop"]["sustained"] = sustained_figure(ctx, t_node / k_node, info_n0, info, step_node)

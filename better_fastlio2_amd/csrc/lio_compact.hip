@@ -337,8 +337,9 @@ __global__ __launch_bounds__(256) void pend_build_kernel(PendBuildArgs a) {
     const uint32_t tp = (a.n_plain + 255u) / 256u;              // tiles of the plain list (by the launch bound with desc)
     // (round 6) the counts and the cell frame may still be on the device: n_plain / n_surv_slots are then launch bounds
     uint32_t n_plain = a.n_plain, half = a.n_surv_slots, n_half = a.n_surv_slots;
-    if (a.desc != nullptr) { n_plain = min(a.n_plain, a.desc->n_plain); half = a.n_surv_slots / 2u; n_half = min(half, a.desc->n_add); a.frame = a.desc->cf; }
-    const int kb = frame_bits(a.frame) + 1;
+    if (a.desc != nullptr) { n_plain = min(a.n_plain, a.desc->n_plain); half = a.n_surv_slots / 2u; n_half = min(half, a.desc->n_add); }
+    const KeyFrame frame = a.desc != nullptr ? a.desc->cf : a.frame;     // (a local: never assign into the by-value argument struct)
+    const int kb = frame_bits(frame) + 1;
     if (a.count_parts != nullptr && blockIdx.x == gridDim.x - 1) {
         // the extra workgroup: the fold's counters, one pair per workgroup of fold_commit_kernel, added up (fixed order)
         uint32_t r = 0, c = 0;
@@ -360,8 +361,8 @@ __global__ __launch_bounds__(256) void pend_build_kernel(PendBuildArgs a) {
         // the cell of 0: the bounding box counted it as 0 too)
         auto fin = [](float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u ? v : 0.0f; };
         const int cx = cell_coord(fin(p.x), a.grid.inv_cell), cy = cell_coord(fin(p.y), a.grid.inv_cell), cz = cell_coord(fin(p.z), a.grid.inv_cell);
-        if (!frame_holds(a.frame, cx, cy, cz)) atomicOr(a.flags, 2u);          // the host's frame is wrong: reported
-        const uint64_t key = (frame_key(a.frame, cx, cy, cz) << 1) | (uint64_t)list;
+        if (!frame_holds(frame, cx, cy, cz)) atomicOr(a.flags, 2u);            // the host's frame is wrong: reported
+        const uint64_t key = (frame_key(frame, cx, cy, cz) << 1) | (uint64_t)list;
         a.pend[pos] = make_float4(p.x, p.y, p.z, 0.0f);
         a.keys[pos] = key;
         a.order[pos] = pos;

@@ -277,6 +277,8 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     { const char* e = std::getenv("LIO_ARM_NEXT_SCAN"); if (e != nullptr && e[0] == '0') c->dbg_arm_next_scan = 0; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_GATE_IN_KERNEL"); if (e != nullptr && e[0] >= '0' && e[0] <= '7' && e[1] == 0) c->gate_in_kernel = e[0] - '0'; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_ASSIST_PULL"); if (e != nullptr && e[0] >= '0' && e[0] <= '9') c->dbg_assist_pull = std::atoi(e); }   // (A/B runs of scripts)
+    { const char* e = std::getenv("LIO_PUBLISH_IN_KERNEL"); if (e != nullptr && e[0] == '0') c->dbg_publish_in_kernel = false; }   // (A/B runs of scripts)
+    { const char* e = std::getenv("LIO_SIDE_EVENT"); if (e != nullptr && e[0] == '0') c->dbg_side_event = false; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_FAST_UPDATE"); if (e != nullptr && e[0] == '0') c->dbg_fast_update = false; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_KNN_WALK"); if (e != nullptr && (e[0] == '0' || e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0) c->dbg_knn_walk = e[0] - '0'; }
     hipDeviceProp_t prop;

@@ -34,7 +34,7 @@ constexpr int GS_IB = GSORT_INDEX_BITS;
 constexpr u64 GS_IMASK = (1ull << GS_IB) - 1ull;
 constexpr uint32_t GS_TILE = 2048;               // records per partition tile: 8 wavefronts x 4 rounds x 64 lanes
 constexpr uint32_t GS_LDS_CAP = 8192;            // records of a bucket that is sorted inside LDS
-constexpr uint32_t GS_RANK_CAP = 256;            // ... that is ranked by counting there (no passes)
+constexpr uint32_t GS_RANK_CAP = 512;            // ... that is ranked by counting there (no passes)
 
 // lanes of this wavefront (among the valid ones) that hold the same digit
 __device__ __forceinline__ u64 gs_match(uint32_t d, bool valid, int bits) {

@@ -53,8 +53,9 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(VoxelKeyArgs a) {
     // (round 6) count and frame may still be on the device: a.n is then the launch bound, the survivor slots are laid out by it
     const uint32_t n_slots = a.n;
     uint32_t n = a.n;
-    if (a.desc != nullptr) { n = min(a.n, a.desc->n_add); a.frame = a.desc->vf; }
-    const int kb = frame_bits(a.frame);
+    if (a.desc != nullptr) n = min(a.n, a.desc->n_add);
+    const KeyFrame frame = a.desc != nullptr ? a.desc->vf : a.frame;
+    const int kb = frame_bits(frame);
     const uint64_t junk = kb >= 64 ? ~0ull : (1ull << kb) - 1ull;      // a key no point of the frame has (lio_mapadd.h)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         a.dirty[i] = 0;
@@ -65,9 +66,9 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(VoxelKeyArgs a) {
         const int ix = voxel_coord(p.x, a.ds), iy = voxel_coord(p.y, a.ds), iz = voxel_coord(p.z, a.ds);
         // a point with a non-finite coordinate never enters the map through Add_Points(.., true) (its box holds nothing and
         // same_point(p, p) is false, :440-445): all of them form one group of their own, behind every real key
-        const bool fin = finite3(p), held = frame_holds(a.frame, ix, iy, iz);
+        const bool fin = finite3(p), held = frame_holds(frame, ix, iy, iz);
         if (fin && !held) atomicOr(a.flags, 1u);                   // the host's frame is wrong: reported, never silent
-        const uint64_t key = (fin && held) ? frame_key(a.frame, ix, iy, iz) : junk;
+        const uint64_t key = (fin && held) ? frame_key(frame, ix, iy, iz) : junk;
         a.keys[i] = key;
         a.order[i] = i;
         if (a.hist != nullptr) atomicAdd(&s_hist[gsort_digit(key, kb)], 1u);
@@ -175,9 +176,9 @@ __device__ __forceinline__ void mark_group_dirty(const BoundaryArgs& a, uint32_t
     const uint64_t key = a.view.skey[h];
     for (uint32_t s = h; s < n && a.view.skey[s] == key; ++s) a.dirty_pt[a.view.sord[s]] = 1;
 }
-__device__ __forceinline__ uint32_t find_voxel_group(const BoundaryArgs& a, uint32_t n, int x, int y, int z) {
-    if (!frame_holds(a.frame, x, y, z)) return 0xffffffffu;       // no batch point lives outside the frame
-    return view_find(a.view, n, frame_key(a.frame, x, y, z));
+__device__ __forceinline__ uint32_t find_voxel_group(const BoundaryArgs& a, const KeyFrame& f, uint32_t n, int x, int y, int z) {
+    if (!frame_holds(f, x, y, z)) return 0xffffffffu;             // no batch point lives outside the frame
+    return view_find(a.view, n, frame_key(f, x, y, z));
 }
 
 // Add_Points(downsample) for the points of dirty groups, replayed in batch order by ONE wavefront with the
@@ -383,7 +384,7 @@ __device__ __forceinline__ uint32_t count_live_points(const float4* map_pts, uin
 // every dirty mark of the batch is known.  The replay only touches the voxels of dirty groups, and a map point inside two
 // boxes makes both groups dirty, so nothing a clean group's plan was computed from changes before it is carried out.
 __global__ __launch_bounds__(64) void fold_plan_kernel(FoldArgs a, BoundaryArgs ba) {
-    if (ba.frame_dev != nullptr) ba.frame = *ba.frame_dev;      // (round 6: the frame may still be on the device, BatchDesc)
+    const KeyFrame vframe = ba.frame_dev != nullptr ? *ba.frame_dev : ba.frame;   // (round 6: the frame may still be on the device, BatchDesc; a local: see cell_apply_kernel)
     const uint32_t n = view_count(a.view);
     const float ds = a.ds;
     const int lane = threadIdx.x, t = lane & 7;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(64) void fold_plan_kernel(FoldArgs a, BoundaryArgs 
                 k[ax] = iv[ax] + (bit ? dir[ax] : 0);
             }
             if (!use) continue;
-            const uint32_t g = find_voxel_group(ba, n, k[0], k[1], k[2]);
+            const uint32_t g = find_voxel_group(ba, vframe, n, k[0], k[1], k[2]);
             if (g != 0xffffffffu) mark_group_dirty(ba, n, g);
         }
     }
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(64) void fold_plan_kernel(FoldArgs a, BoundaryArgs 
                     k[ax] = iv[ax] + (bit ? dir[ax] : 0);
                 }
                 if (!use) continue;
-                const uint32_t h = find_voxel_group(ba, n, k[0], k[1], k[2]);
+                const uint32_t h = find_voxel_group(ba, vframe, n, k[0], k[1], k[2]);
                 if (h != 0xffffffffu) { mark_group_dirty(ba, n, h); mark_group_dirty(ba, n, s); }
             }
         });
@@ -627,7 +628,7 @@ __device__ __forceinline__ bool plan_tile_prefix(uint32_t mine, uint32_t b, unsi
 __global__ __launch_bounds__(256) void cell_plan_kernel(ApplyArgs a) {
     __shared__ uint32_t s_w[4];
     __shared__ uint8_t s_head[256];
-    if (a.frame_dev != nullptr) a.frame = *a.frame_dev;         // (round 6: the frame may still be on the device, BatchDesc)
+    const KeyFrame frame = a.frame_dev != nullptr ? *a.frame_dev : a.frame;   // (round 6: the frame may still be on the device, BatchDesc)
     const uint32_t n = view_count(a.view);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the statistics the apply kernel accumulates start from zero (nothing reads them before it)
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void cell_plan_kernel(ApplyArgs a) {
     if (head) {
         const uint64_t key = a.view.skey[s] >> 1;                  // (the low bit tells the two lists apart, not the cells)
         int cx, cy, cz;
-        frame_decode(a.frame, key, cx, cy, cz);
+        frame_decode(frame, key, cx, cy, cz);
         CellPlan pl{0u, 0u, 0xffffffffu, 0u, 0u, 0u};
         cell_find(a.ltable + a.levels.off[1], a.levels.mask[1], a.child, (uint32_t)cx, (uint32_t)cy, (uint32_t)cz, pl.old_start, pl.old_count, &pl.index);
         pl.found = pl.old_count != 0u ? 1u : 0u;                  // records are only ever written with count >= 1
@@ -691,7 +692,9 @@ __device__ __forceinline__ uint32_t table_claim(HashEntry* table, uint32_t mask,
 __global__ __launch_bounds__(256) void cell_apply_kernel(ApplyArgs a) {
     __shared__ uint32_t s_stat[4][2];
     __shared__ uint32_t s_last;
-    if (a.frame_dev != nullptr) a.frame = *a.frame_dev;
+    // (a LOCAL frame: assigning into the by-value argument struct makes the compiler keep a private copy of all ~700 bytes of it --
+    // 720 bytes of scratch per lane, every access of a.levels through it: this kernel went from 12.5 to 33 us that way)
+    const KeyFrame frame = a.frame_dev != nullptr ? *a.frame_dev : a.frame;
     const uint32_t n = view_count(a.view);
     // room check on the device (every lane sees the same total): either the whole batch is applied or nothing is
     const uint32_t total = a.stats[3];
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(256) void cell_apply_kernel(ApplyArgs a) {
         const uint32_t count = pl.live + pl.n_new;
         retired_sum += retired;
         int icx, icy, icz;
-        frame_decode(a.frame, key, icx, icy, icz);
+        frame_decode(frame, key, icx, icy, icz);
         const uint32_t cx = (uint32_t)icx, cy = (uint32_t)icy, cz = (uint32_t)icz;
         const uint32_t pos = ((cx & 3u) << 4) | ((cy & 3u) << 2) | (cz & 3u);        // place inside the child block
         if (pl.found) {
@@ -783,12 +786,18 @@ __global__ __launch_bounds__(256) void cell_apply_kernel(ApplyArgs a) {
     if (threadIdx.x == 0) s_last = atomicAdd(a.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
     if (s_last == 0u) return;
-    if (threadIdx.x < 32) a.publish_dst[threadIdx.x] = __hip_atomic_load(a.stats + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
+    // NO system-scope fence / release here: it would write the whole L2 back first -- this kernel has just filled it with re-written
+    // buckets (measured: the kernel 12.5 -> 34 us on an eight-rank batch).  The words go to host-mapped (uncached) memory as
+    // system-scope stores, are acknowledged (vmcnt), and only then is the sequence number stored the same way: posted writes to
+    // one destination do not pass each other.  The host reads nothing of this kernel but these words.
+    if (threadIdx.x < 32)
+        __hip_atomic_store(a.publish_dst + threadIdx.x, __hip_atomic_load(a.stats + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.publish_dst + 32, a.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.publish_dst + 32, a.publish_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -405,6 +405,13 @@ static int apply_pending_finish(lio_ctx* c, const uint32_t st[32], int rc) {
 }
 int apply_pending(lio_ctx* c) {
     bool launched = false;
+    if (!c->dbg_publish_in_kernel) {            // (LIO_PUBLISH_IN_KERNEL=0, A/B runs of scripts: a publish launch behind the apply kernel, as until round 5)
+        int rc0 = apply_pending_enqueue(c, &launched);
+        if (rc0 != LIO_OK || !launched) return rc0;
+        uint32_t st0[32] = {};
+        rc0 = fetch_batch_counts(c, st0);
+        return apply_pending_finish(c, st0, rc0);
+    }
     const uint32_t seq = ++c->small_seq;
     int rc = apply_pending_enqueue(c, &launched, c->d_small, seq);
     if (rc != LIO_OK || !launched) return rc;
@@ -1190,15 +1197,25 @@ static int deferred_settle_side_begin(lio_ctx* c) {
     // ordered behind everything the main stream holds at this moment.  By the call graph that is nothing that reads the map (every
     // reader was collected by the host before lio_replicate_step, armed passes were called off by enter()) -- the event is usually
     // complete when it is recorded; it is there so that a future main-stream launch in front of this point cannot race silently.
-    if (!c->ev_main) HIPCHK(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
-    HIPCHK(c, hipEventRecord(c->ev_main, main_stream));
-    HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_main, 0));
+    if (c->dbg_side_event) {
+        if (!c->ev_main) HIPCHK(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_main, main_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_main, 0));
+    }
     c->stream = c->side_stream;                 // (every launch helper of the update takes the context's stream)
     bool launched = false;
     int rc = fold_batch_commit(c, d.fa, d.ba, n_add, box);
     if (rc == LIO_OK) rc = plain_batch_device(c, c->d_def_plain[cur], n_plain, box);
     c->settle_seq = ++c->small4_seq;            // (published by the apply kernel itself, into the mail box of the side stream)
-    if (rc == LIO_OK) rc = apply_pending_enqueue(c, &launched, c->d_small4, c->settle_seq);
+    if (c->dbg_publish_in_kernel) {
+        if (rc == LIO_OK) rc = apply_pending_enqueue(c, &launched, c->d_small4, c->settle_seq);
+    } else {
+        if (rc == LIO_OK) rc = apply_pending_enqueue(c, &launched);
+        if (rc == LIO_OK && launched) {
+            const hipError_t e = launch_publish_words(c->d_apply, 32, c->d_small4, c->settle_seq, c->side_stream);
+            if (e != hipSuccess) rc = c->fail(LIO_ERR_HIP, "deferred exchange: publishing the statistics", hipGetErrorString(e));
+        }
+    }
     c->stream = main_stream;
     if (rc != LIO_OK) {
         // part of the chain may be on the side stream: nothing of the error handling on the main stream may run beside it

@@ -1,0 +1,23 @@
+# A/B of the two key layouts on one box: x | y | z from the top (ab/liblio_hip_oldkey.so) against low coordinate bits on top (the tree)
+tag=${1:-r06i}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
+cd $R
+export LIO_SYNTH_CACHE=/tmp/lio_synth; mkdir -p $LIO_SYNTH_CACHE
+for i in 1 2; do for v in oldkey new; do
+if [ $v = oldkey ]; then export LIO_HIP_LIBRARY=$R/better_fastlio2_amd/lib/ab/liblio_hip_oldkey.so; else unset LIO_HIP_LIBRARY; fi
+LIO_BENCH_LONG_STEPS=0 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --long-steps 0 --other-configs "" --no-loop-body > $O/bench_${v}_$i.json 2> $O/bench_${v}_$i.err
+python - <<PY
+import json
+d=json.loads(open('$O/bench_${v}_$i.json').read().strip().splitlines()[-1])
+ew=d['node_loop_emulated_world8']; nl=d['node_loop']
+print('$v run $i value %.0f node_loop %.0f map_update %.1f us | ew deferred vs1 %.3f update %.1f us step %.1f us | immediate vs1 %.3f update %.1f us' % (d['value'], nl['value'], nl['map_update_ms_per_step']*1e3,
+      ew['vs_node_loop_world1'], ew['map_update_ms_per_step']*1e3, ew['scan_step_ms']*1e3, ew['immediate_schedule']['vs_node_loop_world1'], ew['immediate_schedule']['map_update_ms_per_step']*1e3))
+PY
+done; done
+unset LIO_HIP_LIBRARY
+for v in oldkey new; do
+if [ $v = oldkey ]; then export LIO_HIP_LIBRARY=$R/better_fastlio2_amd/lib/ab/liblio_hip_oldkey.so; else unset LIO_HIP_LIBRARY; fi
+( cd /tmp && export TMPDIR=/tmp && LIO_BENCH_LONG_STEPS=0 timeout 500 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$v -- python $R/bench.py --steps 16 --warmup 2 --no-cpu-baseline --long-steps 0 --other-configs "" --no-loop-body --emulate-world 0 > $O/trace_$v.log 2> $O/trace_$v.err )
+python scripts/node_loop_timeline.py $O/trace_$v $O/node_loop_timeline_$v.txt | tail -16
+find $O/trace_$v -name "*kernel_trace.csv" -delete
+done

@@ -2,10 +2,14 @@
 filter (csrc/lio_esekf.cpp), compiled for the host by tests/csrc/host_harness.cpp and compared
 with the oracle -- bit for bit where the oracle is fp-deterministic."""
 import ctypes as C
+import os
+import subprocess
 
 import numpy as np
 
 from conftest import bits_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from test_oracle_math import _planar_sets
 
 
@@ -148,3 +152,16 @@ def test_hth_from_callback_rows(host_harness):
         assert np.allclose(HTh, hx.T @ h, rtol=1e-12, atol=1e-12 * max(m, 1))
         assert np.array_equal(HTH.reshape(12, 12), HTH.reshape(12, 12).T)
     assert secs < 0.01                                          # 90 k rows: a fraction of a millisecond on one core, not 8 ms
+
+
+def test_batch_key_layout_roundtrip_and_frame_independence(tmp_path):
+    """csrc/lio_mapadd.h: the key of the map update's group sorts (a digit of middle coordinate bits on top) decodes back, keeps the
+    all-ones key for the spare coordinates, and orders a batch the same way whatever box its frame was derived from."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    exe = str(tmp_path / "key_layout_check")
+    subprocess.check_call([hipcc, "-x", "hip", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "better_fastlio2_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                           "-o", exe, os.path.join(ROOT, "tests", "csrc", "key_layout_check.cpp")])
+    assert subprocess.check_output([exe]).decode().strip() == "ok"
