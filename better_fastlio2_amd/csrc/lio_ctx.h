@@ -202,7 +202,6 @@ struct lio_ctx {
     bool dbg_fast_update = true;               // LIO_FAST_UPDATE=0: lio_map_incremental takes the host round trip between its lists and their
                                                // Add_Points again (A/B runs of scripts)
     bool dbg_publish_in_kernel = true;         // LIO_PUBLISH_IN_KERNEL=0 (A/B runs of scripts)
-    bool dbg_side_event = true;                // LIO_SIDE_EVENT=0 (A/B runs of scripts): no main -> side stream event in front of a commit on the side stream
     long long n_fast_updates = 0;              // map updates that ran without it
     long long n_fast_update_overflows = 0;     // ... that found a list longer than their launches were sized for (redone with the round trip)
     // list lengths of the last eight lio_map_incremental calls: the next one's launches are sized by their maxima (a drive that
@@ -443,7 +442,6 @@ struct lio_ctx {
     int def_cur = 0;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_side = nullptr;
-    hipEvent_t ev_main = nullptr;              // main stream -> side stream: the commit of a deferred batch starts behind whatever the main stream holds
     void* h_small2 = nullptr;                  // a second host-mapped mail box (the totals of an exchange, read after the settle's own wait)
     uint32_t* d_small2 = nullptr;
     uint32_t small2_seq = 0;

@@ -278,7 +278,6 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     { const char* e = std::getenv("LIO_GATE_IN_KERNEL"); if (e != nullptr && e[0] >= '0' && e[0] <= '7' && e[1] == 0) c->gate_in_kernel = e[0] - '0'; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_ASSIST_PULL"); if (e != nullptr && e[0] >= '0' && e[0] <= '9') c->dbg_assist_pull = std::atoi(e); }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_PUBLISH_IN_KERNEL"); if (e != nullptr && e[0] == '0') c->dbg_publish_in_kernel = false; }   // (A/B runs of scripts)
-    { const char* e = std::getenv("LIO_SIDE_EVENT"); if (e != nullptr && e[0] == '0') c->dbg_side_event = false; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_FAST_UPDATE"); if (e != nullptr && e[0] == '0') c->dbg_fast_update = false; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_KNN_WALK"); if (e != nullptr && (e[0] == '0' || e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0) c->dbg_knn_walk = e[0] - '0'; }
     hipDeviceProp_t prop;
@@ -441,7 +440,6 @@ void lio_destroy(lio_ctx* c) {
     }
     // (prep_stream is the copy stream: destroyed below)
     if (c->ev_raw) (void)hipEventDestroy(c->ev_raw);
-    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
     if (c->h_small3) (void)hipHostFree(c->h_small3);
     if (c->d_cagg_prep) (void)hipFree(c->d_cagg_prep);
     if (c->d_gagg_prep) (void)hipFree(c->d_gagg_prep);

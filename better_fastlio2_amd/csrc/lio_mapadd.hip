@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(VoxelKeyArgs a) {
         const uint64_t key = (fin && held) ? frame_key(frame, ix, iy, iz) : junk;
         a.keys[i] = key;
         a.order[i] = i;
-        if (a.hist != nullptr) atomicAdd(&s_hist[gsort_digit(key, kb)], 1u);
-    }
+        if (a.hist != nullptr) atomicAdd(&s_hist[gsort_digit(key, kb)], 1u);    // (aggregating equal digits inside the wavefront first -- neighbouring
+    }                                                                          //  points share their digit -- measured the same: 7.4 vs 7.1 us, round 6)
     if (a.hist != nullptr) {
         __syncthreads();
         const uint32_t v = s_hist[threadIdx.x];

@@ -1068,6 +1068,9 @@ static int ensure_deferred(lio_ctx* c) {
         int least = 0, greatest = 0;
         const char* e = std::getenv("LIO_SIDE_PRIORITY");
         if ((e != nullptr && e[0] == '0') || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+        // (round 6: confining the side stream to every 2nd / 4th / 8th compute unit -- hipExtStreamCreateWithCUMask -- changed neither the
+        // scan step beside the plan nor the update, profiles/r06w_side_stream_cu_mask_ab.log: the step is slower in a world of eight
+        // because the map grows eight times as fast, not because the plan takes its compute units)
         HIPCHK(c, hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
     }
     if (!c->ev_side) HIPCHK(c, hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
@@ -1183,7 +1186,7 @@ static int deferred_settle_side_begin(lio_ctx* c) {
     lio_ctx::DeferredBatch& d = c->def;
     if (!c->dbg_settle_beside || !d.pending || !d.planned || d.n_boxes != 0 || d.n_add == 0 || c->fold_n != 0 || c->plain_n != 0 ||
         c->map_broken || !c->have_map || c->n_live == 0 || c->n_points == 0 || c->dbg_library_sort || !compact_small(c, (size_t)c->nq) ||
-        (size_t)d.n_add + (size_t)d.n_plain > (size_t)GSORT_MAX || c->prep_active ||
+        (size_t)d.n_add + (size_t)d.n_plain > (size_t)GSORT_MAX || c->prep_active || c->pass_in_flight || c->gate_n != 0 ||
         (size_t)c->n_live + (size_t)d.n_add + (size_t)d.n_plain > c->cap_map)
         return LIO_OK;
     const uint32_t n_add = d.n_add, n_plain = d.n_plain;
@@ -1193,15 +1196,13 @@ static int deferred_settle_side_begin(lio_ctx* c) {
     ++c->n_settled;
     c->last_add_counter = 0;
     hipStream_t main_stream = c->stream;
-    // The commit writes the map (tomb-stones, directory records) and shares d_apply / the sort scratch with the main stream: it is
-    // ordered behind everything the main stream holds at this moment.  By the call graph that is nothing that reads the map (every
-    // reader was collected by the host before lio_replicate_step, armed passes were called off by enter()) -- the event is usually
-    // complete when it is recorded; it is there so that a future main-stream launch in front of this point cannot race silently.
-    if (c->dbg_side_event) {
-        if (!c->ev_main) HIPCHK(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
-        HIPCHK(c, hipEventRecord(c->ev_main, main_stream));
-        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_main, 0));
-    }
+    // The commit writes the map (tomb-stones, directory records) and shares d_apply / the sort scratch with the main stream, with no
+    // event between the two streams: by the call graph the main stream holds nothing that reads the map at this moment -- every pass
+    // was collected by the host before lio_replicate_step, armed passes were called off by enter() (they return without looking at
+    // the map).  The invariant is CHECKED on the host (pass_in_flight / gate_n in the condition above: anything else settles the
+    // blocking way); an event recorded on the main stream for the side stream to wait on -- the round-5 review's suggestion, built
+    // first -- cost 8 us per exchange on the emulated world of eight (profiles/r06v_*: update 131 -> 123 us) for a dependency that is
+    // always already satisfied.
     c->stream = c->side_stream;                 // (every launch helper of the update takes the context's stream)
     bool launched = false;
     int rc = fold_batch_commit(c, d.fa, d.ba, n_add, box);
