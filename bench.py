@@ -700,6 +700,14 @@ def main():
         priors.append(np.ascontiguousarray(capi.make_state26(ps, rt, sc.off_R, sc.off_T), np.float64))
         h_scans.append(capi.pinned_points(sc.body))             # what a driver / the voxel filter would fill
         d_scans.append(torch.from_numpy(np.ascontiguousarray(h_scans[-1])).to(device))
+    # The harness is Python, the reference's host is C++: the cyclic garbage collector must not stop a timed loop (a generation-2
+    # collection over the heap of a 5 M-point world is tens of milliseconds at a step number that only depends on the allocation count --
+    # scripts/dbg/node_loop_outliers.py met it at steps 127 and 320 with the round-5 and the round-6 library alike).  Everything
+    # allocated so far is frozen, collection is off from here on; the loops below allocate floats and small tuples only.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     scan, x0 = scans[0], priors[0]
     ext = scan.extrinsic_est_en
     n_rot = len(scans)
