@@ -16,6 +16,9 @@ def bits_equal(a, b):
     return a.shape == b.shape and np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
 
 
+FAST = [0, 0]
+
+
 def run_case(seed):
     rng = np.random.default_rng(seed)
     w = synth.make_world(int(rng.choice([120_000, 200_000])), 0.2, seed=seed)
@@ -31,6 +34,11 @@ def run_case(seed):
     cell = float(rng.choice([0.0, 0.0, 0.0, 0.25, 0.5, 1.0, 2.0]))              # 0 = auto (0.5 m for the 0.2 m voxel)
     ctx = capi.LioContext(ds, max_scan_points=nq, max_map_points=600_000, lanes_per_query=lanes, cell_size=cell)
     ctx.map_build(base)
+    # round 6: a TWIN context that calls map_incremental the way the node does (no lists wanted): from its second scan on the whole
+    # map update runs without a host round trip (lio_update.hip: BatchDesc, launches sized by the previous lists; every case ends up
+    # overflowing or not by its own inserts).  Same inputs => the same counts and, point for point in order, the same map.
+    twin = capi.LioContext(ds, max_scan_points=nq, max_map_points=600_000, lanes_per_query=lanes, cell_size=cell)
+    twin.map_build(base)
     ref = po.RefIkdTree(ds); ref.build(base); po.use_reference_knn(ref)
     om = po.OracleMap(ds)                                        # only carries parameters: k-NN goes to the reference tree
     fov = po.FovSegment()
@@ -45,6 +53,8 @@ def run_case(seed):
             lid = np.asarray(sc.pos, np.float64) + off
             boxes_o = fov.step(lid, 60.0, 12.0)
             boxes_g, nd_g = ctx.fov_segment(lid, 60.0, 12.0)
+            boxes_t, nd_t = twin.fov_segment(lid, 60.0, 12.0)
+            assert bits_equal(boxes_t, boxes_g) and nd_t == nd_g, (seed, k, "twin: fov")
             assert boxes_g.shape == boxes_o.shape and bits_equal(boxes_g, boxes_o), (seed, k, "fov boxes")
             nd_o = ref.delete_boxes(boxes_o) if len(boxes_o) else 0
             assert nd_g == nd_o, (seed, k, "fov delete count", nd_g, nd_o)
@@ -70,8 +80,18 @@ def run_case(seed):
             ref.quiesce(30)
             assert r["add_counter"] == c1, (seed, k, "Add_Points counter", r["add_counter"], c1)
             assert ctx.map_validnum() == ref.validnum(), (seed, k, "validnum", ctx.map_validnum(), ref.validnum())
+            kt = capi.Esekf(3); kt.change_x(x0); kt.change_P(synth.init_cov())
+            twin.scan_set(sc.body)
+            kt.update_iterated_dyn_share_modified(twin, 0.001, ext)
+            assert bits_equal(kt.get_x(), kf.get_x()), (seed, k, "twin: posterior")
+            rt = twin.map_incremental(xo[:14], ds, True, apply=True, want_lists=False)
+            assert (rt["n_add"], rt["n_nodown"], rt["add_counter"]) == (r["n_add"], r["n_nodown"], r["add_counter"]), (seed, k, "twin: counts", rt, r["n_add"], r["n_nodown"], r["add_counter"])
+            assert twin.map_validnum() == ctx.map_validnum(), (seed, k, "twin: validnum")
+            assert bits_equal(twin.map_flatten(), ctx.map_flatten()), (seed, k, "twin: the maps differ")
     finally:
         po.use_reference_knn(None)
+        FAST[0] += twin.debug_get("fast_updates"); FAST[1] += twin.debug_get("fast_update_overflows")
+        twin.close()
         ctx.close()
 
 
@@ -80,4 +100,4 @@ if __name__ == "__main__":
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 7000
     for seed in range(s0, s0 + n):
         run_case(seed)
-    print("FUZZ LOOP OK: %d cases" % n, flush=True)
+    print("FUZZ LOOP OK: %d cases; the twin's map updates without a host round trip: %d (+ %d redone after a list outgrew its launches)" % (n, FAST[0], FAST[1]), flush=True)
