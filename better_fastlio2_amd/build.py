@@ -20,7 +20,7 @@ OBJ = os.path.join(PKG, "lib", "obj")
 LIB = os.path.join(PKG, "lib", "liblio_hip.so")
 ARCH = "gfx950"
 
-SOURCES = ["lio_knn.hip", "lio_measure.hip", "lio_map.hip", "lio_mapadd.hip", "lio_scanprep.hip", "lio_sort.hip", "lio_compact.hip", "lio_gsort.hip", "lio_replicate.hip", "lio_ctx.hip", "lio_update.hip", "lio_scan.hip", "lio_pull.hip", "lio_pass.hip", "lio_capi_eskf.hip",
+SOURCES = ["lio_knn.hip", "lio_measure.hip", "lio_map.hip", "lio_mapadd.hip", "lio_scanprep.hip", "lio_sort.hip", "lio_rebuild.hip", "lio_compact.hip", "lio_gsort.hip", "lio_replicate.hip", "lio_ctx.hip", "lio_update.hip", "lio_scan.hip", "lio_pull.hip", "lio_pass.hip", "lio_capi_eskf.hip",
            "lio_esekf.cpp", "lio_imu.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result", "-I", CSRC, "-I", os.path.join(ROOT, "include")]

@@ -30,6 +30,7 @@
 #include "lio_imu.hpp"
 #include "lio_kernels.h"
 #include "lio_mapadd.h"
+#include "lio_rebuild.h"
 #include "lio_scanprep.h"
 
 using namespace lio;
@@ -158,6 +159,8 @@ struct lio_ctx {
     size_t child_blocks_cap = 0;
     uint32_t n_child_blocks = 0;               // blocks handed out (host view; the device bump counter is d_apply[9])
     uint32_t* d_rank = nullptr;                // iota scratch of the index build
+    uint32_t* d_level_parts = nullptr;         // [PLACE_WORKGROUPS][TREE_MAX_LEVELS] partial counts of the rebuild by cell runs (lio_rebuild.h)
+    bool rebuild_by_cells = true;              // LIO_REBUILD_BY_CELLS=0 (A/B runs of scripts) or lio_debug_set("library_sort"): the point sort
     void* d_temp = nullptr;
     size_t temp_bytes = 0;
     uint32_t* d_counters = nullptr;            // [0] n_unresolved, [2..3] delete / build scratch, [4] run counts, [7] removed points, [16] walked queries of a search pass

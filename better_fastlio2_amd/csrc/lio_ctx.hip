@@ -263,6 +263,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipSetDevice(c->device));
     { const char* e = std::getenv("LIO_TRACE_REBUILDS"); c->trace_rebuilds = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_TRACE_HOST"); c->trace_host = e != nullptr && e[0] == '1'; }
+    { const char* e = std::getenv("LIO_REBUILD_BY_CELLS"); if (e != nullptr && e[0] == '0') c->rebuild_by_cells = false; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_PRE_ENQUEUE"); if (e != nullptr && e[0] == '0') c->dbg_pre_enqueue = 0; }   // (A/B runs of scripts)
     // Environments in which a launch call returns only when its kernel has ended (HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL: debugging
     // aids of the runtime): a pass put on the stream AHEAD of its pose would wait for a word the host can only write after the launch
@@ -336,6 +337,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->d_cell_counts, nm * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_cell_starts, nm * sizeof(uint32_t)));
     CREATE_CHK(hipMalloc((void**)&c->d_rank, nm * sizeof(uint32_t)));
+    CREATE_CHK(hipMalloc((void**)&c->d_level_parts, (size_t)PLACE_WORKGROUPS * TREE_MAX_LEVELS * sizeof(uint32_t)));
     size_t tb = sort_pairs_temp_bytes(nm);
     size_t t2 = rle_temp_bytes(nm); if (t2 > tb) tb = t2;
     t2 = scan_temp_bytes(nm); if (t2 > tb) tb = t2;
@@ -412,7 +414,7 @@ void lio_destroy(lio_ctx* c) {
     if (c->gate_n > 0) gate_call_off(c);                       // (a pass armed across a scan boundary may still wait for its pose)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_pts, c->d_pts_tmp, c->d_mkeys, c->d_mkeys_tmp, c->d_vals, c->d_vals_tmp, c->d_cell_keys,
-                   c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_gs_part, c->d_gs_part2, c->d_porder, c->d_porder2, c->d_pnewoff, c->d_plan, c->d_ghist, c->d_gagg, c->d_apply, c->d_temp, c->d_counters, c->d_cagg, c->d_cand, c->d_boxes,
+                   c->d_cell_counts, c->d_cell_starts, c->d_rank, c->d_level_parts, c->d_child, c->d_ltable, c->d_pend, c->d_pkeys, c->d_pkeys2, c->d_gs_part, c->d_gs_part2, c->d_porder, c->d_porder2, c->d_pnewoff, c->d_plan, c->d_ghist, c->d_gagg, c->d_apply, c->d_temp, c->d_counters, c->d_cagg, c->d_cand, c->d_boxes,
                    c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_useeds, c->d_lunits, c->d_rows, c->d_rows_c,
                    c->d_units, c->d_gunits, c->d_knn_stamps, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, c->d_qs_useeds,
                    c->d_raw, c->d_raw_back, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,

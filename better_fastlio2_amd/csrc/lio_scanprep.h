@@ -33,8 +33,9 @@ constexpr uint32_t VOX_EMPTY = 1u, VOX_OVERFLOW = 2u;
 hipError_t launch_scan_pull(const void* src_device_alias, int stride_bytes, int n, float4* dst, hipStream_t s);
 // key[i] = order-preserving image of pts[i].w (time offset), order[i] = i
 hipError_t launch_time_keys(const float4* pts, int n, uint64_t* keys, uint32_t* order, hipStream_t s);
+// parts (optional): [ceil(n / 256)][8] the extremes of every workgroup's compensated points + its time-order flag (lio_scanprep.hip)
 hipError_t launch_undistort(const float4* raw, int n, const double* poses, int n_poses, const Pose14& end, float4* out,
-                            hipStream_t s);
+                            hipStream_t s, uint32_t* parts = nullptr);
 // getMinMax3D and, by the last workgroup to arrive, min_b_ / divb_mul_ / the width of the leaf index (vox->g, flags, probe[1]);
 // check_time_order: also sets vox->probe[0] when some point's time key is below its predecessor's
 hipError_t launch_minmax_params(const float4* pts, int n, VoxelGridDev* vox, float inv_leaf, bool check_time_order, hipStream_t s);
@@ -42,7 +43,10 @@ hipError_t launch_voxel_index(const float4* pts, int n, const VoxelGridDev* vox,
                               hipStream_t s);
 // the compact form for clouds already in time order: key = leaf index (< 2^leaf_bits; non-finite points: 2^leaf_bits - 1, beyond
 // every leaf), digit histograms of the keys into vox->hist; a stable sort by this key is the sort by (leaf, time, input order)
-hipError_t launch_voxel_index_compact(const float4* pts, int n, VoxelGridDev* vox, uint64_t* keys, hipStream_t s);
+// parts / n_parts (optional): launch_undistort's records of this cloud -- no launch_minmax_params ran, the kernel folds them and derives
+// the grid itself (vox->g, flags, probe as launch_minmax_params leaves them)
+hipError_t launch_voxel_index_compact(const float4* pts, int n, VoxelGridDev* vox, uint64_t* keys, hipStream_t s, const uint32_t* parts = nullptr,
+                                      uint32_t n_parts = 0, float inv_leaf = 0.0f, bool check_time_order = false);
 // centroids of the runs [leaf_start[l], leaf_start[l + 1]) of the leaf-sorted order, written to out[l] (l < cap_out);
 // launched for at most max_leaves runs, the run count is read from vox->n_leaves
 // zero_for_next_call: another record, cleared here for the next call (no memset launch in front of it);

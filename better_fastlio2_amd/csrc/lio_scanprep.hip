@@ -24,12 +24,18 @@ __device__ __forceinline__ void mat3_mul(const double a[9], const double b[9], d
         for (int j = 0; j < 3; ++j) r[i * 3 + j] = (a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j]) + a[i * 3 + 2] * b[6 + j];
 }
 
+__device__ __forceinline__ int float_ordered(float f);
+__device__ __forceinline__ uint32_t float_ordered_u(float f);
+// parts (optional): [workgroup][8] = getMinMax3D of the workgroup's compensated points as order images (~min x, y, z, max x, y, z;
+// 0 = no finite point), [6] = 1 when one of its points is earlier than its predecessor in the sweep -- what minmax_kernel would
+// otherwise read the cloud again for (the voxel filter's key kernel folds the workgroups' words, voxel_index_compact_kernel)
 __global__ __launch_bounds__(256) void undistort_kernel(const float4* raw, int n, const double* poses, int n_poses,
-                                                        Pose14 end, float4* out) {
+                                                        Pose14 end, float4* out, uint32_t* parts) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = raw[i];
+    const bool valid = i < n;
+    const float4 p = valid ? raw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 o = p;
+    if (valid) {
     const double t = (double)p.w / double(1000);                       // curvature holds the offset in ms (:351)
     // the IMU interval whose head precedes the point: largest k <= K-2 with poses[k].offset_time < t
     int k = -1;
@@ -74,6 +80,29 @@ __global__ __launch_bounds__(256) void undistort_kernel(const float4* raw, int n
         o.x = (float)c.x; o.y = (float)c.y; o.z = (float)c.z;
     }
     out[i] = o;
+    }
+    if (parts == nullptr) return;
+    __shared__ uint32_t s_mm[4][7];
+    uint32_t m[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (valid) {
+        if (i > 0 && float_ordered_u(p.w) < float_ordered_u(raw[i - 1].w)) m[6] = 1u;
+        if (isfinite(o.x) && isfinite(o.y) && isfinite(o.z)) {
+            const uint32_t v[3] = {float_ordered_u(o.x), float_ordered_u(o.y), float_ordered_u(o.z)};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { m[a] = ~v[a]; m[3 + a] = v[a]; }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) m[a] = max(m[a], (uint32_t)__shfl_xor((int)m[a], sh, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 7; ++a) s_mm[threadIdx.x >> 6][a] = m[a];
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) parts[(size_t)blockIdx.x * 8u + threadIdx.x] = max(max(s_mm[0][threadIdx.x], s_mm[1][threadIdx.x]), max(s_mm[2][threadIdx.x], s_mm[3][threadIdx.x]));
 }
 
 // ---- voxel grid ------------------------------------------------------------------------------------
@@ -147,10 +176,9 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float4* pts, int n, V
 }
 
 // min_b_, div_b_, divb_mul_ from the bounding box (voxel_grid.hpp, first pass), on the device: one lane
-__device__ void voxel_params(VoxelGridDev* vox, const uint32_t mm[6], float inv_leaf) {
-    VoxelGridParams g;
+__device__ void voxel_params_of(const uint32_t mm[6], float inv_leaf, VoxelGridParams& g, uint32_t& flags, uint32_t& bits) {
     g.inv_leaf = inv_leaf;
-    uint32_t flags = 0u;
+    flags = 0u;
     if (mm[0] == 0u) flags |= VOX_EMPTY;                                // no finite point
     long long div[3] = {1, 1, 1};
     for (int a = 0; a < 3; ++a) {
@@ -161,14 +189,19 @@ __device__ void voxel_params(VoxelGridDev* vox, const uint32_t mm[6], float inv_
     }
     if (!(flags & VOX_EMPTY) && div[0] * div[1] * div[2] > (long long)0x7fffffff) flags |= VOX_OVERFLOW;
     g.divb_mul[0] = 1; g.divb_mul[1] = (int)div[0]; g.divb_mul[2] = (int)(div[0] * div[1]);
-    vox->g = g;
-    vox->flags = flags;
     // bits of a leaf index: 2^bits > number of leaves, so that 2^bits - 1 lies beyond every leaf (the key of the dropped points)
-    uint32_t bits = 1u;
+    bits = 1u;
     if (flags == 0u) {
         const unsigned long long leaves = (unsigned long long)(div[0] * div[1] * div[2]);
         while ((1ull << bits) <= leaves) ++bits;
     }
+}
+__device__ void voxel_params(VoxelGridDev* vox, const uint32_t mm[6], float inv_leaf) {
+    VoxelGridParams g;
+    uint32_t flags, bits;
+    voxel_params_of(mm, inv_leaf, g, flags, bits);
+    vox->g = g;
+    vox->flags = flags;
     vox->probe[1] = bits;
 }
 
@@ -196,12 +229,50 @@ __global__ __launch_bounds__(256) void voxel_index_kernel(const float4* pts, int
 
 // The compact form of the key for a cloud that already is in time order: the leaf index alone (stability supplies the rest).
 // Every workgroup adds its share to the histograms of the four 8-bit digits of the key (LDS first, one atomic per non-empty bin).
-__global__ __launch_bounds__(256) void voxel_index_compact_kernel(const float4* pts, int n, VoxelGridDev* vox, uint64_t* keys) {
+// parts (optional; undistort_kernel's per-workgroup extremes): no minmax_kernel ran -- every workgroup folds the n_parts records
+// itself (a few KB out of the L2) and derives the grid; workgroup 0 leaves it in `vox` for the kernels behind this one
+__global__ __launch_bounds__(256) void voxel_index_compact_kernel(const float4* pts, int n, VoxelGridDev* vox, uint64_t* keys, const uint32_t* parts,
+                                                                  uint32_t n_parts, float inv_leaf, bool check_time_order) {
     __shared__ uint32_t s_hist[4][256];
+    __shared__ uint32_t s_mm[4][7];
+    __shared__ VoxelGridParams s_g;
+    __shared__ uint32_t s_bits;
     for (int x = threadIdx.x; x < 4 * 256; x += 256) (&s_hist[0][0])[x] = 0u;
+    if (parts != nullptr) {
+        uint32_t m[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        for (uint32_t q = threadIdx.x; q < n_parts; q += 256u) {
+#pragma unroll
+            for (int a = 0; a < 7; ++a) m[a] = max(m[a], parts[(size_t)q * 8u + a]);
+        }
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) m[a] = max(m[a], (uint32_t)__shfl_xor((int)m[a], sh, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int a = 0; a < 7; ++a) s_mm[threadIdx.x >> 6][a] = m[a];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t all[7];
+#pragma unroll
+            for (int a = 0; a < 7; ++a) all[a] = max(max(s_mm[0][a], s_mm[1][a]), max(s_mm[2][a], s_mm[3][a]));
+            VoxelGridParams g0;
+            uint32_t flags, bits0;
+            voxel_params_of(all, inv_leaf, g0, flags, bits0);
+            s_g = g0; s_bits = bits0;
+            if (blockIdx.x == 0) {
+                vox->g = g0; vox->flags = flags; vox->probe[1] = bits0;
+                if (check_time_order && all[6] != 0u) vox->probe[0] = 1u;
+            }
+        }
+    } else if (threadIdx.x == 0) {
+        s_g = vox->g; s_bits = vox->probe[1];
+    }
     __syncthreads();
-    const VoxelGridParams g = vox->g;
-    const uint32_t bits = vox->probe[1];
+    const VoxelGridParams g = s_g;
+    const uint32_t bits = s_bits;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float4 p = pts[i];
         uint32_t key = bits >= 32u ? 0xffffffffu : (1u << bits) - 1u;   // non-finite points sort last and are dropped
@@ -314,9 +385,9 @@ hipError_t launch_scan_pull(const void* src_device_alias, int stride_bytes, int 
     return hipGetLastError();
 }
 hipError_t launch_undistort(const float4* raw, int n, const double* poses, int n_poses, const Pose14& end, float4* out,
-                            hipStream_t s) {
+                            hipStream_t s, uint32_t* parts) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(undistort_kernel, dim3((n + 255) / 256), dim3(256), 0, s, raw, n, poses, n_poses, end, out);
+    hipLaunchKernelGGL(undistort_kernel, dim3((n + 255) / 256), dim3(256), 0, s, raw, n, poses, n_poses, end, out, parts);
     return hipGetLastError();
 }
 hipError_t launch_minmax_params(const float4* pts, int n, VoxelGridDev* vox, float inv_leaf, bool check_time_order, hipStream_t s) {
@@ -326,11 +397,12 @@ hipError_t launch_minmax_params(const float4* pts, int n, VoxelGridDev* vox, flo
     hipLaunchKernelGGL(minmax_kernel, dim3(b), dim3(256), 0, s, pts, n, vox, inv_leaf, check_time_order);
     return hipGetLastError();
 }
-hipError_t launch_voxel_index_compact(const float4* pts, int n, VoxelGridDev* vox, uint64_t* keys, hipStream_t s) {
+hipError_t launch_voxel_index_compact(const float4* pts, int n, VoxelGridDev* vox, uint64_t* keys, hipStream_t s, const uint32_t* parts, uint32_t n_parts,
+                                      float inv_leaf, bool check_time_order) {
     if (n <= 0) return hipSuccess;
     int b = (n + 1023) / 1024;                 // four points per lane: fewer, fuller histogram flushes
     if (b > 256) b = 256;                      // (64 workgroups, eight points per lane: 8.5 us instead of 7.3)
-    hipLaunchKernelGGL(voxel_index_compact_kernel, dim3(b), dim3(256), 0, s, pts, n, vox, keys);
+    hipLaunchKernelGGL(voxel_index_compact_kernel, dim3(b), dim3(256), 0, s, pts, n, vox, keys, parts, n_parts, inv_leaf, check_time_order);
     return hipGetLastError();
 }
 hipError_t launch_voxel_index(const float4* pts, int n, const VoxelGridDev* vox, bool time_minor, uint64_t* keys, uint32_t* order,

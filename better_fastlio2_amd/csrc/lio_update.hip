@@ -26,21 +26,19 @@ static void box_of_host_points(HostBox& box, const float* pts, size_t n, int str
     }
 }
 
-// Second half of every (re)build: c->d_pts[0..n) is Morton-sorted and live, c->d_mkeys[0..n) holds the
-// keys.  Run-length encode the cells, derive the coarser tree levels (hash tables), fill the child blocks of the
-// cell directory.
-int finish_index(lio_ctx* c, uint32_t n) {
+// Last part of every (re)build: c->d_pts[0..n) is Morton-sorted and live, c->d_cell_keys / d_cell_counts [0..n_cells) hold
+// the Morton code and the number of points of every occupied grid cell, in order.  Derive the coarser tree levels (hash
+// tables), fill the child blocks of the cell directory.  level_cells (optional): the number of cells of every level, already
+// known to the host (the rebuild by cell runs counts them on the way) -- nothing is read back between the levels then.
+static int finish_index_levels(lio_ctx* c, uint32_t n, uint32_t n_cells, const uint32_t* level_cells) {
     hipStream_t s = c->stream;
     c->n_points = n; c->n_live = n; c->n_cells = 0;
     c->n_retired = 0; c->n_dead = 0; c->n_new_cells = 0; c->n_cells_built = 0;
     c->grid.n_points = n;
     HIPCHK(c, hipMemsetAsync(c->d_apply + APPLY_LEVEL_NEW, 0, TREE_MAX_LEVELS * sizeof(uint32_t), s));
-    HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_mkeys, n, c->d_cell_keys, c->d_cell_counts,
-                                    c->d_counters + 4, s));
-    uint32_t n_cells = 0;
-    HIPCHK(c, read_back(c, &n_cells, c->d_counters + 4, sizeof(uint32_t)));
     HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_cell_counts, c->d_cell_starts, n_cells, s));
     c->n_cells = n_cells; c->n_cells_built = n_cells;
+    bool drained = false;                      // the last thing this function did was wait for the stream
 
     // ---- coarser levels of the hashed 64-ary tree (exact fallback of the k-NN): level L+1 is a
     // reduce-by-key of level L (keys >> 6, counts summed) -- the point array is not touched again
@@ -55,7 +53,8 @@ int finish_index(lio_ctx* c, uint32_t n) {
     for (int L = 1; L < TREE_MAX_LEVELS; ++L) {
         HIPCHK(c, coarsen_level(c->d_temp, c->temp_bytes, kin, cin, n_prev, kout, cout, c->d_counters + 4, s));
         uint32_t n_l = 0;
-        HIPCHK(c, read_back(c, &n_l, c->d_counters + 4, sizeof(uint32_t)));
+        if (level_cells != nullptr) n_l = level_cells[L];
+        else HIPCHK(c, read_back(c, &n_l, c->d_counters + 4, sizeof(uint32_t)));
         if (L >= 2 && n_l <= (uint32_t)TREE_MAX_ROOTS) {
             // root keys through the host-mapped counter block (a copy into pageable memory may be completed by the
             // runtime after the stream is seen idle): at most TREE_MAX_ROOTS x 8 bytes = 2 x 128 bytes
@@ -68,6 +67,7 @@ int finish_index(lio_ctx* c, uint32_t n) {
             for (uint32_t i = 0; i < n_l; ++i) {
                 lv.root_x[i] = compact21(rk[i] >> 2); lv.root_y[i] = compact21(rk[i] >> 1); lv.root_z[i] = compact21(rk[i]);
             }
+            drained = n_l != 0u;
             break;
         }
         size_t sl = 64;
@@ -114,14 +114,79 @@ int finish_index(lio_ctx* c, uint32_t n) {
         if (kout == c->d_mkeys_tmp) { kin = c->d_mkeys_tmp; cin = c->d_vals_tmp; kout = c->d_cell_keys; cout = c->d_cell_counts; }
         else { kin = c->d_cell_keys; cin = c->d_cell_counts; kout = c->d_mkeys_tmp; cout = c->d_vals_tmp; }
     }
-    HIPCHK(c, stream_wait(c));
+    if (!drained) HIPCHK(c, stream_wait(c));
     c->levels = lv;
     c->have_map = true; c->map_broken = false;
     ++c->n_full_rebuilds;
     return LIO_OK;
 }
+// ... behind the POINT sort (c->d_mkeys[0..n): the sorted keys): the cells are the runs of equal keys
+int finish_index(lio_ctx* c, uint32_t n) {
+    HIPCHK(c, run_length_encode_u64(c->d_temp, c->temp_bytes, c->d_mkeys, n, c->d_cell_keys, c->d_cell_counts, c->d_counters + 4, c->stream));
+    uint32_t n_cells = 0;
+    HIPCHK(c, read_back(c, &n_cells, c->d_counters + 4, sizeof(uint32_t)));
+    return finish_index_levels(c, n, n_cells, nullptr);
+}
 
-// (re)build the index from n points at src (device, float4, must not alias c->d_pts): full sort
+// the POINT sort (points in no order; lio_debug_set "library_sort", LIO_REBUILD_BY_CELLS=0): Morton code per point, 63-bit radix sort, gather
+static int build_index_by_points(lio_ctx* c, const float4* src, uint32_t n) {
+    hipStream_t s = c->stream;
+    HIPCHK(c, launch_point_keys(src, n, c->grid, c->d_mkeys_tmp, c->d_vals_tmp, s));
+    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_mkeys_tmp, c->d_mkeys, c->d_vals_tmp, c->d_vals, n, s));
+    HIPCHK(c, launch_gather_points(src, c->d_vals, n, c->d_pts, s));
+    return finish_index(c, n);
+}
+
+// (Re)build by CELL RUNS (lio_rebuild.h): the n points at src are a sequence of runs of equal grid cells -- the buckets of the old
+// index in array order, then the pending points -- and only the runs are sorted, by a compressed key.  Two waits on the way (the
+// number of runs with the cells' bounding box; the cells per level), one at the end (the roots).  Same d_pts, cell table and
+// tree as the point sort, bit for bit (tests/test_gpu_parity.py::test_rebuild_by_cell_runs_equals_the_point_sort).
+static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n) {
+    hipStream_t s = c->stream;
+    const uint32_t n_tiles = (n + RUN_TILE - 1u) / RUN_TILE;
+    uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(c->d_temp);                 // (the sort workspace is idle until sort_runs)
+    uint32_t* tile_off = tile_cnt + (n_tiles + 4u);
+    uint32_t* tile_box = tile_off + (n_tiles + 4u);
+    uint64_t* run_key = c->d_mkeys_tmp;        // Morton code per run -> compressed key (sort input) -> Morton code per SORTED run
+    uint64_t* sorted_key = c->d_mkeys;
+    uint32_t* run_start = c->d_vals_tmp;       // [n] at most (before the number of runs is known)
+    // (first point, points) per run, in and out of the sort: 8 bytes per run in the 4-byte-per-point arrays -- at most n / 2 runs get here
+    uint64_t* run_val = reinterpret_cast<uint64_t*>(c->d_vals);
+    uint64_t* sorted_val = reinterpret_cast<uint64_t*>(c->d_rank);
+    uint32_t* dst_start = c->d_cell_starts;    // (the scan of the cell counts overwrites it later)
+    HIPCHK(c, launch_cell_runs_count(src, n, c->grid, tile_cnt, tile_box, s));
+    HIPCHK(c, launch_exclusive_scan(tile_cnt, n_tiles + 1u, tile_off, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+    HIPCHK(c, launch_cell_runs_emit(src, n, c->grid, tile_off, run_key, run_start, c->d_counters + 4, s));
+    uint32_t seq = ++c->small_seq;
+    HIPCHK(c, launch_cell_box_publish(tile_box, n_tiles, c->d_counters + 4, c->d_small, seq, s));
+    HIPCHK(c, wait_published(c, seq));
+    uint32_t w[7];
+    std::memcpy(w, c->h_small, sizeof(w));
+    const uint32_t n_runs = w[0];
+    if (n_runs == 0u || n_runs > n) return c->fail(LIO_ERR_HIP, "index rebuild", "the run kernels left an impossible number of cell runs");
+    // points in no particular order (a Build from the caller's cloud): as many runs as points, the run sort would only add to the work
+    if ((size_t)n_runs * 2u > (size_t)n) return build_index_by_points(c, src, n);
+    const CellKeyFrame f = cell_key_frame(w + 1, w + 4);
+    HIPCHK(c, launch_compress_run_keys(run_key, run_start, n_runs, n, f, run_val, c->d_apply + 15, s));
+    HIPCHK(c, sort_runs(c->d_temp, c->temp_bytes, run_key, sorted_key, run_val, sorted_val, n_runs, f.bits, s));
+    HIPCHK(c, scan_run_lengths(c->d_temp, c->temp_bytes, sorted_val, n_runs, dst_start, s));
+    HIPCHK(c, launch_runs_place(src, c->d_pts, sorted_key, sorted_val, dst_start, n_runs, f, run_key, c->d_level_parts, s));
+    HIPCHK(c, reduce_runs_to_cells(c->d_temp, c->temp_bytes, run_key, sorted_val, n_runs, c->d_cell_keys, c->d_cell_counts, c->d_counters + 4, s));
+    seq = ++c->small_seq;
+    HIPCHK(c, launch_level_counts_publish(c->d_level_parts, c->d_apply + 15, c->d_small, seq, s));
+    HIPCHK(c, wait_published(c, seq));
+    uint32_t lv[TREE_MAX_LEVELS + 1];
+    std::memcpy(lv, c->h_small, sizeof(lv));
+    if (lv[TREE_MAX_LEVELS] != 0u) {            // d_apply[15]: a bounded wait of the tile scan ran out (bit 0), a cell outside the key frame (bit 1)
+        (void)hipMemsetAsync(c->d_apply + 15, 0, sizeof(uint32_t), s);
+        return c->fail(LIO_ERR_HIP, "index rebuild", lv[TREE_MAX_LEVELS] & 2u ? "a grid cell lies outside the key frame derived from the cells' bounding box"
+                                                                              : "a bounded wait of a compaction kernel ran out");
+    }
+    if (lv[0] == 0u || lv[0] > n_runs) return c->fail(LIO_ERR_HIP, "index rebuild", "the run kernels left an impossible number of cells");
+    return finish_index_levels(c, n, lv[0], lv);
+}
+
+// (re)build the index from n points at src (device, float4, must not alias c->d_pts)
 int build_index(lio_ctx* c, const float4* src, uint32_t n) {
     hipStream_t s = c->stream;
     c->have_map = false;
@@ -137,10 +202,10 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
         c->have_map = true; c->map_broken = false;
         return LIO_OK;
     }
-    HIPCHK(c, launch_point_keys(src, n, c->grid, c->d_mkeys_tmp, c->d_vals_tmp, s));
-    HIPCHK(c, sort_pairs_u64_u32(c->d_temp, c->temp_bytes, c->d_mkeys_tmp, c->d_mkeys, c->d_vals_tmp, c->d_vals, n, s));
-    HIPCHK(c, launch_gather_points(src, c->d_vals, n, c->d_pts, s));
-    return finish_index(c, n);
+    if (c->rebuild_by_cells && !c->dbg_library_sort && (size_t)n / RUN_TILE + 2u <= COMPACT_MAX_ITEMS &&
+        ((size_t)n / RUN_TILE + 4u) * 8u * sizeof(uint32_t) <= c->temp_bytes)
+        return build_index_by_cells(c, src, n);
+    return build_index_by_points(c, src, n);
 }
 
 // box-deleted points not handed out yet -> the tail of d_removed (they stay tomb-stones in d_pts, re-marked)

@@ -918,6 +918,69 @@ def test_incremental_index_stress(gpu_capi, oracle, small_case):
     ctx.close()
 
 
+def test_rebuild_by_cell_runs_equals_the_point_sort(gpu_capi, small_case, monkeypatch):
+    """Build / reconstruct / the full rebuild of a mutated map through the sort of CELL RUNS (lio_rebuild.hip: the default) against the
+    63-bit point sort it replaces (LIO_REBUILD_BY_CELLS=0): the same point array slot for slot (flatten is order-preserving), the same
+    cell and level counts, the same neighbours for near and far queries -- after a Build of points in arbitrary order (every point
+    its own run), after a forced rebuild behind incremental updates and box deletes (buckets at the tail, tomb-stones inside
+    buckets, pending points), and with a far-away cluster in the map (a key frame with many more bits)."""
+    w = small_case["world"]
+    rng = np.random.default_rng(606)
+    base = np.ascontiguousarray(w.points[::2])
+    ctxs = []
+    for by_cells in ("1", "0"):
+        monkeypatch.setenv("LIO_REBUILD_BY_CELLS", by_cells)
+        ctxs.append(gpu_capi.LioContext(0.2, max_scan_points=4096, max_map_points=600_000))
+    monkeypatch.delenv("LIO_REBUILD_BY_CELLS")
+    lo, hi = base.min(0), base.max(0)
+    q = np.concatenate([base[rng.choice(len(base), 800, replace=False)] + rng.normal(0, 0.05, (800, 3)),
+                        rng.uniform(lo - 40.0, hi + 40.0, (400, 3))]).astype(np.float32)
+
+    def same(extra=None):
+        a, b = ctxs
+        ia, ib = a.map_info(), b.map_info()
+        for k in ("n_points", "n_live", "n_cells", "n_retired", "n_full_rebuilds"):
+            assert ia[k] == ib[k], k
+        assert bits_equal(a.map_flatten(), b.map_flatten())
+        qq = q if extra is None else np.concatenate([q, extra]).astype(np.float32)
+        (ax, ad, ac), (bx, bd, bc) = a.nearest_search(qq), b.nearest_search(qq)
+        assert np.array_equal(ac, bc) and bits_equal(ad, bd) and bits_equal(ax, bx)
+
+    for c in ctxs:
+        c.map_build(base)
+    same()
+    shuffled = base[np.random.default_rng(1).permutation(len(base))]
+    for c in ctxs:
+        c.map_reconstruct(shuffled)
+    same()
+    for k in range(4):
+        src = w.points[1::2][rng.choice(len(w.points) // 2, 3000, replace=False)]
+        batch = (src + rng.uniform(-0.02, 0.02, src.shape)).astype(np.float32)
+        c0 = np.array([rng.uniform(lo[0] + 5, hi[0] - 5), rng.uniform(lo[1] + 5, hi[1] - 5), 1.0])
+        box = np.concatenate([c0 - 3.0, c0 + 3.0]).astype(np.float32)[None]
+        for c in ctxs:
+            c.map_add(batch, True)
+            c.map_delete_boxes(box)
+    info = [c.map_info() for c in ctxs]
+    assert info[0]["n_retired"] > 0 and info[0]["n_incremental_updates"] > 0
+    for c in ctxs:
+        c.debug_set("retired_budget", 1024)
+    strip = rng.uniform([hi[0] + 1.0, lo[1], 0.0], [hi[0] + 20.0, hi[1], 6.0], (3000, 3)).astype(np.float32)
+    for c in ctxs:
+        c.map_add(strip, False)                                   # over the budget: the full rebuild takes the pending strip in
+    assert ctxs[0].map_info()["n_full_rebuilds"] == info[0]["n_full_rebuilds"] + 1 and ctxs[0].map_info()["n_retired"] == 0
+    same(strip[:200] + np.float32(0.01))
+    for c in ctxs:
+        c.debug_set("retired_budget", 0)
+    away = (rng.uniform(-3.0, 3.0, (500, 3)) + np.array([4000.0, -2500.0, 10.0])).astype(np.float32)
+    for c in ctxs:
+        c.map_add(away, False)
+        c.map_reconstruct(c.map_flatten())
+    same(away[:100] + np.float32(0.02))
+    for c in ctxs:
+        c.close()
+
+
 def test_incremental_insert_outside_tree_root(gpu_capi, oracle, small_case):
     """A map inside one octant has a small root node; a new cell outside it cannot be hung into the tree
     levels, so the update falls back to a full rebuild with a higher root -- and far queries (tree walk)

@@ -165,3 +165,16 @@ def test_batch_key_layout_roundtrip_and_frame_independence(tmp_path):
     subprocess.check_call([hipcc, "-x", "hip", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "better_fastlio2_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
                            "-o", exe, os.path.join(ROOT, "tests", "csrc", "key_layout_check.cpp")])
     assert subprocess.check_output([exe]).decode().strip() == "ok"
+
+
+def test_cell_key_frame_keeps_the_morton_order(tmp_path):
+    """csrc/lio_rebuild.h: the compressed cell keys of the rebuild by cell runs ([rank of the coarse parent | low Morton bits]) sort like
+    the absolute Morton codes, expand back to them, fit the bits the frame declares and refuse cells outside the frame."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    exe = str(tmp_path / "cell_frame_check")
+    subprocess.check_call([hipcc, "-x", "hip", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "better_fastlio2_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                           "-o", exe, os.path.join(ROOT, "tests", "csrc", "cell_frame_check.cpp")])
+    assert subprocess.check_output([exe]).decode().strip() == "ok 400 frames"
