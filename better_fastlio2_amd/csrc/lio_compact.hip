@@ -14,63 +14,11 @@
 #include "lio_mapadd.h"
 #include "lio_incr.h"
 #include "lio_bbox.h"
+#include "lio_tile.h"
 
 namespace lio {
 
 typedef unsigned long long u64;
-constexpr unsigned COMPACT_SPIN_LIMIT = 1u << 22;
-
-// exclusive prefix of `mine` over the tiles before this one (K independent streams), the tile's own count published
-// first.  All 256 threads call it; returns false when a wait ran out.
-template <int K>
-__device__ __forceinline__ bool tile_exclusive_prefix(const uint32_t (&mine)[K], u64* agg, uint32_t stamp, uint32_t (&before)[K], int tile = -1) {
-    __shared__ uint32_t s_sum[K][4];
-    __shared__ uint32_t s_bad;
-    const int tid = threadIdx.x, b = tile >= 0 ? tile : (int)blockIdx.x;
-    if (tid == 0) s_bad = 0u;
-    __syncthreads();
-    if (tid < K) __hip_atomic_store(agg + (size_t)b * K + tid, (u64)mine[tid] | ((u64)stamp << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t acc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0u;
-    bool bad = false;
-    for (int p = tid; p < b; p += 256) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            u64 v;
-            unsigned spins = 0;
-            do { v = __hip_atomic_load(agg + (size_t)p * K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            while ((uint32_t)(v >> 32) != stamp && ++spins < COMPACT_SPIN_LIMIT);
-            bad = bad || (uint32_t)(v >> 32) != stamp;
-            acc[k] += (uint32_t)v;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        uint32_t v = acc[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-        if ((tid & 63) == 0) s_sum[k][tid >> 6] = v;
-    }
-    if (bad) s_bad = 1u;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; ++k) before[k] = s_sum[k][0] + s_sum[k][1] + s_sum[k][2] + s_sum[k][3];
-    return s_bad == 0u;
-}
-
-// position of this thread's item among the flagged items of its 256-item tile (exclusive), and the tile's total
-__device__ __forceinline__ uint32_t tile_rank(bool flag, uint32_t& tile_total, uint32_t (&s_wave)[4]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 m = __ballot(flag);
-    const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t off = 0;
-    for (int w = 0; w < wave; ++w) off += s_wave[w];
-    tile_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    return off + in_wave;
-}
 
 __global__ __launch_bounds__(256) void bbox_kernel(const float4* pts, uint32_t n, uint32_t* bbox) {
     for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {     // (block-uniform: every lane reaches the barriers)

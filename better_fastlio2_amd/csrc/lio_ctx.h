@@ -381,6 +381,9 @@ struct lio_ctx {
     uint64_t *d_raw_keys = nullptr, *d_raw_keys2 = nullptr, *d_leaf_keys = nullptr;
     uint32_t *d_raw_order = nullptr, *d_raw_order2 = nullptr, *d_leaf_count = nullptr, *d_leaf_start = nullptr;
     double* d_imu_poses = nullptr;             // up to 512 Pose6D records (22 doubles each)
+    uint32_t* d_undist_parts = nullptr;        // [ceil(cap_raw / 256)][8] extremes + time-order flag per workgroup of undistort_kernel (lio_scanprep.hip)
+    uint32_t undist_parts_n = 0;               // records that describe d_undist as it is now (0: none, the filter runs minmax_kernel)
+    bool prep_fused = true;                    // LIO_PREP_FUSED=0 (A/B runs of scripts): minmax / run heads as launches of their own
     VoxelGridDev* d_vox = nullptr;             // two records, used alternately: the centroid kernel of a call clears the other one
     int vox_cur = 0;
     bool vox_clean[2] = {false, false};

@@ -263,6 +263,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     CREATE_CHK(hipSetDevice(c->device));
     { const char* e = std::getenv("LIO_TRACE_REBUILDS"); c->trace_rebuilds = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_TRACE_HOST"); c->trace_host = e != nullptr && e[0] == '1'; }
+    { const char* e = std::getenv("LIO_PREP_FUSED"); if (e != nullptr && e[0] == '0') c->prep_fused = false; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_REBUILD_BY_CELLS"); if (e != nullptr && e[0] == '0') c->rebuild_by_cells = false; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_PRE_ENQUEUE"); if (e != nullptr && e[0] == '0') c->dbg_pre_enqueue = 0; }   // (A/B runs of scripts)
     // Environments in which a launch call returns only when its kernel has ended (HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL: debugging
@@ -418,7 +419,7 @@ void lio_destroy(lio_ctx* c) {
                    c->d_body, c->d_body_back, c->d_world, c->d_nbr, c->d_normvec, c->d_plane, c->d_cnt, c->d_sel, c->d_ulist, c->d_useeds, c->d_lunits, c->d_rows, c->d_rows_c,
                    c->d_units, c->d_gunits, c->d_knn_stamps, c->d_removed, c->d_scratch, c->d_qs_world, c->d_qs_nbr, c->d_qs_cnt, c->d_qs_ulist, c->d_qs_useeds,
                    c->d_raw, c->d_raw_back, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
-                   c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_imu_poses, c->d_vox,
+                   c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_undist_parts, c->d_imu_poses, c->d_vox,
                    c->d_add_pts, c->d_add_pts2, c->d_add_cls, c->d_add_out, c->d_add_keys, c->d_add_keys2,
                    c->d_add_order, c->d_add_order2, c->d_add_dirty, c->d_add_dirty_pt, c->d_add_dlist, c->d_add_plan, c->d_add_ranges, c->d_add_parts,
                    c->d_rep_send, c->d_rep_recv};

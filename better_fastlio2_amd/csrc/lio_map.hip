@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void table_insert_kernel(const uint64_t* cell_
             unsigned long long* kp = reinterpret_cast<unsigned long long*>(&table[slot]);
             const unsigned long long prev = atomicCAS(kp, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
             if (prev == KEY_EMPTY || prev == key) {
-                table[slot].start = cell_start[c];
+                table[slot].start = cell_start != nullptr ? cell_start[c] : c;          // (nullptr: the entry's rank)
                 table[slot].count = cell_count[c];
                 break;
             }

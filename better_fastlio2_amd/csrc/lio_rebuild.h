@@ -14,7 +14,8 @@ namespace lio {
 
 // Compressed sort key of a grid cell.  Cell coordinates are biased by 2^20 (lio_common.h), a map around the origin
 // straddles that boundary on every axis and its Morton codes differ from bit 62 down.  But the map touches only a few
-// cells of a coarse level `a` (grid coarsened by 4^a): their Morton codes (`parent`, ascending) are listed, a cell's key is
+// cells of a coarse level `a` (grid coarsened by 4^a): a box of n[0] x n[1] x n[2] <= 64 of them from p0 on.  Their Morton
+// codes (`parent`, ascending) are listed, a cell's key is
 //      [rank of its level-a parent in that list | the low 6a bits of its own Morton code]
 // -- the same order as the absolute Morton code, in 6a + log2(parents) bits.
 constexpr int CELL_FRAME_PARENTS = 64;
@@ -22,30 +23,36 @@ struct CellKeyFrame {
     int      a;                             // parent level, 1..10
     int      n_parents;
     int      bits;                          // key bits: 6a + bits of (n_parents - 1)
-    int      pad;
-    uint64_t parent[CELL_FRAME_PARENTS];    // Morton codes >> 6a of the level-a cells of the map's bounding box, ascending
+    uint32_t p0[3], n[3];                   // the parents' box: coordinates >> 2a from p0[i], n[i] of them
+    uint32_t pad;
+    uint64_t rank_of[CELL_FRAME_PARENTS / 8];   // byte (dx * n[1] + dy) * n[2] + dz: the rank of that parent
+    uint64_t parent[CELL_FRAME_PARENTS];    // Morton codes >> 6a of the parents, ascending (unused entries: ~0)
 };
 // the frame of the cells lo..hi (inclusive, biased coordinates): the finest level whose cells of the box number <= CELL_FRAME_PARENTS
 inline CellKeyFrame cell_key_frame(const uint32_t lo[3], const uint32_t hi[3]) {
     CellKeyFrame f{};
     for (int a = 1; a <= 10; ++a) {
         uint64_t np = 1;
-        uint32_t p0[3], cnt[3];
-        for (int i = 0; i < 3; ++i) { p0[i] = lo[i] >> (2 * a); cnt[i] = (hi[i] >> (2 * a)) - p0[i] + 1u; np *= cnt[i]; }
+        for (int i = 0; i < 3; ++i) { f.p0[i] = lo[i] >> (2 * a); f.n[i] = (hi[i] >> (2 * a)) - f.p0[i] + 1u; np *= f.n[i]; }
         if (np > (uint64_t)CELL_FRAME_PARENTS && a < 10) continue;
-        if (np > (uint64_t)CELL_FRAME_PARENTS) np = CELL_FRAME_PARENTS;      // (cannot happen: 21-bit coordinates leave <= 2 parents per axis at a = 10)
-        f.a = a; f.n_parents = 0;
-        for (uint32_t x = 0; x < cnt[0]; ++x)
-            for (uint32_t y = 0; y < cnt[1]; ++y)
-                for (uint32_t z = 0; z < cnt[2]; ++z)
-                    if (f.n_parents < CELL_FRAME_PARENTS) f.parent[f.n_parents++] = morton3(p0[0] + x, p0[1] + y, p0[2] + z);
+        // (a = 10: 21-bit coordinates leave at most 2 parents per axis)
+        f.a = a; f.n_parents = (int)np;
+        uint64_t code[CELL_FRAME_PARENTS];
+        int at[CELL_FRAME_PARENTS];
+        for (uint32_t x = 0; x < f.n[0]; ++x)
+            for (uint32_t y = 0; y < f.n[1]; ++y)
+                for (uint32_t z = 0; z < f.n[2]; ++z) {
+                    const int idx = (int)((x * f.n[1] + y) * f.n[2] + z);
+                    code[idx] = morton3(f.p0[0] + x, f.p0[1] + y, f.p0[2] + z); at[idx] = idx;
+                }
         for (int i = 1; i < f.n_parents; ++i) {                               // insertion sort: <= 64 codes
-            const uint64_t v = f.parent[i];
+            const uint64_t v = code[i]; const int w = at[i];
             int j = i - 1;
-            while (j >= 0 && f.parent[j] > v) { f.parent[j + 1] = f.parent[j]; --j; }
-            f.parent[j + 1] = v;
+            while (j >= 0 && code[j] > v) { code[j + 1] = code[j]; at[j + 1] = at[j]; --j; }
+            code[j + 1] = v; at[j + 1] = w;
         }
-        for (int i = f.n_parents; i < CELL_FRAME_PARENTS; ++i) f.parent[i] = ~0ull;   // (above every code: cell_key_compress)
+        for (int r = 0; r < CELL_FRAME_PARENTS; ++r) f.parent[r] = r < f.n_parents ? code[r] : ~0ull;
+        for (int r = 0; r < f.n_parents; ++r) f.rank_of[at[r] >> 3] |= (uint64_t)r << (8 * (at[r] & 7));
         int rb = 0;
         while ((1 << rb) < f.n_parents) ++rb;
         f.bits = 6 * a + rb;
@@ -53,17 +60,18 @@ inline CellKeyFrame cell_key_frame(const uint32_t lo[3], const uint32_t hi[3]) {
     }
     return f;
 }
-// Morton code -> compressed key; *ok = false when the cell's parent is not one of the frame's.  (Fixed trip counts over the whole
-// list -- the unused entries hold ~0, above every code -- so that a kernel fetches the list from its arguments once, up front; and a
-// loop of selects, not f.parent[rank]: a per-lane index into a by-value kernel argument would send the struct to scratch.)
-LIO_HD uint64_t cell_key_compress(const CellKeyFrame& f, uint64_t mk, bool* ok) {
-    const uint64_t pm = mk >> (6 * f.a);
-    uint32_t r = 0;
-    bool found = false;
+// cell coordinates -> compressed key; *ok = false when the cell's parent is not one of the frame's.  (Selects over the words of the
+// rank table, not rank_of[i]: a per-lane index into a by-value kernel argument would send the struct to scratch.)
+LIO_HD uint64_t cell_key_compress(const CellKeyFrame& f, uint32_t cx, uint32_t cy, uint32_t cz, bool* ok) {
+    const uint32_t dx = (cx >> (2 * f.a)) - f.p0[0], dy = (cy >> (2 * f.a)) - f.p0[1], dz = (cz >> (2 * f.a)) - f.p0[2];
+    *ok = dx < f.n[0] && dy < f.n[1] && dz < f.n[2];
+    const uint32_t idx = *ok ? (dx * f.n[1] + dy) * f.n[2] + dz : 0u;
+    uint64_t w = 0;
 #pragma unroll
-    for (int i = 0; i < CELL_FRAME_PARENTS; ++i) { r += f.parent[i] < pm ? 1u : 0u; found = found || f.parent[i] == pm; }
-    *ok = found;
-    return ((uint64_t)r << (6 * f.a)) | (mk & ((1ull << (6 * f.a)) - 1ull));
+    for (int k = 0; k < CELL_FRAME_PARENTS / 8; ++k) w = (idx >> 3) == (uint32_t)k ? f.rank_of[k] : w;
+    const uint64_t r = (w >> (8u * (idx & 7u))) & 255ull;
+    const uint32_t m = (1u << (2 * f.a)) - 1u;
+    return (r << (6 * f.a)) | morton3(cx & m, cy & m, cz & m);
 }
 LIO_HD uint64_t cell_key_expand(const CellKeyFrame& f, uint64_t ck) {
     const uint32_t r = (uint32_t)(ck >> (6 * f.a));
@@ -79,11 +87,11 @@ constexpr uint32_t PLACE_WORKGROUPS = 1024;  // workgroups of runs_place_kernel 
 // runs of equal grid cells in pts[0..n): tile_cnt[n_tiles + 1] run heads per tile (the last entry: 0, the scan's total),
 // tile_box[n_tiles][6] the cells' bounding box per tile {min x, y, z, max x, y, z}
 hipError_t launch_cell_runs_count(const float4* pts, uint32_t n, Grid grid, uint32_t* tile_cnt, uint32_t* tile_box, hipStream_t s);
-// run_key[r] = Morton code of the run's cell, run_start[r] = its first point; *n_runs = tile_off[n_tiles]
-hipError_t launch_cell_runs_emit(const float4* pts, uint32_t n, Grid grid, const uint32_t* tile_off, uint64_t* run_key, uint32_t* run_start,
-                                 uint32_t* n_runs, hipStream_t s);
-// dst_mapped[0] = *n_runs, [1..6] = the box of all tiles, then `seq` at dst_mapped[32] (system scope): the host polls (wait_published)
-hipError_t launch_cell_box_publish(const uint32_t* tile_box, uint32_t n_tiles, const uint32_t* n_runs, uint32_t* dst_mapped, uint32_t seq, hipStream_t s);
+// run_key[r] = packed cell coordinates (pack_key) of the run's cell, run_start[r] = its first point (tile_off: the scanned tile_cnt)
+hipError_t launch_cell_runs_emit(const float4* pts, uint32_t n, Grid grid, const uint32_t* tile_off, uint64_t* run_key, uint32_t* run_start, hipStream_t s);
+// dst_mapped[0] = *n_runs, [1..6] = the box of all tiles, [7] = *check (optional), then `seq` at dst_mapped[32] (system scope): the host polls
+hipError_t launch_cell_box_publish(const uint32_t* tile_box, uint32_t n_tiles, const uint32_t* n_runs, const uint32_t* check, uint32_t* dst_mapped, uint32_t seq,
+                                   hipStream_t s);
 // run_key[r] -> compressed key, in place; run_val[r] = first point << 32 | points of run r; *err |= 2 when a cell lies outside the frame
 hipError_t launch_compress_run_keys(uint64_t* run_key, const uint32_t* run_start, uint32_t n_runs, uint32_t n, const CellKeyFrame& f, uint64_t* run_val,
                                     uint32_t* err, hipStream_t s);

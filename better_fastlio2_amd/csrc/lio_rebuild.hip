@@ -11,8 +11,8 @@
 
 namespace lio {
 
-// keys of a tile into LDS (s_key[RUN_TILE + 1]: entry 0 = the key of the point in front of the tile, ~0 for the first tile --
-// no Morton code has bit 63), the cell coordinates' extrema of this thread's points into lo / hi
+// keys (packed cell coordinates) of a tile into LDS (s_key[RUN_TILE + 1]: entry 0 = the key of the point in front of the tile, ~0 for
+// the first tile -- no packed key has bit 63), the cell coordinates' extrema of this thread's points into lo / hi
 __device__ __forceinline__ void tile_keys(const float4* __restrict__ pts, uint32_t n, Grid grid, uint32_t tile, uint64_t* s_key, uint32_t (&lo)[3], uint32_t (&hi)[3]) {
     const uint32_t tid = threadIdx.x, i0 = tile * RUN_TILE;
     float4 p[8];
@@ -26,7 +26,7 @@ __device__ __forceinline__ void tile_keys(const float4* __restrict__ pts, uint32
     for (uint32_t u = 0; u < 8u; ++u) {
         const uint32_t i = i0 + u * 256u + tid;
         const uint32_t c[3] = {(uint32_t)cell_coord(p[u].x, grid.inv_cell), (uint32_t)cell_coord(p[u].y, grid.inv_cell), (uint32_t)cell_coord(p[u].z, grid.inv_cell)};
-        s_key[1u + u * 256u + tid] = morton3(c[0], c[1], c[2]);
+        s_key[1u + u * 256u + tid] = pack_key(c[0], c[1], c[2]);
         if (i < n) {
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) { lo[ax] = min(lo[ax], c[ax]); hi[ax] = max(hi[ax], c[ax]); }
@@ -36,7 +36,7 @@ __device__ __forceinline__ void tile_keys(const float4* __restrict__ pts, uint32
         uint64_t k = ~0ull;
         if (i0 > 0u) {
             const float4 q = pts[i0 - 1u];
-            k = morton3((uint32_t)cell_coord(q.x, grid.inv_cell), (uint32_t)cell_coord(q.y, grid.inv_cell), (uint32_t)cell_coord(q.z, grid.inv_cell));
+            k = pack_key((uint32_t)cell_coord(q.x, grid.inv_cell), (uint32_t)cell_coord(q.y, grid.inv_cell), (uint32_t)cell_coord(q.z, grid.inv_cell));
         }
         s_key[0] = k;
     }
@@ -78,8 +78,7 @@ __global__ __launch_bounds__(256) void cell_runs_count_kernel(const float4* __re
 }
 
 __global__ __launch_bounds__(256) void cell_runs_emit_kernel(const float4* __restrict__ pts, uint32_t n, Grid grid, const uint32_t* __restrict__ tile_off,
-                                                             uint64_t* __restrict__ run_key, uint32_t* __restrict__ run_start, uint32_t* __restrict__ n_runs,
-                                                             uint32_t n_tiles) {
+                                                             uint64_t* __restrict__ run_key, uint32_t* __restrict__ run_start) {
     __shared__ uint64_t s_key[RUN_TILE + 1];
     __shared__ uint32_t s_w[4];
     const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -112,11 +111,10 @@ __global__ __launch_bounds__(256) void cell_runs_emit_kernel(const float4* __res
             ++pos;
         }
     }
-    if (t == 0 && tid == 0) *n_runs = tile_off[n_tiles];
 }
 
 __global__ __launch_bounds__(1024) void cell_box_publish_kernel(const uint32_t* __restrict__ tile_box, uint32_t n_tiles, const uint32_t* __restrict__ n_runs,
-                                                                uint32_t* dst_mapped, uint32_t seq) {
+                                                                const uint32_t* __restrict__ check, uint32_t* dst_mapped, uint32_t seq) {
     __shared__ uint32_t s_w[16][6];
     const uint32_t tid = threadIdx.x;
     uint32_t v[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
@@ -140,19 +138,21 @@ __global__ __launch_bounds__(1024) void cell_box_publish_kernel(const uint32_t* 
         dst_mapped[1u + tid] = r;
     }
     if (tid == 6u) dst_mapped[0] = *n_runs;
+    if (tid == 7u) dst_mapped[7] = check != nullptr ? *check : 0u;
     __threadfence_system();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(dst_mapped + 32, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// run r: its Morton code -> the compressed sort key (in place), and the value that rides with it through the sort:
+// run r: its cell's packed coordinates -> the compressed sort key (in place), and the value that rides with it through the sort:
 // first point << 32 | number of points (the next run's first point is known by now)
 __global__ __launch_bounds__(256) void compress_run_keys_kernel(uint64_t* __restrict__ run_key, const uint32_t* __restrict__ run_start, uint32_t n_runs,
                                                                 uint32_t n, CellKeyFrame f, uint64_t* __restrict__ run_val, uint32_t* err) {
     bool bad = false;
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n_runs; r += gridDim.x * 256u) {
         bool ok;
-        run_key[r] = cell_key_compress(f, run_key[r], &ok);
+        const uint64_t pk = run_key[r];
+        run_key[r] = cell_key_compress(f, (uint32_t)(pk >> 42) & 0x1fffffu, (uint32_t)(pk >> 21) & 0x1fffffu, (uint32_t)pk & 0x1fffffu, &ok);
         bad = bad || !ok;
         const uint32_t s0 = run_start[r], s1 = r + 1u < n_runs ? run_start[r + 1u] : n;
         run_val[r] = ((uint64_t)s0 << 32) | (uint64_t)(s1 - s0);
@@ -232,14 +232,14 @@ hipError_t launch_cell_runs_count(const float4* pts, uint32_t n, Grid grid, uint
     hipLaunchKernelGGL(cell_runs_count_kernel, dim3(nt + 1u), dim3(256), 0, s, pts, n, grid, tile_cnt, tile_box, nt);
     return hipGetLastError();
 }
-hipError_t launch_cell_runs_emit(const float4* pts, uint32_t n, Grid grid, const uint32_t* tile_off, uint64_t* run_key, uint32_t* run_start,
-                                 uint32_t* n_runs, hipStream_t s) {
+hipError_t launch_cell_runs_emit(const float4* pts, uint32_t n, Grid grid, const uint32_t* tile_off, uint64_t* run_key, uint32_t* run_start, hipStream_t s) {
     const uint32_t nt = tiles_of(n);
-    hipLaunchKernelGGL(cell_runs_emit_kernel, dim3(nt), dim3(256), 0, s, pts, n, grid, tile_off, run_key, run_start, n_runs, nt);
+    hipLaunchKernelGGL(cell_runs_emit_kernel, dim3(nt), dim3(256), 0, s, pts, n, grid, tile_off, run_key, run_start);
     return hipGetLastError();
 }
-hipError_t launch_cell_box_publish(const uint32_t* tile_box, uint32_t n_tiles, const uint32_t* n_runs, uint32_t* dst_mapped, uint32_t seq, hipStream_t s) {
-    hipLaunchKernelGGL(cell_box_publish_kernel, dim3(1), dim3(1024), 0, s, tile_box, n_tiles, n_runs, dst_mapped, seq);
+hipError_t launch_cell_box_publish(const uint32_t* tile_box, uint32_t n_tiles, const uint32_t* n_runs, const uint32_t* check, uint32_t* dst_mapped, uint32_t seq,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(cell_box_publish_kernel, dim3(1), dim3(1024), 0, s, tile_box, n_tiles, n_runs, check, dst_mapped, seq);
     return hipGetLastError();
 }
 hipError_t launch_compress_run_keys(uint64_t* run_key, const uint32_t* run_start, uint32_t n_runs, uint32_t n, const CellKeyFrame& f, uint64_t* run_val,

@@ -93,11 +93,12 @@ static int ensure_raw_buffers(lio_ctx* c, size_t n) {
     if (!c->d_vox) HIPCHK(c, hipMalloc((void**)&c->d_vox, 2 * sizeof(VoxelGridDev)));
     if (n <= c->cap_raw) return LIO_OK;
     void* old[] = {c->d_raw, c->d_raw_back, c->d_undist, c->d_leafpts, c->d_raw_keys, c->d_raw_keys2, c->d_leaf_keys, c->d_raw_order,
-                   c->d_raw_order2, c->d_leaf_count, c->d_leaf_start};
+                   c->d_raw_order2, c->d_leaf_count, c->d_leaf_start, c->d_undist_parts};
     for (void* p : old) if (p) (void)hipFree(p);           // (hipFree waits for the device: nothing in flight reads them)
     c->raw_prefetched = false;
     c->d_raw = c->d_raw_back = c->d_undist = c->d_leafpts = nullptr; c->d_raw_keys = c->d_raw_keys2 = c->d_leaf_keys = nullptr;
     c->d_raw_order = c->d_raw_order2 = c->d_leaf_count = c->d_leaf_start = nullptr; c->cap_raw = 0;
+    c->d_undist_parts = nullptr; c->undist_parts_n = 0;
     HIPCHK(c, hipMalloc((void**)&c->d_raw, n * sizeof(float4)));
     HIPCHK(c, hipMalloc((void**)&c->d_raw_back, n * sizeof(float4)));     // destination of lio_scan_prefetch_raw
     HIPCHK(c, hipMalloc((void**)&c->d_undist, n * sizeof(float4)));
@@ -109,6 +110,7 @@ static int ensure_raw_buffers(lio_ctx* c, size_t n) {
     HIPCHK(c, hipMalloc((void**)&c->d_raw_order2, n * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_leaf_count, n * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_leaf_start, n * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_undist_parts, ((n + 255) / 256) * 8 * sizeof(uint32_t)));
     c->cap_raw = n;
     return LIO_OK;
 }
@@ -129,7 +131,7 @@ int lio_scan_upload_raw(lio_ctx* c, const float* raw_pts, int n, int stride_byte
     hipStream_t s = c->prep_active ? c->prep_stream : c->stream;      // (lio_scan_prep_begin: the preparation runs on a stream of its own)
     int rc = ensure_raw_buffers(c, (size_t)(n > 0 ? n : 1));
     if (rc != LIO_OK) return rc;
-    c->n_raw = n; c->have_raw = false; c->raw_uploaded = true;
+    c->n_raw = n; c->have_raw = false; c->raw_uploaded = true; c->undist_parts_n = 0;
     c->raw_time_keyed = time_offset_bytes >= 0;
     if (n == 0) return LIO_OK;
     rc = ensure_stage(c, (size_t)n + POSE_STAGE_SLOTS);                        // the IMU poses travel behind the points (lio_scan_compensate)
@@ -187,6 +189,7 @@ int lio_scan_compensate(lio_ctx* c, const lio_pose6d* imu_poses, int n_poses, co
         HIPCHK(c, hipMemcpyAsync(c->d_undist, c->d_raw, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, s));
         c->undist_sorted = true;                                               // no sort, no compensation
         c->raw_time_keyed = false;
+        c->undist_parts_n = 0;
         return LIO_OK;
     }
     // the poses go through the tail of the pinned staging buffer (bytes the point copy does not read)
@@ -208,7 +211,10 @@ int lio_scan_compensate(lio_ctx* c, const lio_pose6d* imu_poses, int n_poses, co
     // the input order).
     Pose14 end;
     for (int i = 0; i < 14; ++i) end.v[i] = end_state14[i];
-    HIPCHK(c, launch_undistort(c->d_raw, n, c->d_imu_poses, n_poses, end, c->d_undist, s));
+    // (the kernel also leaves the extremes of every workgroup's compensated points and whether the sweep is in time order: the voxel
+    // filter's first pass over the cloud, getMinMax3D, is then a fold of ~500 records inside its key kernel)
+    HIPCHK(c, launch_undistort(c->d_raw, n, c->d_imu_poses, n_poses, end, c->d_undist, s, c->prep_fused ? c->d_undist_parts : nullptr));
+    c->undist_parts_n = c->prep_fused ? (uint32_t)((n + 255) / 256) : 0u;
     c->undist_sorted = false;
     return LIO_OK;
 }
@@ -233,6 +239,7 @@ static int sort_undistorted_by_time(lio_ctx* c) {
     HIPCHK(c, launch_gather_points(c->d_undist, c->d_raw_order2, (uint32_t)n, c->d_leafpts, s));
     float4* t = c->d_undist; c->d_undist = c->d_leafpts; c->d_leafpts = t;
     c->undist_sorted = true;
+    c->undist_parts_n = 0;                     // (their time-order flag describes the cloud as it was)
     return LIO_OK;
 }
 
@@ -277,7 +284,8 @@ static int voxel_enqueue(lio_ctx* c, VoxelRun& r, hipStream_t s, bool prep, floa
     c->vox_clean[c->vox_cur] = false;
     c->vox_clean[c->vox_cur ^ 1] = false;                           // (until the centroid launch below is known to be enqueued)
     // inverse_leaf_size_ = 1 / leaf_size_; the order of the points is checked whenever it matters for the next prediction
-    HIPCHK(c, launch_minmax_params(c->d_undist, n, vox, 1.0f / r.leaf, r.may_compact && r.time_minor, s));
+    const bool folded = r.compact && c->undist_parts_n != 0u && c->undist_parts_n == (uint32_t)((n + 255) / 256);   // (the compensation kernel left the extremes)
+    if (!folded) HIPCHK(c, launch_minmax_params(c->d_undist, n, vox, 1.0f / r.leaf, r.may_compact && r.time_minor, s));
     unsigned long long* agg = nullptr;
     if (r.compact) {
         r.passes = c->vox_passes_guess;
@@ -288,7 +296,8 @@ static int voxel_enqueue(lio_ctx* c, VoxelRun& r, hipStream_t s, bool prep, floa
             HIPCHK(c, hipMemsetAsync(gagg, 0, GSORT_AGG_WORDS * sizeof(unsigned long long), s));
             gseq = 0u;
         }
-        HIPCHK(c, launch_voxel_index_compact(c->d_undist, n, vox, c->d_raw_keys, s));
+        HIPCHK(c, launch_voxel_index_compact(c->d_undist, n, vox, c->d_raw_keys, s, folded ? c->d_undist_parts : nullptr, c->undist_parts_n, 1.0f / r.leaf,
+                                             r.may_compact && r.time_minor));
         GsortLsdArgs g{};
         g.keys = c->d_raw_keys; g.n = (uint32_t)n; g.kb = 8 * r.passes; g.passes = r.passes; g.keys_out = c->d_raw_keys2; g.vals_out = c->d_raw_order2;
         g.part = c->d_leaf_keys; g.part2 = reinterpret_cast<uint64_t*>(c->d_leafpts);  // (scratch of this call: 8 and 16 bytes per point)
@@ -296,6 +305,12 @@ static int voxel_enqueue(lio_ctx* c, VoxelRun& r, hipStream_t s, bool prep, floa
         gseq += (uint32_t)r.passes;
         HIPCHK(c, launch_gsort_lsd(g, s));
         const uint32_t stamp = voxel_compact_stamp(c, prep, s, &agg);
+        if (c->prep_fused) {                                        // run heads inside the centroid launch
+            HIPCHK(c, launch_leaf_centroids(c->d_undist, c->d_raw_order2, c->d_raw_keys2, vox, (uint32_t)n, (uint32_t)c->cap_q, out_body, vox_next, agg, stamp, s));
+            c->vox_clean[c->vox_cur ^ 1] = true;
+            c->vox_cur ^= 1;
+            return LIO_OK;
+        }
         HIPCHK(c, launch_run_heads(c->d_raw_keys2, (uint32_t)n, 0, c->d_leaf_start, &vox->n_leaves, agg, stamp, &vox->summary[3], s));
     } else {
         HIPCHK(c, launch_voxel_index(c->d_undist, n, vox, r.time_minor, c->d_raw_keys, c->d_raw_order, s));

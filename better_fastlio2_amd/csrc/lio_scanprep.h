@@ -56,4 +56,9 @@ hipError_t launch_centroids(const float4* pts, const uint32_t* order, const uint
                             VoxelGridDev* vox, uint32_t n, uint32_t max_leaves, uint32_t cap_out, float4* out, hipStream_t s,
                             bool compact_keys = false, VoxelGridDev* zero_for_next_call = nullptr);
 
+// run heads + centroids of a leaf-sorted cloud with COMPACT keys in one launch (n <= 262144; agg / stamp: the stamped scratch of the
+// single-launch compactions, lio_tile.h); vox->n_leaves / summary as launch_run_heads + launch_centroids leave them
+hipError_t launch_leaf_centroids(const float4* pts, const uint32_t* order, const uint64_t* sorted_keys, VoxelGridDev* vox, uint32_t n, uint32_t cap_out, float4* out,
+                                 VoxelGridDev* zero_for_next_call, unsigned long long* agg, uint32_t stamp, hipStream_t s);
+
 }  // namespace lio

@@ -14,6 +14,7 @@
 #include "lio_kernels.h"
 #include "lio_math.h"
 #include "lio_scanprep.h"
+#include "lio_tile.h"
 
 namespace lio {
 
@@ -354,6 +355,83 @@ __global__ __launch_bounds__(256) void centroid_kernel(const float4* pts, const 
         const float fn = (float)(en - st);
         if (r == 0 && l < cap_out) out[l] = make_float4(sx / fn, sy / fn, sz / fn, 0.0f);
     }
+}
+
+// Run heads AND centroids in one launch (time-ordered sweeps, compact keys): a workgroup takes a tile of 256 sorted points, finds the
+// leaves that START in it, numbers them through the stamped tile prefix (lio_tile.h) -- out[] is in ascending leaf order -- and gives each
+// to sixteen lanes, which follow the run to its end (into later tiles if need be: the end is where the key changes) with the very
+// additions of centroid_kernel.  Saves the run-head launch and the round trip of the leaf starts through memory.
+__global__ __launch_bounds__(256) void leaf_centroids_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ order, const uint64_t* __restrict__ sorted_keys,
+                                                             VoxelGridDev* vox, uint32_t n, uint32_t cap_out, float4* __restrict__ out, VoxelGridDev* zero_next,
+                                                             unsigned long long* agg, uint32_t stamp) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_head[256];
+    const uint32_t tid = threadIdx.x;
+    if (zero_next != nullptr && blockIdx.x == gridDim.x - 1u) {          // (nobody reads that record in this call)
+        uint32_t* w = reinterpret_cast<uint32_t*>(zero_next);
+        for (uint32_t x = tid; x < sizeof(VoxelGridDev) / 4u; x += 256u) w[x] = 0u;
+    }
+    const uint32_t flags = vox->flags;
+    const uint64_t drop_key = vox->probe[1] >= 32u ? 0xffffffffull : (1ull << vox->probe[1]) - 1ull;   // the run of dropped (non-finite) points
+    const uint32_t i = blockIdx.x * 256u + tid;
+    const uint64_t key = i < n ? sorted_keys[i] : 0ull;
+    const bool head = i < n && (i == 0u || sorted_keys[i - 1u] != key);
+    uint32_t tot;
+    const uint32_t r = tile_rank(head, tot, s_w);
+    if (head) s_head[r] = i;
+    const uint32_t mine[1] = {tot};
+    uint32_t before[1];
+    const bool ok = tile_exclusive_prefix<1>(mine, agg, stamp, before);   // (its barriers also publish s_head)
+    if (!ok && tid == 0) atomicOr(&vox->summary[3], 1u);
+    if (blockIdx.x == gridDim.x - 1u && tid == 0) {
+        const uint32_t n_leaves = ok ? before[0] + tot : 0u;
+        vox->n_leaves = n_leaves;
+        vox->summary[0] = n_leaves;
+        vox->summary[1] = (n_leaves > 0u && sorted_keys[n - 1u] == drop_key) ? 1u : 0u;
+        vox->summary[2] = flags;
+    }
+    if (flags != 0u || !ok) return;
+    const uint32_t r16 = tid & 15u, lane = tid & 63u;
+    for (uint32_t h = tid >> 4; h < tot; h += 16u) {
+        const uint32_t st = s_head[h];
+        const uint64_t k0 = sorted_keys[st];
+        if (k0 == drop_key) continue;                                     // (always the last run)
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        uint32_t count = 0u;
+        uint32_t j = st + r16;
+        bool in = j < n && sorted_keys[j] == k0;
+        float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) nxt = pts[order[j]];
+        for (;;) {
+            const float4 p = nxt;
+            // the points of the run among these sixteen: a prefix (the keys are sorted)
+            const int cnt = __popcll((__ballot(in) >> (lane & 48u)) & 0xffffull);
+            if (cnt == 16) {                                              // the next sixteen are in flight while these are added
+                j += 16u;
+                in = j < n && sorted_keys[j] == k0;
+                if (in) nxt = pts[order[j]];
+                centroid_add16<0>(p, sx, sy, sz);
+            } else {
+                for (int k = 0; k < cnt; ++k) {
+                    sx += __shfl(p.x, k, 16);
+                    sy += __shfl(p.y, k, 16);
+                    sz += __shfl(p.z, k, 16);
+                }
+            }
+            count += (uint32_t)cnt;
+            if (cnt < 16) break;
+        }
+        const float fn = (float)count;
+        const uint32_t l = before[0] + h;
+        if (r16 == 0u && l < cap_out) out[l] = make_float4(sx / fn, sy / fn, sz / fn, 0.0f);
+    }
+}
+hipError_t launch_leaf_centroids(const float4* pts, const uint32_t* order, const uint64_t* sorted_keys, VoxelGridDev* vox, uint32_t n, uint32_t cap_out, float4* out,
+                                 VoxelGridDev* zero_for_next_call, unsigned long long* agg, uint32_t stamp, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (n > 262144u) return hipErrorInvalidValue;                         // (1024 tiles: all resident at once)
+    hipLaunchKernelGGL(leaf_centroids_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, pts, order, sorted_keys, vox, n, cap_out, out, zero_for_next_call, agg, stamp);
+    return hipGetLastError();
 }
 
 hipError_t launch_time_keys(const float4* pts, int n, uint64_t* keys, uint32_t* order, hipStream_t s) {

@@ -84,10 +84,9 @@ static int finish_index_levels(lio_ctx* c, uint32_t n, uint32_t n_cells, const u
             c->d_ltable = nt; c->ltable_slots = cap;
         }
         HIPCHK(c, hipMemsetAsync(c->d_ltable + used, 0xFF, sl * sizeof(HashEntry), s));
-        // `start` of a coarse entry is its rank among the cells of its level; level 1 uses it as the number of its
-        // child block, the levels above only need to exist
-        HIPCHK(c, launch_iota(c->d_rank, n_l, s));
-        HIPCHK(c, launch_table_insert(kout, c->d_rank, cout, n_l, c->d_ltable + used, (uint32_t)(sl - 1), s));
+        // `start` of a coarse entry is its rank among the cells of its level (cell_start == nullptr); level 1 uses it as the number
+        // of its child block, the levels above only need to exist
+        HIPCHK(c, launch_table_insert(kout, nullptr, cout, n_l, c->d_ltable + used, (uint32_t)(sl - 1), s));
         lv.off[L] = (uint32_t)used; lv.mask[L] = (uint32_t)(sl - 1);
         c->level_entries[L] = n_l;
         if (L == 1) {
@@ -128,6 +127,11 @@ int finish_index(lio_ctx* c, uint32_t n) {
     return finish_index_levels(c, n, n_cells, nullptr);
 }
 
+constexpr int LIO_RETRY_COUNT = -1000;         // internal: build_index found another number of live points than it was told
+// does a (re)build of n points go through the sort of cell runs?
+static bool by_cell_runs(const lio_ctx* c, size_t n) {
+    return c->rebuild_by_cells && !c->dbg_library_sort && n > 0 && n / RUN_TILE + 2u <= COMPACT_MAX_ITEMS && (n / RUN_TILE + 4u) * 8u * sizeof(uint32_t) <= c->temp_bytes;
+}
 // the POINT sort (points in no order; lio_debug_set "library_sort", LIO_REBUILD_BY_CELLS=0): Morton code per point, 63-bit radix sort, gather
 static int build_index_by_points(lio_ctx* c, const float4* src, uint32_t n) {
     hipStream_t s = c->stream;
@@ -141,7 +145,7 @@ static int build_index_by_points(lio_ctx* c, const float4* src, uint32_t n) {
 // index in array order, then the pending points -- and only the runs are sorted, by a compressed key.  Two waits on the way (the
 // number of runs with the cells' bounding box; the cells per level), one at the end (the roots).  Same d_pts, cell table and
 // tree as the point sort, bit for bit (tests/test_gpu_parity.py::test_rebuild_by_cell_runs_equals_the_point_sort).
-static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n) {
+static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n, const uint32_t* live_dev, uint32_t live_expected, uint32_t* live_found) {
     hipStream_t s = c->stream;
     const uint32_t n_tiles = (n + RUN_TILE - 1u) / RUN_TILE;
     uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(c->d_temp);                 // (the sort workspace is idle until sort_runs)
@@ -156,12 +160,14 @@ static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n) {
     uint32_t* dst_start = c->d_cell_starts;    // (the scan of the cell counts overwrites it later)
     HIPCHK(c, launch_cell_runs_count(src, n, c->grid, tile_cnt, tile_box, s));
     HIPCHK(c, launch_exclusive_scan(tile_cnt, n_tiles + 1u, tile_off, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
-    HIPCHK(c, launch_cell_runs_emit(src, n, c->grid, tile_off, run_key, run_start, c->d_counters + 4, s));
+    // the number of runs (the scan's total) and the cells' box are known from here: they travel to the host BESIDE the emit kernel
     uint32_t seq = ++c->small_seq;
-    HIPCHK(c, launch_cell_box_publish(tile_box, n_tiles, c->d_counters + 4, c->d_small, seq, s));
+    HIPCHK(c, launch_cell_box_publish(tile_box, n_tiles, tile_off + n_tiles, live_dev, c->d_small, seq, s));
+    HIPCHK(c, launch_cell_runs_emit(src, n, c->grid, tile_off, run_key, run_start, s));
     HIPCHK(c, wait_published(c, seq));
-    uint32_t w[7];
+    uint32_t w[8];
     std::memcpy(w, c->h_small, sizeof(w));
+    if (live_dev != nullptr && w[7] != live_expected) { *live_found = w[7]; return LIO_RETRY_COUNT; }
     const uint32_t n_runs = w[0];
     if (n_runs == 0u || n_runs > n) return c->fail(LIO_ERR_HIP, "index rebuild", "the run kernels left an impossible number of cell runs");
     // points in no particular order (a Build from the caller's cloud): as many runs as points, the run sort would only add to the work
@@ -171,9 +177,10 @@ static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n) {
     HIPCHK(c, sort_runs(c->d_temp, c->temp_bytes, run_key, sorted_key, run_val, sorted_val, n_runs, f.bits, s));
     HIPCHK(c, scan_run_lengths(c->d_temp, c->temp_bytes, sorted_val, n_runs, dst_start, s));
     HIPCHK(c, launch_runs_place(src, c->d_pts, sorted_key, sorted_val, dst_start, n_runs, f, run_key, c->d_level_parts, s));
-    HIPCHK(c, reduce_runs_to_cells(c->d_temp, c->temp_bytes, run_key, sorted_val, n_runs, c->d_cell_keys, c->d_cell_counts, c->d_counters + 4, s));
+    // (the cells per level travel to the host beside the reduction of the runs to cells)
     seq = ++c->small_seq;
     HIPCHK(c, launch_level_counts_publish(c->d_level_parts, c->d_apply + 15, c->d_small, seq, s));
+    HIPCHK(c, reduce_runs_to_cells(c->d_temp, c->temp_bytes, run_key, sorted_val, n_runs, c->d_cell_keys, c->d_cell_counts, c->d_counters + 4, s));
     HIPCHK(c, wait_published(c, seq));
     uint32_t lv[TREE_MAX_LEVELS + 1];
     std::memcpy(lv, c->h_small, sizeof(lv));
@@ -187,7 +194,9 @@ static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n) {
 }
 
 // (re)build the index from n points at src (device, float4, must not alias c->d_pts)
-int build_index(lio_ctx* c, const float4* src, uint32_t n) {
+// live_dev (optional): a device word that must equal `live_expected` -- read with the rebuild's first wait; LIO_RETRY_COUNT and
+// *live_found when it does not (nothing of the index has been touched then)
+int build_index(lio_ctx* c, const float4* src, uint32_t n, const uint32_t* live_dev = nullptr, uint32_t live_expected = 0u, uint32_t* live_found = nullptr) {
     hipStream_t s = c->stream;
     c->have_map = false;
     c->hint_valid = false;                     // neighbours of an older map state no longer bound a search
@@ -202,9 +211,7 @@ int build_index(lio_ctx* c, const float4* src, uint32_t n) {
         c->have_map = true; c->map_broken = false;
         return LIO_OK;
     }
-    if (c->rebuild_by_cells && !c->dbg_library_sort && (size_t)n / RUN_TILE + 2u <= COMPACT_MAX_ITEMS &&
-        ((size_t)n / RUN_TILE + 4u) * 8u * sizeof(uint32_t) <= c->temp_bytes)
-        return build_index_by_cells(c, src, n);
+    if (by_cell_runs(c, n)) return build_index_by_cells(c, src, n, live_dev, live_expected, live_found);
     return build_index_by_points(c, src, n);
 }
 
@@ -354,16 +361,27 @@ int rebuild_full(lio_ctx* c) {
         const int rc = collect_box_deleted(c);
         if (rc != LIO_OK) return rc;
     }
+    // The host keeps count of the live points (n_live): the rebuild by cell runs goes ahead on that number and has the compaction's
+    // own count delivered with its first wait; should the two ever differ, it starts over from the device's.
     uint32_t live = 0;
+    bool counted = true;
     if (n_all > 0) {
         HIPCHK(c, compact_live_any(c, c->d_pts, n_all, c->d_pts_tmp, c->d_counters + 3));
-        HIPCHK(c, read_back(c, &live, c->d_counters + 3, sizeof(uint32_t)));
+        counted = !by_cell_runs(c, c->n_live + n_pend) || c->n_live == 0u || c->n_live > n_all;
+        if (counted) HIPCHK(c, read_back(c, &live, c->d_counters + 3, sizeof(uint32_t)));
+        else live = c->n_live;
     }
-    if ((size_t)live + (size_t)n_pend > c->cap_map)
-        return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
-    if (n_pend > 0)
-        HIPCHK(c, hipMemcpyAsync(c->d_pts_tmp + live, c->d_pend, (size_t)n_pend * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    return build_index(c, c->d_pts_tmp, live + n_pend);
+    for (;;) {
+        if ((size_t)live + (size_t)n_pend > c->cap_map)
+            return c->fail(LIO_ERR_CAPACITY, "Add_Points", "live points + batch exceed max_map_points");
+        if (n_pend > 0)
+            HIPCHK(c, hipMemcpyAsync(c->d_pts_tmp + live, c->d_pend, (size_t)n_pend * sizeof(float4), hipMemcpyDeviceToDevice, s));
+        uint32_t live_dev = live;
+        const int rc = build_index(c, c->d_pts_tmp, live + n_pend, counted ? nullptr : c->d_counters + 3, live, &live_dev);
+        if (rc != LIO_RETRY_COUNT) return rc;
+        if (c->trace_rebuilds) std::fprintf(stderr, "lio: full rebuild: the host counted %u live points, the compaction %u\n", live, live_dev);
+        live = live_dev; counted = true;
+    }
 }
 
 // how many retired slots (copies of re-written buckets) the map may carry before a full rebuild compacts them away

@@ -31,7 +31,7 @@ int main() {
             if (k < 8) for (int i = 0; i < 3; ++i) c[i] = (k >> i) & 1 ? hi[i] : lo[i];          // the corners
             const uint64_t mk = morton3(c[0], c[1], c[2]);
             bool ok = false;
-            const uint64_t ck = cell_key_compress(f, mk, &ok);
+            const uint64_t ck = cell_key_compress(f, c[0], c[1], c[2], &ok);
             if (!ok) { std::printf("cell of the box refused\n"); return 1; }
             if (f.bits < 64 && (ck >> f.bits) != 0) { std::printf("key wider than the frame says\n"); return 1; }
             if (cell_key_expand(f, ck) != mk) { std::printf("expand does not invert compress\n"); return 1; }
@@ -44,7 +44,7 @@ int main() {
         const uint32_t step = 1u << (2 * f.a);
         if (hi[0] + 2 * step < (1u << 21)) {
             bool ok = true;
-            (void)cell_key_compress(f, morton3(hi[0] + 2 * step, lo[1], lo[2]), &ok);
+            (void)cell_key_compress(f, hi[0] + 2 * step, lo[1], lo[2], &ok);
             if (ok) { std::printf("cell outside the frame accepted\n"); return 1; }
         }
         ++frames;
