@@ -92,17 +92,18 @@ hipError_t launch_cell_runs_emit(const float4* pts, uint32_t n, Grid grid, const
 // dst_mapped[0] = *n_runs, [1..6] = the box of all tiles, [7] = *check (optional), then `seq` at dst_mapped[32] (system scope): the host polls
 hipError_t launch_cell_box_publish(const uint32_t* tile_box, uint32_t n_tiles, const uint32_t* n_runs, const uint32_t* check, uint32_t* dst_mapped, uint32_t seq,
                                    hipStream_t s);
-// run_key[r] -> compressed key, in place; run_val[r] = first point << 32 | points of run r; *err |= 2 when a cell lies outside the frame
-hipError_t launch_compress_run_keys(uint64_t* run_key, const uint32_t* run_start, uint32_t n_runs, uint32_t n, const CellKeyFrame& f, uint64_t* run_val,
-                                    uint32_t* err, hipStream_t s);
-// stable sort of the runs by compressed key (the values ride along: nothing is gathered through an index afterwards)
-hipError_t sort_runs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint64_t* vals_in, uint64_t* vals_out, uint32_t n_runs,
-                     int bits, hipStream_t s);
+// sort_key[r] = compressed key of run_key[r] (uint32_t[] when f.bits <= 32, uint64_t[] otherwise), run_val[r] = first point << 32 | points
+// of run r; *err |= 2 when a cell lies outside the frame
+hipError_t launch_compress_run_keys(const uint64_t* run_key, const uint32_t* run_start, uint32_t n_runs, uint32_t n, const CellKeyFrame& f, void* sort_key,
+                                    uint64_t* run_val, uint32_t* err, hipStream_t s);
+// stable sort of the runs by compressed key, 32- or 64-bit keys by `bits` (the values ride along: nothing is gathered through an index afterwards)
+hipError_t sort_runs(void* temp, size_t temp_bytes, const void* keys_in, void* keys_out, const uint64_t* vals_in, uint64_t* vals_out, uint32_t n_runs, int bits,
+                     hipStream_t s);
 // first destination slot of every sorted run (exclusive scan of the run lengths in sorted order)
 hipError_t scan_run_lengths(void* temp, size_t temp_bytes, const uint64_t* sorted_val, uint32_t n_runs, uint32_t* dst_start, hipStream_t s);
 // the points of sorted run j to dst[dst_start[j]..); abs_key[j] = Morton code of its cell; level_parts[PLACE_WORKGROUPS][TREE_MAX_LEVELS]:
 // per workgroup, the sorted runs that start a new cell of level L
-hipError_t launch_runs_place(const float4* src, float4* dst, const uint64_t* sorted_key, const uint64_t* sorted_val, const uint32_t* dst_start,
+hipError_t launch_runs_place(const float4* src, float4* dst, const void* sorted_key, const uint64_t* sorted_val, const uint32_t* dst_start,
                              uint32_t n_runs, const CellKeyFrame& f, uint64_t* abs_key, uint32_t* level_parts, hipStream_t s);
 // cells = runs of equal abs_key: cell_keys, cell_counts (points), *n_cells
 hipError_t reduce_runs_to_cells(void* temp, size_t temp_bytes, const uint64_t* abs_key, const uint64_t* sorted_val, uint32_t n_runs, uint64_t* cell_keys,

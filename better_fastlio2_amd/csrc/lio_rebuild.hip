@@ -132,27 +132,31 @@ __global__ __launch_bounds__(1024) void cell_box_publish_kernel(const uint32_t* 
         for (int k = 0; k < 6; ++k) s_w[tid >> 6][k] = v[k];
     }
     __syncthreads();
+    // (no system-scope fence: it would write back an L2 full of what the kernels before this one have just produced -- the words go
+    // to host-mapped memory as system-scope stores, are acknowledged, then the sequence number follows the same way: cell_apply_kernel)
     if (tid < 6u) {
         uint32_t r = s_w[0][tid];
         for (int w = 1; w < 16; ++w) r = tid < 3u ? min(r, s_w[w][tid]) : max(r, s_w[w][tid]);
-        dst_mapped[1u + tid] = r;
+        __hip_atomic_store(dst_mapped + 1u + tid, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (tid == 6u) dst_mapped[0] = *n_runs;
-    if (tid == 7u) dst_mapped[7] = check != nullptr ? *check : 0u;
-    __threadfence_system();
+    if (tid == 6u) __hip_atomic_store(dst_mapped, *n_runs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 7u) __hip_atomic_store(dst_mapped + 7, check != nullptr ? *check : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(dst_mapped + 32, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(dst_mapped + 32, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// run r: its cell's packed coordinates -> the compressed sort key (in place), and the value that rides with it through the sort:
+// run r: its cell's packed coordinates -> the compressed sort key (KEY = uint32_t when the frame's keys fit: a third less to move per radix
+// pass), and the value that rides with it through the sort:
 // first point << 32 | number of points (the next run's first point is known by now)
-__global__ __launch_bounds__(256) void compress_run_keys_kernel(uint64_t* __restrict__ run_key, const uint32_t* __restrict__ run_start, uint32_t n_runs,
-                                                                uint32_t n, CellKeyFrame f, uint64_t* __restrict__ run_val, uint32_t* err) {
+template <class KEY>
+__global__ __launch_bounds__(256) void compress_run_keys_kernel(const uint64_t* __restrict__ run_key, const uint32_t* __restrict__ run_start, uint32_t n_runs,
+                                                                uint32_t n, CellKeyFrame f, KEY* __restrict__ sort_key, uint64_t* __restrict__ run_val, uint32_t* err) {
     bool bad = false;
     for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n_runs; r += gridDim.x * 256u) {
         bool ok;
         const uint64_t pk = run_key[r];
-        run_key[r] = cell_key_compress(f, (uint32_t)(pk >> 42) & 0x1fffffu, (uint32_t)(pk >> 21) & 0x1fffffu, (uint32_t)pk & 0x1fffffu, &ok);
+        sort_key[r] = (KEY)cell_key_compress(f, (uint32_t)(pk >> 42) & 0x1fffffu, (uint32_t)(pk >> 21) & 0x1fffffu, (uint32_t)pk & 0x1fffffu, &ok);
         bad = bad || !ok;
         const uint32_t s0 = run_start[r], s1 = r + 1u < n_runs ? run_start[r + 1u] : n;
         run_val[r] = ((uint64_t)s0 << 32) | (uint64_t)(s1 - s0);
@@ -163,7 +167,8 @@ __global__ __launch_bounds__(256) void compress_run_keys_kernel(uint64_t* __rest
 // One lane per sorted run: its points to their final place.  Adjacent lanes write adjacent destinations; the reads are the
 // scattered side (a run is 16 x len contiguous bytes).  Also: the Morton code of the run's cell (for the cell table that
 // follows) and, per tree level L, whether this run starts a new cell of that level -- keys differ in a bit of digit >= L.
-__global__ __launch_bounds__(256) void runs_place_kernel(const float4* __restrict__ src, float4* __restrict__ dst, const uint64_t* __restrict__ sorted_key,
+template <class KEY>
+__global__ __launch_bounds__(256) void runs_place_kernel(const float4* __restrict__ src, float4* __restrict__ dst, const KEY* __restrict__ sorted_key,
                                                          const uint64_t* __restrict__ sorted_val, const uint32_t* __restrict__ dst_start, uint32_t n_runs,
                                                          CellKeyFrame f, uint64_t* __restrict__ abs_key, uint32_t* __restrict__ level_parts) {
     __shared__ uint32_t s_lv[TREE_MAX_LEVELS];
@@ -177,11 +182,11 @@ __global__ __launch_bounds__(256) void runs_place_kernel(const float4* __restric
             const uint64_t v = sorted_val[j];
             const uint32_t s0 = (uint32_t)(v >> 32), len = (uint32_t)v;
             const uint32_t d0 = dst_start[j];
-            const uint64_t mk = cell_key_expand(f, sorted_key[j]);
+            const uint64_t mk = cell_key_expand(f, (uint64_t)sorted_key[j]);
             abs_key[j] = mk;
             if (j == 0u) top = TREE_MAX_LEVELS - 1;
             else {
-                const uint64_t x = mk ^ cell_key_expand(f, sorted_key[j - 1u]);
+                const uint64_t x = mk ^ cell_key_expand(f, (uint64_t)sorted_key[j - 1u]);
                 if (x != 0ull) top = (63 - __clzll((long long)x)) / 6;
             }
             for (uint32_t k = 0; k < len; ++k) dst[d0 + k] = src[s0 + k];
@@ -217,12 +222,12 @@ __global__ __launch_bounds__(1024) void level_counts_publish_kernel(const uint32
     if (tid < (uint32_t)TREE_MAX_LEVELS) {
         uint32_t r = 0;
         for (int w = 0; w < 16; ++w) r += s_w[w][tid];
-        dst_mapped[tid] = r;
+        __hip_atomic_store(dst_mapped + tid, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (tid == (uint32_t)TREE_MAX_LEVELS) dst_mapped[tid] = *err;
-    __threadfence_system();
+    if (tid == (uint32_t)TREE_MAX_LEVELS) __hip_atomic_store(dst_mapped + tid, *err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(dst_mapped + 32, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(dst_mapped + 32, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 static inline uint32_t tiles_of(uint32_t n) { return (n + RUN_TILE - 1u) / RUN_TILE; }
@@ -242,16 +247,22 @@ hipError_t launch_cell_box_publish(const uint32_t* tile_box, uint32_t n_tiles, c
     hipLaunchKernelGGL(cell_box_publish_kernel, dim3(1), dim3(1024), 0, s, tile_box, n_tiles, n_runs, check, dst_mapped, seq);
     return hipGetLastError();
 }
-hipError_t launch_compress_run_keys(uint64_t* run_key, const uint32_t* run_start, uint32_t n_runs, uint32_t n, const CellKeyFrame& f, uint64_t* run_val,
-                                    uint32_t* err, hipStream_t s) {
+hipError_t launch_compress_run_keys(const uint64_t* run_key, const uint32_t* run_start, uint32_t n_runs, uint32_t n, const CellKeyFrame& f, void* sort_key,
+                                    uint64_t* run_val, uint32_t* err, hipStream_t s) {
     uint32_t b = (n_runs + 255u) / 256u;
     if (b > 4096u) b = 4096u;
-    hipLaunchKernelGGL(compress_run_keys_kernel, dim3(b), dim3(256), 0, s, run_key, run_start, n_runs, n, f, run_val, err);
+    if (f.bits <= 32) hipLaunchKernelGGL(compress_run_keys_kernel<uint32_t>, dim3(b), dim3(256), 0, s, run_key, run_start, n_runs, n, f, (uint32_t*)sort_key, run_val, err);
+    else hipLaunchKernelGGL(compress_run_keys_kernel<uint64_t>, dim3(b), dim3(256), 0, s, run_key, run_start, n_runs, n, f, (uint64_t*)sort_key, run_val, err);
     return hipGetLastError();
 }
-hipError_t launch_runs_place(const float4* src, float4* dst, const uint64_t* sorted_key, const uint64_t* sorted_val, const uint32_t* dst_start,
+hipError_t launch_runs_place(const float4* src, float4* dst, const void* sorted_key, const uint64_t* sorted_val, const uint32_t* dst_start,
                              uint32_t n_runs, const CellKeyFrame& f, uint64_t* abs_key, uint32_t* level_parts, hipStream_t s) {
-    hipLaunchKernelGGL(runs_place_kernel, dim3(PLACE_WORKGROUPS), dim3(256), 0, s, src, dst, sorted_key, sorted_val, dst_start, n_runs, f, abs_key, level_parts);
+    if (f.bits <= 32)
+        hipLaunchKernelGGL(runs_place_kernel<uint32_t>, dim3(PLACE_WORKGROUPS), dim3(256), 0, s, src, dst, (const uint32_t*)sorted_key, sorted_val, dst_start, n_runs, f,
+                           abs_key, level_parts);
+    else
+        hipLaunchKernelGGL(runs_place_kernel<uint64_t>, dim3(PLACE_WORKGROUPS), dim3(256), 0, s, src, dst, (const uint64_t*)sorted_key, sorted_val, dst_start, n_runs, f,
+                           abs_key, level_parts);
     return hipGetLastError();
 }
 hipError_t launch_level_counts_publish(const uint32_t* level_parts, const uint32_t* err, uint32_t* dst_mapped, uint32_t seq, hipStream_t s) {
@@ -260,13 +271,19 @@ hipError_t launch_level_counts_publish(const uint32_t* level_parts, const uint32
 }
 
 // ---- the library halves: radix sort of the runs, scan of their lengths, runs -> cells --------------------------------------
-hipError_t sort_runs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint64_t* vals_in, uint64_t* vals_out, uint32_t n_runs,
-                     int bits, hipStream_t s) {
+template <class KEY>
+static hipError_t sort_runs_t(void* temp, size_t temp_bytes, const KEY* keys_in, KEY* keys_out, const uint64_t* vals_in, uint64_t* vals_out, uint32_t n_runs, int bits,
+                              hipStream_t s) {
     size_t need = 0;
     hipError_t e = rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)n_runs, 0u, (unsigned)bits, s);
     if (e != hipSuccess) return e;
     if (need > temp_bytes) return hipErrorOutOfMemory;
     return rocprim::radix_sort_pairs(temp, need, keys_in, keys_out, vals_in, vals_out, (size_t)n_runs, 0u, (unsigned)bits, s);
+}
+hipError_t sort_runs(void* temp, size_t temp_bytes, const void* keys_in, void* keys_out, const uint64_t* vals_in, uint64_t* vals_out, uint32_t n_runs, int bits,
+                     hipStream_t s) {
+    if (bits <= 32) return sort_runs_t<uint32_t>(temp, temp_bytes, (const uint32_t*)keys_in, (uint32_t*)keys_out, vals_in, vals_out, n_runs, bits, s);
+    return sort_runs_t<uint64_t>(temp, temp_bytes, (const uint64_t*)keys_in, (uint64_t*)keys_out, vals_in, vals_out, n_runs, bits, s);
 }
 struct RunLength {                            // points of a run: the low half of its value
     __host__ __device__ uint32_t operator()(uint64_t v) const { return (uint32_t)v; }

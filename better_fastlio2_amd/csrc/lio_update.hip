@@ -151,8 +151,9 @@ static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n, const
     uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(c->d_temp);                 // (the sort workspace is idle until sort_runs)
     uint32_t* tile_off = tile_cnt + (n_tiles + 4u);
     uint32_t* tile_box = tile_off + (n_tiles + 4u);
-    uint64_t* run_key = c->d_mkeys_tmp;        // Morton code per run -> compressed key (sort input) -> Morton code per SORTED run
-    uint64_t* sorted_key = c->d_mkeys;
+    uint64_t* run_key = c->d_mkeys_tmp;        // packed cell coordinates per run; later the Morton code per SORTED run
+    void* sort_key = c->d_cell_keys;           // compressed keys, in and out of the sort (32-bit when the frame allows; free until the cells are made)
+    void* sorted_key = c->d_mkeys;
     uint32_t* run_start = c->d_vals_tmp;       // [n] at most (before the number of runs is known)
     // (first point, points) per run, in and out of the sort: 8 bytes per run in the 4-byte-per-point arrays -- at most n / 2 runs get here
     uint64_t* run_val = reinterpret_cast<uint64_t*>(c->d_vals);
@@ -173,8 +174,8 @@ static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n, const
     // points in no particular order (a Build from the caller's cloud): as many runs as points, the run sort would only add to the work
     if ((size_t)n_runs * 2u > (size_t)n) return build_index_by_points(c, src, n);
     const CellKeyFrame f = cell_key_frame(w + 1, w + 4);
-    HIPCHK(c, launch_compress_run_keys(run_key, run_start, n_runs, n, f, run_val, c->d_apply + 15, s));
-    HIPCHK(c, sort_runs(c->d_temp, c->temp_bytes, run_key, sorted_key, run_val, sorted_val, n_runs, f.bits, s));
+    HIPCHK(c, launch_compress_run_keys(run_key, run_start, n_runs, n, f, sort_key, run_val, c->d_apply + 15, s));
+    HIPCHK(c, sort_runs(c->d_temp, c->temp_bytes, sort_key, sorted_key, run_val, sorted_val, n_runs, f.bits, s));
     HIPCHK(c, scan_run_lengths(c->d_temp, c->temp_bytes, sorted_val, n_runs, dst_start, s));
     HIPCHK(c, launch_runs_place(src, c->d_pts, sorted_key, sorted_val, dst_start, n_runs, f, run_key, c->d_level_parts, s));
     // (the cells per level travel to the host beside the reduction of the runs to cells)
