@@ -395,9 +395,9 @@ def sustained_figure(ctx, per_step_s, info0, info1, one_more_step):
     one_more_step()                                            # (untimed: under the deferred exchange schedule this step only holds its batch back;
     ctx.synchronize()                                          #  the NEXT one lets it into the map -- and meets the budget)
     t0 = time.perf_counter()
-    one_more_step()
-    ctx.synchronize()
-    forced_ms = (time.perf_counter() - t0) * 1e3
+    own = one_more_step()                                      # (a step function that times its own share -- the emulated world's: the other
+    ctx.synchronize()                                          #  ranks' untimed scan steps are not part of a step's price -- returns it, in seconds)
+    forced_ms = (own if own is not None else time.perf_counter() - t0) * 1e3
     ctx.debug_set("retired_budget", 0)
     info2 = ctx.map_info()
     info1 = dict(info1, n_full_rebuilds=info2["n_full_rebuilds"] - 1) if info2["n_full_rebuilds"] - info1["n_full_rebuilds"] == 2 else info1   # (the untimed step rebuilt too)
@@ -481,6 +481,9 @@ def emulated_world_loop(W, ctx, kf, capi, synth, world, nq, kind, voxel, ext_i, 
             acc["own"] += t1 - t0; acc["exchange"] += t2 - t1; acc["steps"] += 1
             acc["n_add"] += na.value; acc["n_nodown"] += nb.value
             lat.append(t2 - t0)
+            return None
+        ctx.synchronize()                                       # (sustained_figure: the forced rebuild's step, its own share only, drained)
+        return time.perf_counter() - t0
 
     tick[0] = 0
     for _ in range(2):

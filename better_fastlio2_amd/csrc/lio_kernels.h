@@ -170,6 +170,8 @@ hipError_t launch_iota(uint32_t* out, uint32_t n, hipStream_t s);
 hipError_t launch_publish_words(const uint32_t* src, int n, uint32_t* dst_mapped, uint32_t seq, hipStream_t s);
 hipError_t launch_fill_child_blocks(const uint64_t* cell_mkeys, const uint32_t* cell_start, const uint32_t* cell_count,
                                     uint32_t n_cells, const HashEntry* l1table, uint32_t l1mask, uint2* child, hipStream_t s);
+hipError_t launch_fill_child_blocks_packed(const uint64_t* cell_mkeys, const uint64_t* cell_val, uint32_t n_cells, const HashEntry* l1table, uint32_t l1mask,
+                                           uint2* child, uint32_t* block_bump, uint32_t n_blocks, uint32_t* level_new, hipStream_t s);
 // w != 0 for every live point inside any of the nb half-open boxes; *counter += points tomb-stoned
 hipError_t launch_delete_boxes(float4* pts, uint32_t n, const float* boxes6, int nb, uint32_t* counter,
                                hipStream_t s);

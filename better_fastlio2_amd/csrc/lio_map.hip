@@ -68,6 +68,25 @@ __global__ __launch_bounds__(256) void fill_child_blocks_kernel(const uint64_t* 
     }
 }
 
+// the same from the packed cell records of the rebuild by cell runs (first point << 32 | points); lane 0 of the launch also sets the
+// number of child blocks in use (*block_bump) and clears the per-level counters of new entries (level_new[TREE_MAX_LEVELS]): two small
+// copies less on the stream
+__global__ __launch_bounds__(256) void fill_child_blocks_packed_kernel(const uint64_t* cell_mkeys, const uint64_t* cell_val, uint32_t n_cells,
+                                                                       const HashEntry* l1table, uint32_t l1mask, uint2* child, uint32_t* block_bump,
+                                                                       uint32_t n_blocks, uint32_t* level_new) {
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t)TREE_MAX_LEVELS) level_new[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *block_bump = n_blocks;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cells; c += gridDim.x * blockDim.x) {
+        const uint64_t mk = cell_mkeys[c];
+        const uint32_t cx = compact21(mk >> 2), cy = compact21(mk >> 1), cz = compact21(mk);
+        uint32_t blk, one;
+        table_find(l1table, l1mask, pack_key(cx >> 2, cy >> 2, cz >> 2), blk, one);
+        if (one == 0u) continue;
+        const uint64_t v = cell_val[c];
+        child[(size_t)blk * 64u + (((cx & 3u) << 4) | ((cy & 3u) << 2) | (cz & 3u))] = make_uint2((uint32_t)(v >> 32), (uint32_t)v);
+    }
+}
+
 // Delete_by_range (ikd_Tree.cpp:648-710): a live point is removed when
 // min <= p < max on every axis for any of the boxes.
 __global__ __launch_bounds__(256) void delete_boxes_kernel(float4* pts, uint32_t n, const float* boxes6, int nb,
@@ -166,6 +185,12 @@ hipError_t launch_fill_child_blocks(const uint64_t* cell_mkeys, const uint32_t* 
     if (n_cells == 0) return hipSuccess;
     hipLaunchKernelGGL(fill_child_blocks_kernel, grid_for(n_cells), dim3(256), 0, s, cell_mkeys, cell_start, cell_count,
                        n_cells, l1table, l1mask, child);
+    return hipGetLastError();
+}
+hipError_t launch_fill_child_blocks_packed(const uint64_t* cell_mkeys, const uint64_t* cell_val, uint32_t n_cells, const HashEntry* l1table, uint32_t l1mask,
+                                           uint2* child, uint32_t* block_bump, uint32_t n_blocks, uint32_t* level_new, hipStream_t s) {
+    hipLaunchKernelGGL(fill_child_blocks_packed_kernel, grid_for(n_cells), dim3(256), 0, s, cell_mkeys, cell_val, n_cells, l1table, l1mask, child, block_bump,
+                       n_blocks, level_new);
     return hipGetLastError();
 }
 hipError_t launch_delete_boxes(float4* pts, uint32_t n, const float* boxes6, int nb, uint32_t* counter, hipStream_t s) {

@@ -105,9 +105,12 @@ hipError_t scan_run_lengths(void* temp, size_t temp_bytes, const uint64_t* sorte
 // per workgroup, the sorted runs that start a new cell of level L
 hipError_t launch_runs_place(const float4* src, float4* dst, const void* sorted_key, const uint64_t* sorted_val, const uint32_t* dst_start,
                              uint32_t n_runs, const CellKeyFrame& f, uint64_t* abs_key, uint32_t* level_parts, hipStream_t s);
-// cells = runs of equal abs_key: cell_keys, cell_counts (points), *n_cells
-hipError_t reduce_runs_to_cells(void* temp, size_t temp_bytes, const uint64_t* abs_key, const uint64_t* sorted_val, uint32_t n_runs, uint64_t* cell_keys,
-                                uint32_t* cell_counts, uint32_t* n_cells, hipStream_t s);
+// cells = runs of equal abs_key: cell_keys, cell_val (first point << 32 | points), *n_cells
+hipError_t reduce_runs_to_cells(void* temp, size_t temp_bytes, const uint64_t* abs_key, const uint64_t* sorted_val, const uint32_t* dst_start, uint32_t n_runs,
+                                uint64_t* cell_keys, uint64_t* cell_val, uint32_t* n_cells, hipStream_t s);
+// tree level 1 from the packed cell records (keys >> 6, points summed)
+hipError_t coarsen_cells_packed(void* temp, size_t temp_bytes, const uint64_t* cell_keys, const uint64_t* cell_val, size_t n, uint64_t* keys_out, uint32_t* counts_out,
+                                uint32_t* n_out, hipStream_t s);
 // dst_mapped[L] = cells of level L (sum of the partials), L < TREE_MAX_LEVELS, [TREE_MAX_LEVELS] = *err; then `seq` as above
 hipError_t launch_level_counts_publish(const uint32_t* level_parts, const uint32_t* err, uint32_t* dst_mapped, uint32_t seq, hipStream_t s);
 

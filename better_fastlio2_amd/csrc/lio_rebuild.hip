@@ -296,16 +296,37 @@ hipError_t scan_run_lengths(void* temp, size_t temp_bytes, const uint64_t* sorte
     if (need > temp_bytes) return hipErrorOutOfMemory;
     return rocprim::exclusive_scan(temp, need, len, dst_start, 0u, (size_t)n_runs, rocprim::plus<uint32_t>(), s);
 }
-hipError_t reduce_runs_to_cells(void* temp, size_t temp_bytes, const uint64_t* abs_key, const uint64_t* sorted_val, uint32_t n_runs, uint64_t* cell_keys,
-                                uint32_t* cell_counts, uint32_t* n_cells, hipStream_t s) {
-    auto len = rocprim::make_transform_iterator(sorted_val, RunLength{});
+// cells = runs of equal abs_key; cell_val[c] = first point of the cell << 32 | its points: the reduction keeps the first run's start and
+// adds the lengths (associative, applied in order) -- the cells' starts need no scan of their own
+struct RunPlaced {
+    const uint32_t* dst_start;
+    const uint64_t* sorted_val;
+    __host__ __device__ uint64_t operator()(uint32_t j) const { return ((uint64_t)dst_start[j] << 32) | (uint64_t)(uint32_t)sorted_val[j]; }
+};
+struct FirstStartSumLength {
+    __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return (a & 0xffffffff00000000ull) | (uint64_t)((uint32_t)a + (uint32_t)b); }
+};
+hipError_t reduce_runs_to_cells(void* temp, size_t temp_bytes, const uint64_t* abs_key, const uint64_t* sorted_val, const uint32_t* dst_start, uint32_t n_runs,
+                                uint64_t* cell_keys, uint64_t* cell_val, uint32_t* n_cells, hipStream_t s) {
+    auto val = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), RunPlaced{dst_start, sorted_val});
     size_t need = 0;
-    hipError_t e = rocprim::reduce_by_key(nullptr, need, abs_key, len, (size_t)n_runs, cell_keys, cell_counts, n_cells, rocprim::plus<uint32_t>(),
+    hipError_t e = rocprim::reduce_by_key(nullptr, need, abs_key, val, (size_t)n_runs, cell_keys, cell_val, n_cells, FirstStartSumLength(),
                                           rocprim::equal_to<uint64_t>(), s);
     if (e != hipSuccess) return e;
     if (need > temp_bytes) return hipErrorOutOfMemory;
-    return rocprim::reduce_by_key(temp, need, abs_key, len, (size_t)n_runs, cell_keys, cell_counts, n_cells, rocprim::plus<uint32_t>(),
-                                  rocprim::equal_to<uint64_t>(), s);
+    return rocprim::reduce_by_key(temp, need, abs_key, val, (size_t)n_runs, cell_keys, cell_val, n_cells, FirstStartSumLength(), rocprim::equal_to<uint64_t>(), s);
+}
+// level 1 from the packed cell records: keys >> 6, the points summed (coarsen_level of lio_sort.hip for the packed form)
+struct ShiftRight6 { __host__ __device__ uint64_t operator()(uint64_t k) const { return k >> 6; } };
+hipError_t coarsen_cells_packed(void* temp, size_t temp_bytes, const uint64_t* cell_keys, const uint64_t* cell_val, size_t n, uint64_t* keys_out, uint32_t* counts_out,
+                                uint32_t* n_out, hipStream_t s) {
+    auto kin = rocprim::make_transform_iterator(cell_keys, ShiftRight6{});
+    auto cin = rocprim::make_transform_iterator(cell_val, RunLength{});
+    size_t need = 0;
+    hipError_t e = rocprim::reduce_by_key(nullptr, need, kin, cin, n, keys_out, counts_out, n_out, rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), s);
+    if (e != hipSuccess) return e;
+    if (need > temp_bytes) return hipErrorOutOfMemory;
+    return rocprim::reduce_by_key(temp, need, kin, cin, n, keys_out, counts_out, n_out, rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), s);
 }
 
 }  // namespace lio

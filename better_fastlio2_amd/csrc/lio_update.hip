@@ -30,15 +30,40 @@ static void box_of_host_points(HostBox& box, const float* pts, size_t n, int str
 // the Morton code and the number of points of every occupied grid cell, in order.  Derive the coarser tree levels (hash
 // tables), fill the child blocks of the cell directory.  level_cells (optional): the number of cells of every level, already
 // known to the host (the rebuild by cell runs counts them on the way) -- nothing is read back between the levels then.
-static int finish_index_levels(lio_ctx* c, uint32_t n, uint32_t n_cells, const uint32_t* level_cells) {
+// cell_val (optional, with level_cells): the cells as packed records (first point << 32 | points) in place of d_cell_counts / a scan for d_cell_starts.
+static int finish_index_levels(lio_ctx* c, uint32_t n, uint32_t n_cells, const uint32_t* level_cells, const uint64_t* cell_val = nullptr) {
     hipStream_t s = c->stream;
     c->n_points = n; c->n_live = n; c->n_cells = 0;
     c->n_retired = 0; c->n_dead = 0; c->n_new_cells = 0; c->n_cells_built = 0;
     c->grid.n_points = n;
-    HIPCHK(c, hipMemsetAsync(c->d_apply + APPLY_LEVEL_NEW, 0, TREE_MAX_LEVELS * sizeof(uint32_t), s));
-    HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_cell_counts, c->d_cell_starts, n_cells, s));
+    if (cell_val == nullptr) {                  // (with packed records the child-block kernel clears the level counters and no scan is needed)
+        HIPCHK(c, hipMemsetAsync(c->d_apply + APPLY_LEVEL_NEW, 0, TREE_MAX_LEVELS * sizeof(uint32_t), s));
+        HIPCHK(c, exclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_cell_counts, c->d_cell_starts, n_cells, s));
+    }
     c->n_cells = n_cells; c->n_cells_built = n_cells;
     bool drained = false;                      // the last thing this function did was wait for the stream
+    // every level's size known up front: the hash tables of all levels are sized, (re)allocated and cleared at once
+    bool tables_ready = false;
+    if (level_cells != nullptr) {
+        size_t total = 0;
+        for (int L = 1; L < TREE_MAX_LEVELS; ++L) {
+            if (L >= 2 && level_cells[L] <= (uint32_t)TREE_MAX_ROOTS) break;
+            size_t sl = 64;
+            while (sl < (size_t)level_cells[L] * 4) sl <<= 1;
+            total += sl;
+        }
+        if (total > c->ltable_slots) {
+            size_t cap = c->ltable_slots ? c->ltable_slots : 4096;
+            while (cap < total) cap <<= 1;
+            HashEntry* nt = nullptr;
+            HIPCHK(c, hipMalloc((void**)&nt, cap * sizeof(HashEntry)));
+            HIPCHK(c, stream_wait(c));
+            if (c->d_ltable) (void)hipFree(c->d_ltable);
+            c->d_ltable = nt; c->ltable_slots = cap;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_ltable, 0xFF, total * sizeof(HashEntry), s));
+        tables_ready = true;
+    }
 
     // ---- coarser levels of the hashed 64-ary tree (exact fallback of the k-NN): level L+1 is a
     // reduce-by-key of level L (keys >> 6, counts summed) -- the point array is not touched again
@@ -51,7 +76,8 @@ static int finish_index_levels(lio_ctx* c, uint32_t n, uint32_t n_cells, const u
     // levels 0 and 1 always exist (the cell directory hangs off level 1); the first level from 2 up with at most
     // TREE_MAX_ROOTS cells is not hashed but listed: its cells are the roots of the walk
     for (int L = 1; L < TREE_MAX_LEVELS; ++L) {
-        HIPCHK(c, coarsen_level(c->d_temp, c->temp_bytes, kin, cin, n_prev, kout, cout, c->d_counters + 4, s));
+        if (L == 1 && cell_val != nullptr) HIPCHK(c, coarsen_cells_packed(c->d_temp, c->temp_bytes, kin, cell_val, n_prev, kout, cout, c->d_counters + 4, s));
+        else HIPCHK(c, coarsen_level(c->d_temp, c->temp_bytes, kin, cin, n_prev, kout, cout, c->d_counters + 4, s));
         uint32_t n_l = 0;
         if (level_cells != nullptr) n_l = level_cells[L];
         else HIPCHK(c, read_back(c, &n_l, c->d_counters + 4, sizeof(uint32_t)));
@@ -72,7 +98,7 @@ static int finish_index_levels(lio_ctx* c, uint32_t n, uint32_t n_cells, const u
         }
         size_t sl = 64;
         while (sl < (size_t)n_l * 4) sl <<= 1;
-        if (used + sl > c->ltable_slots) {
+        if (!tables_ready && used + sl > c->ltable_slots) {
             // grow (keeps the levels already inserted)
             size_t cap = c->ltable_slots ? c->ltable_slots : 4096;
             while (cap < used + sl) cap <<= 1;
@@ -83,7 +109,7 @@ static int finish_index_levels(lio_ctx* c, uint32_t n, uint32_t n_cells, const u
             if (c->d_ltable) (void)hipFree(c->d_ltable);
             c->d_ltable = nt; c->ltable_slots = cap;
         }
-        HIPCHK(c, hipMemsetAsync(c->d_ltable + used, 0xFF, sl * sizeof(HashEntry), s));
+        if (!tables_ready) HIPCHK(c, hipMemsetAsync(c->d_ltable + used, 0xFF, sl * sizeof(HashEntry), s));
         // `start` of a coarse entry is its rank among the cells of its level (cell_start == nullptr); level 1 uses it as the number
         // of its child block, the levels above only need to exist
         HIPCHK(c, launch_table_insert(kout, nullptr, cout, n_l, c->d_ltable + used, (uint32_t)(sl - 1), s));
@@ -102,10 +128,15 @@ static int finish_index_levels(lio_ctx* c, uint32_t n, uint32_t n_cells, const u
                 c->child_blocks_cap = need;
             }
             HIPCHK(c, hipMemsetAsync(c->d_child, 0, c->child_blocks_cap * 64 * sizeof(uint2), s));
-            HIPCHK(c, launch_fill_child_blocks(c->d_cell_keys, c->d_cell_starts, c->d_cell_counts, n_cells,
-                                               c->d_ltable + used, (uint32_t)(sl - 1), c->d_child, s));
             c->n_child_blocks = n_l;
-            HIPCHK(c, hipMemcpyAsync(c->d_apply + 9, &c->n_child_blocks, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            if (cell_val != nullptr) {
+                HIPCHK(c, launch_fill_child_blocks_packed(c->d_cell_keys, cell_val, n_cells, c->d_ltable + used, (uint32_t)(sl - 1), c->d_child, c->d_apply + 9, n_l,
+                                                          c->d_apply + APPLY_LEVEL_NEW, s));
+            } else {
+                HIPCHK(c, launch_fill_child_blocks(c->d_cell_keys, c->d_cell_starts, c->d_cell_counts, n_cells,
+                                                   c->d_ltable + used, (uint32_t)(sl - 1), c->d_child, s));
+                HIPCHK(c, hipMemcpyAsync(c->d_apply + 9, &c->n_child_blocks, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            }
         }
         used += sl;
         n_prev = n_l;
@@ -127,6 +158,7 @@ int finish_index(lio_ctx* c, uint32_t n) {
     return finish_index_levels(c, n, n_cells, nullptr);
 }
 
+int build_index(lio_ctx* c, const float4* src, uint32_t n, const uint32_t* live_dev = nullptr, uint32_t live_expected = 0u, uint32_t* live_found = nullptr);
 constexpr int LIO_RETRY_COUNT = -1000;         // internal: build_index found another number of live points than it was told
 // does a (re)build of n points go through the sort of cell runs?
 static bool by_cell_runs(const lio_ctx* c, size_t n) {
@@ -145,12 +177,9 @@ static int build_index_by_points(lio_ctx* c, const float4* src, uint32_t n) {
 // index in array order, then the pending points -- and only the runs are sorted, by a compressed key.  Two waits on the way (the
 // number of runs with the cells' bounding box; the cells per level), one at the end (the roots).  Same d_pts, cell table and
 // tree as the point sort, bit for bit (tests/test_gpu_parity.py::test_rebuild_by_cell_runs_equals_the_point_sort).
-static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n, const uint32_t* live_dev, uint32_t live_expected, uint32_t* live_found) {
+// Second half: the runs are known (d_mkeys_tmp: packed cell per run, d_vals_tmp: first point), box6 = the cells' bounding box.
+static int build_index_from_runs(lio_ctx* c, const float4* src, uint32_t n, uint32_t n_runs, const uint32_t box6[6]) {
     hipStream_t s = c->stream;
-    const uint32_t n_tiles = (n + RUN_TILE - 1u) / RUN_TILE;
-    uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(c->d_temp);                 // (the sort workspace is idle until sort_runs)
-    uint32_t* tile_off = tile_cnt + (n_tiles + 4u);
-    uint32_t* tile_box = tile_off + (n_tiles + 4u);
     uint64_t* run_key = c->d_mkeys_tmp;        // packed cell coordinates per run; later the Morton code per SORTED run
     void* sort_key = c->d_cell_keys;           // compressed keys, in and out of the sort (32-bit when the frame allows; free until the cells are made)
     void* sorted_key = c->d_mkeys;
@@ -158,30 +187,20 @@ static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n, const
     // (first point, points) per run, in and out of the sort: 8 bytes per run in the 4-byte-per-point arrays -- at most n / 2 runs get here
     uint64_t* run_val = reinterpret_cast<uint64_t*>(c->d_vals);
     uint64_t* sorted_val = reinterpret_cast<uint64_t*>(c->d_rank);
-    uint32_t* dst_start = c->d_cell_starts;    // (the scan of the cell counts overwrites it later)
-    HIPCHK(c, launch_cell_runs_count(src, n, c->grid, tile_cnt, tile_box, s));
-    HIPCHK(c, launch_exclusive_scan(tile_cnt, n_tiles + 1u, tile_off, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
-    // the number of runs (the scan's total) and the cells' box are known from here: they travel to the host BESIDE the emit kernel
-    uint32_t seq = ++c->small_seq;
-    HIPCHK(c, launch_cell_box_publish(tile_box, n_tiles, tile_off + n_tiles, live_dev, c->d_small, seq, s));
-    HIPCHK(c, launch_cell_runs_emit(src, n, c->grid, tile_off, run_key, run_start, s));
-    HIPCHK(c, wait_published(c, seq));
-    uint32_t w[8];
-    std::memcpy(w, c->h_small, sizeof(w));
-    if (live_dev != nullptr && w[7] != live_expected) { *live_found = w[7]; return LIO_RETRY_COUNT; }
-    const uint32_t n_runs = w[0];
+    uint32_t* dst_start = c->d_cell_starts;
     if (n_runs == 0u || n_runs > n) return c->fail(LIO_ERR_HIP, "index rebuild", "the run kernels left an impossible number of cell runs");
     // points in no particular order (a Build from the caller's cloud): as many runs as points, the run sort would only add to the work
     if ((size_t)n_runs * 2u > (size_t)n) return build_index_by_points(c, src, n);
-    const CellKeyFrame f = cell_key_frame(w + 1, w + 4);
+    const CellKeyFrame f = cell_key_frame(box6, box6 + 3);
     HIPCHK(c, launch_compress_run_keys(run_key, run_start, n_runs, n, f, sort_key, run_val, c->d_apply + 15, s));
     HIPCHK(c, sort_runs(c->d_temp, c->temp_bytes, sort_key, sorted_key, run_val, sorted_val, n_runs, f.bits, s));
     HIPCHK(c, scan_run_lengths(c->d_temp, c->temp_bytes, sorted_val, n_runs, dst_start, s));
     HIPCHK(c, launch_runs_place(src, c->d_pts, sorted_key, sorted_val, dst_start, n_runs, f, run_key, c->d_level_parts, s));
     // (the cells per level travel to the host beside the reduction of the runs to cells)
-    seq = ++c->small_seq;
+    const uint32_t seq = ++c->small_seq;
     HIPCHK(c, launch_level_counts_publish(c->d_level_parts, c->d_apply + 15, c->d_small, seq, s));
-    HIPCHK(c, reduce_runs_to_cells(c->d_temp, c->temp_bytes, run_key, sorted_val, n_runs, c->d_cell_keys, c->d_cell_counts, c->d_counters + 4, s));
+    uint64_t* cell_val = reinterpret_cast<uint64_t*>(c->d_cell_counts);       // (first point, points) per cell: at most n / 2 of them
+    HIPCHK(c, reduce_runs_to_cells(c->d_temp, c->temp_bytes, run_key, sorted_val, dst_start, n_runs, c->d_cell_keys, cell_val, c->d_counters + 4, s));
     HIPCHK(c, wait_published(c, seq));
     uint32_t lv[TREE_MAX_LEVELS + 1];
     std::memcpy(lv, c->h_small, sizeof(lv));
@@ -191,13 +210,31 @@ static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n, const
                                                                               : "a bounded wait of a compaction kernel ran out");
     }
     if (lv[0] == 0u || lv[0] > n_runs) return c->fail(LIO_ERR_HIP, "index rebuild", "the run kernels left an impossible number of cells");
-    return finish_index_levels(c, n, lv[0], lv);
+    return finish_index_levels(c, n, lv[0], lv, cell_val);
 }
-
+// First half: run heads per tile of the n (live) points
+static int build_index_by_cells(lio_ctx* c, const float4* src, uint32_t n, const uint32_t* live_dev, uint32_t live_expected, uint32_t* live_found) {
+    hipStream_t s = c->stream;
+    const uint32_t n_tiles = (n + RUN_TILE - 1u) / RUN_TILE;
+    uint32_t* tile_cnt = reinterpret_cast<uint32_t*>(c->d_temp);                 // (the sort workspace is idle until sort_runs)
+    uint32_t* tile_off = tile_cnt + (n_tiles + 4u);
+    uint32_t* tile_box = tile_off + (n_tiles + 4u);
+    HIPCHK(c, launch_cell_runs_count(src, n, c->grid, tile_cnt, tile_box, s));
+    HIPCHK(c, launch_exclusive_scan(tile_cnt, n_tiles + 1u, tile_off, c->d_cagg, next_compact_stamp(c), c->d_apply + 15, s));
+    // the number of runs (the scan's total) and the cells' box are known from here: they travel to the host BESIDE the emit kernel
+    const uint32_t seq = ++c->small_seq;
+    HIPCHK(c, launch_cell_box_publish(tile_box, n_tiles, tile_off + n_tiles, live_dev, c->d_small, seq, s));
+    HIPCHK(c, launch_cell_runs_emit(src, n, c->grid, tile_off, c->d_mkeys_tmp, c->d_vals_tmp, s));
+    HIPCHK(c, wait_published(c, seq));
+    uint32_t w[8];
+    std::memcpy(w, c->h_small, sizeof(w));
+    if (live_dev != nullptr && w[7] != live_expected) { *live_found = w[7]; return LIO_RETRY_COUNT; }
+    return build_index_from_runs(c, src, n, w[0], w + 1);
+}
 // (re)build the index from n points at src (device, float4, must not alias c->d_pts)
 // live_dev (optional): a device word that must equal `live_expected` -- read with the rebuild's first wait; LIO_RETRY_COUNT and
 // *live_found when it does not (nothing of the index has been touched then)
-int build_index(lio_ctx* c, const float4* src, uint32_t n, const uint32_t* live_dev = nullptr, uint32_t live_expected = 0u, uint32_t* live_found = nullptr) {
+int build_index(lio_ctx* c, const float4* src, uint32_t n, const uint32_t* live_dev, uint32_t live_expected, uint32_t* live_found) {
     hipStream_t s = c->stream;
     c->have_map = false;
     c->hint_valid = false;                     // neighbours of an older map state no longer bound a search

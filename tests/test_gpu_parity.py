@@ -937,14 +937,17 @@ def test_rebuild_by_cell_runs_equals_the_point_sort(gpu_capi, small_case, monkey
                         rng.uniform(lo - 40.0, hi + 40.0, (400, 3))]).astype(np.float32)
 
     def same(extra=None):
-        a, b = ctxs
-        ia, ib = a.map_info(), b.map_info()
-        for k in ("n_points", "n_live", "n_cells", "n_retired", "n_full_rebuilds"):
-            assert ia[k] == ib[k], k
-        assert bits_equal(a.map_flatten(), b.map_flatten())
+        a = ctxs[0]
+        ia, fa = a.map_info(), a.map_flatten()
         qq = q if extra is None else np.concatenate([q, extra]).astype(np.float32)
-        (ax, ad, ac), (bx, bd, bc) = a.nearest_search(qq), b.nearest_search(qq)
-        assert np.array_equal(ac, bc) and bits_equal(ad, bd) and bits_equal(ax, bx)
+        ax, ad, ac = a.nearest_search(qq)
+        for b in ctxs[1:]:
+            ib = b.map_info()
+            for k in ("n_points", "n_live", "n_cells", "n_retired", "n_full_rebuilds"):
+                assert ia[k] == ib[k], k
+            assert bits_equal(fa, b.map_flatten())
+            bx, bd, bc = b.nearest_search(qq)
+            assert np.array_equal(ac, bc) and bits_equal(ad, bd) and bits_equal(ax, bx)
 
     for c in ctxs:
         c.map_build(base)
