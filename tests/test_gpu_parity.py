@@ -980,6 +980,14 @@ def test_rebuild_by_cell_runs_equals_the_point_sort(gpu_capi, small_case, monkey
         c.map_add(away, False)
         c.map_reconstruct(c.map_flatten())
     same(away[:100] + np.float32(0.02))
+    # a sparse map three kilometres wide: tens of thousands of level-2 cells, roots at level 6 (a frame of few parents at a high level,
+    # every tree level sized from the counts of the copy kernel); far queries walk the tree through every level
+    wide = (rng.uniform(-1500.0, 1500.0, (60_000, 3)) * [1, 1, 0.004]).astype(np.float32)
+    for c in ctxs:
+        c.map_build(wide)
+        c.map_reconstruct(c.map_flatten())                        # (in order now: the rebuild by cell runs)
+    q = np.concatenate([wide[:600] + np.float32(0.03), (rng.uniform(-1700.0, 1700.0, (600, 3)) * [1, 1, 0.01])]).astype(np.float32)
+    same()
     for c in ctxs:
         c.close()
 
