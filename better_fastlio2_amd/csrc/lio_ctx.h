@@ -160,6 +160,7 @@ struct lio_ctx {
     uint32_t n_child_blocks = 0;               // blocks handed out (host view; the device bump counter is d_apply[9])
     uint32_t* d_rank = nullptr;                // iota scratch of the index build
     uint32_t* d_level_parts = nullptr;         // [PLACE_WORKGROUPS][TREE_MAX_LEVELS] partial counts of the rebuild by cell runs (lio_rebuild.h)
+    bool test_live_miscount = false;           // LIO_TEST_LIVE_MISCOUNT=1 (tests): a full rebuild starts from a live count that is off by one
     bool rebuild_by_cells = true;              // LIO_REBUILD_BY_CELLS=0 (A/B runs of scripts) or lio_debug_set("library_sort"): the point sort
     void* d_temp = nullptr;
     size_t temp_bytes = 0;

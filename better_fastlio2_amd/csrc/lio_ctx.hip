@@ -264,6 +264,7 @@ int lio_create(const lio_config* cfg, lio_ctx** out) {
     { const char* e = std::getenv("LIO_TRACE_REBUILDS"); c->trace_rebuilds = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_TRACE_HOST"); c->trace_host = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_PREP_FUSED"); if (e != nullptr && e[0] == '0') c->prep_fused = false; }   // (A/B runs of scripts)
+    { const char* e = std::getenv("LIO_TEST_LIVE_MISCOUNT"); c->test_live_miscount = e != nullptr && e[0] == '1'; }
     { const char* e = std::getenv("LIO_REBUILD_BY_CELLS"); if (e != nullptr && e[0] == '0') c->rebuild_by_cells = false; }   // (A/B runs of scripts)
     { const char* e = std::getenv("LIO_PRE_ENQUEUE"); if (e != nullptr && e[0] == '0') c->dbg_pre_enqueue = 0; }   // (A/B runs of scripts)
     // Environments in which a launch call returns only when its kernel has ended (HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL: debugging

@@ -407,7 +407,7 @@ int rebuild_full(lio_ctx* c) {
         HIPCHK(c, compact_live_any(c, c->d_pts, n_all, c->d_pts_tmp, c->d_counters + 3));
         counted = !by_cell_runs(c, c->n_live + n_pend) || c->n_live == 0u || c->n_live > n_all;
         if (counted) HIPCHK(c, read_back(c, &live, c->d_counters + 3, sizeof(uint32_t)));
-        else live = c->n_live;
+        else live = c->n_live + (c->test_live_miscount ? 1u : 0u);   // (LIO_TEST_LIVE_MISCOUNT=1: the tests' way into the restart below)
     }
     for (;;) {
         if ((size_t)live + (size_t)n_pend > c->cap_map)

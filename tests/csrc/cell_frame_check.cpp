@@ -15,6 +15,9 @@ int main() {
     for (int trial = 0; trial < 400; ++trial) {
         uint32_t lo[3], hi[3];
         const int kind = trial % 4;
+        if (trial == 399) {                                       // the whole grid: two parents per axis at level 10, 63-bit keys
+            for (int i = 0; i < 3; ++i) { lo[i] = 0u; hi[i] = (1u << 21) - 1u; }
+        } else
         for (int i = 0; i < 3; ++i) {
             // boxes around the bias (a map around the origin), anywhere, tiny, and kilometres wide
             const uint32_t centre = kind == 0 ? (1u << 20) : (uint32_t)(rng() % ((1u << 21) - 70000u)) + 35000u;
@@ -23,6 +26,7 @@ int main() {
         }
         const CellKeyFrame f = cell_key_frame(lo, hi);
         if (f.a < 1 || f.a > 10 || f.n_parents < 1 || f.n_parents > CELL_FRAME_PARENTS || f.bits > 63) { std::printf("bad frame\n"); return 1; }
+        if (trial == 399 && (f.a != 10 || f.n_parents != 8 || f.bits != 63)) { std::printf("whole-grid frame: a %d parents %d bits %d\n", f.a, f.n_parents, f.bits); return 1; }
         for (int i = 1; i < f.n_parents; ++i) if (!(f.parent[i - 1] < f.parent[i])) { std::printf("parents not ascending\n"); return 1; }
         std::vector<std::pair<uint64_t, uint64_t>> keys;
         for (int k = 0; k < 3000; ++k) {

@@ -928,10 +928,13 @@ def test_rebuild_by_cell_runs_equals_the_point_sort(gpu_capi, small_case, monkey
     rng = np.random.default_rng(606)
     base = np.ascontiguousarray(w.points[::2])
     ctxs = []
-    for by_cells in ("1", "0"):
+    # the default; the point sort; cell runs with a host-side live count that is off by one (the rebuild restarts from the device's count)
+    for by_cells, miscount in (("1", "0"), ("0", "0"), ("1", "1")):
         monkeypatch.setenv("LIO_REBUILD_BY_CELLS", by_cells)
+        monkeypatch.setenv("LIO_TEST_LIVE_MISCOUNT", miscount)
         ctxs.append(gpu_capi.LioContext(0.2, max_scan_points=4096, max_map_points=600_000))
     monkeypatch.delenv("LIO_REBUILD_BY_CELLS")
+    monkeypatch.delenv("LIO_TEST_LIVE_MISCOUNT")
     lo, hi = base.min(0), base.max(0)
     q = np.concatenate([base[rng.choice(len(base), 800, replace=False)] + rng.normal(0, 0.05, (800, 3)),
                         rng.uniform(lo - 40.0, hi + 40.0, (400, 3))]).astype(np.float32)
